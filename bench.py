@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- FASTQ batch-parse throughput on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1]): synthetic 150 bp Illumina FASTQ from the reference's generator
+(blazeseq/utils.mojo:831-917, args (num_reads, 150, 150, 33, 73, "generic")), 10 M reads per GPU,
+batches(4096), validation off.  The input is generated on the device and is resident in HBM when
+the timed region starts.  One "step" = one pass of the whole hot path over that input:
+delimiter scan -> record table -> FastqBatch columns (+ per-batch ends), i.e. everything
+``for batch in parser.batches(4096): batch.to_device()`` does in the reference.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): a single stream of N x 10 M reads is
+cut into N byte ranges (not record aligned); each step also does the shard scan, the summary
+all_gather, the halo send/recv of the straddling record over RCCL and the count reductions
+(blazeseq_amd/sharded.py).  Weak scaling.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(reads: int, read_len: int, check: bool):
+    """Reference-algorithm CPU baseline: the C restatement of BlazeSeq's streaming parser
+    (oracle/bzq_oracle.c), batches(4096) mode, 64 KiB buffer like the reference's own runner
+    (benchmark/throughput/run_throughput_blazeseq.mojo:28-40), one core, bounded sample."""
+    from oracle import oracle as O
+    data = O.generate_synthetic(reads, read_len, read_len, 33, 73, "generic")
+    cfg = O.make_config(buffer_capacity=64 * 1024, check_ascii=check, check_quality=check, batch_size=4096)
+    for _ in range(2):
+        O.bench_run(data, cfg, "batches")
+    t_budget, times, nrec = 12.0, [], 0
+    t_start = time.perf_counter()
+    while time.perf_counter() - t_start < t_budget and len(times) < 15:
+        t0 = time.perf_counter()
+        nrec, _ = O.bench_run(data, cfg, "batches")
+        times.append(time.perf_counter() - t0)
+    assert nrec == reads
+    best = sum(times) / len(times)
+    return {"value": round(data.size / best / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "mrecords_per_s": round(reads / best / 1e6, 3),
+            "sample": f"{reads} reads x {read_len} bp ({data.size} B) synthetic, batches(4096), 64 KiB buffer, "
+                      f"validation {'on' if check else 'off'}, mean of {len(times)} runs, in-memory"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--validate", action="store_true", help="config 3: check_ascii + check_quality, sanger")
+    ap.add_argument("--pass-bytes", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reads", type=int, default=1_000_000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import blazeseq_amd as B
+    from blazeseq_amd import _lib as L
+    from blazeseq_amd import sharded
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = B.ParserConfig(check_ascii=args.validate, check_quality=args.validate,
+                         quality_schema="sanger" if args.validate else None)
+    ctx = B.Context(cfg, "generic", 4096, local_rank, pass_bytes=args.pass_bytes)
+    ctx.set_option("timing_detail", 1)
+
+    # ---- synthetic input, generated on the device (record i depends only on i) ------------------
+    total_reads = args.reads * world
+    rec_bytes = ctx.generate_synthetic_device(total_reads, args.read_len, 33, 73, "generic", count=1)
+    total_bytes = rec_bytes * total_reads
+    lo = total_bytes * rank // world
+    hi = total_bytes * (rank + 1) // world
+    n = hi - lo
+    slack = 1 << 20  # room for the halo (one record) behind the shard
+    shard = torch.empty(n + slack, dtype=torch.uint8, device=dev)
+    i0, i1 = lo // rec_bytes, (hi + rec_bytes - 1) // rec_bytes
+    if lo == i0 * rec_bytes:
+        ctx.generate_synthetic_device(total_reads, args.read_len, 33, 73, "generic", shard.data_ptr(),
+                                      shard.numel(), first=i0, count=min(i1, total_reads) - i0)
+    else:
+        tmp = torch.empty((i1 - i0) * rec_bytes + 64, dtype=torch.uint8, device=dev)
+        ctx.generate_synthetic_device(total_reads, args.read_len, 33, 73, "generic", tmp.data_ptr(), tmp.numel(),
+                                      first=i0, count=i1 - i0)
+        off = lo - i0 * rec_bytes
+        shard[:n].copy_(tmp[off:off + n])
+        del tmp
+    torch.cuda.synchronize()
+
+    def step():
+        if world == 1:
+            ctx.submit_device(shard.data_ptr(), n, 0, True)
+            return ctx.result(), None, None
+        res, plan, totals, first_err = sharded.parse_sharded(ctx, shard, n, lo)
+        return res, totals, first_err
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ms_emit = ms_agg = ms_scan = ms_rebase = ms_kernels = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res, totals, first_err = step()
+        ms_emit += res.ms_emit; ms_agg += res.ms_aggregate; ms_scan += res.ms_scan
+        ms_rebase += res.ms_rebase; ms_kernels += res.ms_total
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- correctness guard on the timed configuration (size-independent properties) --------------
+    recs = int(res.n_records)
+    if world == 1:
+        assert recs == args.reads and res.status == L.EOF, (recs, res.status, ctx.format_error())
+        assert int(res.seq_bytes) == args.read_len * recs == int(res.qual_bytes)
+        global_records, global_bytes = recs, n
+    else:
+        assert totals[0] == total_reads and first_err == sharded.NO_ERROR, (totals, first_err)
+        global_records, global_bytes = totals[0], total_bytes
+
+    if rank == 0:
+        steps = args.steps
+        sec_per_step = elapsed / steps
+        id_len = rec_bytes - 2 * args.read_len - 6
+        A = rec_bytes + 2 * args.read_len + id_len + 16   # algorithmic bytes per record
+        per_rank_records = recs
+        emit_s = ms_emit / steps / 1e3
+        path_s = ms_kernels / steps / 1e3
+        out = {
+            "metric": "FASTQ GB/s + Mrecords/s (150 bp synthetic) at 1/2/4/8 MI355X vs HBM roofline",
+            "value": round(global_bytes / sec_per_step / 1e9, 3),
+            "unit": "GB/s",
+            "mrecords_per_s": round(global_records / sec_per_step / 1e6, 3),
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(sec_per_step * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.read_len} bp Illumina FASTQ, {args.reads} reads/GPU "
+                                   f"({rec_bytes} B/record), batches(4096), validation "
+                                   f"{'ascii+quality (sanger)' if args.validate else 'off'}, input resident in HBM",
+                       "records_per_gpu": args.reads, "record_bytes": rec_bytes, "batch_size": 4096,
+                       "parallelism": f"byte-range shards x{world}" if world > 1 else "single GPU",
+                       "pass_bytes": args.pass_bytes},
+            "fraction_of_hbm_peak_input_rate": round(global_bytes / world / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
+            "roofline": {
+                "bound": "hbm", "kernel": "k_tile_emit",
+                "achieved": round(A * per_rank_records / emit_s / 1e9, 2) if emit_s > 0 else None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(A * per_rank_records / emit_s / 1e9 / HBM_PEAK_GBS, 4) if emit_s > 0 else None,
+                "traffic": None,
+                "algorithmic_bytes_per_record": A,
+                "avg_launch_ms": round(ms_emit / steps / max(1, int(res.n_passes)), 4),
+                "launches_per_step": int(res.n_passes),
+            },
+            "roofline_path": {
+                "note": "whole hot path (aggregate + scan + emit + rebase kernels), hipEvent time on the ctx stream",
+                "achieved": round(A * per_rank_records / path_s / 1e9, 2) if path_s > 0 else None,
+                "frac": round(A * per_rank_records / path_s / 1e9 / HBM_PEAK_GBS, 4) if path_s > 0 else None,
+                "ms": {"aggregate": round(ms_agg / steps, 4), "scan": round(ms_scan / steps, 4),
+                       "emit": round(ms_emit / steps, 4), "rebase": round(ms_rebase / steps, 4),
+                       "kernels_total": round(ms_kernels / steps, 4)},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_reads, args.read_len, args.validate)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+"""ctypes binding of libblazeseq_hip.so (the C ABI declared in include/blazeseq_hip.h).
+
+The HIP library IS the product path: if it is missing or cannot be loaded this module raises --
+there is no CPU fallback and nothing here ever imports the test oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libblazeseq_hip.so")
+
+OK, ID_NO_AT, SEP_NO_PLUS, SEQ_QUAL_LEN_MISMATCH, ASCII_INVALID, QUALITY_OUT_OF_RANGE, EOF, \
+    UNEXPECTED_EOF, BUFFER_EXCEEDED, BUFFER_AT_MAX, OTHER = range(11)
+ERR_HIP, ERR_ARG, ERR_NOMEM, ERR_NO_DEVICE, ERR_IO = -1, -2, -3, -4, -5
+
+
+class BzqConfig(C.Structure):
+    _fields_ = [
+        ("buffer_capacity", C.c_int64),
+        ("buffer_max_capacity", C.c_int64),
+        ("buffer_growth_enabled", C.c_int32),
+        ("check_ascii", C.c_int32),
+        ("check_quality", C.c_int32),
+        ("q_lower", C.c_uint8), ("q_upper", C.c_uint8), ("q_offset", C.c_uint8), ("_pad0", C.c_uint8),
+        ("batch_size", C.c_int32),
+        ("compat_simd_width", C.c_int32),
+        ("emit_offsets", C.c_int32),
+        ("_pad1", C.c_int32),
+        ("max_chunk_bytes", C.c_int64),
+        ("pass_bytes", C.c_int64),
+        ("min_record_bytes", C.c_int32),
+        ("_pad2", C.c_int32),
+    ]
+
+
+class BzqChunk(C.Structure):
+    _fields_ = [
+        ("n_bytes", C.c_uint64), ("n_records", C.c_uint64), ("bytes_consumed", C.c_uint64),
+        ("total_newlines", C.c_uint64),
+        ("status", C.c_int32), ("tail_phase", C.c_int32),
+        ("error_record", C.c_int64),
+        ("seq_bytes", C.c_uint64), ("qual_bytes", C.c_uint64), ("id_bytes", C.c_uint64),
+        ("d_seq", C.c_void_p), ("d_qual", C.c_void_p), ("d_id", C.c_void_p),
+        ("d_ends", C.c_void_p), ("d_id_ends", C.c_void_p),
+        ("d_batch_ends", C.c_void_p), ("d_batch_id_ends", C.c_void_p),
+        ("d_record_end", C.c_void_p),
+        ("d_header_start", C.c_void_p), ("d_seq_start", C.c_void_p), ("d_sep_start", C.c_void_p),
+        ("d_qual_start", C.c_void_p),
+        ("ms_total", C.c_float), ("ms_aggregate", C.c_float), ("ms_scan", C.c_float),
+        ("ms_emit", C.c_float), ("ms_rebase", C.c_float),
+        ("n_passes", C.c_uint32), ("_pad", C.c_uint32),
+    ]
+
+
+class BzqDeviceBatch(C.Structure):
+    _fields_ = [
+        ("num_records", C.c_int64), ("seq_len", C.c_int64), ("total_id_bytes", C.c_int64),
+        ("quality_offset", C.c_uint8), ("_pad", C.c_uint8 * 7),
+        ("qual_buffer", C.c_void_p), ("sequence_buffer", C.c_void_p), ("ends", C.c_void_p),
+        ("id_buffer", C.c_void_p), ("id_ends", C.c_void_p),
+        ("first_record", C.c_uint64),
+    ]
+
+
+class BzqHostBatch(C.Structure):
+    _fields_ = [
+        ("num_records", C.c_int64),
+        ("quality_bytes", C.c_void_p), ("sequence_bytes", C.c_void_p), ("id_bytes", C.c_void_p),
+        ("ends", C.c_void_p), ("id_ends", C.c_void_p),
+        ("quality_offset", C.c_uint8), ("_pad", C.c_uint8 * 7),
+    ]
+
+
+class BzqShardSummary(C.Structure):
+    _fields_ = [
+        ("n_bytes", C.c_uint64), ("n_newlines", C.c_uint64),
+        ("first_nl", C.c_int64 * 4),
+        ("first_byte", C.c_uint8), ("last_byte", C.c_uint8), ("_pad", C.c_uint8 * 6),
+    ]
+
+
+# every symbol include/blazeseq_hip.h declares (tests/test_abi_symbols.py checks the header against this)
+SYMBOLS = {
+    "bzq_abi_version": (C.c_int32, []),
+    "bzq_config_default": (None, [C.POINTER(BzqConfig)]),
+    "bzq_schema_from_name": (C.c_int32, [C.c_char_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
+    "bzq_message_for_code": (C.c_char_p, [C.c_int32]),
+    "bzq_create": (C.c_int32, [C.c_int32, C.POINTER(BzqConfig), C.POINTER(C.c_void_p)]),
+    "bzq_destroy": (None, [C.c_void_p]),
+    "bzq_last_error": (C.c_char_p, [C.c_void_p]),
+    "bzq_set_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "bzq_get_config": (C.c_int32, [C.c_void_p, C.POINTER(BzqConfig)]),
+    "bzq_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "bzq_pinned_alloc": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "bzq_pinned_free": (C.c_int32, [C.c_void_p]),
+    "bzq_submit_chunk_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32]),
+    "bzq_submit_chunk_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32]),
+    "bzq_chunk_result": (C.c_int32, [C.c_void_p, C.POINTER(BzqChunk)]),
+    "bzq_batch_view": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(BzqDeviceBatch)]),
+    "bzq_batch_to_host": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.POINTER(BzqHostBatch)]),
+    "bzq_copy_to_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bzq_format_error": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]),
+    "bzq_shard_scan": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(BzqShardSummary)]),
+    "bzq_submit_shard": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint8,
+                                      C.c_uint64, C.c_int32]),
+    "bzq_shard_head_bytes": (C.c_int32, [C.POINTER(BzqShardSummary), C.c_uint64, C.c_uint8, C.POINTER(C.c_uint64)]),
+    "bzq_generate_synthetic_device": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
+                                                  C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_uint64,
+                                                  C.POINTER(C.c_uint64)]),
+}
+
+_lib = None
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libblazeseq_hip.so.  Raises LibraryMissing (never falls back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LibraryMissing(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  blazeseq_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

@@ -1,0 +1,879 @@
+// bzq_api.hip -- host side of libblazeseq_hip.so (C ABI in include/blazeseq_hip.h).
+//
+// Mirrors, for whole chunks at a time, what blazeseq/fastq/parser.mojo does record by record:
+// the ctx is the FastqParser, bzq_submit_*/bzq_chunk_result are next_batch for every batch of the
+// chunk at once, bzq_batch_view is the FastqBatch -> DeviceFastqBatch hand-off
+// (blazeseq/fastq/record_batch.mojo:89-90, 404-411) without the five allocations, five copies and
+// three synchronisations per 4096 records.  There is NO CPU fallback: without a gfx950 device
+// bzq_create fails.
+#include "../../include/blazeseq_hip.h"
+#include "bzq_device.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace bzq;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+const char* message_for_code(int code) {
+    // errors.mojo:71-90
+    switch (code) {
+        case BZQ_ID_NO_AT: return "Sequence id line does not start with '@'";
+        case BZQ_SEP_NO_PLUS: return "Separator line does not start with '+'";
+        case BZQ_SEQ_QUAL_LEN_MISMATCH: return "Quality and sequence line do not match in length";
+        case BZQ_ASCII_INVALID: return "Non ASCII letters found";
+        case BZQ_QUALITY_OUT_OF_RANGE: return "Corrupt quality score according to provided schema";
+        case BZQ_UNEXPECTED_EOF: return "Unexpected end of file in FASTQ record";
+        case BZQ_BUFFER_EXCEEDED: return "FASTQ record exceeds buffer capacity";
+        case BZQ_BUFFER_AT_MAX: return "FASTQ record exceeds maximum buffer capacity";
+        default: return "Parse or validation error";
+    }
+}
+
+// BufferedReader window arithmetic on stream offsets (io/buffered.mojo:137-290), used only to
+// decide which terminal error the reference raises for trailing bytes that are not a record.
+struct Window {
+    int64_t w = 0, end = 0, cap = 0, N = 0;
+    bool eof = false;
+    int64_t fill() { // _fill_buffer, buffered.mojo:262-281
+        if (eof) return 0;
+        int64_t space = cap - (end - w);
+        if (space == 0) return 0;
+        int64_t amt = std::min<int64_t>(space, N - end);
+        if (amt < 0) amt = 0;
+        end += amt;
+        if (amt == 0) eof = true;
+        return amt;
+    }
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+} // namespace
+
+struct bzq_ctx {
+    int device = 0;
+    bzq_config cfg{};
+    hipStream_t stream = nullptr;
+    bool own_stream = true;
+    std::string err;
+    // arenas
+    DevBuf in, seq, qual, id;
+    DevBuf ends, id_ends, rec_end, b_ends, b_id_ends, off[4], view_e, view_i;
+    int64_t rec_cap = 0;
+    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI;
+    int64_t tile_cap = 0;
+    ChunkState* d_state = nullptr;
+    ChunkState* h_state = nullptr; // pinned
+    hipEvent_t ev[8]{};
+    std::vector<hipEvent_t> ev_detail;
+    // options
+    int force_dense = 0, timing_detail = 0;
+    // current chunk
+    const uint8_t* cur = nullptr;
+    uint64_t cur_n = 0, cur_stream_pos = 0;
+    int cur_is_eof = 0;
+    uint32_t cur_prev_byte = 10;
+    int64_t cur_first_header = 0;
+    bool pending = false, have_result = false;
+    int64_t n_passes = 0;
+    bzq_chunk res{};
+    // terminal-status details for bzq_format_error
+    int term_phase = 0;
+    int64_t term_cap = 0;
+    // shard mode
+    bool shard_mode = false;
+    const uint8_t* agg_ptr = nullptr;  // shard whose tile aggregates are already in the arenas
+    uint64_t agg_n = 0;
+    int head_lines = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+            return BZQ_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+int ensure(bzq_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        c->err = "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e);
+        b.p = nullptr;
+        return BZQ_ERR_NOMEM;
+    }
+    b.cap = bytes;
+    return 0;
+}
+
+int64_t tiles_for(uint64_t n) { return (int64_t)((n + TILE - 1) / TILE); }
+
+int ensure_chunk_arenas(bzq_ctx* c, uint64_t n, bool need_input) {
+    int rc;
+    const size_t col = (size_t)n + 64;
+    if (need_input && (rc = ensure(c, c->in, (size_t)n + 64))) return rc;
+    if ((rc = ensure(c, c->seq, col)) || (rc = ensure(c, c->qual, col)) || (rc = ensure(c, c->id, col))) return rc;
+    const int64_t nt = tiles_for(n) + 1;
+    if (nt > c->tile_cap) {
+        if ((rc = ensure(c, c->tile_c, nt * 4)) || (rc = ensure(c, c->tile_a, nt * 8)) ||
+            (rc = ensure(c, c->tile_idc, nt * 8)) || (rc = ensure(c, c->tileP, nt * 8)) ||
+            (rc = ensure(c, c->tileS, nt * 8)) || (rc = ensure(c, c->tileQ, nt * 8)) ||
+            (rc = ensure(c, c->tileI, nt * 8)))
+            return rc;
+        c->tile_cap = nt;
+    }
+    return 0;
+}
+
+int ensure_record_arenas(bzq_ctx* c, int64_t recs) {
+    if (recs <= c->rec_cap) return 0;
+    int rc;
+    const size_t b = (size_t)recs * 8;
+    if ((rc = ensure(c, c->ends, b)) || (rc = ensure(c, c->id_ends, b)) || (rc = ensure(c, c->rec_end, b)) ||
+        (rc = ensure(c, c->b_ends, b)) || (rc = ensure(c, c->b_id_ends, b)))
+        return rc;
+    if (c->cfg.emit_offsets)
+        for (int i = 0; i < 4; ++i)
+            if ((rc = ensure(c, c->off[i], b))) return rc;
+    c->rec_cap = recs;
+    return 0;
+}
+
+int64_t pass_tiles(const bzq_ctx* c) {
+    int64_t pb = c->cfg.pass_bytes > 0 ? c->cfg.pass_bytes : (int64_t)1 << 40;
+    int64_t t = pb / TILE;
+    return t < 1 ? 1 : t;
+}
+
+template <bool CA, bool CQ>
+void launch_emit_off(bool offs, dim3 grid, hipStream_t s, const EmitArgs& a) {
+    if (offs) hipLaunchKernelGGL((k_tile_emit<CA, CQ, true>), grid, dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((k_tile_emit<CA, CQ, false>), grid, dim3(BLOCK), 0, s, a);
+}
+void launch_emit(const bzq_ctx* c, dim3 grid, const EmitArgs& a) {
+    const bool ca = c->cfg.check_ascii != 0, cq = c->cfg.check_quality != 0, off = c->cfg.emit_offsets != 0;
+    if (ca && cq) launch_emit_off<true, true>(off, grid, c->stream, a);
+    else if (ca) launch_emit_off<true, false>(off, grid, c->stream, a);
+    else if (cq) launch_emit_off<false, true>(off, grid, c->stream, a);
+    else launch_emit_off<false, false>(off, grid, c->stream, a);
+}
+
+EmitArgs make_emit_args(bzq_ctx* c) {
+    EmitArgs e{};
+    e.g = c->cur; e.n = (int64_t)c->cur_n; e.prev_byte = c->cur_prev_byte;
+    e.tileP = (const int64_t*)c->tileP.p; e.tileS = (const int64_t*)c->tileS.p;
+    e.tileQ = (const int64_t*)c->tileQ.p; e.tileI = (const int64_t*)c->tileI.p;
+    e.col_seq = (uint8_t*)c->seq.p; e.col_qual = (uint8_t*)c->qual.p; e.col_id = (uint8_t*)c->id.p;
+    e.ends = (int64_t*)c->ends.p; e.id_ends = (int64_t*)c->id_ends.p; e.rec_end = (int64_t*)c->rec_end.p;
+    e.rec_cap = c->rec_cap;
+    e.o_hdr = (int64_t*)c->off[0].p; e.o_seq = (int64_t*)c->off[1].p;
+    e.o_sep = (int64_t*)c->off[2].p; e.o_qual = (int64_t*)c->off[3].p;
+    e.st = c->d_state; e.q_lower = c->cfg.q_lower; e.q_upper = c->cfg.q_upper;
+    e.force_dense = c->force_dense;
+    return e;
+}
+
+// Enqueue aggregate -> scan -> emit for every pass of the current chunk.  `emit_only` re-runs just
+// the emit kernels (after the per-record arrays were re-sized).
+int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
+    const int64_t nt = tiles_for(c->cur_n);
+    const int64_t pt = pass_tiles(c);
+    int64_t passes = 0;
+    if (!emit_only && skip_aggregate_mid) {
+        // shard whose aggregates exist already (bzq_shard_scan): only tile 0 (prev byte now known)
+        // and the tiles touched by the appended halo change
+        AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, 0, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
+                  (u64*)c->tile_idc.p};
+        hipLaunchKernelGGL(k_tile_aggregate, dim3(1), dim3(BLOCK), 0, c->stream, a);
+        const int64_t tb = std::max<int64_t>(1, (int64_t)(c->agg_n / TILE));
+        if (tb < nt) {
+            a.tile_begin = tb;
+            hipLaunchKernelGGL(k_tile_aggregate, dim3((unsigned)(nt - tb)), dim3(BLOCK), 0, c->stream, a);
+        }
+    }
+    for (int64_t tb = 0; tb < nt; tb += pt, ++passes) {
+        const int64_t te = std::min(nt, tb + pt);
+        const dim3 grid((unsigned)(te - tb));
+        if (!emit_only) {
+            if (c->timing_detail) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
+            if (!skip_aggregate_mid) {
+                AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, (uint32_t*)c->tile_c.p,
+                          (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
+                hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
+            }
+            if (c->timing_detail) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
+            ScanArgs s{tb, te, (const uint32_t*)c->tile_c.p, (const u64*)c->tile_a.p, (const u64*)c->tile_idc.p,
+                       (int64_t*)c->tileP.p, (int64_t*)c->tileS.p, (int64_t*)c->tileQ.p, (int64_t*)c->tileI.p,
+                       c->d_state, tb == 0 ? 1 : 0};
+            hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, s);
+            if (c->timing_detail) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
+        }
+        EmitArgs e = make_emit_args(c);
+        e.tile_begin = tb;
+        launch_emit(c, grid, e);
+        if (!emit_only && c->timing_detail) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    }
+    c->n_passes = passes;
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { c->err = std::string("kernel launch: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
+    return 0;
+}
+
+int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream_pos, int is_eof,
+                  int64_t P0, int64_t S0, int64_t Q0, int64_t I0, uint32_t prev_byte, int64_t first_header,
+                  const int64_t* first_nl = nullptr, int head_lines = 0, bool reuse_aggregates = false) {
+    int rc;
+    if ((rc = ensure_chunk_arenas(c, n, false))) return rc;
+    int64_t want = (int64_t)(n / (uint64_t)std::max(4, c->cfg.min_record_bytes)) + 1024;
+    if ((rc = ensure_record_arenas(c, want))) return rc;
+    c->cur = d_data; c->cur_n = n; c->cur_stream_pos = stream_pos; c->cur_is_eof = is_eof;
+    c->cur_prev_byte = prev_byte; c->cur_first_header = first_header;
+    for (hipEvent_t e : c->ev_detail) hipEventDestroy(e);
+    c->ev_detail.clear();
+    ChunkState* h = c->h_state;
+    memset(h, 0, sizeof(*h));
+    h->P0 = P0; h->S0 = S0; h->Q0 = Q0; h->I0 = I0;
+    h->P = P0; h->S = S0; h->Q = Q0; h->I = I0;
+    h->last_nl_tile = -1; h->tail_start = 0;
+    h->err_struct = ~0ull; h->err_valid = ~0ull; h->err_buf = ~0ull;
+    for (int i = 0; i < 4; ++i) h->first_nl[i] = first_nl ? first_nl[i] : -1;
+    HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (head_lines > 0)
+        hipLaunchKernelGGL(k_head, dim3(1), dim3(64), 0, c->stream, d_data, (int64_t)n, prev_byte, head_lines, c->d_state);
+    if (n > 0) {
+        if ((rc = enqueue_passes(c, false, reuse_aggregates))) return rc;
+        hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    c->pending = true; c->have_result = false;
+    return 0;
+}
+
+// Replays the reference's BufferedReader over the delivered records to learn the window state at
+// the moment the parser reaches the trailing non-record bytes, then classifies them exactly as
+// _next_ref_complete does (parser.mojo:451-522).  Cold path: only for a stream that ends in junk.
+int classify_tail(bzq_ctx* c, const std::vector<int64_t>& rec_end, int64_t first_header, int64_t consumed,
+                  int tail_phase, bool tail_nonblank, bool* accept_last, int* phase_out, int64_t* cap_out) {
+    Window s;
+    s.N = (int64_t)c->cur_n; s.cap = c->cfg.buffer_capacity; s.w = 0; s.end = 0; s.eof = false;
+    s.fill(); // BufferedReader.__init__, buffered.mojo:149
+    const bool growth = c->cfg.buffer_growth_enabled != 0;
+    const int64_t maxcap = c->cfg.buffer_max_capacity;
+    int64_t head = first_header;
+    for (size_t r = 0; r < rec_end.size(); ++r) {
+        const int64_t E = rec_end[r];
+        if (head == s.end) { s.w = head; s.fill(); }
+        while (!(E < s.end)) {
+            if (head == s.w) {
+                if (!growth || s.cap >= maxcap) break; // cannot happen for delivered records (err_buf caught it)
+                s.cap = std::min(maxcap, s.cap + std::min(s.cap, maxcap - s.cap));
+            } else {
+                s.w = head;
+            }
+            s.fill();
+        }
+        head = E + 1;
+    }
+    *accept_last = false;
+    head = consumed;
+    if (head == s.end) { s.w = head; s.fill(); }
+    if (head == s.end && s.eof) return BZQ_EOF;
+    for (;;) {
+        const int64_t avail = s.end - head;
+        if (avail < s.cap && s.eof) {
+            if (tail_phase == 3) {
+                if (!tail_nonblank) return BZQ_OTHER; // `raise Error()` with an empty message, parser.mojo:350-351
+                *accept_last = true;
+                return BZQ_OK;
+            }
+            *phase_out = tail_phase;
+            return BZQ_UNEXPECTED_EOF;
+        }
+        if (head == s.w) {
+            if (!growth) { *cap_out = s.cap; return BZQ_BUFFER_EXCEEDED; }
+            if (s.cap >= maxcap) { *cap_out = maxcap; return BZQ_BUFFER_AT_MAX; }
+            s.cap = std::min(maxcap, s.cap + std::min(s.cap, maxcap - s.cap));
+        } else {
+            s.w = head;
+        }
+        const int64_t filled = s.fill();
+        if (filled == 0 && s.end - head == 0) return BZQ_EOF;
+    }
+}
+
+void sb_put(std::string& s, const char* label, long long v) {
+    s += label;
+    s += std::to_string(v);
+}
+
+} // namespace
+
+// ================================================================================== C ABI
+
+extern "C" {
+
+int32_t bzq_abi_version(void) { return BZQ_ABI_VERSION; }
+
+void bzq_config_default(bzq_config* cfg) {
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->buffer_capacity = 256 * 1024;       // CONSTS.mojo:26
+    cfg->buffer_max_capacity = 1ll << 30;    // CONSTS.mojo:28
+    cfg->q_lower = 33; cfg->q_upper = 126; cfg->q_offset = 33; // generic_schema
+    cfg->batch_size = 4096;                  // CONSTS.mojo:31
+    cfg->max_chunk_bytes = 256ll << 20;
+    cfg->pass_bytes = 0;
+    cfg->min_record_bytes = 32;
+}
+
+int32_t bzq_schema_from_name(const char* name, uint8_t* lower, uint8_t* upper, uint8_t* offset) {
+    // utils.mojo:612-637 over quality_schema.mojo:26-31
+    struct Row { const char* n; uint8_t lo, up, off; };
+    static const Row rows[] = {{"sanger", 33, 126, 33},       {"solexa", 59, 126, 64},
+                               {"illumina_1.3", 64, 126, 64}, {"illumina_1.5", 66, 126, 64},
+                               {"illumina_1.8", 33, 126, 33}, {"generic", 33, 126, 33}};
+    for (const Row& r : rows)
+        if (name && strcmp(name, r.n) == 0) { *lower = r.lo; *upper = r.up; *offset = r.off; return 1; }
+    *lower = 33; *upper = 126; *offset = 33;
+    return 0;
+}
+
+const char* bzq_message_for_code(int32_t code) { return message_for_code(code); }
+
+int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
+    if (!cfg || !out) return BZQ_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = "no HIP device available (libblazeseq_hip has no CPU fallback)";
+        return BZQ_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= ndev) { g_create_error = "device ordinal out of range"; return BZQ_ERR_ARG; }
+    if (cfg->batch_size <= 0 || cfg->buffer_capacity <= 0 || cfg->q_upper > 127 || cfg->q_lower > 128 ||
+        cfg->q_lower > cfg->q_upper ||
+        !(cfg->compat_simd_width == 0 || cfg->compat_simd_width == 16 || cfg->compat_simd_width == 32 ||
+          cfg->compat_simd_width == 64)) {
+        g_create_error = "invalid bzq_config";
+        return BZQ_ERR_ARG;
+    }
+    bzq_ctx* c = new bzq_ctx();
+    c->device = device;
+    c->cfg = *cfg;
+    if (c->cfg.min_record_bytes <= 0) c->cfg.min_record_bytes = 32;
+    if (c->cfg.pass_bytes > 0) c->cfg.pass_bytes = std::max<int64_t>(TILE, (c->cfg.pass_bytes / TILE) * TILE);
+#define CRT(call)                                                                     \
+    do {                                                                              \
+        hipError_t e2 = (call);                                                       \
+        if (e2 != hipSuccess) {                                                       \
+            g_create_error = std::string(#call) + ": " + hipGetErrorString(e2);       \
+            delete c;                                                                 \
+            return BZQ_ERR_HIP;                                                       \
+        }                                                                             \
+    } while (0)
+    CRT(hipSetDevice(device));
+    CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CRT(hipMalloc((void**)&c->d_state, sizeof(ChunkState)));
+    CRT(hipHostMalloc((void**)&c->h_state, sizeof(ChunkState), hipHostMallocDefault));
+    for (auto& ev : c->ev) CRT(hipEventCreate(&ev));
+#undef CRT
+    *out = c;
+    return 0;
+}
+
+void bzq_destroy(bzq_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->in, &c->seq, &c->qual, &c->id, &c->ends, &c->id_ends, &c->rec_end, &c->b_ends,
+                      &c->b_id_ends, &c->off[0], &c->off[1], &c->off[2], &c->off[3], &c->view_e, &c->view_i,
+                      &c->tile_c, &c->tile_a,
+                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI};
+    for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+    if (c->d_state) hipFree(c->d_state);
+    if (c->h_state) hipHostFree(c->h_state);
+    for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
+    for (hipEvent_t e : c->ev_detail) hipEventDestroy(e);
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* bzq_last_error(const bzq_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int32_t bzq_set_stream(bzq_ctx* c, void* hip_stream) {
+    if (!c) return BZQ_ERR_ARG;
+    if (c->pending) { c->err = "bzq_set_stream while a chunk is in flight"; return BZQ_ERR_ARG; }
+    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)hip_stream;
+    c->own_stream = false;
+    return 0;
+}
+
+int32_t bzq_get_config(const bzq_ctx* c, bzq_config* out) {
+    if (!c || !out) return BZQ_ERR_ARG;
+    *out = c->cfg;
+    return 0;
+}
+
+int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
+    if (!c || !key) return BZQ_ERR_ARG;
+    if (!strcmp(key, "force_dense")) c->force_dense = (int)value;
+    else if (!strcmp(key, "timing_detail")) c->timing_detail = (int)value;
+    else if (!strcmp(key, "pass_bytes")) c->cfg.pass_bytes = value > 0 ? std::max<int64_t>(TILE, (value / TILE) * TILE) : 0;
+    else { c->err = std::string("unknown option ") + key; return BZQ_ERR_ARG; }
+    return 0;
+}
+
+int32_t bzq_pinned_alloc(size_t bytes, void** out) {
+    if (!out) return BZQ_ERR_ARG;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? 0 : BZQ_ERR_NOMEM;
+}
+int32_t bzq_pinned_free(void* p) { return hipHostFree(p) == hipSuccess ? 0 : BZQ_ERR_HIP; }
+
+int32_t bzq_submit_chunk_device(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream_pos, int32_t is_eof) {
+    if (!c || (!d_data && n)) return BZQ_ERR_ARG;
+    if (((uintptr_t)d_data & 15u) != 0) { c->err = "device chunk must be 16-byte aligned"; return BZQ_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    c->shard_mode = false;
+    return submit_common(c, d_data, n, stream_pos, is_eof, 0, 0, 0, 0, 10u, 0);
+}
+
+int32_t bzq_submit_chunk_host(bzq_ctx* c, const uint8_t* data, uint64_t n, uint64_t stream_pos, int32_t is_eof) {
+    if (!c || (!data && n)) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_chunk_arenas(c, n, true))) return rc;
+    if (n) HIPCHK(c, hipMemcpyAsync(c->in.p, data, n, hipMemcpyHostToDevice, c->stream));
+    c->shard_mode = false;
+    return submit_common(c, (const uint8_t*)c->in.p, n, stream_pos, is_eof, 0, 0, 0, 0, 10u, 0);
+}
+
+int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
+    if (!c || !out) return BZQ_ERR_ARG;
+    if (!c->pending && !c->have_result) { c->err = "no chunk submitted"; return BZQ_ERR_ARG; }
+    if (c->have_result) { *out = c->res; return (c->res.status > 0 && c->res.status != BZQ_EOF) ? c->res.status : 0; }
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ChunkState* h = c->h_state;
+    HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
+    if (h->rec_overflow) {
+        // shorter records than the sizing hint assumed: re-size to the exact count, re-run the emit pass
+        const int64_t need = std::max<int64_t>(0, h->P >> 2) + 2;
+        int rc;
+        if ((rc = ensure_record_arenas(c, need + 1024))) return rc;
+        ChunkState fresh = *h;
+        fresh.rec_overflow = 0; fresh.err_struct = ~0ull; fresh.err_valid = ~0ull; fresh.err_buf = ~0ull;
+        fresh.dense_tiles = 0;
+        *h = fresh;
+        HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
+        if ((rc = enqueue_passes(c, true, false))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
+        if (h->rec_overflow) { c->err = "record arrays still too small after re-size"; return BZQ_ERR_NOMEM; }
+    }
+    const int64_t n = (int64_t)c->cur_n;
+    const int64_t lines = h->P;                       // P0 + total newlines
+    int64_t n_complete = lines > 0 ? (lines >> 2) : 0; // records with all four newlines
+    const int tail_phase = (int)(lines & 3);
+    const int64_t batch = c->cfg.batch_size;
+    const bool growth = c->cfg.buffer_growth_enabled != 0;
+    const int64_t len_limit = growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity;
+
+    // per-record post pass: per-batch ends + longest-record check (+ optional SIMD-width emulation)
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    if (n_complete > 0) {
+        RebaseArgs ra{n_complete, (const int64_t*)c->ends.p, (const int64_t*)c->id_ends.p,
+                      (const int64_t*)c->rec_end.p, (int64_t*)c->b_ends.p, (int64_t*)c->b_id_ends.p, batch,
+                      c->cur_first_header, len_limit, c->d_state};
+        hipLaunchKernelGGL(k_rebase, dim3((unsigned)((n_complete + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, ra);
+        if (c->cfg.check_quality && c->cfg.compat_simd_width > 0)
+            hipLaunchKernelGGL(k_compat_quality, dim3((unsigned)((n_complete + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
+                               c->stream, c->cur, n_complete, (const int64_t*)c->ends.p,
+                               (const int64_t*)c->rec_end.p, (int)c->cfg.compat_simd_width, (uint32_t)c->cfg.q_upper,
+                               c->d_state);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
+
+    int64_t consumed = c->cur_first_header;
+    if (n_complete > 0) {
+        int64_t last_end = 0;
+        HIPCHK(c, hipMemcpy(&last_end, (const int64_t*)c->rec_end.p + (n_complete - 1), 8, hipMemcpyDeviceToHost));
+        consumed = last_end + 1;
+    }
+
+    bzq_chunk r{};
+    r.n_bytes = c->cur_n;
+    r.total_newlines = (uint64_t)(h->P - h->P0);
+    r.tail_phase = tail_phase;
+    r.error_record = -1;
+    r.status = BZQ_OK;
+    c->term_phase = 0; c->term_cap = c->cfg.buffer_capacity;
+
+    auto key_rec = [](u64 k) { return (int64_t)(k >> 3); };
+    // first failing record among the complete ones; same record: buffer < structure < validation
+    u64 best = ~0ull;
+    if (h->err_buf != ~0ull && key_rec(h->err_buf) < n_complete) best = std::min(best, h->err_buf);
+    if (h->err_struct != ~0ull && key_rec(h->err_struct) < n_complete) best = std::min(best, h->err_struct);
+    if (h->err_valid != ~0ull && key_rec(h->err_valid) < n_complete) best = std::min(best, h->err_valid);
+    int64_t n_records = n_complete;
+    bool accept_last = false;
+    if (best != ~0ull) {
+        n_records = key_rec(best);
+        int code = (int)(best & 7);
+        if (code == 0) { code = growth ? BZQ_BUFFER_AT_MAX : BZQ_BUFFER_EXCEEDED; c->term_cap = len_limit; }
+        r.status = code;
+        r.error_record = n_records;
+    } else if (c->cur_is_eof && !c->shard_mode) {
+        if (consumed >= n) {
+            r.status = BZQ_EOF;
+        } else {
+            std::vector<int64_t> re((size_t)n_complete);
+            if (n_complete) HIPCHK(c, hipMemcpy(re.data(), c->rec_end.p, (size_t)n_complete * 8, hipMemcpyDeviceToHost));
+            int ph = 0; int64_t cap = c->cfg.buffer_capacity;
+            int code = classify_tail(c, re, c->cur_first_header, consumed, tail_phase, h->tail_nonblank != 0,
+                                     &accept_last, &ph, &cap);
+            c->term_phase = ph; c->term_cap = cap;
+            if (accept_last) {
+                // last record without trailing newline (Q4): structure check skipped, validation still applies
+                if (n_complete + 1 > c->rec_cap) {
+                    c->err = "record arrays too small for the unterminated last record";
+                    return BZQ_ERR_NOMEM;
+                }
+                hipLaunchKernelGGL(k_fix_last, dim3(1), dim3(64), 0, c->stream, n_complete, n, batch,
+                                   (int64_t*)c->ends.p, (int64_t*)c->id_ends.p, (int64_t*)c->rec_end.p,
+                                   (int64_t*)c->b_ends.p, (int64_t*)c->b_id_ends.p, (const ChunkState*)c->d_state);
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                n_records = n_complete + 1;
+                consumed = n;
+                if (h->err_valid != ~0ull && key_rec(h->err_valid) == n_complete) {
+                    r.status = (int)(h->err_valid & 7);
+                    r.error_record = n_complete;
+                    n_records = n_complete;
+                } else {
+                    r.status = BZQ_EOF;
+                }
+            } else {
+                r.status = code;
+                r.error_record = (code == BZQ_EOF) ? -1 : n_complete;
+            }
+        }
+    } else if (c->cur_is_eof && c->shard_mode) {
+        // last shard: the window-alignment quirk of the reference is not replayed
+        // across shards; trailing bytes get the outcome the reference gives when its window holds
+        // them completely (probability 1 - tail/buffer_capacity on a large file)
+        if (consumed >= n) r.status = BZQ_EOF;
+        else if (tail_phase == 3 && h->tail_nonblank) {
+            if (n_complete + 1 > c->rec_cap) { c->err = "record arrays too small"; return BZQ_ERR_NOMEM; }
+            hipLaunchKernelGGL(k_fix_last, dim3(1), dim3(64), 0, c->stream, n_complete, n, batch,
+                               (int64_t*)c->ends.p, (int64_t*)c->id_ends.p, (int64_t*)c->rec_end.p,
+                               (int64_t*)c->b_ends.p, (int64_t*)c->b_id_ends.p, (const ChunkState*)c->d_state);
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            accept_last = true;
+            n_records = n_complete + 1; consumed = n;
+            if (h->err_valid != ~0ull && key_rec(h->err_valid) == n_complete) {
+                r.status = (int)(h->err_valid & 7); r.error_record = n_complete; n_records = n_complete;
+            } else r.status = BZQ_EOF;
+        } else if (tail_phase == 3) { r.status = BZQ_OTHER; r.error_record = n_complete; }
+        else { r.status = BZQ_UNEXPECTED_EOF; r.error_record = n_complete; c->term_phase = tail_phase; }
+    }
+
+    r.n_records = (uint64_t)n_records;
+    if (r.status > 0 && r.status != BZQ_EOF && r.error_record >= 0 && r.error_record < n_complete && n_records < n_complete) {
+        // consumed = end of the last delivered record
+        if (n_records > 0) {
+            int64_t le = 0;
+            HIPCHK(c, hipMemcpy(&le, (const int64_t*)c->rec_end.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
+            consumed = le + 1;
+        } else consumed = c->cur_first_header;
+    }
+    r.bytes_consumed = (uint64_t)consumed;
+    if (n_records > 0) {
+        int64_t e2[2] = {0, 0};
+        HIPCHK(c, hipMemcpy(&e2[0], (const int64_t*)c->ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&e2[1], (const int64_t*)c->id_ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
+        r.qual_bytes = (uint64_t)e2[0];
+        r.seq_bytes = accept_last && r.status == BZQ_EOF ? (uint64_t)h->S : (uint64_t)e2[0];
+        r.id_bytes = (uint64_t)e2[1];
+    }
+    r.d_seq = (const uint8_t*)c->seq.p; r.d_qual = (const uint8_t*)c->qual.p; r.d_id = (const uint8_t*)c->id.p;
+    r.d_ends = (const int64_t*)c->ends.p; r.d_id_ends = (const int64_t*)c->id_ends.p;
+    r.d_batch_ends = (const int64_t*)c->b_ends.p; r.d_batch_id_ends = (const int64_t*)c->b_id_ends.p;
+    r.d_record_end = (const int64_t*)c->rec_end.p;
+    if (c->cfg.emit_offsets) {
+        r.d_header_start = (const int64_t*)c->off[0].p; r.d_seq_start = (const int64_t*)c->off[1].p;
+        r.d_sep_start = (const int64_t*)c->off[2].p; r.d_qual_start = (const int64_t*)c->off[3].p;
+    }
+    float ms0 = 0.f, ms1 = 0.f;
+    hipEventElapsedTime(&ms0, c->ev[0], c->ev[1]);
+    hipEventElapsedTime(&ms1, c->ev[2], c->ev[3]);
+    r.ms_total = ms0 + ms1;
+    r.ms_rebase = ms1;
+    if (c->timing_detail && c->ev_detail.size() >= 4) {
+        for (size_t i = 0; i + 3 < c->ev_detail.size(); i += 4) {
+            float a = 0, b = 0, d = 0;
+            hipEventElapsedTime(&a, c->ev_detail[i], c->ev_detail[i + 1]);
+            hipEventElapsedTime(&b, c->ev_detail[i + 1], c->ev_detail[i + 2]);
+            hipEventElapsedTime(&d, c->ev_detail[i + 2], c->ev_detail[i + 3]);
+            r.ms_aggregate += a; r.ms_scan += b; r.ms_emit += d;
+        }
+    }
+    r.n_passes = (uint32_t)c->n_passes;
+    r._pad = (uint32_t)h->dense_tiles;
+    c->res = r;
+    c->pending = false; c->have_result = true;
+    *out = r;
+    return (r.status > 0 && r.status != BZQ_EOF) ? r.status : 0;
+}
+
+int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, bzq_device_batch* out) {
+    if (!c || !out || !c->have_result) { if (c) c->err = "bzq_batch_view: no parsed chunk"; return BZQ_ERR_ARG; }
+    if (max_records == 0) { c->err = "bzq_batch_view: max_records must be > 0"; return BZQ_ERR_ARG; }
+    const uint64_t bs = (uint64_t)c->cfg.batch_size;
+    memset(out, 0, sizeof(*out));
+    out->quality_offset = 33; // parser.mojo:243 builds FastqBatch(batch_size=limit): default offset
+    out->first_record = first_record;
+    if (first_record >= c->res.n_records) return 0; // empty batch: the iterator stops (parser.mojo:727-729)
+    const uint64_t nrec = std::min<uint64_t>(max_records, c->res.n_records - first_record);
+    HIPCHK(c, hipSetDevice(c->device));
+    int64_t base[2] = {0, 0}, last[2] = {0, 0};
+    if (first_record > 0) {
+        HIPCHK(c, hipMemcpy(&base[0], c->res.d_ends + (first_record - 1), 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&base[1], c->res.d_id_ends + (first_record - 1), 8, hipMemcpyDeviceToHost));
+    }
+    HIPCHK(c, hipMemcpy(&last[0], c->res.d_ends + (first_record + nrec - 1), 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&last[1], c->res.d_id_ends + (first_record + nrec - 1), 8, hipMemcpyDeviceToHost));
+    out->num_records = (int64_t)nrec;
+    out->seq_len = last[0] - base[0];
+    out->total_id_bytes = last[1] - base[1];
+    out->qual_buffer = c->res.d_qual + base[0];
+    out->sequence_buffer = c->res.d_seq + base[0];
+    out->id_buffer = c->res.d_id + base[1];
+    if (first_record % bs == 0 && max_records <= bs) {
+        // batch aligned: the per-batch ends were produced with the chunk (k_rebase), zero copy
+        out->ends = c->res.d_batch_ends + first_record;
+        out->id_ends = c->res.d_batch_id_ends + first_record;
+    } else {
+        int rc;
+        if ((rc = ensure(c, c->view_e, nrec * 8)) || (rc = ensure(c, c->view_i, nrec * 8))) return rc;
+        hipLaunchKernelGGL(k_rebase_range, dim3((unsigned)((nrec + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream,
+                           c->res.d_ends, c->res.d_id_ends, (int64_t)first_record, (int64_t)nrec,
+                           (int64_t*)c->view_e.p, (int64_t*)c->view_i.p);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        out->ends = (const int64_t*)c->view_e.p;
+        out->id_ends = (const int64_t*)c->view_i.p;
+    }
+    return 0;
+}
+
+int32_t bzq_batch_to_host(bzq_ctx* c, const bzq_device_batch* b, bzq_host_batch* out) {
+    if (!c || !b || !out) return BZQ_ERR_ARG;
+    out->num_records = b->num_records;
+    out->quality_offset = b->quality_offset;
+    if (b->num_records == 0) return 0;
+    HIPCHK(c, hipMemcpy(out->quality_bytes, b->qual_buffer, (size_t)b->seq_len, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out->sequence_bytes, b->sequence_buffer, (size_t)b->seq_len, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out->id_bytes, b->id_buffer, (size_t)b->total_id_bytes, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out->ends, b->ends, (size_t)b->num_records * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(out->id_ends, b->id_ends, (size_t)b->num_records * 8, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int32_t bzq_copy_to_host(bzq_ctx* c, void* dst, const void* d_src, size_t bytes) {
+    if (!c || (!dst && bytes)) return BZQ_ERR_ARG;
+    if (bytes) HIPCHK(c, hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int64_t bzq_format_error(bzq_ctx* c, uint64_t records_before, char* buf, size_t cap) {
+    if (!c || !c->have_result) return -1;
+    const bzq_chunk& r = c->res;
+    std::string s;
+    const int code = r.status;
+    if (code == BZQ_OK) s = "";
+    else if (code == BZQ_EOF) s = "EOF"; // CONSTS.mojo:19
+    else if (code == BZQ_OTHER) s = "";
+    else if (code == BZQ_UNEXPECTED_EOF) {
+        s = "Unexpected end of file in FASTQ record at phase " + std::to_string(c->term_phase); // parser.mojo:295-298
+    } else if (code == BZQ_BUFFER_EXCEEDED) {
+        s = "FASTQ record exceeds buffer capacity (" + std::to_string(c->term_cap) +
+            " bytes). Enable buffer growth or increase buffer_capacity."; // parser.mojo:299-304
+    } else if (code == BZQ_BUFFER_AT_MAX) {
+        s = "FASTQ record exceeds maximum buffer capacity (" + std::to_string(c->cfg.buffer_max_capacity) +
+            " bytes). Enable buffer growth or increase max_capacity."; // parser.mojo:305-309
+    } else {
+        // the failing record's bytes: [start, record_end]
+        const int64_t rec = r.error_record;
+        int64_t start = c->cur_first_header, end = 0;
+        if (rec > 0) {
+            hipMemcpy(&start, r.d_record_end + (rec - 1), 8, hipMemcpyDeviceToHost);
+            start += 1;
+        }
+        if ((uint64_t)rec < (uint64_t)(c->h_state->P >> 2)) hipMemcpy(&end, r.d_record_end + rec, 8, hipMemcpyDeviceToHost);
+        else end = (int64_t)c->cur_n - 1; // unterminated last record
+        int64_t len = end - start + 1;
+        if (len < 0) len = 0;
+        const int64_t fetch = std::min<int64_t>(len, 1 << 20);
+        std::vector<uint8_t> raw((size_t)fetch);
+        if (fetch) hipMemcpy(raw.data(), c->cur + start, (size_t)fetch, hipMemcpyDeviceToHost);
+        const long long recno = (long long)(records_before + (uint64_t)rec + 1);
+        s = message_for_code(code);
+        if (code <= BZQ_SEQ_QUAL_LEN_MISMATCH) {
+            // ParseError.write_to (errors.mojo:178-192) with parser.mojo:332-338 numbering
+            sb_put(s, "\n  Record number: ", recno);
+            sb_put(s, "\n  Line number: ", 4 * (recno - 1) + 1);
+            const long long pos = (long long)(c->cur_stream_pos + (uint64_t)start);
+            if (pos > 0) sb_put(s, "\n  File position: ", pos);
+            const int64_t sn = std::min<int64_t>(std::min<int64_t>(len, 200), fetch); // utils.mojo:435-445
+            if (sn > 0) { s += "\n  Record snippet: "; s.append((const char*)raw.data(), (size_t)sn); }
+        } else {
+            // ValidationError.write_to (errors.mojo:223-234); snippet = id "\n" sequence prefix (parser.mojo:597-610)
+            sb_put(s, "\n  Record number: ", recno);
+            int64_t nl[3] = {-1, -1, -1}; int k = 0;
+            for (int64_t i = 0; i < fetch && k < 3; ++i) if (raw[(size_t)i] == 10) nl[k++] = i;
+            std::string snip;
+            if (k >= 1) {
+                int64_t a = 1, b = nl[0];
+                auto sp = [](uint8_t ch) { return ch <= 32 && ((0x170003E00ull >> ch) & 1ull); };
+                if (b > a && (sp(raw[(size_t)a]) || sp(raw[(size_t)(b - 1)]))) {
+                    while (a < b && sp(raw[(size_t)a])) ++a;
+                    while (b > a && sp(raw[(size_t)(b - 1)])) --b;
+                }
+                if (b > a) {
+                    snip.append((const char*)raw.data() + a, (size_t)(b - a));
+                    if (snip.size() < 200) snip += "\n";
+                }
+                const int64_t s0 = nl[0] + 1, s1 = k >= 2 ? nl[1] : fetch;
+                if (snip.size() < 200 && s1 > s0) {
+                    const int64_t take = std::min<int64_t>(s1 - s0, 200 - (int64_t)snip.size());
+                    snip.append((const char*)raw.data() + s0, (size_t)take);
+                }
+                if (snip.size() > 200) snip = snip.substr(0, 197) + "...";
+            }
+            if (!snip.empty()) { s += "\n  Record snippet: "; s += snip; }
+        }
+    }
+    if (buf && cap) {
+        const size_t nbytes = std::min(cap - 1, s.size());
+        memcpy(buf, s.data(), nbytes);
+        buf[nbytes] = 0;
+    }
+    return (int64_t)s.size();
+}
+
+int32_t bzq_shard_scan(bzq_ctx* c, const uint8_t* d_data, uint64_t n, bzq_shard_summary* out) {
+    if (!c || !out || (!d_data && n)) return BZQ_ERR_ARG;
+    if (((uintptr_t)d_data & 15u) != 0) { c->err = "device shard must be 16-byte aligned"; return BZQ_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure_chunk_arenas(c, n + (64u << 20), false))) return rc; // room for the halo tiles too
+    memset(out, 0, sizeof(*out));
+    out->n_bytes = n;
+    for (int i = 0; i < 4; ++i) out->first_nl[i] = -1;
+    if (n == 0) {
+        out->first_byte = 10; out->last_byte = 10;
+        for (int i = 0; i < 4; ++i) c->h_state->first_nl[i] = -1;
+        c->agg_ptr = d_data; c->agg_n = 0;
+        return 0;
+    }
+    ChunkState* h = c->h_state;
+    memset(h, 0, sizeof(*h));
+    h->last_nl_tile = -1;
+    h->err_struct = ~0ull; h->err_valid = ~0ull; h->err_buf = ~0ull;
+    HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
+    const int64_t nt = tiles_for(n);
+    AggArgs a{d_data, (int64_t)n, 10u, 0, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
+    hipLaunchKernelGGL(k_tile_aggregate, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
+    ScanArgs s{0, nt, (const uint32_t*)c->tile_c.p, (const u64*)c->tile_a.p, (const u64*)c->tile_idc.p,
+               (int64_t*)c->tileP.p, (int64_t*)c->tileS.p, (int64_t*)c->tileQ.p, (int64_t*)c->tileI.p, c->d_state, 1};
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(SCAN_BLOCK), 0, c->stream, s);
+    hipLaunchKernelGGL(k_first_newlines, dim3(1), dim3(BLOCK), 0, c->stream, d_data, (int64_t)n, c->d_state);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
+    out->n_newlines = (uint64_t)h->P;
+    for (int i = 0; i < 4; ++i) out->first_nl[i] = h->first_nl[i];
+    HIPCHK(c, hipMemcpy(&out->first_byte, d_data, 1, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&out->last_byte, d_data + (n - 1), 1, hipMemcpyDeviceToHost));
+    c->agg_ptr = d_data; c->agg_n = n;
+    return 0;
+}
+
+int32_t bzq_shard_head_bytes(const bzq_shard_summary* s, uint64_t lines_before, uint8_t prev_last_byte,
+                             uint64_t* head_bytes) {
+    if (!s || !head_bytes) return BZQ_ERR_ARG;
+    const int p0 = (int)(lines_before & 3);
+    if (prev_last_byte == 10 && p0 == 0) { *head_bytes = 0; return 0; }
+    const int k = 4 - p0; // lines left of the record that started in an earlier shard
+    if (s->first_nl[k - 1] < 0) return BZQ_ERR_ARG; // record longer than a whole shard
+    *head_bytes = (uint64_t)s->first_nl[k - 1] + 1;
+    return 0;
+}
+
+int32_t bzq_submit_shard(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t halo_bytes, uint64_t lines_before,
+                         uint8_t prev_last_byte, uint64_t stream_pos, int32_t is_last_shard) {
+    if (!c || (!d_data && n)) return BZQ_ERR_ARG;
+    if (((uintptr_t)d_data & 15u) != 0) { c->err = "device shard must be 16-byte aligned"; return BZQ_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const bool reuse = (c->agg_ptr == d_data && c->agg_n == n && n >= (uint64_t)TILE &&
+                        tiles_for(n + halo_bytes) + 1 <= c->tile_cap);
+    int64_t first_nl[4] = {-1, -1, -1, -1};
+    if (c->agg_ptr == d_data && c->agg_n == n) for (int i = 0; i < 4; ++i) first_nl[i] = c->h_state->first_nl[i];
+    else { c->err = "bzq_submit_shard must follow bzq_shard_scan of the same shard"; return BZQ_ERR_ARG; }
+    const int p0 = (int)(lines_before & 3);
+    int head_lines = 0;
+    int64_t first_header = 0;
+    if (!(prev_last_byte == 10 && p0 == 0)) {
+        head_lines = 4 - p0;
+        if (first_nl[head_lines - 1] < 0) { c->err = "a record spans more than one whole shard"; return BZQ_ERR_ARG; }
+        first_header = first_nl[head_lines - 1] + 1;
+    }
+    c->shard_mode = true;
+    c->head_lines = head_lines;
+    const int rc = submit_common(c, d_data, n + halo_bytes, stream_pos, is_last_shard, -(int64_t)head_lines, 0, 0, 0,
+                                 prev_last_byte, first_header, first_nl, head_lines, reuse);
+    c->agg_ptr = nullptr; c->agg_n = 0;
+    return rc;
+}
+
+int32_t bzq_generate_synthetic_device(bzq_ctx* c, int64_t num_reads, int64_t first, int64_t count, int32_t read_len,
+                                      int32_t min_phred, int32_t max_phred, const char* schema, uint8_t* d_out,
+                                      uint64_t cap, uint64_t* out_bytes) {
+    if (!c || num_reads <= 0 || first < 0 || count < 0 || first + count > num_reads || read_len < 0 ||
+        min_phred < 0 || max_phred < min_phred)
+        return BZQ_ERR_ARG;
+    int nd = 1;
+    if (num_reads > 1) nd = (int)std::to_string(num_reads - 1).size(); // utils.mojo:880-882
+    const uint64_t rec_bytes = 6 + (uint64_t)nd + 1 + 2 * ((uint64_t)read_len + 1) + 2;
+    const uint64_t total = rec_bytes * (uint64_t)count;
+    if (out_bytes) *out_bytes = total;
+    if (!d_out) return 0;
+    if (cap < total) { c->err = "bzq_generate_synthetic_device: output buffer too small"; return BZQ_ERR_ARG; }
+    uint8_t lo, up, off;
+    (void)bzq_schema_from_name(schema ? schema : "generic", &lo, &up, &off);
+    HIPCHK(c, hipSetDevice(c->device));
+    GenArgs g{d_out, first, count, num_reads, read_len, nd, min_phred, max_phred, off, lo, up};
+    if (count > 0)
+        hipLaunchKernelGGL(k_generate, dim3((unsigned)((count + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, g);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,884 @@
+// bzq_device.hpp -- gfx950 (CDNA4, wave64) kernels of the FASTQ batch-parse path.
+//
+// What this replaces in the reference (paths relative to the BlazeSeq tree):
+//   _scan_record + _validate_fastq_structure   blazeseq/utils.mojo:448-551
+//   _strip_spaces / is_posix_space             blazeseq/utils.mojo:221-242, 267-289
+//   Validator._validate (ascii, quality)       blazeseq/fastq/record.mojo:76-116, 162-172
+//   FastqBatch.add (SoA columns + ends)        blazeseq/fastq/record_batch.mojo:77-87
+//   stage_batch_to_host/move_staged_to_device  blazeseq/fastq/record_batch.mojo:308-411
+//
+// Formulation (not a translation of the record-at-a-time CPU loop): the chunk starts at a record
+// start, so the k-th '\n' ends line k, line k has role k&3 (0 header, 1 sequence, 2 '+', 3 quality)
+// and belongs to record k>>2 -- strict 4-line framing, exactly what the reference does (it never
+// re-synchronises on '@').  The chunk is cut into 16 KiB tiles, one 256-thread workgroup each:
+//
+//   k_tile_aggregate  pass A: per tile, phase-agnostic summary {newlines, bytes per line class
+//                     (line index mod 4), id bytes per class after strip}.  Pure streaming read.
+//   k_scan_tiles      exclusive scan of the summaries -> per tile {line index, seq/qual/id column
+//                     offsets}.  One workgroup, tiny data.
+//   k_tile_emit       pass B: re-reads the tile (coalesced 16 B/lane) into LDS, rebuilds the line
+//                     table, and gathers the sequence / quality / id streams out of LDS into the
+//                     packed columns with aligned, coalesced 16 B stores; writes ends / id_ends /
+//                     record_end per record; structure + ascii + quality checks feed a
+//                     min-reduction on (record << 3 | code) = "first failing record".
+//   k_rebase          per-batch `ends` restart + longest-record check (BUFFER_EXCEEDED parity).
+//
+// No MFMA: byte/integer work, HBM-bound.  Algorithmic traffic per record = B + 2L + D + 16
+// (DESIGN.md); this two-read design moves 2B + 2L + D + ~40.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bzq {
+
+constexpr int TILE = 16384;         // bytes per workgroup tile
+constexpr int BLOCK = 256;          // 4 waves of 64
+constexpr int PIECES = TILE / 16;   // 16-byte pieces per tile
+constexpr int MAXL = 1020;          // fast path handles tiles with <= MAXL newlines (<= 256 lines per role)
+constexpr int SEGS = 256;
+constexpr int SCAN_BLOCK = 1024;
+constexpr int SCAN_ITEMS = 4;
+
+typedef unsigned long long u64;
+
+// Device-resident per-chunk state (host reads it back once per chunk).
+struct ChunkState {
+    // initial prefix (host)
+    int64_t P0, S0, Q0, I0;
+    // running carry of the tile scan (scan kernel), = totals after the last pass
+    int64_t P, S, Q, I;
+    int64_t last_nl_tile;     // last tile that holds a newline, -1 if none
+    int64_t tail_start;       // offset after the last newline (k_tail)
+    int32_t tail_nonblank;    // tail holds a byte outside {\n,\r,space,tab} (utils.mojo:311-322)
+    int32_t rec_overflow;     // a record index exceeded the per-record array capacity
+    u64 err_struct;           // min (record<<3 | code) over codes 1..3
+    u64 err_valid;            // min over codes 4..5
+    u64 err_buf;              // min (record<<3) over records longer than the reference buffer limit
+    int64_t dense_tiles;      // tiles that took the serial path (diagnostics)
+    int64_t max_record_len;
+    int64_t first_nl[4];      // offsets of the first four newlines (shard stitch), -1 if absent
+};
+
+__device__ __forceinline__ bool is_posix_space(uint32_t c) {
+    // blazeseq/utils.mojo:267-289: {9,10,11,12,13,28,29,30,32}
+    return c <= 32u && ((0x170003E00ull >> c) & 1ull);
+}
+
+// 4-bit mask of bytes equal to '\n' in a little-endian dword (exact, no borrow artefacts).
+__device__ __forceinline__ uint32_t nl_mask4(uint32_t x) {
+    uint32_t y = x ^ 0x0A0A0A0Au;
+    uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); // 0x80 where byte == 0
+    return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+}
+__device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
+    return nl_mask4(v.x) | (nl_mask4(v.y) << 4) | (nl_mask4(v.z) << 8) | (nl_mask4(v.w) << 12);
+}
+
+// Guarded 16-byte load of chunk bytes [pos, pos+16): bytes at or beyond n read as 0.
+__device__ __forceinline__ uint4 load16(const uint8_t* __restrict__ g, int64_t pos, int64_t n) {
+    if (pos + 16 <= n) return *reinterpret_cast<const uint4*>(g + pos);
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    for (int i = 0; i < 16; ++i)
+        if (pos + i < n) w[i >> 2] |= (uint32_t)g[pos + i] << (8 * (i & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+struct ByteSrc {
+    const uint8_t* __restrict__ g;
+    int64_t n;
+    uint32_t prev_byte; // the byte before offset 0 ('\n' for a chunk that starts at a record start)
+    __device__ __forceinline__ uint32_t at(int64_t pos) const {
+        if (pos >= 0) return g[pos];
+        return pos == -1 ? prev_byte : 10u;
+    }
+};
+
+// Kept (post-strip, '@' excluded) part of the header-line bytes [ls, le) that lie in this tile.
+// The line really spans [h, e) with h <= ls and e >= le; start_known: ls == h (the '@' position is
+// ls), end_known: le == e (the newline is at le).  Bytes are classified by where they ARE, so a
+// leading/trailing space run that crosses a tile edge is looked at from both sides and every byte
+// is dropped exactly once.  Follows _strip_spaces, blazeseq/utils.mojo:221-242 (all-space ids
+// collapse to empty).
+__device__ inline void header_kept(const ByteSrc& b, int64_t ls, int64_t le, bool start_known,
+                                   bool end_known, int64_t tile_end, int64_t& lo_out, int64_t& hi_out) {
+    int64_t lo = ls, hi = le;
+    if (hi <= lo) { lo_out = lo; hi_out = lo; return; }
+    bool in_lead;
+    if (start_known) {
+        lo = ls + 1; // '@' (or whatever sits at header_start) is never part of the id
+        in_lead = true;
+    } else {
+        // does the leading-space run that began right after header_start reach this tile?
+        int64_t p = ls - 1;
+        in_lead = false;
+        for (;;) {
+            uint32_t c = b.at(p);
+            if (c == 10u) { in_lead = true; break; }           // p+1 was header_start and a space
+            if (!is_posix_space(c)) {                            // non-space: only fine at header_start
+                in_lead = (b.at(p - 1) == 10u);
+                break;
+            }
+            --p;
+        }
+    }
+    if (in_lead)
+        while (lo < hi && is_posix_space(b.at(lo))) ++lo;
+    if (hi > lo && is_posix_space(b.at(hi - 1))) {
+        bool trailing = end_known;
+        if (!end_known) {
+            // the line continues past this tile: trailing run only if everything up to '\n' is space
+            int64_t p = tile_end;
+            trailing = false;
+            while (p < b.n) {
+                uint32_t c = b.g[p];
+                if (c == 10u) { trailing = true; break; }
+                if (!is_posix_space(c)) break;
+                ++p;
+            }
+        }
+        if (trailing)
+            while (hi > lo && is_posix_space(b.at(hi - 1))) --hi;
+    }
+    lo_out = lo;
+    hi_out = hi;
+}
+
+// ---- block-wide scans ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Exclusive scan over the block; s_w needs NW entries.  Two barriers.
+template <typename T, int NW>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* s_w, T& total) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    T incl = wave_inclusive_scan<T>(v, lane);
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    T base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+        T x = s_w[i];
+        if (i < w) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+
+// ---- tile front end shared by both passes -----------------------------------------------------
+// Loads the tile (coalesced 16 B per lane, 4 rounds), optionally stages it in LDS, builds the
+// newline bitmap: s_mask[q] = 16-bit mask of piece q; read back as one u64 per thread = the 64
+// contiguous bytes [64*tid, 64*tid+64).
+template <bool STAGE>
+__device__ __forceinline__ void tile_load(const uint8_t* __restrict__ g, int64_t n, int64_t t0, int valid,
+                                          uint16_t* s_mask, uint8_t* s_tile /* +16 front pad applied */) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int q = tid + BLOCK * s;
+        const int pos = q * 16;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (pos < valid) v = load16(g, t0 + pos, n);
+        uint32_t m = nl_mask16(v);
+        int rem = valid - pos;
+        if (rem < 16) m &= rem > 0 ? ((1u << rem) - 1u) : 0u;
+        s_mask[q] = (uint16_t)m;
+        if (STAGE) *reinterpret_cast<uint4*>(s_tile + pos) = v;
+    }
+}
+
+__device__ __forceinline__ int prev_newline_before_word(const u64* s_mask64, int word) {
+    for (int w = word - 1; w >= 0; --w) {
+        u64 mm = s_mask64[w];
+        if (mm) return w * 64 + 63 - __builtin_clzll(mm);
+    }
+    return -1;
+}
+
+// Calls f(j, start, end, end_in_tile) for every line this thread owns: a line is owned by the
+// thread whose 64 bytes hold its terminating newline; the tile's unterminated last line (index c)
+// by thread BLOCK-1.  start/end are tile-local, end is the newline position (or `valid`).
+template <typename F>
+__device__ __forceinline__ void for_each_owned_line(const u64* s_mask64, u64 m64, int excl, int c, int valid, F&& f) {
+    const int tid = threadIdx.x;
+    int prev = -2, idx = 0;
+    u64 m = m64;
+    while (m) {
+        const int bit = __builtin_ctzll(m);
+        m &= m - 1;
+        const int nl = tid * 64 + bit;
+        const int start = (idx == 0 ? prev_newline_before_word(s_mask64, tid) : prev) + 1;
+        f(excl + idx, start, nl, true);
+        prev = nl;
+        ++idx;
+    }
+    if (tid == BLOCK - 1) {
+        int last = m64 ? (tid * 64 + 63 - __builtin_clzll(m64)) : prev_newline_before_word(s_mask64, tid);
+        f(c, last + 1, valid, false);
+    }
+}
+
+// =================================================================================== pass A
+struct AggArgs {
+    const uint8_t* g;
+    int64_t n;
+    uint32_t prev_byte;
+    int64_t tile_begin;
+    uint32_t* tile_c;   // newlines per tile
+    u64* tile_a;        // 4 x u16: non-newline bytes per line class (local line index & 3)
+    u64* tile_idc;      // 4 x u16: id bytes per class if that class were the header role
+};
+
+__global__ __launch_bounds__(BLOCK) void k_tile_aggregate(AggArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
+    __shared__ uint32_t s_w[4];
+    __shared__ uint32_t s_a[4], s_idc[4];
+    const int tid = threadIdx.x;
+    const int64_t t = a.tile_begin + blockIdx.x;
+    const int64_t t0 = t * TILE;
+    const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+    if (tid < 4) { s_a[tid] = 0; s_idc[tid] = 0; }
+    tile_load<false>(a.g, a.n, t0, valid, s_mask, nullptr);
+    __syncthreads();
+    const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);
+    const u64 m64 = s_mask64[tid];
+    uint32_t c = 0;
+    const uint32_t excl = block_exclusive_scan<uint32_t, 4>((uint32_t)__popcll(m64), s_w, c);
+    ByteSrc bs{a.g, a.n, a.prev_byte};
+    const bool first_starts = (bs.at(t0 - 1) == 10u);
+    uint32_t la[4] = {0, 0, 0, 0}, li[4] = {0, 0, 0, 0};
+    for_each_owned_line(s_mask64, m64, (int)excl, (int)c, valid, [&](int j, int start, int end, bool end_in) {
+        const int cls = j & 3;
+        const int len = end - start;
+        if (len <= 0) return;
+        la[cls] += (uint32_t)len;
+        const bool start_in = j > 0 ? true : first_starts;
+        int64_t lo, hi;
+        header_kept(bs, t0 + start, t0 + end, start_in, end_in, t0 + valid, lo, hi);
+        li[cls] += (uint32_t)(hi - lo);
+    });
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (la[k]) atomicAdd(&s_a[k], la[k]);
+        if (li[k]) atomicAdd(&s_idc[k], li[k]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        a.tile_c[t] = c;
+        a.tile_a[t] = (u64)s_a[0] | ((u64)s_a[1] << 16) | ((u64)s_a[2] << 32) | ((u64)s_a[3] << 48);
+        a.tile_idc[t] = (u64)s_idc[0] | ((u64)s_idc[1] << 16) | ((u64)s_idc[2] << 32) | ((u64)s_idc[3] << 48);
+    }
+}
+
+// =================================================================================== tile scan
+struct ScanArgs {
+    int64_t tile_begin, tile_end;
+    const uint32_t* tile_c;
+    const u64* tile_a;
+    const u64* tile_idc;
+    int64_t* tileP;
+    int64_t* tileS;
+    int64_t* tileQ;
+    int64_t* tileI;
+    ChunkState* st;
+    int32_t first_pass; // load the carry from P0.. instead of P..
+};
+
+__device__ __forceinline__ int64_t field16(u64 v, int k) { return (int64_t)((v >> (16 * (k & 3))) & 0xFFFFull); }
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tiles(ScanArgs a) {
+    __shared__ int64_t s_w[SCAN_BLOCK / 64];
+    __shared__ int64_t s_last;
+    const int tid = threadIdx.x;
+    int64_t cP, cS, cQ, cI;
+    if (a.first_pass) { cP = a.st->P0; cS = a.st->S0; cQ = a.st->Q0; cI = a.st->I0; }
+    else { cP = a.st->P; cS = a.st->S; cQ = a.st->Q; cI = a.st->I; }
+    if (tid == 0) s_last = a.first_pass ? -1 : a.st->last_nl_tile;
+    __syncthreads();
+    int64_t my_last = -1;
+    for (int64_t base = a.tile_begin; base < a.tile_end; base += SCAN_BLOCK * SCAN_ITEMS) {
+        const int64_t i0 = base + (int64_t)tid * SCAN_ITEMS;
+        int64_t c[SCAN_ITEMS];
+        u64 av[SCAN_ITEMS], iv[SCAN_ITEMS];
+        int64_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            const int64_t i = i0 + k;
+            const bool ok = i < a.tile_end;
+            c[k] = ok ? (int64_t)a.tile_c[i] : 0;
+            av[k] = ok ? a.tile_a[i] : 0ull;
+            iv[k] = ok ? a.tile_idc[i] : 0ull;
+            if (ok && c[k] > 0) my_last = i;
+            sum += c[k];
+        }
+        int64_t tot;
+        int64_t p = cP + block_exclusive_scan<int64_t, SCAN_BLOCK / 64>(sum, s_w, tot);
+        int64_t ps[SCAN_ITEMS], sv[SCAN_ITEMS], qv[SCAN_ITEMS], dv[SCAN_ITEMS];
+        int64_t ss = 0, sq = 0, si = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            ps[k] = p;
+            const int ph = (int)(p & 3);            // role of the tile's first line
+            sv[k] = field16(av[k], 1 - ph);         // class whose role is 1 (sequence)
+            qv[k] = field16(av[k], 3 - ph);         // role 3 (quality)
+            dv[k] = field16(iv[k], 0 - ph);         // role 0 (header) after strip
+            ss += sv[k]; sq += qv[k]; si += dv[k];
+            p += c[k];
+        }
+        cP += tot;
+        int64_t tS, tQ, tI;
+        int64_t eS = cS + block_exclusive_scan<int64_t, SCAN_BLOCK / 64>(ss, s_w, tS);
+        int64_t eQ = cQ + block_exclusive_scan<int64_t, SCAN_BLOCK / 64>(sq, s_w, tQ);
+        int64_t eI = cI + block_exclusive_scan<int64_t, SCAN_BLOCK / 64>(si, s_w, tI);
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            const int64_t i = i0 + k;
+            if (i < a.tile_end) {
+                a.tileP[i] = ps[k]; a.tileS[i] = eS; a.tileQ[i] = eQ; a.tileI[i] = eI;
+            }
+            eS += sv[k]; eQ += qv[k]; eI += dv[k];
+        }
+        cS += tS; cQ += tQ; cI += tI;
+    }
+    if (my_last >= 0) atomicMax((long long*)&s_last, (long long)my_last);
+    __syncthreads();
+    if (tid == 0) {
+        a.st->P = cP; a.st->S = cS; a.st->Q = cQ; a.st->I = cI;
+        a.st->last_nl_tile = s_last;
+    }
+}
+
+// Tail after the last newline: where it starts and whether it is more than blanks
+// (_check_end_qual, blazeseq/utils.mojo:292-329).  One workgroup.
+__global__ __launch_bounds__(BLOCK) void k_tail(const uint8_t* __restrict__ g, int64_t n, ChunkState* st) {
+    __shared__ int s_pos;
+    __shared__ int s_nb;
+    const int tid = threadIdx.x;
+    if (tid == 0) { s_pos = -1; s_nb = 0; }
+    __syncthreads();
+    const int64_t lt = st->last_nl_tile;
+    int64_t tail = 0;
+    if (lt >= 0) {
+        const int64_t t0 = lt * TILE;
+        int best = -1;
+        for (int i = tid; i < TILE; i += BLOCK)
+            if (t0 + i < n && g[t0 + i] == 10) best = i;
+        if (best >= 0) atomicMax(&s_pos, best);
+        __syncthreads();
+        tail = t0 + s_pos + 1;
+    }
+    int nb = 0;
+    for (int64_t p = tail + tid; p < n; p += BLOCK) {
+        const uint32_t c = g[p];
+        if (c != 10u && c != 13u && c != 32u && c != 9u) { nb = 1; break; }
+    }
+    if (nb) atomicOr(&s_nb, 1);
+    __syncthreads();
+    if (tid == 0) { st->tail_start = tail; st->tail_nonblank = s_nb; }
+}
+
+// =================================================================================== pass B
+struct EmitArgs {
+    const uint8_t* g;
+    int64_t n;
+    uint32_t prev_byte;
+    int64_t tile_begin;
+    const int64_t* tileP;
+    const int64_t* tileS;
+    const int64_t* tileQ;
+    const int64_t* tileI;
+    uint8_t* col_seq;
+    uint8_t* col_qual;
+    uint8_t* col_id;
+    int64_t* ends;
+    int64_t* id_ends;
+    int64_t* rec_end;
+    int64_t rec_cap;
+    int64_t* o_hdr;
+    int64_t* o_seq;
+    int64_t* o_sep;
+    int64_t* o_qual;
+    ChunkState* st;
+    uint32_t q_lower, q_upper;
+    int32_t force_dense;
+};
+
+struct ErrAcc {
+    u64 e_struct, e_valid;
+    __device__ __forceinline__ void structure(int64_t rec, int code) {
+        const u64 k = ((u64)rec << 3) | (u64)code;
+        if (rec >= 0 && k < e_struct) e_struct = k;
+    }
+    __device__ __forceinline__ void valid(int64_t rec, int code) {
+        const u64 k = ((u64)rec << 3) | (u64)code;
+        if (rec >= 0 && k < e_valid) e_valid = k;
+    }
+};
+
+__device__ __forceinline__ uint32_t byte_range_mask(int i, int a, int b) {
+    // mask of the bytes of dword i (bytes 4i..4i+3 of a 16-byte piece) that fall in [a, b)
+    int lo = a - 4 * i, hi = b - 4 * i;
+    lo = lo < 0 ? 0 : (lo > 4 ? 4 : lo);
+    hi = hi < 0 ? 0 : (hi > 4 ? 4 : hi);
+    if (hi <= lo) return 0u;
+    const uint32_t mh = (uint32_t)((1ull << (8 * hi)) - 1ull);
+    const uint32_t ml = (uint32_t)((1ull << (8 * lo)) - 1ull);
+    return mh & ~ml;
+}
+
+// ascii: any byte with the high bit (record.mojo:106-116, utils.mojo:245-263)
+__device__ __forceinline__ bool any_non_ascii(uint32_t x) { return (x & 0x80808080u) != 0u; }
+// quality: any byte outside [lower, upper], i.e. (q - lower) > (upper - lower) unsigned (record.mojo:99-102)
+__device__ __forceinline__ bool any_out_of_range(uint32_t x, uint32_t lower, uint32_t upper) {
+    const uint32_t less = (x - 0x01010101u * lower) & ~x & 0x80808080u;            // some byte < lower (lower <= 128)
+    const uint32_t more = ((x + 0x01010101u * (127u - upper)) | x) & 0x80808080u;  // some byte > upper (upper <= 127)
+    return (less | more) != 0u;
+}
+
+// Gather one role's byte stream of this tile into its packed column.
+//   stream coordinate o in [0, n_role): the o-th byte of this role inside the tile;
+//   segment k: bytes [seg_dst[k], seg_dst[k]+seg_len[k]) of the stream come from tile offset seg_src[k].
+// Each lane produces one aligned 16-byte piece of the destination column from <= a few unaligned
+// LDS windows; interior pieces are single coalesced dwordx4 stores, the (at most two) partial edge
+// pieces of the tile's range are stored bytewise because the neighbouring tiles own the rest.
+template <int ROLE, bool CA, bool CQ>
+__device__ __forceinline__ void gather_role(uint8_t* __restrict__ col, int64_t D, int n_role,
+                                            const uint16_t* seg_src, const uint16_t* seg_len,
+                                            const uint16_t* seg_dst, int nk, const uint8_t* s_tile,
+                                            int64_t line0 /* P + j0(role) */, uint32_t qlo, uint32_t qhi,
+                                            ErrAcc& err) {
+    if (n_role <= 0) return;
+    const int tid = threadIdx.x;
+    const int64_t hi_abs = D + n_role;
+    const int64_t pa = D >> 4, pb = (hi_abs - 1) >> 4;
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tile - 16); // dword view incl. the front pad
+    for (int64_t pi = pa + tid; pi <= pb; pi += BLOCK) {
+        const int64_t p0 = pi << 4;
+        if (p0 + 16 <= 0) continue; // bytes of the straddling head record (owned by the previous shard)
+        int xl = (int)(D > p0 ? D - p0 : 0);
+        int xh = (int)(hi_abs - p0 < 16 ? hi_abs - p0 : 16);
+        if (p0 < 0 && xl < (int)(-p0)) xl = (int)(-p0);
+        int o = (int)(p0 - D) + xl;
+        // segment holding stream byte o: last k with seg_dst[k] <= o
+        int lo = 0, hi = nk;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)seg_dst[mid] <= o) lo = mid + 1; else hi = mid;
+        }
+        int k = lo - 1;
+        uint32_t acc[4] = {0u, 0u, 0u, 0u};
+        int x = xl;
+        while (x < xh) {
+            int send = (int)seg_dst[k] + (int)seg_len[k];
+            while (o >= send) { ++k; send = (int)seg_dst[k] + (int)seg_len[k]; }
+            int take = xh - x;
+            if (send - o < take) take = send - o;
+            const int A = (int)seg_src[k] + (o - (int)seg_dst[k]); // tile offset of piece byte x
+            const int ws = A - x + 16;                               // window start incl. front pad (>= 1)
+            const int wd = ws >> 2, sh = ws & 3;
+            const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
+            uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+            uint32_t w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            uint32_t w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            uint32_t w3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+            if (take < 16) {
+                const uint32_t m0 = byte_range_mask(0, x, x + take), m1 = byte_range_mask(1, x, x + take),
+                               m2 = byte_range_mask(2, x, x + take), m3 = byte_range_mask(3, x, x + take);
+                w0 &= m0; w1 &= m1; w2 &= m2; w3 &= m3;
+                if (CA || CQ) {
+                    if (CA && any_non_ascii(w0 | w1 | w2 | w3)) err.valid((line0 + 4 * (int64_t)k) >> 2, 4);
+                    if (CQ && ROLE == 3) {
+                        const uint32_t fill = 0x01010101u * qlo;
+                        if (any_out_of_range(w0 | (fill & ~m0), qlo, qhi) | any_out_of_range(w1 | (fill & ~m1), qlo, qhi) |
+                            any_out_of_range(w2 | (fill & ~m2), qlo, qhi) | any_out_of_range(w3 | (fill & ~m3), qlo, qhi))
+                            err.valid((line0 + 4 * (int64_t)k) >> 2, 5);
+                    }
+                }
+                acc[0] |= w0; acc[1] |= w1; acc[2] |= w2; acc[3] |= w3;
+            } else {
+                if (CA && any_non_ascii(w0 | w1 | w2 | w3)) err.valid((line0 + 4 * (int64_t)k) >> 2, 4);
+                if (CQ && ROLE == 3) {
+                    if (any_out_of_range(w0, qlo, qhi) | any_out_of_range(w1, qlo, qhi) |
+                        any_out_of_range(w2, qlo, qhi) | any_out_of_range(w3, qlo, qhi))
+                        err.valid((line0 + 4 * (int64_t)k) >> 2, 5);
+                }
+                acc[0] = w0; acc[1] = w1; acc[2] = w2; acc[3] = w3;
+            }
+            x += take;
+            o += take;
+        }
+        if (xl == 0 && xh == 16) {
+            *reinterpret_cast<uint4*>(col + p0) = make_uint4(acc[0], acc[1], acc[2], acc[3]);
+        } else {
+            for (int i = xl; i < xh; ++i) col[p0 + i] = (uint8_t)(acc[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+}
+
+template <bool CA, bool CQ, bool OFFS>
+__global__ __launch_bounds__(BLOCK) void k_tile_emit(EmitArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
+    __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
+    __shared__ uint16_t s_src[3][SEGS], s_len[3][SEGS], s_dst[3][SEGS];
+    __shared__ u64 s_w64[4];
+    __shared__ uint32_t s_w[4];
+    uint8_t* s_tile = s_tile_raw + 16;
+    const int tid = threadIdx.x;
+    const int64_t t = a.tile_begin + blockIdx.x;
+    const int64_t t0 = t * TILE;
+    const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+    tile_load<true>(a.g, a.n, t0, valid, s_mask, s_tile);
+    // role slot in the segment tables: 0 header, 1 sequence, 2 quality
+    s_len[0][tid] = 0; s_len[1][tid] = 0; s_len[2][tid] = 0;
+    s_src[0][tid] = 0; s_src[1][tid] = 0; s_src[2][tid] = 0;
+    __syncthreads();
+    const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);
+    const u64 m64 = s_mask64[tid];
+    uint32_t c = 0;
+    const uint32_t excl = block_exclusive_scan<uint32_t, 4>((uint32_t)__popcll(m64), s_w, c);
+    const int64_t P = a.tileP[t];
+    const int64_t S = a.tileS[t], Q = a.tileQ[t], I = a.tileI[t];
+    ByteSrc bs{a.g, a.n, a.prev_byte};
+    const bool first_starts = (bs.at(t0 - 1) == 10u);
+    ErrAcc err{~0ull, ~0ull};
+    bool overflow = false;
+
+    if ((int)c > MAXL || a.force_dense) {
+        // ---------------------------------------------------------------- serial path (any input)
+        if (tid == 0) {
+            int64_t rs = S, rq = Q, ri = I;
+            int j = 0, line_start = 0;
+            bool start_in = first_starts;
+            auto handle = [&](int start, int end, bool end_in) {
+                const int64_t L = P + j;
+                const int role = (int)(L & 3);
+                const int64_t rec = L >> 2;
+                const int64_t ls = t0 + start, le = t0 + end;
+                const bool sin = start_in && start < valid;
+                if (role == 0) {
+                    if (sin) {
+                        if (s_tile[start] != 64) err.structure(rec, 1);
+                        if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_hdr[rec] = ls;
+                    }
+                    int64_t lo = ls, hi = ls;
+                    if (end > start) header_kept(bs, ls, le, start_in, end_in, t0 + valid, lo, hi);
+                    for (int64_t p = lo; p < hi; ++p) {
+                        const uint8_t ch = s_tile[p - t0];
+                        if (CA && (ch & 0x80)) err.valid(rec, 4);
+                        if (ri >= 0) a.col_id[ri] = ch;
+                        ++ri;
+                    }
+                    if (end_in && rec >= 0) { if (rec < a.rec_cap) a.id_ends[rec] = ri; else overflow = true; }
+                } else if (role == 1) {
+                    if (sin && OFFS && rec >= 0 && rec < a.rec_cap) a.o_seq[rec] = ls;
+                    for (int p = start; p < end; ++p) {
+                        const uint8_t ch = s_tile[p];
+                        if (CA && (ch & 0x80)) err.valid(rec, 4);
+                        if (rs >= 0) a.col_seq[rs] = ch;
+                        ++rs;
+                    }
+                } else if (role == 2) {
+                    if (sin) {
+                        if (s_tile[start] != 43) err.structure(rec, 2);
+                        if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_sep[rec] = ls;
+                    }
+                } else {
+                    if (sin && OFFS && rec >= 0 && rec < a.rec_cap) a.o_qual[rec] = ls;
+                    for (int p = start; p < end; ++p) {
+                        const uint8_t ch = s_tile[p];
+                        if (CA && (ch & 0x80)) err.valid(rec, 4);
+                        if (CQ && (uint32_t)((ch - a.q_lower) & 0xFFu) > (a.q_upper - a.q_lower)) err.valid(rec, 5);
+                        if (rq >= 0) a.col_qual[rq] = ch;
+                        ++rq;
+                    }
+                    if (end_in && rec >= 0) {
+                        if (rec < a.rec_cap) { a.ends[rec] = rq; a.rec_end[rec] = le; } else overflow = true;
+                        if (rs != rq) err.structure(rec, 3);
+                    }
+                }
+            };
+            for (int w = 0; w < BLOCK; ++w) {
+                u64 m = s_mask64[w];
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int nl = w * 64 + bit;
+                    handle(line_start, nl, true);
+                    line_start = nl + 1;
+                    start_in = true;
+                    ++j;
+                }
+            }
+            handle(line_start, valid, false);
+            atomicAdd((u64*)&a.st->dense_tiles, 1ull);
+        }
+    } else {
+        // ---------------------------------------------------------------- fast path
+        // pass 1 over owned lines: segment tables + line-start checks
+        for_each_owned_line(s_mask64, m64, (int)excl, (int)c, valid, [&](int j, int start, int end, bool end_in) {
+            const int64_t L = P + j;
+            const int role = (int)(L & 3);
+            const int64_t rec = L >> 2;
+            const int k = j >> 2;
+            const bool sin = (j > 0 ? true : first_starts) && start < valid;
+            const int64_t ls = t0 + start;
+            if (role == 0) {
+                if (sin) {
+                    if (s_tile[start] != 64) err.structure(rec, 1);   // '@', utils.mojo:454
+                    if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_hdr[rec] = ls;
+                }
+                int64_t lo = ls, hi = ls;
+                if (end > start) header_kept(bs, ls, t0 + end, j > 0 ? true : first_starts, end_in, t0 + valid, lo, hi);
+                s_src[0][k] = (uint16_t)(lo - t0);
+                s_len[0][k] = (uint16_t)(hi - lo);
+            } else if (role == 1) {
+                if (sin && OFFS && rec >= 0 && rec < a.rec_cap) a.o_seq[rec] = ls;
+                s_src[1][k] = (uint16_t)start;
+                s_len[1][k] = (uint16_t)(end - start);
+            } else if (role == 2) {
+                if (sin) {
+                    if (s_tile[start] != 43) err.structure(rec, 2);   // '+', utils.mojo:456
+                    if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_sep[rec] = ls;
+                }
+            } else {
+                if (sin && OFFS && rec >= 0 && rec < a.rec_cap) a.o_qual[rec] = ls;
+                s_src[2][k] = (uint16_t)start;
+                s_len[2][k] = (uint16_t)(end - start);
+            }
+        });
+        __syncthreads();
+        // exclusive scan of the three segment-length tables at once (21-bit fields)
+        const u64 packed = (u64)s_len[0][tid] | ((u64)s_len[1][tid] << 21) | ((u64)s_len[2][tid] << 42);
+        u64 tot = 0;
+        const u64 ex = block_exclusive_scan<u64, 4>(packed, s_w64, tot);
+        s_dst[0][tid] = (uint16_t)(ex & 0x1FFFFFull);
+        s_dst[1][tid] = (uint16_t)((ex >> 21) & 0x1FFFFFull);
+        s_dst[2][tid] = (uint16_t)((ex >> 42) & 0x1FFFFFull);
+        const int n_id = (int)(tot & 0x1FFFFFull), n_seq = (int)((tot >> 21) & 0x1FFFFFull),
+                  n_qual = (int)((tot >> 42) & 0x1FFFFFull);
+        __syncthreads();
+        // pass 2 over owned lines that END here: per-record outputs
+        {
+            u64 m = m64;
+            int idx = 0;
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int j = (int)excl + idx;
+                ++idx;
+                const int64_t L = P + j;
+                const int role = (int)(L & 3);
+                const int64_t rec = L >> 2;
+                if (rec < 0) continue;
+                const int k = j >> 2;
+                if (role == 0) {
+                    if (rec < a.rec_cap) a.id_ends[rec] = I + (int64_t)s_dst[0][k] + (int64_t)s_len[0][k];
+                    else overflow = true;
+                } else if (role == 3) {
+                    const int64_t qe = Q + (int64_t)s_dst[2][k] + (int64_t)s_len[2][k];
+                    // sequence bytes seen so far = column offset after this record's sequence line (line j-2)
+                    int64_t se = S;
+                    if (j >= 2) { const int k1 = (j - 2) >> 2; se = S + (int64_t)s_dst[1][k1] + (int64_t)s_len[1][k1]; }
+                    if (rec < a.rec_cap) { a.ends[rec] = qe; a.rec_end[rec] = t0 + tid * 64 + bit; }
+                    else overflow = true;
+                    // seq_len != qual_len for some record <= rec  <=>  cumulative sums differ (utils.mojo:458-461)
+                    if (se != qe) err.structure(rec, 3);
+                }
+            }
+        }
+        // gather the three streams
+        const int jh = (int)((0 - P) & 3), js = (int)((1 - P) & 3), jq = (int)((3 - P) & 3);
+        const int nl_lines = (int)c + 1;
+        const int nk_h = jh < nl_lines ? ((nl_lines - 1 - jh) >> 2) + 1 : 0;
+        const int nk_s = js < nl_lines ? ((nl_lines - 1 - js) >> 2) + 1 : 0;
+        const int nk_q = jq < nl_lines ? ((nl_lines - 1 - jq) >> 2) + 1 : 0;
+        gather_role<1, CA, CQ>(a.col_seq, S, n_seq, s_src[1], s_len[1], s_dst[1], nk_s, s_tile, P + js, a.q_lower, a.q_upper, err);
+        gather_role<3, CA, CQ>(a.col_qual, Q, n_qual, s_src[2], s_len[2], s_dst[2], nk_q, s_tile, P + jq, a.q_lower, a.q_upper, err);
+        gather_role<0, CA, CQ>(a.col_id, I, n_id, s_src[0], s_len[0], s_dst[0], nk_h, s_tile, P + jh, a.q_lower, a.q_upper, err);
+    }
+    if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
+    if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
+    if (overflow) atomicOr(&a.st->rec_overflow, 1);
+}
+
+// =================================================================================== per record
+struct RebaseArgs {
+    int64_t n_rec;
+    const int64_t* ends;
+    const int64_t* id_ends;
+    const int64_t* rec_end;
+    int64_t* b_ends;
+    int64_t* b_id_ends;
+    int64_t batch;
+    int64_t first_header;  // offset of record 0's header
+    int64_t len_limit;     // records longer than this are refused by the reference's buffer
+    ChunkState* st;
+};
+
+// FastqBatch._ends / _id_ends restart at every batch (record_batch.mojo:77-87 via parser.mojo:243):
+// b_ends[r] = ends[r] - ends[first record of r's batch - 1].  Also finds the first record the
+// reference could not hold in its buffer (parser.mojo:484-492).
+__global__ __launch_bounds__(BLOCK) void k_rebase(RebaseArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= a.n_rec) return;
+    const int64_t b0 = (r / a.batch) * a.batch;
+    const int64_t e0 = b0 ? a.ends[b0 - 1] : 0, i0 = b0 ? a.id_ends[b0 - 1] : 0;
+    a.b_ends[r] = a.ends[r] - e0;
+    a.b_id_ends[r] = a.id_ends[r] - i0;
+    const int64_t prev = r ? a.rec_end[r - 1] : a.first_header - 1;
+    const int64_t len = a.rec_end[r] - prev; // header_start .. '\n' inclusive
+    if (len > a.len_limit) atomicMin(&a.st->err_buf, (u64)r << 3);
+}
+
+// Rebased ends for an arbitrary record range (a next_batch call that is not batch aligned).
+__global__ __launch_bounds__(BLOCK) void k_rebase_range(const int64_t* ends, const int64_t* id_ends, int64_t first,
+                                                        int64_t count, int64_t* out_e, int64_t* out_i) {
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= count) return;
+    const int64_t e0 = first ? ends[first - 1] : 0, i0 = first ? id_ends[first - 1] : 0;
+    out_e[r] = ends[first + r] - e0;
+    out_i[r] = id_ends[first + r] - i0;
+}
+
+// Host-SIMD-width emulation of the reference's quality check (record.mojo:90-97): inside the first
+// floor(n/W)*W quality bytes a byte equal to UPPER is rejected too.  Optional (compat_simd_width).
+__global__ __launch_bounds__(BLOCK) void k_compat_quality(const uint8_t* __restrict__ g, int64_t n_rec,
+                                                          const int64_t* ends, const int64_t* rec_end,
+                                                          int W, uint32_t upper, ChunkState* st) {
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n_rec) return;
+    const int64_t qlen = ends[r] - (r ? ends[r - 1] : 0);
+    const int64_t qs = rec_end[r] - qlen;
+    const int64_t body = (qlen / W) * W;
+    for (int64_t i = 0; i < body; ++i)
+        if (g[qs + i] == upper) { atomicMin(&st->err_valid, ((u64)r << 3) | 5ull); break; }
+}
+
+// Writes the per-record outputs of a last record that has no trailing newline (parser.mojo:464-475,
+// utils.mojo:327-329): the columns already hold its bytes.
+__global__ void k_fix_last(int64_t rec, int64_t n, int64_t batch, int64_t* ends, int64_t* id_ends,
+                           int64_t* rec_end, int64_t* b_ends, int64_t* b_id_ends, const ChunkState* st) {
+    if (threadIdx.x || blockIdx.x) return;
+    ends[rec] = st->Q; id_ends[rec] = st->I; rec_end[rec] = n;
+    const int64_t b0 = (rec / batch) * batch;
+    b_ends[rec] = st->Q - (b0 ? ends[b0 - 1] : 0);
+    b_id_ends[rec] = st->I - (b0 ? id_ends[b0 - 1] : 0);
+}
+
+// =================================================================================== shard stitch
+// Offsets of the first four newlines of a shard (one workgroup; a record is a few hundred bytes to
+// a few tens of kB, so this touches a handful of 4 KiB steps).
+__global__ __launch_bounds__(BLOCK) void k_first_newlines(const uint8_t* __restrict__ g, int64_t n, ChunkState* st) {
+    __shared__ uint32_t s_w[4];
+    __shared__ int s_found;
+    const int tid = threadIdx.x;
+    if (tid < 4) st->first_nl[tid] = -1;
+    if (tid == 0) s_found = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += BLOCK * 16) {
+        const int64_t pos = base + (int64_t)tid * 16;
+        uint32_t m = 0;
+        if (pos < n) {
+            m = nl_mask16(load16(g, pos, n));
+            const int64_t rem = n - pos;
+            if (rem < 16) m &= (1u << rem) - 1u;
+        }
+        uint32_t tot = 0;
+        const uint32_t ex = block_exclusive_scan<uint32_t, 4>((uint32_t)__popc(m), s_w, tot);
+        const int have = s_found;
+        uint32_t mm = m;
+        int idx = 0;
+        while (mm) {
+            const int bit = __builtin_ctz(mm);
+            mm &= mm - 1;
+            const int rank = have + (int)ex + idx;
+            if (rank < 4) st->first_nl[rank] = pos + bit;
+            ++idx;
+        }
+        __syncthreads();
+        if (tid == 0) s_found = have + (int)tot;
+        __syncthreads();
+        if (s_found >= 4) break;
+    }
+}
+
+// Column offsets that make the first OWNED record of a shard start at 0: the head lines (the
+// straddling record's remainder, owned by the previous shard) get negative offsets.
+__global__ void k_head(const uint8_t* __restrict__ g, int64_t n, uint32_t prev_byte, int head_lines, ChunkState* st) {
+    if (threadIdx.x || blockIdx.x) return;
+    ByteSrc bs{g, n, prev_byte};
+    int64_t s0 = 0, q0 = 0, i0 = 0;
+    int64_t start = 0;
+    const int64_t P0 = st->P0;
+    for (int j = 0; j < head_lines; ++j) {
+        const int64_t end = st->first_nl[j];
+        if (end < 0) break;
+        const int role = (int)((P0 + j) & 3);
+        if (role == 1) s0 -= end - start;
+        else if (role == 3) q0 -= end - start;
+        else if (role == 0 && end > start) {
+            int64_t lo, hi;
+            header_kept(bs, start, end, j > 0 ? true : (prev_byte == 10u), true, end, lo, hi);
+            i0 -= hi - lo;
+        }
+        start = end + 1;
+    }
+    st->S0 = s0; st->Q0 = q0; st->I0 = i0;
+}
+
+// =================================================================================== generator
+// generate_synthetic_fastq_buffer for fixed-length reads (blazeseq/utils.mojo:736-917): record i
+// depends only on i, one thread per record.
+struct GenArgs {
+    uint8_t* out;
+    int64_t first, count, num_reads;
+    int32_t read_len, num_digits, min_phred, max_phred;
+    uint32_t q_offset, q_lower, q_upper;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_generate(GenArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (idx >= a.count) return;
+    const int64_t i = a.first + idx;
+    const int64_t rec_bytes = 6 + a.num_digits + 1 + 2 * ((int64_t)a.read_len + 1) + 2;
+    uint8_t* o = a.out + idx * rec_bytes;
+    const uint8_t lut[8] = {'G', 'C', 'G', 'C', 'A', 'T', 'A', 'T'}; // gc_bias = 0.5, utils.mojo:707-733
+    *o++ = '@'; *o++ = 'r'; *o++ = 'e'; *o++ = 'a'; *o++ = 'd'; *o++ = '_';
+    {
+        int64_t v = i;
+        for (int d = a.num_digits - 1; d >= 0; --d) { o[d] = (uint8_t)('0' + (int)(v % 10)); v /= 10; }
+        o += a.num_digits;
+    }
+    *o++ = '\n';
+    const u64 MASK = 0x7FFFFFFFFFFFFFFFull;
+    u64 st = ((u64)i * 6364136223846793005ull + 1442695040888963407ull) & MASK;
+    for (int b = 0; b < a.read_len; ++b) {
+        st = (st * 6364136223846793005ull + 1442695040888963407ull) & MASK;
+        *o++ = lut[(st >> 33) & 7];
+    }
+    *o++ = '\n'; *o++ = '+'; *o++ = '\n';
+    const int64_t q_start = a.max_phred, q_range = a.max_phred - a.min_phred, noise_amp = q_range / 6 + 1;
+    u64 qr = ((u64)i * 2654435761ull + 1013904223ull) & MASK;
+    const int64_t lm1 = a.read_len - 1;
+    for (int64_t p = 0; p < a.read_len; ++p) {
+        const int64_t mean = lm1 == 0 ? q_start : q_start - (q_range * p + lm1 / 2) / lm1;
+        qr = (qr * 1664525ull + 1013904223ull) & MASK;
+        const int64_t noise = (int64_t)((qr >> 17) % (u64)(2 * noise_amp + 1));
+        int64_t ph = mean + noise - noise_amp;
+        ph = ph < a.min_phred ? a.min_phred : (ph > a.max_phred ? a.max_phred : ph);
+        int64_t c = (int64_t)a.q_offset + ph;
+        c = c < (int64_t)a.q_lower ? (int64_t)a.q_lower : (c > (int64_t)a.q_upper ? (int64_t)a.q_upper : c);
+        *o++ = (uint8_t)c;
+    }
+    *o++ = '\n';
+}
+
+} // namespace bzq

@@ -1,0 +1,501 @@
+"""Host-side mirror of the reference's FASTQ parser API over the C ABI.
+
+Same names, argument meaning and error behaviour as the reference (paths relative to the BlazeSeq
+tree):
+
+* ``ParserConfig``       blazeseq/fastq/parser.mojo:33-74
+* ``FastqParser``        blazeseq/fastq/parser.mojo:77-274 (ctors 89-145, has_more 155, next_batch 239,
+                         views/records/batches 253-274, iterators 628-735)
+* ``FastqBatch``         blazeseq/fastq/record_batch.mojo:19-207
+* ``DeviceFastqBatch``   blazeseq/fastq/record_batch.mojo:210-244
+
+The difference is where the work happens: a chunk of the input is parsed, validated and packed into
+the FastqBatch columns on the GPU in one go, and ``batches()`` hands out zero-copy slices of those
+columns; ``FastqBatch.to_device()`` therefore costs nothing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import io
+import os
+from dataclasses import dataclass
+from typing import Iterator, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+DEFAULT_CAPACITY = 256 * 1024      # blazeseq/CONSTS.mojo:26
+MAX_CAPACITY = 1 << 30             # blazeseq/CONSTS.mojo:28
+DEFAULT_BATCH_SIZE = 4096          # blazeseq/CONSTS.mojo:31
+DEFAULT_CHUNK_BYTES = 256 << 20
+
+
+class ParseError(Exception):
+    """The reference raises ``Error(String)``; ``code`` is the FastxErrorCode behind it
+    (blazeseq/errors.mojo:33-68) and ``message`` the exact text as bytes."""
+
+    def __init__(self, code: int, message: bytes):
+        super().__init__(message.decode("latin-1"))
+        self.code = code
+        self.message = message
+
+
+class EOFError_(ParseError):
+    pass
+
+
+def quality_schema(name: str) -> Tuple[int, int, int, bool]:
+    """_parse_schema, blazeseq/utils.mojo:612-637 -> (LOWER, UPPER, OFFSET, known)."""
+    lo, up, off = C.c_uint8(), C.c_uint8(), C.c_uint8()
+    known = L.lib().bzq_schema_from_name(name.encode(), C.byref(lo), C.byref(up), C.byref(off))
+    if not known:
+        print("Unknown quality schema please choose one of 'sanger', 'solexa', 'illumina_1.3', 'illumina_1.5' "
+              "'illumina_1.8', or 'generic'.\nParsing with generic schema.")
+    return lo.value, up.value, off.value, bool(known)
+
+
+@dataclass
+class ParserConfig:
+    """blazeseq/fastq/parser.mojo:33-74 (same fields, same defaults) plus two GPU-side switches."""
+    buffer_capacity: int = DEFAULT_CAPACITY
+    buffer_max_capacity: int = MAX_CAPACITY
+    buffer_growth_enabled: bool = False
+    check_ascii: bool = False
+    check_quality: bool = False
+    quality_schema: Optional[str] = None
+    compat_simd_width: int = 0     # reproduce the host-SIMD-width quirk of the quality check
+    emit_offsets: bool = False     # also materialise the RecordOffsets columns
+
+
+def _check(ctx_handle, rc: int, what: str):
+    if rc < 0:
+        msg = L.lib().bzq_last_error(ctx_handle)
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def _as_u8(data) -> np.ndarray:
+    if isinstance(data, np.ndarray):
+        return np.ascontiguousarray(data, dtype=np.uint8).reshape(-1)
+    if isinstance(data, str):
+        data = data.encode("latin-1")
+    return np.frombuffer(bytes(data), dtype=np.uint8)
+
+
+class ChunkResult:
+    """bzq_chunk plus helpers that copy device columns to numpy (tests, CPU consumers)."""
+
+    def __init__(self, ctx: "Context", raw: L.BzqChunk):
+        self.ctx = ctx
+        self.raw = raw
+        for name, _ in L.BzqChunk._fields_:
+            setattr(self, name, getattr(raw, name))
+
+    def _i64(self, ptr, count) -> np.ndarray:
+        out = np.empty(int(count), dtype=np.int64)
+        if count:
+            self.ctx.copy_to_host(out, ptr, int(count) * 8)
+        return out
+
+    def _u8(self, ptr, count) -> np.ndarray:
+        out = np.empty(int(count), dtype=np.uint8)
+        if count:
+            self.ctx.copy_to_host(out, ptr, int(count))
+        return out
+
+    def ends(self): return self._i64(self.d_ends, self.n_records)
+    def id_ends(self): return self._i64(self.d_id_ends, self.n_records)
+    def batch_ends(self): return self._i64(self.d_batch_ends, self.n_records)
+    def batch_id_ends(self): return self._i64(self.d_batch_id_ends, self.n_records)
+    def record_end(self): return self._i64(self.d_record_end, self.n_records)
+    def header_start(self): return self._i64(self.d_header_start, self.n_records)
+    def seq_start(self): return self._i64(self.d_seq_start, self.n_records)
+    def sep_start(self): return self._i64(self.d_sep_start, self.n_records)
+    def qual_start(self): return self._i64(self.d_qual_start, self.n_records)
+    def seq(self): return self._u8(self.d_seq, self.seq_bytes)
+    def qual(self): return self._u8(self.d_qual, self.qual_bytes)
+    def id(self): return self._u8(self.d_id, self.id_bytes)
+
+
+class Context:
+    """One bzq_ctx (= one FastqParser's device side).  Not thread safe, like the reference parser."""
+
+    def __init__(self, config: Optional[ParserConfig] = None, schema: str = "generic",
+                 batch_size: int = DEFAULT_BATCH_SIZE, device: int = 0, pass_bytes: int = 0,
+                 min_record_bytes: int = 32):
+        lib = L.lib()
+        self.config = config if config is not None else ParserConfig()
+        c = L.BzqConfig()
+        lib.bzq_config_default(C.byref(c))
+        c.buffer_capacity = self.config.buffer_capacity
+        c.buffer_max_capacity = self.config.buffer_max_capacity
+        c.buffer_growth_enabled = int(self.config.buffer_growth_enabled)
+        c.check_ascii = int(self.config.check_ascii)
+        c.check_quality = int(self.config.check_quality)
+        # config.quality_schema overrides the ctor's schema argument (parser.mojo:134-139)
+        name = self.config.quality_schema if self.config.quality_schema else schema
+        c.q_lower, c.q_upper, c.q_offset, _ = quality_schema(name)
+        c.batch_size = batch_size
+        c.compat_simd_width = self.config.compat_simd_width
+        c.emit_offsets = int(self.config.emit_offsets)
+        c.pass_bytes = pass_bytes
+        c.min_record_bytes = min_record_bytes
+        self.raw_config = c
+        self.batch_size = batch_size
+        self.quality_offset_schema = c.q_offset
+        h = C.c_void_p()
+        rc = lib.bzq_create(device, C.byref(c), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"bzq_create failed ({rc}): {lib.bzq_last_error(None).decode()}")
+        self.h = h
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib().bzq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key: str, value: int):
+        _check(self.h, L.lib().bzq_set_option(self.h, key.encode(), int(value)), "bzq_set_option")
+
+    def set_stream(self, hip_stream: int):
+        _check(self.h, L.lib().bzq_set_stream(self.h, C.c_void_p(hip_stream)), "bzq_set_stream")
+
+    def submit_host(self, data, stream_pos: int = 0, is_eof: bool = True):
+        arr = _as_u8(data)
+        self._keep = arr
+        _check(self.h, L.lib().bzq_submit_chunk_host(self.h, arr.ctypes.data if arr.size else None, arr.size,
+                                                    stream_pos, int(is_eof)), "bzq_submit_chunk_host")
+
+    def submit_device(self, d_ptr: int, n: int, stream_pos: int = 0, is_eof: bool = True):
+        _check(self.h, L.lib().bzq_submit_chunk_device(self.h, C.c_void_p(d_ptr), n, stream_pos, int(is_eof)),
+               "bzq_submit_chunk_device")
+
+    def result(self) -> ChunkResult:
+        raw = L.BzqChunk()
+        rc = L.lib().bzq_chunk_result(self.h, C.byref(raw))
+        _check(self.h, rc, "bzq_chunk_result")
+        return ChunkResult(self, raw)
+
+    def parse(self, data, stream_pos: int = 0, is_eof: bool = True) -> ChunkResult:
+        self.submit_host(data, stream_pos, is_eof)
+        return self.result()
+
+    def format_error(self, records_before: int = 0) -> bytes:
+        buf = C.create_string_buffer(4096)
+        n = L.lib().bzq_format_error(self.h, records_before, buf, 4096)
+        return buf.raw[:max(0, min(n, 4095))]
+
+    def copy_to_host(self, out: np.ndarray, d_ptr, nbytes: int):
+        _check(self.h, L.lib().bzq_copy_to_host(self.h, out.ctypes.data, C.c_void_p(d_ptr), nbytes), "bzq_copy_to_host")
+
+    def batch_view(self, first_record: int, max_records: int) -> L.BzqDeviceBatch:
+        b = L.BzqDeviceBatch()
+        _check(self.h, L.lib().bzq_batch_view(self.h, first_record, max_records, C.byref(b)), "bzq_batch_view")
+        return b
+
+    def generate_synthetic_device(self, num_reads: int, read_len: int, min_phred: int, max_phred: int,
+                                  schema: str, d_out: int = 0, cap: int = 0, first: int = 0,
+                                  count: Optional[int] = None) -> int:
+        if count is None:
+            count = num_reads - first
+        nb = C.c_uint64()
+        _check(self.h, L.lib().bzq_generate_synthetic_device(self.h, num_reads, first, count, read_len, min_phred,
+                                                            max_phred, schema.encode(),
+                                                            C.c_void_p(d_out) if d_out else None, cap, C.byref(nb)),
+               "bzq_generate_synthetic_device")
+        return nb.value
+
+    def shard_scan(self, d_ptr: int, n: int) -> L.BzqShardSummary:
+        s = L.BzqShardSummary()
+        _check(self.h, L.lib().bzq_shard_scan(self.h, C.c_void_p(d_ptr), n, C.byref(s)), "bzq_shard_scan")
+        return s
+
+    def submit_shard(self, d_ptr: int, n: int, halo_bytes: int, lines_before: int, prev_last_byte: int,
+                     stream_pos: int, is_last: bool):
+        _check(self.h, L.lib().bzq_submit_shard(self.h, C.c_void_p(d_ptr), n, halo_bytes, lines_before,
+                                               prev_last_byte, stream_pos, int(is_last)), "bzq_submit_shard")
+
+
+@dataclass
+class FastqRecord:
+    """Owned record (blazeseq/fastq/record.mojo:230-428), plumbing only."""
+    id: bytes
+    sequence: bytes
+    quality: bytes
+    phred_offset: int = 33
+
+    def __len__(self):
+        return len(self.sequence)
+
+
+class DeviceFastqBatch:
+    """blazeseq/fastq/record_batch.mojo:210-220: five device buffers + four scalars.  The buffers are
+    device pointers (ints) into the parser's chunk columns."""
+
+    def __init__(self, ctx: Context, raw: L.BzqDeviceBatch):
+        self._ctx = ctx
+        self.raw = raw
+        self.num_records = raw.num_records
+        self.seq_len = raw.seq_len
+        self.quality_offset = raw.quality_offset
+        self.total_id_bytes = raw.total_id_bytes
+        self.qual_buffer = raw.qual_buffer
+        self.sequence_buffer = raw.sequence_buffer
+        self.ends = raw.ends
+        self.id_buffer = raw.id_buffer
+        self.id_ends = raw.id_ends
+
+    def copy_to_host(self) -> "FastqBatch":
+        """record_batch.mojo:222-244"""
+        return FastqBatch(self._ctx, self.raw)
+
+    def to_records(self) -> List[FastqRecord]:
+        return self.copy_to_host().to_records()
+
+
+class FastqBatch:
+    """blazeseq/fastq/record_batch.mojo:19-207.  Created by the parser from a device batch; the host
+    copies of the five columns (``_id_bytes, _quality_bytes, _sequence_bytes, _id_ends, _ends``) are
+    fetched on first use."""
+
+    def __init__(self, ctx: Context, raw: L.BzqDeviceBatch):
+        self._ctx = ctx
+        self._raw = raw
+        self._host = None
+        self._quality_offset = raw.quality_offset
+
+    def _fetch(self):
+        if self._host is None:
+            r = self._raw
+            n = int(r.num_records)
+            q = np.empty(int(r.seq_len), dtype=np.uint8)
+            s = np.empty(int(r.seq_len), dtype=np.uint8)
+            i = np.empty(int(r.total_id_bytes), dtype=np.uint8)
+            e = np.empty(n, dtype=np.int64)
+            ie = np.empty(n, dtype=np.int64)
+            hb = L.BzqHostBatch()
+            hb.quality_bytes = q.ctypes.data; hb.sequence_bytes = s.ctypes.data; hb.id_bytes = i.ctypes.data
+            hb.ends = e.ctypes.data; hb.id_ends = ie.ctypes.data
+            _check(self._ctx.h, L.lib().bzq_batch_to_host(self._ctx.h, C.byref(r), C.byref(hb)), "bzq_batch_to_host")
+            self._host = (i, q, s, ie, e)
+        return self._host
+
+    @property
+    def _id_bytes(self): return self._fetch()[0]
+    @property
+    def _quality_bytes(self): return self._fetch()[1]
+    @property
+    def _sequence_bytes(self): return self._fetch()[2]
+    @property
+    def _id_ends(self): return self._fetch()[3]
+    @property
+    def _ends(self): return self._fetch()[4]
+
+    def num_records(self) -> int: return int(self._raw.num_records)
+    def seq_len(self) -> int: return int(self._raw.seq_len)
+    def quality_offset(self) -> int: return self._quality_offset
+    def __len__(self): return self.num_records()
+    def __repr__(self): return f"FastqBatch(records={self.num_records()}, quality_offset={self._quality_offset})"
+
+    def to_device(self, ctx=None) -> DeviceFastqBatch:
+        """record_batch.mojo:89-90.  The columns already live on the device: zero copy."""
+        return DeviceFastqBatch(self._ctx, self._raw)
+
+    def get_record(self, index: int) -> FastqRecord:
+        """record_batch.mojo:116-150"""
+        n = self.num_records()
+        if index < 0 or index >= n:
+            raise IndexError("FastqBatch.get_record index out of range")
+        i, q, s, ie, e = self._fetch()
+        i0 = 0 if index == 0 else int(ie[index - 1])
+        s0 = 0 if index == 0 else int(e[index - 1])
+        return FastqRecord(i[i0:int(ie[index])].tobytes(), s[s0:int(e[index])].tobytes(),
+                           q[s0:int(e[index])].tobytes(), self._quality_offset)
+
+    get_ref = get_record
+
+    def to_records(self) -> List[FastqRecord]:
+        return [self.get_record(k) for k in range(self.num_records())]
+
+
+class _Source:
+    """Reader.read_to_buffer semantics (blazeseq/io/readers.mojo:51-79): returns up to n bytes, b"" at EOF."""
+
+    def __init__(self, src):
+        self._mv = None
+        self._f = None
+        self._pos = 0
+        if isinstance(src, (bytes, bytearray, memoryview, np.ndarray, str)) and not (isinstance(src, str) and os.path.exists(src)):
+            self._mv = _as_u8(src)
+        elif isinstance(src, (str, os.PathLike)):
+            self._f = open(src, "rb", buffering=0)
+        elif hasattr(src, "read"):
+            self._f = src
+        else:
+            raise TypeError("FastqParser source must be bytes, a numpy array, a path or a binary file object")
+
+    def read(self, n: int) -> np.ndarray:
+        if self._mv is not None:
+            out = self._mv[self._pos:self._pos + n]
+            self._pos += out.size
+            return out
+        b = self._f.read(n)
+        return np.frombuffer(b if b else b"", dtype=np.uint8)
+
+
+class FastqParser:
+    """blazeseq/fastq/parser.mojo:77-274 over GPU chunks.
+
+    ``FastqParser(source, schema="generic", batch_size=4096, config=ParserConfig())`` -- the three
+    reference constructors collapse into keyword arguments; ``config.quality_schema`` overrides
+    ``schema`` (parser.mojo:134-139).  ``source``: bytes / numpy uint8 / path / binary file object.
+    """
+
+    def __init__(self, source, schema: str = "generic", batch_size: int = DEFAULT_BATCH_SIZE,
+                 config: Optional[ParserConfig] = None, device: int = 0, chunk_bytes: int = DEFAULT_CHUNK_BYTES,
+                 pass_bytes: int = 0):
+        self.config = config if config is not None else ParserConfig()
+        self._batch_size = batch_size
+        self._ctx = Context(self.config, schema, batch_size, device, pass_bytes=pass_bytes)
+        self._src = _Source(source)
+        self._chunk_bytes = max(int(chunk_bytes), 1 << 16)
+        self._carry = np.zeros(0, dtype=np.uint8)
+        self._stream_pos = 0          # stream offset of the current chunk's first byte
+        self._records_before = 0      # records delivered by earlier chunks
+        self._src_eof = False
+        self._chunk: Optional[ChunkResult] = None
+        self._chunk_data: Optional[np.ndarray] = None
+        self._next = 0                # next record of the current chunk to hand out
+        self._terminal: Optional[Tuple[int, bytes]] = None  # (code, message) once the stream has ended
+        self._eof_seen = False
+
+    # ------------------------------------------------------------------ chunk pipeline
+    def _load_chunk(self, min_records: int):
+        """Read + parse the next chunk (carry first).  Grows the chunk until it holds at least
+        ``min_records`` complete records or the stream ends."""
+        want = max(self._chunk_bytes, self._carry.size + (1 << 16))
+        data = self._carry
+        while True:
+            parts = [data]
+            have = data.size
+            while have < want and not self._src_eof:
+                blk = self._src.read(want - have)
+                if blk.size == 0:
+                    self._src_eof = True
+                    break
+                parts.append(blk)
+                have += blk.size
+            if len(parts) > 1:
+                data = np.concatenate(parts)
+            self._ctx.submit_host(data, self._stream_pos, self._src_eof)
+            res = self._ctx.result()
+            if res.status == L.OK and int(res.n_records) < min_records:
+                want = max(want * 2, data.size * 2)   # not the end of the stream: read further
+                continue
+            break
+        self._carry = np.zeros(0, dtype=np.uint8)
+        self._chunk, self._chunk_data, self._next = res, data, 0
+        if res.status != L.OK:
+            self._terminal = (int(res.status), self._ctx.format_error(self._records_before))
+
+    def _retire_chunk(self):
+        """Drop the current chunk; bytes from the first record not handed out become the carry
+        (the chunk-level analogue of the SearchPhase resume, utils.mojo:485-487)."""
+        res, data = self._chunk, self._chunk_data
+        if self._next == 0:
+            cut = 0
+        elif self._next == int(res.n_records):
+            cut = int(res.bytes_consumed)
+        else:
+            one = np.empty(1, dtype=np.int64)
+            self._ctx.copy_to_host(one, res.d_record_end + 8 * (self._next - 1), 8)
+            cut = int(one[0]) + 1
+        self._carry = data[cut:].copy()
+        self._stream_pos += cut
+        self._records_before += self._next
+        self._chunk = None
+        self._chunk_data = None
+
+    # ------------------------------------------------------------------ reference API
+    def has_more(self) -> bool:
+        """parser.mojo:155-157: True until the end of the stream has been observed."""
+        return not self._eof_seen
+
+    def next_batch(self, max_records: int = DEFAULT_BATCH_SIZE) -> FastqBatch:
+        """parser.mojo:239-251.  Up to ``max_records`` records; fewer (possibly zero) only at the end
+        of the stream; raises ParseError when the batch would reach the stream's failing record
+        (the records already collected for that batch are dropped, exactly like the reference's
+        raise out of ``batch.add(self.next_view())``)."""
+        limit = max_records if max_records else self._batch_size
+        while True:
+            if self._chunk is None:
+                if self._terminal is not None:
+                    break
+                self._load_chunk(limit)
+            avail = int(self._chunk.n_records) - self._next
+            if avail >= limit or self._terminal is not None:
+                break
+            self._retire_chunk()   # not enough records left and more input follows: re-chunk
+        avail = (int(self._chunk.n_records) - self._next) if self._chunk is not None else 0
+        if avail < limit:
+            # the batch runs into the terminal event of the stream
+            code, msg = self._terminal
+            self._eof_seen = True
+            if code != L.EOF:
+                self._next += avail
+                raise ParseError(code, msg)
+        take = min(limit, avail)
+        if take == 0:
+            return FastqBatch(self._ctx, L.BzqDeviceBatch())
+        raw = self._ctx.batch_view(self._next, take)
+        self._next += take
+        return FastqBatch(self._ctx, raw)
+
+    def batches(self, max_records: Optional[int] = None) -> Iterator[FastqBatch]:
+        """parser.mojo:267-274 + _FastqParserBatchIter 700-735: stops on an empty batch or on any
+        error (printing it when it carries a record number)."""
+        limit = max_records if max_records else self._batch_size
+        while self.has_more():
+            try:
+                b = self.next_batch(limit)
+            except ParseError as e:
+                if b"Record number:" in e.message:
+                    print(e.message.decode("latin-1"))
+                return
+            if len(b) == 0:
+                return
+            yield b
+
+    def next_record(self) -> FastqRecord:
+        """parser.mojo:188-211 (config-1 plumbing: one record at a time through a 1-record batch)."""
+        b = self.next_batch(1)
+        if len(b) == 0:
+            raise EOFError_(L.EOF, b"EOF")
+        r = b.get_record(0)
+        r.phred_offset = self._ctx.quality_offset_schema
+        return r
+
+    next_view = next_record
+
+    def records(self) -> Iterator[FastqRecord]:
+        """parser.mojo:260-265 + _FastqParserRecordIter 664-697: errors are printed and end the iteration."""
+        while self.has_more():
+            try:
+                b = self.next_batch(self._batch_size)
+            except ParseError as e:
+                print(e.message.decode("latin-1"))
+                return
+            if len(b) == 0:
+                return
+            for r in b.to_records():
+                r.phred_offset = self._ctx.quality_offset_schema
+                yield r
+
+    views = records

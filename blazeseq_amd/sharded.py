@@ -1,0 +1,146 @@
+"""Multi-GPU byte-range sharding of one FASTQ stream (new design; the reference is single process,
+SURVEY.md 8e).
+
+The file is cut into P contiguous BYTE ranges (not record aligned), one per rank/GPU.  Strict 4-line
+framing means the only global dependency is the line index of each shard's first byte, so the
+exchange is tiny and latency bound:
+
+  1. every rank scans its shard once (``bzq_shard_scan``): newline count, offsets of its first four
+     newlines, first/last byte                                   -> all_gather of 8 x int64 per rank
+  2. ownership: a record belongs to the rank that holds its header-line start.  Rank r+1's leading
+     bytes up to the end of the straddling record (``head``) are sent to rank r, which appends them
+     behind its own bytes (``halo``)                             -> one send/recv per neighbour pair
+  3. every rank parses [its bytes + halo] with ``bzq_submit_shard``; counts and the first failing
+     record are reduced                                           -> two small all_reduce
+
+No bulk data ever crosses xGMI.  The collectives go through ``torch.distributed`` (backend "nccl" is
+RCCL on ROCm; the same code runs over "gloo" on CPU tensors, which is how the protocol is tested
+without GPUs).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+SUMMARY_WORDS = 8  # n_bytes, n_newlines, first_nl[4], first_byte, last_byte
+
+
+@dataclass
+class ShardPlan:
+    lines_before: int      # global line index of this shard's first (possibly partial) line
+    prev_last_byte: int    # byte preceding the shard in the stream (10 for the first shard)
+    head_bytes: int        # leading bytes owned by the previous rank's last record
+    halo_bytes: int        # bytes to append from the next non-empty shard
+    halo_src: int          # rank that sends the halo (-1: none)
+    head_dst: int          # rank that receives our head (-1: none)
+    records_before: int = 0  # filled after parsing (exclusive scan of per-rank record counts)
+
+
+def head_bytes_of(summary: Sequence[int], lines_before: int, prev_last_byte: int) -> int:
+    """Mirror of bzq_shard_head_bytes (include/blazeseq_hip.h): bytes up to and including the newline
+    that ends the record which started in an earlier shard.  -1: the record does not end here."""
+    n_bytes, first_nl = summary[0], summary[2:6]
+    if n_bytes == 0:
+        return 0
+    p0 = lines_before & 3
+    if prev_last_byte == 10 and p0 == 0:
+        return 0
+    k = 4 - p0
+    if first_nl[k - 1] < 0:
+        return -1
+    return int(first_nl[k - 1]) + 1
+
+
+def plan_shards(summaries: Sequence[Sequence[int]]) -> List[ShardPlan]:
+    """Pure function of the gathered summaries: what every rank must skip, send and receive."""
+    P = len(summaries)
+    plans: List[ShardPlan] = []
+    lines = 0
+    prev_byte = 10
+    for r in range(P):
+        s = summaries[r]
+        hb = head_bytes_of(s, lines, prev_byte)
+        if hb < 0:
+            raise ValueError(f"shard {r}: a record spans more than one whole shard; use fewer/larger shards")
+        plans.append(ShardPlan(lines, prev_byte, hb, 0, -1, -1))
+        if s[0] > 0:
+            lines += int(s[1])
+            prev_byte = int(s[7])
+    # the halo of rank r is the head of the next non-empty shard
+    for r in range(P):
+        if summaries[r][0] == 0:
+            continue
+        nxt = next((q for q in range(r + 1, P) if summaries[q][0] > 0), -1)
+        if nxt >= 0 and plans[nxt].head_bytes > 0:
+            plans[r].halo_bytes = plans[nxt].head_bytes
+            plans[r].halo_src = nxt
+            plans[nxt].head_dst = r
+    return plans
+
+
+def gather_summaries(local: Sequence[int], device, group=None) -> List[List[int]]:
+    """all_gather of the 8-word shard summaries."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor(list(local), dtype=torch.int64, device=device)
+    out = [torch.empty(SUMMARY_WORDS, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return [t.cpu().tolist() for t in out]
+
+
+def exchange_halo(shard: torch.Tensor, n: int, plan: ShardPlan, group=None) -> None:
+    """Send our head to the previous owner, receive our halo behind our own bytes.
+    ``shard`` is a uint8 tensor with at least n + plan.halo_bytes elements."""
+    ops = []
+    if plan.head_dst >= 0 and plan.head_bytes > 0:
+        ops.append(dist.P2POp(dist.isend, shard[:plan.head_bytes], plan.head_dst, group))
+    if plan.halo_src >= 0 and plan.halo_bytes > 0:
+        if shard.numel() < n + plan.halo_bytes:
+            raise ValueError("shard tensor has no room for the halo")
+        ops.append(dist.P2POp(dist.irecv, shard[n:n + plan.halo_bytes], plan.halo_src, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def reduce_counts(records: int, bases: int, nbytes: int, first_error_global: int, device, group=None):
+    """Global totals (sum) and the first failing record over all ranks (min; 2^62 = none)."""
+    t = torch.tensor([records, bases, nbytes], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    e = torch.tensor([first_error_global], dtype=torch.int64, device=device)
+    dist.all_reduce(e, op=dist.ReduceOp.MIN, group=group)
+    return [int(x) for x in t.cpu().tolist()], int(e.item())
+
+
+def records_before(n_records: int, device, group=None) -> int:
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    mine = torch.tensor([n_records], dtype=torch.int64, device=device)
+    out = [torch.empty(1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(out, mine, group=group)
+    return int(sum(int(t.item()) for t in out[:rank]))
+
+
+NO_ERROR = 1 << 62
+
+
+def parse_sharded(ctx, shard: torch.Tensor, n: int, stream_pos: int, group=None):
+    """Full protocol for one rank on a device-resident shard.  Returns (ChunkResult, plan, totals,
+    first_error_global_record)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    s = ctx.shard_scan(shard.data_ptr(), n)
+    local = [int(s.n_bytes), int(s.n_newlines), *[int(x) for x in s.first_nl], int(s.first_byte), int(s.last_byte)]
+    summaries = gather_summaries(local, shard.device, group)
+    plan = plan_shards(summaries)[rank]
+    exchange_halo(shard, n, plan, group)
+    is_last = all(summaries[q][0] == 0 for q in range(rank + 1, world))
+    ctx.submit_shard(shard.data_ptr(), n, plan.halo_bytes, plan.lines_before, plan.prev_last_byte, stream_pos, is_last)
+    res = ctx.result()
+    plan.records_before = records_before(int(res.n_records), shard.device, group)
+    err = NO_ERROR
+    if res.status not in (0, 6):
+        err = plan.records_before + int(res.error_record)
+    totals, first_err = reduce_counts(int(res.n_records), int(res.seq_bytes), n, err, shard.device, group)
+    return res, plan, totals, first_err

@@ -1,0 +1,253 @@
+/*
+ * blazeseq_hip.h -- C ABI of libblazeseq_hip.so: the MI355X (gfx950) FASTQ batch-parse path.
+ *
+ * This is the drop-in boundary for BlazeSeq's hot path.  Every entry point names the reference
+ * interface it replaces (file:line relative to the BlazeSeq tree).  Plain pointers and sizes only:
+ * a Mojo host binds these with OwnedDLHandle/get_function exactly like the reference binds libz
+ * (blazeseq/io/readers.mojo:226-280); INTEGRATION.md shows that shim.
+ *
+ * Conventions
+ *   - every call returns int32: 0 = OK, < 0 = runtime failure (HIP / allocation / misuse; text via
+ *     bzq_last_error), > 0 = a FastxErrorCode (blazeseq/errors.mojo:33-68) where documented.
+ *   - one bzq_ctx per host thread (the reference parser is single-threaded, README.md:113); a ctx
+ *     owns its HIP stream, its device arenas and the result of the most recent chunk.
+ *   - device pointers returned in bzq_chunk / bzq_device_batch are owned by the ctx and stay valid
+ *     until the next bzq_submit_* on that ctx (the device analogue of "FastqView is valid until the
+ *     next parser call", blazeseq/fastq/record.mojo:437-440).
+ *   - all positions are int64 byte offsets relative to the first byte of the submitted chunk.
+ */
+#ifndef BLAZESEQ_HIP_H
+#define BLAZESEQ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BZQ_ABI_VERSION 1
+
+/* FastxErrorCode, blazeseq/errors.mojo:33-68 (values are part of the ABI). */
+enum {
+    BZQ_OK = 0,
+    BZQ_ID_NO_AT = 1,
+    BZQ_SEP_NO_PLUS = 2,
+    BZQ_SEQ_QUAL_LEN_MISMATCH = 3,
+    BZQ_ASCII_INVALID = 4,
+    BZQ_QUALITY_OUT_OF_RANGE = 5,
+    BZQ_EOF = 6,
+    BZQ_UNEXPECTED_EOF = 7,
+    BZQ_BUFFER_EXCEEDED = 8,
+    BZQ_BUFFER_AT_MAX = 9,
+    BZQ_OTHER = 10
+};
+
+/* runtime failures (negative) */
+enum {
+    BZQ_ERR_HIP = -1,       /* a HIP call failed */
+    BZQ_ERR_ARG = -2,       /* bad argument / call order */
+    BZQ_ERR_NOMEM = -3,     /* arena too small for the chunk and growth refused */
+    BZQ_ERR_NO_DEVICE = -4, /* no gfx950 device visible: the product path has no CPU fallback */
+    BZQ_ERR_IO = -5
+};
+
+/* ParserConfig (blazeseq/fastq/parser.mojo:33-74) + QualitySchema triple
+ * (blazeseq/fastq/quality_schema.mojo:9-31) + the parser's batch size (parser.mojo:125-145). */
+typedef struct bzq_config {
+    int64_t buffer_capacity;        /* ParserConfig.buffer_capacity (default 256 KiB, CONSTS.mojo:26).
+                                       The GPU path has no such buffer; the value only decides which
+                                       records the reference would have refused (BUFFER_EXCEEDED) */
+    int64_t buffer_max_capacity;    /* default 2^30, CONSTS.mojo:28 */
+    int32_t buffer_growth_enabled;  /* default 0 */
+    int32_t check_ascii;            /* default 0 */
+    int32_t check_quality;          /* default 0 */
+    uint8_t q_lower, q_upper, q_offset, _pad0; /* QualitySchema.LOWER/UPPER/OFFSET */
+    int32_t batch_size;             /* DEFAULT_BATCH_SIZE = 4096, CONSTS.mojo:31 */
+    int32_t compat_simd_width;      /* 0 (default): quality bounds inclusive [LOWER,UPPER] (the scalar
+                                       branch, record.mojo:99-102).  16/32/64: also reproduce the SIMD
+                                       body's `>=` for the first floor(n/W)*W quality bytes
+                                       (record.mojo:90-97) */
+    int32_t emit_offsets;           /* also materialise RecordOffsets columns (utils.mojo:37-93) */
+    int32_t _pad1;
+    int64_t max_chunk_bytes;        /* device arena sizing; chunks larger than this re-size the arena */
+    int64_t pass_bytes;             /* bytes handled per kernel round (0 = library default) */
+    int32_t min_record_bytes;       /* sizing hint for the per-record arrays (default 32); an input
+                                       with shorter records transparently re-sizes and re-runs */
+    int32_t _pad2;
+} bzq_config;
+
+typedef struct bzq_ctx bzq_ctx;
+
+/* One parsed chunk.  Mirrors what FastqParser.next_view/next_batch expose record by record
+ * (parser.mojo:159-170, 239-251), for all records of the chunk at once. */
+typedef struct bzq_chunk {
+    uint64_t n_bytes;          /* bytes submitted */
+    uint64_t n_records;        /* records delivered: complete, and before the first failing record */
+    uint64_t bytes_consumed;   /* chunk offset after the last delivered record; the caller carries
+                                  [bytes_consumed, n_bytes) into its next chunk (the chunk-level
+                                  analogue of SearchPhase resume, utils.mojo:485-487) */
+    uint64_t total_newlines;
+    int32_t status;            /* BZQ_OK: more input may follow (is_eof was 0);
+                                  BZQ_EOF: clean end of stream; otherwise the FastxErrorCode the
+                                  reference parser raises after delivering n_records records */
+    int32_t tail_phase;        /* SearchPhase of the undelivered tail (0..3) */
+    int64_t error_record;      /* chunk-local index of the failing record, -1 if none */
+    uint64_t seq_bytes, qual_bytes, id_bytes; /* column lengths over the delivered records */
+    /* FastqBatch columns for the whole chunk (record_batch.mojo:19-41), device resident */
+    const uint8_t* d_seq;      /* u8[seq_bytes]  concatenated sequence lines */
+    const uint8_t* d_qual;     /* u8[qual_bytes] concatenated quality lines */
+    const uint8_t* d_id;       /* u8[id_bytes]   concatenated stripped ids (no '@') */
+    const int64_t* d_ends;     /* i64[n_records] inclusive running sum of quality lengths (Q11) */
+    const int64_t* d_id_ends;  /* i64[n_records] inclusive running sum of id lengths */
+    const int64_t* d_batch_ends;    /* same, restarted every batch_size records: exactly the
+                                       `_ends` of the FastqBatch that next_batch would build */
+    const int64_t* d_batch_id_ends;
+    const int64_t* d_record_end;    /* i64[n_records] offset of the record's terminating '\n'
+                                       (RecordOffsets.record_end, utils.mojo:61) */
+    /* RecordOffsets columns (absolute chunk offsets), NULL unless config.emit_offsets */
+    const int64_t* d_header_start;
+    const int64_t* d_seq_start;
+    const int64_t* d_sep_start;
+    const int64_t* d_qual_start;
+    /* timing of the kernels of this chunk, hipEvent on the ctx stream (milliseconds) */
+    float ms_total;            /* first kernel start -> last kernel end */
+    float ms_aggregate, ms_scan, ms_emit, ms_rebase;
+    uint32_t n_passes;
+    uint32_t _pad;
+} bzq_chunk;
+
+/* DeviceFastqBatch (blazeseq/fastq/record_batch.mojo:210-220): what FastqBatch.to_device(ctx)
+ * returns (record_batch.mojo:89-90, 404-411).  Zero-copy slices of the chunk columns. */
+typedef struct bzq_device_batch {
+    int64_t num_records;
+    int64_t seq_len;           /* ends[num_records-1] */
+    int64_t total_id_bytes;    /* id_ends[num_records-1] */
+    uint8_t quality_offset;    /* always 33 on the parser path (parser.mojo:243) */
+    uint8_t _pad[7];
+    const uint8_t* qual_buffer;
+    const uint8_t* sequence_buffer;
+    const int64_t* ends;       /* inclusive, relative to this batch */
+    const uint8_t* id_buffer;
+    const int64_t* id_ends;
+    uint64_t first_record;     /* chunk-local index of record 0 of this batch */
+} bzq_device_batch;
+
+/* FastqBatch on the host (record_batch.mojo:19-41), filled by bzq_batch_to_host: the caller
+ * provides buffers of at least the sizes in the matching bzq_device_batch. */
+typedef struct bzq_host_batch {
+    int64_t num_records;
+    uint8_t* quality_bytes;    /* seq_len bytes */
+    uint8_t* sequence_bytes;   /* seq_len bytes */
+    uint8_t* id_bytes;         /* total_id_bytes bytes */
+    int64_t* ends;             /* num_records */
+    int64_t* id_ends;          /* num_records */
+    uint8_t quality_offset;
+    uint8_t _pad[7];
+} bzq_host_batch;
+
+/* ---- configuration -------------------------------------------------------------------------- */
+
+int32_t bzq_abi_version(void);
+/* ParserConfig() defaults, parser.mojo:60-74; schema = generic */
+void bzq_config_default(bzq_config* cfg);
+/* _parse_schema, blazeseq/utils.mojo:612-637.  Returns 1 for a known name, 0 when it fell back to
+ * generic (the reference prints a warning and continues). */
+int32_t bzq_schema_from_name(const char* name, uint8_t* lower, uint8_t* upper, uint8_t* offset);
+/* FastxErrorCode.message(), blazeseq/errors.mojo:71-90 */
+const char* bzq_message_for_code(int32_t code);
+
+/* ---- context -------------------------------------------------------------------------------- */
+
+/* FastqParser.__init__ (parser.mojo:89-145): one per parser.  `device` is the HIP ordinal.
+ * Fails with BZQ_ERR_NO_DEVICE when no GPU is present -- there is no CPU fallback. */
+int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out);
+void bzq_destroy(bzq_ctx* ctx);
+const char* bzq_last_error(const bzq_ctx* ctx);   /* ctx may be NULL: last create() failure */
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the ctx's own. */
+int32_t bzq_set_stream(bzq_ctx* ctx, void* hip_stream);
+int32_t bzq_get_config(const bzq_ctx* ctx, bzq_config* out);
+/* Run-time knobs that are not part of ParserConfig: "pass_bytes" (bytes per kernel round),
+ * "timing_detail" (per-kernel hipEvent timing in bzq_chunk), "force_dense" (tests: route every
+ * tile through the serial in-kernel path). */
+int32_t bzq_set_option(bzq_ctx* ctx, const char* key, int64_t value);
+
+/* DeviceContext.enqueue_create_host_buffer (record_batch.mojo:316-323): pinned staging the host
+ * fills with Reader.read_to_buffer semantics (io/readers.mojo:71-76). */
+int32_t bzq_pinned_alloc(size_t bytes, void** out);
+int32_t bzq_pinned_free(void* p);
+
+/* ---- the hot path --------------------------------------------------------------------------- */
+
+/* Replaces _find_and_consume_ref_record/_scan_record/_validate_fastq_structure (parser.mojo:311-379,
+ * utils.mojo:448-551), Validator._validate (record.mojo:162-172), FastqBatch.add
+ * (record_batch.mojo:77-87) and the upload (record_batch.mojo:308-411) for a whole chunk.
+ * The chunk must start at a record start.  `stream_pos` is the stream offset of data[0] (used for
+ * error text only).  is_eof != 0 marks the last chunk of the stream.  Asynchronous on the ctx
+ * stream; bzq_chunk_result waits.
+ *   _host:   `data` is host memory (pinned for full speed); copied H2D first.
+ *   _device: `data` is device memory on the ctx's GPU and is read in place. */
+int32_t bzq_submit_chunk_host(bzq_ctx* ctx, const uint8_t* data, uint64_t n, uint64_t stream_pos,
+                              int32_t is_eof);
+int32_t bzq_submit_chunk_device(bzq_ctx* ctx, const uint8_t* d_data, uint64_t n, uint64_t stream_pos,
+                                int32_t is_eof);
+/* Blocks until the chunk is parsed; fills `out`.  Returns out->status when it is an error code
+ * (>0, not EOF), else 0. */
+int32_t bzq_chunk_result(bzq_ctx* ctx, bzq_chunk* out);
+
+/* next_batch (parser.mojo:239-251) + to_device (record_batch.mojo:89-90): records
+ * [first_record, first_record+max_records) of the current chunk.  When first_record is a multiple
+ * of config.batch_size and max_records <= batch_size (the batches() iteration) the view is zero
+ * copy; any other range gets its rebased `ends` from a small kernel into ctx scratch that is valid
+ * until the next bzq_batch_view. */
+int32_t bzq_batch_view(bzq_ctx* ctx, uint64_t first_record, uint32_t max_records, bzq_device_batch* out);
+/* DeviceFastqBatch.copy_to_host (record_batch.mojo:222-244) */
+int32_t bzq_batch_to_host(bzq_ctx* ctx, const bzq_device_batch* batch, bzq_host_batch* out);
+/* Copy any device range of the current chunk's arrays to the host (tests, error snippets). */
+int32_t bzq_copy_to_host(bzq_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+
+/* ParseError / ValidationError text of the current chunk's terminal status (errors.mojo:178-234,
+ * parser.mojo:276-309, 332-338, 597-610): exactly String(e) of the reference's raise.
+ * `records_before` / `lines_before` are the counts delivered by earlier chunks of the same stream.
+ * Returns the text length (may exceed cap; output is truncated, always NUL terminated). */
+int64_t bzq_format_error(bzq_ctx* ctx, uint64_t records_before, char* buf, size_t cap);
+
+/* ---- multi-GPU shard stitch (new) --------------------------------------------- */
+
+/* Summary of a raw byte shard that does NOT start at a record start.  Filled by
+ * bzq_shard_scan; exchanged between ranks by the host (all-gather over RCCL). */
+typedef struct bzq_shard_summary {
+    uint64_t n_bytes;
+    uint64_t n_newlines;
+    int64_t first_nl[4];   /* offsets of the first four newlines, -1 if absent */
+    uint8_t first_byte, last_byte;
+    uint8_t _pad[6];
+} bzq_shard_summary;
+
+/* Count newlines of a device-resident shard (one read pass; its tile aggregates are reused by
+ * the following bzq_submit_shard). */
+int32_t bzq_shard_scan(bzq_ctx* ctx, const uint8_t* d_data, uint64_t n, bzq_shard_summary* out);
+/* Parse shard bytes [0, n + halo_bytes) where `lines_before` is the global line index of the
+ * shard's first (possibly partial) line and prev_last_byte the byte preceding the shard (0x0A for
+ * rank 0).  The halo (the straddling record's remainder received from the next rank) must already
+ * sit at d_data + n.  Records whose header starts in [0, n) are delivered. */
+int32_t bzq_submit_shard(bzq_ctx* ctx, const uint8_t* d_data, uint64_t n, uint64_t halo_bytes,
+                         uint64_t lines_before, uint8_t prev_last_byte, uint64_t stream_pos,
+                         int32_t is_last_shard);
+/* Number of leading bytes of this shard that belong to the previous rank's last record. */
+int32_t bzq_shard_head_bytes(const bzq_shard_summary* s, uint64_t lines_before, uint8_t prev_last_byte,
+                             uint64_t* head_bytes);
+
+/* ---- synthetic input (measurement only) ----------------------------------------------------- */
+
+/* generate_synthetic_fastq_buffer (blazeseq/utils.mojo:831-917) for fixed-length reads, written
+ * straight into device memory: records [first, first+count) of a num_reads-record file.
+ * Returns bytes written via *out_bytes.  d_out == NULL only sizes. */
+int32_t bzq_generate_synthetic_device(bzq_ctx* ctx, int64_t num_reads, int64_t first, int64_t count,
+                                      int32_t read_len, int32_t min_phred, int32_t max_phred,
+                                      const char* schema, uint8_t* d_out, uint64_t cap, uint64_t* out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLAZESEQ_HIP_H */

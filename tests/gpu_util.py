@@ -1,0 +1,55 @@
+"""Helpers for the -m gpu parity tests: run the HIP path through the C ABI, compare with the oracle."""
+import numpy as np
+
+import blazeseq_amd as B
+from blazeseq_amd import _lib as L
+from oracle import oracle as O
+
+
+def make_pair(batch_size=4096, schema="generic", pass_bytes=0, min_record_bytes=32, **kw):
+    """(Context, oracle config) with the same ParserConfig."""
+    okw = {k: v for k, v in kw.items() if k not in ("compat_simd_width", "emit_offsets")}
+    cfg = B.ParserConfig(**kw)
+    name = cfg.quality_schema if cfg.quality_schema else schema
+    ctx = B.Context(cfg, schema, batch_size, 0, pass_bytes=pass_bytes, min_record_bytes=min_record_bytes)
+    okw.pop("quality_schema", None)
+    ocfg = O.make_config(quality_schema=name, simd_width=kw.get("compat_simd_width", 0), batch_size=batch_size, **okw)
+    return ctx, ocfg
+
+
+def check_against_oracle(ctx, ocfg, data, is_eof=True, offsets=False, what=""):
+    """Parse `data` on the GPU and with the flat oracle; every output must be bit-identical."""
+    data = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    res = ctx.parse(data, 0, is_eof)
+    f = O.flat_parse(data, ocfg, is_eof=is_eof)
+    tag = f"{what} n={data.size}"
+    assert int(res.n_records) == f.n_records, (tag, int(res.n_records), f.n_records, res.status, f.term_code)
+    assert res.status == f.term_code, (tag, res.status, f.term_code, ctx.format_error(), f.term_msg)
+    if res.status != L.OK:
+        assert ctx.format_error() == f.term_msg, (tag, ctx.format_error(), f.term_msg)
+        assert (int(res.error_record) if res.status != L.EOF else -1) == f.term_record, tag
+    assert int(res.bytes_consumed) == f.consumed, (tag, int(res.bytes_consumed), f.consumed)
+    assert int(res.total_newlines) == f.n_newlines, tag
+    n = f.n_records
+    if n:
+        np.testing.assert_array_equal(res.ends(), f.ends, err_msg=tag + " ends")
+        np.testing.assert_array_equal(res.id_ends(), f.id_ends, err_msg=tag + " id_ends")
+        np.testing.assert_array_equal(res.record_end(), f.record_end, err_msg=tag + " record_end")
+        bs = ocfg.batch_size
+        r = np.arange(n)
+        b0 = (r // bs) * bs
+        base_e = np.where(b0 > 0, f.ends[np.maximum(b0 - 1, 0)], 0)
+        base_i = np.where(b0 > 0, f.id_ends[np.maximum(b0 - 1, 0)], 0)
+        np.testing.assert_array_equal(res.batch_ends(), f.ends - base_e, err_msg=tag + " batch_ends")
+        np.testing.assert_array_equal(res.batch_id_ends(), f.id_ends - base_i, err_msg=tag + " batch_id_ends")
+        assert int(res.qual_bytes) == f.qual_bytes.size and int(res.id_bytes) == f.id_bytes.size, tag
+        assert int(res.seq_bytes) == f.seq_bytes.size, (tag, int(res.seq_bytes), f.seq_bytes.size)
+        np.testing.assert_array_equal(res.seq(), f.seq_bytes, err_msg=tag + " seq column")
+        np.testing.assert_array_equal(res.qual(), f.qual_bytes, err_msg=tag + " qual column")
+        np.testing.assert_array_equal(res.id(), f.id_bytes, err_msg=tag + " id column")
+        if offsets:
+            np.testing.assert_array_equal(res.header_start(), f.header_start, err_msg=tag + " header_start")
+            np.testing.assert_array_equal(res.seq_start(), f.seq_start, err_msg=tag + " seq_start")
+            np.testing.assert_array_equal(res.sep_start(), f.sep_start, err_msg=tag + " sep_start")
+            np.testing.assert_array_equal(res.qual_start(), f.qual_start, err_msg=tag + " qual_start")
+    return res, f

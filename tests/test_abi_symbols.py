@@ -1,0 +1,69 @@
+"""The C-ABI library loads without a GPU and exports every function include/blazeseq_hip.h declares;
+the product package never touches the oracle and has no CPU fallback."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "blazeseq_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bzq_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from blazeseq_amd import _lib
+    names = declared_functions()
+    assert len(names) >= 20
+    assert sorted(_lib.SYMBOLS) == names          # the Python binding covers the whole header
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert _lib.lib().bzq_abi_version() == 1
+
+
+def test_struct_sizes_match_header():
+    from blazeseq_amd import _lib
+    assert ctypes.sizeof(_lib.BzqConfig) == 72
+    assert ctypes.sizeof(_lib.BzqDeviceBatch) == 80
+    assert ctypes.sizeof(_lib.BzqShardSummary) == 56
+
+
+def test_config_defaults_and_schema_table_without_gpu():
+    from blazeseq_amd import _lib
+    L = _lib.lib()
+    c = _lib.BzqConfig()
+    L.bzq_config_default(ctypes.byref(c))
+    # ParserConfig defaults, blazeseq/fastq/parser.mojo:60-74 + CONSTS.mojo:26-31
+    assert (c.buffer_capacity, c.buffer_max_capacity, c.buffer_growth_enabled, c.check_ascii, c.check_quality,
+            c.batch_size, c.q_lower, c.q_upper, c.q_offset) == (256 * 1024, 1 << 30, 0, 0, 0, 4096, 33, 126, 33)
+    import blazeseq_amd as B
+    assert B.quality_schema("solexa") == (59, 126, 64, True)
+    assert B.quality_schema("illumina_1.5") == (66, 126, 64, True)
+    assert L.bzq_message_for_code(3) == b"Quality and sequence line do not match in length"
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import blazeseq_amd as B
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        B.Context()
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        B.FastqParser(b"@a\nA\n+\n!\n")
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "blazeseq_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                if re.search(r"(from|import)\s+oracle|bzq_oracle|libbzq_oracle|orc_[a-z_]+\(", text):
+                    bad.append(os.path.join(dirpath, fn))
+    assert not bad, bad

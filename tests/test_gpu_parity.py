@@ -1,0 +1,201 @@
+"""GPU parity: the HIP path (through the C ABI) must be bit-identical to the CPU oracle -- record
+offsets, lengths, validation outcome, error text, FastqBatch columns -- on the reference's corpus,
+on adversarial streams (ragged, truncated, CRLF, non-ASCII, empty), with every kernel path (fast /
+serial / multi-pass) and every ParserConfig switch."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+from fastq_fuzz import rand_stream
+from gpu_util import make_pair, check_against_oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CORPUS = json.load(open(os.path.join(HERE, "golden", "corpus_expected.json")))
+
+
+def test_inline_known_answers():
+    ctx, oc = make_pair(emit_offsets=True)
+    for data in (b"@r1\nACGT\n+\n!!!!\n@r2\nTGCA\n+\n####\n", b"", b"\n", b"@", b"@a\nA\n+\n!\n",
+                 b"r1\nACGT\n+\n!!!!\n", b"@r1\nACGT\n+\n!!!\n", b"@r1\nACGT\n-\n!!!!\n",
+                 b"@a\nAC\n+\n!!\n@b\nACGT\n+\n!!", b"@a\nAC\n+\n!!\n@b\nAC\n+\n \t", b"@a\nAC\n+\n!!\n\n",
+                 b"@only\nACGT", b"@a\nAC\n+\n!!\n@only\nACGT", b"@id\r\nACGT\r\n+\r\n!!!!\r\n",
+                 b"@ \t id with spaces \t\nAC\n+\n!!\n@\nAC\n+\n!!\n@   \nAC\n+\n!!\n", b"\n\n\n\n", b"\n\n\n\n\n\n\n\n\n"):
+        check_against_oracle(ctx, oc, data, offsets=True, what=repr(data[:20]))
+
+
+@pytest.mark.parametrize("cfgname", ["default", "validated_generic", "validated_schema", "validated_schema_simd32",
+                                     "cap64", "cap64_growth"])
+def test_corpus(cfgname, corpus_dir):
+    for name, e in sorted(CORPUS.items()):
+        data = open(os.path.join(corpus_dir, name), "rb").read()
+        sc = e["schema"]
+        kw = {"default": {}, "validated_generic": dict(check_ascii=True, check_quality=True),
+              "validated_schema": dict(check_ascii=True, check_quality=True, quality_schema=sc),
+              "validated_schema_simd32": dict(check_ascii=True, check_quality=True, quality_schema=sc, compat_simd_width=32),
+              "cap64": dict(buffer_capacity=64),
+              "cap64_growth": dict(buffer_capacity=64, buffer_growth_enabled=True, buffer_max_capacity=1 << 20)}[cfgname]
+        ctx, oc = make_pair(emit_offsets=True, **kw)
+        res, f = check_against_oracle(ctx, oc, data, offsets=True, what=f"{name}/{cfgname}")
+        g = e[cfgname]
+        assert (int(res.n_records), res.status, ctx.format_error().decode("latin-1") if res.status else "") == \
+               (g["n_records"], g["term_code"], g["term_msg"]), name
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_small(seed):
+    rng = np.random.default_rng(1000 + seed)
+    for rep in range(6):
+        data = rand_stream(rng, n_records=int(rng.integers(0, 60)), max_len=int(rng.integers(1, 80)),
+                           dirty=float(rng.choice([0.0, 0.02, 0.1])), crlf=bool(rng.random() < 0.15))
+        for kw in (dict(), dict(check_ascii=True, check_quality=True),
+                   dict(check_ascii=True, check_quality=True, quality_schema="solexa", compat_simd_width=16),
+                   dict(buffer_capacity=48), dict(buffer_capacity=48, buffer_growth_enabled=True, buffer_max_capacity=200)):
+            ctx, oc = make_pair(batch_size=int(rng.choice([1, 3, 4096])), emit_offsets=True, **kw)
+            check_against_oracle(ctx, oc, data, offsets=True, what=f"seed{seed}/{rep}/{kw}")
+            if rep == 0:
+                ctx.set_option("force_dense", 1)   # every tile through the serial in-kernel path
+                check_against_oracle(ctx, oc, data, offsets=True, what=f"dense seed{seed}/{kw}")
+            ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_multi_tile(seed):
+    """Streams of 0.2-3 MB: lines straddle 16 KiB tile edges, several kernel passes, chunk mode."""
+    rng = np.random.default_rng(2000 + seed)
+    max_len = int(rng.choice([30, 150, 400, 5000, 40000]))
+    nrec = int(rng.integers(50, 4000)) if max_len <= 400 else int(rng.integers(20, 120))
+    dirty = float(rng.choice([0.0, 0.0, 0.001]))
+    data = rand_stream(rng, n_records=nrec, max_len=max_len, dirty=dirty, crlf=bool(rng.random() < 0.2))
+    for kw, pb in ((dict(), 0), (dict(check_ascii=True, check_quality=True), 64 * 1024),
+                   (dict(check_ascii=True, check_quality=True), 16 * 1024)):
+        ctx, oc = make_pair(batch_size=int(rng.choice([7, 4096])), pass_bytes=pb, emit_offsets=True, **kw)
+        check_against_oracle(ctx, oc, data, offsets=True, what=f"mt seed{seed} {kw} pass={pb}")
+        check_against_oracle(ctx, oc, data, is_eof=False, offsets=True, what=f"mt chunk-mode seed{seed}")
+        ctx.set_option("force_dense", 1)
+        check_against_oracle(ctx, oc, data, offsets=True, what=f"mt dense seed{seed}")
+        ctx.close()
+
+
+def test_space_runs_across_tile_edges():
+    """Header lines made of spaces that straddle tile boundaries: every id byte dropped exactly once."""
+    rng = np.random.default_rng(7)
+    parts = []
+    for i in range(40):
+        lead = b" " * int(rng.integers(0, 3000)); trail = b"\t" * int(rng.integers(0, 3000))
+        rid = bytes(rng.integers(48, 123, int(rng.integers(0, 9))).astype(np.uint8))
+        L = int(rng.integers(0, 5000))
+        parts.append(b"@" + lead + rid + trail + b"\n" + b"A" * L + b"\n+\n" + b"I" * L + b"\n")
+    data = b"".join(parts)
+    for dense in (0, 1):
+        ctx, oc = make_pair(emit_offsets=True, check_ascii=True, check_quality=True)
+        ctx.set_option("force_dense", dense)
+        check_against_oracle(ctx, oc, data, offsets=True, what=f"space runs dense={dense}")
+        ctx.close()
+
+
+def test_tiny_records_take_serial_path_and_resize():
+    """> 1020 newlines in a 16 KiB tile (records of 4-12 bytes): serial in-kernel path, and the
+    per-record arrays are re-sized transparently."""
+    data = b"@\n\n+\n\n" * 9000 + b"@a\nC\n+\n!\n" * 3000
+    ctx, oc = make_pair(emit_offsets=True, check_ascii=True, check_quality=True)
+    res, f = check_against_oracle(ctx, oc, data, offsets=True, what="tiny")
+    assert res._pad > 0  # dense tiles were used
+    ctx.close()
+
+
+def test_device_generator_matches_oracle():
+    import torch
+    ctx, _ = make_pair()
+    for (nreads, L, lo, hi, sch) in ((64, 150, 33, 73, "generic"), (1000, 100, 0, 40, "sanger"), (10, 1, 5, 5, "solexa"), (3, 0, 0, 0, "generic")):
+        nb = ctx.generate_synthetic_device(nreads, L, lo, hi, sch)
+        t = torch.empty(nb + 16, dtype=torch.uint8, device="cuda")
+        assert ctx.generate_synthetic_device(nreads, L, lo, hi, sch, t.data_ptr(), nb) == nb
+        ref = O.generate_synthetic(nreads, L, L, lo, hi, sch)
+        np.testing.assert_array_equal(t[:nb].cpu().numpy(), ref)
+    ctx.close()
+
+
+@pytest.mark.parametrize("validate", [False, True])
+def test_synthetic_150bp_medium(validate):
+    """Config 2/3 shape at a size the oracle parses in a second: 150k reads (47.7 MB)."""
+    data = O.generate_synthetic(150_000, 150, 150, 33, 73, "generic")
+    kw = dict(check_ascii=True, check_quality=True, quality_schema="sanger") if validate else {}
+    ctx, oc = make_pair(emit_offsets=True, **kw)
+    res, f = check_against_oracle(ctx, oc, data, offsets=True, what="150bp")
+    assert int(res.n_records) == 150_000 and res.status == 6
+    if validate:
+        # negative variant: byte flips at record indices {0, 4095, 4096, R-1}
+        for rec, pos, val, code in ((149_999, 30, 0x80, 4), (4096, 170, 0x1F, 5), (4095, 20, 0xC3, 4), (0, 165, 0x7F, 5)):
+            bad = data.copy(); bad[rec * 318 + pos] = val
+            r2, f2 = check_against_oracle(ctx, oc, bad, what=f"flip rec {rec}")
+            assert r2.status == code and int(r2.n_records) == rec
+    ctx.close()
+
+
+def test_long_reads_medium():
+    """Config 4 shape: 200..19800 bp, high length variance (2000 reads, ~40 MB)."""
+    data = O.generate_synthetic(2000, 200, 19800, 5, 30, "sanger")
+    ctx, oc = make_pair(buffer_capacity=64 * 1024, check_ascii=True, check_quality=True, quality_schema="sanger", emit_offsets=True)
+    check_against_oracle(ctx, oc, data, offsets=True, what="long reads")
+    ctx.close()
+    ctx, oc = make_pair(buffer_capacity=16 * 1024)   # the reference refuses records longer than its buffer
+    res, f = check_against_oracle(ctx, oc, data, what="long reads small buffer")
+    assert res.status == 8
+    ctx.close()
+
+
+def test_parser_api_mirrors_reference_tests(corpus_dir):
+    """The reference's own API-level tests (tests/fastq/test_parser.mojo:122-215, tests/test_python_bindings.py:31-67)
+    replayed on blazeseq_amd.FastqParser."""
+    import blazeseq_amd as B
+    content = b"@r1\nACGT\n+\n!!!!\n@r2\nTGCA\n+\n####\n@r3\nNNNN\n+\n!!!!\n"
+    assert [len(b) for b in B.FastqParser(content, schema="generic", batch_size=2).batches()] == [2, 1]
+    p = B.FastqParser(b"@a\nA\n+\n!\n@b\nB\n+\n!\n@c\nC\n+\n!\n@d\nD\n+\n!\n@e\nE\n+\n!\n", batch_size=2)
+    assert [len(p.next_batch(2)) for _ in range(3)] == [2, 2, 1] and not p.has_more()
+    b = B.FastqParser(b"@seq1\nACGT\n+\n!!!!\n", batch_size=4).next_batch(4)
+    r = b.get_record(0)
+    assert (len(b), r.id, r.sequence, r.quality) == (1, b"seq1", b"ACGT", b"!!!!")
+    assert list(B.FastqParser(b"", batch_size=4).batches()) == []
+    p = B.FastqParser(b"@r1\nA\n+\n!\n", batch_size=4)
+    assert p.has_more(); p.next_batch(4); assert not p.has_more()
+    data = open(os.path.join(corpus_dir, "example.fastq"), "rb").read()
+    recs = list(B.FastqParser(data).records())
+    assert [r.id for r in recs] == [b"EAS54_6_R1_2_1_413_324", b"EAS54_6_R1_2_1_540_792", b"EAS54_6_R1_2_1_443_348"]
+    assert b"CCCTTCTTGTCTTCAGCGTTTCTCC" in recs[0].sequence
+    p = B.FastqParser(os.path.join(corpus_dir, "example.fastq"))
+    assert len(p.next_batch(2)) == 2 and len(p.next_batch(10)) == 1
+    # FastqBatch layout, tests/fastq/test_record_batch.mojo:26-38
+    b = B.FastqParser(b"@a\nAC\n+\n!!\n@b\nGT\n+\n!!\n").next_batch(4)
+    assert b.num_records() == 2 and b.seq_len() == 4 and b._ends.tolist() == [2, 4]
+    assert len(b._quality_bytes) == 4 and len(b._sequence_bytes) == 4 and b.quality_offset() == 33
+    d = b.to_device()
+    assert d.num_records == 2 and d.seq_len == 4 and d.total_id_bytes == 2
+    back = d.copy_to_host()  # commented-out GPU round trip of tests/fastq/test_record_batch.mojo:144-378
+    assert [(r.id, r.sequence, r.quality) for r in back.to_records()] == [(b"a", b"AC", b"!!"), (b"b", b"GT", b"!!")]
+    # error text, tests/test_error_context.mojo:97-137
+    p = B.FastqParser(b"@r1\nAT\n+\n!@\nr2\nGC\n+\n#$\n", config=B.ParserConfig(check_ascii=True, check_quality=True))
+    assert len(p.next_record()) == 2
+    with pytest.raises(B.ParseError, match="Record number: 2"):
+        p.next_record()
+    with pytest.raises(B.ParseError, match="Non ASCII letters found"):
+        B.FastqParser(bytes([64, 114, 49, 10, 65, 200, 67, 10, 43, 10, 33, 33, 33, 10]), config=B.ParserConfig(check_ascii=True)).next_record()
+
+
+def test_streaming_chunks_equal_one_shot():
+    """Multi-chunk streaming (carry of the partial record/batch) yields the same batches as one chunk."""
+    import blazeseq_amd as B
+    data = O.generate_synthetic(30_000, 50, 150, 0, 40, "sanger")
+    ref = [b for b in O.StreamParser(data, O.make_config(batch_size=1000)).batches()]
+    for chunk in (1 << 16, 300_000, 1 << 30):
+        got = list(B.FastqParser(data, batch_size=1000, chunk_bytes=chunk).batches())
+        assert [len(b) for b in got] == [len(b) for b in ref]
+        for g, r in zip(got[::7], ref[::7]):
+            assert g._ends.tolist() == r.ends and g._id_ends.tolist() == r.id_ends
+            assert g._sequence_bytes.tobytes() == r.seq_bytes and g._quality_bytes.tobytes() == r.qual_bytes
+            assert g._id_bytes.tobytes() == r.id_bytes
