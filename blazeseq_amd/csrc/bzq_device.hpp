@@ -36,8 +36,6 @@ constexpr int BLOCK = 256;          // 4 waves of 64
 constexpr int PIECES = TILE / 16;   // 16-byte pieces per tile
 constexpr int MAXL = 1020;          // fast path handles tiles with <= MAXL newlines (<= 256 lines per role)
 constexpr int SEGS = 256;
-constexpr int SCAN_BLOCK = 1024;
-constexpr int SCAN_ITEMS = 4;
 
 typedef unsigned long long u64;
 
@@ -87,7 +85,12 @@ struct ByteSrc {
     const uint8_t* __restrict__ g;
     int64_t n;
     uint32_t prev_byte; // the byte before offset 0 ('\n' for a chunk that starts at a record start)
+    const uint8_t* lds; // this tile staged in LDS (bytes [t0, t0+valid)), or nullptr
+    int64_t t0;
+    int valid;
     __device__ __forceinline__ uint32_t at(int64_t pos) const {
+        const int64_t d = pos - t0;
+        if (lds && d >= 0 && d < valid) return lds[d];
         if (pos >= 0) return g[pos];
         return pos == -1 ? prev_byte : 10u;
     }
@@ -130,7 +133,7 @@ __device__ inline void header_kept(const ByteSrc& b, int64_t ls, int64_t le, boo
             int64_t p = tile_end;
             trailing = false;
             while (p < b.n) {
-                uint32_t c = b.g[p];
+                uint32_t c = b.at(p);
                 if (c == 10u) { trailing = true; break; }
                 if (!is_posix_space(c)) break;
                 ++p;
@@ -238,6 +241,7 @@ struct AggArgs {
 };
 
 __global__ __launch_bounds__(BLOCK) void k_tile_aggregate(AggArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[TILE];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
     __shared__ uint32_t s_w[4];
     __shared__ uint32_t s_a[4], s_idc[4];
@@ -246,13 +250,13 @@ __global__ __launch_bounds__(BLOCK) void k_tile_aggregate(AggArgs a) {
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     if (tid < 4) { s_a[tid] = 0; s_idc[tid] = 0; }
-    tile_load<false>(a.g, a.n, t0, valid, s_mask, nullptr);
+    tile_load<true>(a.g, a.n, t0, valid, s_mask, s_tile);
     __syncthreads();
     const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);
     const u64 m64 = s_mask64[tid];
     uint32_t c = 0;
     const uint32_t excl = block_exclusive_scan<uint32_t, 4>((uint32_t)__popcll(m64), s_w, c);
-    ByteSrc bs{a.g, a.n, a.prev_byte};
+    ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
     const bool first_starts = (bs.at(t0 - 1) == 10u);
     uint32_t la[4] = {0, 0, 0, 0}, li[4] = {0, 0, 0, 0};
     for_each_owned_line(s_mask64, m64, (int)excl, (int)c, valid, [&](int j, int start, int end, bool end_in) {
@@ -279,6 +283,17 @@ __global__ __launch_bounds__(BLOCK) void k_tile_aggregate(AggArgs a) {
 }
 
 // =================================================================================== tile scan
+// Three small kernels over the per-tile summaries (20 B per 16 KiB tile):
+//   k_scan_reduce  one workgroup per 1024 tiles: the group's summary in the same phase-agnostic
+//                  class form (a tile that starts L lines into the group contributes its class k to
+//                  group class (k+L)&3)
+//   k_scan_spine   one wave walks the group summaries with the running (line index, seq, qual, id)
+//                  carry -- the only place the line phase is resolved
+//   k_scan_down    one workgroup per group: exclusive prefix per tile from the group's carry
+constexpr int SG_THREADS = 256;
+constexpr int SG_ITEMS = 4;
+constexpr int SG_TILES = SG_THREADS * SG_ITEMS;
+
 struct ScanArgs {
     int64_t tile_begin, tile_end;
     const uint32_t* tile_c;
@@ -288,71 +303,129 @@ struct ScanArgs {
     int64_t* tileS;
     int64_t* tileQ;
     int64_t* tileI;
+    // per group (index relative to the group of tile_begin): c, a[4], idc[4], last tile with a newline
+    int64_t* grp;        // 10 x int64 per group
+    int64_t* grp_carry;  // 4 x int64 per group: P, S, Q, I at the group's first tile
     ChunkState* st;
-    int32_t first_pass; // load the carry from P0.. instead of P..
+    int32_t first_pass;  // load the carry from P0.. instead of P..
 };
 
 __device__ __forceinline__ int64_t field16(u64 v, int k) { return (int64_t)((v >> (16 * (k & 3))) & 0xFFFFull); }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tiles(ScanArgs a) {
-    __shared__ int64_t s_w[SCAN_BLOCK / 64];
-    __shared__ int64_t s_last;
+__global__ __launch_bounds__(SG_THREADS) void k_scan_reduce(ScanArgs a) {
+    __shared__ int64_t s_w[SG_THREADS / 64];
+    __shared__ u64 s_acc[10];
     const int tid = threadIdx.x;
-    int64_t cP, cS, cQ, cI;
-    if (a.first_pass) { cP = a.st->P0; cS = a.st->S0; cQ = a.st->Q0; cI = a.st->I0; }
-    else { cP = a.st->P; cS = a.st->S; cQ = a.st->Q; cI = a.st->I; }
-    if (tid == 0) s_last = a.first_pass ? -1 : a.st->last_nl_tile;
-    __syncthreads();
-    int64_t my_last = -1;
-    for (int64_t base = a.tile_begin; base < a.tile_end; base += SCAN_BLOCK * SCAN_ITEMS) {
-        const int64_t i0 = base + (int64_t)tid * SCAN_ITEMS;
-        int64_t c[SCAN_ITEMS];
-        u64 av[SCAN_ITEMS], iv[SCAN_ITEMS];
-        int64_t sum = 0;
+    if (tid < 10) s_acc[tid] = tid == 9 ? 0ull : 0ull;
+    const int64_t i0 = a.tile_begin + (int64_t)blockIdx.x * SG_TILES + (int64_t)tid * SG_ITEMS;
+    int64_t c[SG_ITEMS];
+    u64 av[SG_ITEMS], iv[SG_ITEMS];
+    int64_t sum = 0, my_last = -1;
 #pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) {
-            const int64_t i = i0 + k;
-            const bool ok = i < a.tile_end;
-            c[k] = ok ? (int64_t)a.tile_c[i] : 0;
-            av[k] = ok ? a.tile_a[i] : 0ull;
-            iv[k] = ok ? a.tile_idc[i] : 0ull;
-            if (ok && c[k] > 0) my_last = i;
-            sum += c[k];
-        }
-        int64_t tot;
-        int64_t p = cP + block_exclusive_scan<int64_t, SCAN_BLOCK / 64>(sum, s_w, tot);
-        int64_t ps[SCAN_ITEMS], sv[SCAN_ITEMS], qv[SCAN_ITEMS], dv[SCAN_ITEMS];
-        int64_t ss = 0, sq = 0, si = 0;
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) {
-            ps[k] = p;
-            const int ph = (int)(p & 3);            // role of the tile's first line
-            sv[k] = field16(av[k], 1 - ph);         // class whose role is 1 (sequence)
-            qv[k] = field16(av[k], 3 - ph);         // role 3 (quality)
-            dv[k] = field16(iv[k], 0 - ph);         // role 0 (header) after strip
-            ss += sv[k]; sq += qv[k]; si += dv[k];
-            p += c[k];
-        }
-        cP += tot;
-        int64_t tS, tQ, tI;
-        int64_t eS = cS + block_exclusive_scan<int64_t, SCAN_BLOCK / 64>(ss, s_w, tS);
-        int64_t eQ = cQ + block_exclusive_scan<int64_t, SCAN_BLOCK / 64>(sq, s_w, tQ);
-        int64_t eI = cI + block_exclusive_scan<int64_t, SCAN_BLOCK / 64>(si, s_w, tI);
-#pragma unroll
-        for (int k = 0; k < SCAN_ITEMS; ++k) {
-            const int64_t i = i0 + k;
-            if (i < a.tile_end) {
-                a.tileP[i] = ps[k]; a.tileS[i] = eS; a.tileQ[i] = eQ; a.tileI[i] = eI;
-            }
-            eS += sv[k]; eQ += qv[k]; eI += dv[k];
-        }
-        cS += tS; cQ += tQ; cI += tI;
+    for (int k = 0; k < SG_ITEMS; ++k) {
+        const int64_t i = i0 + k;
+        const bool ok = i < a.tile_end;
+        c[k] = ok ? (int64_t)a.tile_c[i] : 0;
+        av[k] = ok ? a.tile_a[i] : 0ull;
+        iv[k] = ok ? a.tile_idc[i] : 0ull;
+        if (ok && c[k] > 0) my_last = i;
+        sum += c[k];
     }
-    if (my_last >= 0) atomicMax((long long*)&s_last, (long long)my_last);
+    int64_t tot;
+    int64_t ell = block_exclusive_scan<int64_t, SG_THREADS / 64>(sum, s_w, tot);
+    int64_t A[4] = {0, 0, 0, 0}, D[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < SG_ITEMS; ++k) {
+        const int rot = (int)(ell & 3);
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            A[(cls + rot) & 3] += field16(av[k], cls);
+            D[(cls + rot) & 3] += field16(iv[k], cls);
+        }
+        ell += c[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (A[k]) atomicAdd(&s_acc[1 + k], (u64)A[k]);
+        if (D[k]) atomicAdd(&s_acc[5 + k], (u64)D[k]);
+    }
+    if (my_last >= 0) atomicMax(&s_acc[9], (u64)(my_last + 1)); // +1 so that 0 means none
     __syncthreads();
-    if (tid == 0) {
-        a.st->P = cP; a.st->S = cS; a.st->Q = cQ; a.st->I = cI;
-        a.st->last_nl_tile = s_last;
+    if (tid < 10) {
+        int64_t v = tid == 0 ? tot : (int64_t)s_acc[tid];
+        a.grp[(int64_t)blockIdx.x * 10 + tid] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_scan_spine(ScanArgs a, int64_t n_groups) {
+    __shared__ int64_t s_g[64 * 10];
+    const int lane = threadIdx.x;
+    int64_t P, S, Q, I, last;
+    if (a.first_pass) { P = a.st->P0; S = a.st->S0; Q = a.st->Q0; I = a.st->I0; last = -1; }
+    else { P = a.st->P; S = a.st->S; Q = a.st->Q; I = a.st->I; last = a.st->last_nl_tile; }
+    for (int64_t base = 0; base < n_groups; base += 64) {
+        const int64_t cnt = n_groups - base < 64 ? n_groups - base : 64;
+        for (int64_t i = lane; i < cnt * 10; i += 64) s_g[i] = a.grp[base * 10 + i];
+        __syncthreads();
+        if (lane == 0) {
+            for (int64_t b = 0; b < cnt; ++b) {
+                const int64_t* g = &s_g[b * 10];
+                int64_t* out = &a.grp_carry[(base + b) * 4];
+                out[0] = P; out[1] = S; out[2] = Q; out[3] = I;
+                const int ph = (int)(P & 3);
+                S += g[1 + ((1 - ph) & 3)];
+                Q += g[1 + ((3 - ph) & 3)];
+                I += g[5 + ((0 - ph) & 3)];
+                P += g[0];
+                if (g[9] > 0) last = g[9] - 1;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) { a.st->P = P; a.st->S = S; a.st->Q = Q; a.st->I = I; a.st->last_nl_tile = last; }
+}
+
+__global__ __launch_bounds__(SG_THREADS) void k_scan_down(ScanArgs a) {
+    __shared__ int64_t s_w[SG_THREADS / 64];
+    const int tid = threadIdx.x;
+    const int64_t* carry = &a.grp_carry[(int64_t)blockIdx.x * 4];
+    const int64_t cP = carry[0], cS = carry[1], cQ = carry[2], cI = carry[3];
+    const int64_t i0 = a.tile_begin + (int64_t)blockIdx.x * SG_TILES + (int64_t)tid * SG_ITEMS;
+    int64_t c[SG_ITEMS];
+    u64 av[SG_ITEMS], iv[SG_ITEMS];
+    int64_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SG_ITEMS; ++k) {
+        const int64_t i = i0 + k;
+        const bool ok = i < a.tile_end;
+        c[k] = ok ? (int64_t)a.tile_c[i] : 0;
+        av[k] = ok ? a.tile_a[i] : 0ull;
+        iv[k] = ok ? a.tile_idc[i] : 0ull;
+        sum += c[k];
+    }
+    int64_t tot;
+    int64_t p = cP + block_exclusive_scan<int64_t, SG_THREADS / 64>(sum, s_w, tot);
+    int64_t ps[SG_ITEMS], sv[SG_ITEMS], qv[SG_ITEMS], dv[SG_ITEMS];
+    int64_t ss = 0, sq = 0, si = 0;
+#pragma unroll
+    for (int k = 0; k < SG_ITEMS; ++k) {
+        ps[k] = p;
+        const int ph = (int)(p & 3);            // role of the tile's first line
+        sv[k] = field16(av[k], 1 - ph);         // class whose role is 1 (sequence)
+        qv[k] = field16(av[k], 3 - ph);         // role 3 (quality)
+        dv[k] = field16(iv[k], 0 - ph);         // role 0 (header) after strip
+        ss += sv[k]; sq += qv[k]; si += dv[k];
+        p += c[k];
+    }
+    int64_t tS, tQ, tI;
+    int64_t eS = cS + block_exclusive_scan<int64_t, SG_THREADS / 64>(ss, s_w, tS);
+    int64_t eQ = cQ + block_exclusive_scan<int64_t, SG_THREADS / 64>(sq, s_w, tQ);
+    int64_t eI = cI + block_exclusive_scan<int64_t, SG_THREADS / 64>(si, s_w, tI);
+#pragma unroll
+    for (int k = 0; k < SG_ITEMS; ++k) {
+        const int64_t i = i0 + k;
+        if (i < a.tile_end) { a.tileP[i] = ps[k]; a.tileS[i] = eS; a.tileQ[i] = eQ; a.tileI[i] = eI; }
+        eS += sv[k]; eQ += qv[k]; eI += dv[k];
     }
 }
 
@@ -546,7 +619,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile_emit(EmitArgs a) {
     const uint32_t excl = block_exclusive_scan<uint32_t, 4>((uint32_t)__popcll(m64), s_w, c);
     const int64_t P = a.tileP[t];
     const int64_t S = a.tileS[t], Q = a.tileQ[t], I = a.tileI[t];
-    ByteSrc bs{a.g, a.n, a.prev_byte};
+    ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
     const bool first_starts = (bs.at(t0 - 1) == 10u);
     ErrAcc err{~0ull, ~0ull};
     bool overflow = false;
@@ -814,7 +887,7 @@ __global__ __launch_bounds__(BLOCK) void k_first_newlines(const uint8_t* __restr
 // straddling record's remainder, owned by the previous shard) get negative offsets.
 __global__ void k_head(const uint8_t* __restrict__ g, int64_t n, uint32_t prev_byte, int head_lines, ChunkState* st) {
     if (threadIdx.x || blockIdx.x) return;
-    ByteSrc bs{g, n, prev_byte};
+    ByteSrc bs{g, n, prev_byte, nullptr, 0, 0};
     int64_t s0 = 0, q0 = 0, i0 = 0;
     int64_t start = 0;
     const int64_t P0 = st->P0;

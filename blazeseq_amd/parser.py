@@ -18,6 +18,7 @@ from __future__ import annotations
 import ctypes as C
 import io
 import os
+import weakref
 from dataclasses import dataclass
 from typing import Iterator, List, Optional, Tuple
 
@@ -269,7 +270,15 @@ class FastqBatch:
         self._ctx = ctx
         self._raw = raw
         self._host = None
+        self._device_valid = True
         self._quality_offset = raw.quality_offset
+
+    def _detach(self):
+        """The parser is about to recycle the chunk columns: take the host copy now, so that the
+        batch stays an owned object like the reference's FastqBatch."""
+        if self._device_valid and self._raw.num_records:
+            self._fetch()
+        self._device_valid = False
 
     def _fetch(self):
         if self._host is None:
@@ -305,7 +314,11 @@ class FastqBatch:
     def __repr__(self): return f"FastqBatch(records={self.num_records()}, quality_offset={self._quality_offset})"
 
     def to_device(self, ctx=None) -> DeviceFastqBatch:
-        """record_batch.mojo:89-90.  The columns already live on the device: zero copy."""
+        """record_batch.mojo:89-90.  The columns already live on the device: zero copy.  Valid until
+        the parser refills (call it inside the ``for batch in parser.batches()`` body)."""
+        if not self._device_valid:
+            raise RuntimeError("FastqBatch.to_device(): the parser has moved past this batch's chunk; "
+                               "call to_device() before advancing the parser")
         return DeviceFastqBatch(self._ctx, self._raw)
 
     def get_record(self, index: int) -> FastqRecord:
@@ -375,6 +388,7 @@ class FastqParser:
         self._next = 0                # next record of the current chunk to hand out
         self._terminal: Optional[Tuple[int, bytes]] = None  # (code, message) once the stream has ended
         self._eof_seen = False
+        self._live = weakref.WeakSet()   # batches handed out from the current chunk
 
     # ------------------------------------------------------------------ chunk pipeline
     def _load_chunk(self, min_records: int):
@@ -408,6 +422,9 @@ class FastqParser:
     def _retire_chunk(self):
         """Drop the current chunk; bytes from the first record not handed out become the carry
         (the chunk-level analogue of the SearchPhase resume, utils.mojo:485-487)."""
+        for b in list(self._live):
+            b._detach()
+        self._live = weakref.WeakSet()
         res, data = self._chunk, self._chunk_data
         if self._next == 0:
             cut = 0
@@ -456,7 +473,9 @@ class FastqParser:
             return FastqBatch(self._ctx, L.BzqDeviceBatch())
         raw = self._ctx.batch_view(self._next, take)
         self._next += take
-        return FastqBatch(self._ctx, raw)
+        b = FastqBatch(self._ctx, raw)
+        self._live.add(b)
+        return b
 
     def batches(self, max_records: Optional[int] = None) -> Iterator[FastqBatch]:
         """parser.mojo:267-274 + _FastqParserBatchIter 700-735: stops on an empty batch or on any

@@ -131,8 +131,8 @@ def test_synthetic_150bp_medium(validate):
     assert int(res.n_records) == 150_000 and res.status == 6
     if validate:
         # negative variant: byte flips at record indices {0, 4095, 4096, R-1}
-        for rec, pos, val, code in ((149_999, 30, 0x80, 4), (4096, 170, 0x1F, 5), (4095, 20, 0xC3, 4), (0, 165, 0x7F, 5)):
-            bad = data.copy(); bad[rec * 318 + pos] = val
+        for rec, pos, val, code in ((149_999, 30, 0x80, 4), (4096, 170, 0x1F, 5), (4095, 20, 0xC3, 4), (0, 200, 0x7F, 5)):
+            bad = data.copy(); bad[rec * (data.size // 150_000) + pos] = val
             r2, f2 = check_against_oracle(ctx, oc, bad, what=f"flip rec {rec}")
             assert r2.status == code and int(r2.n_records) == rec
     ctx.close()
@@ -193,9 +193,18 @@ def test_streaming_chunks_equal_one_shot():
     data = O.generate_synthetic(30_000, 50, 150, 0, 40, "sanger")
     ref = [b for b in O.StreamParser(data, O.make_config(batch_size=1000)).batches()]
     for chunk in (1 << 16, 300_000, 1 << 30):
+        # batches kept in a list outlive their chunk: they stay owned host objects like the reference's
         got = list(B.FastqParser(data, batch_size=1000, chunk_bytes=chunk).batches())
         assert [len(b) for b in got] == [len(b) for b in ref]
-        for g, r in zip(got[::7], ref[::7]):
+        for g, r in zip(got, ref):
             assert g._ends.tolist() == r.ends and g._id_ends.tolist() == r.id_ends
             assert g._sequence_bytes.tobytes() == r.seq_bytes and g._quality_bytes.tobytes() == r.qual_bytes
             assert g._id_bytes.tobytes() == r.id_bytes
+        # streaming use: to_device() inside the loop is a zero-copy view of the live chunk
+        n = 0
+        for g, r in zip(B.FastqParser(data, batch_size=1000, chunk_bytes=chunk).batches(), ref):
+            d = g.to_device()
+            assert d.num_records == len(r) and d.seq_len == r.ends[-1] and d.total_id_bytes == r.id_ends[-1]
+            assert d.copy_to_host()._sequence_bytes.tobytes() == r.seq_bytes
+            n += 1
+        assert n == len(ref)
