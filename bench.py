@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--validate", action="store_true", help="config 3: check_ascii + check_quality, sanger")
     ap.add_argument("--pass-bytes", type=int, default=0)
+    ap.add_argument("--two-pass", action="store_true", help="use the two-pass kernels instead of the single-pass one")
+    ap.add_argument("--kernels-v1", action="store_true", help="two-pass mode with the first-generation kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1_000_000)
     args = ap.parse_args()
@@ -86,6 +88,8 @@ def main():
                          quality_schema="sanger" if args.validate else None)
     ctx = B.Context(cfg, "generic", 4096, local_rank, pass_bytes=args.pass_bytes)
     ctx.set_option("timing_detail", 1)
+    ctx.set_option("single_pass", 0 if (args.two_pass or args.kernels_v1) else 1)
+    ctx.set_option("kernels_v2", 0 if args.kernels_v1 else 1)
 
     # ---- synthetic input, generated on the device (record i depends only on i) ------------------
     total_reads = args.reads * world
@@ -171,7 +175,7 @@ def main():
                        "pass_bytes": args.pass_bytes},
             "fraction_of_hbm_peak_input_rate": round(global_bytes / world / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {
-                "bound": "hbm", "kernel": "k_tile_emit",
+                "bound": "hbm", "kernel": "k_tile_emit" if args.kernels_v1 else ("k_fused<LB=false>" if args.two_pass else "k_fused<LB=true>"),
                 "achieved": round(A * per_rank_records / emit_s / 1e9, 2) if emit_s > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(A * per_rank_records / emit_s / 1e9 / HBM_PEAK_GBS, 4) if emit_s > 0 else None,

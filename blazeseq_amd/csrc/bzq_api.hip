@@ -7,7 +7,7 @@
 // three synchronisations per 4096 records.  There is NO CPU fallback: without a gfx950 device
 // bzq_create fails.
 #include "../../include/blazeseq_hip.h"
-#include "bzq_device.hpp"
+#include "bzq_fused.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -71,14 +71,15 @@ struct bzq_ctx {
     DevBuf in, seq, qual, id;
     DevBuf ends, id_ends, rec_end, b_ends, b_id_ends, off[4], view_e, view_i;
     int64_t rec_cap = 0;
-    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, grp_carry;
+    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, grp_carry, desc;
     int64_t tile_cap = 0;
     ChunkState* d_state = nullptr;
     ChunkState* h_state = nullptr; // pinned
     hipEvent_t ev[8]{};
     std::vector<hipEvent_t> ev_detail;
     // options
-    int force_dense = 0, timing_detail = 0;
+    int force_dense = 0, timing_detail = 0, single_pass = 1, v2 = 1;
+    bool ran_single_pass = false;
     // current chunk
     const uint8_t* cur = nullptr;
     uint64_t cur_n = 0, cur_stream_pos = 0;
@@ -136,7 +137,7 @@ int ensure_chunk_arenas(bzq_ctx* c, uint64_t n, bool need_input) {
             (rc = ensure(c, c->tile_idc, nt * 8)) || (rc = ensure(c, c->tileP, nt * 8)) ||
             (rc = ensure(c, c->tileS, nt * 8)) || (rc = ensure(c, c->tileQ, nt * 8)) ||
             (rc = ensure(c, c->tileI, nt * 8)) || (rc = ensure(c, c->grp, (nt / SG_TILES + 2) * 80)) ||
-            (rc = ensure(c, c->grp_carry, (nt / SG_TILES + 2) * 32)))
+            (rc = ensure(c, c->grp_carry, (nt / SG_TILES + 2) * 32)) || (rc = ensure(c, c->desc, (nt * 5 + 8) * 8)))
             return rc;
         c->tile_cap = nt;
     }
@@ -191,6 +192,50 @@ EmitArgs make_emit_args(bzq_ctx* c) {
     return e;
 }
 
+template <bool CA, bool CQ, bool LB>
+void launch_fused_off(bool offs, dim3 grid, hipStream_t s, const FusedArgs& a) {
+    if (offs) hipLaunchKernelGGL((k_fused<CA, CQ, true, LB>), grid, dim3(BLOCK), 0, s, a);
+    else hipLaunchKernelGGL((k_fused<CA, CQ, false, LB>), grid, dim3(BLOCK), 0, s, a);
+}
+template <bool LB>
+void launch_fused(const bzq_ctx* c, dim3 grid, const FusedArgs& f) {
+    const bool ca = c->cfg.check_ascii != 0, cq = c->cfg.check_quality != 0, off = c->cfg.emit_offsets != 0;
+    if (ca && cq) launch_fused_off<true, true, LB>(off, grid, c->stream, f);
+    else if (ca) launch_fused_off<true, false, LB>(off, grid, c->stream, f);
+    else if (cq) launch_fused_off<false, true, LB>(off, grid, c->stream, f);
+    else launch_fused_off<false, false, LB>(off, grid, c->stream, f);
+}
+FusedArgs make_fused_args(bzq_ctx* c) {
+    FusedArgs f{};
+    f.g = c->cur; f.n = (int64_t)c->cur_n; f.prev_byte = c->cur_prev_byte; f.n_tiles = tiles_for(c->cur_n);
+    f.tileP = (const int64_t*)c->tileP.p; f.tileS = (const int64_t*)c->tileS.p;
+    f.tileQ = (const int64_t*)c->tileQ.p; f.tileI = (const int64_t*)c->tileI.p;
+    f.col_seq = (uint8_t*)c->seq.p; f.col_qual = (uint8_t*)c->qual.p; f.col_id = (uint8_t*)c->id.p;
+    f.ends = (int64_t*)c->ends.p; f.id_ends = (int64_t*)c->id_ends.p; f.rec_end = (int64_t*)c->rec_end.p;
+    f.rec_cap = c->rec_cap;
+    f.o_hdr = (int64_t*)c->off[0].p; f.o_seq = (int64_t*)c->off[1].p;
+    f.o_sep = (int64_t*)c->off[2].p; f.o_qual = (int64_t*)c->off[3].p;
+    f.st = c->d_state; f.q_lower = c->cfg.q_lower; f.q_upper = c->cfg.q_upper; f.force_dense = c->force_dense;
+    return f;
+}
+
+// One launch for the whole chunk (single-pass kernel, bzq_fused.hpp).
+int enqueue_fused(bzq_ctx* c) {
+    const int64_t nt = tiles_for(c->cur_n);
+    u64* d = (u64*)c->desc.p;
+    hipError_t e = hipMemsetAsync(d, 0, (size_t)(nt * 5 + 8) * 8, c->stream);
+    if (e != hipSuccess) { c->err = std::string("hipMemsetAsync(desc): ") + hipGetErrorString(e); return BZQ_ERR_HIP; }
+    FusedArgs f = make_fused_args(c);
+    f.ticket = d; f.desc_c = d + 8; f.desc_agg = d + 8 + nt; f.desc_pre = d + 8 + 2 * nt;
+    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    launch_fused<true>(c, dim3((unsigned)nt), f);
+    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    c->n_passes = 1;
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { c->err = std::string("kernel launch: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
+    return 0;
+}
+
 void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, bool first_pass) {
     ScanArgs s{tb, te, (const uint32_t*)c->tile_c.p, (const u64*)c->tile_a.p, (const u64*)c->tile_idc.p,
                (int64_t*)c->tileP.p, (int64_t*)c->tileS.p, (int64_t*)c->tileQ.p, (int64_t*)c->tileI.p,
@@ -213,31 +258,38 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
         // and the tiles touched by the appended halo change
         AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, 0, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
                   (u64*)c->tile_idc.p};
-        hipLaunchKernelGGL(k_tile_aggregate, dim3(1), dim3(BLOCK), 0, c->stream, a);
+        hipLaunchKernelGGL(k_tile_aggregate2, dim3(1), dim3(BLOCK), 0, c->stream, a);
         const int64_t tb = std::max<int64_t>(1, (int64_t)(c->agg_n / TILE));
         if (tb < nt) {
             a.tile_begin = tb;
-            hipLaunchKernelGGL(k_tile_aggregate, dim3((unsigned)(nt - tb)), dim3(BLOCK), 0, c->stream, a);
+            hipLaunchKernelGGL(k_tile_aggregate2, dim3((unsigned)(nt - tb)), dim3(BLOCK), 0, c->stream, a);
         }
     }
     for (int64_t tb = 0; tb < nt; tb += pt, ++passes) {
         const int64_t te = std::min(nt, tb + pt);
         const dim3 grid((unsigned)(te - tb));
         if (!emit_only) {
-            if (c->timing_detail) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
+            if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
             if (!skip_aggregate_mid) {
                 AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, (uint32_t*)c->tile_c.p,
                           (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
-                hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
+                if (c->v2) hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
+                else hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
             }
-            if (c->timing_detail) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
+            if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
             launch_scan(c, tb, te, tb == 0);
-            if (c->timing_detail) { hipEvent_t e; hipEventCreate(&e); hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
+            if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
         }
-        EmitArgs e = make_emit_args(c);
-        e.tile_begin = tb;
-        launch_emit(c, grid, e);
-        if (!emit_only && c->timing_detail) { hipEvent_t ev; hipEventCreate(&ev); hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+        if (c->v2) {
+            FusedArgs f = make_fused_args(c);
+            f.tile_begin = tb;
+            launch_fused<false>(c, grid, f);
+        } else {
+            EmitArgs e = make_emit_args(c);
+            e.tile_begin = tb;
+            launch_emit(c, grid, e);
+        }
+        if (!emit_only && c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
     }
     c->n_passes = passes;
     hipError_t le = hipGetLastError();
@@ -268,7 +320,9 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     if (head_lines > 0)
         hipLaunchKernelGGL(k_head, dim3(1), dim3(64), 0, c->stream, d_data, (int64_t)n, prev_byte, head_lines, c->d_state);
     if (n > 0) {
-        if ((rc = enqueue_passes(c, false, reuse_aggregates))) return rc;
+        c->ran_single_pass = c->single_pass != 0;
+        if (c->ran_single_pass) { if ((rc = enqueue_fused(c))) return rc; }
+        else if ((rc = enqueue_passes(c, false, reuse_aggregates))) return rc;
         hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state);
     }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -414,7 +468,7 @@ void bzq_destroy(bzq_ctx* c) {
     DevBuf* bufs[] = {&c->in, &c->seq, &c->qual, &c->id, &c->ends, &c->id_ends, &c->rec_end, &c->b_ends,
                       &c->b_id_ends, &c->off[0], &c->off[1], &c->off[2], &c->off[3], &c->view_e, &c->view_i,
                       &c->tile_c, &c->tile_a,
-                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->grp_carry};
+                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->grp_carry, &c->desc};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->d_state) hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
@@ -445,6 +499,8 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return BZQ_ERR_ARG;
     if (!strcmp(key, "force_dense")) c->force_dense = (int)value;
     else if (!strcmp(key, "timing_detail")) c->timing_detail = (int)value;
+    else if (!strcmp(key, "single_pass")) c->single_pass = (int)value;
+    else if (!strcmp(key, "kernels_v2")) c->v2 = (int)value;
     else if (!strcmp(key, "pass_bytes")) c->cfg.pass_bytes = value > 0 ? std::max<int64_t>(TILE, (value / TILE) * TILE) : 0;
     else { c->err = std::string("unknown option ") + key; return BZQ_ERR_ARG; }
     return 0;
@@ -482,17 +538,35 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     ChunkState* h = c->h_state;
     HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
+    if (h->lookback_timeout && c->cur_n > 0) {
+        // never expected: the single-pass kernel gave up on a predecessor tile.  Same chunk again on
+        // the two-pass kernels (no inter-workgroup waiting).
+        ChunkState fresh = *h;
+        fresh.P = fresh.P0; fresh.S = fresh.S0; fresh.Q = fresh.Q0; fresh.I = fresh.I0;
+        fresh.last_nl_tile = -1; fresh.rec_overflow = 0; fresh.lookback_timeout = 0; fresh.dense_tiles = 0;
+        fresh.err_struct = ~0ull; fresh.err_valid = ~0ull; fresh.err_buf = ~0ull;
+        *h = fresh;
+        HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
+        int rc;
+        c->ran_single_pass = false;
+        if ((rc = enqueue_passes(c, false, false))) return rc;
+        hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)c->cur_n, c->d_state);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
+    }
     if (h->rec_overflow) {
-        // shorter records than the sizing hint assumed: re-size to the exact count, re-run the emit pass
+        // shorter records than the sizing hint assumed: re-size to the exact count, re-run
         const int64_t need = std::max<int64_t>(0, h->P >> 2) + 2;
         int rc;
         if ((rc = ensure_record_arenas(c, need + 1024))) return rc;
         ChunkState fresh = *h;
         fresh.rec_overflow = 0; fresh.err_struct = ~0ull; fresh.err_valid = ~0ull; fresh.err_buf = ~0ull;
         fresh.dense_tiles = 0;
+        if (c->ran_single_pass) { fresh.last_nl_tile = -1; }
         *h = fresh;
         HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
-        if ((rc = enqueue_passes(c, true, false))) return rc;
+        if (c->ran_single_pass) { if ((rc = enqueue_fused(c))) return rc; }
+        else if ((rc = enqueue_passes(c, true, false))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
         if (h->rec_overflow) { c->err = "record arrays still too small after re-size"; return BZQ_ERR_NOMEM; }
@@ -636,7 +710,11 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     hipEventElapsedTime(&ms1, c->ev[2], c->ev[3]);
     r.ms_total = ms0 + ms1;
     r.ms_rebase = ms1;
-    if (c->timing_detail && c->ev_detail.size() >= 4) {
+    if (c->timing_detail && c->ran_single_pass && c->ev_detail.size() >= 2) {
+        float d = 0;
+        hipEventElapsedTime(&d, c->ev_detail[c->ev_detail.size() - 2], c->ev_detail[c->ev_detail.size() - 1]);
+        r.ms_emit = d;
+    } else if (c->timing_detail && c->ev_detail.size() >= 4) {
         for (size_t i = 0; i + 3 < c->ev_detail.size(); i += 4) {
             float a = 0, b = 0, d = 0;
             hipEventElapsedTime(&a, c->ev_detail[i], c->ev_detail[i + 1]);
@@ -810,7 +888,7 @@ int32_t bzq_shard_scan(bzq_ctx* c, const uint8_t* d_data, uint64_t n, bzq_shard_
     HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
     const int64_t nt = tiles_for(n);
     AggArgs a{d_data, (int64_t)n, 10u, 0, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
-    hipLaunchKernelGGL(k_tile_aggregate, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
+    hipLaunchKernelGGL(k_tile_aggregate2, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
     launch_scan(c, 0, nt, true);
     hipLaunchKernelGGL(k_first_newlines, dim3(1), dim3(BLOCK), 0, c->stream, d_data, (int64_t)n, c->d_state);
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -55,6 +55,8 @@ struct ChunkState {
     int64_t dense_tiles;      // tiles that took the serial path (diagnostics)
     int64_t max_record_len;
     int64_t first_nl[4];      // offsets of the first four newlines (shard stitch), -1 if absent
+    int32_t lookback_timeout; // single-pass kernel gave up waiting for a predecessor tile (never expected)
+    int32_t _pad;
 };
 
 __device__ __forceinline__ bool is_posix_space(uint32_t c) {

@@ -1,0 +1,568 @@
+// bzq_fused.hpp -- single-pass version of the FASTQ batch-parse path (default mode).
+//
+// One launch, one read of the input: every 16 KiB tile is loaded once (coalesced 16 B/lane into
+// LDS), analysed, and its sequence / quality / id streams are gathered straight into the packed
+// FastqBatch columns.  The two cross-tile dependencies
+//   (1) the line index of the tile's first byte        -> which lines are header/seq/'+'/quality
+//   (2) the column offsets of the tile's three streams -> where the bytes go
+// are resolved in-kernel by two decoupled look-backs over 8-byte {flag, value} granules (relaxed
+// agent-scope atomics: the data IS the flag, MI355X_MICROARCH.md "R2"), with tiles numbered by an
+// atomic ticket so a workgroup only ever waits on workgroups that have already started.  Spins are
+// bounded: on timeout the kernel flags ChunkState::lookback_timeout and the host re-runs the chunk
+// on the two-pass kernels of bzq_device.hpp (same results, one more read of the input).
+//
+// Reference semantics implemented here: see the header of bzq_device.hpp (same citations).
+#pragma once
+#include "bzq_device.hpp"
+
+namespace bzq {
+
+constexpr u64 DESC_A = 1ull << 62;              // granule holds this tile's own aggregate
+constexpr u64 DESC_P = 2ull << 62;              // granule holds the inclusive prefix through this tile
+constexpr u64 DESC_VMASK = (1ull << 62) - 1ull;
+constexpr int64_t DESC_BIAS = 1ll << 44;        // prefixes may be slightly negative (shard head)
+constexpr int SPIN_LIMIT = 1 << 21;
+
+__device__ __forceinline__ u64 ld_agent(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(u64* p, u64 v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int64_t wave_sum(int64_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+struct FusedArgs {
+    const uint8_t* g;
+    int64_t n;
+    uint32_t prev_byte;
+    int64_t n_tiles;
+    u64* ticket;     // 1 word, zeroed before the launch
+    u64* desc_c;     // [n_tiles]   newline count aggregate / inclusive line prefix
+    u64* desc_agg;   // [n_tiles]   packed (seq, qual, id) byte counts of the tile
+    u64* desc_pre;   // [3*n_tiles] inclusive column prefixes S, Q, I
+    // LB == false: prefixes come from the tile scan (k_tile_aggregate2 + k_scan_*)
+    int64_t tile_begin;
+    const int64_t* tileP;
+    const int64_t* tileS;
+    const int64_t* tileQ;
+    const int64_t* tileI;
+    uint8_t* col_seq;
+    uint8_t* col_qual;
+    uint8_t* col_id;
+    int64_t* ends;
+    int64_t* id_ends;
+    int64_t* rec_end;
+    int64_t rec_cap;
+    int64_t* o_hdr;
+    int64_t* o_seq;
+    int64_t* o_sep;
+    int64_t* o_qual;
+    ChunkState* st;
+    uint32_t q_lower, q_upper;
+    int32_t force_dense;
+};
+
+// Exclusive line prefix of tile t (wave 0, all 64 lanes).  Lane i inspects predecessor t-1-i.
+__device__ inline int64_t lookback_lines(const u64* desc_c, int64_t t, int64_t P0, int lane, ChunkState* st) {
+    if (t == 0) return P0;
+    int64_t running = 0, base = t - 1;
+    int spins = 0;
+    for (;;) {
+        const int64_t p = base - lane;
+        const u64 g = p >= 0 ? ld_agent(&desc_c[p]) : (DESC_P | (u64)(P0 + DESC_BIAS));
+        const int flag = (int)(g >> 62);
+        const u64 pm = __ballot(flag == 2), xm = __ballot(flag == 0);
+        const int f = pm ? __builtin_ctzll(pm) : 64;
+        const u64 nearer = f >= 64 ? ~0ull : ((1ull << f) - 1ull);
+        if (xm & nearer) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > SPIN_LIMIT) { if (lane == 0) st->lookback_timeout = 1; return running; }
+            continue;
+        }
+        int64_t v = (int64_t)(g & DESC_VMASK);
+        if (flag == 2) v -= DESC_BIAS;
+        running += wave_sum(lane <= f ? v : 0);
+        if (f < 64) return running;
+        base -= 64;
+    }
+}
+
+struct Cols { int64_t s, q, d; };
+
+__device__ inline Cols lookback_cols(const u64* desc_agg, const u64* desc_pre, int64_t t, int64_t S0, int64_t Q0,
+                                     int64_t I0, int lane, ChunkState* st) {
+    if (t == 0) return Cols{S0, Q0, I0};
+    Cols run{0, 0, 0};
+    int64_t base = t - 1;
+    int spins = 0;
+    for (;;) {
+        const int64_t p = base - lane;
+        int flag = 0;
+        int64_t vs = 0, vq = 0, vd = 0;
+        if (p < 0) { flag = 2; vs = S0; vq = Q0; vd = I0; }
+        else {
+            const u64 a = ld_agent(&desc_pre[3 * p]), b = ld_agent(&desc_pre[3 * p + 1]), c = ld_agent(&desc_pre[3 * p + 2]);
+            if ((a >> 62) == 2 && (b >> 62) == 2 && (c >> 62) == 2) {
+                flag = 2;
+                vs = (int64_t)(a & DESC_VMASK) - DESC_BIAS;
+                vq = (int64_t)(b & DESC_VMASK) - DESC_BIAS;
+                vd = (int64_t)(c & DESC_VMASK) - DESC_BIAS;
+            } else {
+                const u64 ag = ld_agent(&desc_agg[p]);
+                if ((ag >> 62) == 1) {
+                    flag = 1;
+                    vs = (int64_t)(ag & 0xFFFFFull); vq = (int64_t)((ag >> 20) & 0xFFFFFull); vd = (int64_t)((ag >> 40) & 0xFFFFFull);
+                }
+            }
+        }
+        const u64 pm = __ballot(flag == 2), xm = __ballot(flag == 0);
+        const int f = pm ? __builtin_ctzll(pm) : 64;
+        const u64 nearer = f >= 64 ? ~0ull : ((1ull << f) - 1ull);
+        if (xm & nearer) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > SPIN_LIMIT) { if (lane == 0) st->lookback_timeout = 1; return run; }
+            continue;
+        }
+        const bool use = lane <= f;
+        run.s += wave_sum(use ? vs : 0);
+        run.q += wave_sum(use ? vq : 0);
+        run.d += wave_sum(use ? vd : 0);
+        if (f < 64) return run;
+        base -= 64;
+    }
+}
+
+__device__ __forceinline__ uint32_t bytes_from_mask(int i, int x) {
+    // mask of the bytes of dword i (piece bytes 4i..4i+3) at piece offset >= x
+    int lo = x - 4 * i;
+    lo = lo < 0 ? 0 : lo;
+    return lo >= 4 ? 0u : (0xFFFFFFFFu << (8 * lo));
+}
+
+template <int ROLE, bool CA, bool CQ>
+__device__ __forceinline__ void validate_window(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int a, int b,
+                                                int64_t rec, uint32_t qlo, uint32_t qhi, ErrAcc& err) {
+    if (!(CA || (CQ && ROLE == 3))) return;
+    if (a > 0 || b < 16) {
+        const uint32_t m0 = byte_range_mask(0, a, b), m1 = byte_range_mask(1, a, b), m2 = byte_range_mask(2, a, b),
+                       m3 = byte_range_mask(3, a, b);
+        const uint32_t fill = (CQ && ROLE == 3) ? 0x01010101u * qlo : 0u;
+        w0 = (w0 & m0) | (fill & ~m0); w1 = (w1 & m1) | (fill & ~m1);
+        w2 = (w2 & m2) | (fill & ~m2); w3 = (w3 & m3) | (fill & ~m3);
+    }
+    if (CA && any_non_ascii(w0 | w1 | w2 | w3)) err.valid(rec, 4);
+    if (CQ && ROLE == 3) {
+        if (any_out_of_range(w0, qlo, qhi) | any_out_of_range(w1, qlo, qhi) | any_out_of_range(w2, qlo, qhi) |
+            any_out_of_range(w3, qlo, qhi))
+            err.valid(rec, 5);
+    }
+}
+
+// Same contract as gather_role (bzq_device.hpp), restructured: the piece's first window is read
+// unconditionally; only lanes whose piece crosses into further segments run the merge loop.
+template <int ROLE, bool CA, bool CQ>
+__device__ __forceinline__ void gather_role2(uint8_t* __restrict__ col, int64_t D, int n_role, const uint16_t* seg_src,
+                                             const uint16_t* seg_len, const uint16_t* seg_dst, int nk,
+                                             const uint8_t* s_tile, int64_t line0, uint32_t qlo, uint32_t qhi, ErrAcc& err) {
+    if (n_role <= 0) return;
+    const int tid = threadIdx.x;
+    const int64_t hi_abs = D + n_role;
+    const int64_t pa = D >> 4, pb = (hi_abs - 1) >> 4;
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tile - 16);
+    for (int64_t pi = pa + tid; pi <= pb; pi += BLOCK) {
+        const int64_t p0 = pi << 4;
+        if (p0 + 16 <= 0) continue;
+        int xl = (int)(D > p0 ? D - p0 : 0);
+        const int xh = (int)(hi_abs - p0 < 16 ? hi_abs - p0 : 16);
+        if (p0 < 0 && xl < (int)(-p0)) xl = (int)(-p0);
+        int o = (int)(p0 - D) + xl;
+        int lo = 0, hi = nk;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if ((int)seg_dst[mid] <= o) lo = mid + 1; else hi = mid;
+        }
+        int k = lo - 1;
+        const int dk = (int)seg_dst[k], lk = (int)seg_len[k];
+        int take = dk + lk - o;
+        if (take > xh - xl) take = xh - xl;
+        uint32_t a0, a1, a2, a3;
+        {
+            const int ws = (int)seg_src[k] + (o - dk) - xl + 16;
+            const int wd = ws >> 2, sh = ws & 3;
+            const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
+            a0 = __builtin_amdgcn_alignbyte(d1, d0, sh); a1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+            a2 = __builtin_amdgcn_alignbyte(d3, d2, sh); a3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+        }
+        validate_window<ROLE, CA, CQ>(a0, a1, a2, a3, xl, xl + take, (line0 + 4 * (int64_t)k) >> 2, qlo, qhi, err);
+        int x = xl + take;
+        while (x < xh) { // the piece continues in the next non-empty segment(s)
+            do { ++k; } while (seg_len[k] == 0);
+            int tk = (int)seg_len[k];
+            if (tk > xh - x) tk = xh - x;
+            const int ws = (int)seg_src[k] - x + 16;
+            const int wd = ws >> 2, sh = ws & 3;
+            const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
+            const uint32_t b0 = __builtin_amdgcn_alignbyte(d1, d0, sh), b1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                           b2 = __builtin_amdgcn_alignbyte(d3, d2, sh), b3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+            const uint32_t m0 = bytes_from_mask(0, x), m1 = bytes_from_mask(1, x), m2 = bytes_from_mask(2, x),
+                           m3 = bytes_from_mask(3, x);
+            a0 = (b0 & m0) | (a0 & ~m0); a1 = (b1 & m1) | (a1 & ~m1);
+            a2 = (b2 & m2) | (a2 & ~m2); a3 = (b3 & m3) | (a3 & ~m3);
+            validate_window<ROLE, CA, CQ>(b0, b1, b2, b3, x, x + tk, (line0 + 4 * (int64_t)k) >> 2, qlo, qhi, err);
+            x += tk;
+        }
+        if (xl == 0 && xh == 16) {
+            *reinterpret_cast<uint4*>(col + p0) = make_uint4(a0, a1, a2, a3);
+        } else {
+            const uint32_t acc[4] = {a0, a1, a2, a3};
+            for (int i = xl; i < xh; ++i) col[p0 + i] = (uint8_t)(acc[i >> 2] >> (8 * (i & 3)));
+        }
+    }
+}
+
+template <bool CA, bool CQ, bool OFFS, bool LB>
+__global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
+    __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
+    __shared__ uint16_t s_nl[MAXL + 4];
+    __shared__ uint16_t s_src[3][SEGS], s_len[3][SEGS], s_dst[3][SEGS];
+    __shared__ u64 s_w64[4];
+    __shared__ uint32_t s_w[4];
+    __shared__ int64_t s_bcast[4];   // tile, P / S, Q, I
+    __shared__ int s_cnt[3];
+    uint8_t* s_tile = s_tile_raw + 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    if (LB) {
+        if (tid == 0) s_bcast[0] = (int64_t)atomicAdd(a.ticket, 1ull);
+        __syncthreads();
+    }
+    const int64_t t = LB ? s_bcast[0] : a.tile_begin + (int64_t)blockIdx.x;
+    const int64_t t0 = t * TILE;
+    const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+    tile_load<true>(a.g, a.n, t0, valid, s_mask, s_tile);
+    ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
+    const bool first_starts = (bs.at(t0 - 1) == 10u);
+    __syncthreads();
+    const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);
+    const u64 m64 = s_mask64[tid];
+    uint32_t c = 0;
+    const uint32_t excl = block_exclusive_scan<uint32_t, 4>((uint32_t)__popcll(m64), s_w, c);
+    const bool dense = ((int)c > MAXL) || a.force_dense;
+
+    // ---- look-back 1: line index of the tile's first line --------------------------------------
+    if (LB && wave == 0) {
+        if (lane == 0 && t > 0) st_agent(&a.desc_c[t], DESC_A | (u64)c);
+        const int64_t Pex = lookback_lines(a.desc_c, t, a.st->P0, lane, a.st);
+        if (lane == 0) {
+            st_agent(&a.desc_c[t], DESC_P | (u64)(Pex + (int64_t)c + DESC_BIAS));
+            s_bcast[1] = Pex;
+        }
+    }
+    if (!dense) { // newline position table (other waves overlap this with wave 0's look-back)
+        u64 m = m64;
+        int idx = 0;
+        while (m) {
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1;
+            s_nl[excl + idx] = (uint16_t)(tid * 64 + bit);
+            ++idx;
+        }
+    }
+    __syncthreads();
+    const int64_t P = LB ? s_bcast[1] : a.tileP[t];
+    ErrAcc err{~0ull, ~0ull};
+    bool overflow = false;
+    const int ph = (int)(P & 3);
+
+    // walks every line of the tile serially (any input): used by the dense path, count then emit
+    auto dense_walk = [&](bool emit, int64_t S, int64_t Q, int64_t I, int64_t& ns, int64_t& nq, int64_t& ni) {
+        int64_t rs = S, rq = Q, ri = I;
+        int j = 0, line_start = 0;
+        bool start_in = first_starts;
+        auto handle = [&](int start, int end, bool end_in) {
+            const int64_t L = P + j;
+            const int role = (int)(L & 3);
+            const int64_t rec = L >> 2;
+            const int64_t ls = t0 + start, le = t0 + end;
+            const bool sin = start_in && start < valid;
+            if (role == 0) {
+                if (emit && sin) {
+                    if (s_tile[start] != 64) err.structure(rec, 1);
+                    if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_hdr[rec] = ls;
+                }
+                int64_t lo = ls, hi = ls;
+                if (end > start) header_kept(bs, ls, le, start_in, end_in, t0 + valid, lo, hi);
+                if (emit)
+                    for (int64_t p = lo; p < hi; ++p) {
+                        const uint8_t ch = s_tile[p - t0];
+                        if (CA && (ch & 0x80)) err.valid(rec, 4);
+                        if (ri + (p - lo) >= 0) a.col_id[ri + (p - lo)] = ch;
+                    }
+                ri += hi - lo;
+                if (emit && end_in && rec >= 0) { if (rec < a.rec_cap) a.id_ends[rec] = ri; else overflow = true; }
+            } else if (role == 1) {
+                if (emit && sin && OFFS && rec >= 0 && rec < a.rec_cap) a.o_seq[rec] = ls;
+                if (emit)
+                    for (int p = start; p < end; ++p) {
+                        const uint8_t ch = s_tile[p];
+                        if (CA && (ch & 0x80)) err.valid(rec, 4);
+                        if (rs + (p - start) >= 0) a.col_seq[rs + (p - start)] = ch;
+                    }
+                rs += end - start;
+            } else if (role == 2) {
+                if (emit && sin) {
+                    if (s_tile[start] != 43) err.structure(rec, 2);
+                    if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_sep[rec] = ls;
+                }
+            } else {
+                if (emit && sin && OFFS && rec >= 0 && rec < a.rec_cap) a.o_qual[rec] = ls;
+                if (emit)
+                    for (int p = start; p < end; ++p) {
+                        const uint8_t ch = s_tile[p];
+                        if (CA && (ch & 0x80)) err.valid(rec, 4);
+                        if (CQ && (uint32_t)((ch - a.q_lower) & 0xFFu) > (a.q_upper - a.q_lower)) err.valid(rec, 5);
+                        if (rq + (p - start) >= 0) a.col_qual[rq + (p - start)] = ch;
+                    }
+                rq += end - start;
+                if (emit && end_in && rec >= 0) {
+                    if (rec < a.rec_cap) { a.ends[rec] = rq; a.rec_end[rec] = le; } else overflow = true;
+                    if (rs != rq) err.structure(rec, 3);
+                }
+            }
+        };
+        for (int w = 0; w < BLOCK; ++w) {
+            u64 m = s_mask64[w];
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int nl = w * 64 + bit;
+                handle(line_start, nl, true);
+                line_start = nl + 1;
+                start_in = true;
+                ++j;
+            }
+        }
+        handle(line_start, valid, false);
+        ns = rs - S; nq = rq - Q; ni = ri - I;
+    };
+
+    int n_id = 0, n_seq = 0, n_qual = 0;
+    if (dense) {
+        if (LB) {
+            if (tid == 0) {
+                int64_t ns, nq, ni;
+                dense_walk(false, 0, 0, 0, ns, nq, ni);
+                s_cnt[0] = (int)ni; s_cnt[1] = (int)ns; s_cnt[2] = (int)nq;
+            }
+            __syncthreads();
+            n_id = s_cnt[0]; n_seq = s_cnt[1]; n_qual = s_cnt[2];
+        }
+    } else {
+        // ---- line pass: thread k owns lines 4k..4k+3 = one line of every role (role of line
+        // 4k+r is (P+r)&3 for every k, so each unrolled step is branch-uniform) -------------------
+        uint32_t lh = 0, lsq = 0, lq = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 4 * tid + r;
+            const int role = (ph + r) & 3;
+            if (j <= (int)c) {
+                const int start = j ? (int)s_nl[j - 1] + 1 : 0;
+                const bool end_in = j < (int)c;
+                const int end = end_in ? (int)s_nl[j] : valid;
+                const int64_t rec = (P + j) >> 2;
+                const bool sknown = j > 0 ? true : first_starts;
+                const bool sin = sknown && start < valid;
+                const int64_t ls = t0 + start;
+                if (role == 0) {
+                    if (sin) {
+                        if (s_tile[start] != 64) err.structure(rec, 1);   // '@', utils.mojo:454
+                        if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_hdr[rec] = ls;
+                    }
+                    int64_t lo = ls, hi = ls;
+                    if (end > start) header_kept(bs, ls, t0 + end, sknown, end_in, t0 + valid, lo, hi);
+                    s_src[0][tid] = (uint16_t)(lo - t0);
+                    lh = (uint32_t)(hi - lo);
+                } else if (role == 1) {
+                    if (sin && OFFS && rec >= 0 && rec < a.rec_cap) a.o_seq[rec] = ls;
+                    s_src[1][tid] = (uint16_t)start;
+                    lsq = (uint32_t)(end - start);
+                } else if (role == 2) {
+                    if (sin) {
+                        if (s_tile[start] != 43) err.structure(rec, 2);   // '+', utils.mojo:456
+                        if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_sep[rec] = ls;
+                    }
+                } else {
+                    if (sin && OFFS && rec >= 0 && rec < a.rec_cap) a.o_qual[rec] = ls;
+                    s_src[2][tid] = (uint16_t)start;
+                    lq = (uint32_t)(end - start);
+                }
+            }
+        }
+        s_len[0][tid] = (uint16_t)lh; s_len[1][tid] = (uint16_t)lsq; s_len[2][tid] = (uint16_t)lq;
+        const u64 packed = (u64)lh | ((u64)lsq << 21) | ((u64)lq << 42);
+        u64 tot = 0;
+        const u64 ex = block_exclusive_scan<u64, 4>(packed, s_w64, tot);
+        s_dst[0][tid] = (uint16_t)(ex & 0x1FFFFFull);
+        s_dst[1][tid] = (uint16_t)((ex >> 21) & 0x1FFFFFull);
+        s_dst[2][tid] = (uint16_t)((ex >> 42) & 0x1FFFFFull);
+        n_id = (int)(tot & 0x1FFFFFull); n_seq = (int)((tot >> 21) & 0x1FFFFFull); n_qual = (int)((tot >> 42) & 0x1FFFFFull);
+    }
+
+    // ---- look-back 2: column offsets --------------------------------------------------------------
+    if (LB && wave == 0) {
+        if (lane == 0 && t > 0)
+            st_agent(&a.desc_agg[t], DESC_A | (u64)n_seq | ((u64)n_qual << 20) | ((u64)n_id << 40));
+        const Cols ex = lookback_cols(a.desc_agg, a.desc_pre, t, a.st->S0, a.st->Q0, a.st->I0, lane, a.st);
+        if (lane == 0) {
+            st_agent(&a.desc_pre[3 * t], DESC_P | (u64)(ex.s + n_seq + DESC_BIAS));
+            st_agent(&a.desc_pre[3 * t + 1], DESC_P | (u64)(ex.q + n_qual + DESC_BIAS));
+            st_agent(&a.desc_pre[3 * t + 2], DESC_P | (u64)(ex.d + n_id + DESC_BIAS));
+            s_bcast[1] = ex.s; s_bcast[2] = ex.q; s_bcast[3] = ex.d;
+            if (t == a.n_tiles - 1) { // totals for the host
+                a.st->P = P + (int64_t)c; a.st->S = ex.s + n_seq; a.st->Q = ex.q + n_qual; a.st->I = ex.d + n_id;
+            }
+            if (c > 0) atomicMax((long long*)&a.st->last_nl_tile, (long long)t);
+        }
+    }
+    __syncthreads();
+    const int64_t S = LB ? s_bcast[1] : a.tileS[t], Q = LB ? s_bcast[2] : a.tileQ[t], I = LB ? s_bcast[3] : a.tileI[t];
+
+    if (dense) {
+        if (tid == 0) {
+            int64_t ns, nq, ni;
+            dense_walk(true, S, Q, I, ns, nq, ni);
+            atomicAdd((u64*)&a.st->dense_tiles, 1ull);
+        }
+    } else {
+        // ---- per-record outputs of lines that END in this tile --------------------------------------
+        const int jh = (0 - ph) & 3, jq = (3 - ph) & 3;
+        {
+            const int j = 4 * tid + jh;           // this thread's header line
+            const int64_t rec = (P + j) >> 2;
+            if (j < (int)c && rec >= 0) {
+                if (rec < a.rec_cap) a.id_ends[rec] = I + (int64_t)s_dst[0][tid] + (int64_t)s_len[0][tid];
+                else overflow = true;
+            }
+        }
+        {
+            const int j = 4 * tid + jq;           // this thread's quality line
+            const int64_t rec = (P + j) >> 2;
+            if (j < (int)c && rec >= 0) {
+                const int64_t qe = Q + (int64_t)s_dst[2][tid] + (int64_t)s_len[2][tid];
+                // sequence bytes up to and including this record's sequence line (line j-2)
+                int64_t se = S;
+                if (jq >= 2) se = S + (int64_t)s_dst[1][tid] + (int64_t)s_len[1][tid];
+                else if (tid > 0) se = S + (int64_t)s_dst[1][tid - 1] + (int64_t)s_len[1][tid - 1];
+                if (rec < a.rec_cap) { a.ends[rec] = qe; a.rec_end[rec] = t0 + (int64_t)s_nl[j]; }
+                else overflow = true;
+                if (se != qe) err.structure(rec, 3); // utils.mojo:458-461 as a cumulative test
+            }
+        }
+        // ---- gather the three streams -------------------------------------------------------------
+        const int js = (1 - ph) & 3;
+        const int nl_lines = (int)c + 1;
+        const int nk_h = jh < nl_lines ? ((nl_lines - 1 - jh) >> 2) + 1 : 0;
+        const int nk_s = js < nl_lines ? ((nl_lines - 1 - js) >> 2) + 1 : 0;
+        const int nk_q = jq < nl_lines ? ((nl_lines - 1 - jq) >> 2) + 1 : 0;
+        gather_role2<1, CA, CQ>(a.col_seq, S, n_seq, s_src[1], s_len[1], s_dst[1], nk_s, s_tile, P + js, a.q_lower, a.q_upper, err);
+        gather_role2<3, CA, CQ>(a.col_qual, Q, n_qual, s_src[2], s_len[2], s_dst[2], nk_q, s_tile, P + jq, a.q_lower, a.q_upper, err);
+        gather_role2<0, CA, CQ>(a.col_id, I, n_id, s_src[0], s_len[0], s_dst[0], nk_h, s_tile, P + jh, a.q_lower, a.q_upper, err);
+    }
+    if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
+    if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
+    if (overflow) atomicOr(&a.st->rec_overflow, 1);
+}
+
+
+// Pass A of the two-pass mode, table-driven like k_fused: the phase is unknown here, so thread k
+// takes lines 4k..4k+3 = one line of every CLASS (line index mod 4) and treats each as a potential
+// header for the id-byte count.  Same output as k_tile_aggregate.
+__global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[TILE];
+    __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
+    __shared__ uint16_t s_nl[MAXL + 4];
+    __shared__ uint32_t s_w[4];
+    __shared__ u64 s_red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t t = a.tile_begin + blockIdx.x;
+    const int64_t t0 = t * TILE;
+    const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+    tile_load<true>(a.g, a.n, t0, valid, s_mask, s_tile);
+    ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
+    const bool first_starts = (bs.at(t0 - 1) == 10u);
+    __syncthreads();
+    const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);
+    const u64 m64 = s_mask64[tid];
+    uint32_t c = 0;
+    const uint32_t excl = block_exclusive_scan<uint32_t, 4>((uint32_t)__popcll(m64), s_w, c);
+    u64 pa = 0, pi = 0; // 4 x 16-bit fields: bytes / id bytes per class
+    if ((int)c <= MAXL) {
+        u64 m = m64;
+        int idx = 0;
+        while (m) {
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1;
+            s_nl[excl + idx] = (uint16_t)(tid * 64 + bit);
+            ++idx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 4 * tid + r;
+            if (j <= (int)c) {
+                const int start = j ? (int)s_nl[j - 1] + 1 : 0;
+                const bool end_in = j < (int)c;
+                const int end = end_in ? (int)s_nl[j] : valid;
+                if (end > start) {
+                    int64_t lo, hi;
+                    header_kept(bs, t0 + start, t0 + end, j > 0 ? true : first_starts, end_in, t0 + valid, lo, hi);
+                    pa += (u64)(end - start) << (16 * r);
+                    pi += (u64)(hi - lo) << (16 * r);
+                }
+            }
+        }
+    } else if (tid == 0) { // serial path for tiles with > MAXL newlines
+        int j = 0, line_start = 0;
+        bool start_in = first_starts;
+        uint32_t la[4] = {0, 0, 0, 0}, li[4] = {0, 0, 0, 0};
+        auto handle = [&](int start, int end, bool end_in) {
+            if (end > start) {
+                int64_t lo, hi;
+                header_kept(bs, t0 + start, t0 + end, start_in, end_in, t0 + valid, lo, hi);
+                la[j & 3] += (uint32_t)(end - start);
+                li[j & 3] += (uint32_t)(hi - lo);
+            }
+        };
+        for (int w = 0; w < BLOCK; ++w) {
+            u64 m = s_mask64[w];
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int nl = w * 64 + bit;
+                handle(line_start, nl, true);
+                line_start = nl + 1;
+                start_in = true;
+                ++j;
+            }
+        }
+        handle(line_start, valid, false);
+        for (int k = 0; k < 4; ++k) { pa |= (u64)la[k] << (16 * k); pi |= (u64)li[k] << (16 * k); }
+    }
+    // block sum of the packed fields (every field total <= 16384, no carry between fields)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { pa += __shfl_xor(pa, d); pi += __shfl_xor(pi, d); }
+    if (lane == 0) { s_red[0][wave] = pa; s_red[1][wave] = pi; }
+    __syncthreads();
+    if (tid == 0) {
+        a.tile_c[t] = c;
+        a.tile_a[t] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        a.tile_idc[t] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+    }
+}
+
+} // namespace bzq

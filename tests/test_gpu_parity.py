@@ -18,8 +18,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CORPUS = json.load(open(os.path.join(HERE, "golden", "corpus_expected.json")))
 
 
-def test_inline_known_answers():
-    ctx, oc = make_pair(emit_offsets=True)
+@pytest.mark.parametrize("single_pass", [True, False, "v1"])
+def test_inline_known_answers(single_pass):
+    ctx, oc = make_pair(emit_offsets=True, single_pass=single_pass)
     for data in (b"@r1\nACGT\n+\n!!!!\n@r2\nTGCA\n+\n####\n", b"", b"\n", b"@", b"@a\nA\n+\n!\n",
                  b"r1\nACGT\n+\n!!!!\n", b"@r1\nACGT\n+\n!!!\n", b"@r1\nACGT\n-\n!!!!\n",
                  b"@a\nAC\n+\n!!\n@b\nACGT\n+\n!!", b"@a\nAC\n+\n!!\n@b\nAC\n+\n \t", b"@a\nAC\n+\n!!\n\n",
@@ -28,9 +29,10 @@ def test_inline_known_answers():
         check_against_oracle(ctx, oc, data, offsets=True, what=repr(data[:20]))
 
 
+@pytest.mark.parametrize("single_pass", [True, False, "v1"])
 @pytest.mark.parametrize("cfgname", ["default", "validated_generic", "validated_schema", "validated_schema_simd32",
                                      "cap64", "cap64_growth"])
-def test_corpus(cfgname, corpus_dir):
+def test_corpus(cfgname, single_pass, corpus_dir):
     for name, e in sorted(CORPUS.items()):
         data = open(os.path.join(corpus_dir, name), "rb").read()
         sc = e["schema"]
@@ -39,7 +41,7 @@ def test_corpus(cfgname, corpus_dir):
               "validated_schema_simd32": dict(check_ascii=True, check_quality=True, quality_schema=sc, compat_simd_width=32),
               "cap64": dict(buffer_capacity=64),
               "cap64_growth": dict(buffer_capacity=64, buffer_growth_enabled=True, buffer_max_capacity=1 << 20)}[cfgname]
-        ctx, oc = make_pair(emit_offsets=True, **kw)
+        ctx, oc = make_pair(emit_offsets=True, single_pass=single_pass, **kw)
         res, f = check_against_oracle(ctx, oc, data, offsets=True, what=f"{name}/{cfgname}")
         g = e[cfgname]
         assert (int(res.n_records), res.status, ctx.format_error().decode("latin-1") if res.status else "") == \
@@ -56,7 +58,7 @@ def test_fuzz_small(seed):
         for kw in (dict(), dict(check_ascii=True, check_quality=True),
                    dict(check_ascii=True, check_quality=True, quality_schema="solexa", compat_simd_width=16),
                    dict(buffer_capacity=48), dict(buffer_capacity=48, buffer_growth_enabled=True, buffer_max_capacity=200)):
-            ctx, oc = make_pair(batch_size=int(rng.choice([1, 3, 4096])), emit_offsets=True, **kw)
+            ctx, oc = make_pair(batch_size=int(rng.choice([1, 3, 4096])), emit_offsets=True, single_pass=[True, False, "v1"][rep % 3], **kw)
             check_against_oracle(ctx, oc, data, offsets=True, what=f"seed{seed}/{rep}/{kw}")
             if rep == 0:
                 ctx.set_option("force_dense", 1)   # every tile through the serial in-kernel path
@@ -74,8 +76,10 @@ def test_fuzz_multi_tile(seed):
     data = rand_stream(rng, n_records=nrec, max_len=max_len, dirty=dirty, crlf=bool(rng.random() < 0.2))
     for kw, pb in ((dict(), 0), (dict(check_ascii=True, check_quality=True), 64 * 1024),
                    (dict(check_ascii=True, check_quality=True), 16 * 1024)):
-        ctx, oc = make_pair(batch_size=int(rng.choice([7, 4096])), pass_bytes=pb, emit_offsets=True, **kw)
+        ctx, oc = make_pair(batch_size=int(rng.choice([7, 4096])), pass_bytes=pb, emit_offsets=True, single_pass=(pb == 0), **kw)
         check_against_oracle(ctx, oc, data, offsets=True, what=f"mt seed{seed} {kw} pass={pb}")
+        ctx.set_option("single_pass", 1)
+        check_against_oracle(ctx, oc, data, offsets=True, what=f"mt single-pass seed{seed} {kw}")
         check_against_oracle(ctx, oc, data, is_eof=False, offsets=True, what=f"mt chunk-mode seed{seed}")
         ctx.set_option("force_dense", 1)
         check_against_oracle(ctx, oc, data, offsets=True, what=f"mt dense seed{seed}")
@@ -93,20 +97,22 @@ def test_space_runs_across_tile_edges():
         parts.append(b"@" + lead + rid + trail + b"\n" + b"A" * L + b"\n+\n" + b"I" * L + b"\n")
     data = b"".join(parts)
     for dense in (0, 1):
-        ctx, oc = make_pair(emit_offsets=True, check_ascii=True, check_quality=True)
-        ctx.set_option("force_dense", dense)
-        check_against_oracle(ctx, oc, data, offsets=True, what=f"space runs dense={dense}")
-        ctx.close()
+        for sp in (True, False, "v1"):
+            ctx, oc = make_pair(emit_offsets=True, check_ascii=True, check_quality=True, single_pass=sp)
+            ctx.set_option("force_dense", dense)
+            check_against_oracle(ctx, oc, data, offsets=True, what=f"space runs dense={dense} single_pass={sp}")
+            ctx.close()
 
 
 def test_tiny_records_take_serial_path_and_resize():
     """> 1020 newlines in a 16 KiB tile (records of 4-12 bytes): serial in-kernel path, and the
     per-record arrays are re-sized transparently."""
     data = b"@\n\n+\n\n" * 9000 + b"@a\nC\n+\n!\n" * 3000
-    ctx, oc = make_pair(emit_offsets=True, check_ascii=True, check_quality=True)
-    res, f = check_against_oracle(ctx, oc, data, offsets=True, what="tiny")
-    assert res._pad > 0  # dense tiles were used
-    ctx.close()
+    for sp in (True, False, "v1"):
+        ctx, oc = make_pair(emit_offsets=True, check_ascii=True, check_quality=True, single_pass=sp)
+        res, f = check_against_oracle(ctx, oc, data, offsets=True, what=f"tiny single_pass={sp}")
+        assert res._pad > 0  # dense tiles were used
+        ctx.close()
 
 
 def test_device_generator_matches_oracle():
@@ -121,12 +127,13 @@ def test_device_generator_matches_oracle():
     ctx.close()
 
 
+@pytest.mark.parametrize("single_pass", [True, False, "v1"])
 @pytest.mark.parametrize("validate", [False, True])
-def test_synthetic_150bp_medium(validate):
+def test_synthetic_150bp_medium(validate, single_pass):
     """Config 2/3 shape at a size the oracle parses in a second: 150k reads (47.7 MB)."""
     data = O.generate_synthetic(150_000, 150, 150, 33, 73, "generic")
     kw = dict(check_ascii=True, check_quality=True, quality_schema="sanger") if validate else {}
-    ctx, oc = make_pair(emit_offsets=True, **kw)
+    ctx, oc = make_pair(emit_offsets=True, single_pass=single_pass, **kw)
     res, f = check_against_oracle(ctx, oc, data, offsets=True, what="150bp")
     assert int(res.n_records) == 150_000 and res.status == 6
     if validate:
