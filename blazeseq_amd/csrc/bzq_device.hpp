@@ -149,14 +149,39 @@ __device__ inline void header_kept(const ByteSrc& b, int64_t ls, int64_t le, boo
 }
 
 // ---- block-wide scans ---------------------------------------------------------------------------
+// Wave64 inclusive scan on DPP (row_shr within rows of 16, then row_bcast:15 / :31 across rows):
+// six v_add_*_dpp, no LDS round trips.
+__device__ __forceinline__ uint32_t dpp_scan_u32(uint32_t v) {
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x142, 0xa, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0u, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+#define BZQ_DPP64(ctrl, rm, bc)                                                                    \
+    do {                                                                                           \
+        const uint32_t lo_ = __builtin_amdgcn_update_dpp(0u, (uint32_t)v, ctrl, rm, 0xf, bc);      \
+        const uint32_t hi_ = __builtin_amdgcn_update_dpp(0u, (uint32_t)(v >> 32), ctrl, rm, 0xf, bc); \
+        v += ((u64)hi_ << 32) | lo_;                                                               \
+    } while (0)
+__device__ __forceinline__ u64 dpp_scan_u64(u64 v) {
+    BZQ_DPP64(0x111, 0xf, true); BZQ_DPP64(0x112, 0xf, true); BZQ_DPP64(0x114, 0xf, true); BZQ_DPP64(0x118, 0xf, true);
+    BZQ_DPP64(0x142, 0xa, false); BZQ_DPP64(0x143, 0xc, false);
+    return v;
+}
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_scan(T v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        T t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
+    (void)lane;
+    if constexpr (sizeof(T) == 4) return (T)dpp_scan_u32((uint32_t)v);
+    else return (T)dpp_scan_u64((u64)v);
+}
+// sum over the wave, result in every lane
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+    v = dpp_scan_u64(v);
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, 63), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), 63);
+    return ((u64)hi << 32) | lo;
 }
 
 // Exclusive scan over the block; s_w needs NW entries.  Two barriers.
@@ -179,25 +204,38 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* s_w, T& total) {
 }
 
 // ---- tile front end shared by both passes -----------------------------------------------------
-// Loads the tile (coalesced 16 B per lane, 4 rounds), optionally stages it in LDS, builds the
-// newline bitmap: s_mask[q] = 16-bit mask of piece q; read back as one u64 per thread = the 64
-// contiguous bytes [64*tid, 64*tid+64).
+// tile_fetch: coalesced 16 B per lane, 4 rounds (piece q = tid + 256*s), into registers.
+// tile_stage: newline bitmap s_mask[q] (16-bit mask of piece q; read back as one u64 per thread = the
+// 64 contiguous bytes [64*tid, 64*tid+64)) and, optionally, the bytes themselves into LDS.
+__device__ __forceinline__ void tile_fetch(const uint8_t* __restrict__ g, int64_t n, int64_t t0, int valid, uint4 (&r)[4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int pos = (tid + BLOCK * s) * 16;
+        r[s] = make_uint4(0u, 0u, 0u, 0u);
+        if (pos < valid) r[s] = load16(g, t0 + pos, n);
+    }
+}
 template <bool STAGE>
-__device__ __forceinline__ void tile_load(const uint8_t* __restrict__ g, int64_t n, int64_t t0, int valid,
-                                          uint16_t* s_mask, uint8_t* s_tile /* +16 front pad applied */) {
+__device__ __forceinline__ void tile_stage(const uint4 (&r)[4], int valid, uint16_t* s_mask, uint8_t* s_tile) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int q = tid + BLOCK * s;
         const int pos = q * 16;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (pos < valid) v = load16(g, t0 + pos, n);
-        uint32_t m = nl_mask16(v);
-        int rem = valid - pos;
+        uint32_t m = nl_mask16(r[s]);
+        const int rem = valid - pos;
         if (rem < 16) m &= rem > 0 ? ((1u << rem) - 1u) : 0u;
         s_mask[q] = (uint16_t)m;
-        if (STAGE) *reinterpret_cast<uint4*>(s_tile + pos) = v;
+        if (STAGE) *reinterpret_cast<uint4*>(s_tile + pos) = r[s];
     }
+}
+template <bool STAGE>
+__device__ __forceinline__ void tile_load(const uint8_t* __restrict__ g, int64_t n, int64_t t0, int valid,
+                                          uint16_t* s_mask, uint8_t* s_tile /* +16 front pad applied */) {
+    uint4 r[4];
+    tile_fetch(g, n, t0, valid, r);
+    tile_stage<STAGE>(r, valid, s_mask, s_tile);
 }
 
 __device__ __forceinline__ int prev_newline_before_word(const u64* s_mask64, int word) {
@@ -237,6 +275,7 @@ struct AggArgs {
     int64_t n;
     uint32_t prev_byte;
     int64_t tile_begin;
+    int64_t tile_end;   // persistent kernels walk [tile_begin + blockIdx.x, tile_end) with stride gridDim.x
     uint32_t* tile_c;   // newlines per tile
     u64* tile_a;        // 4 x u16: non-newline bytes per line class (local line index & 3)
     u64* tile_idc;      // 4 x u16: id bytes per class if that class were the header role

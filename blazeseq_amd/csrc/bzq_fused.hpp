@@ -29,11 +29,7 @@ __device__ __forceinline__ u64 ld_agent(const u64* p) {
 __device__ __forceinline__ void st_agent(u64* p, u64 v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ int64_t wave_sum(int64_t v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
-    return v;
-}
+__device__ __forceinline__ int64_t wave_sum(int64_t v) { return (int64_t)wave_sum_u64((u64)v); }
 
 struct FusedArgs {
     const uint8_t* g;
@@ -45,7 +41,7 @@ struct FusedArgs {
     u64* desc_agg;   // [n_tiles]   packed (seq, qual, id) byte counts of the tile
     u64* desc_pre;   // [3*n_tiles] inclusive column prefixes S, Q, I
     // LB == false: prefixes come from the tile scan (k_tile_aggregate2 + k_scan_*)
-    int64_t tile_begin;
+    int64_t tile_begin, tile_end;
     const int64_t* tileP;
     const int64_t* tileS;
     const int64_t* tileQ;
@@ -489,12 +485,27 @@ __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
     __shared__ uint32_t s_w[4];
     __shared__ u64 s_red[2][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t t = a.tile_begin + blockIdx.x;
+    // persistent workgroups: tiles blockIdx.x, +gridDim.x, ... with a register prefetch of the next
+    // tile, so its HBM latency hides behind this tile's work
+    int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    if (t >= a.tile_end) return;
+    uint4 pre[4];
+    {
+        const int64_t t0p = t * TILE;
+        tile_fetch(a.g, a.n, t0p, (int)((a.n - t0p) < TILE ? (a.n - t0p) : TILE), pre);
+    }
+  for (;;) {
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
-    tile_load<true>(a.g, a.n, t0, valid, s_mask, s_tile);
+    const uint32_t prev_b = t0 > 0 ? (uint32_t)a.g[t0 - 1] : a.prev_byte; // issued before the prefetch (vmcnt is in order)
+    tile_stage<true>(pre, valid, s_mask, s_tile);
+    const int64_t t_next = t + (int64_t)gridDim.x;
+    if (t_next < a.tile_end) {
+        const int64_t t0p = t_next * TILE;
+        tile_fetch(a.g, a.n, t0p, (int)((a.n - t0p) < TILE ? (a.n - t0p) : TILE), pre);
+    }
     ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
-    const bool first_starts = (bs.at(t0 - 1) == 10u);
+    const bool first_starts = (prev_b == 10u);
     __syncthreads();
     const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);
     const u64 m64 = s_mask64[tid];
@@ -554,8 +565,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
         for (int k = 0; k < 4; ++k) { pa |= (u64)la[k] << (16 * k); pi |= (u64)li[k] << (16 * k); }
     }
     // block sum of the packed fields (every field total <= 16384, no carry between fields)
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { pa += __shfl_xor(pa, d); pi += __shfl_xor(pi, d); }
+    pa = wave_sum_u64(pa); pi = wave_sum_u64(pi);
     if (lane == 0) { s_red[0][wave] = pa; s_red[1][wave] = pi; }
     __syncthreads();
     if (tid == 0) {
@@ -563,6 +573,10 @@ __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
         a.tile_a[t] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
         a.tile_idc[t] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
     }
+    if (t_next >= a.tile_end) break;
+    t = t_next;
+    __syncthreads();
+  }
 }
 
 } // namespace bzq
