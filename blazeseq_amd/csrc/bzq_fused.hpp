@@ -162,7 +162,7 @@ __device__ __forceinline__ void validate_window(uint32_t w0, uint32_t w1, uint32
 // unconditionally; only lanes whose piece crosses into further segments run the merge loop.
 template <int ROLE, bool CA, bool CQ>
 __device__ __forceinline__ void gather_role2(uint8_t* __restrict__ col, int64_t D, int n_role, const uint16_t* seg_src,
-                                             const uint16_t* seg_len, const uint16_t* seg_dst, int nk,
+                                             const uint16_t* seg_len, const uint16_t* seg_dst, const uint8_t* seg_blk, int nk,
                                              const uint8_t* s_tile, int64_t line0, uint32_t qlo, uint32_t qhi, ErrAcc& err) {
     if (n_role <= 0) return;
     const int tid = threadIdx.x;
@@ -176,12 +176,24 @@ __device__ __forceinline__ void gather_role2(uint8_t* __restrict__ col, int64_t 
         const int xh = (int)(hi_abs - p0 < 16 ? hi_abs - p0 : 16);
         if (p0 < 0 && xl < (int)(-p0)) xl = (int)(-p0);
         int o = (int)(p0 - D) + xl;
-        int lo = 0, hi = nk;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if ((int)seg_dst[mid] <= o) lo = mid + 1; else hi = mid;
+        // segment holding stream byte o: coarse index (segment at the start of o's 256-byte block), then
+        // a short forward walk; tiles with many tiny segments fall back to a binary search
+        int k = (int)seg_blk[o >> 8];
+        {
+            int steps = 0;
+            while (k + 1 < nk && (int)seg_dst[k + 1] <= o) {
+                ++k;
+                if (++steps == 6) {
+                    int lo = k + 1, hi = nk;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if ((int)seg_dst[mid] <= o) lo = mid + 1; else hi = mid;
+                    }
+                    k = lo - 1;
+                    break;
+                }
+            }
         }
-        int k = lo - 1;
         const int dk = (int)seg_dst[k], lk = (int)seg_len[k];
         int take = dk + lk - o;
         if (take > xh - xl) take = xh - xl;
@@ -226,6 +238,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
     __shared__ uint16_t s_nl[MAXL + 4];
     __shared__ uint16_t s_src[3][SEGS], s_len[3][SEGS], s_dst[3][SEGS];
+    __shared__ uint8_t s_blk[3][TILE / 256 + 1];   // segment that holds the first byte of each 256-byte stream block
     __shared__ u64 s_w64[4];
     __shared__ uint32_t s_w[4];
     __shared__ int64_t s_bcast[4];   // tile, P / S, Q, I
@@ -403,10 +416,13 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         const u64 packed = (u64)lh | ((u64)lsq << 21) | ((u64)lq << 42);
         u64 tot = 0;
         const u64 ex = block_exclusive_scan<u64, 4>(packed, s_w64, tot);
-        s_dst[0][tid] = (uint16_t)(ex & 0x1FFFFFull);
-        s_dst[1][tid] = (uint16_t)((ex >> 21) & 0x1FFFFFull);
-        s_dst[2][tid] = (uint16_t)((ex >> 42) & 0x1FFFFFull);
+        const int dh = (int)(ex & 0x1FFFFFull), ds = (int)((ex >> 21) & 0x1FFFFFull), dq = (int)((ex >> 42) & 0x1FFFFFull);
+        s_dst[0][tid] = (uint16_t)dh; s_dst[1][tid] = (uint16_t)ds; s_dst[2][tid] = (uint16_t)dq;
         n_id = (int)(tot & 0x1FFFFFull); n_seq = (int)((tot >> 21) & 0x1FFFFFull); n_qual = (int)((tot >> 42) & 0x1FFFFFull);
+        // coarse index: this thread's segment k = tid covers stream bytes [d, d+len) of its role
+        for (int b = (dh + 255) >> 8; b <= (dh + (int)lh - 1) >> 8 && lh; ++b) s_blk[0][b] = (uint8_t)tid;
+        for (int b = (ds + 255) >> 8; b <= (ds + (int)lsq - 1) >> 8 && lsq; ++b) s_blk[1][b] = (uint8_t)tid;
+        for (int b = (dq + 255) >> 8; b <= (dq + (int)lq - 1) >> 8 && lq; ++b) s_blk[2][b] = (uint8_t)tid;
     }
 
     // ---- look-back 2: column offsets --------------------------------------------------------------
@@ -465,9 +481,9 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         const int nk_h = jh < nl_lines ? ((nl_lines - 1 - jh) >> 2) + 1 : 0;
         const int nk_s = js < nl_lines ? ((nl_lines - 1 - js) >> 2) + 1 : 0;
         const int nk_q = jq < nl_lines ? ((nl_lines - 1 - jq) >> 2) + 1 : 0;
-        gather_role2<1, CA, CQ>(a.col_seq, S, n_seq, s_src[1], s_len[1], s_dst[1], nk_s, s_tile, P + js, a.q_lower, a.q_upper, err);
-        gather_role2<3, CA, CQ>(a.col_qual, Q, n_qual, s_src[2], s_len[2], s_dst[2], nk_q, s_tile, P + jq, a.q_lower, a.q_upper, err);
-        gather_role2<0, CA, CQ>(a.col_id, I, n_id, s_src[0], s_len[0], s_dst[0], nk_h, s_tile, P + jh, a.q_lower, a.q_upper, err);
+        gather_role2<1, CA, CQ>(a.col_seq, S, n_seq, s_src[1], s_len[1], s_dst[1], s_blk[1], nk_s, s_tile, P + js, a.q_lower, a.q_upper, err);
+        gather_role2<3, CA, CQ>(a.col_qual, Q, n_qual, s_src[2], s_len[2], s_dst[2], s_blk[2], nk_q, s_tile, P + jq, a.q_lower, a.q_upper, err);
+        gather_role2<0, CA, CQ>(a.col_id, I, n_id, s_src[0], s_len[0], s_dst[0], s_blk[0], nk_h, s_tile, P + jh, a.q_lower, a.q_upper, err);
     }
     if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
     if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
