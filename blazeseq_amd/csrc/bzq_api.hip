@@ -78,6 +78,7 @@ struct bzq_ctx {
     hipEvent_t ev[8]{};
     std::vector<hipEvent_t> ev_detail;
     // options
+    int ablate = 0;
     int force_dense = 0, timing_detail = 0, single_pass = 1, v2 = 1, num_cu = 256, wg_per_cu = 0;
     bool ran_single_pass = false;
     // current chunk
@@ -250,7 +251,7 @@ FusedArgs make_fused_args(bzq_ctx* c) {
     f.rec_cap = c->rec_cap;
     f.o_hdr = (int64_t*)c->off[0].p; f.o_seq = (int64_t*)c->off[1].p;
     f.o_sep = (int64_t*)c->off[2].p; f.o_qual = (int64_t*)c->off[3].p;
-    f.st = c->d_state; f.q_lower = c->cfg.q_lower; f.q_upper = c->cfg.q_upper; f.force_dense = c->force_dense;
+    f.st = c->d_state; f.q_lower = c->cfg.q_lower; f.q_upper = c->cfg.q_upper; f.force_dense = c->force_dense; f.ablate = c->ablate;
     return f;
 }
 
@@ -541,6 +542,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "single_pass")) c->single_pass = (int)value;
     else if (!strcmp(key, "kernels_v2")) c->v2 = (int)value;
     else if (!strcmp(key, "wg_per_cu")) c->wg_per_cu = (int)value;
+    else if (!strcmp(key, "ablate")) c->ablate = (int)value;
     else if (!strcmp(key, "pass_bytes")) c->cfg.pass_bytes = value > 0 ? std::max<int64_t>(TILE, (value / TILE) * TILE) : 0;
     else { c->err = std::string("unknown option ") + key; return BZQ_ERR_ARG; }
     return 0;

@@ -60,6 +60,7 @@ struct FusedArgs {
     ChunkState* st;
     uint32_t q_lower, q_upper;
     int32_t force_dense;
+    int32_t ablate;   // timing experiments only: bit0 skip gathers, bit1 skip record outputs, bit2 skip line pass+scan
 };
 
 // Exclusive line prefix of tile t (wave 0, all 64 lanes).  Lane i inspects predecessor t-1-i.
@@ -481,9 +482,11 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         const int nk_h = jh < nl_lines ? ((nl_lines - 1 - jh) >> 2) + 1 : 0;
         const int nk_s = js < nl_lines ? ((nl_lines - 1 - js) >> 2) + 1 : 0;
         const int nk_q = jq < nl_lines ? ((nl_lines - 1 - jq) >> 2) + 1 : 0;
+        if (!(a.ablate & 1)) {
         gather_role2<1, CA, CQ>(a.col_seq, S, n_seq, s_src[1], s_len[1], s_dst[1], s_blk[1], nk_s, s_tile, P + js, a.q_lower, a.q_upper, err);
         gather_role2<3, CA, CQ>(a.col_qual, Q, n_qual, s_src[2], s_len[2], s_dst[2], s_blk[2], nk_q, s_tile, P + jq, a.q_lower, a.q_upper, err);
         gather_role2<0, CA, CQ>(a.col_id, I, n_id, s_src[0], s_len[0], s_dst[0], s_blk[0], nk_h, s_tile, P + jh, a.q_lower, a.q_upper, err);
+        }
     }
     if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
     if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
