@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--pass-bytes", type=int, default=0)
     ap.add_argument("--two-pass", action="store_true", help="use the two-pass kernels instead of the single-pass one")
     ap.add_argument("--kernels-v1", action="store_true", help="two-pass mode with the first-generation kernels")
+    ap.add_argument("--emit-persistent", type=int, default=1)
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (results are wrong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1_000_000)
@@ -93,6 +94,7 @@ def main():
     ctx.set_option("kernels_v2", 0 if args.kernels_v1 else 1)
     if args.ablate:
         ctx.set_option("ablate", args.ablate)
+    ctx.set_option("emit_persistent", args.emit_persistent)
 
     # ---- synthetic input, generated on the device (record i depends only on i) ------------------
     total_reads = args.reads * world

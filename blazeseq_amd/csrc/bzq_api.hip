@@ -78,7 +78,7 @@ struct bzq_ctx {
     hipEvent_t ev[8]{};
     std::vector<hipEvent_t> ev_detail;
     // options
-    int ablate = 0;
+    int ablate = 0, emit_persistent = 1;
     int force_dense = 0, timing_detail = 0, single_pass = 1, v2 = 1, num_cu = 256, wg_per_cu = 0;
     bool ran_single_pass = false;
     // current chunk
@@ -319,7 +319,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
         if (c->v2) {
             FusedArgs f = make_fused_args(c);
             f.tile_begin = tb; f.tile_end = te;
-            launch_fused<false>(c, grid, f);
+            launch_fused<false>(c, c->emit_persistent ? dim3(0) : grid, f);
         } else {
             EmitArgs e = make_emit_args(c);
             e.tile_begin = tb;
@@ -543,6 +543,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "kernels_v2")) c->v2 = (int)value;
     else if (!strcmp(key, "wg_per_cu")) c->wg_per_cu = (int)value;
     else if (!strcmp(key, "ablate")) c->ablate = (int)value;
+    else if (!strcmp(key, "emit_persistent")) c->emit_persistent = (int)value;
     else if (!strcmp(key, "pass_bytes")) c->cfg.pass_bytes = value > 0 ? std::max<int64_t>(TILE, (value / TILE) * TILE) : 0;
     else { c->err = std::string("unknown option ") + key; return BZQ_ERR_ARG; }
     return 0;

@@ -233,13 +233,46 @@ __device__ __forceinline__ void gather_role2(uint8_t* __restrict__ col, int64_t 
     }
 }
 
+
+// ---- source-driven scatter --------------------------------------------------------------------
+// gfx950 handles byte-unaligned vector accesses in hardware (one global_store_dwordx4 for an
+// align-1 16-byte store), so an aligned 16-byte source piece that lies wholly inside one line goes
+// from the registers it was loaded into straight to its column position; only the <= 15-byte head
+// and tail of every line go through the LDS window.
+struct __attribute__((packed, aligned(1))) U16B { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U8B { uint32_t x, y; };
+struct __attribute__((packed, aligned(1))) U4B { uint32_t x; };
+struct __attribute__((packed, aligned(1))) U2B { uint16_t x; };
+
+__device__ __forceinline__ void store_bytes(uint8_t* p, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int n) {
+    // first n (< 16) bytes of the little-endian 16-byte value {w0..w3}
+    if (n & 8) { U8B v{w0, w1}; *reinterpret_cast<U8B*>(p) = v; p += 8; w0 = w2; w1 = w3; }
+    if (n & 4) { U4B v{w0}; *reinterpret_cast<U4B*>(p) = v; p += 4; w0 = w1; }
+    if (n & 2) { U2B v{(uint16_t)w0}; *reinterpret_cast<U2B*>(p) = v; p += 2; w0 >>= 16; }
+    if (n & 1) *p = (uint8_t)w0;
+}
+
+// n (1..15) bytes of the LDS tile starting at tile offset s0 -> col[gaddr ...]
+template <int ROLE, bool CA, bool CQ>
+__device__ __forceinline__ void emit_part(uint8_t* __restrict__ col, int64_t gaddr, int s0, int n, const uint8_t* s_tile,
+                                          int64_t rec, uint32_t qlo, uint32_t qhi, ErrAcc& err) {
+    if (n <= 0) return;
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tile - 16);
+    const int ws = s0 + 16, wd = ws >> 2, sh = ws & 3;
+    const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                   w2 = __builtin_amdgcn_alignbyte(d3, d2, sh), w3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    validate_window<ROLE, CA, CQ>(w0, w1, w2, w3, 0, n, rec, qlo, qhi, err);
+    store_bytes(col + gaddr, w0, w1, w2, w3, n);
+}
+
 template <bool CA, bool CQ, bool OFFS, bool LB>
 __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
     __shared__ uint16_t s_nl[MAXL + 4];
     __shared__ uint16_t s_src[3][SEGS], s_len[3][SEGS], s_dst[3][SEGS];
-    __shared__ uint8_t s_blk[3][TILE / 256 + 1];   // segment that holds the first byte of each 256-byte stream block
+    __shared__ __attribute__((aligned(16))) uint16_t s_pline[PIECES];            // tile-local line index of each 16-byte piece's first byte
     __shared__ u64 s_w64[4];
     __shared__ uint32_t s_w[4];
     __shared__ int64_t s_bcast[4];   // tile, P / S, Q, I
@@ -251,10 +284,18 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         if (tid == 0) s_bcast[0] = (int64_t)atomicAdd(a.ticket, 1ull);
         __syncthreads();
     }
-    const int64_t t = LB ? s_bcast[0] : a.tile_begin + (int64_t)blockIdx.x;
+    int64_t t = LB ? s_bcast[0] : a.tile_begin + (int64_t)blockIdx.x;
+    if (!LB && t >= a.tile_end) return;
+  for (;;) {
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
-    tile_load<true>(a.g, a.n, t0, valid, s_mask, s_tile);
+    // every global LOAD of this tile is issued here, before any store: vmcnt retires in order, so a
+    // load waited for after the record-output stores would also wait for those stores' round trip
+    int64_t tP = 0, tS = 0, tQ = 0, tI = 0;
+    if (!LB) { tP = a.tileP[t]; tS = a.tileS[t]; tQ = a.tileQ[t]; tI = a.tileI[t]; }
+    uint4 r[4];   // this thread's four source pieces (q = tid + 256 s); they stay in registers for the scatter
+    tile_fetch(a.g, a.n, t0, valid, r);
+    tile_stage<true>(r, valid, s_mask, s_tile);
     ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
     const bool first_starts = (bs.at(t0 - 1) == 10u);
     __syncthreads();
@@ -263,6 +304,11 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     uint32_t c = 0;
     const uint32_t excl = block_exclusive_scan<uint32_t, 4>((uint32_t)__popcll(m64), s_w, c);
     const bool dense = ((int)c > MAXL) || a.force_dense;
+    {   // line index at the first byte of each of this thread's four analysis pieces (bytes 64*tid + 16*i)
+        const uint32_t l0 = excl, l1 = l0 + (uint32_t)__popc((uint32_t)m64 & 0xFFFFu),
+                       l2 = l0 + (uint32_t)__popc((uint32_t)m64), l3 = l0 + (uint32_t)__popcll(m64 & 0xFFFFFFFFFFFFull);
+        *reinterpret_cast<u64*>(&s_pline[4 * tid]) = (u64)l0 | ((u64)l1 << 16) | ((u64)l2 << 32) | ((u64)l3 << 48);
+    }
 
     // ---- look-back 1: line index of the tile's first line --------------------------------------
     if (LB && wave == 0) {
@@ -284,7 +330,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         }
     }
     __syncthreads();
-    const int64_t P = LB ? s_bcast[1] : a.tileP[t];
+    const int64_t P = LB ? s_bcast[1] : tP;
     ErrAcc err{~0ull, ~0ull};
     bool overflow = false;
     const int ph = (int)(P & 3);
@@ -420,10 +466,6 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         const int dh = (int)(ex & 0x1FFFFFull), ds = (int)((ex >> 21) & 0x1FFFFFull), dq = (int)((ex >> 42) & 0x1FFFFFull);
         s_dst[0][tid] = (uint16_t)dh; s_dst[1][tid] = (uint16_t)ds; s_dst[2][tid] = (uint16_t)dq;
         n_id = (int)(tot & 0x1FFFFFull); n_seq = (int)((tot >> 21) & 0x1FFFFFull); n_qual = (int)((tot >> 42) & 0x1FFFFFull);
-        // coarse index: this thread's segment k = tid covers stream bytes [d, d+len) of its role
-        for (int b = (dh + 255) >> 8; b <= (dh + (int)lh - 1) >> 8 && lh; ++b) s_blk[0][b] = (uint8_t)tid;
-        for (int b = (ds + 255) >> 8; b <= (ds + (int)lsq - 1) >> 8 && lsq; ++b) s_blk[1][b] = (uint8_t)tid;
-        for (int b = (dq + 255) >> 8; b <= (dq + (int)lq - 1) >> 8 && lq; ++b) s_blk[2][b] = (uint8_t)tid;
     }
 
     // ---- look-back 2: column offsets --------------------------------------------------------------
@@ -443,7 +485,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         }
     }
     __syncthreads();
-    const int64_t S = LB ? s_bcast[1] : a.tileS[t], Q = LB ? s_bcast[2] : a.tileQ[t], I = LB ? s_bcast[3] : a.tileI[t];
+    const int64_t S = LB ? s_bcast[1] : tS, Q = LB ? s_bcast[2] : tQ, I = LB ? s_bcast[3] : tI;
 
     if (dense) {
         if (tid == 0) {
@@ -476,21 +518,75 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                 if (se != qe) err.structure(rec, 3); // utils.mojo:458-461 as a cumulative test
             }
         }
-        // ---- gather the three streams -------------------------------------------------------------
-        const int js = (1 - ph) & 3;
-        const int nl_lines = (int)c + 1;
-        const int nk_h = jh < nl_lines ? ((nl_lines - 1 - jh) >> 2) + 1 : 0;
-        const int nk_s = js < nl_lines ? ((nl_lines - 1 - js) >> 2) + 1 : 0;
-        const int nk_q = jq < nl_lines ? ((nl_lines - 1 - jq) >> 2) + 1 : 0;
+        // ---- scatter: whole source pieces from registers, line heads/tails through the LDS window ----
         if (!(a.ablate & 1)) {
-        gather_role2<1, CA, CQ>(a.col_seq, S, n_seq, s_src[1], s_len[1], s_dst[1], s_blk[1], nk_s, s_tile, P + js, a.q_lower, a.q_upper, err);
-        gather_role2<3, CA, CQ>(a.col_qual, Q, n_qual, s_src[2], s_len[2], s_dst[2], s_blk[2], nk_q, s_tile, P + jq, a.q_lower, a.q_upper, err);
-        gather_role2<0, CA, CQ>(a.col_id, I, n_id, s_src[0], s_len[0], s_dst[0], s_blk[0], nk_h, s_tile, P + jh, a.q_lower, a.q_upper, err);
+#pragma unroll
+            for (int sidx = 0; sidx < ((a.ablate & 4) ? 0 : 4); ++sidx) {
+                const int q = tid + BLOCK * sidx;
+                const int pos = q * 16;
+                if (pos < valid) {
+                    const int j = (int)s_pline[q];
+                    const int role = (ph + j) & 3;
+                    const int k = j >> 2;
+                    const int slot = role == 0 ? 0 : (role == 1 ? 1 : 2);
+                    const int src = (int)s_src[slot][k], len = (int)s_len[slot][k], dd = (int)s_dst[slot][k];
+                    const int64_t base = role == 0 ? I : (role == 1 ? S : Q);
+                    uint8_t* col = role == 0 ? a.col_id : (role == 1 ? a.col_seq : a.col_qual);
+                    int64_t addr = base + dd + (pos - src);
+                    if (a.ablate & 8) addr &= 0xFFFFF;
+                    if (role != 2 && pos >= src && pos + 16 <= src + len && base + dd >= 0) {
+                        const int64_t rec = (P + j) >> 2;
+                        if (CA && any_non_ascii(r[sidx].x | r[sidx].y | r[sidx].z | r[sidx].w)) err.valid(rec, 4);
+                        if (CQ && role == 3 &&
+                            (any_out_of_range(r[sidx].x, a.q_lower, a.q_upper) | any_out_of_range(r[sidx].y, a.q_lower, a.q_upper) |
+                             any_out_of_range(r[sidx].z, a.q_lower, a.q_upper) | any_out_of_range(r[sidx].w, a.q_lower, a.q_upper)))
+                            err.valid(rec, 5);
+                        U16B v{r[sidx].x, r[sidx].y, r[sidx].z, r[sidx].w};
+                        if (!(a.ablate & 16)) *reinterpret_cast<U16B*>(col + addr) = v;
+                        else if (addr == -12345) *reinterpret_cast<U16B*>(col + addr) = v;
+                    }
+                }
+            }
+            // heads and tails: thread k owns segment k of every role
+            if (!(a.ablate & 2)) {
+                const int jr[3] = {jh, (1 - ph) & 3, jq};
+#pragma unroll
+                for (int slot = 0; slot < 3; ++slot) {
+                    const int len = (int)s_len[slot][tid];
+                    const int64_t base = slot == 0 ? I : (slot == 1 ? S : Q);
+                    int64_t d0 = base + (int64_t)s_dst[slot][tid];
+                    if (a.ablate & 8) d0 &= 0xFFFFF;
+                    if (len > 0 && d0 >= 0) {
+                        uint8_t* col = slot == 0 ? a.col_id : (slot == 1 ? a.col_seq : a.col_qual);
+                        const int src = (int)s_src[slot][tid];
+                        const int64_t rec = (P + 4 * tid + jr[slot]) >> 2;
+                        const int au = (src + 15) & ~15;
+                        const int a1 = au < src + len ? au : src + len;          // head: [src, a1)
+                        const int ad = (src + len) & ~15;
+                        const int b0 = ad > a1 ? ad : a1;                         // tail: [b0, src+len)
+                        if (slot == 0) {
+                            emit_part<0, CA, CQ>(col, d0, src, a1 - src, s_tile, rec, a.q_lower, a.q_upper, err);
+                            emit_part<0, CA, CQ>(col, d0 + (b0 - src), b0, src + len - b0, s_tile, rec, a.q_lower, a.q_upper, err);
+                        } else if (slot == 1) {
+                            emit_part<1, CA, CQ>(col, d0, src, a1 - src, s_tile, rec, a.q_lower, a.q_upper, err);
+                            emit_part<1, CA, CQ>(col, d0 + (b0 - src), b0, src + len - b0, s_tile, rec, a.q_lower, a.q_upper, err);
+                        } else {
+                            emit_part<3, CA, CQ>(col, d0, src, a1 - src, s_tile, rec, a.q_lower, a.q_upper, err);
+                            emit_part<3, CA, CQ>(col, d0 + (b0 - src), b0, src + len - b0, s_tile, rec, a.q_lower, a.q_upper, err);
+                        }
+                    }
+                }
+            }
         }
     }
     if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
     if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
     if (overflow) atomicOr(&a.st->rec_overflow, 1);
+    if (LB) break;
+    t += (int64_t)gridDim.x;      // persistent workgroups: the column stores of this tile drain while the next one loads
+    if (t >= a.tile_end) break;
+    __syncthreads();
+  }
 }
 
 

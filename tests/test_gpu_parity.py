@@ -215,3 +215,83 @@ def test_streaming_chunks_equal_one_shot():
             assert d.copy_to_host()._sequence_bytes.tobytes() == r.seq_bytes
             n += 1
         assert n == len(ref)
+
+
+def _run_shards_on_one_gpu(data: np.ndarray, cuts, ocfg, single_pass=True, **kw):
+    """Every shard goes through bzq_shard_scan / bzq_submit_shard on the one GPU; the halo exchange that
+    RCCL does between ranks is a device-to-device copy here."""
+    import torch
+    from blazeseq_amd import sharded
+    import blazeseq_amd as B
+    bounds = [0, *cuts, data.size]
+    P = len(bounds) - 1
+    ctxs, bufs, sums = [], [], []
+    for r in range(P):
+        n = bounds[r + 1] - bounds[r]
+        t = torch.zeros(n + (1 << 17), dtype=torch.uint8, device="cuda")
+        t[:n] = torch.from_numpy(data[bounds[r]:bounds[r + 1]].copy()).cuda()
+        ctx = B.Context(B.ParserConfig(**kw), "generic", 4096, 0)
+        ctx.set_option("single_pass", int(single_pass))
+        s = ctx.shard_scan(t.data_ptr(), n)
+        ctxs.append(ctx); bufs.append(t)
+        sums.append([int(s.n_bytes), int(s.n_newlines), *[int(x) for x in s.first_nl], int(s.first_byte), int(s.last_byte)])
+        assert sums[-1][1] == int(np.count_nonzero(data[bounds[r]:bounds[r + 1]] == 10))
+    plans = sharded.plan_shards(sums)
+    total, ids, seqs, quals, ends = 0, [], [], [], []
+    for r in range(P):
+        n = bounds[r + 1] - bounds[r]
+        p = plans[r]
+        if p.halo_src >= 0:
+            bufs[r][n:n + p.halo_bytes] = bufs[p.halo_src][:p.halo_bytes]
+        is_last = all(s[0] == 0 for s in sums[r + 1:])
+        ctxs[r].submit_shard(bufs[r].data_ptr(), n, p.halo_bytes, p.lines_before, p.prev_last_byte, bounds[r], is_last)
+        res = ctxs[r].result()
+        assert res.status in (0, 6), (r, res.status, ctxs[r].format_error())
+        total += int(res.n_records)
+        ids.append(res.id()); seqs.append(res.seq()); quals.append(res.qual())
+        e = res.ends()
+        ends.append(e + (ends[-1][-1] if ends and ends[-1].size else 0) if e.size else e)
+    for c in ctxs:
+        c.close()
+    cat = lambda xs, dt: np.concatenate(xs) if xs else np.zeros(0, dt)
+    return total, cat(ids, np.uint8), cat(seqs, np.uint8), cat(quals, np.uint8), cat([e for e in ends if e.size], np.int64)
+
+
+@pytest.mark.parametrize("single_pass", [True, False])
+@pytest.mark.parametrize("seed", range(6))
+def test_shards_on_one_gpu(seed, single_pass):
+    """bzq_shard_scan + k_head + bzq_submit_shard: byte-range shards cut anywhere reproduce the whole parse."""
+    rng = np.random.default_rng(3000 + seed)
+    max_len = int(rng.choice([40, 150, 3000]))
+    data = np.frombuffer(rand_stream(rng, n_records=int(rng.integers(300, 1500)) if max_len < 1000 else 60,
+                                     max_len=max_len, dirty=0.0, tail=0, crlf=bool(rng.random() < 0.2)), dtype=np.uint8)
+    oc = O.make_config(check_ascii=True, check_quality=True)
+    whole = O.flat_parse(data, oc)
+    assert whole.term_code == O.EOF
+    for P in (2, 3, 5):
+        lo = 4 * (2 * max_len + 40)
+        if data.size < P * lo * 2:
+            continue
+        cuts = sorted(int(x) for x in rng.integers(lo, data.size - lo, P - 1))
+        cuts = [c for i, c in enumerate(cuts) if i == 0 or c - cuts[i - 1] > lo]
+        total, ids, seqs, quals, ends = _run_shards_on_one_gpu(data, cuts, oc, single_pass=single_pass,
+                                                              check_ascii=True, check_quality=True)
+        assert total == whole.n_records, (P, cuts)
+        np.testing.assert_array_equal(ids, whole.id_bytes)
+        np.testing.assert_array_equal(seqs, whole.seq_bytes)
+        np.testing.assert_array_equal(quals, whole.qual_bytes)
+        np.testing.assert_array_equal(ends, whole.ends)
+
+
+def test_shards_record_aligned_and_header_cut():
+    """Cuts exactly at a record start, exactly after '@', and inside the '+' line."""
+    rec = b"@read7 desc\nACGTACGT\n+read7\nIIIIIIII\n"
+    data = np.frombuffer(rec * 800, dtype=np.uint8)
+    oc = O.make_config()
+    whole = O.flat_parse(data, oc)
+    L = len(rec)
+    for cut in (L * 400, L * 400 + 1, L * 400 + 12, L * 400 + 22, L * 400 + 27, L * 400 + L - 1):
+        total, ids, seqs, quals, ends = _run_shards_on_one_gpu(data, [cut], oc)
+        assert total == whole.n_records, cut
+        np.testing.assert_array_equal(ids, whole.id_bytes)
+        np.testing.assert_array_equal(quals, whole.qual_bytes)
