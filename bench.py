@@ -60,9 +60,11 @@ def main():
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--validate", action="store_true", help="config 3: check_ascii + check_quality, sanger")
     ap.add_argument("--pass-bytes", type=int, default=0)
-    ap.add_argument("--two-pass", action="store_true", help="use the two-pass kernels instead of the single-pass one")
+    ap.add_argument("--single-pass", action="store_true", help="one fused launch with in-kernel look-back (slower today)")
+    ap.add_argument("--two-pass", action="store_true", help="(default) aggregate + scan + emit kernels")
     ap.add_argument("--kernels-v1", action="store_true", help="two-pass mode with the first-generation kernels")
-    ap.add_argument("--emit-persistent", type=int, default=1)
+    ap.add_argument("--emit-persistent", type=int, default=0)
+    ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU shard protocol even with one rank")
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (results are wrong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-reads", type=int, default=1_000_000)
@@ -82,15 +84,18 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    sharded_mode = world > 1 or args.force_sharded
+    if sharded_mode:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = B.ParserConfig(check_ascii=args.validate, check_quality=args.validate,
                          quality_schema="sanger" if args.validate else None)
     ctx = B.Context(cfg, "generic", 4096, local_rank, pass_bytes=args.pass_bytes)
     ctx.set_option("timing_detail", 1)
-    ctx.set_option("single_pass", 0 if (args.two_pass or args.kernels_v1) else 1)
+    ctx.set_option("single_pass", 1 if (args.single_pass and not args.kernels_v1) else 0)
     ctx.set_option("kernels_v2", 0 if args.kernels_v1 else 1)
     if args.ablate:
         ctx.set_option("ablate", args.ablate)
@@ -119,7 +124,7 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        if world == 1:
+        if not sharded_mode:
             ctx.submit_device(shard.data_ptr(), n, 0, True)
             return ctx.result(), None, None
         res, plan, totals, first_err = sharded.parse_sharded(ctx, shard, n, lo)
@@ -128,7 +133,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded_mode:
         dist.barrier()
     ms_emit = ms_agg = ms_scan = ms_rebase = ms_kernels = 0.0
     t0 = time.perf_counter()
@@ -137,10 +142,10 @@ def main():
         ms_emit += res.ms_emit; ms_agg += res.ms_aggregate; ms_scan += res.ms_scan
         ms_rebase += res.ms_rebase; ms_kernels += res.ms_total
     torch.cuda.synchronize()
-    if world > 1:
+    if sharded_mode:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if sharded_mode:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -149,7 +154,7 @@ def main():
     recs = int(res.n_records)
     if args.ablate:
         global_records, global_bytes = args.reads, n
-    elif world == 1:
+    elif not sharded_mode:
         assert recs == args.reads and res.status == L.EOF, (recs, res.status, ctx.format_error())
         assert int(res.seq_bytes) == args.read_len * recs == int(res.qual_bytes)
         global_records, global_bytes = recs, n
@@ -157,6 +162,9 @@ def main():
         assert totals[0] == total_reads and first_err == sharded.NO_ERROR, (totals, first_err)
         global_records, global_bytes = totals[0], total_bytes
 
+    if sharded_mode:
+        dist.barrier()
+        dist.destroy_process_group()
     if rank == 0:
         steps = args.steps
         sec_per_step = elapsed / steps
@@ -182,7 +190,7 @@ def main():
                        "pass_bytes": args.pass_bytes},
             "fraction_of_hbm_peak_input_rate": round(global_bytes / world / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {
-                "bound": "hbm", "kernel": "k_tile_emit" if args.kernels_v1 else ("k_fused<LB=false>" if args.two_pass else "k_fused<LB=true>"),
+                "bound": "hbm", "kernel": "k_tile_emit" if args.kernels_v1 else ("k_fused<LB=true>" if args.single_pass else "k_fused<LB=false>"),
                 "achieved": round(A * per_rank_records / emit_s / 1e9, 2) if emit_s > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(A * per_rank_records / emit_s / 1e9 / HBM_PEAK_GBS, 4) if emit_s > 0 else None,
@@ -202,9 +210,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_reads, args.read_len, args.validate)
-        print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+        # RCCL writes a version banner to C stdio; flush it first so that the JSON is the last line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -78,8 +78,8 @@ struct bzq_ctx {
     hipEvent_t ev[8]{};
     std::vector<hipEvent_t> ev_detail;
     // options
-    int ablate = 0, emit_persistent = 1;
-    int force_dense = 0, timing_detail = 0, single_pass = 1, v2 = 1, num_cu = 256, wg_per_cu = 0;
+    int ablate = 0, emit_persistent = 0;
+    int force_dense = 0, timing_detail = 0, single_pass = 0, v2 = 1, num_cu = 256, wg_per_cu = 0;
     bool ran_single_pass = false;
     // current chunk
     const uint8_t* cur = nullptr;
