@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--validate", action="store_true", help="config 3: check_ascii + check_quality, sanger")
     ap.add_argument("--pass-bytes", type=int, default=0)
     ap.add_argument("--single-pass", action="store_true", help="one fused launch with in-kernel look-back (slower today)")
+    ap.add_argument("--service", action="store_true", help="one launch, prefix-service workgroup (bzq_single.hpp)")
+    ap.add_argument("--hier", action="store_true", help="one launch, two-level decoupled look-back (bzq_single.hpp)")
     ap.add_argument("--two-pass", action="store_true", help="(default) aggregate + scan + emit kernels")
     ap.add_argument("--kernels-v1", action="store_true", help="two-pass mode with the first-generation kernels")
     ap.add_argument("--emit-persistent", type=int, default=0)
@@ -95,7 +97,7 @@ def main():
                          quality_schema="sanger" if args.validate else None)
     ctx = B.Context(cfg, "generic", 4096, local_rank, pass_bytes=args.pass_bytes)
     ctx.set_option("timing_detail", 1)
-    ctx.set_option("single_pass", 1 if (args.single_pass and not args.kernels_v1) else 0)
+    ctx.set_option("single_pass", 3 if args.hier else 2 if args.service else (1 if (args.single_pass and not args.kernels_v1) else 0))
     ctx.set_option("kernels_v2", 0 if args.kernels_v1 else 1)
     if args.ablate:
         ctx.set_option("ablate", args.ablate)
@@ -190,7 +192,7 @@ def main():
                        "pass_bytes": args.pass_bytes},
             "fraction_of_hbm_peak_input_rate": round(global_bytes / world / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {
-                "bound": "hbm", "kernel": "k_tile_emit" if args.kernels_v1 else ("k_fused<LB=true>" if args.single_pass else "k_fused<LB=false>"),
+                "bound": "hbm", "kernel": "k_tile_emit" if args.kernels_v1 else ("k_single<look-back>" if args.hier else "k_single<service>" if args.service else ("k_fused<LB=true>" if args.single_pass else "k_fused<LB=false>")),
                 "achieved": round(A * per_rank_records / emit_s / 1e9, 2) if emit_s > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(A * per_rank_records / emit_s / 1e9 / HBM_PEAK_GBS, 4) if emit_s > 0 else None,

@@ -7,7 +7,7 @@
 // three synchronisations per 4096 records.  There is NO CPU fallback: without a gfx950 device
 // bzq_create fails.
 #include "../../include/blazeseq_hip.h"
-#include "bzq_fused.hpp"
+#include "bzq_single.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -145,7 +145,7 @@ int ensure_chunk_arenas(bzq_ctx* c, uint64_t n, bool need_input) {
             (rc = ensure(c, c->tile_idc, nt * 8)) || (rc = ensure(c, c->tileP, nt * 8)) ||
             (rc = ensure(c, c->tileS, nt * 8)) || (rc = ensure(c, c->tileQ, nt * 8)) ||
             (rc = ensure(c, c->tileI, nt * 8)) || (rc = ensure(c, c->grp, (nt / SG_TILES + 2) * 80)) ||
-            (rc = ensure(c, c->grp_carry, (nt / SG_TILES + 2) * 32)) || (rc = ensure(c, c->desc, (nt * 5 + 8) * 8)))
+            (rc = ensure(c, c->grp_carry, (nt / SG_TILES + 2) * 32)) || (rc = ensure(c, c->desc, (nt * 6 + (nt / 64 + 2) * 4 + 16) * 8)))
             return rc;
         c->tile_cap = nt;
     }
@@ -272,6 +272,44 @@ int enqueue_fused(bzq_ctx* c) {
     return 0;
 }
 
+template <bool CA, bool CQ>
+void launch_single_off(const bzq_ctx* c, bool offs, int mode, dim3 grid, const SingleArgs& a) {
+    if (mode == 0) {
+        if (offs) hipLaunchKernelGGL((k_single<CA, CQ, true, 0>), grid, dim3(BLOCK), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_single<CA, CQ, false, 0>), grid, dim3(BLOCK), 0, c->stream, a);
+    } else {
+        if (offs) hipLaunchKernelGGL((k_single<CA, CQ, true, 1>), grid, dim3(BLOCK), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_single<CA, CQ, false, 1>), grid, dim3(BLOCK), 0, c->stream, a);
+    }
+}
+
+// One launch for the whole chunk: tiles + one prefix-service workgroup (bzq_single.hpp).
+int enqueue_single(bzq_ctx* c) {
+    const int64_t nt = tiles_for(c->cur_n);
+    u64* d = (u64*)c->desc.p;
+    const int64_t nb = nt / HB + 2;
+    hipError_t e = hipMemsetAsync(d, 0, (size_t)(nt * 6 + nb * 4 + 16) * 8, c->stream);
+    if (e != hipSuccess) { c->err = std::string("hipMemsetAsync(desc): ") + hipGetErrorString(e); return BZQ_ERR_HIP; }
+    SingleArgs sa{};
+    sa.f = make_fused_args(c);
+    sa.f.ticket = d;
+    sa.dc = d + 16; sa.pc = sa.dc + nt; sa.da = sa.pc + nt; sa.ps = sa.da + nt; sa.pq = sa.ps + nt; sa.pi = sa.pq + nt;
+    sa.bc = sa.pi + nt; sa.bs = sa.bc + nb; sa.bq = sa.bs + nb; sa.bi = sa.bq + nb;
+    const int mode = c->single_pass == 3 ? 1 : 0;
+    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    const dim3 grid((unsigned)(nt + (mode == 0 ? 1 : 0)));
+    const bool ca = c->cfg.check_ascii != 0, cq = c->cfg.check_quality != 0, off = c->cfg.emit_offsets != 0;
+    if (ca && cq) launch_single_off<true, true>(c, off, mode, grid, sa);
+    else if (ca) launch_single_off<true, false>(c, off, mode, grid, sa);
+    else if (cq) launch_single_off<false, true>(c, off, mode, grid, sa);
+    else launch_single_off<false, false>(c, off, mode, grid, sa);
+    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    c->n_passes = 1;
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { c->err = std::string("kernel launch: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
+    return 0;
+}
+
 void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, bool first_pass) {
     ScanArgs s{tb, te, (const uint32_t*)c->tile_c.p, (const u64*)c->tile_a.p, (const u64*)c->tile_idc.p,
                (int64_t*)c->tileP.p, (int64_t*)c->tileS.p, (int64_t*)c->tileQ.p, (int64_t*)c->tileI.p,
@@ -357,7 +395,7 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
         hipLaunchKernelGGL(k_head, dim3(1), dim3(64), 0, c->stream, d_data, (int64_t)n, prev_byte, head_lines, c->d_state);
     if (n > 0) {
         c->ran_single_pass = c->single_pass != 0;
-        if (c->ran_single_pass) { if ((rc = enqueue_fused(c))) return rc; }
+        if (c->ran_single_pass) { if ((rc = (c->single_pass >= 2 ? enqueue_single(c) : enqueue_fused(c)))) return rc; }
         else if ((rc = enqueue_passes(c, false, reuse_aggregates))) return rc;
         hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state);
     }
@@ -608,7 +646,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         if (c->ran_single_pass) { fresh.last_nl_tile = -1; }
         *h = fresh;
         HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
-        if (c->ran_single_pass) { if ((rc = enqueue_fused(c))) return rc; }
+        if (c->ran_single_pass) { if ((rc = (c->single_pass >= 2 ? enqueue_single(c) : enqueue_fused(c)))) return rc; }
         else if ((rc = enqueue_passes(c, true, false))) return rc;
         HIPCHK(c, hipStreamSynchronize(c->stream));
         HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));

@@ -14,7 +14,7 @@ def make_pair(batch_size=4096, schema="generic", pass_bytes=0, min_record_bytes=
     ctx = B.Context(cfg, schema, batch_size, 0, pass_bytes=pass_bytes, min_record_bytes=min_record_bytes)
     # single_pass: True = one fused launch with in-kernel look-back; False = aggregate + scan + emit
     # (table-driven v2 kernels); "v1" = the first-generation two-pass kernels
-    ctx.set_option("single_pass", int(single_pass is True))
+    ctx.set_option("single_pass", {"svc": 2, "hier": 3}.get(single_pass, int(single_pass is True)))
     ctx.set_option("kernels_v2", 0 if single_pass == "v1" else 1)
     okw.pop("quality_schema", None)
     ocfg = O.make_config(quality_schema=name, simd_width=kw.get("compat_simd_width", 0), batch_size=batch_size, **okw)

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CORPUS = json.load(open(os.path.join(HERE, "golden", "corpus_expected.json")))
 
 
-@pytest.mark.parametrize("single_pass", [True, False, "v1"])
+@pytest.mark.parametrize("single_pass", [True, False, "v1", "svc", "hier"])
 def test_inline_known_answers(single_pass):
     ctx, oc = make_pair(emit_offsets=True, single_pass=single_pass)
     for data in (b"@r1\nACGT\n+\n!!!!\n@r2\nTGCA\n+\n####\n", b"", b"\n", b"@", b"@a\nA\n+\n!\n",
@@ -29,7 +29,7 @@ def test_inline_known_answers(single_pass):
         check_against_oracle(ctx, oc, data, offsets=True, what=repr(data[:20]))
 
 
-@pytest.mark.parametrize("single_pass", [True, False, "v1"])
+@pytest.mark.parametrize("single_pass", [True, False, "v1", "svc", "hier"])
 @pytest.mark.parametrize("cfgname", ["default", "validated_generic", "validated_schema", "validated_schema_simd32",
                                      "cap64", "cap64_growth"])
 def test_corpus(cfgname, single_pass, corpus_dir):
@@ -58,7 +58,7 @@ def test_fuzz_small(seed):
         for kw in (dict(), dict(check_ascii=True, check_quality=True),
                    dict(check_ascii=True, check_quality=True, quality_schema="solexa", compat_simd_width=16),
                    dict(buffer_capacity=48), dict(buffer_capacity=48, buffer_growth_enabled=True, buffer_max_capacity=200)):
-            ctx, oc = make_pair(batch_size=int(rng.choice([1, 3, 4096])), emit_offsets=True, single_pass=[True, False, "v1"][rep % 3], **kw)
+            ctx, oc = make_pair(batch_size=int(rng.choice([1, 3, 4096])), emit_offsets=True, single_pass=[True, False, "v1", "svc", "hier"][rep % 5], **kw)
             check_against_oracle(ctx, oc, data, offsets=True, what=f"seed{seed}/{rep}/{kw}")
             if rep == 0:
                 ctx.set_option("force_dense", 1)   # every tile through the serial in-kernel path
@@ -80,6 +80,10 @@ def test_fuzz_multi_tile(seed):
         check_against_oracle(ctx, oc, data, offsets=True, what=f"mt seed{seed} {kw} pass={pb}")
         ctx.set_option("single_pass", 1)
         check_against_oracle(ctx, oc, data, offsets=True, what=f"mt single-pass seed{seed} {kw}")
+        ctx.set_option("single_pass", 2)
+        check_against_oracle(ctx, oc, data, offsets=True, what=f"mt service seed{seed} {kw}")
+        ctx.set_option("single_pass", 3)
+        check_against_oracle(ctx, oc, data, offsets=True, what=f"mt two-level look-back seed{seed} {kw}")
         check_against_oracle(ctx, oc, data, is_eof=False, offsets=True, what=f"mt chunk-mode seed{seed}")
         ctx.set_option("force_dense", 1)
         check_against_oracle(ctx, oc, data, offsets=True, what=f"mt dense seed{seed}")
@@ -97,7 +101,7 @@ def test_space_runs_across_tile_edges():
         parts.append(b"@" + lead + rid + trail + b"\n" + b"A" * L + b"\n+\n" + b"I" * L + b"\n")
     data = b"".join(parts)
     for dense in (0, 1):
-        for sp in (True, False, "v1"):
+        for sp in (True, False, "v1", "svc", "hier"):
             ctx, oc = make_pair(emit_offsets=True, check_ascii=True, check_quality=True, single_pass=sp)
             ctx.set_option("force_dense", dense)
             check_against_oracle(ctx, oc, data, offsets=True, what=f"space runs dense={dense} single_pass={sp}")
@@ -108,7 +112,7 @@ def test_tiny_records_take_serial_path_and_resize():
     """> 1020 newlines in a 16 KiB tile (records of 4-12 bytes): serial in-kernel path, and the
     per-record arrays are re-sized transparently."""
     data = b"@\n\n+\n\n" * 9000 + b"@a\nC\n+\n!\n" * 3000
-    for sp in (True, False, "v1"):
+    for sp in (True, False, "v1", "svc", "hier"):
         ctx, oc = make_pair(emit_offsets=True, check_ascii=True, check_quality=True, single_pass=sp)
         res, f = check_against_oracle(ctx, oc, data, offsets=True, what=f"tiny single_pass={sp}")
         assert res._pad > 0  # dense tiles were used
@@ -127,7 +131,7 @@ def test_device_generator_matches_oracle():
     ctx.close()
 
 
-@pytest.mark.parametrize("single_pass", [True, False, "v1"])
+@pytest.mark.parametrize("single_pass", [True, False, "v1", "svc", "hier"])
 @pytest.mark.parametrize("validate", [False, True])
 def test_synthetic_150bp_medium(validate, single_pass):
     """Config 2/3 shape at a size the oracle parses in a second: 150k reads (47.7 MB)."""
@@ -257,7 +261,7 @@ def _run_shards_on_one_gpu(data: np.ndarray, cuts, ocfg, single_pass=True, **kw)
     return total, cat(ids, np.uint8), cat(seqs, np.uint8), cat(quals, np.uint8), cat([e for e in ends if e.size], np.int64)
 
 
-@pytest.mark.parametrize("single_pass", [True, False])
+@pytest.mark.parametrize("single_pass", [True, False, 2, 3])
 @pytest.mark.parametrize("seed", range(6))
 def test_shards_on_one_gpu(seed, single_pass):
     """bzq_shard_scan + k_head + bzq_submit_shard: byte-range shards cut anywhere reproduce the whole parse."""
