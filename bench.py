@@ -26,6 +26,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+# rocprofv3 PMC, emit kernel, 10 M x 150 bp: FETCH_SIZE 1589372 KB (x2 on gfx950) + WRITE_SIZE 3782130 KB per launch
+MEASURED_TRAFFIC_B_PER_RECORD = (1589372.4 * 2 + 3782130.3) * 1024 / 1e7
 
 
 def cpu_baseline(reads: int, read_len: int, check: bool):
@@ -66,6 +68,7 @@ def main():
     ap.add_argument("--two-pass", action="store_true", help="(default) aggregate + scan + emit kernels")
     ap.add_argument("--kernels-v1", action="store_true", help="two-pass mode with the first-generation kernels")
     ap.add_argument("--emit-persistent", type=int, default=0)
+    ap.add_argument("--overlap", type=int, default=0, help="overlap pass A of sub-chunk k+1 with the emit of sub-chunk k (needs --pass-bytes)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU shard protocol even with one rank")
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (results are wrong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,6 +105,8 @@ def main():
     if args.ablate:
         ctx.set_option("ablate", args.ablate)
     ctx.set_option("emit_persistent", args.emit_persistent)
+    ctx.set_option("overlap", args.overlap)
+    ctx.set_option("timing_detail", 0 if args.overlap else 1)
 
     # ---- synthetic input, generated on the device (record i depends only on i) ------------------
     total_reads = args.reads * world
@@ -196,7 +201,15 @@ def main():
                 "achieved": round(A * per_rank_records / emit_s / 1e9, 2) if emit_s > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(A * per_rank_records / emit_s / 1e9 / HBM_PEAK_GBS, 4) if emit_s > 0 else None,
-                "traffic": None,
+                # HBM bytes per launch from the PMC counters of the same command (rocprofv3, separate --pmc passes;
+                # FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md), committed under profiles/.
+                # Only quoted for the profiled configuration (150 bp, validation off, two-pass default).
+                "traffic": (round(MEASURED_TRAFFIC_B_PER_RECORD * per_rank_records / 1e9, 3)
+                            if (args.read_len == 150 and not args.validate and not args.single_pass and not args.service
+                                and not args.hier and not args.kernels_v1) else None),
+                "traffic_unit": "GB per launch",
+                "traffic_source": "profiles/r1_final_default_summary.txt: k_fused FETCH_SIZE*2 + WRITE_SIZE",
+                "algorithmic_gb_per_launch": round(A * per_rank_records / 1e9, 3),
                 "algorithmic_bytes_per_record": A,
                 "avg_launch_ms": round(ms_emit / steps / max(1, int(res.n_passes)), 4),
                 "launches_per_step": int(res.n_passes),

@@ -65,6 +65,9 @@ struct bzq_ctx {
     int device = 0;
     bzq_config cfg{};
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // emit kernels of sub-chunk k overlap pass A of sub-chunk k+1
+    std::vector<hipEvent_t> ev_pipe;
+    int overlap = 0;
     bool own_stream = true;
     std::string err;
     // arenas
@@ -357,7 +360,19 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
         if (c->v2) {
             FusedArgs f = make_fused_args(c);
             f.tile_begin = tb; f.tile_end = te;
-            launch_fused<false>(c, c->emit_persistent ? dim3(0) : grid, f);
+            if (c->overlap && !emit_only) {
+                // emit(k) runs on the second stream behind scan(k); pass A of k+1 proceeds on the main stream
+                while ((int64_t)c->ev_pipe.size() <= 2 * passes + 1) { hipEvent_t ev; (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming); c->ev_pipe.push_back(ev); }
+                (void)hipEventRecord(c->ev_pipe[2 * passes], c->stream);
+                (void)hipStreamWaitEvent(c->stream2, c->ev_pipe[2 * passes], 0);
+                hipStream_t keep = c->stream;
+                c->stream = c->stream2;
+                launch_fused<false>(c, c->emit_persistent ? dim3(0) : grid, f);
+                c->stream = keep;
+                (void)hipEventRecord(c->ev_pipe[2 * passes + 1], c->stream2);
+            } else {
+                launch_fused<false>(c, c->emit_persistent ? dim3(0) : grid, f);
+            }
         } else {
             EmitArgs e = make_emit_args(c);
             e.tile_begin = tb;
@@ -365,6 +380,8 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
         }
         if (!emit_only && c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
     }
+    if (c->overlap && !emit_only && c->v2)
+        for (int64_t k = 0; k < passes; ++k) (void)hipStreamWaitEvent(c->stream, c->ev_pipe[2 * k + 1], 0);
     c->n_passes = passes;
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->err = std::string("kernel launch: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
@@ -531,6 +548,7 @@ int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
     }
     CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    CRT(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
     CRT(hipMalloc((void**)&c->d_state, sizeof(ChunkState)));
     CRT(hipHostMalloc((void**)&c->h_state, sizeof(ChunkState), hipHostMallocDefault));
     for (auto& ev : c->ev) CRT(hipEventCreate(&ev));
@@ -553,6 +571,8 @@ void bzq_destroy(bzq_ctx* c) {
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     for (hipEvent_t e : c->ev_detail) hipEventDestroy(e);
     if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (c->stream2) hipStreamDestroy(c->stream2);
+    for (hipEvent_t e : c->ev_pipe) hipEventDestroy(e);
     delete c;
 }
 
@@ -582,6 +602,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "wg_per_cu")) c->wg_per_cu = (int)value;
     else if (!strcmp(key, "ablate")) c->ablate = (int)value;
     else if (!strcmp(key, "emit_persistent")) c->emit_persistent = (int)value;
+    else if (!strcmp(key, "overlap")) c->overlap = (int)value;
     else if (!strcmp(key, "pass_bytes")) c->cfg.pass_bytes = value > 0 ? std::max<int64_t>(TILE, (value / TILE) * TILE) : 0;
     else { c->err = std::string("unknown option ") + key; return BZQ_ERR_ARG; }
     return 0;

@@ -1,27 +1,20 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): kernel-trace stats + separate PMC passes of the bench command.
-# Usage: scripts/gpu_profile.sh <tag> [bench args...]
+# Runs on the GPU box (via gpurun): kernel-trace stats + separate PMC passes of the bench command
+# (PMC never combined with other tracing, per the pool rules).  Usage: scripts/gpu_profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r1}; shift || true
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 BENCH="python bench.py --no-cpu-baseline $*"
-(timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o $TAG -- $BENCH --steps 5 --warmup 2) > $OUT/kt.log 2>&1
-echo "kt rc=$?"
-(timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq -o $TAG -- $BENCH --steps 2 --warmup 1) > $OUT/pmc_sq.log 2>&1
-echo "pmc_sq rc=$?"
-(timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM -d $OUT/pmc_sq2 -o $TAG -- $BENCH --steps 2 --warmup 1) > $OUT/pmc_sq2.log 2>&1
-echo "pmc_sq2 rc=$?"
-(timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG -- $BENCH --steps 2 --warmup 1) > $OUT/pmc_fetch.log 2>&1
-echo "pmc_fetch rc=$?"
-(timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG -- $BENCH --steps 2 --warmup 1) > $OUT/pmc_write.log 2>&1
-echo "pmc_write rc=$?"
-find $OUT -name "*.csv" | head -30
-du -sh $OUT
-# keep only the CSVs small enough to travel back
+(timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o $TAG -- $BENCH --steps 10 --warmup 3) > $OUT/kt.log 2>&1; echo "kt rc=$?"
+(timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq -o $TAG -- $BENCH --steps 2 --warmup 1) > $OUT/pmc_sq.log 2>&1; echo "pmc_sq rc=$?"
+(timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM -d $OUT/pmc_sq2 -o $TAG -- $BENCH --steps 2 --warmup 1) > $OUT/pmc_sq2.log 2>&1; echo "pmc_sq2 rc=$?"
+(timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG -- $BENCH --steps 2 --warmup 1) > $OUT/pmc_fetch.log 2>&1; echo "pmc_fetch rc=$?"
+(timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG -- $BENCH --steps 2 --warmup 1) > $OUT/pmc_write.log 2>&1; echo "pmc_write rc=$?"
+tail -1 $OUT/kt.log > $OUT/bench_line_under_profiler.json
 find $OUT -type f -size +8M -delete
 python scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
