@@ -388,10 +388,20 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
     return 0;
 }
 
+void enqueue_rebase(bzq_ctx* c) {
+    const bool growth = c->cfg.buffer_growth_enabled != 0;
+    RebaseArgs ra{(const int64_t*)c->ends.p, (const int64_t*)c->id_ends.p, (const int64_t*)c->rec_end.p,
+                  (int64_t*)c->b_ends.p, (int64_t*)c->b_id_ends.p, (int64_t)c->cfg.batch_size, c->cur_first_header,
+                  growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->rec_cap, c->d_state, c->cur,
+                  c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper};
+    hipLaunchKernelGGL(k_rebase, dim3((unsigned)(c->num_cu * 8)), dim3(BLOCK), 0, c->stream, ra);
+}
+
 int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream_pos, int is_eof,
                   int64_t P0, int64_t S0, int64_t Q0, int64_t I0, uint32_t prev_byte, int64_t first_header,
                   const int64_t* first_nl = nullptr, int head_lines = 0, bool reuse_aggregates = false) {
     int rc;
+    if (c->pending) HIPCHK(c, hipStreamSynchronize(c->stream)); // h_state is reused
     if ((rc = ensure_chunk_arenas(c, n, false))) return rc;
     int64_t want = (int64_t)(n / (uint64_t)std::max(4, c->cfg.min_record_bytes)) + 1024;
     if ((rc = ensure_record_arenas(c, want))) return rc;
@@ -417,6 +427,10 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
         hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state);
     }
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    enqueue_rebase(c);
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
     c->pending = true; c->have_result = false;
     return 0;
 }
@@ -638,8 +652,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     if (c->have_result) { *out = c->res; return (c->res.status > 0 && c->res.status != BZQ_EOF) ? c->res.status : 0; }
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    ChunkState* h = c->h_state;
-    HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
+    ChunkState* h = c->h_state; // filled by the async D2H enqueued behind k_rebase
     if (h->lookback_timeout && c->cur_n > 0) {
         // never expected: the single-pass kernel gave up on a predecessor tile.  Same chunk again on
         // the two-pass kernels (no inter-workgroup waiting).
@@ -653,8 +666,9 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         c->ran_single_pass = false;
         if ((rc = enqueue_passes(c, false, false))) return rc;
         hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)c->cur_n, c->d_state);
+        enqueue_rebase(c);
+        HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
     }
     if (h->rec_overflow) {
         // shorter records than the sizing hint assumed: re-size to the exact count, re-run
@@ -669,8 +683,9 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
         if (c->ran_single_pass) { if ((rc = (c->single_pass >= 2 ? enqueue_single(c) : enqueue_fused(c)))) return rc; }
         else if ((rc = enqueue_passes(c, true, false))) return rc;
+        enqueue_rebase(c);
+        HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
         if (h->rec_overflow) { c->err = "record arrays still too small after re-size"; return BZQ_ERR_NOMEM; }
     }
     const int64_t n = (int64_t)c->cur_n;
@@ -680,30 +695,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     const int64_t batch = c->cfg.batch_size;
     const bool growth = c->cfg.buffer_growth_enabled != 0;
     const int64_t len_limit = growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity;
-
-    // per-record post pass: per-batch ends + longest-record check (+ optional SIMD-width emulation)
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    if (n_complete > 0) {
-        RebaseArgs ra{n_complete, (const int64_t*)c->ends.p, (const int64_t*)c->id_ends.p,
-                      (const int64_t*)c->rec_end.p, (int64_t*)c->b_ends.p, (int64_t*)c->b_id_ends.p, batch,
-                      c->cur_first_header, len_limit, c->d_state};
-        hipLaunchKernelGGL(k_rebase, dim3((unsigned)((n_complete + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, ra);
-        if (c->cfg.check_quality && c->cfg.compat_simd_width > 0)
-            hipLaunchKernelGGL(k_compat_quality, dim3((unsigned)((n_complete + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
-                               c->stream, c->cur, n_complete, (const int64_t*)c->ends.p,
-                               (const int64_t*)c->rec_end.p, (int)c->cfg.compat_simd_width, (uint32_t)c->cfg.q_upper,
-                               c->d_state);
-    }
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
-
-    int64_t consumed = c->cur_first_header;
-    if (n_complete > 0) {
-        int64_t last_end = 0;
-        HIPCHK(c, hipMemcpy(&last_end, (const int64_t*)c->rec_end.p + (n_complete - 1), 8, hipMemcpyDeviceToHost));
-        consumed = last_end + 1;
-    }
+    int64_t consumed = n_complete > 0 ? h->last_record_end + 1 : c->cur_first_header;
 
     bzq_chunk r{};
     r.n_bytes = c->cur_n;
@@ -792,9 +784,11 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     }
     r.bytes_consumed = (uint64_t)consumed;
     if (n_records > 0) {
-        int64_t e2[2] = {0, 0};
-        HIPCHK(c, hipMemcpy(&e2[0], (const int64_t*)c->ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(&e2[1], (const int64_t*)c->id_ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
+        int64_t e2[2] = {h->last_ends, h->last_id_ends};
+        if (n_records != n_complete) { // truncated by an error, or extended by the unterminated last record
+            HIPCHK(c, hipMemcpy(&e2[0], (const int64_t*)c->ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&e2[1], (const int64_t*)c->id_ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
+        }
         r.qual_bytes = (uint64_t)e2[0];
         r.seq_bytes = accept_last && r.status == BZQ_EOF ? (uint64_t)h->S : (uint64_t)e2[0];
         r.id_bytes = (uint64_t)e2[1];

@@ -57,6 +57,10 @@ struct ChunkState {
     int64_t first_nl[4];      // offsets of the first four newlines (shard stitch), -1 if absent
     int32_t lookback_timeout; // single-pass kernel gave up waiting for a predecessor tile (never expected)
     int32_t _pad;
+    // written by k_rebase (one D2H of this struct is all the host needs in the common case)
+    int64_t n_complete;       // records with all four newlines
+    int64_t last_record_end;  // record_end[n_complete-1], or first_header-1
+    int64_t last_ends, last_id_ends;
 };
 
 __device__ __forceinline__ bool is_posix_space(uint32_t c) {
@@ -825,7 +829,6 @@ __global__ __launch_bounds__(BLOCK) void k_tile_emit(EmitArgs a) {
 
 // =================================================================================== per record
 struct RebaseArgs {
-    int64_t n_rec;
     const int64_t* ends;
     const int64_t* id_ends;
     const int64_t* rec_end;
@@ -834,22 +837,45 @@ struct RebaseArgs {
     int64_t batch;
     int64_t first_header;  // offset of record 0's header
     int64_t len_limit;     // records longer than this are refused by the reference's buffer
+    int64_t rec_cap;
     ChunkState* st;
+    // optional host-SIMD-width emulation of the quality check (record.mojo:90-97), 0 = off
+    const uint8_t* g;
+    int32_t compat_w;
+    uint32_t q_upper;
 };
 
 // FastqBatch._ends / _id_ends restart at every batch (record_batch.mojo:77-87 via parser.mojo:243):
 // b_ends[r] = ends[r] - ends[first record of r's batch - 1].  Also finds the first record the
-// reference could not hold in its buffer (parser.mojo:484-492).
+// reference could not hold in its buffer (parser.mojo:484-492).  Grid-stride over the records; the
+// record count is read from the device state, so the host can enqueue this without a sync.
 __global__ __launch_bounds__(BLOCK) void k_rebase(RebaseArgs a) {
-    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= a.n_rec) return;
-    const int64_t b0 = (r / a.batch) * a.batch;
-    const int64_t e0 = b0 ? a.ends[b0 - 1] : 0, i0 = b0 ? a.id_ends[b0 - 1] : 0;
-    a.b_ends[r] = a.ends[r] - e0;
-    a.b_id_ends[r] = a.id_ends[r] - i0;
-    const int64_t prev = r ? a.rec_end[r - 1] : a.first_header - 1;
-    const int64_t len = a.rec_end[r] - prev; // header_start .. '\n' inclusive
-    if (len > a.len_limit) atomicMin(&a.st->err_buf, (u64)r << 3);
+    const int64_t lines = a.st->P;
+    int64_t n_rec = lines > 0 ? (lines >> 2) : 0;
+    if (n_rec > a.rec_cap) n_rec = a.rec_cap; // overflow: the host re-sizes and re-runs
+    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < n_rec; r += (int64_t)gridDim.x * BLOCK) {
+        const int64_t b0 = (r / a.batch) * a.batch;
+        const int64_t e0 = b0 ? a.ends[b0 - 1] : 0, i0 = b0 ? a.id_ends[b0 - 1] : 0;
+        const int64_t e = a.ends[r];
+        a.b_ends[r] = e - e0;
+        a.b_id_ends[r] = a.id_ends[r] - i0;
+        const int64_t re = a.rec_end[r];
+        const int64_t prev = r ? a.rec_end[r - 1] : a.first_header - 1;
+        if (re - prev > a.len_limit) atomicMin(&a.st->err_buf, (u64)r << 3); // header_start .. '\n' inclusive
+        if (a.compat_w > 0) {
+            // inside the first floor(n/W)*W quality bytes a byte equal to UPPER is rejected too
+            const int64_t qlen = e - (r ? a.ends[r - 1] : 0);
+            const int64_t qs = re - qlen, body = (qlen / a.compat_w) * a.compat_w;
+            for (int64_t i = 0; i < body; ++i)
+                if (a.g[qs + i] == a.q_upper) { atomicMin(&a.st->err_valid, ((u64)r << 3) | 5ull); break; }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.st->n_complete = n_rec;
+        a.st->last_record_end = n_rec ? a.rec_end[n_rec - 1] : a.first_header - 1;
+        a.st->last_ends = n_rec ? a.ends[n_rec - 1] : 0;
+        a.st->last_id_ends = n_rec ? a.id_ends[n_rec - 1] : 0;
+    }
 }
 
 // Rebased ends for an arbitrary record range (a next_batch call that is not batch aligned).
@@ -860,20 +886,6 @@ __global__ __launch_bounds__(BLOCK) void k_rebase_range(const int64_t* ends, con
     const int64_t e0 = first ? ends[first - 1] : 0, i0 = first ? id_ends[first - 1] : 0;
     out_e[r] = ends[first + r] - e0;
     out_i[r] = id_ends[first + r] - i0;
-}
-
-// Host-SIMD-width emulation of the reference's quality check (record.mojo:90-97): inside the first
-// floor(n/W)*W quality bytes a byte equal to UPPER is rejected too.  Optional (compat_simd_width).
-__global__ __launch_bounds__(BLOCK) void k_compat_quality(const uint8_t* __restrict__ g, int64_t n_rec,
-                                                          const int64_t* ends, const int64_t* rec_end,
-                                                          int W, uint32_t upper, ChunkState* st) {
-    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= n_rec) return;
-    const int64_t qlen = ends[r] - (r ? ends[r - 1] : 0);
-    const int64_t qs = rec_end[r] - qlen;
-    const int64_t body = (qlen / W) * W;
-    for (int64_t i = 0; i < body; ++i)
-        if (g[qs + i] == upper) { atomicMin(&st->err_valid, ((u64)r << 3) | 5ull); break; }
 }
 
 // Writes the per-record outputs of a last record that has no trailing newline (parser.mojo:464-475,
