@@ -266,6 +266,68 @@ __device__ __forceinline__ void emit_part(uint8_t* __restrict__ col, int64_t gad
     store_bytes(col + gaddr, w0, w1, w2, w3, n);
 }
 
+// emit_part with the role decided at run time (all threads of the block share the head/tail work)
+template <bool CA, bool CQ>
+__device__ __forceinline__ void emit_part_rt(uint8_t* __restrict__ col, int64_t gaddr, int s0, int n, const uint8_t* s_tile,
+                                             int64_t rec, bool is_qual, uint32_t qlo, uint32_t qhi, ErrAcc& err) {
+    if (n <= 0) return;
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tile - 16);
+    const int ws = s0 + 16, wd = ws >> 2, sh = ws & 3;
+    const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
+    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
+                   w2 = __builtin_amdgcn_alignbyte(d3, d2, sh), w3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    if (CA || CQ) {
+        const uint32_t m0 = byte_range_mask(0, 0, n), m1 = byte_range_mask(1, 0, n), m2 = byte_range_mask(2, 0, n),
+                       m3 = byte_range_mask(3, 0, n);
+        if (CA && any_non_ascii((w0 & m0) | (w1 & m1) | (w2 & m2) | (w3 & m3))) err.valid(rec, 4);
+        if (CQ && is_qual) {
+            const uint32_t fill = 0x01010101u * qlo;
+            if (any_out_of_range((w0 & m0) | (fill & ~m0), qlo, qhi) | any_out_of_range((w1 & m1) | (fill & ~m1), qlo, qhi) |
+                any_out_of_range((w2 & m2) | (fill & ~m2), qlo, qhi) | any_out_of_range((w3 & m3) | (fill & ~m3), qlo, qhi))
+                err.valid(rec, 5);
+        }
+    }
+    store_bytes(col + gaddr, w0, w1, w2, w3, n);
+}
+
+// 16 bytes = first nA bytes of the LDS window at tile offset offA, then the bytes of line B that follow
+// (window at offB - nA, so they already sit at their final byte positions), stored unaligned at col+gaddr.
+template <bool CA, bool CQ>
+__device__ __forceinline__ void merge_store16(uint8_t* __restrict__ col, int64_t gaddr, int offA, int nA, int offB,
+                                              const uint8_t* s_tile, int64_t recA, int64_t recB, bool is_qual,
+                                              uint32_t qlo, uint32_t qhi, ErrAcc& err) {
+    const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tile - 16);
+    uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+    {
+        const int ws = offA + 16, wd = ws >> 2, sh = ws & 3;
+        const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
+        a0 = __builtin_amdgcn_alignbyte(d1, d0, sh); a1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        a2 = __builtin_amdgcn_alignbyte(d3, d2, sh); a3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    }
+    {
+        const int ws = offB - nA + 16, wd = ws >> 2, sh = ws & 3;
+        const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
+        b0 = __builtin_amdgcn_alignbyte(d1, d0, sh); b1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+        b2 = __builtin_amdgcn_alignbyte(d3, d2, sh); b3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    }
+    const uint32_t m0 = bytes_from_mask(0, nA), m1 = bytes_from_mask(1, nA), m2 = bytes_from_mask(2, nA), m3 = bytes_from_mask(3, nA);
+    if (CA || CQ) {
+        if (CA && any_non_ascii((a0 & ~m0) | (a1 & ~m1) | (a2 & ~m2) | (a3 & ~m3))) err.valid(recA, 4);
+        if (CA && any_non_ascii((b0 & m0) | (b1 & m1) | (b2 & m2) | (b3 & m3))) err.valid(recB, 4);
+        if (CQ && is_qual) {
+            const uint32_t fill = 0x01010101u * qlo;
+            if (any_out_of_range((a0 & ~m0) | (fill & m0), qlo, qhi) | any_out_of_range((a1 & ~m1) | (fill & m1), qlo, qhi) |
+                any_out_of_range((a2 & ~m2) | (fill & m2), qlo, qhi) | any_out_of_range((a3 & ~m3) | (fill & m3), qlo, qhi))
+                err.valid(recA, 5);
+            if (any_out_of_range((b0 & m0) | (fill & ~m0), qlo, qhi) | any_out_of_range((b1 & m1) | (fill & ~m1), qlo, qhi) |
+                any_out_of_range((b2 & m2) | (fill & ~m2), qlo, qhi) | any_out_of_range((b3 & m3) | (fill & ~m3), qlo, qhi))
+                err.valid(recB, 5);
+        }
+    }
+    U16B v{(b0 & m0) | (a0 & ~m0), (b1 & m1) | (a1 & ~m1), (b2 & m2) | (a2 & ~m2), (b3 & m3) | (a3 & ~m3)};
+    *reinterpret_cast<U16B*>(col + gaddr) = v;
+}
+
 template <bool CA, bool CQ, bool OFFS, bool LB>
 __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
@@ -419,47 +481,43 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             n_id = s_cnt[0]; n_seq = s_cnt[1]; n_qual = s_cnt[2];
         }
     } else {
-        // ---- line pass: thread k owns lines 4k..4k+3 = one line of every role (role of line
-        // 4k+r is (P+r)&3 for every k, so each unrolled step is branch-uniform) -------------------
-        uint32_t lh = 0, lsq = 0, lq = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = 4 * tid + r;
-            const int role = (ph + r) & 3;
-            if (j <= (int)c) {
-                const int start = j ? (int)s_nl[j - 1] + 1 : 0;
-                const bool end_in = j < (int)c;
-                const int end = end_in ? (int)s_nl[j] : valid;
-                const int64_t rec = (P + j) >> 2;
-                const bool sknown = j > 0 ? true : first_starts;
-                const bool sin = sknown && start < valid;
-                const int64_t ls = t0 + start;
-                if (role == 0) {
-                    if (sin) {
-                        if (s_tile[start] != 64) err.structure(rec, 1);   // '@', utils.mojo:454
-                        if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_hdr[rec] = ls;
-                    }
-                    int64_t lo = ls, hi = ls;
-                    if (end > start) header_kept(bs, ls, t0 + end, sknown, end_in, t0 + valid, lo, hi);
-                    s_src[0][tid] = (uint16_t)(lo - t0);
-                    lh = (uint32_t)(hi - lo);
-                } else if (role == 1) {
-                    if (sin && OFFS && rec >= 0 && rec < a.rec_cap) a.o_seq[rec] = ls;
-                    s_src[1][tid] = (uint16_t)start;
-                    lsq = (uint32_t)(end - start);
-                } else if (role == 2) {
-                    if (sin) {
-                        if (s_tile[start] != 43) err.structure(rec, 2);   // '+', utils.mojo:456
-                        if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_sep[rec] = ls;
-                    }
-                } else {
-                    if (sin && OFFS && rec >= 0 && rec < a.rec_cap) a.o_qual[rec] = ls;
-                    s_src[2][tid] = (uint16_t)start;
-                    lq = (uint32_t)(end - start);
+        // ---- line pass: one line per thread (j = tid, tid+256, ...), so a 150 bp tile (~207 lines)
+        // keeps all four waves busy; line j has role (ph+j)&3 and is segment k = j>>2 of that role
+        s_len[0][tid] = 0; s_len[1][tid] = 0; s_len[2][tid] = 0;
+        __syncthreads();
+        for (int j = tid; j <= (int)c; j += BLOCK) {
+            const int role = (ph + j) & 3;
+            const int k = j >> 2;
+            const int start = j ? (int)s_nl[j - 1] + 1 : 0;
+            const bool end_in = j < (int)c;
+            const int end = end_in ? (int)s_nl[j] : valid;
+            const int64_t rec = (P + j) >> 2;
+            const bool sknown = j > 0 ? true : first_starts;
+            const bool sin = sknown && start < valid;
+            const int64_t ls = t0 + start;
+            if (role == 0) {
+                if (sin) {
+                    if (s_tile[start] != 64) err.structure(rec, 1);   // '@', utils.mojo:454
+                    if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_hdr[rec] = ls;
                 }
+                int64_t lo = ls, hi = ls;
+                if (end > start) header_kept(bs, ls, t0 + end, sknown, end_in, t0 + valid, lo, hi);
+                s_src[0][k] = (uint16_t)(lo - t0);
+                s_len[0][k] = (uint16_t)(hi - lo);
+            } else if (role == 2) {
+                if (sin) {
+                    if (s_tile[start] != 43) err.structure(rec, 2);   // '+', utils.mojo:456
+                    if (OFFS && rec >= 0 && rec < a.rec_cap) a.o_sep[rec] = ls;
+                }
+            } else {
+                const int slot = role == 1 ? 1 : 2;
+                if (sin && OFFS && rec >= 0 && rec < a.rec_cap) (role == 1 ? a.o_seq : a.o_qual)[rec] = ls;
+                s_src[slot][k] = (uint16_t)start;
+                s_len[slot][k] = (uint16_t)(end - start);
             }
         }
-        s_len[0][tid] = (uint16_t)lh; s_len[1][tid] = (uint16_t)lsq; s_len[2][tid] = (uint16_t)lq;
+        __syncthreads();
+        const uint32_t lh = s_len[0][tid], lsq = s_len[1][tid], lq = s_len[2][tid];
         const u64 packed = (u64)lh | ((u64)lsq << 21) | ((u64)lq << 42);
         u64 tot = 0;
         const u64 ex = block_exclusive_scan<u64, 4>(packed, s_w64, tot);
@@ -547,33 +605,56 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                     }
                 }
             }
-            // heads and tails: thread k owns segment k of every role
+            // line heads and tails.  Work item (role, k) = the junction between segments k and k+1 of one role:
+            // the <= 15-byte tail of k and the <= 15-byte head of k+1 are adjacent in the column.  When k+1 holds
+            // at least 16 bytes the junction is written with one or two full 16-byte unaligned stores (tail bytes
+            // merged with the following bytes of k+1; bytes that overlap the whole-piece stores above carry the
+            // same values); otherwise it falls back to byte-exact partial stores.
             if (!(a.ablate & 2)) {
-                const int jr[3] = {jh, (1 - ph) & 3, jq};
-#pragma unroll
-                for (int slot = 0; slot < 3; ++slot) {
-                    const int len = (int)s_len[slot][tid];
+                const int nseg = ((int)c + 4) >> 2; // segment indices in use
+                const int js = (1 - ph) & 3;
+                for (int pidx = tid; pidx < 3 * (nseg + 1); pidx += BLOCK) {
+                    const int slot = pidx / (nseg + 1);
+                    const int k = pidx - slot * (nseg + 1) - 1;            // left segment (-1: none)
                     const int64_t base = slot == 0 ? I : (slot == 1 ? S : Q);
-                    int64_t d0 = base + (int64_t)s_dst[slot][tid];
-                    if (a.ablate & 8) d0 &= 0xFFFFF;
-                    if (len > 0 && d0 >= 0) {
-                        uint8_t* col = slot == 0 ? a.col_id : (slot == 1 ? a.col_seq : a.col_qual);
-                        const int src = (int)s_src[slot][tid];
-                        const int64_t rec = (P + 4 * tid + jr[slot]) >> 2;
-                        const int au = (src + 15) & ~15;
-                        const int a1 = au < src + len ? au : src + len;          // head: [src, a1)
-                        const int ad = (src + len) & ~15;
-                        const int b0 = ad > a1 ? ad : a1;                         // tail: [b0, src+len)
-                        if (slot == 0) {
-                            emit_part<0, CA, CQ>(col, d0, src, a1 - src, s_tile, rec, a.q_lower, a.q_upper, err);
-                            emit_part<0, CA, CQ>(col, d0 + (b0 - src), b0, src + len - b0, s_tile, rec, a.q_lower, a.q_upper, err);
-                        } else if (slot == 1) {
-                            emit_part<1, CA, CQ>(col, d0, src, a1 - src, s_tile, rec, a.q_lower, a.q_upper, err);
-                            emit_part<1, CA, CQ>(col, d0 + (b0 - src), b0, src + len - b0, s_tile, rec, a.q_lower, a.q_upper, err);
-                        } else {
-                            emit_part<3, CA, CQ>(col, d0, src, a1 - src, s_tile, rec, a.q_lower, a.q_upper, err);
-                            emit_part<3, CA, CQ>(col, d0 + (b0 - src), b0, src + len - b0, s_tile, rec, a.q_lower, a.q_upper, err);
+                    uint8_t* col = slot == 0 ? a.col_id : (slot == 1 ? a.col_seq : a.col_qual);
+                    const int jr = slot == 0 ? jh : (slot == 1 ? js : jq);
+                    const bool is_qual = slot == 2;
+                    int tlen = 0, toff = 0, hlen = 0, hoff = 0, lenR = 0;
+                    int64_t tdst = 0, hdst = 0;
+                    if (k >= 0) {
+                        const int len = (int)s_len[slot][k], src = (int)s_src[slot][k];
+                        if (len > 0) {
+                            const int au = (src + 15) & ~15;
+                            const int a1 = au < src + len ? au : src + len;
+                            const int ad = (src + len) & ~15;
+                            toff = ad > a1 ? ad : a1;
+                            tlen = src + len - toff;
+                            tdst = base + (int64_t)s_dst[slot][k] + (toff - src);
                         }
+                    }
+                    if (k + 1 < nseg) {
+                        lenR = (int)s_len[slot][k + 1];
+                        if (lenR > 0) {
+                            hoff = (int)s_src[slot][k + 1];
+                            const int au = (hoff + 15) & ~15;
+                            hlen = (au < hoff + lenR ? au : hoff + lenR) - hoff;
+                            hdst = base + (int64_t)s_dst[slot][k + 1];
+                        }
+                    }
+                    if (tlen + hlen == 0) continue;
+                    const int64_t recL = (P + 4 * k + jr) >> 2, recR = (P + 4 * (k + 1) + jr) >> 2;
+                    const int64_t d0 = tlen > 0 ? tdst : hdst;
+                    if (lenR >= 16 && d0 >= 0 && !(a.ablate & 32)) {
+                        const int len = tlen + hlen;
+                        // tail bytes [0,tlen) then the bytes of k+1 from its start
+                        merge_store16<CA, CQ>(col, (a.ablate & 8) ? (d0 & 0xFFFFF) : d0, toff, tlen, hoff, s_tile, recL, recR, is_qual, a.q_lower, a.q_upper, err);
+                        if (len > 16)   // the last 16 bytes of the junction
+                            merge_store16<CA, CQ>(col, (a.ablate & 8) ? ((d0 + len - 16) & 0xFFFFF) : d0 + len - 16, toff + len - 16, 16 - hlen, hoff, s_tile,
+                                                  recL, recR, is_qual, a.q_lower, a.q_upper, err);
+                    } else {
+                        if (tlen > 0 && tdst >= 0) emit_part_rt<CA, CQ>(col, tdst, toff, tlen, s_tile, recL, is_qual, a.q_lower, a.q_upper, err);
+                        if (hlen > 0 && hdst >= 0) emit_part_rt<CA, CQ>(col, hdst, hoff, hlen, s_tile, recR, is_qual, a.q_lower, a.q_upper, err);
                     }
                 }
             }
