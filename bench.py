@@ -27,7 +27,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 # rocprofv3 PMC, emit kernel, 10 M x 150 bp: FETCH_SIZE 1589372 KB (x2 on gfx950) + WRITE_SIZE 3782130 KB per launch
-MEASURED_TRAFFIC_B_PER_RECORD = (1589372.4 * 2 + 3782130.3) * 1024 / 1e7
+MEASURED_TRAFFIC_B_PER_RECORD = (1589267.2 * 2 + 3434547.2) * 1024 / 1e7
 
 
 def cpu_baseline(reads: int, read_len: int, check: bool):
@@ -208,7 +208,7 @@ def main():
                             if (args.read_len == 150 and not args.validate and not args.single_pass and not args.service
                                 and not args.hier and not args.kernels_v1) else None),
                 "traffic_unit": "GB per launch",
-                "traffic_source": "profiles/r1_final_default_summary.txt: k_fused FETCH_SIZE*2 + WRITE_SIZE",
+                "traffic_source": "profiles/r1_junction_summary.txt: k_fused FETCH_SIZE*2 + WRITE_SIZE",
                 "algorithmic_gb_per_launch": round(A * per_rank_records / 1e9, 3),
                 "algorithmic_bytes_per_record": A,
                 "avg_launch_ms": round(ms_emit / steps / max(1, int(res.n_passes)), 4),
