@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblazeseq_hip.so")
+LIB_PATH = os.environ.get("BLAZESEQ_HIP_LIB") or os.path.join(_HERE, "libblazeseq_hip.so")  # override: A/B of two builds
 
 OK, ID_NO_AT, SEP_NO_PLUS, SEQ_QUAL_LEN_MISMATCH, ASCII_INVALID, QUALITY_OUT_OF_RANGE, EOF, \
     UNEXPECTED_EOF, BUFFER_EXCEEDED, BUFFER_AT_MAX, OTHER = range(11)

@@ -653,6 +653,11 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     ChunkState* h = c->h_state; // filled by the async D2H enqueued behind k_rebase
+    if (c->ablate & 64) {   // debug: emit-kernel phase cycles (thread 0 of every workgroup)
+        fprintf(stderr, "bzq phase_cycles:");
+        for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", h->phase_cycles[i]);
+        fprintf(stderr, "\n");
+    }
     if (h->lookback_timeout && c->cur_n > 0) {
         // never expected: the single-pass kernel gave up on a predecessor tile.  Same chunk again on
         // the two-pass kernels (no inter-workgroup waiting).

@@ -61,6 +61,8 @@ struct ChunkState {
     int64_t n_complete;       // records with all four newlines
     int64_t last_record_end;  // record_end[n_complete-1], or first_header-1
     int64_t last_ends, last_id_ends;
+    // debug only (option ablate bit 64): shader-clock cycles workgroup thread 0 spent in each phase of the emit kernel
+    unsigned long long phase_cycles[12];
 };
 
 __device__ __forceinline__ bool is_posix_space(uint32_t c) {
@@ -68,14 +70,20 @@ __device__ __forceinline__ bool is_posix_space(uint32_t c) {
     return c <= 32u && ((0x170003E00ull >> c) & 1ull);
 }
 
-// 4-bit mask of bytes equal to '\n' in a little-endian dword (exact, no borrow artefacts).
-__device__ __forceinline__ uint32_t nl_mask4(uint32_t x) {
-    uint32_t y = x ^ 0x0A0A0A0Au;
-    uint32_t z = ~(((y & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | y | 0x7F7F7F7Fu); // 0x80 where byte == 0
-    return (((z >> 7) * 0x01020408u) >> 24) & 0xFu;
+// 16-bit newline mask of 16 bytes.  v_perm_b32 with the DATA as the selector: selector byte 12 yields 0x00 and,
+// with both sources all-ones, every other selector value yields 0xFF (0-7 pick source bytes, 8-11 their sign
+// bits, >= 13 the constant 0xFF) -- so (x ^ 0x06) used as the selector is 0x00 exactly where x == '\n' and -1
+// elsewhere.  A signed dot4 with weights 1,2,4,8 | 16,32,64,-128 and a start value of 127 then accumulates the
+// flags of two dwords straight into mask bits (bit 7 comes out inverted and is flipped at the end).
+__device__ __forceinline__ uint32_t nl_flags(uint32_t x) {
+    return __builtin_amdgcn_perm(0xFFFFFFFFu, 0xFFFFFFFFu, x ^ 0x06060606u);
 }
 __device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
-    return nl_mask4(v.x) | (nl_mask4(v.y) << 4) | (nl_mask4(v.z) << 8) | (nl_mask4(v.w) << 12);
+    int lo = __builtin_amdgcn_sdot4((int)nl_flags(v.x), 0x08040201, 127, false);
+    lo = __builtin_amdgcn_sdot4((int)nl_flags(v.y), (int)0x80402010, lo, false);
+    int hi = __builtin_amdgcn_sdot4((int)nl_flags(v.z), 0x08040201, 127, false);
+    hi = __builtin_amdgcn_sdot4((int)nl_flags(v.w), (int)0x80402010, hi, false);
+    return (((uint32_t)hi << 8) | (uint32_t)lo) ^ 0x8080u;
 }
 
 // Guarded 16-byte load of chunk bytes [pos, pos+16): bytes at or beyond n read as 0.

@@ -266,16 +266,18 @@ __device__ __forceinline__ void emit_part(uint8_t* __restrict__ col, int64_t gad
     store_bytes(col + gaddr, w0, w1, w2, w3, n);
 }
 
+// 16 bytes of the LDS tile at any byte offset (gfx950 reads unaligned LDS addresses in one ds_read_b128)
+__device__ __forceinline__ U16B lds_window16(const uint8_t* s_tile, int off) {
+    return *reinterpret_cast<const U16B*>(s_tile + off);
+}
+
 // emit_part with the role decided at run time (all threads of the block share the head/tail work)
 template <bool CA, bool CQ>
 __device__ __forceinline__ void emit_part_rt(uint8_t* __restrict__ col, int64_t gaddr, int s0, int n, const uint8_t* s_tile,
                                              int64_t rec, bool is_qual, uint32_t qlo, uint32_t qhi, ErrAcc& err) {
     if (n <= 0) return;
-    const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tile - 16);
-    const int ws = s0 + 16, wd = ws >> 2, sh = ws & 3;
-    const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
-    const uint32_t w0 = __builtin_amdgcn_alignbyte(d1, d0, sh), w1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
-                   w2 = __builtin_amdgcn_alignbyte(d3, d2, sh), w3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    const U16B w = lds_window16(s_tile, s0);
+    const uint32_t w0 = w.x, w1 = w.y, w2 = w.z, w3 = w.w;
     if (CA || CQ) {
         const uint32_t m0 = byte_range_mask(0, 0, n), m1 = byte_range_mask(1, 0, n), m2 = byte_range_mask(2, 0, n),
                        m3 = byte_range_mask(3, 0, n);
@@ -290,42 +292,16 @@ __device__ __forceinline__ void emit_part_rt(uint8_t* __restrict__ col, int64_t 
     store_bytes(col + gaddr, w0, w1, w2, w3, n);
 }
 
-// 16 bytes = first nA bytes of the LDS window at tile offset offA, then the bytes of line B that follow
-// (window at offB - nA, so they already sit at their final byte positions), stored unaligned at col+gaddr.
+// 16 whole bytes of one line: LDS tile offset off -> col[gaddr, gaddr+16), both unaligned
 template <bool CA, bool CQ>
-__device__ __forceinline__ void merge_store16(uint8_t* __restrict__ col, int64_t gaddr, int offA, int nA, int offB,
-                                              const uint8_t* s_tile, int64_t recA, int64_t recB, bool is_qual,
-                                              uint32_t qlo, uint32_t qhi, ErrAcc& err) {
-    const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tile - 16);
-    uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
-    {
-        const int ws = offA + 16, wd = ws >> 2, sh = ws & 3;
-        const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
-        a0 = __builtin_amdgcn_alignbyte(d1, d0, sh); a1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        a2 = __builtin_amdgcn_alignbyte(d3, d2, sh); a3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-    }
-    {
-        const int ws = offB - nA + 16, wd = ws >> 2, sh = ws & 3;
-        const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
-        b0 = __builtin_amdgcn_alignbyte(d1, d0, sh); b1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-        b2 = __builtin_amdgcn_alignbyte(d3, d2, sh); b3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-    }
-    const uint32_t m0 = bytes_from_mask(0, nA), m1 = bytes_from_mask(1, nA), m2 = bytes_from_mask(2, nA), m3 = bytes_from_mask(3, nA);
-    if (CA || CQ) {
-        if (CA && any_non_ascii((a0 & ~m0) | (a1 & ~m1) | (a2 & ~m2) | (a3 & ~m3))) err.valid(recA, 4);
-        if (CA && any_non_ascii((b0 & m0) | (b1 & m1) | (b2 & m2) | (b3 & m3))) err.valid(recB, 4);
-        if (CQ && is_qual) {
-            const uint32_t fill = 0x01010101u * qlo;
-            if (any_out_of_range((a0 & ~m0) | (fill & m0), qlo, qhi) | any_out_of_range((a1 & ~m1) | (fill & m1), qlo, qhi) |
-                any_out_of_range((a2 & ~m2) | (fill & m2), qlo, qhi) | any_out_of_range((a3 & ~m3) | (fill & m3), qlo, qhi))
-                err.valid(recA, 5);
-            if (any_out_of_range((b0 & m0) | (fill & ~m0), qlo, qhi) | any_out_of_range((b1 & m1) | (fill & ~m1), qlo, qhi) |
-                any_out_of_range((b2 & m2) | (fill & ~m2), qlo, qhi) | any_out_of_range((b3 & m3) | (fill & ~m3), qlo, qhi))
-                err.valid(recB, 5);
-        }
-    }
-    U16B v{(b0 & m0) | (a0 & ~m0), (b1 & m1) | (a1 & ~m1), (b2 & m2) | (a2 & ~m2), (b3 & m3) | (a3 & ~m3)};
-    *reinterpret_cast<U16B*>(col + gaddr) = v;
+__device__ __forceinline__ void copy16(uint8_t* __restrict__ col, int64_t gaddr, int off, const uint8_t* s_tile, int64_t rec,
+                                       bool is_qual, uint32_t qlo, uint32_t qhi, ErrAcc& err) {
+    const U16B w = lds_window16(s_tile, off);
+    if (CA && any_non_ascii(w.x | w.y | w.z | w.w)) err.valid(rec, 4);
+    if (CQ && is_qual &&
+        (any_out_of_range(w.x, qlo, qhi) | any_out_of_range(w.y, qlo, qhi) | any_out_of_range(w.z, qlo, qhi) | any_out_of_range(w.w, qlo, qhi)))
+        err.valid(rec, 5);
+    *reinterpret_cast<U16B*>(col + gaddr) = w;
 }
 
 template <bool CA, bool CQ, bool OFFS, bool LB>
@@ -349,6 +325,15 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     int64_t t = LB ? s_bcast[0] : a.tile_begin + (int64_t)blockIdx.x;
     if (!LB && t >= a.tile_end) return;
   for (;;) {
+    u64 tprev = 0;
+    auto phase_mark = [&](int i) {
+        if ((a.ablate & 64) && tid == 0 && (t & 63) == 0) {   // 1 workgroup in 64 (all-workgroup atomics would dominate)
+            const u64 now = __builtin_readcyclecounter();
+            if (i >= 0) atomicAdd(&a.st->phase_cycles[i], now - tprev);
+            tprev = now;
+        }
+    };
+    phase_mark(-1);
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     // every global LOAD of this tile is issued here, before any store: vmcnt retires in order, so a
@@ -361,6 +346,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
     const bool first_starts = (bs.at(t0 - 1) == 10u);
     __syncthreads();
+    phase_mark(0);   // tile loaded, masks built, staged
     const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);
     const u64 m64 = s_mask64[tid];
     uint32_t c = 0;
@@ -392,6 +378,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         }
     }
     __syncthreads();
+    phase_mark(1);   // newline count scan + position table
     const int64_t P = LB ? s_bcast[1] : tP;
     ErrAcc err{~0ull, ~0ull};
     bool overflow = false;
@@ -517,6 +504,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             }
         }
         __syncthreads();
+        phase_mark(2);   // line pass
         const uint32_t lh = s_len[0][tid], lsq = s_len[1][tid], lq = s_len[2][tid];
         const u64 packed = (u64)lh | ((u64)lsq << 21) | ((u64)lq << 42);
         u64 tot = 0;
@@ -544,6 +532,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     }
     __syncthreads();
     const int64_t S = LB ? s_bcast[1] : tS, Q = LB ? s_bcast[2] : tQ, I = LB ? s_bcast[3] : tI;
+    phase_mark(3);   // segment scan
 
     if (dense) {
         if (tid == 0) {
@@ -576,6 +565,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                 if (se != qe) err.structure(rec, 3); // utils.mojo:458-461 as a cumulative test
             }
         }
+        phase_mark(4);   // record outputs
         // ---- scatter: whole source pieces from registers, line heads/tails through the LDS window ----
         if (!(a.ablate & 1)) {
 #pragma unroll
@@ -605,61 +595,37 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                     }
                 }
             }
-            // line heads and tails.  Work item (role, k) = the junction between segments k and k+1 of one role:
-            // the <= 15-byte tail of k and the <= 15-byte head of k+1 are adjacent in the column.  When k+1 holds
-            // at least 16 bytes the junction is written with one or two full 16-byte unaligned stores (tail bytes
-            // merged with the following bytes of k+1; bytes that overlap the whole-piece stores above carry the
-            // same values); otherwise it falls back to byte-exact partial stores.
+            phase_mark(5);   // whole-piece stores
+            // line heads and tails: a line of >= 16 bytes gets its FIRST 16 and its LAST 16 bytes copied whole
+            // (one unaligned LDS read + one unaligned 16-byte store each); with the whole pieces above that
+            // covers every byte, and bytes written twice carry the same value.  Shorter lines go byte-exact.
             if (!(a.ablate & 2)) {
                 const int nseg = ((int)c + 4) >> 2; // segment indices in use
                 const int js = (1 - ph) & 3;
-                for (int pidx = tid; pidx < 3 * (nseg + 1); pidx += BLOCK) {
-                    const int slot = pidx / (nseg + 1);
-                    const int k = pidx - slot * (nseg + 1) - 1;            // left segment (-1: none)
-                    const int64_t base = slot == 0 ? I : (slot == 1 ? S : Q);
+                for (int pidx = tid; pidx < 6 * nseg; pidx += BLOCK) {
+                    const int side = pidx & 1, sk = pidx >> 1;
+                    const int k = sk / 3, slot = sk - 3 * k;
+                    const int len = (int)s_len[slot][k];
+                    if (len == 0) continue;
+                    const int src = (int)s_src[slot][k];
+                    const int64_t d0 = (slot == 0 ? I : (slot == 1 ? S : Q)) + (int64_t)s_dst[slot][k];
+                    if (d0 < 0) continue;   // a head line owned by the previous shard
                     uint8_t* col = slot == 0 ? a.col_id : (slot == 1 ? a.col_seq : a.col_qual);
-                    const int jr = slot == 0 ? jh : (slot == 1 ? js : jq);
-                    const bool is_qual = slot == 2;
-                    int tlen = 0, toff = 0, hlen = 0, hoff = 0, lenR = 0;
-                    int64_t tdst = 0, hdst = 0;
-                    if (k >= 0) {
-                        const int len = (int)s_len[slot][k], src = (int)s_src[slot][k];
-                        if (len > 0) {
-                            const int au = (src + 15) & ~15;
-                            const int a1 = au < src + len ? au : src + len;
-                            const int ad = (src + len) & ~15;
-                            toff = ad > a1 ? ad : a1;
-                            tlen = src + len - toff;
-                            tdst = base + (int64_t)s_dst[slot][k] + (toff - src);
-                        }
-                    }
-                    if (k + 1 < nseg) {
-                        lenR = (int)s_len[slot][k + 1];
-                        if (lenR > 0) {
-                            hoff = (int)s_src[slot][k + 1];
-                            const int au = (hoff + 15) & ~15;
-                            hlen = (au < hoff + lenR ? au : hoff + lenR) - hoff;
-                            hdst = base + (int64_t)s_dst[slot][k + 1];
-                        }
-                    }
-                    if (tlen + hlen == 0) continue;
-                    const int64_t recL = (P + 4 * k + jr) >> 2, recR = (P + 4 * (k + 1) + jr) >> 2;
-                    const int64_t d0 = tlen > 0 ? tdst : hdst;
-                    if (lenR >= 16 && d0 >= 0 && !(a.ablate & 32)) {
-                        const int len = tlen + hlen;
-                        // tail bytes [0,tlen) then the bytes of k+1 from its start
-                        merge_store16<CA, CQ>(col, (a.ablate & 8) ? (d0 & 0xFFFFF) : d0, toff, tlen, hoff, s_tile, recL, recR, is_qual, a.q_lower, a.q_upper, err);
-                        if (len > 16)   // the last 16 bytes of the junction
-                            merge_store16<CA, CQ>(col, (a.ablate & 8) ? ((d0 + len - 16) & 0xFFFFF) : d0 + len - 16, toff + len - 16, 16 - hlen, hoff, s_tile,
-                                                  recL, recR, is_qual, a.q_lower, a.q_upper, err);
-                    } else {
-                        if (tlen > 0 && tdst >= 0) emit_part_rt<CA, CQ>(col, tdst, toff, tlen, s_tile, recL, is_qual, a.q_lower, a.q_upper, err);
-                        if (hlen > 0 && hdst >= 0) emit_part_rt<CA, CQ>(col, hdst, hoff, hlen, s_tile, recR, is_qual, a.q_lower, a.q_upper, err);
+                    const int64_t rec = (P + 4 * k + (slot == 0 ? jh : (slot == 1 ? js : jq))) >> 2;
+                    if (len >= 16) {
+                        const int off = side ? src + len - 16 : src;
+                        if (((side ? src + len : src) & 15) == 0) continue;   // that end is a whole piece already
+                        int64_t g = d0 + (off - src);
+                        if (a.ablate & 8) g &= 0xFFFFF;
+                        copy16<CA, CQ>(col, g, off, s_tile, rec, slot == 2, a.q_lower, a.q_upper, err);
+                    } else if (side == 0) {
+                        emit_part_rt<CA, CQ>(col, d0, src, len, s_tile, rec, slot == 2, a.q_lower, a.q_upper, err);
                     }
                 }
             }
         }
     }
+    phase_mark(6);   // junctions
     if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
     if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
     if (overflow) atomicOr(&a.st->rec_overflow, 1);

@@ -90,6 +90,22 @@ def test_fuzz_multi_tile(seed):
         ctx.close()
 
 
+@pytest.mark.parametrize("single_pass", [False, True])
+def test_every_byte_value_is_classified_exactly(single_pass):
+    """All 255 non-newline byte values at every alignment in id, sequence and quality lines: the newline
+    detector (v_perm with the data as selector) and the strip logic must not mistake any of them."""
+    allb = bytes(b for b in range(256) if b != 10)
+    recs = []
+    for i in range(300):
+        rot = allb[i % 255:] + allb[:i % 255]
+        body = rot[: 40 + (i * 7) % 215]
+        recs.append(b"@" + rot[: (i * 3) % 60] + b"\n" + body + b"\n+\n" + body[::-1] + b"\n")
+    data = b"".join(recs)
+    ctx, ocfg = make_pair(single_pass=single_pass, check_ascii=False, check_quality=False)
+    res, f = check_against_oracle(ctx, ocfg, data, what="all byte values")
+    assert f.n_records == 300
+
+
 def test_space_runs_across_tile_edges():
     """Header lines made of spaces that straddle tile boundaries: every id byte dropped exactly once."""
     rng = np.random.default_rng(7)
