@@ -221,6 +221,12 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* s_w, T& total) {
 // 64 contiguous bytes [64*tid, 64*tid+64)) and, optionally, the bytes themselves into LDS.
 __device__ __forceinline__ void tile_fetch(const uint8_t* __restrict__ g, int64_t n, int64_t t0, int valid, uint4 (&r)[4]) {
     const int tid = threadIdx.x;
+    if (valid == TILE) {   // every tile but the last: no guards
+        const uint4* __restrict__ p = reinterpret_cast<const uint4*>(g + t0) + tid;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) r[s] = p[BLOCK * s];
+        return;
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int pos = (tid + BLOCK * s) * 16;
@@ -236,8 +242,10 @@ __device__ __forceinline__ void tile_stage(const uint4 (&r)[4], int valid, uint1
         const int q = tid + BLOCK * s;
         const int pos = q * 16;
         uint32_t m = nl_mask16(r[s]);
-        const int rem = valid - pos;
-        if (rem < 16) m &= rem > 0 ? ((1u << rem) - 1u) : 0u;
+        if (valid != TILE) {   // last tile: bytes at or beyond the end are not newlines
+            const int rem = valid - pos;
+            if (rem < 16) m &= rem > 0 ? ((1u << rem) - 1u) : 0u;
+        }
         s_mask[q] = (uint16_t)m;
         if (STAGE) *reinterpret_cast<uint4*>(s_tile + pos) = r[s];
     }

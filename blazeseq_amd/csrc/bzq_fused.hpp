@@ -31,6 +31,13 @@ __device__ __forceinline__ void st_agent(u64* p, u64 v) {
 }
 __device__ __forceinline__ int64_t wave_sum(int64_t v) { return (int64_t)wave_sum_u64((u64)v); }
 
+// Timing experiments (skip / stop-after-phase switches and the phase clock) cost SGPRs and prologue instructions in
+// every workgroup, so they exist only in an EXPERIMENTS build; the shipped kernels ignore the "ablate" option.
+#ifndef BZQ_EXPERIMENTS
+#define BZQ_EXPERIMENTS 0
+#endif
+#define BZQ_ABLATE(bit) (BZQ_EXPERIMENTS && (a.ablate & (bit)))
+
 struct FusedArgs {
     const uint8_t* g;
     int64_t n;
@@ -60,7 +67,7 @@ struct FusedArgs {
     ChunkState* st;
     uint32_t q_lower, q_upper;
     int32_t force_dense;
-    int32_t ablate;   // timing experiments only: bit0 skip gathers, bit1 skip record outputs, bit2 skip line pass+scan
+    int32_t ablate;   // timing experiments, compiled in only with -DBZQ_EXPERIMENTS=1 (make EXPERIMENTS=1): see BZQ_ABLATE uses
 };
 
 // Exclusive line prefix of tile t (wave 0, all 64 lanes).  Lane i inspects predecessor t-1-i.
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
   for (;;) {
     u64 tprev = 0;
     auto phase_mark = [&](int i) {
-        if ((a.ablate & 64) && tid == 0 && (t & 63) == 0) {   // 1 workgroup in 64 (all-workgroup atomics would dominate)
+        if (BZQ_ABLATE(64) && tid == 0 && (t & 63) == 0) {   // 1 workgroup in 64 (all-workgroup atomics would dominate)
             const u64 now = __builtin_readcyclecounter();
             if (i >= 0) atomicAdd(&a.st->phase_cycles[i], now - tprev);
             tprev = now;
@@ -347,6 +354,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     const bool first_starts = (bs.at(t0 - 1) == 10u);
     __syncthreads();
     phase_mark(0);   // tile loaded, masks built, staged
+    if (!LB && BZQ_ABLATE(128)) return;   // experiment: stop here
     const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);
     const u64 m64 = s_mask64[tid];
     uint32_t c = 0;
@@ -379,6 +387,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     }
     __syncthreads();
     phase_mark(1);   // newline count scan + position table
+    if (!LB && BZQ_ABLATE(256)) return;   // experiment: stop here
     const int64_t P = LB ? s_bcast[1] : tP;
     ErrAcc err{~0ull, ~0ull};
     bool overflow = false;
@@ -505,6 +514,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         }
         __syncthreads();
         phase_mark(2);   // line pass
+    if (!LB && BZQ_ABLATE(512)) return;   // experiment: stop here
         const uint32_t lh = s_len[0][tid], lsq = s_len[1][tid], lq = s_len[2][tid];
         const u64 packed = (u64)lh | ((u64)lsq << 21) | ((u64)lq << 42);
         u64 tot = 0;
@@ -533,6 +543,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     __syncthreads();
     const int64_t S = LB ? s_bcast[1] : tS, Q = LB ? s_bcast[2] : tQ, I = LB ? s_bcast[3] : tI;
     phase_mark(3);   // segment scan
+    if (!LB && BZQ_ABLATE(1024)) return;   // experiment: stop here
 
     if (dense) {
         if (tid == 0) {
@@ -567,9 +578,9 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         }
         phase_mark(4);   // record outputs
         // ---- scatter: whole source pieces from registers, line heads/tails through the LDS window ----
-        if (!(a.ablate & 1)) {
+        if (!BZQ_ABLATE(1)) {
 #pragma unroll
-            for (int sidx = 0; sidx < ((a.ablate & 4) ? 0 : 4); ++sidx) {
+            for (int sidx = 0; sidx < (BZQ_ABLATE(4) ? 0 : 4); ++sidx) {
                 const int q = tid + BLOCK * sidx;
                 const int pos = q * 16;
                 if (pos < valid) {
@@ -581,7 +592,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                     const int64_t base = role == 0 ? I : (role == 1 ? S : Q);
                     uint8_t* col = role == 0 ? a.col_id : (role == 1 ? a.col_seq : a.col_qual);
                     int64_t addr = base + dd + (pos - src);
-                    if (a.ablate & 8) addr &= 0xFFFFF;
+                    if BZQ_ABLATE(8) addr &= 0xFFFFF;
                     if (role != 2 && pos >= src && pos + 16 <= src + len && base + dd >= 0) {
                         const int64_t rec = (P + j) >> 2;
                         if (CA && any_non_ascii(r[sidx].x | r[sidx].y | r[sidx].z | r[sidx].w)) err.valid(rec, 4);
@@ -590,7 +601,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                              any_out_of_range(r[sidx].z, a.q_lower, a.q_upper) | any_out_of_range(r[sidx].w, a.q_lower, a.q_upper)))
                             err.valid(rec, 5);
                         U16B v{r[sidx].x, r[sidx].y, r[sidx].z, r[sidx].w};
-                        if (!(a.ablate & 16)) *reinterpret_cast<U16B*>(col + addr) = v;
+                        if (!BZQ_ABLATE(16)) *reinterpret_cast<U16B*>(col + addr) = v;
                         else if (addr == -12345) *reinterpret_cast<U16B*>(col + addr) = v;
                     }
                 }
@@ -599,7 +610,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             // line heads and tails: a line of >= 16 bytes gets its FIRST 16 and its LAST 16 bytes copied whole
             // (one unaligned LDS read + one unaligned 16-byte store each); with the whole pieces above that
             // covers every byte, and bytes written twice carry the same value.  Shorter lines go byte-exact.
-            if (!(a.ablate & 2)) {
+            if (!BZQ_ABLATE(2)) {
                 const int nseg = ((int)c + 4) >> 2; // segment indices in use
                 const int js = (1 - ph) & 3;
                 for (int pidx = tid; pidx < 6 * nseg; pidx += BLOCK) {
@@ -616,7 +627,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                         const int off = side ? src + len - 16 : src;
                         if (((side ? src + len : src) & 15) == 0) continue;   // that end is a whole piece already
                         int64_t g = d0 + (off - src);
-                        if (a.ablate & 8) g &= 0xFFFFF;
+                        if BZQ_ABLATE(8) g &= 0xFFFFF;
                         copy16<CA, CQ>(col, g, off, s_tile, rec, slot == 2, a.q_lower, a.q_upper, err);
                     } else if (side == 0) {
                         emit_part_rt<CA, CQ>(col, d0, src, len, s_tile, rec, slot == 2, a.q_lower, a.q_upper, err);
