@@ -314,10 +314,15 @@ __device__ __forceinline__ void copy16(uint8_t* __restrict__ col, int64_t gaddr,
 template <bool CA, bool CQ, bool OFFS, bool LB>
 __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
-    __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
+    __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];   // newline bitmap, 16 bits per 16-byte piece
     __shared__ uint16_t s_nl[MAXL + 4];
-    __shared__ uint16_t s_src[3][SEGS], s_len[3][SEGS], s_dst[3][SEGS];
-    __shared__ __attribute__((aligned(16))) uint16_t s_pline[PIECES];            // tile-local line index of each 16-byte piece's first byte
+    // segment k of role slot (0 id, 1 sequence, 2 quality): tile offset of its kept bytes | length << 16 |
+    // (offset in the tile's part of the column - tile offset) << 32; one ds_read_b64 per lookup
+    __shared__ u64 s_seg[3][SEGS];
+    __shared__ u64 s_colbase[4];   // by line role: column pointer + this tile's column offset (role 2: unused)
+    // tile-local line index at each 16-byte piece's first byte.  Lives in s_mask: a thread overwrites exactly the
+    // 8 bytes of the bitmap it has just read (the serial dense path keeps the bitmap instead).
+    uint16_t* s_pline = s_mask;
     __shared__ u64 s_w64[4];
     __shared__ uint32_t s_w[4];
     __shared__ int64_t s_bcast[4];   // tile, P / S, Q, I
@@ -360,7 +365,9 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     uint32_t c = 0;
     const uint32_t excl = block_exclusive_scan<uint32_t, 4>((uint32_t)__popcll(m64), s_w, c);
     const bool dense = ((int)c > MAXL) || a.force_dense;
-    {   // line index at the first byte of each of this thread's four analysis pieces (bytes 64*tid + 16*i)
+    reinterpret_cast<uint32_t*>(&s_seg[0][tid])[0] = 0u; reinterpret_cast<uint32_t*>(&s_seg[1][tid])[0] = 0u;
+    reinterpret_cast<uint32_t*>(&s_seg[2][tid])[0] = 0u;   // length 0 until the line pass fills it
+    if (!dense) {   // line index at the first byte of each of this thread's four analysis pieces (bytes 64*tid + 16*i)
         const uint32_t l0 = excl, l1 = l0 + (uint32_t)__popc((uint32_t)m64 & 0xFFFFu),
                        l2 = l0 + (uint32_t)__popc((uint32_t)m64), l3 = l0 + (uint32_t)__popcll(m64 & 0xFFFFFFFFFFFFull);
         *reinterpret_cast<u64*>(&s_pline[4 * tid]) = (u64)l0 | ((u64)l1 << 16) | ((u64)l2 << 32) | ((u64)l3 << 48);
@@ -466,6 +473,8 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     };
 
     int n_id = 0, n_seq = 0, n_qual = 0;
+    uint32_t lh = 0, lsq = 0, lq = 0;   // this thread's segment (k = tid) of each role: kept length ...
+    int dh = 0, ds = 0, dq = 0;         // ... and offset within the tile's part of the column
     if (dense) {
         if (LB) {
             if (tid == 0) {
@@ -479,8 +488,6 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     } else {
         // ---- line pass: one line per thread (j = tid, tid+256, ...), so a 150 bp tile (~207 lines)
         // keeps all four waves busy; line j has role (ph+j)&3 and is segment k = j>>2 of that role
-        s_len[0][tid] = 0; s_len[1][tid] = 0; s_len[2][tid] = 0;
-        __syncthreads();
         for (int j = tid; j <= (int)c; j += BLOCK) {
             const int role = (ph + j) & 3;
             const int k = j >> 2;
@@ -498,8 +505,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                 }
                 int64_t lo = ls, hi = ls;
                 if (end > start) header_kept(bs, ls, t0 + end, sknown, end_in, t0 + valid, lo, hi);
-                s_src[0][k] = (uint16_t)(lo - t0);
-                s_len[0][k] = (uint16_t)(hi - lo);
+                reinterpret_cast<uint32_t*>(&s_seg[0][k])[0] = (uint32_t)(lo - t0) | ((uint32_t)(hi - lo) << 16);
             } else if (role == 2) {
                 if (sin) {
                     if (s_tile[start] != 43) err.structure(rec, 2);   // '+', utils.mojo:456
@@ -508,19 +514,24 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             } else {
                 const int slot = role == 1 ? 1 : 2;
                 if (sin && OFFS && rec >= 0 && rec < a.rec_cap) (role == 1 ? a.o_seq : a.o_qual)[rec] = ls;
-                s_src[slot][k] = (uint16_t)start;
-                s_len[slot][k] = (uint16_t)(end - start);
+                reinterpret_cast<uint32_t*>(&s_seg[slot][k])[0] = (uint32_t)start | ((uint32_t)(end - start) << 16);
             }
         }
         __syncthreads();
         phase_mark(2);   // line pass
     if (!LB && BZQ_ABLATE(512)) return;   // experiment: stop here
-        const uint32_t lh = s_len[0][tid], lsq = s_len[1][tid], lq = s_len[2][tid];
+        const uint32_t g0 = reinterpret_cast<const uint32_t*>(&s_seg[0][tid])[0], g1 = reinterpret_cast<const uint32_t*>(&s_seg[1][tid])[0],
+                       g2 = reinterpret_cast<const uint32_t*>(&s_seg[2][tid])[0];
+        lh = g0 >> 16; lsq = g1 >> 16; lq = g2 >> 16;
         const u64 packed = (u64)lh | ((u64)lsq << 21) | ((u64)lq << 42);
         u64 tot = 0;
         const u64 ex = block_exclusive_scan<u64, 4>(packed, s_w64, tot);
-        const int dh = (int)(ex & 0x1FFFFFull), ds = (int)((ex >> 21) & 0x1FFFFFull), dq = (int)((ex >> 42) & 0x1FFFFFull);
-        s_dst[0][tid] = (uint16_t)dh; s_dst[1][tid] = (uint16_t)ds; s_dst[2][tid] = (uint16_t)dq;
+        dh = (int)(ex & 0x1FFFFFull); ds = (int)((ex >> 21) & 0x1FFFFFull); dq = (int)((ex >> 42) & 0x1FFFFFull);
+        reinterpret_cast<int32_t*>(&s_seg[0][tid])[1] = dh - (int)(g0 & 0xFFFFu);
+        reinterpret_cast<int32_t*>(&s_seg[1][tid])[1] = ds - (int)(g1 & 0xFFFFu);
+        reinterpret_cast<int32_t*>(&s_seg[2][tid])[1] = dq - (int)(g2 & 0xFFFFu);
+        if (!LB && tid < 4)
+            s_colbase[tid] = (u64)(tid == 0 ? a.col_id + tI : (tid == 1 ? a.col_seq + tS : a.col_qual + tQ));
         n_id = (int)(tot & 0x1FFFFFull); n_seq = (int)((tot >> 21) & 0x1FFFFFull); n_qual = (int)((tot >> 42) & 0x1FFFFFull);
     }
 
@@ -554,11 +565,15 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     } else {
         // ---- per-record outputs of lines that END in this tile --------------------------------------
         const int jh = (0 - ph) & 3, jq = (3 - ph) & 3;
+        if (LB) {   // column offsets only known now
+            if (tid < 4) s_colbase[tid] = (u64)(tid == 0 ? a.col_id + I : (tid == 1 ? a.col_seq + S : a.col_qual + Q));
+            __syncthreads();
+        }
         {
             const int j = 4 * tid + jh;           // this thread's header line
             const int64_t rec = (P + j) >> 2;
             if (j < (int)c && rec >= 0) {
-                if (rec < a.rec_cap) a.id_ends[rec] = I + (int64_t)s_dst[0][tid] + (int64_t)s_len[0][tid];
+                if (rec < a.rec_cap) a.id_ends[rec] = I + (int64_t)(dh + (int)lh);
                 else overflow = true;
             }
         }
@@ -566,43 +581,50 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             const int j = 4 * tid + jq;           // this thread's quality line
             const int64_t rec = (P + j) >> 2;
             if (j < (int)c && rec >= 0) {
-                const int64_t qe = Q + (int64_t)s_dst[2][tid] + (int64_t)s_len[2][tid];
-                // sequence bytes up to and including this record's sequence line (line j-2)
-                int64_t se = S;
-                if (jq >= 2) se = S + (int64_t)s_dst[1][tid] + (int64_t)s_len[1][tid];
-                else if (tid > 0) se = S + (int64_t)s_dst[1][tid - 1] + (int64_t)s_len[1][tid - 1];
+                const int64_t qe = Q + (int64_t)(dq + (int)lq);
+                // sequence bytes up to and including this record's sequence line (line j-2): with this thread's
+                // sequence segment when that line is in the same group of four, else everything before it
+                const int64_t se = S + (int64_t)(jq >= 2 ? ds + (int)lsq : ds);
                 if (rec < a.rec_cap) { a.ends[rec] = qe; a.rec_end[rec] = t0 + (int64_t)s_nl[j]; }
                 else overflow = true;
                 if (se != qe) err.structure(rec, 3); // utils.mojo:458-461 as a cumulative test
             }
         }
         phase_mark(4);   // record outputs
-        // ---- scatter: whole source pieces from registers, line heads/tails through the LDS window ----
+        // ---- scatter --------------------------------------------------------------------------------------
+        // lines with a negative index belong to the previous shard (their column offsets are below 0): not written
+        const int jmin = P < 0 ? (int)(-P) : 0;
         if (!BZQ_ABLATE(1)) {
+            // whole 16-byte source pieces that lie inside one kept line, straight from the registers they
+            // were loaded into (consecutive lanes -> consecutive destination bytes within a line)
+            if (!BZQ_ABLATE(4)) {
+                uint32_t jj[4];
+                u64 sg[4], cb[4];
 #pragma unroll
-            for (int sidx = 0; sidx < (BZQ_ABLATE(4) ? 0 : 4); ++sidx) {
-                const int q = tid + BLOCK * sidx;
-                const int pos = q * 16;
-                if (pos < valid) {
-                    const int j = (int)s_pline[q];
-                    const int role = (ph + j) & 3;
-                    const int k = j >> 2;
-                    const int slot = role == 0 ? 0 : (role == 1 ? 1 : 2);
-                    const int src = (int)s_src[slot][k], len = (int)s_len[slot][k], dd = (int)s_dst[slot][k];
-                    const int64_t base = role == 0 ? I : (role == 1 ? S : Q);
-                    uint8_t* col = role == 0 ? a.col_id : (role == 1 ? a.col_seq : a.col_qual);
-                    int64_t addr = base + dd + (pos - src);
-                    if BZQ_ABLATE(8) addr &= 0xFFFFF;
-                    if (role != 2 && pos >= src && pos + 16 <= src + len && base + dd >= 0) {
-                        const int64_t rec = (P + j) >> 2;
+                for (int sidx = 0; sidx < 4; ++sidx) jj[sidx] = s_pline[tid + BLOCK * sidx];
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const uint32_t role = ((uint32_t)ph + jj[sidx]) & 3u;
+                    sg[sidx] = s_seg[role < 2u ? role : 2u][jj[sidx] >> 2];
+                    cb[sidx] = s_colbase[role];
+                }
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int pos = (tid + BLOCK * sidx) * 16;
+                    const uint32_t role = ((uint32_t)ph + jj[sidx]) & 3u;
+                    const int src = (int)((uint32_t)sg[sidx] & 0xFFFFu), len = (int)((uint32_t)sg[sidx] >> 16);
+                    const int delta = (int)(sg[sidx] >> 32);
+                    if (role != 2u && pos >= src && pos + 16 <= src + len && (int)jj[sidx] >= jmin) {
+                        const int64_t rec = (P + (int64_t)jj[sidx]) >> 2;
                         if (CA && any_non_ascii(r[sidx].x | r[sidx].y | r[sidx].z | r[sidx].w)) err.valid(rec, 4);
-                        if (CQ && role == 3 &&
+                        if (CQ && role == 3u &&
                             (any_out_of_range(r[sidx].x, a.q_lower, a.q_upper) | any_out_of_range(r[sidx].y, a.q_lower, a.q_upper) |
                              any_out_of_range(r[sidx].z, a.q_lower, a.q_upper) | any_out_of_range(r[sidx].w, a.q_lower, a.q_upper)))
                             err.valid(rec, 5);
-                        U16B v{r[sidx].x, r[sidx].y, r[sidx].z, r[sidx].w};
-                        if (!BZQ_ABLATE(16)) *reinterpret_cast<U16B*>(col + addr) = v;
-                        else if (addr == -12345) *reinterpret_cast<U16B*>(col + addr) = v;
+                        int64_t off = (int64_t)(delta + pos);
+                        if (BZQ_ABLATE(8)) off &= 0xFFFFF;
+                        const U16B v{r[sidx].x, r[sidx].y, r[sidx].z, r[sidx].w};
+                        if (!BZQ_ABLATE(16)) *reinterpret_cast<U16B*>(reinterpret_cast<uint8_t*>(cb[sidx]) + off) = v;
                     }
                 }
             }
@@ -612,25 +634,25 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             // covers every byte, and bytes written twice carry the same value.  Shorter lines go byte-exact.
             if (!BZQ_ABLATE(2)) {
                 const int nseg = ((int)c + 4) >> 2; // segment indices in use
-                const int js = (1 - ph) & 3;
                 for (int pidx = tid; pidx < 6 * nseg; pidx += BLOCK) {
                     const int side = pidx & 1, sk = pidx >> 1;
                     const int k = sk / 3, slot = sk - 3 * k;
-                    const int len = (int)s_len[slot][k];
-                    if (len == 0) continue;
-                    const int src = (int)s_src[slot][k];
-                    const int64_t d0 = (slot == 0 ? I : (slot == 1 ? S : Q)) + (int64_t)s_dst[slot][k];
-                    if (d0 < 0) continue;   // a head line owned by the previous shard
-                    uint8_t* col = slot == 0 ? a.col_id : (slot == 1 ? a.col_seq : a.col_qual);
-                    const int64_t rec = (P + 4 * k + (slot == 0 ? jh : (slot == 1 ? js : jq))) >> 2;
+                    const u64 sg = s_seg[slot][k];
+                    const int len = (int)((uint32_t)sg >> 16);
+                    const int role = slot == 2 ? 3 : slot;
+                    const int j = 4 * k + ((role - ph) & 3);
+                    if (len == 0 || j < jmin) continue;
+                    const int src = (int)((uint32_t)sg & 0xFFFFu), delta = (int)(sg >> 32);
+                    uint8_t* col = reinterpret_cast<uint8_t*>(s_colbase[role]);
+                    const int64_t rec = (P + j) >> 2;
                     if (len >= 16) {
                         const int off = side ? src + len - 16 : src;
                         if (((side ? src + len : src) & 15) == 0) continue;   // that end is a whole piece already
-                        int64_t g = d0 + (off - src);
-                        if BZQ_ABLATE(8) g &= 0xFFFFF;
+                        int64_t g = (int64_t)(delta + off);
+                        if (BZQ_ABLATE(8)) g &= 0xFFFFF;
                         copy16<CA, CQ>(col, g, off, s_tile, rec, slot == 2, a.q_lower, a.q_upper, err);
                     } else if (side == 0) {
-                        emit_part_rt<CA, CQ>(col, d0, src, len, s_tile, rec, slot == 2, a.q_lower, a.q_upper, err);
+                        emit_part_rt<CA, CQ>(col, (int64_t)(delta + src), src, len, s_tile, rec, slot == 2, a.q_lower, a.q_upper, err);
                     }
                 }
             }
