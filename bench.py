@@ -67,7 +67,6 @@ def main():
     ap.add_argument("--hier", action="store_true", help="one launch, two-level decoupled look-back (bzq_single.hpp)")
     ap.add_argument("--two-pass", action="store_true", help="(default) aggregate + scan + emit kernels")
     ap.add_argument("--kernels-v1", action="store_true", help="two-pass mode with the first-generation kernels")
-    ap.add_argument("--emit-persistent", type=int, default=0)
     ap.add_argument("--overlap", type=int, default=0, help="overlap pass A of sub-chunk k+1 with the emit of sub-chunk k (needs --pass-bytes)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU shard protocol even with one rank")
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (results are wrong)")
@@ -104,7 +103,6 @@ def main():
     ctx.set_option("kernels_v2", 0 if args.kernels_v1 else 1)
     if args.ablate:
         ctx.set_option("ablate", args.ablate)
-    ctx.set_option("emit_persistent", args.emit_persistent)
     ctx.set_option("overlap", args.overlap)
     ctx.set_option("timing_detail", 0 if args.overlap else 1)
 

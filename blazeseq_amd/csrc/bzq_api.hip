@@ -81,8 +81,8 @@ struct bzq_ctx {
     hipEvent_t ev[8]{};
     std::vector<hipEvent_t> ev_detail;
     // options
-    int ablate = 0, emit_persistent = 0;
-    int force_dense = 0, timing_detail = 0, single_pass = 0, v2 = 1, num_cu = 256, wg_per_cu = 0;
+    int ablate = 0;
+    int force_dense = 0, timing_detail = 0, single_pass = 0, v2 = 1, num_cu = 256;
     bool ran_single_pass = false;
     // current chunk
     const uint8_t* cur = nullptr;
@@ -113,13 +113,6 @@ namespace {
             return BZQ_ERR_HIP;                                                                  \
         }                                                                                        \
     } while (0)
-
-template <typename K>
-int occupancy_of(K kernel) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BLOCK, 0) != hipSuccess || nb <= 0) nb = 4;
-    return nb;
-}
 
 int ensure(bzq_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;
@@ -169,20 +162,6 @@ int ensure_record_arenas(bzq_ctx* c, int64_t recs) {
     return 0;
 }
 
-// Persistent kernels: `per_cu` workgroups per compute unit (what their LDS/VGPR budget admits), never
-// more than there are tiles.
-dim3 persistent_grid(const bzq_ctx* c, int64_t tiles, int per_cu) {
-    int64_t g = (int64_t)c->num_cu * (c->wg_per_cu > 0 ? c->wg_per_cu : per_cu);
-    if (g > tiles) g = tiles;
-    if (g < 1) g = 1;
-    return dim3((unsigned)g);
-}
-
-int agg2_occupancy() {
-    static int occ = 0;
-    if (!occ) occ = occupancy_of(k_tile_aggregate2);
-    return occ;
-}
 
 int64_t pass_tiles(const bzq_ctx* c) {
     int64_t pb = c->cfg.pass_bytes > 0 ? c->cfg.pass_bytes : (int64_t)1 << 40;
@@ -218,18 +197,9 @@ EmitArgs make_emit_args(bzq_ctx* c) {
     return e;
 }
 
-dim3 persistent_grid(const bzq_ctx* c, int64_t tiles, int per_cu);
-
-// grid.x == 0: persistent launch sized from the kernel's own occupancy
 template <bool CA, bool CQ, bool OFFS, bool LB>
 void launch_fused_one(const bzq_ctx* c, dim3 grid, const FusedArgs& a) {
-    auto k = k_fused<CA, CQ, OFFS, LB>;
-    if (grid.x == 0) {
-        static int occ = 0;
-        if (!occ) occ = occupancy_of(k);
-        grid = persistent_grid(c, a.tile_end - a.tile_begin, occ);
-    }
-    hipLaunchKernelGGL(k, grid, dim3(BLOCK), 0, c->stream, a);
+    hipLaunchKernelGGL((k_fused<CA, CQ, OFFS, LB>), grid, dim3(BLOCK), 0, c->stream, a);
 }
 template <bool CA, bool CQ, bool LB>
 void launch_fused_off(const bzq_ctx* c, bool offs, dim3 grid, const FusedArgs& a) {
@@ -350,7 +320,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
             if (!skip_aggregate_mid) {
                 AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p,
                           (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
-                if (c->v2) hipLaunchKernelGGL(k_tile_aggregate2, persistent_grid(c, te - tb, agg2_occupancy()), dim3(BLOCK), 0, c->stream, a);
+                if (c->v2) hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
                 else hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
             }
             if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
@@ -367,11 +337,11 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
                 (void)hipStreamWaitEvent(c->stream2, c->ev_pipe[2 * passes], 0);
                 hipStream_t keep = c->stream;
                 c->stream = c->stream2;
-                launch_fused<false>(c, c->emit_persistent ? dim3(0) : grid, f);
+                launch_fused<false>(c, grid, f);
                 c->stream = keep;
                 (void)hipEventRecord(c->ev_pipe[2 * passes + 1], c->stream2);
             } else {
-                launch_fused<false>(c, c->emit_persistent ? dim3(0) : grid, f);
+                launch_fused<false>(c, grid, f);
             }
         } else {
             EmitArgs e = make_emit_args(c);
@@ -613,9 +583,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "timing_detail")) c->timing_detail = (int)value;
     else if (!strcmp(key, "single_pass")) c->single_pass = (int)value;
     else if (!strcmp(key, "kernels_v2")) c->v2 = (int)value;
-    else if (!strcmp(key, "wg_per_cu")) c->wg_per_cu = (int)value;
     else if (!strcmp(key, "ablate")) c->ablate = (int)value;
-    else if (!strcmp(key, "emit_persistent")) c->emit_persistent = (int)value;
     else if (!strcmp(key, "overlap")) c->overlap = (int)value;
     else if (!strcmp(key, "pass_bytes")) c->cfg.pass_bytes = value > 0 ? std::max<int64_t>(TILE, (value / TILE) * TILE) : 0;
     else { c->err = std::string("unknown option ") + key; return BZQ_ERR_ARG; }
@@ -989,7 +957,7 @@ int32_t bzq_shard_scan(bzq_ctx* c, const uint8_t* d_data, uint64_t n, bzq_shard_
     HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
     const int64_t nt = tiles_for(n);
     AggArgs a{d_data, (int64_t)n, 10u, 0, nt, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
-    hipLaunchKernelGGL(k_tile_aggregate2, persistent_grid(c, nt, agg2_occupancy()), dim3(BLOCK), 0, c->stream, a);
+    hipLaunchKernelGGL(k_tile_aggregate2, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
     launch_scan(c, 0, nt, true);
     hipLaunchKernelGGL(k_first_newlines, dim3(1), dim3(BLOCK), 0, c->stream, d_data, (int64_t)n, c->d_state);
     HIPCHK(c, hipStreamSynchronize(c->stream));

@@ -86,13 +86,29 @@ __device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
     return (((uint32_t)hi << 8) | (uint32_t)lo) ^ 0x8080u;
 }
 
-// Guarded 16-byte load of chunk bytes [pos, pos+16): bytes at or beyond n read as 0.
+// Guarded 16-byte load of chunk bytes [pos, pos+16): bytes at or beyond n read as 0.  The one piece that straddles
+// n is taken from the 16 bytes that END at n and shifted down (no byte-by-byte path in the hot kernels).
 __device__ __forceinline__ uint4 load16(const uint8_t* __restrict__ g, int64_t pos, int64_t n) {
     if (pos + 16 <= n) return *reinterpret_cast<const uint4*>(g + pos);
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-    for (int i = 0; i < 16; ++i)
-        if (pos + i < n) w[i >> 2] |= (uint32_t)g[pos + i] << (8 * (i & 3));
-    return make_uint4(w[0], w[1], w[2], w[3]);
+    u64 lo = 0, hi = 0;
+    if (pos < n) {
+        if (n >= 16) {
+            // an UNALIGNED load and typed as one: behind a uint4* the compiler may assume n % 16 == 0
+            struct __attribute__((packed, aligned(1))) Tail16 { u64 lo, hi; };
+            const Tail16 v = *reinterpret_cast<const Tail16*>(g + (n - 16));
+            const u64 vlo = v.lo, vhi = v.hi;
+            const int sh = (int)(pos + 16 - n) * 8;   // 8..120: drop the bytes before pos
+            if (sh < 64) { lo = (vlo >> sh) | (vhi << (64 - sh)); hi = vhi >> sh; }
+            else lo = vhi >> (sh - 64);
+        } else {   // a chunk shorter than 16 bytes
+#pragma unroll 1
+            for (int i = 0; pos + i < n; ++i) {
+                const u64 b = (u64)g[pos + i];
+                if (i < 8) lo |= b << (8 * i); else hi |= b << (8 * (i - 8));
+            }
+        }
+    }
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 
 struct ByteSrc {

@@ -311,6 +311,9 @@ __device__ __forceinline__ void copy16(uint8_t* __restrict__ col, int64_t gaddr,
     *reinterpret_cast<U16B*>(col + gaddr) = w;
 }
 
+// One workgroup per tile, straight-line (no persistent loop: a loop lets the compiler hoist ~35 VGPRs of invariants,
+// and a register-prefetching persistent variant measured 10% SLOWER -- this kernel is bound by HBM traffic, not by
+// reads in flight: capping it at 4 or 5 workgroups per CU instead of 6 does not change its time).
 template <bool CA, bool CQ, bool OFFS, bool LB>
 __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
@@ -327,16 +330,32 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     __shared__ uint32_t s_w[4];
     __shared__ int64_t s_bcast[4];   // tile, P / S, Q, I
     __shared__ int s_cnt[3];
+#if BZQ_EXPERIMENTS && defined(BZQ_PAD_LDS)
+    __shared__ uint8_t s_pad[BZQ_PAD_LDS];   // experiment: cap workgroups per CU through LDS
+    if (a.n < 0) s_pad[a.n & 1023] = 1;
+#endif
     uint8_t* s_tile = s_tile_raw + 16;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid0 = threadIdx.x;
 
     if (LB) {
-        if (tid == 0) s_bcast[0] = (int64_t)atomicAdd(a.ticket, 1ull);
+        if (tid0 == 0) s_bcast[0] = (int64_t)atomicAdd(a.ticket, 1ull);
         __syncthreads();
     }
     int64_t t = LB ? s_bcast[0] : a.tile_begin + (int64_t)blockIdx.x;
     if (!LB && t >= a.tile_end) return;
-  for (;;) {
+    // every global LOAD of a tile is issued by fetch(), before any store of the same loop trip: vmcnt retires in
+    // order, so a load waited for after stores would also wait for those stores' round trip
+    uint4 r[4];   // four source pieces per thread (q = tid + 256 s)
+    int64_t tP = 0, tS = 0, tQ = 0, tI = 0;
+    uint32_t prevb = 10u;
+    auto fetch = [&](int64_t tt) {
+        const int64_t f0 = tt * TILE;
+        if (!LB) { tP = a.tileP[tt]; tS = a.tileS[tt]; tQ = a.tileQ[tt]; tI = a.tileI[tt]; }
+        prevb = f0 > 0 ? (uint32_t)a.g[f0 - 1] : a.prev_byte;
+        tile_fetch(a.g, a.n, f0, (int)((a.n - f0) < TILE ? (a.n - f0) : TILE), r);
+    };
+    fetch(t);
+    const int tid = tid0, lane = tid & 63, wave = tid >> 6;
     u64 tprev = 0;
     auto phase_mark = [&](int i) {
         if (BZQ_ABLATE(64) && tid == 0 && (t & 63) == 0) {   // 1 workgroup in 64 (all-workgroup atomics would dominate)
@@ -348,15 +367,10 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     phase_mark(-1);
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
-    // every global LOAD of this tile is issued here, before any store: vmcnt retires in order, so a
-    // load waited for after the record-output stores would also wait for those stores' round trip
-    int64_t tP = 0, tS = 0, tQ = 0, tI = 0;
-    if (!LB) { tP = a.tileP[t]; tS = a.tileS[t]; tQ = a.tileQ[t]; tI = a.tileI[t]; }
-    uint4 r[4];   // this thread's four source pieces (q = tid + 256 s); they stay in registers for the scatter
-    tile_fetch(a.g, a.n, t0, valid, r);
-    tile_stage<true>(r, valid, s_mask, s_tile);
+    const int64_t cP = tP, cS = tS, cQ = tQ, cI = tI;
+    const bool first_starts = prevb == 10u;
+    tile_stage<true>(r, valid, s_mask, s_tile);   // r[] also stays in registers for the scatter
     ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
-    const bool first_starts = (bs.at(t0 - 1) == 10u);
     __syncthreads();
     phase_mark(0);   // tile loaded, masks built, staged
     if (!LB && BZQ_ABLATE(128)) return;   // experiment: stop here
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     __syncthreads();
     phase_mark(1);   // newline count scan + position table
     if (!LB && BZQ_ABLATE(256)) return;   // experiment: stop here
-    const int64_t P = LB ? s_bcast[1] : tP;
+    const int64_t P = LB ? s_bcast[1] : cP;
     ErrAcc err{~0ull, ~0ull};
     bool overflow = false;
     const int ph = (int)(P & 3);
@@ -531,7 +545,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         reinterpret_cast<int32_t*>(&s_seg[1][tid])[1] = ds - (int)(g1 & 0xFFFFu);
         reinterpret_cast<int32_t*>(&s_seg[2][tid])[1] = dq - (int)(g2 & 0xFFFFu);
         if (!LB && tid < 4)
-            s_colbase[tid] = (u64)(tid == 0 ? a.col_id + tI : (tid == 1 ? a.col_seq + tS : a.col_qual + tQ));
+            s_colbase[tid] = (u64)(tid == 0 ? a.col_id + cI : (tid == 1 ? a.col_seq + cS : a.col_qual + cQ));
         n_id = (int)(tot & 0x1FFFFFull); n_seq = (int)((tot >> 21) & 0x1FFFFFull); n_qual = (int)((tot >> 42) & 0x1FFFFFull);
     }
 
@@ -552,7 +566,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         }
     }
     __syncthreads();
-    const int64_t S = LB ? s_bcast[1] : tS, Q = LB ? s_bcast[2] : tQ, I = LB ? s_bcast[3] : tI;
+    const int64_t S = LB ? s_bcast[1] : cS, Q = LB ? s_bcast[2] : cQ, I = LB ? s_bcast[3] : cI;
     phase_mark(3);   // segment scan
     if (!LB && BZQ_ABLATE(1024)) return;   // experiment: stop here
 
@@ -616,14 +630,15 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                     const int delta = (int)(sg[sidx] >> 32);
                     if (role != 2u && pos >= src && pos + 16 <= src + len && (int)jj[sidx] >= jmin) {
                         const int64_t rec = (P + (int64_t)jj[sidx]) >> 2;
-                        if (CA && any_non_ascii(r[sidx].x | r[sidx].y | r[sidx].z | r[sidx].w)) err.valid(rec, 4);
+                        const uint4 pv = r[sidx];
+                        if (CA && any_non_ascii(pv.x | pv.y | pv.z | pv.w)) err.valid(rec, 4);
                         if (CQ && role == 3u &&
-                            (any_out_of_range(r[sidx].x, a.q_lower, a.q_upper) | any_out_of_range(r[sidx].y, a.q_lower, a.q_upper) |
-                             any_out_of_range(r[sidx].z, a.q_lower, a.q_upper) | any_out_of_range(r[sidx].w, a.q_lower, a.q_upper)))
+                            (any_out_of_range(pv.x, a.q_lower, a.q_upper) | any_out_of_range(pv.y, a.q_lower, a.q_upper) |
+                             any_out_of_range(pv.z, a.q_lower, a.q_upper) | any_out_of_range(pv.w, a.q_lower, a.q_upper)))
                             err.valid(rec, 5);
                         int64_t off = (int64_t)(delta + pos);
                         if (BZQ_ABLATE(8)) off &= 0xFFFFF;
-                        const U16B v{r[sidx].x, r[sidx].y, r[sidx].z, r[sidx].w};
+                        const U16B v{pv.x, pv.y, pv.z, pv.w};
                         if (!BZQ_ABLATE(16)) *reinterpret_cast<U16B*>(reinterpret_cast<uint8_t*>(cb[sidx]) + off) = v;
                     }
                 }
@@ -662,43 +677,29 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
     if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
     if (overflow) atomicOr(&a.st->rec_overflow, 1);
-    if (LB) break;
-    t += (int64_t)gridDim.x;      // persistent workgroups: the column stores of this tile drain while the next one loads
-    if (t >= a.tile_end) break;
-    __syncthreads();
-  }
 }
 
 
-// Pass A of the two-pass mode, table-driven like k_fused: the phase is unknown here, so thread k
-// takes lines 4k..4k+3 = one line of every CLASS (line index mod 4) and treats each as a potential
-// header for the id-byte count.  Same output as k_tile_aggregate.
+// Pass A of the two-pass mode.  The phase (which line of a record a tile starts on) is unknown here, so every line
+// is measured as if it were a header and the byte counts are kept per CLASS (line index mod 4); the scan kernels
+// pick the class that turns out to be the header / sequence / quality one.  One workgroup per tile, one line per
+// thread; 20 KiB of LDS and < 64 VGPRs so that eight workgroups fit a CU (this pass lives on occupancy: its time
+// falls 1.09 / 0.89 / 0.78 / 0.70 ms at 3 / 4 / 5 / 6 workgroups per CU).  Same output as k_tile_aggregate.
+constexpr int MAXL_A = 1012;   // s_nl sized so the kernel's LDS is 8 x 20480 B per CU; more newlines -> serial path
 __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[TILE];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
-    __shared__ uint16_t s_nl[MAXL + 4];
-    __shared__ uint32_t s_w[4];
-    __shared__ u64 s_red[2][4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // persistent workgroups: tiles blockIdx.x, +gridDim.x, ... with a register prefetch of the next
-    // tile, so its HBM latency hides behind this tile's work
-    int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    __shared__ uint16_t s_nl[MAXL_A];
+    __shared__ __attribute__((aligned(8))) uint32_t s_w[4];   // scan scratch, then the two block sums (2 x u64)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
     if (t >= a.tile_end) return;
-    uint4 pre[4];
-    {
-        const int64_t t0p = t * TILE;
-        tile_fetch(a.g, a.n, t0p, (int)((a.n - t0p) < TILE ? (a.n - t0p) : TILE), pre);
-    }
-  for (;;) {
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
-    const uint32_t prev_b = t0 > 0 ? (uint32_t)a.g[t0 - 1] : a.prev_byte; // issued before the prefetch (vmcnt is in order)
-    tile_stage<true>(pre, valid, s_mask, s_tile);
-    const int64_t t_next = t + (int64_t)gridDim.x;
-    if (t_next < a.tile_end) {
-        const int64_t t0p = t_next * TILE;
-        tile_fetch(a.g, a.n, t0p, (int)((a.n - t0p) < TILE ? (a.n - t0p) : TILE), pre);
-    }
+    const uint32_t prev_b = t0 > 0 ? (uint32_t)a.g[t0 - 1] : a.prev_byte;
+    uint4 r[4];
+    tile_fetch(a.g, a.n, t0, valid, r);
+    tile_stage<true>(r, valid, s_mask, s_tile);
     ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
     const bool first_starts = (prev_b == 10u);
     __syncthreads();
@@ -706,8 +707,10 @@ __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
     const u64 m64 = s_mask64[tid];
     uint32_t c = 0;
     const uint32_t excl = block_exclusive_scan<uint32_t, 4>((uint32_t)__popcll(m64), s_w, c);
+    u64* s_sum = reinterpret_cast<u64*>(s_w);
+    if (tid < 2) s_sum[tid] = 0;
     u64 pa = 0, pi = 0; // 4 x 16-bit fields: bytes / id bytes per class
-    if ((int)c <= MAXL) {
+    if ((int)c <= MAXL_A) {
         u64 m = m64;
         int idx = 0;
         while (m) {
@@ -717,61 +720,56 @@ __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
             ++idx;
         }
         __syncthreads();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int j = 4 * tid + r;
-            if (j <= (int)c) {
-                const int start = j ? (int)s_nl[j - 1] + 1 : 0;
-                const bool end_in = j < (int)c;
-                const int end = end_in ? (int)s_nl[j] : valid;
-                if (end > start) {
-                    int64_t lo, hi;
-                    header_kept(bs, t0 + start, t0 + end, j > 0 ? true : first_starts, end_in, t0 + valid, lo, hi);
-                    pa += (u64)(end - start) << (16 * r);
-                    pi += (u64)(hi - lo) << (16 * r);
-                }
-            }
-        }
-    } else if (tid == 0) { // serial path for tiles with > MAXL newlines
-        int j = 0, line_start = 0;
-        bool start_in = first_starts;
-        uint32_t la[4] = {0, 0, 0, 0}, li[4] = {0, 0, 0, 0};
-        auto handle = [&](int start, int end, bool end_in) {
+        for (int j = tid; j <= (int)c; j += BLOCK) {
+            const int start = j ? (int)s_nl[j - 1] + 1 : 0;
+            const bool end_in = j < (int)c;
+            const int end = end_in ? (int)s_nl[j] : valid;
             if (end > start) {
                 int64_t lo, hi;
-                header_kept(bs, t0 + start, t0 + end, start_in, end_in, t0 + valid, lo, hi);
-                la[j & 3] += (uint32_t)(end - start);
-                li[j & 3] += (uint32_t)(hi - lo);
-            }
-        };
-        for (int w = 0; w < BLOCK; ++w) {
-            u64 m = s_mask64[w];
-            while (m) {
-                const int bit = __builtin_ctzll(m);
-                m &= m - 1;
-                const int nl = w * 64 + bit;
-                handle(line_start, nl, true);
-                line_start = nl + 1;
-                start_in = true;
-                ++j;
+                header_kept(bs, t0 + start, t0 + end, j > 0 ? true : first_starts, end_in, t0 + valid, lo, hi);
+                pa += (u64)(end - start) << (16 * (j & 3));
+                pi += (u64)(hi - lo) << (16 * (j & 3));
             }
         }
-        handle(line_start, valid, false);
-        for (int k = 0; k < 4; ++k) { pa |= (u64)la[k] << (16 * k); pi |= (u64)li[k] << (16 * k); }
+    } else {
+        __syncthreads();
+        if (tid == 0) { // serial path for tiles with > MAXL_A newlines
+            int j = 0, line_start = 0;
+            bool start_in = first_starts;
+            uint32_t la[4] = {0, 0, 0, 0}, li[4] = {0, 0, 0, 0};
+            auto handle = [&](int start, int end, bool end_in) {
+                if (end > start) {
+                    int64_t lo, hi;
+                    header_kept(bs, t0 + start, t0 + end, start_in, end_in, t0 + valid, lo, hi);
+                    la[j & 3] += (uint32_t)(end - start);
+                    li[j & 3] += (uint32_t)(hi - lo);
+                }
+            };
+            for (int w = 0; w < BLOCK; ++w) {
+                u64 m = s_mask64[w];
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int nl = w * 64 + bit;
+                    handle(line_start, nl, true);
+                    line_start = nl + 1;
+                    start_in = true;
+                    ++j;
+                }
+            }
+            handle(line_start, valid, false);
+            for (int k = 0; k < 4; ++k) { pa |= (u64)la[k] << (16 * k); pi |= (u64)li[k] << (16 * k); }
+        }
     }
     // block sum of the packed fields (every field total <= 16384, no carry between fields)
     pa = wave_sum_u64(pa); pi = wave_sum_u64(pi);
-    if (lane == 0) { s_red[0][wave] = pa; s_red[1][wave] = pi; }
+    if (lane == 0) { atomicAdd(&s_sum[0], pa); atomicAdd(&s_sum[1], pi); }
     __syncthreads();
     if (tid == 0) {
         a.tile_c[t] = c;
-        a.tile_a[t] = s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
-        a.tile_idc[t] = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+        a.tile_a[t] = s_sum[0];
+        a.tile_idc[t] = s_sum[1];
     }
-    if (t_next >= a.tile_end) break;
-    t = t_next;
-    __syncthreads();
-  }
 }
 
 } // namespace bzq
