@@ -74,7 +74,7 @@ struct bzq_ctx {
     DevBuf in, seq, qual, id;
     DevBuf ends, id_ends, rec_end, b_ends, b_id_ends, off[4], view_e, view_i;
     int64_t rec_cap = 0;
-    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, grp_carry, desc;
+    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc;
     int64_t tile_cap = 0;
     ChunkState* d_state = nullptr;
     ChunkState* h_state = nullptr; // pinned
@@ -141,7 +141,7 @@ int ensure_chunk_arenas(bzq_ctx* c, uint64_t n, bool need_input) {
             (rc = ensure(c, c->tile_idc, nt * 8)) || (rc = ensure(c, c->tileP, nt * 8)) ||
             (rc = ensure(c, c->tileS, nt * 8)) || (rc = ensure(c, c->tileQ, nt * 8)) ||
             (rc = ensure(c, c->tileI, nt * 8)) || (rc = ensure(c, c->grp, (nt / SG_TILES + 2) * 80)) ||
-            (rc = ensure(c, c->grp_carry, (nt / SG_TILES + 2) * 32)) || (rc = ensure(c, c->desc, (nt * 6 + (nt / 64 + 2) * 4 + 16) * 8)))
+            (rc = ensure(c, c->desc, (nt * 6 + (nt / 64 + 2) * 4 + 16) * 8)))
             return rc;
         c->tile_cap = nt;
     }
@@ -283,14 +283,13 @@ int enqueue_single(bzq_ctx* c) {
     return 0;
 }
 
-void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, bool first_pass) {
+void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, int pass) {
     ScanArgs s{tb, te, (const uint32_t*)c->tile_c.p, (const u64*)c->tile_a.p, (const u64*)c->tile_idc.p,
                (int64_t*)c->tileP.p, (int64_t*)c->tileS.p, (int64_t*)c->tileQ.p, (int64_t*)c->tileI.p,
-               (int64_t*)c->grp.p, (int64_t*)c->grp_carry.p, c->d_state, first_pass ? 1 : 0};
+               (int64_t*)c->grp.p, c->d_state, pass};
     const int64_t ng = (te - tb + SG_TILES - 1) / SG_TILES;
     if (ng <= 0) return;
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)ng), dim3(SG_THREADS), 0, c->stream, s);
-    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(64), 0, c->stream, s, ng);
     hipLaunchKernelGGL(k_scan_down, dim3((unsigned)ng), dim3(SG_THREADS), 0, c->stream, s);
 }
 
@@ -324,7 +323,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
                 else hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
             }
             if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
-            launch_scan(c, tb, te, tb == 0);
+            launch_scan(c, tb, te, (int)passes);
             if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
         }
         if (c->v2) {
@@ -548,7 +547,7 @@ void bzq_destroy(bzq_ctx* c) {
     DevBuf* bufs[] = {&c->in, &c->seq, &c->qual, &c->id, &c->ends, &c->id_ends, &c->rec_end, &c->b_ends,
                       &c->b_id_ends, &c->off[0], &c->off[1], &c->off[2], &c->off[3], &c->view_e, &c->view_i,
                       &c->tile_c, &c->tile_a,
-                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->grp_carry, &c->desc};
+                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->d_state) hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
@@ -958,7 +957,7 @@ int32_t bzq_shard_scan(bzq_ctx* c, const uint8_t* d_data, uint64_t n, bzq_shard_
     const int64_t nt = tiles_for(n);
     AggArgs a{d_data, (int64_t)n, 10u, 0, nt, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
     hipLaunchKernelGGL(k_tile_aggregate2, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
-    launch_scan(c, 0, nt, true);
+    launch_scan(c, 0, nt, 0);
     hipLaunchKernelGGL(k_first_newlines, dim3(1), dim3(BLOCK), 0, c->stream, d_data, (int64_t)n, c->d_state);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));

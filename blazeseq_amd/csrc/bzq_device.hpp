@@ -63,6 +63,9 @@ struct ChunkState {
     int64_t last_ends, last_id_ends;
     // debug only (option ablate bit 64): shader-clock cycles workgroup thread 0 spent in each phase of the emit kernel
     unsigned long long phase_cycles[12];
+    // running totals between the passes of one chunk (pass_bytes): P, S, Q, I, last tile with a newline + 1;
+    // pass k reads slot k & 1 and leaves slot (k + 1) & 1
+    int64_t pass_carry[2][5];
 };
 
 __device__ __forceinline__ bool is_posix_space(uint32_t c) {
@@ -360,13 +363,14 @@ __global__ __launch_bounds__(BLOCK) void k_tile_aggregate(AggArgs a) {
 }
 
 // =================================================================================== tile scan
-// Three small kernels over the per-tile summaries (20 B per 16 KiB tile):
+// Two small kernels over the per-tile summaries (20 B per 16 KiB tile):
 //   k_scan_reduce  one workgroup per 1024 tiles: the group's summary in the same phase-agnostic
 //                  class form (a tile that starts L lines into the group contributes its class k to
 //                  group class (k+L)&3)
-//   k_scan_spine   one wave walks the group summaries with the running (line index, seq, qual, id)
-//                  carry -- the only place the line phase is resolved
-//   k_scan_down    one workgroup per group: exclusive prefix per tile from the group's carry
+//   k_scan_down    one workgroup per group.  First it derives the group's own carry (line index, seq, qual, id at
+//                  its first tile) from ALL earlier groups' summaries -- a block scan of the line counts resolves
+//                  every group's phase, which picks the class to sum for each column -- then the exclusive prefix
+//                  per tile.  (A separate one-wave "spine" kernel walking the groups serially took 25 us.)
 constexpr int SG_THREADS = 256;
 constexpr int SG_ITEMS = 4;
 constexpr int SG_TILES = SG_THREADS * SG_ITEMS;
@@ -380,24 +384,36 @@ struct ScanArgs {
     int64_t* tileS;
     int64_t* tileQ;
     int64_t* tileI;
-    // per group (index relative to the group of tile_begin): c, a[4], idc[4], last tile with a newline
+    // per group (index relative to the group of tile_begin): c, a[4], idc[4], last tile with a newline + 1
     int64_t* grp;        // 10 x int64 per group
-    int64_t* grp_carry;  // 4 x int64 per group: P, S, Q, I at the group's first tile
     ChunkState* st;
-    int32_t first_pass;  // load the carry from P0.. instead of P..
+    int32_t pass;        // 0: the carry starts from P0..; k > 0: from pass_carry[k & 1] left by the previous pass
 };
 
 __device__ __forceinline__ int64_t field16(u64 v, int k) { return (int64_t)((v >> (16 * (k & 3))) & 0xFFFFull); }
 
+// block-wide sum of an int64, result in every thread (NW waves; s_r needs NW entries; two barriers)
+template <int NW>
+__device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t* s_r) {
+    const u64 w = wave_sum_u64((u64)v);
+    if ((threadIdx.x & 63) == 0) s_r[threadIdx.x >> 6] = (int64_t)w;
+    __syncthreads();
+    int64_t t = 0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += s_r[i];
+    __syncthreads();
+    return t;
+}
+
 __global__ __launch_bounds__(SG_THREADS) void k_scan_reduce(ScanArgs a) {
-    __shared__ int64_t s_w[SG_THREADS / 64];
-    __shared__ u64 s_acc[10];
-    const int tid = threadIdx.x;
-    if (tid < 10) s_acc[tid] = tid == 9 ? 0ull : 0ull;
+    constexpr int NW = SG_THREADS / 64;
+    __shared__ int64_t s_w[NW];
+    __shared__ int64_t s_acc[NW][9];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i0 = a.tile_begin + (int64_t)blockIdx.x * SG_TILES + (int64_t)tid * SG_ITEMS;
     int64_t c[SG_ITEMS];
     u64 av[SG_ITEMS], iv[SG_ITEMS];
-    int64_t sum = 0, my_last = -1;
+    int64_t sum = 0, my_last = 0;   // last tile with a newline, + 1 (0 = none)
 #pragma unroll
     for (int k = 0; k < SG_ITEMS; ++k) {
         const int64_t i = i0 + k;
@@ -405,11 +421,11 @@ __global__ __launch_bounds__(SG_THREADS) void k_scan_reduce(ScanArgs a) {
         c[k] = ok ? (int64_t)a.tile_c[i] : 0;
         av[k] = ok ? a.tile_a[i] : 0ull;
         iv[k] = ok ? a.tile_idc[i] : 0ull;
-        if (ok && c[k] > 0) my_last = i;
+        if (ok && c[k] > 0) my_last = i + 1;
         sum += c[k];
     }
     int64_t tot;
-    int64_t ell = block_exclusive_scan<int64_t, SG_THREADS / 64>(sum, s_w, tot);
+    int64_t ell = block_exclusive_scan<int64_t, NW>(sum, s_w, tot);
     int64_t A[4] = {0, 0, 0, 0}, D[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < SG_ITEMS; ++k) {
@@ -421,53 +437,69 @@ __global__ __launch_bounds__(SG_THREADS) void k_scan_reduce(ScanArgs a) {
         }
         ell += c[k];
     }
+    // my_last grows with the thread index, so the wave/block maximum is the last non-zero one: sum of a one-hot is
+    // not available, take the max through a u64 add-free path: tiles are < 2^40, pack (my_last) as is and use max
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (A[k]) atomicAdd(&s_acc[1 + k], (u64)A[k]);
-        if (D[k]) atomicAdd(&s_acc[5 + k], (u64)D[k]);
+        const u64 sa = wave_sum_u64((u64)A[k]), sd = wave_sum_u64((u64)D[k]);
+        if (lane == 0) { s_acc[wave][k] = (int64_t)sa; s_acc[wave][4 + k] = (int64_t)sd; }
     }
-    if (my_last >= 0) atomicMax(&s_acc[9], (u64)(my_last + 1)); // +1 so that 0 means none
+    {
+        int64_t m = my_last;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const int64_t o = __shfl_xor(m, off, 64);
+            m = o > m ? o : m;
+        }
+        if (lane == 0) s_acc[wave][8] = m;
+    }
     __syncthreads();
     if (tid < 10) {
-        int64_t v = tid == 0 ? tot : (int64_t)s_acc[tid];
+        int64_t v;
+        if (tid == 0) v = tot;
+        else if (tid == 9) { v = 0; for (int w = 0; w < NW; ++w) v = s_acc[w][8] > v ? s_acc[w][8] : v; }
+        else { v = 0; for (int w = 0; w < NW; ++w) v += s_acc[w][tid - 1]; }
         a.grp[(int64_t)blockIdx.x * 10 + tid] = v;
     }
 }
 
-__global__ __launch_bounds__(64) void k_scan_spine(ScanArgs a, int64_t n_groups) {
-    __shared__ int64_t s_g[64 * 10];
-    const int lane = threadIdx.x;
-    int64_t P, S, Q, I, last;
-    if (a.first_pass) { P = a.st->P0; S = a.st->S0; Q = a.st->Q0; I = a.st->I0; last = -1; }
-    else { P = a.st->P; S = a.st->S; Q = a.st->Q; I = a.st->I; last = a.st->last_nl_tile; }
-    for (int64_t base = 0; base < n_groups; base += 64) {
-        const int64_t cnt = n_groups - base < 64 ? n_groups - base : 64;
-        for (int64_t i = lane; i < cnt * 10; i += 64) s_g[i] = a.grp[base * 10 + i];
-        __syncthreads();
-        if (lane == 0) {
-            for (int64_t b = 0; b < cnt; ++b) {
-                const int64_t* g = &s_g[b * 10];
-                int64_t* out = &a.grp_carry[(base + b) * 4];
-                out[0] = P; out[1] = S; out[2] = Q; out[3] = I;
-                const int ph = (int)(P & 3);
-                S += g[1 + ((1 - ph) & 3)];
-                Q += g[1 + ((3 - ph) & 3)];
-                I += g[5 + ((0 - ph) & 3)];
-                P += g[0];
-                if (g[9] > 0) last = g[9] - 1;
-            }
-        }
-        __syncthreads();
-    }
-    if (lane == 0) { a.st->P = P; a.st->S = S; a.st->Q = Q; a.st->I = I; a.st->last_nl_tile = last; }
-}
-
 __global__ __launch_bounds__(SG_THREADS) void k_scan_down(ScanArgs a) {
-    __shared__ int64_t s_w[SG_THREADS / 64];
+    constexpr int NW = SG_THREADS / 64;
+    __shared__ int64_t s_w[NW];
     const int tid = threadIdx.x;
-    const int64_t* carry = &a.grp_carry[(int64_t)blockIdx.x * 4];
-    const int64_t cP = carry[0], cS = carry[1], cQ = carry[2], cI = carry[3];
-    const int64_t i0 = a.tile_begin + (int64_t)blockIdx.x * SG_TILES + (int64_t)tid * SG_ITEMS;
+    const int64_t g = blockIdx.x, ng = gridDim.x;
+    // ---- this group's carry from the groups before it ---------------------------------------------------
+    int64_t cP, cS, cQ, cI, last;
+    if (a.pass == 0) { cP = a.st->P0; cS = a.st->S0; cQ = a.st->Q0; cI = a.st->I0; last = 0; }
+    else {
+        const int64_t* pc = a.st->pass_carry[a.pass & 1];
+        cP = pc[0]; cS = pc[1]; cQ = pc[2]; cI = pc[3]; last = pc[4];
+    }
+    for (int64_t base = 0; base < g; base += SG_THREADS) {
+        const int64_t h = base + tid;
+        const bool ok = h < g;
+        const int64_t* gs = &a.grp[h * 10];
+        const int64_t ch = ok ? gs[0] : 0;
+        int64_t tot;
+        const int64_t ph64 = cP + block_exclusive_scan<int64_t, NW>(ch, s_w, tot);
+        const int ph = (int)(ph64 & 3);                       // role of group h's first line
+        const int64_t sv = ok ? gs[1 + ((1 - ph) & 3)] : 0;   // its class whose role is 1 (sequence)
+        const int64_t qv = ok ? gs[1 + ((3 - ph) & 3)] : 0;   // role 3 (quality)
+        const int64_t dv = ok ? gs[5 + ((0 - ph) & 3)] : 0;   // role 0 (header) after strip
+        int64_t lv = ok ? gs[9] : 0;
+        cS += block_sum_i64<NW>(sv, s_w);
+        cQ += block_sum_i64<NW>(qv, s_w);
+        cI += block_sum_i64<NW>(dv, s_w);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const int64_t o = __shfl_xor(lv, off, 64); lv = o > lv ? o : lv; }
+        if ((tid & 63) == 0) s_w[tid >> 6] = lv;
+        __syncthreads();
+        for (int w = 0; w < NW; ++w) last = s_w[w] > last ? s_w[w] : last;
+        __syncthreads();
+        cP += tot;
+    }
+    // ---- exclusive prefix per tile -------------------------------------------------------------------------
+    const int64_t i0 = a.tile_begin + g * SG_TILES + (int64_t)tid * SG_ITEMS;
     int64_t c[SG_ITEMS];
     u64 av[SG_ITEMS], iv[SG_ITEMS];
     int64_t sum = 0;
@@ -481,7 +513,7 @@ __global__ __launch_bounds__(SG_THREADS) void k_scan_down(ScanArgs a) {
         sum += c[k];
     }
     int64_t tot;
-    int64_t p = cP + block_exclusive_scan<int64_t, SG_THREADS / 64>(sum, s_w, tot);
+    int64_t p = cP + block_exclusive_scan<int64_t, NW>(sum, s_w, tot);
     int64_t ps[SG_ITEMS], sv[SG_ITEMS], qv[SG_ITEMS], dv[SG_ITEMS];
     int64_t ss = 0, sq = 0, si = 0;
 #pragma unroll
@@ -495,19 +527,27 @@ __global__ __launch_bounds__(SG_THREADS) void k_scan_down(ScanArgs a) {
         p += c[k];
     }
     int64_t tS, tQ, tI;
-    int64_t eS = cS + block_exclusive_scan<int64_t, SG_THREADS / 64>(ss, s_w, tS);
-    int64_t eQ = cQ + block_exclusive_scan<int64_t, SG_THREADS / 64>(sq, s_w, tQ);
-    int64_t eI = cI + block_exclusive_scan<int64_t, SG_THREADS / 64>(si, s_w, tI);
+    int64_t eS = cS + block_exclusive_scan<int64_t, NW>(ss, s_w, tS);
+    int64_t eQ = cQ + block_exclusive_scan<int64_t, NW>(sq, s_w, tQ);
+    int64_t eI = cI + block_exclusive_scan<int64_t, NW>(si, s_w, tI);
 #pragma unroll
     for (int k = 0; k < SG_ITEMS; ++k) {
         const int64_t i = i0 + k;
         if (i < a.tile_end) { a.tileP[i] = ps[k]; a.tileS[i] = eS; a.tileQ[i] = eQ; a.tileI[i] = eI; }
         eS += sv[k]; eQ += qv[k]; eI += dv[k];
     }
+    if (g == ng - 1 && tid == 0) {   // totals of this pass: the next pass's carry and the host's counts
+        const int64_t own = a.grp[g * 10 + 9];
+        if (own > last) last = own;
+        int64_t* pc = a.st->pass_carry[(a.pass + 1) & 1];
+        pc[0] = cP + tot; pc[1] = cS + tS; pc[2] = cQ + tQ; pc[3] = cI + tI; pc[4] = last;
+        a.st->P = cP + tot; a.st->S = cS + tS; a.st->Q = cQ + tQ; a.st->I = cI + tI; a.st->last_nl_tile = last - 1;
+    }
 }
 
 // Tail after the last newline: where it starts and whether it is more than blanks
-// (_check_end_qual, blazeseq/utils.mojo:292-329).  One workgroup.
+// (_check_end_qual, blazeseq/utils.mojo:292-329).  One workgroup; the last tile with a newline is read as 16-byte
+// pieces like every other tile.
 __global__ __launch_bounds__(BLOCK) void k_tail(const uint8_t* __restrict__ g, int64_t n, ChunkState* st) {
     __shared__ int s_pos;
     __shared__ int s_nb;
@@ -518,9 +558,18 @@ __global__ __launch_bounds__(BLOCK) void k_tail(const uint8_t* __restrict__ g, i
     int64_t tail = 0;
     if (lt >= 0) {
         const int64_t t0 = lt * TILE;
+        const int valid = (int)((n - t0) < TILE ? (n - t0) : TILE);
+        uint4 r[4];
+        tile_fetch(g, n, t0, valid, r);
         int best = -1;
-        for (int i = tid; i < TILE; i += BLOCK)
-            if (t0 + i < n && g[t0 + i] == 10) best = i;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int pos = (tid + BLOCK * s) * 16;
+            uint32_t m = nl_mask16(r[s]);
+            const int rem = valid - pos;
+            if (rem < 16) m &= rem > 0 ? ((1u << rem) - 1u) : 0u;
+            if (m) best = pos + 31 - __builtin_clz(m);
+        }
         if (best >= 0) atomicMax(&s_pos, best);
         __syncthreads();
         tail = t0 + s_pos + 1;
