@@ -82,6 +82,13 @@ class BzqShardSummary(C.Structure):
 
 
 # every symbol include/blazeseq_hip.h declares (tests/test_abi_symbols.py checks the header against this)
+class BzqIngestStats(C.Structure):
+    _fields_ = [
+        ("file_bytes", C.c_uint64), ("bytes_read", C.c_uint64), ("chunks", C.c_uint64), ("records", C.c_uint64),
+        ("read_s", C.c_double), ("wait_s", C.c_double), ("total_s", C.c_double),
+    ]
+
+
 SYMBOLS = {
     "bzq_abi_version": (C.c_int32, []),
     "bzq_config_default": (None, [C.POINTER(BzqConfig)]),
@@ -109,6 +116,10 @@ SYMBOLS = {
     "bzq_generate_synthetic_device": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                                   C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_uint64,
                                                   C.POINTER(C.c_uint64)]),
+    "bzq_ingest_open": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "bzq_ingest_next": (C.c_int32, [C.c_void_p, C.c_uint64, C.POINTER(BzqChunk), C.POINTER(C.c_uint64)]),
+    "bzq_ingest_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(BzqIngestStats)]),
+    "bzq_ingest_close": (None, [C.c_void_p]),
 }
 
 _lib = None

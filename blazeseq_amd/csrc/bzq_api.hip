@@ -465,6 +465,8 @@ void sb_put(std::string& s, const char* label, long long v) {
 
 // ================================================================================== C ABI
 
+#include "bzq_ingest.hpp"
+
 extern "C" {
 
 int32_t bzq_abi_version(void) { return BZQ_ABI_VERSION; }
@@ -1028,5 +1030,134 @@ int32_t bzq_generate_synthetic_device(bzq_ctx* c, int64_t num_reads, int64_t fir
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
+
+// ---- host ingest pipeline (bzq_ingest.hpp) ---------------------------------------------------------------------
+
+int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int32_t n_threads, bzq_ingest** out) {
+    if (!c || !path || !out) return BZQ_ERR_ARG;
+    *out = nullptr;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { c->err = std::string("bzq_ingest_open: cannot open ") + path; return BZQ_ERR_IO; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        close(fd);
+        c->err = std::string("bzq_ingest_open: not a regular file: ") + path;
+        return BZQ_ERR_IO;
+    }
+    bzq_ingest* g = new bzq_ingest();
+    g->ctx = c; g->fd = fd; g->file_size = (uint64_t)st.st_size;
+    g->chunk_bytes = chunk_bytes ? ((chunk_bytes + 4095) & ~4095ull) : (256ull << 20);
+    g->reserve = std::max<uint64_t>(16ull << 20, g->chunk_bytes / 8);   // room for the carry in front of a chunk
+    g->n_threads = n_threads > 0 ? n_threads : 8;
+    g->t_open = std::chrono::steady_clock::now();
+    g->stats.file_bytes = g->file_size;
+    bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) {
+        ok = hipHostMalloc((void**)&g->slot[i].pinned, g->reserve + g->chunk_bytes, hipHostMallocDefault) == hipSuccess &&
+             hipMalloc((void**)&g->slot[i].dev, g->reserve + g->chunk_bytes + 64) == hipSuccess &&
+             hipEventCreateWithFlags(&g->slot[i].h2d_done, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&g->dev_free[i], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        c->err = "bzq_ingest_open: allocating the pinned / device chunk buffers failed";
+        bzq::ingest_free(g);
+        return BZQ_ERR_NOMEM;
+    }
+    g->producer = std::thread(bzq::ingest_producer, g);
+    *out = g;
+    return 0;
+}
+
+// Parses the next chunk of the file.  `records_taken` = how many records of the PREVIOUS chunk the caller consumed
+// (ignored on the first call); the rest, and the bytes behind them, are carried in front of this chunk.  Returns like
+// bzq_chunk_result: 0 = records delivered and more input follows, > 0 = the stream's terminal FastxErrorCode (BZQ_EOF
+// for a clean end; the chunk may still deliver records before it), < 0 runtime failure.  out->n_bytes / positions are
+// relative to the chunk; *stream_pos (optional) receives the file offset of its first byte.
+int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, uint64_t* stream_pos) {
+    if (!g || !out) return BZQ_ERR_ARG;
+    bzq_ctx* c = g->ctx;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (g->finished) {
+        memset(out, 0, sizeof(*out));
+        out->status = g->final_status; out->error_record = -1;
+        return g->final_status;
+    }
+    const int64_t k = g->next_k;
+    // ---- carry of the previous chunk -----------------------------------------------------------------------
+    uint64_t carry = 0, carry_src = 0;
+    if (g->have_prev) {
+        uint64_t cut = g->prev_res.bytes_consumed;
+        if (records_taken < g->prev_res.n_records) {
+            cut = 0;
+            if (records_taken > 0) {
+                int64_t e = 0;
+                HIPCHK(c, hipMemcpy(&e, g->prev_res.d_record_end + (records_taken - 1), 8, hipMemcpyDeviceToHost));
+                cut = (uint64_t)e + 1;
+            }
+        }
+        carry = g->prev_n - cut;
+        carry_src = g->prev_off + cut;
+        g->stats.records += std::min<uint64_t>(records_taken, g->prev_res.n_records);
+        if (carry > g->reserve) {
+            c->err = "bzq_ingest_next: " + std::to_string(carry) + " bytes to carry exceed the reserve of " +
+                     std::to_string(g->reserve) + " (open with a larger chunk)";
+            return BZQ_ERR_NOMEM;
+        }
+    }
+    // ---- wait for this chunk's H2D to be enqueued, then order the ctx stream behind it ---------------------------
+    const auto tw = std::chrono::steady_clock::now();
+    {
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->cv.wait(lk, [&] { return g->produced > k || g->stop; });
+        if (g->produced <= k) { c->err = "bzq_ingest_next: " + (g->io_error.empty() ? std::string("reader stopped") : g->io_error); return BZQ_ERR_IO; }
+    }
+    bzq::IngestSlot& s = g->slot[k & 1];
+    HIPCHK(c, hipStreamWaitEvent(c->stream, s.h2d_done, 0));
+    const uint64_t off = g->reserve - carry;
+    if (carry) {
+        const bzq::IngestSlot& p = g->slot[(k - 1) & 1];
+        HIPCHK(c, hipMemcpyAsync(s.dev + off, p.dev + carry_src, carry, hipMemcpyDeviceToDevice, c->stream));
+    }
+    if (g->have_prev) {   // the previous chunk's device buffer may now be refilled (behind the carry copy)
+        HIPCHK(c, hipEventRecord(g->dev_free[(k - 1) & 1], c->stream));
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->dev_free_valid[(k - 1) & 1] = true;
+        g->released = k;
+        g->cv.notify_all();
+    }
+    // the chunk starts wherever its carry starts: the kernels read the input through unaligned-typed vector loads
+    const uint64_t n = carry + s.len;
+    const uint64_t spos = s.file_off - carry;
+    c->shard_mode = false;
+    int rc = submit_common(c, s.dev + off, n, spos, s.eof ? 1 : 0, 0, 0, 0, 0, 10u, 0);
+    if (rc < 0) return rc;
+    rc = bzq_chunk_result(c, out);
+    g->stats.wait_s += bzq::seconds_since(tw);
+    if (rc < 0) return rc;
+    if (stream_pos) *stream_pos = spos;
+    g->stats.chunks += 1;
+    g->stats.total_s = bzq::seconds_since(g->t_open);
+    g->have_prev = true; g->prev_res = *out; g->prev_n = n; g->prev_off = off; g->prev_stream_pos = spos;
+    g->next_k = k + 1;
+    if (out->status != BZQ_OK) {   // terminal: EOF or the first failing record
+        g->finished = true; g->final_status = out->status == BZQ_EOF ? BZQ_EOF : out->status;
+        g->stats.records += out->n_records;
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->stop = true;
+        g->cv.notify_all();
+    } else if (s.eof) {
+        g->finished = true; g->final_status = BZQ_EOF;
+    }
+    return rc;
+}
+
+int32_t bzq_ingest_get_stats(const bzq_ingest* g, bzq_ingest_stats* out) {
+    if (!g || !out) return BZQ_ERR_ARG;
+    *out = g->stats;
+    return 0;
+}
+
+void bzq_ingest_close(bzq_ingest* g) { bzq::ingest_free(g); }
 
 } // extern "C"

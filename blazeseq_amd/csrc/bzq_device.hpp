@@ -89,10 +89,19 @@ __device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
     return (((uint32_t)hi << 8) | (uint32_t)lo) ^ 0x8080u;
 }
 
+// 16 bytes from global memory at ANY byte address, in one global_load_dwordx4 (gfx950 loads unaligned).  Typed as
+// unaligned on purpose: a chunk handed over by the ingest pipeline starts wherever its carry starts, and behind an
+// aligned vector type the compiler would be entitled to assume otherwise.
+struct __attribute__((packed, aligned(1))) G16B { uint32_t x, y, z, w; };
+__device__ __forceinline__ uint4 load16_any(const uint8_t* __restrict__ p) {
+    const G16B v = *reinterpret_cast<const G16B*>(p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // Guarded 16-byte load of chunk bytes [pos, pos+16): bytes at or beyond n read as 0.  The one piece that straddles
 // n is taken from the 16 bytes that END at n and shifted down (no byte-by-byte path in the hot kernels).
 __device__ __forceinline__ uint4 load16(const uint8_t* __restrict__ g, int64_t pos, int64_t n) {
-    if (pos + 16 <= n) return *reinterpret_cast<const uint4*>(g + pos);
+    if (pos + 16 <= n) return load16_any(g + pos);
     u64 lo = 0, hi = 0;
     if (pos < n) {
         if (n >= 16) {
@@ -241,9 +250,9 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* s_w, T& total) {
 __device__ __forceinline__ void tile_fetch(const uint8_t* __restrict__ g, int64_t n, int64_t t0, int valid, uint4 (&r)[4]) {
     const int tid = threadIdx.x;
     if (valid == TILE) {   // every tile but the last: no guards
-        const uint4* __restrict__ p = reinterpret_cast<const uint4*>(g + t0) + tid;
+        const uint8_t* __restrict__ p = g + t0 + tid * 16;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) r[s] = p[BLOCK * s];
+        for (int s = 0; s < 4; ++s) r[s] = load16_any(p + BLOCK * 16 * s);
         return;
     }
 #pragma unroll

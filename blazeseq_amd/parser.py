@@ -338,6 +338,44 @@ class FastqBatch:
         return [self.get_record(k) for k in range(self.num_records())]
 
 
+class Ingest:
+    """bzq_ingest: file -> pinned double buffers -> device -> chunk parser (native reader threads, the H2D copy of
+    chunk k+1 overlaps the consumption of chunk k).  ``next(records_taken)`` parses the next chunk; the records of
+    the previous chunk that were not taken are carried in front of it."""
+
+    def __init__(self, ctx: Context, path: str, chunk_bytes: int = 0, n_threads: int = 0):
+        self._ctx = ctx
+        h = C.c_void_p()
+        _check(ctx.h, L.lib().bzq_ingest_open(ctx.h, os.fsencode(path), int(chunk_bytes), int(n_threads), C.byref(h)),
+               "bzq_ingest_open")
+        self.h = h
+        self.stream_pos = 0
+
+    def next(self, records_taken: int = 0) -> ChunkResult:
+        raw = L.BzqChunk()
+        sp = C.c_uint64(0)
+        rc = L.lib().bzq_ingest_next(self.h, int(records_taken), C.byref(raw), C.byref(sp))
+        _check(self._ctx.h, rc, "bzq_ingest_next")
+        self.stream_pos = int(sp.value)
+        return ChunkResult(self._ctx, raw)
+
+    def stats(self) -> L.BzqIngestStats:
+        st = L.BzqIngestStats()
+        L.lib().bzq_ingest_get_stats(self.h, C.byref(st))
+        return st
+
+    def close(self):
+        if getattr(self, "h", None):
+            L.lib().bzq_ingest_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _Source:
     """Reader.read_to_buffer semantics (blazeseq/io/readers.mojo:51-79): returns up to n bytes, b"" at EOF."""
 
@@ -373,11 +411,19 @@ class FastqParser:
 
     def __init__(self, source, schema: str = "generic", batch_size: int = DEFAULT_BATCH_SIZE,
                  config: Optional[ParserConfig] = None, device: int = 0, chunk_bytes: int = DEFAULT_CHUNK_BYTES,
-                 pass_bytes: int = 0):
+                 pass_bytes: int = 0, native_ingest: bool = True, reader_threads: int = 0):
         self.config = config if config is not None else ParserConfig()
         self._batch_size = batch_size
         self._ctx = Context(self.config, schema, batch_size, device, pass_bytes=pass_bytes)
-        self._src = _Source(source)
+        # a plain file goes through the native ingest pipeline (reader threads + pinned double buffers);
+        # bytes / arrays / file objects through the Reader.read_to_buffer-style loop below
+        self._ingest: Optional[Ingest] = None
+        if native_ingest and isinstance(source, (str, os.PathLike)) and os.path.isfile(source):
+            self._ingest = Ingest(self._ctx, os.fspath(source), max(int(chunk_bytes), 1 << 16), reader_threads)
+            self._src = None
+        else:
+            self._src = _Source(source)
+        self._taken = 0               # records of the previous ingest chunk that were handed out
         self._chunk_bytes = max(int(chunk_bytes), 1 << 16)
         self._carry = np.zeros(0, dtype=np.uint8)
         self._stream_pos = 0          # stream offset of the current chunk's first byte
@@ -394,6 +440,18 @@ class FastqParser:
     def _load_chunk(self, min_records: int):
         """Read + parse the next chunk (carry first).  Grows the chunk until it holds at least
         ``min_records`` complete records or the stream ends."""
+        if self._ingest is not None:
+            while True:
+                res = self._ingest.next(self._taken)
+                self._taken = 0
+                if res.status == L.OK and int(res.n_records) < min_records:
+                    continue   # carry everything and append the next piece of the file
+                break
+            self._stream_pos = self._ingest.stream_pos
+            self._chunk, self._chunk_data, self._next = res, None, 0
+            if res.status != L.OK:
+                self._terminal = (int(res.status), self._ctx.format_error(self._records_before))
+            return
         want = max(self._chunk_bytes, self._carry.size + (1 << 16))
         data = self._carry
         while True:
@@ -426,6 +484,11 @@ class FastqParser:
             b._detach()
         self._live = weakref.WeakSet()
         res, data = self._chunk, self._chunk_data
+        if self._ingest is not None:
+            self._taken = self._next
+            self._records_before += self._next
+            self._chunk = None
+            return
         if self._next == 0:
             cut = 0
         elif self._next == int(res.n_records):

@@ -238,6 +238,35 @@ int32_t bzq_submit_shard(bzq_ctx* ctx, const uint8_t* d_data, uint64_t n, uint64
 int32_t bzq_shard_head_bytes(const bzq_shard_summary* s, uint64_t lines_before, uint8_t prev_last_byte,
                              uint64_t* head_bytes);
 
+/* ---- host ingest pipeline ---------------------------------------------- */
+
+/* Replaces FileReader.read_to_buffer + BufferedReader._fill_buffer/_compact_from for plain files
+ * (blazeseq/io/readers.mojo:86-137, blazeseq/io/buffered.mojo:239-290): a producer thread reads chunk k+1 with
+ * n_threads pread() workers into pinned memory while chunk k travels to the device on its own HIP stream and
+ * chunk k-1 is consumed; the carry (bytes behind the last record handed out) moves device-to-device. */
+typedef struct bzq_ingest bzq_ingest;
+
+typedef struct bzq_ingest_stats {
+    uint64_t file_bytes;   /* size of the file */
+    uint64_t bytes_read;   /* bytes the reader threads have fetched so far */
+    uint64_t chunks;       /* chunks parsed */
+    uint64_t records;      /* records the caller has taken */
+    double read_s;         /* producer: seconds inside pread() */
+    double wait_s;         /* consumer: seconds inside bzq_ingest_next (waiting for H2D + kernels) */
+    double total_s;        /* open -> most recent bzq_ingest_next */
+} bzq_ingest_stats;
+
+/* chunk_bytes 0 = 256 MiB; n_threads <= 0 = 8.  The ctx must outlive the ingest and is used by it. */
+int32_t bzq_ingest_open(bzq_ctx* ctx, const char* path, uint64_t chunk_bytes, int32_t n_threads, bzq_ingest** out);
+/* Parse the next chunk.  records_taken: how many records of the PREVIOUS chunk the caller consumed (ignored on the
+ * first call); the remaining records and the bytes behind them are carried in front of this chunk.  Returns like
+ * bzq_chunk_result: 0 = more input follows, > 0 = the stream's terminal FastxErrorCode (BZQ_EOF = clean end; the
+ * chunk may still deliver records before it), < 0 runtime failure.  *stream_pos (optional): file offset of the
+ * chunk's first byte.  After the terminal chunk every call returns that code with zero records. */
+int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, uint64_t* stream_pos);
+int32_t bzq_ingest_get_stats(const bzq_ingest* g, bzq_ingest_stats* out);
+void bzq_ingest_close(bzq_ingest* g);
+
 /* ---- synthetic input (measurement only) ----------------------------------------------------- */
 
 /* generate_synthetic_fastq_buffer (blazeseq/utils.mojo:831-917) for fixed-length reads, written

@@ -1,0 +1,61 @@
+"""End-to-end (PCIe-inclusive) rate of the native ingest pipeline: file (page cache, /dev/shm) -> pinned -> device ->
+parsed columns.  Never the bench `value` (that is HBM-resident); quoted in DESIGN.md.
+   python scripts/bench_ingest.py [--reads 10000000] [--threads 8] [--chunk-mib 256]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import blazeseq_amd as B
+from blazeseq_amd import _lib as L
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--reads", type=int, default=10_000_000)
+ap.add_argument("--threads", type=int, nargs="+", default=[4, 8, 16])
+ap.add_argument("--chunk-mib", type=int, nargs="+", default=[256])
+ap.add_argument("--dir", default="/dev/shm")
+args = ap.parse_args()
+
+ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
+rec = ctx.generate_synthetic_device(args.reads, 150, 33, 73, "generic", count=1)
+n = rec * args.reads
+buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+ctx.generate_synthetic_device(args.reads, 150, 33, 73, "generic", buf.data_ptr(), buf.numel(), first=0, count=args.reads)
+torch.cuda.synchronize()
+host = buf[:n].cpu().numpy()
+path = os.path.join(args.dir if os.path.isdir(args.dir) else "/tmp", "bzq_ingest_bench.fastq")
+host.tofile(path)
+del buf
+print(f"file {path}: {n/1e9:.2f} GB, host cores {os.cpu_count()}", flush=True)
+# plain H2D of the same bytes from pinned memory, for reference
+pin = torch.empty(n, dtype=torch.uint8).pin_memory()
+pin.numpy()[:] = host
+dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(3): dev.copy_(pin, non_blocking=True)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+print(f"plain pinned H2D copy: {n/dt/1e9:.1f} GB/s")
+del pin, dev
+for chunk in args.chunk_mib:
+    for th in args.threads:
+        best = None
+        for rep in range(3):
+            t0 = time.perf_counter()
+            ing = B.Ingest(ctx, path, chunk_bytes=chunk << 20, n_threads=th)
+            t1 = time.perf_counter()
+            taken, total = 0, 0
+            while True:
+                res = ing.next(taken)
+                taken = int(res.n_records)
+                total += taken
+                if int(res.status) != L.OK:
+                    break
+            dt = time.perf_counter() - t1
+            st = ing.stats()
+            ing.close()
+            assert total == args.reads, (total, args.reads)
+            r = (n / dt / 1e9, dt, st.read_s, st.wait_s, t1 - t0)
+            if best is None or r[0] > best[0]: best = r
+        print(f"chunk {chunk} MiB, {th} reader threads: {best[0]:.1f} GB/s end to end ({best[1]*1e3:.0f} ms; reader busy {best[2]*1e3:.0f} ms, "
+              f"consumer waiting {best[3]*1e3:.0f} ms, open {best[4]*1e3:.0f} ms)", flush=True)
+os.remove(path)

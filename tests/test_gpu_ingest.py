@@ -1,0 +1,137 @@
+"""-m gpu: the native ingest pipeline (bzq_ingest_*: reader threads -> pinned double buffers -> device -> chunk parser)
+against the oracle, through the C ABI.  Replaces FileReader + BufferedReader refills (io/readers.mojo:86-137,
+io/buffered.mojo:239-290) for plain files, so the parity bar is: same records, same batches, same terminal event as
+the reference-algorithm streaming parser reading the same file."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from fastq_fuzz import rand_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _records_of(ctx, res, first, count):
+    """(id, seq, qual) of records [first, first+count) of a parsed chunk, via bzq_batch_view + copy to host."""
+    import blazeseq_amd as B
+    if count == 0:
+        return []
+    fb = B.FastqBatch(ctx, ctx.batch_view(first, count))
+    return [(r.id, r.sequence, r.quality) for r in fb.to_records()]
+
+
+def _oracle_records(f):
+    out, e0, i0 = [], 0, 0
+    for r in range(f.n_records):
+        e1, i1 = int(f.ends[r]), int(f.id_ends[r])
+        out.append((f.id_bytes[i0:i1].tobytes(), f.seq_bytes[e0:e1].tobytes(), f.qual_bytes[e0:e1].tobytes()))
+        e0, i0 = e1, i1
+    return out
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ingest_chunks_with_partial_takes_match_flat_oracle(seed, tmp_path):
+    """Tiny chunks (4-20 KiB), the caller takes all / some / none of each chunk's records: the concatenation of what
+    was taken equals the one-shot parse of the file, and the stream ends with the same event."""
+    import blazeseq_amd as B
+    from blazeseq_amd import _lib as L
+    rng = np.random.default_rng(1000 + seed)
+    dirty = 0.0 if seed < 4 else 0.002
+    data = rand_stream(rng, n_records=int(rng.integers(400, 1500)), max_len=120, dirty=dirty, tail=[0, 1, 2, 3, 0, 5][seed])
+    path = tmp_path / f"s{seed}.fastq"
+    path.write_bytes(data)
+    ocfg = O.make_config(batch_size=4096)
+    f = O.flat_parse(np.frombuffer(data, dtype=np.uint8), ocfg, is_eof=True)
+    want = _oracle_records(f)
+    ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
+    ing = B.Ingest(ctx, str(path), chunk_bytes=[4096, 8192, 20480][seed % 3], n_threads=3)
+    got, taken, status = [], 0, L.OK
+    for it in range(100000):
+        res = ing.next(taken)
+        n = int(res.n_records)
+        status = int(res.status)
+        if status != L.OK:
+            take = n                      # terminal chunk: everything it delivers
+        else:
+            mode = int(rng.integers(0, 4))
+            take = n if mode < 2 else (int(rng.integers(0, n + 1)) if mode == 2 else 0)
+        got += _records_of(ctx, res, 0, take)
+        taken = take
+        if status != L.OK:
+            break
+    assert got == want, (len(got), len(want))
+    assert status == f.term_code, (status, f.term_code)
+    st = ing.stats()
+    assert st.file_bytes == len(data) and st.records == len(want)
+    # a stream that ends in a failing record stops the readers early; otherwise every byte was fetched once
+    assert st.bytes_read == len(data) if f.consumed + 4096 >= len(data) else st.bytes_read <= len(data)
+    # after the terminal chunk the ingest keeps answering with that code and no records
+    again = ing.next(0)
+    assert int(again.status) == status and int(again.n_records) == 0
+    ing.close()
+
+
+def test_parser_on_a_path_uses_the_ingest_and_matches_the_streaming_oracle(tmp_path):
+    import blazeseq_amd as B
+    data = O.generate_synthetic(30_000, 50, 150, 0, 40, "sanger")
+    path = tmp_path / "syn.fastq"
+    path.write_bytes(bytes(data))
+    ref = [b for b in O.StreamParser(data, O.make_config(batch_size=1000)).batches()]
+    for chunk in (1 << 16, 300_000, 1 << 28):
+        p = B.FastqParser(str(path), batch_size=1000, chunk_bytes=chunk)
+        assert p._ingest is not None
+        got = list(p.batches())
+        assert [len(b) for b in got] == [len(b) for b in ref]
+        for g, r in zip(got, ref):
+            assert g._ends.tolist() == r.ends and g._id_ends.tolist() == r.id_ends
+            assert g._sequence_bytes.tobytes() == r.seq_bytes and g._quality_bytes.tobytes() == r.qual_bytes
+            assert g._id_bytes.tobytes() == r.id_bytes
+    # the Reader-style loop (file object) and the ingest give the same thing
+    with open(path, "rb") as fh:
+        got2 = list(B.FastqParser(fh, batch_size=1000, chunk_bytes=1 << 16).batches())
+    assert [b._sequence_bytes.tobytes() for b in got2] == [r.seq_bytes for r in ref]
+
+
+def test_ingest_error_in_a_late_chunk_reports_the_global_record_number(tmp_path):
+    import blazeseq_amd as B
+    recs = [b"@r%d\nACGTACGTAC\n+\nIIIIIIIIII\n" % i for i in range(5000)]
+    recs[3777] = b"@r3777\nACGTACGTAC\n+\nIIIIIIIII\n"   # quality one byte short
+    data = b"".join(recs)
+    path = tmp_path / "bad.fastq"
+    path.write_bytes(data)
+    sp = O.StreamParser(np.frombuffer(data, dtype=np.uint8), O.make_config(batch_size=100))
+    n_ok = 0
+    with pytest.raises(Exception) as ref_err:
+        while True:
+            b = sp.next_batch(100)
+            if len(b) == 0:
+                break
+            n_ok += len(b)
+    p = B.FastqParser(str(path), batch_size=100, chunk_bytes=1 << 16)
+    n = 0
+    with pytest.raises(B.ParseError) as err:
+        while True:
+            b = p.next_batch(100)
+            if len(b) == 0:
+                break
+            n += len(b)
+    assert n == n_ok == 3700
+    assert b"Record number: 3778" in err.value.message
+    assert err.value.message.decode("latin-1") == str(ref_err.value)
+
+
+def test_ingest_empty_and_missing_files(tmp_path):
+    import blazeseq_amd as B
+    from blazeseq_amd import _lib as L
+    empty = tmp_path / "empty.fastq"
+    empty.write_bytes(b"")
+    ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
+    ing = B.Ingest(ctx, str(empty))
+    res = ing.next(0)
+    assert int(res.status) == L.EOF and int(res.n_records) == 0
+    ing.close()
+    assert list(B.FastqParser(str(empty)).batches()) == []
+    with pytest.raises(RuntimeError, match="cannot open"):
+        B.Ingest(ctx, str(tmp_path / "nope.fastq"))
