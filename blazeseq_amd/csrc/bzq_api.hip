@@ -1046,7 +1046,7 @@ int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int3
         return BZQ_ERR_IO;
     }
     bzq_ingest* g = new bzq_ingest();
-    g->ctx = c; g->fd = fd; g->file_size = (uint64_t)st.st_size;
+    g->ctx = c; g->device = c->device; g->fd = fd; g->file_size = (uint64_t)st.st_size;
     g->chunk_bytes = chunk_bytes ? ((chunk_bytes + 4095) & ~4095ull) : (256ull << 20);
     g->reserve = std::max<uint64_t>(16ull << 20, g->chunk_bytes / 8);   // room for the carry in front of a chunk
     g->n_threads = n_threads > 0 ? n_threads : 8;

@@ -33,6 +33,7 @@ struct IngestSlot {
 
 struct bzq_ingest {
     bzq_ctx* ctx = nullptr;
+    int device = 0;                // copied at open: close must not look at a ctx that may already be gone
     int fd = -1;
     uint64_t file_size = 0, chunk_bytes = 0, reserve = 0;
     int n_threads = 4;
@@ -88,7 +89,7 @@ inline bool parallel_pread(int fd, uint8_t* dst, uint64_t off, uint64_t len, int
 }
 
 inline void ingest_producer(bzq_ingest* g) {
-    (void)hipSetDevice(g->ctx->device);
+    (void)hipSetDevice(g->device);
     uint64_t off = 0;
     for (int64_t k = 0;; ++k) {
         IngestSlot& s = g->slot[k & 1];
@@ -137,7 +138,7 @@ inline void ingest_free(bzq_ingest* g) {
         g->cv.notify_all();
     }
     if (g->producer.joinable()) g->producer.join();
-    (void)hipSetDevice(g->ctx->device);
+    (void)hipSetDevice(g->device);
     if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
     for (int i = 0; i < 2; ++i) {
         if (g->slot[i].pinned) (void)hipHostFree(g->slot[i].pinned);

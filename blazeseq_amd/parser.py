@@ -150,9 +150,12 @@ class Context:
             raise RuntimeError(f"bzq_create failed ({rc}): {lib.bzq_last_error(None).decode()}")
         self.h = h
         self._keep = None
+        self._ingests = weakref.WeakSet()   # open Ingest objects: they use this ctx and must be closed before it
 
     def close(self):
         if getattr(self, "h", None):
+            for ing in list(getattr(self, "_ingests", ())):
+                ing.close()
             L.lib().bzq_destroy(self.h)
             self.h = None
 
@@ -350,6 +353,7 @@ class Ingest:
                "bzq_ingest_open")
         self.h = h
         self.stream_pos = 0
+        ctx._ingests.add(self)
 
     def next(self, records_taken: int = 0) -> ChunkResult:
         raw = L.BzqChunk()
