@@ -12,3 +12,6 @@ from .parser import (ParserConfig, FastqParser, FastqBatch, DeviceFastqBatch, Fa
 
 __all__ = ["ParserConfig", "FastqParser", "FastqBatch", "DeviceFastqBatch", "FastqRecord", "ParseError", "Context",
            "Ingest", "ChunkResult", "quality_schema", "LibraryMissing", "LIB_PATH"]
+from .pyapi import parser, create_parser, PyParser, PyFastqBatch, PyFastqRecord  # noqa: E402
+
+__all__ += ["parser", "create_parser"]

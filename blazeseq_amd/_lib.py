@@ -129,6 +129,26 @@ class LibraryMissing(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """A PyTorch wheel bundles its own libamdhip64.so.7; the system ROCm has one with the same SONAME.  Whichever is
+    loaded first serves both, and torch does not find its GPUs on the system copy.  So when torch is installed (and
+    not imported yet) its copy is loaded first -- without importing torch -- and this library binds to it; device
+    pointers and streams are then shared with torch in either import order."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass   # no torch, or an unusual layout: the system HIP runtime is used
+
+
 def lib():
     """Load libblazeseq_hip.so.  Raises LibraryMissing (never falls back) if it is not built."""
     global _lib
@@ -137,6 +157,7 @@ def lib():
             raise LibraryMissing(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  blazeseq_amd has no CPU fallback.")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch

@@ -512,11 +512,12 @@ class FastqParser:
         """parser.mojo:155-157: True until the end of the stream has been observed."""
         return not self._eof_seen
 
-    def next_batch(self, max_records: int = DEFAULT_BATCH_SIZE) -> FastqBatch:
+    def next_batch(self, max_records: int = DEFAULT_BATCH_SIZE, partial_ok: bool = False) -> FastqBatch:
         """parser.mojo:239-251.  Up to ``max_records`` records; fewer (possibly zero) only at the end
         of the stream; raises ParseError when the batch would reach the stream's failing record
         (the records already collected for that batch are dropped, exactly like the reference's
-        raise out of ``batch.add(self.next_view())``)."""
+        raise out of ``batch.add(self.next_view())``).  ``partial_ok`` (record-wise iteration in bulk): the records
+        before a failing record are returned first, the error is raised by the following call."""
         limit = max_records if max_records else self._batch_size
         while True:
             if self._chunk is None:
@@ -531,10 +532,13 @@ class FastqParser:
         if avail < limit:
             # the batch runs into the terminal event of the stream
             code, msg = self._terminal
-            self._eof_seen = True
-            if code != L.EOF:
-                self._next += avail
-                raise ParseError(code, msg)
+            if code != L.EOF and partial_ok and avail > 0:
+                limit = avail   # hand out what precedes the failing record; the next call raises
+            else:
+                self._eof_seen = True
+                if code != L.EOF:
+                    self._next += avail
+                    raise ParseError(code, msg)
         take = min(limit, avail)
         if take == 0:
             return FastqBatch(self._ctx, L.BzqDeviceBatch())
