@@ -74,7 +74,7 @@ struct bzq_ctx {
     DevBuf in, seq, qual, id;
     DevBuf ends, id_ends, rec_end, b_ends, b_id_ends, off[4], view_e, view_i;
     int64_t rec_cap = 0;
-    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc;
+    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch;
     int64_t tile_cap = 0;
     ChunkState* d_state = nullptr;
     ChunkState* h_state = nullptr; // pinned
@@ -465,6 +465,7 @@ void sb_put(std::string& s, const char* label, long long v) {
 
 // ================================================================================== C ABI
 
+#include "bzq_consumers.hpp"
 #include "bzq_ingest.hpp"
 
 extern "C" {
@@ -549,7 +550,7 @@ void bzq_destroy(bzq_ctx* c) {
     DevBuf* bufs[] = {&c->in, &c->seq, &c->qual, &c->id, &c->ends, &c->id_ends, &c->rec_end, &c->b_ends,
                       &c->b_id_ends, &c->off[0], &c->off[1], &c->off[2], &c->off[3], &c->view_e, &c->view_i,
                       &c->tile_c, &c->tile_a,
-                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc};
+                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc, &c->consumer_scratch};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->d_state) hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
@@ -1159,5 +1160,51 @@ int32_t bzq_ingest_get_stats(const bzq_ingest* g, bzq_ingest_stats* out) {
 }
 
 void bzq_ingest_close(bzq_ingest* g) { bzq::ingest_free(g); }
+
+// ---- device-side consumers of a DeviceFastqBatch (bzq_consumers.hpp) --------------------------------------------
+
+int32_t bzq_batch_nw_scores(bzq_ctx* c, const bzq_device_batch* b, const uint8_t* ref, int32_t ref_len, int32_t* d_scores) {
+    if (!c || !b || ref_len < 0 || (ref_len && !ref) || (b->num_records && !d_scores)) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->num_records <= 0) return 0;
+    int rc;
+    if ((rc = ensure(c, c->consumer_scratch, 4096))) return rc;
+    const int copy = ref_len > NW_MAX_LEN ? NW_MAX_LEN : ref_len;   // longer references score 0 like the example
+    if (copy) HIPCHK(c, hipMemcpyAsync(c->consumer_scratch.p, ref, (size_t)copy, hipMemcpyHostToDevice, c->stream));
+    const int64_t n = b->num_records;
+    hipLaunchKernelGGL(k_nw_scores, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, c->stream,
+                       (const uint8_t*)c->consumer_scratch.p, (int)ref_len, b->sequence_buffer, b->ends, n, d_scores);
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // the host reference bytes may go away after the call
+    return 0;
+}
+
+int32_t bzq_batch_quality_sums(bzq_ctx* c, const bzq_device_batch* b, int64_t* d_sums) {
+    if (!c || !b || (b->num_records && !d_sums)) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int64_t n = b->num_records;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_quality_sums, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, c->stream,
+                       b->qual_buffer, b->ends, n, (int)b->quality_offset, d_sums);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { c->err = std::string("k_quality_sums: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
+    return 0;
+}
+
+int32_t bzq_column_histogram(bzq_ctx* c, const uint8_t* d_col, uint64_t n, uint64_t* hist) {
+    if (!c || !hist || (n && !d_col)) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->consumer_scratch, 4096))) return rc;
+    u64* d_h = (u64*)c->consumer_scratch.p + 64;   // behind the reference bytes
+    HIPCHK(c, hipMemsetAsync(d_h, 0, 256 * 8, c->stream));
+    if (n) {
+        const uint64_t steps = (n + (uint64_t)BLOCK * 16 - 1) / ((uint64_t)BLOCK * 16);
+        const unsigned grid = (unsigned)std::min<uint64_t>(steps, (uint64_t)c->num_cu * 8);
+        hipLaunchKernelGGL(k_byte_histogram, dim3(grid), dim3(BLOCK), 0, c->stream, d_col, (int64_t)n, d_h);
+    }
+    HIPCHK(c, hipMemcpyAsync(hist, d_h, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return 0;
+}
 
 } // extern "C"

@@ -263,6 +263,26 @@ class DeviceFastqBatch:
     def to_records(self) -> List[FastqRecord]:
         return self.copy_to_host().to_records()
 
+    # ---- device-side consumers (bzq_consumers.hpp): outputs are device pointers the caller owns ----------------
+    def nw_scores(self, reference: bytes, d_scores: int):
+        """examples/nw_gpu: score of every record against ``reference`` into device int32[num_records]."""
+        ref = bytes(reference)
+        _check(self._ctx.h, L.lib().bzq_batch_nw_scores(self._ctx.h, C.byref(self.raw), ref, len(ref), C.c_void_p(d_scores)),
+               "bzq_batch_nw_scores")
+
+    def quality_sums(self, d_sums: int):
+        """Per-record sum of Phred scores into device int64[num_records] (asynchronous on the ctx stream)."""
+        _check(self._ctx.h, L.lib().bzq_batch_quality_sums(self._ctx.h, C.byref(self.raw), C.c_void_p(d_sums)),
+               "bzq_batch_quality_sums")
+
+    def histogram(self, column: str = "sequence") -> np.ndarray:
+        """256-bin byte histogram of the sequence or quality column of this batch."""
+        ptr = self.sequence_buffer if column == "sequence" else self.qual_buffer
+        out = (C.c_uint64 * 256)()
+        _check(self._ctx.h, L.lib().bzq_column_histogram(self._ctx.h, C.c_void_p(ptr), int(self.seq_len), out),
+               "bzq_column_histogram")
+        return np.frombuffer(out, dtype=np.uint64).copy()
+
 
 class FastqBatch:
     """blazeseq/fastq/record_batch.mojo:19-207.  Created by the parser from a device batch; the host

@@ -267,6 +267,20 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
 int32_t bzq_ingest_get_stats(const bzq_ingest* g, bzq_ingest_stats* out);
 void bzq_ingest_close(bzq_ingest* g);
 
+/* ---- device-side consumers of a DeviceFastqBatch ------------------------ */
+
+/* The nw_gpu example on the device batch (examples/nw_gpu/kernels.mojo:21-89, execution.mojo:96-140): global
+ * alignment score (match +1, mismatch -1, gap -1) of every record's sequence against `ref` (host bytes).
+ * d_scores: device int32[num_records].  Records or references longer than 256 score 0 (kernels.mojo:48-50). */
+int32_t bzq_batch_nw_scores(bzq_ctx* ctx, const bzq_device_batch* b, const uint8_t* ref, int32_t ref_len, int32_t* d_scores);
+/* Per-record sum of Phred scores, quality byte - b->quality_offset (FastqRecord.phred_scores, record.mojo:340-346;
+ * the v0.1 "quality prefix-sum kernel", CHANGELOG.md:73).  d_sums: device int64[num_records].  Asynchronous on the
+ * ctx stream. */
+int32_t bzq_batch_quality_sums(bzq_ctx* ctx, const bzq_device_batch* b, int64_t* d_sums);
+/* 256-bin byte histogram of a device column (base composition of sequence_buffer, quality distribution of
+ * qual_buffer; the v0.1 quality_distribution example, CHANGELOG.md:73).  hist: host uint64[256]. */
+int32_t bzq_column_histogram(bzq_ctx* ctx, const uint8_t* d_col, uint64_t n, uint64_t* hist);
+
 /* ---- synthetic input (measurement only) ----------------------------------------------------- */
 
 /* generate_synthetic_fastq_buffer (blazeseq/utils.mojo:831-917) for fixed-length reads, written

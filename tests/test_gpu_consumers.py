@@ -1,0 +1,86 @@
+"""-m gpu: device-side consumers of a DeviceFastqBatch (bzq_consumers.hpp) against restatements of the reference's
+example code: the nw_gpu kernel (examples/nw_gpu/kernels.mojo:21-89), FastqRecord.phred_scores (record.mojo:340-346),
+and byte histograms of the columns.  Integer work: results must be identical."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def nw_kernel_restated(ref: bytes, query: bytes) -> int:
+    """examples/nw_gpu/kernels.mojo:21-89, line for line in Python: two DP rows, match +1, mismatch -1, gap -1,
+    0 when either length exceeds 256."""
+    ref_len, query_len = len(ref), len(query)
+    if query_len > 256 or ref_len > 256:
+        return 0
+    prev = [-i for i in range(ref_len + 1)]
+    for j in range(1, query_len + 1):
+        curr = [-j] + [0] * ref_len
+        for i in range(1, ref_len + 1):
+            diag = prev[i - 1] + (1 if ref[i - 1] == query[j - 1] else -1)
+            best = max(diag, prev[i] - 1, curr[i - 1] - 1)
+            curr[i] = best
+        prev = curr
+    return prev[ref_len]
+
+
+def _batch_from(data: bytes, n):
+    import blazeseq_amd as B
+    p = B.FastqParser(data, batch_size=n)
+    b = p.next_batch(n)
+    return p, b, b.to_device()
+
+
+@pytest.mark.parametrize("ref_len", [0, 1, 17, 40, 64, 65, 130, 256, 300])
+def test_nw_scores_match_the_example_kernel(ref_len):
+    import torch
+    rng = np.random.default_rng(ref_len)
+    ref = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), ref_len))
+    recs = []
+    for i in range(70):
+        L = int(rng.integers(0, 60)) if i % 7 else [0, 1, 64, 255, 256, 257, 300][i // 7 % 7]
+        s = bytes(rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), L))
+        if i % 5 == 0 and L and ref_len:   # reads related to the reference score high
+            s = (ref * (L // ref_len + 1))[:L]
+        recs.append(b"@r%d\n" % i + s + b"\n+\n" + b"I" * L + b"\n")
+    p, b, d = _batch_from(b"".join(recs), len(recs))
+    scores = torch.full((d.num_records,), -12345, dtype=torch.int32, device="cuda")
+    d.nw_scores(ref, scores.data_ptr())
+    torch.cuda.synchronize()
+    want = [nw_kernel_restated(ref, r.sequence) for r in b.to_records()]
+    assert scores.cpu().tolist() == want
+
+
+def test_quality_sums_and_histograms_match_numpy():
+    import torch
+    import blazeseq_amd as B
+    data = O.generate_synthetic(20_000, 30, 200, 0, 40, "sanger")
+    p = B.FastqParser(data, batch_size=4096)
+    seen = 0
+    for b in p.batches():
+        d = b.to_device()
+        sums = torch.empty(d.num_records, dtype=torch.int64, device="cuda")
+        d.quality_sums(sums.data_ptr())
+        hs, hq = d.histogram("sequence"), d.histogram("quality")
+        torch.cuda.synchronize()
+        recs = b.to_records()
+        want = [int(np.frombuffer(r.quality, dtype=np.uint8).astype(np.int64).sum()) - 33 * len(r.quality) for r in recs]
+        assert sums.cpu().tolist() == want
+        np.testing.assert_array_equal(hs, np.bincount(b._sequence_bytes, minlength=256).astype(np.uint64))
+        np.testing.assert_array_equal(hq, np.bincount(b._quality_bytes, minlength=256).astype(np.uint64))
+        seen += len(recs)
+    assert seen == 20_000
+
+
+def test_consumers_on_an_empty_batch_and_odd_sizes():
+    import torch
+    p, b, d = _batch_from(b"@a\nACGTA\n+\n!!!!!\n", 4)
+    s = torch.zeros(1, dtype=torch.int32, device="cuda")
+    d.nw_scores(b"ACGTA", s.data_ptr())
+    assert s.item() == 5
+    assert int(d.histogram("sequence")[ord("A")]) == 2 and int(d.histogram("quality")[ord("!")]) == 5
+    q = torch.zeros(1, dtype=torch.int64, device="cuda")
+    d.quality_sums(q.data_ptr()); torch.cuda.synchronize()
+    assert q.item() == 0
