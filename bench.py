@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--validate", action="store_true", help="config 3: check_ascii + check_quality, sanger")
+    ap.add_argument("--long-reads", action="store_true",
+                    help="config 4: 300 000 reads/GPU of 200..19 800 bases (phred 5..30, sanger); record-aligned shards")
     ap.add_argument("--pass-bytes", type=int, default=0)
     ap.add_argument("--single-pass", action="store_true", help="one fused launch with in-kernel look-back (slower today)")
     ap.add_argument("--service", action="store_true", help="one launch, prefix-service workgroup (bzq_single.hpp)")
@@ -107,16 +109,37 @@ def main():
     ctx.set_option("timing_detail", 0 if args.overlap else 1)
 
     # ---- synthetic input, generated on the device (record i depends only on i) ------------------
+    if args.long_reads and args.reads == 10_000_000:
+        args.reads = 300_000
     total_reads = args.reads * world
-    rec_bytes = ctx.generate_synthetic_device(total_reads, args.read_len, 33, 73, "generic", count=1)
-    total_bytes = rec_bytes * total_reads
-    lo = total_bytes * rank // world
-    hi = total_bytes * (rank + 1) // world
-    n = hi - lo
+    gen = (dict(read_len=200, max_len=19_800, min_phred=5, max_phred=30, schema="sanger") if args.long_reads else
+           dict(read_len=args.read_len, max_len=None, min_phred=33, max_phred=73, schema="generic"))
+
+    def generate(d_out=0, cap=0, first=0, count=None):
+        return ctx.generate_synthetic_device(total_reads, gen["read_len"], gen["min_phred"], gen["max_phred"], gen["schema"],
+                                             d_out, cap, first=first, count=count, max_len=gen["max_len"])
+
     slack = 1 << 20  # room for the halo (one record) behind the shard
-    shard = torch.empty(n + slack, dtype=torch.uint8, device=dev)
-    i0, i1 = lo // rec_bytes, (hi + rec_bytes - 1) // rec_bytes
-    if lo == i0 * rec_bytes:
+    if args.long_reads:
+        # variable record sizes: every rank takes an equal number of records (record-aligned shards)
+        total_bytes = generate(count=total_reads)
+        lo = generate(count=rank * args.reads) if rank else 0
+        n = generate(first=rank * args.reads, count=args.reads)
+        rec_bytes = n // args.reads   # mean, for the workload description only
+        shard = torch.empty(n + slack, dtype=torch.uint8, device=dev)
+        generate(shard.data_ptr(), shard.numel(), first=rank * args.reads, count=args.reads)
+        i0 = i1 = 0
+    else:
+        rec_bytes = generate(count=1)
+        total_bytes = rec_bytes * total_reads
+        lo = total_bytes * rank // world
+        hi = total_bytes * (rank + 1) // world
+        n = hi - lo
+        shard = torch.empty(n + slack, dtype=torch.uint8, device=dev)
+        i0, i1 = lo // rec_bytes, (hi + rec_bytes - 1) // rec_bytes
+    if args.long_reads:
+        pass
+    elif lo == i0 * rec_bytes:
         ctx.generate_synthetic_device(total_reads, args.read_len, 33, 73, "generic", shard.data_ptr(),
                                       shard.numel(), first=i0, count=min(i1, total_reads) - i0)
     else:
@@ -161,7 +184,7 @@ def main():
         global_records, global_bytes = args.reads, n
     elif not sharded_mode:
         assert recs == args.reads and res.status == L.EOF, (recs, res.status, ctx.format_error())
-        assert int(res.seq_bytes) == args.read_len * recs == int(res.qual_bytes)
+        assert int(res.seq_bytes) == int(res.qual_bytes) and (args.long_reads or int(res.seq_bytes) == args.read_len * recs)
         global_records, global_bytes = recs, n
     else:
         assert totals[0] == total_reads and first_err == sharded.NO_ERROR, (totals, first_err)
@@ -173,9 +196,10 @@ def main():
     if rank == 0:
         steps = args.steps
         sec_per_step = elapsed / steps
-        id_len = rec_bytes - 2 * args.read_len - 6
-        A = rec_bytes + 2 * args.read_len + id_len + 16   # algorithmic bytes per record
+        # algorithmic bytes of this rank's launch: input once + the three columns + ends/id_ends
+        A_total = n + int(res.seq_bytes) + int(res.qual_bytes) + int(res.id_bytes) + 16 * recs
         per_rank_records = recs
+        A = A_total / max(1, recs)
         emit_s = ms_emit / steps / 1e3
         path_s = ms_kernels / steps / 1e3
         out = {
@@ -187,35 +211,38 @@ def main():
             "ms_per_step": round(sec_per_step * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.read_len} bp Illumina FASTQ, {args.reads} reads/GPU "
-                                   f"({rec_bytes} B/record), batches(4096), validation "
-                                   f"{'ascii+quality (sanger)' if args.validate else 'off'}, input resident in HBM",
+            "config": {"workload": (f"synthetic long reads 200..19800 bases (BASELINE config 4), {args.reads} reads/GPU "
+                                    f"(mean {rec_bytes} B/record), batches(4096), validation " if args.long_reads else
+                                    f"synthetic {args.read_len} bp Illumina FASTQ, {args.reads} reads/GPU "
+                                    f"({rec_bytes} B/record), batches(4096), validation ")
+                                   + f"{'ascii+quality (sanger)' if args.validate else 'off'}, input resident in HBM",
                        "records_per_gpu": args.reads, "record_bytes": rec_bytes, "batch_size": 4096,
-                       "parallelism": f"byte-range shards x{world}" if world > 1 else "single GPU",
+                       "parallelism": (f"{'record-aligned' if args.long_reads else 'byte-range'} shards x{world}"
+                                       if world > 1 else "single GPU"),
                        "pass_bytes": args.pass_bytes},
             "fraction_of_hbm_peak_input_rate": round(global_bytes / world / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {
                 "bound": "hbm", "kernel": "k_tile_emit" if args.kernels_v1 else ("k_single<look-back>" if args.hier else "k_single<service>" if args.service else ("k_fused<LB=true>" if args.single_pass else "k_fused<LB=false>")),
-                "achieved": round(A * per_rank_records / emit_s / 1e9, 2) if emit_s > 0 else None,
+                "achieved": round(A_total / emit_s / 1e9, 2) if emit_s > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(A * per_rank_records / emit_s / 1e9 / HBM_PEAK_GBS, 4) if emit_s > 0 else None,
+                "frac": round(A_total / emit_s / 1e9 / HBM_PEAK_GBS, 4) if emit_s > 0 else None,
                 # HBM bytes per launch from the PMC counters of the same command (rocprofv3, separate --pmc passes;
                 # FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md), committed under profiles/.
                 # Only quoted for the profiled configuration (150 bp, validation off, two-pass default).
                 "traffic": (round(MEASURED_TRAFFIC_B_PER_RECORD * per_rank_records / 1e9, 3)
-                            if (args.read_len == 150 and not args.validate and not args.single_pass and not args.service
+                            if (args.read_len == 150 and not args.long_reads and not args.validate and not args.single_pass and not args.service
                                 and not args.hier and not args.kernels_v1) else None),
                 "traffic_unit": "GB per launch",
                 "traffic_source": "profiles/r1_final2_summary.txt: k_fused FETCH_SIZE*2 + WRITE_SIZE",
-                "algorithmic_gb_per_launch": round(A * per_rank_records / 1e9, 3),
-                "algorithmic_bytes_per_record": A,
+                "algorithmic_gb_per_launch": round(A_total / 1e9, 3),
+                "algorithmic_bytes_per_record": round(A, 1),
                 "avg_launch_ms": round(ms_emit / steps / max(1, int(res.n_passes)), 4),
                 "launches_per_step": int(res.n_passes),
             },
             "roofline_path": {
                 "note": "whole hot path (aggregate + scan + emit + rebase kernels), hipEvent time on the ctx stream",
-                "achieved": round(A * per_rank_records / path_s / 1e9, 2) if path_s > 0 else None,
-                "frac": round(A * per_rank_records / path_s / 1e9 / HBM_PEAK_GBS, 4) if path_s > 0 else None,
+                "achieved": round(A_total / path_s / 1e9, 2) if path_s > 0 else None,
+                "frac": round(A_total / path_s / 1e9 / HBM_PEAK_GBS, 4) if path_s > 0 else None,
                 "ms": {"aggregate": round(ms_agg / steps, 4), "scan": round(ms_scan / steps, 4),
                        "emit": round(ms_emit / steps, 4), "rebase": round(ms_rebase / steps, 4),
                        "kernels_total": round(ms_kernels / steps, 4)},

@@ -116,6 +116,9 @@ SYMBOLS = {
     "bzq_generate_synthetic_device": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                                   C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_uint64,
                                                   C.POINTER(C.c_uint64)]),
+    "bzq_generate_synthetic_device_var": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                                      C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_uint64,
+                                                      C.POINTER(C.c_uint64)]),
     "bzq_ingest_open": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
     "bzq_ingest_next": (C.c_int32, [C.c_void_p, C.c_uint64, C.POINTER(BzqChunk), C.POINTER(C.c_uint64)]),
     "bzq_ingest_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(BzqIngestStats)]),

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <numeric>
 #include <string>
 #include <vector>
 
@@ -74,7 +75,7 @@ struct bzq_ctx {
     DevBuf in, seq, qual, id;
     DevBuf ends, id_ends, rec_end, b_ends, b_id_ends, off[4], view_e, view_i;
     int64_t rec_cap = 0;
-    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch;
+    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, gen_prefix;
     int64_t tile_cap = 0;
     ChunkState* d_state = nullptr;
     ChunkState* h_state = nullptr; // pinned
@@ -550,7 +551,7 @@ void bzq_destroy(bzq_ctx* c) {
     DevBuf* bufs[] = {&c->in, &c->seq, &c->qual, &c->id, &c->ends, &c->id_ends, &c->rec_end, &c->b_ends,
                       &c->b_id_ends, &c->off[0], &c->off[1], &c->off[2], &c->off[3], &c->view_e, &c->view_i,
                       &c->tile_c, &c->tile_a,
-                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc, &c->consumer_scratch};
+                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc, &c->consumer_scratch, &c->gen_prefix};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->d_state) hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
@@ -1009,27 +1010,55 @@ int32_t bzq_submit_shard(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t
     return rc;
 }
 
-int32_t bzq_generate_synthetic_device(bzq_ctx* c, int64_t num_reads, int64_t first, int64_t count, int32_t read_len,
-                                      int32_t min_phred, int32_t max_phred, const char* schema, uint8_t* d_out,
-                                      uint64_t cap, uint64_t* out_bytes) {
-    if (!c || num_reads <= 0 || first < 0 || count < 0 || first + count > num_reads || read_len < 0 ||
+int32_t bzq_generate_synthetic_device_var(bzq_ctx* c, int64_t num_reads, int64_t first, int64_t count, int32_t min_len,
+                                          int32_t max_len, int32_t min_phred, int32_t max_phred, const char* schema,
+                                          uint8_t* d_out, uint64_t cap, uint64_t* out_bytes) {
+    if (!c || num_reads <= 0 || first < 0 || count < 0 || first + count > num_reads || min_len < 0 || max_len < min_len ||
         min_phred < 0 || max_phred < min_phred)
         return BZQ_ERR_ARG;
     int nd = 1;
     if (num_reads > 1) nd = (int)std::to_string(num_reads - 1).size(); // utils.mojo:880-882
-    const uint64_t rec_bytes = 6 + (uint64_t)nd + 1 + 2 * ((uint64_t)read_len + 1) + 2;
-    const uint64_t total = rec_bytes * (uint64_t)count;
+    const int64_t fixed = 6 + nd + 1 + 2 + 2;
+    const int64_t range = (int64_t)max_len - min_len + 1;
+    // lengths min_len + ((31 i + 7) mod range) repeat with period range / gcd(31, range): prefix sums of one period
+    int64_t period = 1;
+    std::vector<int64_t> prefix;
+    uint64_t total;
+    if (range > 1) {
+        period = range / std::gcd<int64_t>(31, range);
+        prefix.resize((size_t)period + 1);
+        prefix[0] = 0;
+        for (int64_t r = 0; r < period; ++r) prefix[(size_t)r + 1] = prefix[(size_t)r] + min_len + (int64_t)(((uint64_t)r * 31u + 7u) % (uint64_t)range);
+        auto sum_to = [&](int64_t i) { return (i / period) * prefix[(size_t)period] + prefix[(size_t)(i % period)]; };
+        total = (uint64_t)(count * fixed + 2 * (sum_to(first + count) - sum_to(first)));
+    } else {
+        total = (uint64_t)((fixed + 2 * (int64_t)min_len) * count);
+    }
     if (out_bytes) *out_bytes = total;
     if (!d_out) return 0;
     if (cap < total) { c->err = "bzq_generate_synthetic_device: output buffer too small"; return BZQ_ERR_ARG; }
     uint8_t lo, up, off;
     (void)bzq_schema_from_name(schema ? schema : "generic", &lo, &up, &off);
     HIPCHK(c, hipSetDevice(c->device));
-    GenArgs g{d_out, first, count, num_reads, read_len, nd, min_phred, max_phred, off, lo, up};
+    int64_t* d_prefix = nullptr;
+    if (range > 1) {
+        int rc;
+        if ((rc = ensure(c, c->gen_prefix, prefix.size() * 8))) return rc;
+        d_prefix = (int64_t*)c->gen_prefix.p;
+        HIPCHK(c, hipMemcpyAsync(d_prefix, prefix.data(), prefix.size() * 8, hipMemcpyHostToDevice, c->stream));
+    }
+    GenArgs g{d_out, first, count, num_reads, min_len, nd, min_phred, max_phred, off, lo, up, range, period, d_prefix};
     if (count > 0)
         hipLaunchKernelGGL(k_generate, dim3((unsigned)((count + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, g);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // `prefix` must outlive the copy
     return 0;
+}
+
+int32_t bzq_generate_synthetic_device(bzq_ctx* c, int64_t num_reads, int64_t first, int64_t count, int32_t read_len,
+                                      int32_t min_phred, int32_t max_phred, const char* schema, uint8_t* d_out,
+                                      uint64_t cap, uint64_t* out_bytes) {
+    return bzq_generate_synthetic_device_var(c, num_reads, first, count, read_len, read_len, min_phred, max_phred, schema,
+                                             d_out, cap, out_bytes);
 }
 
 // ---- host ingest pipeline (bzq_ingest.hpp) ---------------------------------------------------------------------

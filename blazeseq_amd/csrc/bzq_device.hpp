@@ -1056,16 +1056,32 @@ __global__ void k_head(const uint8_t* __restrict__ g, int64_t n, uint32_t prev_b
 struct GenArgs {
     uint8_t* out;
     int64_t first, count, num_reads;
-    int32_t read_len, num_digits, min_phred, max_phred;
+    int32_t read_len, num_digits, min_phred, max_phred;   // read_len = min_len
     uint32_t q_offset, q_lower, q_upper;
+    int64_t len_range;           // max_len - min_len + 1 (1 = fixed length)
+    int64_t period;              // lengths repeat every `period` records
+    const int64_t* len_prefix;   // [period + 1] prefix sums of one period's lengths (device)
 };
 
 __global__ __launch_bounds__(BLOCK) void k_generate(GenArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= a.count) return;
     const int64_t i = a.first + idx;
-    const int64_t rec_bytes = 6 + a.num_digits + 1 + 2 * ((int64_t)a.read_len + 1) + 2;
-    uint8_t* o = a.out + idx * rec_bytes;
+    // read length and record offset (utils.mojo:753-757): lengths repeat with period `period`, len_prefix[r] is the
+    // sum of the first r lengths of one period
+    int64_t L = a.read_len, off;
+    const int64_t fixed = 6 + a.num_digits + 1 + 2 + 2;    // "@read_" digits '\n' ... '\n' "+\n" ... '\n'
+    if (a.len_range > 1) {
+        L = a.read_len + (int64_t)(((u64)i * 31ull + 7ull) % (u64)a.len_range);
+        const int64_t q = i / a.period, r = i - q * a.period;
+        const int64_t q0 = a.first / a.period, r0 = a.first - q0 * a.period;
+        const int64_t sum_i = q * a.len_prefix[a.period] + a.len_prefix[r];
+        const int64_t sum_0 = q0 * a.len_prefix[a.period] + a.len_prefix[r0];
+        off = idx * fixed + 2 * (sum_i - sum_0);
+    } else {
+        off = idx * (fixed + 2 * L);
+    }
+    uint8_t* o = a.out + off;
     const uint8_t lut[8] = {'G', 'C', 'G', 'C', 'A', 'T', 'A', 'T'}; // gc_bias = 0.5, utils.mojo:707-733
     *o++ = '@'; *o++ = 'r'; *o++ = 'e'; *o++ = 'a'; *o++ = 'd'; *o++ = '_';
     {
@@ -1076,15 +1092,15 @@ __global__ __launch_bounds__(BLOCK) void k_generate(GenArgs a) {
     *o++ = '\n';
     const u64 MASK = 0x7FFFFFFFFFFFFFFFull;
     u64 st = ((u64)i * 6364136223846793005ull + 1442695040888963407ull) & MASK;
-    for (int b = 0; b < a.read_len; ++b) {
+    for (int64_t b = 0; b < L; ++b) {
         st = (st * 6364136223846793005ull + 1442695040888963407ull) & MASK;
         *o++ = lut[(st >> 33) & 7];
     }
     *o++ = '\n'; *o++ = '+'; *o++ = '\n';
     const int64_t q_start = a.max_phred, q_range = a.max_phred - a.min_phred, noise_amp = q_range / 6 + 1;
     u64 qr = ((u64)i * 2654435761ull + 1013904223ull) & MASK;
-    const int64_t lm1 = a.read_len - 1;
-    for (int64_t p = 0; p < a.read_len; ++p) {
+    const int64_t lm1 = L - 1;
+    for (int64_t p = 0; p < L; ++p) {
         const int64_t mean = lm1 == 0 ? q_start : q_start - (q_range * p + lm1 / 2) / lm1;
         qr = (qr * 1664525ull + 1013904223ull) & MASK;
         const int64_t noise = (int64_t)((qr >> 17) % (u64)(2 * noise_amp + 1));

@@ -206,14 +206,17 @@ class Context:
 
     def generate_synthetic_device(self, num_reads: int, read_len: int, min_phred: int, max_phred: int,
                                   schema: str, d_out: int = 0, cap: int = 0, first: int = 0,
-                                  count: Optional[int] = None) -> int:
+                                  count: Optional[int] = None, max_len: Optional[int] = None) -> int:
+        """Bytes of records [first, first+count) of the reference generator's num_reads-record file; written to
+        d_out when given.  ``max_len`` > ``read_len``: variable read lengths (utils.mojo:753-757)."""
         if count is None:
             count = num_reads - first
         nb = C.c_uint64()
-        _check(self.h, L.lib().bzq_generate_synthetic_device(self.h, num_reads, first, count, read_len, min_phred,
-                                                            max_phred, schema.encode(),
-                                                            C.c_void_p(d_out) if d_out else None, cap, C.byref(nb)),
-               "bzq_generate_synthetic_device")
+        _check(self.h, L.lib().bzq_generate_synthetic_device_var(self.h, num_reads, first, count, read_len,
+                                                                read_len if max_len is None else max_len, min_phred,
+                                                                max_phred, schema.encode(),
+                                                                C.c_void_p(d_out) if d_out else None, cap, C.byref(nb)),
+               "bzq_generate_synthetic_device_var")
         return nb.value
 
     def shard_scan(self, d_ptr: int, n: int) -> L.BzqShardSummary:

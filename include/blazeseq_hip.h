@@ -289,6 +289,11 @@ int32_t bzq_column_histogram(bzq_ctx* ctx, const uint8_t* d_col, uint64_t n, uin
 int32_t bzq_generate_synthetic_device(bzq_ctx* ctx, int64_t num_reads, int64_t first, int64_t count,
                                       int32_t read_len, int32_t min_phred, int32_t max_phred,
                                       const char* schema, uint8_t* d_out, uint64_t cap, uint64_t* out_bytes);
+/* The same with read lengths min_len + ((31 i + 7) mod (max_len - min_len + 1)) (utils.mojo:753-757): BASELINE
+ * config 4, long reads of 200..19800 bases. */
+int32_t bzq_generate_synthetic_device_var(bzq_ctx* ctx, int64_t num_reads, int64_t first, int64_t count,
+                                          int32_t min_len, int32_t max_len, int32_t min_phred, int32_t max_phred,
+                                          const char* schema, uint8_t* d_out, uint64_t cap, uint64_t* out_bytes);
 
 #ifdef __cplusplus
 }

@@ -144,6 +144,19 @@ def test_device_generator_matches_oracle():
         assert ctx.generate_synthetic_device(nreads, L, lo, hi, sch, t.data_ptr(), nb) == nb
         ref = O.generate_synthetic(nreads, L, L, lo, hi, sch)
         np.testing.assert_array_equal(t[:nb].cpu().numpy(), ref)
+    # variable read lengths (config 4 style), whole file and record sub-ranges
+    for (nreads, lo_len, hi_len, lo, hi, sch) in ((500, 5, 12, 33, 73, "generic"), (700, 200, 1300, 5, 30, "sanger"), (64, 0, 31, 0, 40, "sanger")):
+        ref = O.generate_synthetic(nreads, lo_len, hi_len, lo, hi, sch)
+        nb = ctx.generate_synthetic_device(nreads, lo_len, lo, hi, sch, max_len=hi_len)
+        assert nb == ref.size
+        t = torch.empty(nb + 16, dtype=torch.uint8, device="cuda")
+        ctx.generate_synthetic_device(nreads, lo_len, lo, hi, sch, t.data_ptr(), nb, max_len=hi_len)
+        np.testing.assert_array_equal(t[:nb].cpu().numpy(), ref)
+        first, count = nreads // 3, nreads // 2
+        before = ctx.generate_synthetic_device(nreads, lo_len, lo, hi, sch, count=first, max_len=hi_len)
+        part = ctx.generate_synthetic_device(nreads, lo_len, lo, hi, sch, first=first, count=count, max_len=hi_len)
+        ctx.generate_synthetic_device(nreads, lo_len, lo, hi, sch, t.data_ptr(), nb, first=first, count=count, max_len=hi_len)
+        np.testing.assert_array_equal(t[:part].cpu().numpy(), ref[before:before + part])
     ctx.close()
 
 
