@@ -11,7 +11,7 @@ exchange is tiny and latency bound:
      bytes up to the end of the straddling record (``head``) are sent to rank r, which appends them
      behind its own bytes (``halo``)                             -> one send/recv per neighbour pair
   3. every rank parses [its bytes + halo] with ``bzq_submit_shard``; counts and the first failing
-     record are reduced                                           -> two small all_reduce
+     record come from one more all_gather of 4 x int64 per rank
 
 No bulk data ever crosses xGMI.  The collectives go through ``torch.distributed`` (backend "nccl" is
 RCCL on ROCm; the same code runs over "gloo" on CPU tensors, which is how the protocol is tested
@@ -82,12 +82,8 @@ def plan_shards(summaries: Sequence[Sequence[int]]) -> List[ShardPlan]:
 
 
 def gather_summaries(local: Sequence[int], device, group=None) -> List[List[int]]:
-    """all_gather of the 8-word shard summaries."""
-    world = dist.get_world_size(group)
-    mine = torch.tensor(list(local), dtype=torch.int64, device=device)
-    out = [torch.empty(SUMMARY_WORDS, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(out, mine, group=group)
-    return [t.cpu().tolist() for t in out]
+    """all_gather of the 8-word shard summaries: one collective into a [world, 8] tensor, one copy to the host."""
+    return _gather_rows(local, device, group)
 
 
 def exchange_halo(shard: torch.Tensor, n: int, plan: ShardPlan, group=None) -> None:
@@ -105,22 +101,40 @@ def exchange_halo(shard: torch.Tensor, n: int, plan: ShardPlan, group=None) -> N
             w.wait()
 
 
+def _gather_rows(row: Sequence[int], device, group=None) -> List[List[int]]:
+    """One all_gather_into_tensor of a few int64 per rank and one copy to the host."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor(list(row), dtype=torch.int64, device=device)
+    out = torch.empty(world * len(row), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(out, mine, group=group)
+    return out.cpu().view(world, len(row)).tolist()
+
+
 def reduce_counts(records: int, bases: int, nbytes: int, first_error_global: int, device, group=None):
-    """Global totals (sum) and the first failing record over all ranks (min; 2^62 = none)."""
-    t = torch.tensor([records, bases, nbytes], dtype=torch.int64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    e = torch.tensor([first_error_global], dtype=torch.int64, device=device)
-    dist.all_reduce(e, op=dist.ReduceOp.MIN, group=group)
-    return [int(x) for x in t.cpu().tolist()], int(e.item())
+    """Global totals (sum) and the first failing record over all ranks (min of the global indices; 2^62 = none)."""
+    rows = _gather_rows([records, bases, nbytes, first_error_global], device, group)
+    return [sum(r[k] for r in rows) for k in range(3)], min(r[3] for r in rows)
+
+
+def gather_outcomes(records: int, bases: int, nbytes: int, first_error_local: int, device, group=None):
+    """One all_gather of (records, bases, bytes, first failing LOCAL record or -1) per rank and one copy to the host;
+    everything global is derived from it: totals, this rank's records_before (the global index of its record 0) and
+    the first failing record over all ranks as a global index (NO_ERROR = none)."""
+    rank = dist.get_rank(group)
+    rows = _gather_rows([records, bases, nbytes, first_error_local], device, group)
+    totals = [sum(r[k] for r in rows) for k in range(3)]
+    before, first_err, acc = 0, NO_ERROR, 0
+    for q, r in enumerate(rows):
+        if q == rank:
+            before = acc
+        if r[3] >= 0 and first_err == NO_ERROR:
+            first_err = acc + r[3]
+        acc += r[0]
+    return totals, first_err, before
 
 
 def records_before(n_records: int, device, group=None) -> int:
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    mine = torch.tensor([n_records], dtype=torch.int64, device=device)
-    out = [torch.empty(1, dtype=torch.int64, device=device) for _ in range(world)]
-    dist.all_gather(out, mine, group=group)
-    return int(sum(int(t.item()) for t in out[:rank]))
+    return gather_outcomes(n_records, 0, 0, -1, device, group)[2]
 
 
 NO_ERROR = 1 << 62
@@ -138,9 +152,7 @@ def parse_sharded(ctx, shard: torch.Tensor, n: int, stream_pos: int, group=None)
     is_last = all(summaries[q][0] == 0 for q in range(rank + 1, world))
     ctx.submit_shard(shard.data_ptr(), n, plan.halo_bytes, plan.lines_before, plan.prev_last_byte, stream_pos, is_last)
     res = ctx.result()
-    plan.records_before = records_before(int(res.n_records), shard.device, group)
-    err = NO_ERROR
-    if res.status not in (0, 6):
-        err = plan.records_before + int(res.error_record)
-    totals, first_err = reduce_counts(int(res.n_records), int(res.seq_bytes), n, err, shard.device, group)
+    err_local = int(res.error_record) if res.status not in (0, 6) else -1
+    totals, first_err, before = gather_outcomes(int(res.n_records), int(res.seq_bytes), n, err_local, shard.device, group)
+    plan.records_before = before
     return res, plan, totals, first_err

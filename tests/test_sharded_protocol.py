@@ -108,7 +108,11 @@ def _worker(rank, world, port, data_bytes, cuts, q):
     f = parse_shard(shard[:n + plan.halo_bytes].numpy(), plan, rank == world - 1, cfg)
     before = sharded.records_before(f.n_records, torch.device("cpu"))
     totals, first_err = sharded.reduce_counts(f.n_records, int(f.seq_bytes.size), n, sharded.NO_ERROR, torch.device("cpu"))
-    q.put((rank, f.n_records, before, totals, first_err, f.id_bytes.tobytes()))
+    # the one-collective form used by parse_sharded: same totals / offsets; a (pretend) failing local record 5 on the
+    # last rank comes out as a global index
+    t2, e2, b2 = sharded.gather_outcomes(f.n_records, int(f.seq_bytes.size), n, 5 if rank == world - 1 else -1, torch.device("cpu"))
+    assert t2 == totals and b2 == before and (rank != world - 1 or e2 == before + 5)
+    q.put((rank, f.n_records, before, totals, (first_err, e2), f.id_bytes.tobytes()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -133,5 +137,5 @@ def test_two_rank_gloo_exchange():
     (r0, n0, b0, tot0, e0, id0), (r1, n1, b1, tot1, e1, id1) = got
     assert n0 + n1 == whole.n_records and b0 == 0 and b1 == n0
     assert tot0 == tot1 == [whole.n_records, int(whole.seq_bytes.size), len(data)]
-    assert e0 == e1 == sharded.NO_ERROR
+    assert e0 == e1 == (sharded.NO_ERROR, n0 + 5)
     assert id0 + id1 == whole.id_bytes.tobytes()
