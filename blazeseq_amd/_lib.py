@@ -123,6 +123,8 @@ SYMBOLS = {
     "bzq_ingest_next": (C.c_int32, [C.c_void_p, C.c_uint64, C.POINTER(BzqChunk), C.POINTER(C.c_uint64)]),
     "bzq_ingest_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(BzqIngestStats)]),
     "bzq_ingest_close": (None, [C.c_void_p]),
+    "bzq_upload_batch": (C.c_int32, [C.c_void_p, C.POINTER(BzqHostBatch), C.POINTER(BzqDeviceBatch)]),
+    "bzq_release_batch": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch)]),
     "bzq_batch_nw_scores": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.c_char_p, C.c_int32, C.c_void_p]),
     "bzq_batch_quality_sums": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.c_void_p]),
     "bzq_column_histogram": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),

@@ -1190,6 +1190,55 @@ int32_t bzq_ingest_get_stats(const bzq_ingest* g, bzq_ingest_stats* out) {
 
 void bzq_ingest_close(bzq_ingest* g) { bzq::ingest_free(g); }
 
+// ---- upload of a host FastqBatch (record_batch.mojo:308-411) ---------------------------------------------------
+
+// The reference's upload_batch_to_device: 5 pinned allocations, 5 memcpys, 5 device allocations, 5 H2D copies and 3
+// synchronize() per batch.  Here: ONE device allocation holding the five arrays (each 16-byte aligned), five async
+// copies on the ctx stream, one synchronize.  Only needed for a batch that outlived its chunk (while the chunk is
+// live, bzq_batch_view is zero-copy); the caller owns the result and frees it with bzq_release_batch.
+int32_t bzq_upload_batch(bzq_ctx* c, const bzq_host_batch* h, bzq_device_batch* out) {
+    if (!c || !h || !out || h->num_records < 0) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    memset(out, 0, sizeof(*out));
+    out->quality_offset = h->quality_offset;
+    const int64_t n = h->num_records;
+    if (n == 0) return 0;
+    if (!h->ends || !h->id_ends) return BZQ_ERR_ARG;
+    const int64_t seq_len = h->ends[n - 1], id_len = h->id_ends[n - 1];   // inclusive running sums (Q11)
+    if (seq_len < 0 || id_len < 0 || (seq_len && (!h->quality_bytes || !h->sequence_bytes)) || (id_len && !h->id_bytes)) return BZQ_ERR_ARG;
+    auto up16 = [](int64_t v) { return (size_t)((v + 15) & ~(int64_t)15); };
+    const size_t o_q = 0, o_s = o_q + up16(seq_len), o_i = o_s + up16(seq_len), o_e = o_i + up16(id_len), o_ie = o_e + up16(n * 8),
+                 total = o_ie + up16(n * 8);
+    uint8_t* d = nullptr;
+    hipError_t e = hipMalloc((void**)&d, total);
+    if (e != hipSuccess) { c->err = std::string("bzq_upload_batch: hipMalloc: ") + hipGetErrorString(e); return BZQ_ERR_NOMEM; }
+    bool ok = true;
+    auto cp = [&](size_t off, const void* src, size_t bytes) {
+        if (bytes && hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) ok = false;
+    };
+    cp(o_q, h->quality_bytes, (size_t)seq_len); cp(o_s, h->sequence_bytes, (size_t)seq_len); cp(o_i, h->id_bytes, (size_t)id_len);
+    cp(o_e, h->ends, (size_t)n * 8); cp(o_ie, h->id_ends, (size_t)n * 8);
+    if (!ok || hipStreamSynchronize(c->stream) != hipSuccess) {
+        (void)hipFree(d);
+        c->err = "bzq_upload_batch: host to device copy failed";
+        return BZQ_ERR_HIP;
+    }
+    out->num_records = n; out->seq_len = seq_len; out->total_id_bytes = id_len;
+    out->qual_buffer = d + o_q; out->sequence_buffer = d + o_s; out->id_buffer = d + o_i;
+    out->ends = (const int64_t*)(d + o_e); out->id_ends = (const int64_t*)(d + o_ie);
+    out->first_record = ~0ull;   // not a view of the chunk
+    return 0;
+}
+
+int32_t bzq_release_batch(bzq_ctx* c, bzq_device_batch* b) {
+    if (!c || !b) return BZQ_ERR_ARG;
+    if (b->first_record != ~0ull) { c->err = "bzq_release_batch: not an uploaded batch (views of the chunk are owned by the ctx)"; return BZQ_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    if (b->qual_buffer) HIPCHK(c, hipFree((void*)b->qual_buffer));
+    memset(b, 0, sizeof(*b));
+    return 0;
+}
+
 // ---- device-side consumers of a DeviceFastqBatch (bzq_consumers.hpp) --------------------------------------------
 
 int32_t bzq_batch_nw_scores(bzq_ctx* c, const bzq_device_batch* b, const uint8_t* ref, int32_t ref_len, int32_t* d_scores) {

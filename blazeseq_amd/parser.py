@@ -246,9 +246,10 @@ class DeviceFastqBatch:
     """blazeseq/fastq/record_batch.mojo:210-220: five device buffers + four scalars.  The buffers are
     device pointers (ints) into the parser's chunk columns."""
 
-    def __init__(self, ctx: Context, raw: L.BzqDeviceBatch):
+    def __init__(self, ctx: Context, raw: L.BzqDeviceBatch, owned: bool = False):
         self._ctx = ctx
         self.raw = raw
+        self._owned = owned   # uploaded with bzq_upload_batch: this object frees the device memory
         self.num_records = raw.num_records
         self.seq_len = raw.seq_len
         self.quality_offset = raw.quality_offset
@@ -261,7 +262,21 @@ class DeviceFastqBatch:
 
     def copy_to_host(self) -> "FastqBatch":
         """record_batch.mojo:222-244"""
-        return FastqBatch(self._ctx, self.raw)
+        b = FastqBatch(self._ctx, self.raw)
+        if self._owned:
+            b._detach()   # the host copy must not depend on this object's lifetime
+        return b
+
+    def release(self):
+        if self._owned and getattr(self._ctx, "h", None):
+            L.lib().bzq_release_batch(self._ctx.h, C.byref(self.raw))
+        self._owned = False
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
     def to_records(self) -> List[FastqRecord]:
         return self.copy_to_host().to_records()
@@ -340,11 +355,19 @@ class FastqBatch:
     def __repr__(self): return f"FastqBatch(records={self.num_records()}, quality_offset={self._quality_offset})"
 
     def to_device(self, ctx=None) -> DeviceFastqBatch:
-        """record_batch.mojo:89-90.  The columns already live on the device: zero copy.  Valid until
-        the parser refills (call it inside the ``for batch in parser.batches()`` body)."""
+        """record_batch.mojo:89-90.  While the batch's chunk is live the columns already sit on the device: zero copy,
+        valid until the parser refills.  A batch kept past a refill owns a host copy and is uploaded."""
         if not self._device_valid:
-            raise RuntimeError("FastqBatch.to_device(): the parser has moved past this batch's chunk; "
-                               "call to_device() before advancing the parser")
+            # the parser has moved past this batch's chunk: upload the owned host copy (what the reference always does)
+            i, q, s, ie, e = self._fetch()
+            hb = L.BzqHostBatch()
+            hb.num_records = self.num_records()
+            hb.quality_bytes = q.ctypes.data; hb.sequence_bytes = s.ctypes.data; hb.id_bytes = i.ctypes.data
+            hb.ends = e.ctypes.data; hb.id_ends = ie.ctypes.data
+            hb.quality_offset = self._quality_offset
+            out = L.BzqDeviceBatch()
+            _check(self._ctx.h, L.lib().bzq_upload_batch(self._ctx.h, C.byref(hb), C.byref(out)), "bzq_upload_batch")
+            return DeviceFastqBatch(self._ctx, out, owned=True)
         return DeviceFastqBatch(self._ctx, self._raw)
 
     def get_record(self, index: int) -> FastqRecord:

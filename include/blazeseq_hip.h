@@ -267,6 +267,13 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
 int32_t bzq_ingest_get_stats(const bzq_ingest* g, bzq_ingest_stats* out);
 void bzq_ingest_close(bzq_ingest* g);
 
+/* FastqBatch.to_device() for a batch that OUTLIVED its chunk (record_batch.mojo:89-90, upload_batch_to_device
+ * 404-411: 10 allocations, 10 copies and 3 synchronize() per batch in the reference): one device allocation, five
+ * asynchronous copies, one synchronize.  While the chunk is live use bzq_batch_view (zero copy) instead.  The result
+ * is owned by the caller: release it with bzq_release_batch (first_record == UINT64_MAX marks an uploaded batch). */
+int32_t bzq_upload_batch(bzq_ctx* ctx, const bzq_host_batch* h, bzq_device_batch* out);
+int32_t bzq_release_batch(bzq_ctx* ctx, bzq_device_batch* b);
+
 /* ---- device-side consumers of a DeviceFastqBatch ------------------------ */
 
 /* The nw_gpu example on the device batch (examples/nw_gpu/kernels.mojo:21-89, execution.mojo:96-140): global

@@ -240,6 +240,16 @@ def test_streaming_chunks_equal_one_shot():
             assert g._ends.tolist() == r.ends and g._id_ends.tolist() == r.id_ends
             assert g._sequence_bytes.tobytes() == r.seq_bytes and g._quality_bytes.tobytes() == r.qual_bytes
             assert g._id_bytes.tobytes() == r.id_bytes
+        # a batch kept past the refill owns a host copy; to_device() uploads it (bzq_upload_batch), like the
+        # reference's FastqBatch.to_device always does (record_batch.mojo:89-90, 404-411)
+        for g, r in list(zip(got, ref))[:: max(1, len(ref) // 5)]:
+            d = g.to_device()
+            assert d.num_records == len(r) and d.seq_len == r.ends[-1] and d.total_id_bytes == r.id_ends[-1]
+            back = d.copy_to_host()
+            assert back._sequence_bytes.tobytes() == r.seq_bytes and back._quality_bytes.tobytes() == r.qual_bytes
+            assert back._id_bytes.tobytes() == r.id_bytes and back._ends.tolist() == r.ends and back._id_ends.tolist() == r.id_ends
+            assert int(d.histogram("sequence").sum()) == r.ends[-1]   # consumers run on an uploaded batch too
+            d.release()
         # streaming use: to_device() inside the loop is a zero-copy view of the live chunk
         n = 0
         for g, r in zip(B.FastqParser(data, batch_size=1000, chunk_bytes=chunk).batches(), ref):
