@@ -14,7 +14,7 @@ BENCH="python bench.py --no-cpu-baseline $*"
 (timeout 400 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM -d $OUT/pmc_sq2 -o $TAG -- $BENCH --steps 2 --warmup 1) > $OUT/pmc_sq2.log 2>&1; echo "pmc_sq2 rc=$?"
 (timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc_fetch -o $TAG -- $BENCH --steps 2 --warmup 1) > $OUT/pmc_fetch.log 2>&1; echo "pmc_fetch rc=$?"
 (timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/pmc_write -o $TAG -- $BENCH --steps 2 --warmup 1) > $OUT/pmc_write.log 2>&1; echo "pmc_write rc=$?"
-tail -1 $OUT/kt.log > $OUT/bench_line_under_profiler.json
+grep "^{\"metric\"" $OUT/kt.log | tail -1 > $OUT/bench_line_under_profiler.json
 find $OUT -type f -size +8M -delete
 python scripts/summarize_prof.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
