@@ -140,13 +140,6 @@ __device__ inline Cols lookback_cols(const u64* desc_agg, const u64* desc_pre, i
     }
 }
 
-__device__ __forceinline__ uint32_t bytes_from_mask(int i, int x) {
-    // mask of the bytes of dword i (piece bytes 4i..4i+3) at piece offset >= x
-    int lo = x - 4 * i;
-    lo = lo < 0 ? 0 : lo;
-    return lo >= 4 ? 0u : (0xFFFFFFFFu << (8 * lo));
-}
-
 template <int ROLE, bool CA, bool CQ>
 __device__ __forceinline__ void validate_window(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int a, int b,
                                                 int64_t rec, uint32_t qlo, uint32_t qhi, ErrAcc& err) {
@@ -165,81 +158,6 @@ __device__ __forceinline__ void validate_window(uint32_t w0, uint32_t w1, uint32
             err.valid(rec, 5);
     }
 }
-
-// Same contract as gather_role (bzq_device.hpp), restructured: the piece's first window is read
-// unconditionally; only lanes whose piece crosses into further segments run the merge loop.
-template <int ROLE, bool CA, bool CQ>
-__device__ __forceinline__ void gather_role2(uint8_t* __restrict__ col, int64_t D, int n_role, const uint16_t* seg_src,
-                                             const uint16_t* seg_len, const uint16_t* seg_dst, const uint8_t* seg_blk, int nk,
-                                             const uint8_t* s_tile, int64_t line0, uint32_t qlo, uint32_t qhi, ErrAcc& err) {
-    if (n_role <= 0) return;
-    const int tid = threadIdx.x;
-    const int64_t hi_abs = D + n_role;
-    const int64_t pa = D >> 4, pb = (hi_abs - 1) >> 4;
-    const uint32_t* tw = reinterpret_cast<const uint32_t*>(s_tile - 16);
-    for (int64_t pi = pa + tid; pi <= pb; pi += BLOCK) {
-        const int64_t p0 = pi << 4;
-        if (p0 + 16 <= 0) continue;
-        int xl = (int)(D > p0 ? D - p0 : 0);
-        const int xh = (int)(hi_abs - p0 < 16 ? hi_abs - p0 : 16);
-        if (p0 < 0 && xl < (int)(-p0)) xl = (int)(-p0);
-        int o = (int)(p0 - D) + xl;
-        // segment holding stream byte o: coarse index (segment at the start of o's 256-byte block), then
-        // a short forward walk; tiles with many tiny segments fall back to a binary search
-        int k = (int)seg_blk[o >> 8];
-        {
-            int steps = 0;
-            while (k + 1 < nk && (int)seg_dst[k + 1] <= o) {
-                ++k;
-                if (++steps == 6) {
-                    int lo = k + 1, hi = nk;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if ((int)seg_dst[mid] <= o) lo = mid + 1; else hi = mid;
-                    }
-                    k = lo - 1;
-                    break;
-                }
-            }
-        }
-        const int dk = (int)seg_dst[k], lk = (int)seg_len[k];
-        int take = dk + lk - o;
-        if (take > xh - xl) take = xh - xl;
-        uint32_t a0, a1, a2, a3;
-        {
-            const int ws = (int)seg_src[k] + (o - dk) - xl + 16;
-            const int wd = ws >> 2, sh = ws & 3;
-            const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
-            a0 = __builtin_amdgcn_alignbyte(d1, d0, sh); a1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-            a2 = __builtin_amdgcn_alignbyte(d3, d2, sh); a3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-        }
-        validate_window<ROLE, CA, CQ>(a0, a1, a2, a3, xl, xl + take, (line0 + 4 * (int64_t)k) >> 2, qlo, qhi, err);
-        int x = xl + take;
-        while (x < xh) { // the piece continues in the next non-empty segment(s)
-            do { ++k; } while (seg_len[k] == 0);
-            int tk = (int)seg_len[k];
-            if (tk > xh - x) tk = xh - x;
-            const int ws = (int)seg_src[k] - x + 16;
-            const int wd = ws >> 2, sh = ws & 3;
-            const uint32_t d0 = tw[wd], d1 = tw[wd + 1], d2 = tw[wd + 2], d3 = tw[wd + 3], d4 = tw[wd + 4];
-            const uint32_t b0 = __builtin_amdgcn_alignbyte(d1, d0, sh), b1 = __builtin_amdgcn_alignbyte(d2, d1, sh),
-                           b2 = __builtin_amdgcn_alignbyte(d3, d2, sh), b3 = __builtin_amdgcn_alignbyte(d4, d3, sh);
-            const uint32_t m0 = bytes_from_mask(0, x), m1 = bytes_from_mask(1, x), m2 = bytes_from_mask(2, x),
-                           m3 = bytes_from_mask(3, x);
-            a0 = (b0 & m0) | (a0 & ~m0); a1 = (b1 & m1) | (a1 & ~m1);
-            a2 = (b2 & m2) | (a2 & ~m2); a3 = (b3 & m3) | (a3 & ~m3);
-            validate_window<ROLE, CA, CQ>(b0, b1, b2, b3, x, x + tk, (line0 + 4 * (int64_t)k) >> 2, qlo, qhi, err);
-            x += tk;
-        }
-        if (xl == 0 && xh == 16) {
-            *reinterpret_cast<uint4*>(col + p0) = make_uint4(a0, a1, a2, a3);
-        } else {
-            const uint32_t acc[4] = {a0, a1, a2, a3};
-            for (int i = xl; i < xh; ++i) col[p0 + i] = (uint8_t)(acc[i >> 2] >> (8 * (i & 3)));
-        }
-    }
-}
-
 
 // ---- source-driven scatter --------------------------------------------------------------------
 // gfx950 handles byte-unaligned vector accesses in hardware (one global_store_dwordx4 for an
