@@ -1261,8 +1261,13 @@ int32_t bzq_batch_quality_sums(bzq_ctx* c, const bzq_device_batch* b, int64_t* d
     HIPCHK(c, hipSetDevice(c->device));
     const int64_t n = b->num_records;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_quality_sums, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, c->stream,
-                       b->qual_buffer, b->ends, n, (int)b->quality_offset, d_sums);
+    // short reads: a workgroup per 256 records (coalesced span + LDS accumulators); long reads: a wave per record
+    if (b->seq_len / n < 1024)
+        hipLaunchKernelGGL(k_quality_sums_block, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream,
+                           b->qual_buffer, b->ends, n, b->seq_len, (int)b->quality_offset, d_sums);
+    else
+        hipLaunchKernelGGL(k_quality_sums, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, c->stream,
+                           b->qual_buffer, b->ends, n, b->seq_len, (int)b->quality_offset, d_sums);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->err = std::string("k_quality_sums: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
     return 0;

@@ -17,12 +17,19 @@ namespace bzq {
 
 constexpr int NW_MAX_LEN = 256;   // MAX_REF_LEN / MAX_QUERY_LEN, examples/nw_gpu/kernels.mojo:15-16
 
+// Inclusive prefix maximum over the wave on DPP (row_shr 1/2/4/8 inside rows of 16, then row_bcast:15 / :31 across
+// rows), the max-analogue of dpp_scan_u32: lanes without a source keep the identity INT_MIN.
 __device__ __forceinline__ int wave_prefix_max(int v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(v, off, 64);
-        if (lane >= off) v = o > v ? o : v;
-    }
+    (void)lane;
+    constexpr int ID = (int)0x80000000;
+#define BZQ_DPP_MAX(ctrl, rm)                                                           \
+    do {                                                                                \
+        const int o_ = __builtin_amdgcn_update_dpp(ID, v, ctrl, rm, 0xf, false);        \
+        v = o_ > v ? o_ : v;                                                            \
+    } while (0)
+    BZQ_DPP_MAX(0x111, 0xf); BZQ_DPP_MAX(0x112, 0xf); BZQ_DPP_MAX(0x114, 0xf); BZQ_DPP_MAX(0x118, 0xf);
+    BZQ_DPP_MAX(0x142, 0xa); BZQ_DPP_MAX(0x143, 0xc);
+#undef BZQ_DPP_MAX
     return v;
 }
 
@@ -59,8 +66,7 @@ __global__ __launch_bounds__(BLOCK) void k_nw_scores(const uint8_t* __restrict__
         for (int s = 0; s < 4; ++s) {
             if (s < nseg) {
                 const int i = 64 * s + lane + 1;
-                int diag = __shfl_up(prev[s], 1, 64);
-                if (lane == 0) diag = left_edge;
+                int diag = __builtin_amdgcn_update_dpp(left_edge, prev[s], 0x138, 0xf, 0xf, false);   // wave_shr:1, lane 0 keeps left_edge
                 left_edge = __builtin_amdgcn_readlane(prev[s], 63);
                 const int m0 = diag + (rb[s] == qb ? 1 : -1);
                 const int m1 = prev[s] - 1;                       // deletion: dp[j-1][i] + gap
@@ -83,25 +89,108 @@ __global__ __launch_bounds__(BLOCK) void k_nw_scores(const uint8_t* __restrict__
     if (lane == 0) scores[rec] = out;
 }
 
-// One wave per record: sum over the record's quality bytes of (byte - offset), as int64.
+// Sum of the bytes of four dwords (v_sad_u8 against zero: four bytes per instruction).
+__device__ __forceinline__ uint32_t sum_bytes16(uint4 v, uint32_t acc) {
+    acc = __builtin_amdgcn_sad_u8(v.x, 0u, acc);
+    acc = __builtin_amdgcn_sad_u8(v.y, 0u, acc);
+    acc = __builtin_amdgcn_sad_u8(v.z, 0u, acc);
+    return __builtin_amdgcn_sad_u8(v.w, 0u, acc);
+}
+// 16 bytes at col[p..] where only bytes below col_len may be touched (the batch may end exactly at an allocation's end)
+__device__ __forceinline__ uint4 load16_tail(const uint8_t* __restrict__ col, int64_t p, int64_t col_len) {
+    if (p + 16 <= col_len) return load16_any(col + p);
+    u64 lo = 0, hi = 0;
+#pragma unroll 1
+    for (int i = 0; p + i < col_len && i < 16; ++i) {
+        const u64 b = col[p + i];
+        if (i < 8) lo |= b << (8 * i); else hi |= b << (8 * (i - 8));
+    }
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
+// keep the first k bytes (0..16) of a 16-byte value
+__device__ __forceinline__ uint4 keep_first(uint4 v, int k) {
+    const u64 lo = (u64)v.x | ((u64)v.y << 32), hi = (u64)v.z | ((u64)v.w << 32);
+    const u64 ml = k >= 8 ? ~0ull : ((1ull << (8 * k)) - 1ull);
+    const u64 mh = k >= 16 ? ~0ull : (k > 8 ? ((1ull << (8 * (k - 8))) - 1ull) : 0ull);
+    const u64 l = lo & ml, h = hi & mh;
+    return make_uint4((uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32));
+}
+
+// Per-record sum of (quality byte - offset).  SHORT reads: one workgroup per 256 consecutive records.  Their bytes are
+// one contiguous span of the column, read fully coalesced (16 bytes per lane per step); each 16-byte piece finds its
+// record by a binary search over the 257 record boundaries kept in LDS, is split where it straddles boundaries, and is
+// added to that record's LDS accumulator (v_sad_u8 sums four bytes per instruction).  A thread-per-record version with
+// the same loads ran at 1.07 TB/s: neighbouring lanes are a record (150 B) apart, so every line was fetched ~8 times.
+__global__ __launch_bounds__(BLOCK) void k_quality_sums_block(const uint8_t* __restrict__ qual, const int64_t* __restrict__ ends,
+                                                               int64_t num_records, int64_t col_len, int offset,
+                                                               int64_t* __restrict__ sums) {
+    __shared__ int64_t s_e[BLOCK + 1];   // s_e[k] = start of record r0 + k
+    __shared__ u64 s_sum[BLOCK];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * BLOCK;
+    const int nrec = (int)((num_records - r0) < BLOCK ? (num_records - r0) : BLOCK);
+    if (tid < nrec) s_e[tid] = (r0 + tid) ? ends[r0 + tid - 1] : 0;
+    if (tid == 0) s_e[nrec] = ends[r0 + nrec - 1];   // 257 boundaries, 256 threads
+    s_sum[tid] = 0;
+    __syncthreads();
+    const int64_t b0 = s_e[0], b1 = s_e[nrec];
+    // pieces are aligned to 16 bytes of the COLUMN (not of the span) so that loads are aligned whenever the column is
+    for (int64_t p = (b0 & ~(int64_t)15) + 16 * tid; p < b1; p += 16 * BLOCK) {
+        uint4 v = load16_tail(qual, p < 0 ? 0 : p, col_len);
+        int64_t lo = p < b0 ? b0 : p;                        // first byte of this piece inside the span
+        const int64_t hi = p + 16 < b1 ? p + 16 : b1;        // one past its last byte inside the span
+        // record containing byte lo: largest k with s_e[k] <= lo (records may be empty: take the LAST such k)
+        int k = 0;
+        for (int step = BLOCK / 2; step > 0; step >>= 1)
+            if (k + step <= nrec - 1 && s_e[k + step] <= lo) k += step;
+        while (lo < hi) {
+            while (s_e[k + 1] <= lo) ++k;                    // skip empty records
+            const int64_t e = s_e[k + 1] < hi ? s_e[k + 1] : hi;
+            // bytes [lo, e) of the piece: drop (lo - p) leading bytes, keep (e - lo)
+            const int drop = (int)(lo - p), keep = (int)(e - lo);
+            const u64 vlo = (u64)v.x | ((u64)v.y << 32), vhi = (u64)v.z | ((u64)v.w << 32);
+            u64 slo, shi;
+            if (drop == 0) { slo = vlo; shi = vhi; }
+            else if (drop < 8) { slo = (vlo >> (8 * drop)) | (vhi << (64 - 8 * drop)); shi = vhi >> (8 * drop); }
+            else { slo = vhi >> (8 * (drop - 8)); shi = 0; }
+            const uint4 part = keep_first(make_uint4((uint32_t)slo, (uint32_t)(slo >> 32), (uint32_t)shi, (uint32_t)(shi >> 32)), keep);
+            atomicAdd(&s_sum[k], (u64)sum_bytes16(part, 0u));
+            lo = e;
+        }
+    }
+    __syncthreads();
+    if (tid < nrec) sums[r0 + tid] = (int64_t)s_sum[tid] - (int64_t)offset * (s_e[tid + 1] - s_e[tid]);
+}
+
+// LONG reads: one wave per record, 16 bytes per lane per step (1 KiB per wave instruction).
 __global__ __launch_bounds__(BLOCK) void k_quality_sums(const uint8_t* __restrict__ qual, const int64_t* __restrict__ ends,
-                                                         int64_t num_records, int offset, int64_t* __restrict__ sums) {
+                                                         int64_t num_records, int64_t col_len, int offset, int64_t* __restrict__ sums) {
     const int lane = threadIdx.x & 63;
     const int64_t rec = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
     if (rec >= num_records) return;
     const int64_t q0 = rec ? ends[rec - 1] : 0, q1 = ends[rec];
-    int64_t acc = 0;
-    for (int64_t p = q0 + lane; p < q1; p += 64) acc += (int64_t)qual[p] - offset;
-    const u64 tot = wave_sum_u64((u64)acc);
-    if (lane == 0) sums[rec] = (int64_t)tot;
+    int64_t acc64 = 0;
+    uint32_t acc = 0;
+    int steps = 0;
+    for (int64_t p = q0 + 16 * lane; p < q1; p += 1024) {
+        const uint4 v = load16_tail(qual, p, col_len);
+        acc = sum_bytes16(p + 16 <= q1 ? v : keep_first(v, (int)(q1 - p)), acc);
+        if (++steps == (1 << 19)) { acc64 += acc; acc = 0; steps = 0; }
+    }
+    acc64 += acc;
+    const u64 tot = wave_sum_u64((u64)acc64);
+    if (lane == 0) sums[rec] = (int64_t)tot - (int64_t)offset * (q1 - q0);
 }
 
-// hist[256] += byte counts of col[0, n).  Grid-stride, 16 bytes per lane per step; one LDS histogram per wave.
+// hist[256] += byte counts of col[0, n).  Grid-stride, 16 bytes per lane per step.  LDS histograms: one per wave AND
+// per lane-residue mod 8 (a 5-letter alphabet would otherwise pile 64 lanes onto 5 addresses); bank = bin + replica.
+constexpr int HIST_REP = 8;
 __global__ __launch_bounds__(BLOCK) void k_byte_histogram(const uint8_t* __restrict__ col, int64_t n, u64* __restrict__ hist) {
-    __shared__ uint32_t s_h[BLOCK / 64][256];
-    const int tid = threadIdx.x, wave = tid >> 6;
-    for (int i = tid; i < (BLOCK / 64) * 256; i += BLOCK) (&s_h[0][0])[i] = 0u;
+    __shared__ uint32_t s_h[BLOCK / 64][HIST_REP][256 + 1];   // +1: replicas of one bin land in different banks
+    const int tid = threadIdx.x, wave = tid >> 6, rep = tid & (HIST_REP - 1);
+    for (int i = tid; i < (BLOCK / 64) * HIST_REP * 257; i += BLOCK) (&s_h[0][0][0])[i] = 0u;
     __syncthreads();
+    uint32_t* h = &s_h[wave][rep][0];
     const int64_t stride = (int64_t)gridDim.x * BLOCK * 16;
     for (int64_t base = ((int64_t)blockIdx.x * BLOCK + tid) * 16; base < n; base += stride) {
         if (base + 16 <= n) {
@@ -109,19 +198,21 @@ __global__ __launch_bounds__(BLOCK) void k_byte_histogram(const uint8_t* __restr
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                atomicAdd(&s_h[wave][w[k] & 0xFFu], 1u);
-                atomicAdd(&s_h[wave][(w[k] >> 8) & 0xFFu], 1u);
-                atomicAdd(&s_h[wave][(w[k] >> 16) & 0xFFu], 1u);
-                atomicAdd(&s_h[wave][w[k] >> 24], 1u);
+                atomicAdd(&h[w[k] & 0xFFu], 1u);
+                atomicAdd(&h[(w[k] >> 8) & 0xFFu], 1u);
+                atomicAdd(&h[(w[k] >> 16) & 0xFFu], 1u);
+                atomicAdd(&h[w[k] >> 24], 1u);
             }
         } else {
-            for (int64_t p = base; p < n; ++p) atomicAdd(&s_h[wave][col[p]], 1u);
+            for (int64_t p = base; p < n; ++p) atomicAdd(&h[col[p]], 1u);
         }
     }
     __syncthreads();
     uint32_t t = 0;
 #pragma unroll
-    for (int w = 0; w < BLOCK / 64; ++w) t += s_h[w][tid];
+    for (int w = 0; w < BLOCK / 64; ++w)
+#pragma unroll
+        for (int r = 0; r < HIST_REP; ++r) t += s_h[w][r][tid];
     if (t) atomicAdd(&hist[tid], (u64)t);
 }
 
