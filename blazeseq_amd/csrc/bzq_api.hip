@@ -1094,6 +1094,24 @@ int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int3
         bzq::ingest_free(g);
         return BZQ_ERR_NOMEM;
     }
+    // compressed input?  gzip magic 1f 8b; BGZF if the first member carries the 'BC' extra subfield
+    uint8_t magic[18] = {0};
+    if (g->file_size >= 18 && pread(fd, magic, 18, 0) == 18 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        if (bzq::bgzf_block_size(magic)) {
+            g->compression = 2;
+        } else {
+            g->compression = 1;
+            const int fd2 = dup(fd);
+            g->gz = fd2 >= 0 ? gzdopen(fd2, "rb") : nullptr;
+            if (!g->gz) {
+                if (fd2 >= 0) close(fd2);
+                c->err = std::string("bzq_ingest_open: gzdopen failed for ") + path;
+                bzq::ingest_free(g);
+                return BZQ_ERR_IO;
+            }
+            (void)gzbuffer(g->gz, 1u << 20);
+        }
+    }
     g->producer = std::thread(bzq::ingest_producer, g);
     *out = g;
     return 0;

@@ -17,6 +17,7 @@
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 namespace bzq {
 
@@ -37,6 +38,11 @@ struct bzq_ingest {
     int fd = -1;
     uint64_t file_size = 0, chunk_bytes = 0, reserve = 0;
     int n_threads = 4;
+    // compressed input (the reference's GZFile / RapidgzipReader, io/readers.mojo:283-443): 0 plain, 1 gzip stream
+    // (zlib gzread, serial), 2 BGZF (blocked gzip: blocks inflate independently on the reader threads)
+    int compression = 0;
+    gzFile gz = nullptr;
+    uint64_t bgzf_off = 0;         // compressed offset of the next BGZF block
     bzq::IngestSlot slot[2];
     hipStream_t copy_stream = nullptr;
     hipEvent_t dev_free[2] = {nullptr, nullptr}; // recorded on the ctx stream once slot i's device buffer may be overwritten
@@ -88,9 +94,102 @@ inline bool parallel_pread(int fd, uint8_t* dst, uint64_t off, uint64_t len, int
     return ok;
 }
 
+// ---- compressed sources --------------------------------------------------------------------------------------------
+
+// BGZF block header (SAM spec 4.1): gzip member with FEXTRA and a 'B','C' subfield holding BSIZE = block size - 1.
+// Returns the block size, 0 if the 18 bytes at p are not such a header.
+inline uint32_t bgzf_block_size(const uint8_t* p) {
+    if (p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    if (p[10] != 6 || p[11] != 0 || p[12] != 'B' || p[13] != 'C' || p[14] != 2 || p[15] != 0) return 0;
+    return (uint32_t)(p[16] | (p[17] << 8)) + 1u;
+}
+
+struct BgzfBlock { uint64_t coff; uint32_t csize, usize; uint64_t uoff; };
+
+// Inflate a run of BGZF blocks (already read into `comp`) into dst with n_threads workers.
+inline bool bgzf_inflate_blocks(const std::vector<BgzfBlock>& blocks, const uint8_t* comp, uint64_t comp_base, uint8_t* dst,
+                                int n_threads, std::string& err) {
+    std::atomic<size_t> next{0};
+    std::atomic<bool> ok{true};
+    auto work = [&]() {
+        z_stream zs;
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= blocks.size() || !ok) return;
+            const BgzfBlock& b = blocks[i];
+            if (b.usize == 0) continue;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { ok = false; return; }
+            zs.next_in = const_cast<Bytef*>(comp + (b.coff - comp_base) + 18);
+            zs.avail_in = b.csize - 18 - 8;
+            zs.next_out = dst + b.uoff;
+            zs.avail_out = b.usize;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.avail_out != 0) { ok = false; return; }
+        }
+    };
+    std::vector<std::thread> th;
+    const int nt = (int)std::min<size_t>((size_t)std::max(1, n_threads), blocks.size());
+    for (int i = 1; i < nt; ++i) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    if (!ok) err = "BGZF block failed to inflate (corrupt or truncated file)";
+    return ok;
+}
+
+// Next chunk of DECOMPRESSED bytes into dst (capacity cap).  Returns false on error; *eof when the input is exhausted.
+inline bool read_compressed_chunk(bzq_ingest* g, uint8_t* dst, uint64_t cap, uint64_t* out_len, bool* eof, std::string& err) {
+    *out_len = 0; *eof = false;
+    if (g->compression == 1) {
+        uint64_t got = 0;
+        while (got < cap) {
+            const int r = gzread(g->gz, dst + got, (unsigned)std::min<uint64_t>(cap - got, 1u << 30));
+            if (r < 0) { int en = 0; err = std::string("gzread: ") + gzerror(g->gz, &en); return false; }
+            if (r == 0) {
+                // a truncated or corrupt stream ends "cleanly" for gzread; gzerror tells (Z_BUF_ERROR: unexpected EOF)
+                int en = Z_OK;
+                const char* msg = gzerror(g->gz, &en);
+                if (en != Z_OK && en != Z_STREAM_END) { err = std::string("gzread: ") + (msg ? msg : "stream error"); return false; }
+                *eof = true;
+                break;
+            }
+            got += (uint64_t)r;
+        }
+        *out_len = got;
+        return true;
+    }
+    // BGZF: collect whole blocks until the chunk is full
+    std::vector<BgzfBlock> blocks;
+    uint64_t usum = 0, coff = g->bgzf_off;
+    uint8_t hdr[18], tail[4];
+    while (coff < g->file_size) {
+        if (coff + 28 > g->file_size || pread(g->fd, hdr, 18, (off_t)coff) != 18) { err = "BGZF: truncated block header"; return false; }
+        const uint32_t bs = bgzf_block_size(hdr);
+        if (!bs || bs < 26 || coff + bs > g->file_size) { err = "BGZF: bad block header"; return false; }
+        if (pread(g->fd, tail, 4, (off_t)(coff + bs - 4)) != 4) { err = "BGZF: truncated block"; return false; }
+        const uint32_t us = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+        if (us > 65536) { err = "BGZF: block claims more than 64 KiB"; return false; }
+        if (usum + us > cap) break;
+        blocks.push_back({coff, bs, us, usum});
+        usum += us;
+        coff += bs;
+    }
+    if (!blocks.empty()) {
+        const uint64_t c0 = blocks.front().coff, c1 = blocks.back().coff + blocks.back().csize;
+        std::vector<uint8_t> comp((size_t)(c1 - c0));
+        if (!parallel_pread(g->fd, comp.data(), c0, c1 - c0, g->n_threads, err)) return false;
+        if (!bgzf_inflate_blocks(blocks, comp.data(), c0, dst, g->n_threads, err)) return false;
+    }
+    g->bgzf_off = coff;
+    *out_len = usum;
+    *eof = coff >= g->file_size;
+    return true;
+}
+
 inline void ingest_producer(bzq_ingest* g) {
     (void)hipSetDevice(g->device);
-    uint64_t off = 0;
+    uint64_t off = 0;   // offset in the (decompressed) stream
     for (int64_t k = 0;; ++k) {
         IngestSlot& s = g->slot[k & 1];
         // the pinned buffer of this slot was last used by chunk k-2: its H2D must have finished
@@ -99,10 +198,18 @@ inline void ingest_producer(bzq_ingest* g) {
             std::unique_lock<std::mutex> lk(g->mu);
             if (g->stop) return;
         }
-        const uint64_t len = std::min<uint64_t>(g->chunk_bytes, g->file_size - off);
+        uint64_t len = 0;
+        bool eof = false, ok;
         const auto t0 = std::chrono::steady_clock::now();
         std::string err;
-        if (!parallel_pread(g->fd, s.pinned + g->reserve, off, len, g->n_threads, err)) {
+        if (g->compression == 0) {
+            len = std::min<uint64_t>(g->chunk_bytes, g->file_size - off);
+            ok = parallel_pread(g->fd, s.pinned + g->reserve, off, len, g->n_threads, err);
+            eof = off + len >= g->file_size;
+        } else {
+            ok = read_compressed_chunk(g, s.pinned + g->reserve, g->chunk_bytes, &len, &eof, err);
+        }
+        if (!ok) {
             std::unique_lock<std::mutex> lk(g->mu);
             g->io_error = err; g->stop = true; g->cv.notify_all();
             return;
@@ -119,7 +226,7 @@ inline void ingest_producer(bzq_ingest* g) {
         }
         if (len) (void)hipMemcpyAsync(s.dev + g->reserve, s.pinned + g->reserve, len, hipMemcpyHostToDevice, g->copy_stream);
         (void)hipEventRecord(s.h2d_done, g->copy_stream);
-        s.file_off = off; s.len = len; s.eof = (off + len >= g->file_size);
+        s.file_off = off; s.len = len; s.eof = eof;
         off += len;
         {
             std::unique_lock<std::mutex> lk(g->mu);
@@ -146,6 +253,7 @@ inline void ingest_free(bzq_ingest* g) {
         if (g->slot[i].h2d_done) (void)hipEventDestroy(g->slot[i].h2d_done);
         if (g->dev_free[i]) (void)hipEventDestroy(g->dev_free[i]);
     }
+    if (g->gz) gzclose(g->gz);
     if (g->fd >= 0) close(g->fd);
     delete g;
 }

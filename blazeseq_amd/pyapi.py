@@ -4,8 +4,8 @@ records expose ``id / sequence / quality`` as ``str`` plus ``phred_scores`` and 
 ``num_records() / get_record(i)`` and iterate over records (pinned by the reference's
 tests/test_python_bindings.py, replayed in tests/test_gpu_pyapi.py).
 
-Everything below is plumbing over ``FastqParser`` (GPU chunks through the C ABI); gzip input is a decompression problem
-and out of scope."""
+Everything below is plumbing over ``FastqParser`` (GPU chunks through the C ABI); .gz files are inflated by the ingest
+pipeline's reader threads (zlib; block-parallel for BGZF)."""
 from __future__ import annotations
 
 import os
@@ -156,9 +156,7 @@ class PyParser:
 def parser(path: str, quality_schema: str = "generic", parallelism: int = 4) -> PyParser:
     """python/blazeseq/__init__.py:267-290.  ``parallelism`` is the number of ingest reader threads here (the
     reference uses it for gzip decompression threads)."""
-    p = os.fspath(path)
-    if p.endswith((".gz", ".bgz")):
-        raise NotImplementedError("gzip input is out of scope for the HIP path (DESIGN.md §9): decompress first")
+    p = os.fspath(path)   # plain, gzip and BGZF files all go through the native ingest pipeline
     return PyParser(FastqParser(p, schema=quality_schema, reader_threads=max(1, int(parallelism))))
 
 

@@ -59,3 +59,44 @@ for chunk in args.chunk_mib:
         print(f"chunk {chunk} MiB, {th} reader threads: {best[0]:.1f} GB/s end to end ({best[1]*1e3:.0f} ms; reader busy {best[2]*1e3:.0f} ms, "
               f"consumer waiting {best[3]*1e3:.0f} ms, open {best[4]*1e3:.0f} ms)", flush=True)
 os.remove(path)
+
+# ---- compressed input: gzip stream (zlib gzread, serial) and BGZF (block-parallel inflate) ---------------------------
+if os.environ.get("BZQ_BENCH_COMPRESSED"):
+    import struct, zlib, gzip
+    reads = 3_000_000
+    ctx2 = B.Context(B.ParserConfig(), "generic", 4096, 0)
+    rec = ctx2.generate_synthetic_device(reads, 150, 33, 73, "generic", count=1)
+    n2 = rec * reads
+    buf = torch.empty(n2 + 64, dtype=torch.uint8, device="cuda")
+    ctx2.generate_synthetic_device(reads, 150, 33, 73, "generic", buf.data_ptr(), buf.numel(), first=0, count=reads)
+    raw = buf[:n2].cpu().numpy().tobytes()
+    del buf
+    t0 = time.perf_counter()
+    gz_path = os.path.join(args.dir, "bzq_ingest_bench.fastq.gz")
+    with open(gz_path, "wb") as f:
+        f.write(gzip.compress(raw, 1))
+    blocks = []
+    for i in list(range(0, len(raw), 65280)) + [None]:
+        chunk = b"" if i is None else raw[i:i + 65280]
+        c = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        blocks.append(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(body) + 8 - 1)
+                      + body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    bg_path = os.path.join(args.dir, "bzq_ingest_bench.fastq.bgz")
+    with open(bg_path, "wb") as f:
+        f.write(b"".join(blocks))
+    print(f"compressed {n2/1e9:.2f} GB twice in {time.perf_counter()-t0:.1f} s: gzip {os.path.getsize(gz_path)/1e9:.2f} GB, BGZF {os.path.getsize(bg_path)/1e9:.2f} GB", flush=True)
+    for name, path, threads in (("gzip (one zlib stream)", gz_path, [1]), ("BGZF", bg_path, [1, 8, 32, 64])):
+        for th in threads:
+            t1 = time.perf_counter()
+            ing = B.Ingest(ctx2, path, chunk_bytes=64 << 20, n_threads=th)
+            taken, total = 0, 0
+            while True:
+                res = ing.next(taken)
+                taken = int(res.n_records); total += taken
+                if int(res.status) != L.OK: break
+            dt = time.perf_counter() - t1
+            ing.close()
+            assert total == reads
+            print(f"{name}, {th} inflate threads: {n2/dt/1e9:.2f} GB/s of FASTQ ({dt*1e3:.0f} ms)", flush=True)
+    os.remove(gz_path); os.remove(bg_path)

@@ -135,3 +135,57 @@ def test_ingest_empty_and_missing_files(tmp_path):
     assert list(B.FastqParser(str(empty)).batches()) == []
     with pytest.raises(RuntimeError, match="cannot open"):
         B.Ingest(ctx, str(tmp_path / "nope.fastq"))
+
+
+# ---- compressed input (the reference's GZFile / RapidgzipReader, io/readers.mojo:283-443) -------------------------
+
+def _bgzf(data: bytes, block: int = 65280) -> bytes:
+    """BGZF writer (SAM spec 4.1): independent gzip members with a 'BC' extra subfield + the empty EOF block."""
+    import struct
+    import zlib
+    out = []
+    for i in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if i is None else data[i:i + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        bsize = 18 + len(body) + 8 - 1
+        out.append(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize)
+                   + body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("kind", ["gzip", "gzip_multi_member", "bgzf"])
+def test_compressed_files_parse_like_the_plain_file(kind, tmp_path):
+    import gzip
+    import blazeseq_amd as B
+    data = bytes(O.generate_synthetic(20_000, 50, 150, 0, 40, "sanger"))
+    if kind == "gzip":
+        comp = gzip.compress(data, 1)
+    elif kind == "gzip_multi_member":
+        cut = len(data) // 3 + 11   # members split in the middle of a record
+        comp = gzip.compress(data[:cut], 1) + gzip.compress(data[cut:2 * cut], 6) + gzip.compress(data[2 * cut:], 1)
+    else:
+        comp = _bgzf(data)
+    path = tmp_path / ("reads.fastq.gz")
+    path.write_bytes(comp)
+    ref = [b for b in O.StreamParser(np.frombuffer(data, dtype=np.uint8), O.make_config(batch_size=1000)).batches()]
+    for chunk in (1 << 16, 1 << 20, 1 << 28):
+        p = B.FastqParser(str(path), batch_size=1000, chunk_bytes=chunk, reader_threads=3)
+        got = list(p.batches())
+        assert [len(b) for b in got] == [len(b) for b in ref]
+        for g, r in zip(got, ref):
+            assert g._sequence_bytes.tobytes() == r.seq_bytes and g._quality_bytes.tobytes() == r.qual_bytes
+            assert g._id_bytes.tobytes() == r.id_bytes and g._ends.tolist() == r.ends
+    # the reference's Python surface accepts .gz paths (python/blazeseq/__init__.py:267-290)
+    assert sum(1 for _ in B.parser(str(path)).records) == 20_000
+
+
+def test_truncated_gzip_is_a_runtime_error_not_a_parse_result(tmp_path):
+    import gzip
+    import blazeseq_amd as B
+    data = bytes(O.generate_synthetic(5_000, 100, 100, 0, 40, "sanger"))
+    for comp in (gzip.compress(data, 1), _bgzf(data)):
+        path = tmp_path / "cut.fastq.gz"
+        path.write_bytes(comp[: len(comp) // 2])
+        with pytest.raises(RuntimeError, match="gzread|BGZF"):
+            list(B.FastqParser(str(path), batch_size=1000).batches())
