@@ -715,14 +715,14 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
                                    (int64_t*)c->ends.p, (int64_t*)c->id_ends.p, (int64_t*)c->rec_end.p,
                                    (int64_t*)c->b_ends.p, (int64_t*)c->b_id_ends.p, (const ChunkState*)c->d_state);
                 HIPCHK(c, hipStreamSynchronize(c->stream));
-                n_records = n_complete + 1;
-                consumed = n;
                 if (h->err_valid != ~0ull && key_rec(h->err_valid) == n_complete) {
+                    // ... and fails it: the record is not delivered, the stream stops behind the last complete one
                     r.status = (int)(h->err_valid & 7);
                     r.error_record = n_complete;
-                    n_records = n_complete;
                 } else {
                     r.status = BZQ_EOF;
+                    n_records = n_complete + 1;
+                    consumed = n;
                 }
             } else {
                 r.status = code;
@@ -741,10 +741,9 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
                                (int64_t*)c->b_ends.p, (int64_t*)c->b_id_ends.p, (const ChunkState*)c->d_state);
             HIPCHK(c, hipStreamSynchronize(c->stream));
             accept_last = true;
-            n_records = n_complete + 1; consumed = n;
             if (h->err_valid != ~0ull && key_rec(h->err_valid) == n_complete) {
-                r.status = (int)(h->err_valid & 7); r.error_record = n_complete; n_records = n_complete;
-            } else r.status = BZQ_EOF;
+                r.status = (int)(h->err_valid & 7); r.error_record = n_complete;
+            } else { r.status = BZQ_EOF; n_records = n_complete + 1; consumed = n; }
         } else if (tail_phase == 3) { r.status = BZQ_OTHER; r.error_record = n_complete; }
         else { r.status = BZQ_UNEXPECTED_EOF; r.error_record = n_complete; c->term_phase = tail_phase; }
     }

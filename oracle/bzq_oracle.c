@@ -694,6 +694,26 @@ int orc_flat_parse(const uint8_t* data, int64_t n, const orc_config* cfg, int is
         if (!is_eof) {
             if (k < 4) break; /* incomplete tail: carried over by the caller */
             record_end = nlp[3];
+            /* chunk mode has no window to replay, but the refusal of a record that cannot fit the reader's buffer does
+             * not depend on where the window sits (parser.mojo:484-492: a record longer than the capacity -- or, with
+             * growth, than buffer_max_capacity -- never completes), so it is reported here exactly like at EOF */
+            {
+                const int64_t rlen = record_end - head + 1;
+                if (!cfg->buffer_growth_enabled && rlen > cfg->buffer_capacity) {
+                    f->term_code = ORC_BUFFER_EXCEEDED;
+                    format_refill_error(f->term_msg, sizeof f->term_msg, ORC_BUFFER_EXCEEDED, 0, cfg->buffer_capacity,
+                                        cfg->buffer_max_capacity);
+                    f->term_record = f->n_records;
+                    break;
+                }
+                if (cfg->buffer_growth_enabled && rlen > cfg->buffer_max_capacity) {
+                    f->term_code = ORC_BUFFER_AT_MAX;
+                    format_refill_error(f->term_msg, sizeof f->term_msg, ORC_BUFFER_AT_MAX, 0, cfg->buffer_max_capacity,
+                                        cfg->buffer_max_capacity);
+                    f->term_record = f->n_records;
+                    break;
+                }
+            }
         } else {
             int complete = (k == 4 && nlp[3] < s.end);
             if (!complete) {

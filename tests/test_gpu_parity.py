@@ -106,6 +106,17 @@ def test_every_byte_value_is_classified_exactly(single_pass):
     assert f.n_records == 300
 
 
+def test_unterminated_last_record_that_fails_validation_is_not_consumed():
+    """Found by tests/fuzz_campaign.py (seed 8002): the last record has no trailing newline (accepted, Q4) but its
+    quality is out of range for the schema -- it must not be delivered and bytes_consumed stops before it."""
+    data = b"@Tq_\nAGCGN\n+\n?hxj{\n@zbg\nNNAGAGGNACT\n+zbg\n8x+;@W4-)6z"
+    for sp in (False, True):
+        ctx, ocfg = make_pair(batch_size=7, single_pass=sp, check_ascii=True, check_quality=True, quality_schema="solexa")
+        res, f = check_against_oracle(ctx, ocfg, data, what="unterminated + invalid")
+        assert f.n_records == 1 and f.term_code == 5 and f.consumed == 19 and int(res.bytes_consumed) == 19
+        ctx.close()
+
+
 def test_space_runs_across_tile_edges():
     """Header lines made of spaces that straddle tile boundaries: every id byte dropped exactly once."""
     rng = np.random.default_rng(7)
