@@ -61,6 +61,7 @@ class BzqDeviceBatch(C.Structure):
         ("qual_buffer", C.c_void_p), ("sequence_buffer", C.c_void_p), ("ends", C.c_void_p),
         ("id_buffer", C.c_void_p), ("id_ends", C.c_void_p),
         ("first_record", C.c_uint64),
+        ("sequence_bytes", C.c_int64),
     ]
 
 

@@ -822,6 +822,9 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
     out->num_records = (int64_t)nrec;
     out->seq_len = last[0] - base[0];
     out->total_id_bytes = last[1] - base[1];
+    // the sequence column runs in step with the quality column (equal lengths are checked per record) except through
+    // an accepted unterminated last record: a batch that reaches the chunk's last record ends where the column ends
+    out->sequence_bytes = (first_record + nrec == c->res.n_records ? (int64_t)c->res.seq_bytes : last[0]) - base[0];
     out->qual_buffer = c->res.d_qual + base[0];
     out->sequence_buffer = c->res.d_seq + base[0];
     out->id_buffer = c->res.d_id + base[1];
@@ -848,7 +851,7 @@ int32_t bzq_batch_to_host(bzq_ctx* c, const bzq_device_batch* b, bzq_host_batch*
     out->quality_offset = b->quality_offset;
     if (b->num_records == 0) return 0;
     HIPCHK(c, hipMemcpy(out->quality_bytes, b->qual_buffer, (size_t)b->seq_len, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(out->sequence_bytes, b->sequence_buffer, (size_t)b->seq_len, hipMemcpyDeviceToHost));
+    if (b->sequence_bytes > 0) HIPCHK(c, hipMemcpy(out->sequence_bytes, b->sequence_buffer, (size_t)b->sequence_bytes, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(out->id_bytes, b->id_buffer, (size_t)b->total_id_bytes, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(out->ends, b->ends, (size_t)b->num_records * 8, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(out->id_ends, b->id_ends, (size_t)b->num_records * 8, hipMemcpyDeviceToHost));
@@ -1240,7 +1243,7 @@ int32_t bzq_upload_batch(bzq_ctx* c, const bzq_host_batch* h, bzq_device_batch* 
         c->err = "bzq_upload_batch: host to device copy failed";
         return BZQ_ERR_HIP;
     }
-    out->num_records = n; out->seq_len = seq_len; out->total_id_bytes = id_len;
+    out->num_records = n; out->seq_len = seq_len; out->total_id_bytes = id_len; out->sequence_bytes = seq_len;
     out->qual_buffer = d + o_q; out->sequence_buffer = d + o_s; out->id_buffer = d + o_i;
     out->ends = (const int64_t*)(d + o_e); out->id_ends = (const int64_t*)(d + o_ie);
     out->first_record = ~0ull;   // not a view of the chunk

@@ -326,7 +326,7 @@ class FastqBatch:
             r = self._raw
             n = int(r.num_records)
             q = np.empty(int(r.seq_len), dtype=np.uint8)
-            s = np.empty(int(r.seq_len), dtype=np.uint8)
+            s = np.empty(max(0, int(r.sequence_bytes)), dtype=np.uint8)   # == seq_len but for an odd unterminated last record
             i = np.empty(int(r.total_id_bytes), dtype=np.uint8)
             e = np.empty(n, dtype=np.int64)
             ie = np.empty(n, dtype=np.int64)

@@ -131,6 +131,10 @@ typedef struct bzq_device_batch {
     const uint8_t* id_buffer;
     const int64_t* id_ends;
     uint64_t first_record;     /* chunk-local index of record 0 of this batch */
+    int64_t sequence_bytes;    /* valid bytes in sequence_buffer.  == seq_len, except for the batch that holds an
+                                  unterminated last record whose sequence and quality lengths differ (no structure
+                                  check for it, parser.mojo:464-475): the reference's FastqBatch._sequence_bytes then
+                                  holds the true sequence bytes while _ends / seq_len follow the quality lengths */
 } bzq_device_batch;
 
 /* FastqBatch on the host (record_batch.mojo:19-41), filled by bzq_batch_to_host: the caller
@@ -138,7 +142,7 @@ typedef struct bzq_device_batch {
 typedef struct bzq_host_batch {
     int64_t num_records;
     uint8_t* quality_bytes;    /* seq_len bytes */
-    uint8_t* sequence_bytes;   /* seq_len bytes */
+    uint8_t* sequence_bytes;   /* bzq_device_batch.sequence_bytes bytes (== seq_len but for the case described there) */
     uint8_t* id_bytes;         /* total_id_bytes bytes */
     int64_t* ends;             /* num_records */
     int64_t* id_ends;          /* num_records */

@@ -52,8 +52,9 @@ int main(int argc, char** argv) {
             bzq_device_batch db;
             const uint32_t want = (uint32_t)((usable - first) < batch ? (usable - first) : batch);
             if ((rc = bzq_batch_view(ctx, first, want, &db)) < 0) die(ctx, "bzq_batch_view", rc);
-            if ((size_t)db.seq_len + 1 > cap_b || (size_t)db.total_id_bytes + 1 > cap_b) {
-                cap_b = (size_t)(db.seq_len > db.total_id_bytes ? db.seq_len : db.total_id_bytes) * 2 + 64;
+            const int64_t need = db.sequence_bytes > db.seq_len ? db.sequence_bytes : db.seq_len;
+            if ((size_t)need + 1 > cap_b || (size_t)db.total_id_bytes + 1 > cap_b) {
+                cap_b = (size_t)(need > db.total_id_bytes ? need : db.total_id_bytes) * 2 + 64;
                 q = realloc(q, cap_b); s = realloc(s, cap_b); id = realloc(id, cap_b);
             }
             if ((size_t)db.num_records > cap_r) {

@@ -26,11 +26,29 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert _lib.lib().bzq_abi_version() == 1
 
 
-def test_struct_sizes_match_header():
+def test_struct_sizes_match_header(tmp_path):
+    """sizeof and field offsets as the C compiler sees include/blazeseq_hip.h == the ctypes mirror in _lib.py."""
+    import subprocess
     from blazeseq_amd import _lib
-    assert ctypes.sizeof(_lib.BzqConfig) == 72
-    assert ctypes.sizeof(_lib.BzqDeviceBatch) == 80
-    assert ctypes.sizeof(_lib.BzqShardSummary) == 56
+    structs = {"bzq_config": _lib.BzqConfig, "bzq_chunk": _lib.BzqChunk, "bzq_device_batch": _lib.BzqDeviceBatch,
+               "bzq_host_batch": _lib.BzqHostBatch, "bzq_shard_summary": _lib.BzqShardSummary,
+               "bzq_ingest_stats": _lib.BzqIngestStats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "blazeseq_hip.h"', "int main(void) {"]
+    for cname, ct in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in [f[:2] for f in ct._fields_]:
+            lines.append(f'printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["return 0; }"]
+    src = tmp_path / "sz.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "sz"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, ct in structs.items():
+        assert int(out[cname]) == ctypes.sizeof(ct), cname
+        for fname, _ in [f[:2] for f in ct._fields_]:
+            assert int(out[f"{cname}.{fname}"]) == getattr(ct, fname).offset, f"{cname}.{fname}"
+    assert ctypes.sizeof(_lib.BzqConfig) == 72 and ctypes.sizeof(_lib.BzqDeviceBatch) == 88
 
 
 def test_config_defaults_and_schema_table_without_gpu():
