@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--validate", action="store_true", help="config 3: check_ascii + check_quality, sanger")
+    ap.add_argument("--views", action="store_true",
+                    help="views() mode: RecordOffsets + id spans into the chunk, no columns (A = B + 52 bytes/record)")
     ap.add_argument("--long-reads", action="store_true",
                     help="config 4: 300 000 reads/GPU of 200..19 800 bases (phred 5..30, sanger); record-aligned shards")
     ap.add_argument("--pass-bytes", type=int, default=0)
@@ -129,7 +131,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cfg = B.ParserConfig(check_ascii=args.validate, check_quality=args.validate,
-                         quality_schema="sanger" if args.validate else None)
+                         quality_schema="sanger" if args.validate else None, views_only=args.views)
     ctx = B.Context(cfg, "generic", 4096, local_rank, pass_bytes=args.pass_bytes)
     ctx.set_option("timing_detail", 1)
     ctx.set_option("single_pass", 3 if args.hier else 2 if args.service else (1 if (args.single_pass and not args.kernels_v1) else 0))
@@ -215,7 +217,7 @@ def main():
         global_records, global_bytes = args.reads, n
     elif not sharded_mode:
         assert recs == args.reads and res.status == L.EOF, (recs, res.status, ctx.format_error())
-        assert int(res.seq_bytes) == int(res.qual_bytes) and (args.long_reads or int(res.seq_bytes) == args.read_len * recs)
+        assert args.views or (int(res.seq_bytes) == int(res.qual_bytes) and (args.long_reads or int(res.seq_bytes) == args.read_len * recs))
         global_records, global_bytes = recs, n
     else:
         assert totals[0] == total_reads and first_err == sharded.NO_ERROR, (totals, first_err)
@@ -229,6 +231,8 @@ def main():
         sec_per_step = elapsed / steps
         # algorithmic bytes of this rank's launch: input once + the three columns + ends/id_ends
         A_total = n + int(res.seq_bytes) + int(res.qual_bytes) + int(res.id_bytes) + 16 * recs
+        if args.views:   # input once + five i64 offsets + id span (8 + 4) per record
+            A_total = n + 52 * recs
         per_rank_records = recs
         A = A_total / max(1, recs)
         emit_s = ms_emit / steps / 1e3
@@ -245,7 +249,7 @@ def main():
             "config": {"workload": (f"synthetic long reads 200..19800 bases (BASELINE config 4), {args.reads} reads/GPU "
                                     f"(mean {rec_bytes} B/record), batches(4096), validation " if args.long_reads else
                                     f"synthetic {args.read_len} bp Illumina FASTQ, {args.reads} reads/GPU "
-                                    f"({rec_bytes} B/record), batches(4096), validation ")
+                                    f"({rec_bytes} B/record), {'views() mode (offsets + id spans, no columns)' if args.views else 'batches(4096)'}, validation ")
                                    + f"{'ascii+quality (sanger)' if args.validate else 'off'}, input resident in HBM",
                        "records_per_gpu": args.reads, "record_bytes": rec_bytes, "batch_size": 4096,
                        "parallelism": (f"{'record-aligned' if args.long_reads else 'byte-range'} shards x{world}"
@@ -253,7 +257,7 @@ def main():
                        "pass_bytes": args.pass_bytes},
             "fraction_of_hbm_peak_input_rate": round(global_bytes / world / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {
-                "bound": "hbm", "kernel": "k_tile_emit" if args.kernels_v1 else ("k_single<look-back>" if args.hier else "k_single<service>" if args.service else ("k_fused<LB=true>" if args.single_pass else "k_fused<LB=false>")),
+                "bound": "hbm", "kernel": "k_views" if args.views else "k_tile_emit" if args.kernels_v1 else ("k_single<look-back>" if args.hier else "k_single<service>" if args.service else ("k_fused<LB=true>" if args.single_pass else "k_fused<LB=false>")),
                 "achieved": round(A_total / emit_s / 1e9, 2) if emit_s > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(A_total / emit_s / 1e9 / HBM_PEAK_GBS, 4) if emit_s > 0 else None,
@@ -261,7 +265,7 @@ def main():
                 # FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md), committed under profiles/.
                 # Only quoted for the profiled configuration (150 bp, validation off, two-pass default).
                 "traffic": (round(MEASURED_TRAFFIC_B_PER_RECORD * per_rank_records / 1e9, 3)
-                            if (args.read_len == 150 and not args.long_reads and not args.validate and not args.single_pass and not args.service
+                            if (args.read_len == 150 and not args.long_reads and not args.views and not args.validate and not args.single_pass and not args.service
                                 and not args.hier and not args.kernels_v1) else None),
                 "traffic_unit": "GB per launch",
                 "traffic_source": "profiles/r1_final3_summary.txt: k_fused FETCH_SIZE*2 + WRITE_SIZE",
@@ -283,7 +287,7 @@ def main():
             k = min(args.cpu_reads, recs)
             host = shard[:k * rec_bytes].cpu().numpy() if not args.long_reads else shard[:n].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(host, k if not args.long_reads else recs, args.read_len, args.validate)
-            if not args.long_reads:
+            if not args.long_reads and not args.views:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(host, k, rec_bytes, args.validate)
         # RCCL writes a version banner to C stdio; flush it first so that the JSON is the last line
         try:

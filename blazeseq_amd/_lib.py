@@ -27,7 +27,7 @@ class BzqConfig(C.Structure):
         ("batch_size", C.c_int32),
         ("compat_simd_width", C.c_int32),
         ("emit_offsets", C.c_int32),
-        ("_pad1", C.c_int32),
+        ("views_only", C.c_int32),
         ("max_chunk_bytes", C.c_int64),
         ("pass_bytes", C.c_int64),
         ("min_record_bytes", C.c_int32),
@@ -51,6 +51,7 @@ class BzqChunk(C.Structure):
         ("ms_total", C.c_float), ("ms_aggregate", C.c_float), ("ms_scan", C.c_float),
         ("ms_emit", C.c_float), ("ms_rebase", C.c_float),
         ("n_passes", C.c_uint32), ("_pad", C.c_uint32),
+        ("d_id_start", C.c_void_p), ("d_id_len", C.c_void_p),
     ]
 
 
@@ -62,6 +63,15 @@ class BzqDeviceBatch(C.Structure):
         ("id_buffer", C.c_void_p), ("id_ends", C.c_void_p),
         ("first_record", C.c_uint64),
         ("sequence_bytes", C.c_int64),
+    ]
+
+
+class BzqDeviceViews(C.Structure):
+    _fields_ = [
+        ("num_records", C.c_int64), ("chunk", C.c_void_p),
+        ("header_start", C.c_void_p), ("seq_start", C.c_void_p), ("sep_start", C.c_void_p), ("qual_start", C.c_void_p),
+        ("record_end", C.c_void_p), ("id_start", C.c_void_p), ("id_len", C.c_void_p),
+        ("first_record", C.c_uint64),
     ]
 
 
@@ -107,6 +117,7 @@ SYMBOLS = {
     "bzq_submit_chunk_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32]),
     "bzq_chunk_result": (C.c_int32, [C.c_void_p, C.POINTER(BzqChunk)]),
     "bzq_batch_view": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(BzqDeviceBatch)]),
+    "bzq_views": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(BzqDeviceViews)]),
     "bzq_batch_to_host": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.POINTER(BzqHostBatch)]),
     "bzq_copy_to_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bzq_format_error": (C.c_int64, [C.c_void_p, C.c_uint64, C.c_char_p, C.c_size_t]),

@@ -8,6 +8,7 @@
 // bzq_create fails.
 #include "../../include/blazeseq_hip.h"
 #include "bzq_single.hpp"
+#include "bzq_views.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -75,7 +76,7 @@ struct bzq_ctx {
     DevBuf in, seq, qual, id;
     DevBuf ends, id_ends, rec_end, b_ends, b_id_ends, off[4], view_e, view_i;
     int64_t rec_cap = 0;
-    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, gen_prefix;
+    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, gen_prefix, id_start, id_len;
     int64_t tile_cap = 0;
     ChunkState* d_state = nullptr;
     ChunkState* h_state = nullptr; // pinned
@@ -156,9 +157,10 @@ int ensure_record_arenas(bzq_ctx* c, int64_t recs) {
     if ((rc = ensure(c, c->ends, b)) || (rc = ensure(c, c->id_ends, b)) || (rc = ensure(c, c->rec_end, b)) ||
         (rc = ensure(c, c->b_ends, b)) || (rc = ensure(c, c->b_id_ends, b)))
         return rc;
-    if (c->cfg.emit_offsets)
+    if (c->cfg.emit_offsets || c->cfg.views_only)
         for (int i = 0; i < 4; ++i)
             if ((rc = ensure(c, c->off[i], b))) return rc;
+    if (c->cfg.views_only && ((rc = ensure(c, c->id_start, b)) || (rc = ensure(c, c->id_len, b / 2)))) return rc;
     c->rec_cap = recs;
     return 0;
 }
@@ -294,6 +296,18 @@ void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, int pass) {
     hipLaunchKernelGGL(k_scan_down, dim3((unsigned)ng), dim3(SG_THREADS), 0, c->stream, s);
 }
 
+void launch_views(bzq_ctx* c, dim3 grid, int64_t tb, int64_t te) {
+    ViewArgs v{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (const int64_t*)c->tileP.p,
+               (int64_t*)c->off[0].p, (int64_t*)c->off[1].p, (int64_t*)c->off[2].p, (int64_t*)c->off[3].p,
+               (int64_t*)c->rec_end.p, (int64_t*)c->id_start.p, (int32_t*)c->id_len.p, c->rec_cap, c->d_state,
+               (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper, c->force_dense};
+    const bool ca = c->cfg.check_ascii != 0, cq = c->cfg.check_quality != 0;
+    if (ca && cq) hipLaunchKernelGGL((k_views<true, true>), grid, dim3(BLOCK), 0, c->stream, v);
+    else if (ca) hipLaunchKernelGGL((k_views<true, false>), grid, dim3(BLOCK), 0, c->stream, v);
+    else if (cq) hipLaunchKernelGGL((k_views<false, true>), grid, dim3(BLOCK), 0, c->stream, v);
+    else hipLaunchKernelGGL((k_views<false, false>), grid, dim3(BLOCK), 0, c->stream, v);
+}
+
 // Enqueue aggregate -> scan -> emit for every pass of the current chunk.  `emit_only` re-runs just
 // the emit kernels (after the per-record arrays were re-sized).
 int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
@@ -320,14 +334,17 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
             if (!skip_aggregate_mid) {
                 AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p,
                           (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
-                if (c->v2) hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
+                if (c->cfg.views_only) hipLaunchKernelGGL(k_tile_count, grid, dim3(BLOCK), 0, c->stream, a);
+                else if (c->v2) hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
                 else hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
             }
             if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
             launch_scan(c, tb, te, (int)passes);
             if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
         }
-        if (c->v2) {
+        if (c->cfg.views_only) {
+            launch_views(c, grid, tb, te);
+        } else if (c->v2) {
             FusedArgs f = make_fused_args(c);
             f.tile_begin = tb; f.tile_end = te;
             if (c->overlap && !emit_only) {
@@ -360,6 +377,14 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
 
 void enqueue_rebase(bzq_ctx* c) {
     const bool growth = c->cfg.buffer_growth_enabled != 0;
+    if (c->cfg.views_only) {
+        ViewCheckArgs va{(const int64_t*)c->off[0].p, (const int64_t*)c->off[1].p, (const int64_t*)c->off[2].p,
+                         (const int64_t*)c->off[3].p, (const int64_t*)c->rec_end.p, c->cur_first_header,
+                         growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->rec_cap, c->d_state, c->cur,
+                         c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper};
+        hipLaunchKernelGGL(k_views_check, dim3((unsigned)(c->num_cu * 8)), dim3(BLOCK), 0, c->stream, va);
+        return;
+    }
     RebaseArgs ra{(const int64_t*)c->ends.p, (const int64_t*)c->id_ends.p, (const int64_t*)c->rec_end.p,
                   (int64_t*)c->b_ends.p, (int64_t*)c->b_id_ends.p, (int64_t)c->cfg.batch_size, c->cur_first_header,
                   growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->rec_cap, c->d_state, c->cur,
@@ -391,7 +416,7 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     if (head_lines > 0)
         hipLaunchKernelGGL(k_head, dim3(1), dim3(64), 0, c->stream, d_data, (int64_t)n, prev_byte, head_lines, c->d_state);
     if (n > 0) {
-        c->ran_single_pass = c->single_pass != 0;
+        c->ran_single_pass = c->single_pass != 0 && !c->cfg.views_only;   // views mode has only the two-pass kernels
         if (c->ran_single_pass) { if ((rc = (c->single_pass >= 2 ? enqueue_single(c) : enqueue_fused(c)))) return rc; }
         else if ((rc = enqueue_passes(c, false, reuse_aggregates))) return rc;
         hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state);
@@ -551,7 +576,7 @@ void bzq_destroy(bzq_ctx* c) {
     DevBuf* bufs[] = {&c->in, &c->seq, &c->qual, &c->id, &c->ends, &c->id_ends, &c->rec_end, &c->b_ends,
                       &c->b_id_ends, &c->off[0], &c->off[1], &c->off[2], &c->off[3], &c->view_e, &c->view_i,
                       &c->tile_c, &c->tile_a,
-                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc, &c->consumer_scratch, &c->gen_prefix};
+                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc, &c->consumer_scratch, &c->gen_prefix, &c->id_start, &c->id_len};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->d_state) hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
@@ -758,7 +783,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         } else consumed = c->cur_first_header;
     }
     r.bytes_consumed = (uint64_t)consumed;
-    if (n_records > 0) {
+    if (n_records > 0 && !c->cfg.views_only) {
         int64_t e2[2] = {h->last_ends, h->last_id_ends};
         if (n_records != n_complete) { // truncated by an error, or extended by the unterminated last record
             HIPCHK(c, hipMemcpy(&e2[0], (const int64_t*)c->ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
@@ -768,11 +793,15 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         r.seq_bytes = accept_last && r.status == BZQ_EOF ? (uint64_t)h->S : (uint64_t)e2[0];
         r.id_bytes = (uint64_t)e2[1];
     }
-    r.d_seq = (const uint8_t*)c->seq.p; r.d_qual = (const uint8_t*)c->qual.p; r.d_id = (const uint8_t*)c->id.p;
-    r.d_ends = (const int64_t*)c->ends.p; r.d_id_ends = (const int64_t*)c->id_ends.p;
-    r.d_batch_ends = (const int64_t*)c->b_ends.p; r.d_batch_id_ends = (const int64_t*)c->b_id_ends.p;
+    if (!c->cfg.views_only) {
+        r.d_seq = (const uint8_t*)c->seq.p; r.d_qual = (const uint8_t*)c->qual.p; r.d_id = (const uint8_t*)c->id.p;
+        r.d_ends = (const int64_t*)c->ends.p; r.d_id_ends = (const int64_t*)c->id_ends.p;
+        r.d_batch_ends = (const int64_t*)c->b_ends.p; r.d_batch_id_ends = (const int64_t*)c->b_id_ends.p;
+    } else {
+        r.d_id_start = (const int64_t*)c->id_start.p; r.d_id_len = (const int32_t*)c->id_len.p;
+    }
     r.d_record_end = (const int64_t*)c->rec_end.p;
-    if (c->cfg.emit_offsets) {
+    if (c->cfg.emit_offsets || c->cfg.views_only) {
         r.d_header_start = (const int64_t*)c->off[0].p; r.d_seq_start = (const int64_t*)c->off[1].p;
         r.d_sep_start = (const int64_t*)c->off[2].p; r.d_qual_start = (const int64_t*)c->off[3].p;
     }
@@ -805,6 +834,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
 int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, bzq_device_batch* out) {
     if (!c || !out || !c->have_result) { if (c) c->err = "bzq_batch_view: no parsed chunk"; return BZQ_ERR_ARG; }
     if (max_records == 0) { c->err = "bzq_batch_view: max_records must be > 0"; return BZQ_ERR_ARG; }
+    if (c->cfg.views_only) { c->err = "bzq_batch_view: the ctx is in views mode (no columns); use bzq_views"; return BZQ_ERR_ARG; }
     const uint64_t bs = (uint64_t)c->cfg.batch_size;
     memset(out, 0, sizeof(*out));
     out->quality_offset = 33; // parser.mojo:243 builds FastqBatch(batch_size=limit): default offset
@@ -842,6 +872,21 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
         out->ends = (const int64_t*)c->view_e.p;
         out->id_ends = (const int64_t*)c->view_i.p;
     }
+    return 0;
+}
+
+int32_t bzq_views(bzq_ctx* c, uint64_t first_record, uint32_t max_records, bzq_device_views* out) {
+    if (!c || !out || !c->have_result) { if (c) c->err = "bzq_views: no parsed chunk"; return BZQ_ERR_ARG; }
+    if (!c->cfg.views_only) { c->err = "bzq_views: the ctx is not in views mode (config.views_only)"; return BZQ_ERR_ARG; }
+    memset(out, 0, sizeof(*out));
+    out->first_record = first_record;
+    out->chunk = c->cur;
+    if (first_record >= c->res.n_records) return 0;
+    out->num_records = (int64_t)std::min<uint64_t>(max_records, c->res.n_records - first_record);
+    out->header_start = c->res.d_header_start + first_record; out->seq_start = c->res.d_seq_start + first_record;
+    out->sep_start = c->res.d_sep_start + first_record; out->qual_start = c->res.d_qual_start + first_record;
+    out->record_end = c->res.d_record_end + first_record;
+    out->id_start = c->res.d_id_start + first_record; out->id_len = c->res.d_id_len + first_record;
     return 0;
 }
 

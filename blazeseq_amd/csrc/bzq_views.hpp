@@ -1,0 +1,283 @@
+// Views mode: the device analogue of `for view in parser.views()` (parser.mojo:253-258, _FastqParserViewIter 628-661;
+// FastqView record.mojo:431-550): no column packing -- every record is delivered as its RecordOffsets
+// (utils.mojo:37-93: header_start, seq_start, sep_start, qual_start, record_end) plus the stripped-id span, all as
+// offsets into the chunk, which stays where it is (zero copy, like the reference's spans into its buffer).
+// Algorithmic bytes per record: B read + 5 x 8 + 8 + 4 = B + 52 written (SURVEY.md 8d "offsets-only mode").
+//
+//   k_tile_count     pass A': newlines per tile, nothing else (no line classes are needed: no column offsets exist)
+//   k_views          pass B': per line the offsets of its record, '@' / '+' checks, id span, optional validation of the
+//                    bytes by role -- straight from the tile, nothing is moved
+//   k_views_check    per record: sequence / quality length check (utils.mojo:458-461) from the offsets, the
+//                    buffer-capacity refusal, and the chunk totals the host reads
+#pragma once
+#include "bzq_fused.hpp"
+
+namespace bzq {
+
+struct ViewArgs {
+    const uint8_t* g;
+    int64_t n;
+    uint32_t prev_byte;
+    int64_t tile_begin, tile_end;
+    const int64_t* tileP;
+    int64_t* o_hdr;
+    int64_t* o_seq;
+    int64_t* o_sep;
+    int64_t* o_qual;
+    int64_t* rec_end;
+    int64_t* id_start;
+    int32_t* id_len;
+    int64_t rec_cap;
+    ChunkState* st;
+    uint32_t q_lower, q_upper;
+    int32_t force_dense;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_tile_count(AggArgs a) {
+    __shared__ uint32_t s_w[BLOCK / 64];
+    const int tid = threadIdx.x;
+    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    if (t >= a.tile_end) return;
+    const int64_t t0 = t * TILE;
+    const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+    uint4 r[4];
+    tile_fetch(a.g, a.n, t0, valid, r);
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int pos = (tid + BLOCK * s) * 16;
+        uint32_t m = nl_mask16(r[s]);
+        if (valid != TILE) {
+            const int rem = valid - pos;
+            if (rem < 16) m &= rem > 0 ? ((1u << rem) - 1u) : 0u;
+        }
+        cnt += (uint32_t)__popc(m);
+    }
+    const u64 w = wave_sum_u64((u64)cnt);
+    if ((tid & 63) == 0) s_w[tid >> 6] = (uint32_t)w;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t c = 0;
+        for (int i = 0; i < BLOCK / 64; ++i) c += s_w[i];
+        a.tile_c[t] = c; a.tile_a[t] = 0ull; a.tile_idc[t] = 0ull;
+    }
+}
+
+// Stripped id of the header line [ls, le) (ls = the '@', le = its newline), as a span of the chunk
+// (_strip_spaces on [header_start + 1, seq_start - 1), parser.mojo:355-366; all-space ids collapse to empty).
+__device__ inline void id_span(const ByteSrc& b, int64_t ls, int64_t le, int64_t& lo, int64_t& hi) {
+    lo = ls + 1 < le ? ls + 1 : le;
+    hi = le;
+    while (lo < hi && is_posix_space(b.at(lo))) ++lo;
+    while (hi > lo && is_posix_space(b.at(hi - 1))) --hi;
+}
+
+// ascii / quality check of the tile bytes [a, b) (tile offsets) that belong to one line role
+template <bool CA, bool CQ>
+__device__ __forceinline__ void check_bytes(const uint8_t* s_tile, int a, int b, bool is_qual, int64_t rec, uint32_t qlo, uint32_t qhi,
+                                            ErrAcc& err) {
+    for (int p = a & ~15; p < b; p += 16) {
+        const uint4 v = *reinterpret_cast<const uint4*>(s_tile + p);
+        const int x0 = a > p ? a - p : 0, x1 = b - p < 16 ? b - p : 16;
+        const uint32_t m0 = byte_range_mask(0, x0, x1), m1 = byte_range_mask(1, x0, x1), m2 = byte_range_mask(2, x0, x1),
+                       m3 = byte_range_mask(3, x0, x1);
+        if (CA && any_non_ascii((v.x & m0) | (v.y & m1) | (v.z & m2) | (v.w & m3))) err.valid(rec, 4);
+        if (CQ && is_qual) {
+            const uint32_t fill = 0x01010101u * qlo;
+            if (any_out_of_range((v.x & m0) | (fill & ~m0), qlo, qhi) | any_out_of_range((v.y & m1) | (fill & ~m1), qlo, qhi) |
+                any_out_of_range((v.z & m2) | (fill & ~m2), qlo, qhi) | any_out_of_range((v.w & m3) | (fill & ~m3), qlo, qhi))
+                err.valid(rec, 5);
+        }
+    }
+}
+
+constexpr int MAXL_V = 980;   // more newlines in a tile -> the serial path
+
+template <bool CA, bool CQ>
+__global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
+    __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
+    __shared__ uint16_t s_nl[MAXL_V];   // sized so that the kernel's LDS is 8 x 20480 B per CU
+    __shared__ uint32_t s_w[BLOCK / 64];
+    // validation only: line index at the first byte of every 16-byte piece
+    __shared__ uint16_t s_pline[(CA || CQ) ? PIECES : 1];
+    uint8_t* s_tile = s_tile_raw + 16;
+    const int tid = threadIdx.x;
+    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    if (t >= a.tile_end) return;
+    const int64_t t0 = t * TILE;
+    const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+    const int64_t P = a.tileP[t];
+    const uint32_t prevb = t0 > 0 ? (uint32_t)a.g[t0 - 1] : a.prev_byte;
+    uint4 r[4];
+    tile_fetch(a.g, a.n, t0, valid, r);
+    tile_stage<true>(r, valid, s_mask, s_tile);
+    ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
+    const bool first_starts = prevb == 10u;
+    __syncthreads();
+    const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);
+    const u64 m64 = s_mask64[tid];
+    uint32_t c = 0;
+    const uint32_t excl = block_exclusive_scan<uint32_t, BLOCK / 64>((uint32_t)__popcll(m64), s_w, c);
+    const bool dense = ((int)c > MAXL_V) || a.force_dense;
+    ErrAcc err{~0ull, ~0ull};
+    bool overflow = false;
+    if ((CA || CQ) && !dense) {
+        const uint32_t l0 = excl, l1 = l0 + (uint32_t)__popc((uint32_t)m64 & 0xFFFFu),
+                       l2 = l0 + (uint32_t)__popc((uint32_t)m64), l3 = l0 + (uint32_t)__popcll(m64 & 0xFFFFFFFFFFFFull);
+        *reinterpret_cast<u64*>(&s_pline[4 * tid]) = (u64)l0 | ((u64)l1 << 16) | ((u64)l2 << 32) | ((u64)l3 << 48);
+    }
+
+    // one line: offsets of its record, structure bytes, id span, validation.  [start, end) are tile offsets;
+    // sknown: the line starts at `start` (false only for a first line that continues from the previous tile)
+    auto handle = [&](int j, int start, int end, bool sknown, bool end_in, bool check_here) {
+        const int64_t L = P + j;
+        if (L < 0) return;                       // a head line owned by the previous shard
+        const int role = (int)(L & 3);
+        const int64_t rec = L >> 2;
+        const bool in_cap = rec < a.rec_cap;
+        if (!in_cap) { overflow = true; }
+        const bool sin = sknown && start < valid;
+        const int64_t ls = t0 + start;
+        if (role == 0) {
+            if (sin) {
+                if (s_tile[start] != 64) err.structure(rec, 1);   // '@', utils.mojo:454
+                if (in_cap) a.o_hdr[rec] = ls;
+            }
+            if (end_in) {   // the header line ends here: its stripped id as a span of the chunk
+                int64_t h0 = ls;
+                if (!sknown) { h0 = t0; while (bs.at(h0 - 1) != 10u) --h0; }   // started in an earlier tile
+                int64_t lo, hi;
+                id_span(bs, h0, t0 + end, lo, hi);
+                if (in_cap) { a.id_start[rec] = lo; a.id_len[rec] = (int32_t)(hi - lo); }
+            }
+            if (CA) {   // ascii covers the kept id bytes only: their range within this tile
+                int64_t lo = ls, hi = ls;
+                if (end > start) header_kept(bs, ls, t0 + end, sknown, end_in, t0 + valid, lo, hi);
+                (void)check_here;   // headers are short: their kept bytes are always checked by the line's own thread
+                check_bytes<CA, false>(s_tile, (int)(lo - t0), (int)(hi - t0), false, rec, a.q_lower, a.q_upper, err);
+            }
+        } else if (role == 2) {
+            if (sin) {
+                if (s_tile[start] != 43) err.structure(rec, 2);   // '+', utils.mojo:456
+                if (in_cap) a.o_sep[rec] = ls;
+            }
+        } else {
+            if (sin && in_cap) (role == 1 ? a.o_seq : a.o_qual)[rec] = ls;
+            if ((CA || CQ) && end > start) {
+                if (check_here) {
+                    check_bytes<CA, CQ>(s_tile, start, end, role == 3, rec, a.q_lower, a.q_upper, err);
+                } else {
+                    // whole pieces without a newline are checked from registers by the bulk pass below; the line's own
+                    // thread takes the (at most two) pieces it shares with a newline or with the end of the data
+                    const int pa = start >> 4, pb = (end - 1) >> 4;
+                    if (s_mask[pa] != 0 || (pa + 1) * 16 > valid) {
+                        const int e1 = end < (pa + 1) * 16 ? end : (pa + 1) * 16;
+                        check_bytes<CA, CQ>(s_tile, start, e1, role == 3, rec, a.q_lower, a.q_upper, err);
+                    }
+                    if (pb != pa && (s_mask[pb] != 0 || (pb + 1) * 16 > valid))
+                        check_bytes<CA, CQ>(s_tile, pb * 16, end, role == 3, rec, a.q_lower, a.q_upper, err);
+                }
+            }
+            if (role == 3 && end_in && in_cap) a.rec_end[rec] = t0 + end;
+        }
+    };
+
+    if (dense) {   // tiles of tiny records: one thread walks them
+        if (tid == 0) {
+            int j = 0, line_start = 0;
+            bool sknown = first_starts;
+            for (int w = 0; w < BLOCK; ++w) {
+                u64 m = s_mask64[w];
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int nl = w * 64 + bit;
+                    handle(j, line_start, nl, sknown, true, true);
+                    line_start = nl + 1; sknown = true; ++j;
+                }
+            }
+            handle(j, line_start, valid, sknown, false, true);
+            atomicAdd((u64*)&a.st->dense_tiles, 1ull);
+        }
+    } else {
+        u64 m = m64;
+        int idx = 0;
+        while (m) {
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1;
+            s_nl[excl + idx] = (uint16_t)(tid * 64 + bit);
+            ++idx;
+        }
+        __syncthreads();
+        for (int j = tid; j <= (int)c; j += BLOCK) {
+            const int start = j ? (int)s_nl[j - 1] + 1 : 0;
+            const bool end_in = j < (int)c;
+            const int end = end_in ? (int)s_nl[j] : valid;
+            handle(j, start, end, j > 0 ? true : first_starts, end_in, false);
+        }
+        if (CA || CQ) {
+            // bulk validation: every whole 16-byte piece that lies inside ONE sequence / quality line (no newline in it),
+            // straight from the registers it was loaded into; pieces that hold a newline were taken by their lines above
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int q = tid + BLOCK * sidx, pos = q * 16;
+                if (pos + 16 <= valid && s_mask[q] == 0) {
+                    const int64_t L = P + (int64_t)s_pline[q];
+                    const int role = (int)(L & 3);
+                    if ((role & 1) && L >= 0) {
+                        const uint4 v = r[sidx];
+                        if (CA && any_non_ascii(v.x | v.y | v.z | v.w)) err.valid(L >> 2, 4);
+                        if (CQ && role == 3 &&
+                            (any_out_of_range(v.x, a.q_lower, a.q_upper) | any_out_of_range(v.y, a.q_lower, a.q_upper) |
+                             any_out_of_range(v.z, a.q_lower, a.q_upper) | any_out_of_range(v.w, a.q_lower, a.q_upper)))
+                            err.valid(L >> 2, 5);
+                    }
+                }
+            }
+        }
+    }
+    if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
+    if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
+    if (overflow) atomicOr(&a.st->rec_overflow, 1);
+}
+
+struct ViewCheckArgs {
+    const int64_t* o_hdr;
+    const int64_t* o_seq;
+    const int64_t* o_sep;
+    const int64_t* o_qual;
+    const int64_t* rec_end;
+    int64_t first_header, len_limit, rec_cap;
+    ChunkState* st;
+    const uint8_t* g;
+    int32_t compat_w;
+    uint32_t q_upper;
+};
+
+// Grid-stride over the complete records (their count comes from the device state, like k_rebase).
+__global__ __launch_bounds__(BLOCK) void k_views_check(ViewCheckArgs a) {
+    const int64_t lines = a.st->P;
+    int64_t n_rec = lines > 0 ? (lines >> 2) : 0;
+    if (n_rec > a.rec_cap) n_rec = a.rec_cap;
+    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < n_rec; r += (int64_t)gridDim.x * BLOCK) {
+        const int64_t re = a.rec_end[r];
+        const int64_t seq_len = a.o_sep[r] - a.o_seq[r] - 1, qual_len = re - a.o_qual[r];
+        if (seq_len != qual_len) atomicMin(&a.st->err_struct, ((u64)r << 3) | 3ull);   // utils.mojo:458-461
+        const int64_t prev = r ? a.rec_end[r - 1] : a.first_header - 1;
+        if (re - prev > a.len_limit) atomicMin(&a.st->err_buf, (u64)r << 3);
+        if (a.compat_w > 0) {   // SIMD-width quirk of the quality check, as in k_rebase
+            const int64_t qs = re - qual_len, body = (qual_len / a.compat_w) * a.compat_w;
+            for (int64_t i = 0; i < body; ++i)
+                if (a.g[qs + i] == a.q_upper) { atomicMin(&a.st->err_valid, ((u64)r << 3) | 5ull); break; }
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        a.st->n_complete = n_rec;
+        a.st->last_record_end = n_rec ? a.rec_end[n_rec - 1] : a.first_header - 1;
+        a.st->last_ends = 0;
+        a.st->last_id_ends = 0;
+    }
+}
+
+} // namespace bzq

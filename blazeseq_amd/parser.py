@@ -67,6 +67,7 @@ class ParserConfig:
     quality_schema: Optional[str] = None
     compat_simd_width: int = 0     # reproduce the host-SIMD-width quirk of the quality check
     emit_offsets: bool = False     # also materialise the RecordOffsets columns
+    views_only: bool = False       # views() mode: no columns, records as offsets + id spans into the chunk
 
 
 def _check(ctx_handle, rc: int, what: str):
@@ -113,6 +114,12 @@ class ChunkResult:
     def seq_start(self): return self._i64(self.d_seq_start, self.n_records)
     def sep_start(self): return self._i64(self.d_sep_start, self.n_records)
     def qual_start(self): return self._i64(self.d_qual_start, self.n_records)
+    def id_start(self): return self._i64(self.d_id_start, self.n_records)
+    def id_len(self):
+        out = np.empty(int(self.n_records), dtype=np.int32)
+        if out.size:
+            self.ctx.copy_to_host(out, self.d_id_len, out.nbytes)
+        return out
     def seq(self): return self._u8(self.d_seq, self.seq_bytes)
     def qual(self): return self._u8(self.d_qual, self.qual_bytes)
     def id(self): return self._u8(self.d_id, self.id_bytes)
@@ -139,6 +146,7 @@ class Context:
         c.batch_size = batch_size
         c.compat_simd_width = self.config.compat_simd_width
         c.emit_offsets = int(self.config.emit_offsets)
+        c.views_only = int(self.config.views_only)
         c.pass_bytes = pass_bytes
         c.min_record_bytes = min_record_bytes
         self.raw_config = c

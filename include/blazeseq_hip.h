@@ -69,7 +69,8 @@ typedef struct bzq_config {
                                        body's `>=` for the first floor(n/W)*W quality bytes
                                        (record.mojo:90-97) */
     int32_t emit_offsets;           /* also materialise RecordOffsets columns (utils.mojo:37-93) */
-    int32_t _pad1;
+    int32_t views_only;             /* views() mode (parser.mojo:253-258): no columns, every record as RecordOffsets +
+                                       its stripped-id span into the chunk (zero copy); see bzq_views() */
     int64_t max_chunk_bytes;        /* device arena sizing; chunks larger than this re-size the arena */
     int64_t pass_bytes;             /* bytes handled per kernel round (0 = library default) */
     int32_t min_record_bytes;       /* sizing hint for the per-record arrays (default 32); an input
@@ -115,7 +116,28 @@ typedef struct bzq_chunk {
     float ms_aggregate, ms_scan, ms_emit, ms_rebase;
     uint32_t n_passes;
     uint32_t _pad;
+    /* views mode only (config.views_only): the stripped id of record r is chunk[d_id_start[r] .. + d_id_len[r])
+     * (FastqView.id(), record.mojo:431-472); the three column pointers and d_*ends are NULL in that mode */
+    const int64_t* d_id_start;
+    const int32_t* d_id_len;
 } bzq_chunk;
+
+/* Views of records [first_record, first_record + num_records) of the current chunk (views mode): FastqView
+ * (record.mojo:431-550) for many records at once -- spans into the chunk instead of copies.  Record r (relative to
+ * first_record): id = chunk[id_start[r] .. +id_len[r]); sequence = chunk[seq_start[r] .. sep_start[r] - 1);
+ * quality = chunk[qual_start[r] .. record_end[r]).  Valid until the next bzq_submit_* on the ctx. */
+typedef struct bzq_device_views {
+    int64_t num_records;
+    const uint8_t* chunk;          /* the submitted chunk on the device */
+    const int64_t* header_start;   /* RecordOffsets columns (utils.mojo:37-93), absolute chunk offsets */
+    const int64_t* seq_start;
+    const int64_t* sep_start;
+    const int64_t* qual_start;
+    const int64_t* record_end;
+    const int64_t* id_start;
+    const int32_t* id_len;
+    uint64_t first_record;
+} bzq_device_views;
 
 /* DeviceFastqBatch (blazeseq/fastq/record_batch.mojo:210-220): what FastqBatch.to_device(ctx)
  * returns (record_batch.mojo:89-90, 404-411).  Zero-copy slices of the chunk columns. */
@@ -270,6 +292,10 @@ int32_t bzq_ingest_open(bzq_ctx* ctx, const char* path, uint64_t chunk_bytes, in
 int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, uint64_t* stream_pos);
 int32_t bzq_ingest_get_stats(const bzq_ingest* g, bzq_ingest_stats* out);
 void bzq_ingest_close(bzq_ingest* g);
+
+/* views mode: the records [first_record, first_record + max_records) of the current chunk as spans (zero copy).
+ * Mirrors next_view / views() (parser.mojo:159-170, 253-258) for a whole range at once. */
+int32_t bzq_views(bzq_ctx* ctx, uint64_t first_record, uint32_t max_records, bzq_device_views* out);
 
 /* FastqBatch.to_device() for a batch that OUTLIVED its chunk (record_batch.mojo:89-90, upload_batch_to_device
  * 404-411: 10 allocations, 10 copies and 3 synchronize() per batch in the reference): one device allocation, five

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
 import numpy as np
 from fastq_fuzz import rand_stream, rand_record
-from gpu_util import make_pair, check_against_oracle
+from gpu_util import make_pair, check_against_oracle, check_views_against_oracle
 
 
 def make_stream(rng):
@@ -64,6 +64,7 @@ def make_stream(rng):
 ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", default="0:100000")
 ap.add_argument("--seconds", type=float, default=300)
+ap.add_argument("--views", action="store_true", help="views mode (ParserConfig.views_only) instead of the batch path")
 args = ap.parse_args()
 lo, hi = (int(x) for x in args.seeds.split(":"))
 t0, done = time.time(), 0
@@ -78,14 +79,16 @@ for seed in range(lo, hi):
         kw.update(check_ascii=True, check_quality=bool(rng.random() < 0.7))
         if rng.random() < 0.5:
             kw["quality_schema"] = str(rng.choice(["sanger", "solexa", "illumina_1.3", "illumina_1.5", "illumina_1.8"]))
-    if rng.random() < 0.3:
+    if rng.random() < 0.3 and not args.views:
         kw["emit_offsets"] = True
+    if args.views:
+        kw["views_only"] = True
     if rng.random() < 0.2:
         kw["buffer_capacity"] = int(rng.choice([64, 256, 4096, 65536]))
     if rng.random() < 0.15:
         kw["compat_simd_width"] = int(rng.choice([16, 32, 64]))
     bs = int(rng.choice([1, 7, 100, 4096]))
-    sp = [False, True, "v1"][int(rng.integers(0, 3))] if rng.random() < 0.3 else False
+    sp = [False, True, "v1"][int(rng.integers(0, 3))] if (rng.random() < 0.3 and not args.views) else False
     key = (bs, sp, tuple(sorted(kw.items())))
     if key not in pairs:
         if len(pairs) > 40:
@@ -95,7 +98,10 @@ for seed in range(lo, hi):
     ctx, ocfg = pairs[key]
     is_eof = bool(rng.random() < 0.85)
     try:
-        check_against_oracle(ctx, ocfg, data, is_eof=is_eof, offsets=bool(kw.get("emit_offsets")), what=f"seed {seed} {kind}")
+        if args.views:
+            check_views_against_oracle(ctx, ocfg, data, is_eof=is_eof, what=f"seed {seed} {kind}")
+        else:
+            check_against_oracle(ctx, ocfg, data, is_eof=is_eof, offsets=bool(kw.get("emit_offsets")), what=f"seed {seed} {kind}")
     except AssertionError as e:
         print(f"MISMATCH seed={seed} kind={kind} n={len(data)} bs={bs} single_pass={sp} is_eof={is_eof} kw={kw}\n{str(e)[:2000]}")
         sys.exit(1)

@@ -8,7 +8,7 @@ from oracle import oracle as O
 
 def make_pair(batch_size=4096, schema="generic", pass_bytes=0, min_record_bytes=32, single_pass=True, **kw):
     """(Context, oracle config) with the same ParserConfig."""
-    okw = {k: v for k, v in kw.items() if k not in ("compat_simd_width", "emit_offsets")}
+    okw = {k: v for k, v in kw.items() if k not in ("compat_simd_width", "emit_offsets", "views_only")}
     cfg = B.ParserConfig(**kw)
     name = cfg.quality_schema if cfg.quality_schema else schema
     ctx = B.Context(cfg, schema, batch_size, 0, pass_bytes=pass_bytes, min_record_bytes=min_record_bytes)
@@ -56,4 +56,34 @@ def check_against_oracle(ctx, ocfg, data, is_eof=True, offsets=False, what=""):
             np.testing.assert_array_equal(res.seq_start(), f.seq_start, err_msg=tag + " seq_start")
             np.testing.assert_array_equal(res.sep_start(), f.sep_start, err_msg=tag + " sep_start")
             np.testing.assert_array_equal(res.qual_start(), f.qual_start, err_msg=tag + " qual_start")
+    return res, f
+
+
+def check_views_against_oracle(ctx, ocfg, data, is_eof=True, what=""):
+    """Views mode (config.views_only): RecordOffsets + id spans into the chunk must reproduce the oracle's records:
+    same count, terminal event, error text, offsets; id / sequence / quality spans must hold the oracle's bytes."""
+    data = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else data
+    res = ctx.parse(data, 0, is_eof)
+    f = O.flat_parse(data, ocfg, is_eof=is_eof)
+    tag = f"views {what} n={data.size}"
+    assert int(res.n_records) == f.n_records, (tag, int(res.n_records), f.n_records, res.status, f.term_code)
+    assert res.status == f.term_code, (tag, res.status, f.term_code, ctx.format_error(), f.term_msg)
+    if res.status != L.OK:
+        assert ctx.format_error() == f.term_msg, (tag, ctx.format_error(), f.term_msg)
+        assert (int(res.error_record) if res.status != L.EOF else -1) == f.term_record, tag
+    assert int(res.bytes_consumed) == f.consumed, (tag, int(res.bytes_consumed), f.consumed)
+    assert int(res.total_newlines) == f.n_newlines, tag
+    n = f.n_records
+    if n:
+        np.testing.assert_array_equal(res.record_end(), f.record_end, err_msg=tag + " record_end")
+        np.testing.assert_array_equal(res.header_start(), f.header_start, err_msg=tag + " header_start")
+        np.testing.assert_array_equal(res.seq_start(), f.seq_start, err_msg=tag + " seq_start")
+        np.testing.assert_array_equal(res.sep_start(), f.sep_start, err_msg=tag + " sep_start")
+        np.testing.assert_array_equal(res.qual_start(), f.qual_start, err_msg=tag + " qual_start")
+        ids, idl = res.id_start(), res.id_len()
+        np.testing.assert_array_equal(np.cumsum(idl.astype(np.int64)), f.id_ends, err_msg=tag + " id lengths")
+        i0 = np.concatenate([[0], f.id_ends[:-1]])
+        for r in range(n) if n <= 3000 else list(range(0, n, max(1, n // 3000))):
+            a, b = int(ids[r]), int(ids[r]) + int(idl[r])
+            assert data[a:b].tobytes() == f.id_bytes[int(i0[r]):int(f.id_ends[r])].tobytes(), (tag, "id bytes", r)
     return res, f

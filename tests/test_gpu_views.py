@@ -1,0 +1,95 @@
+"""-m gpu: views mode (ParserConfig(views_only=True) -> bzq_config.views_only): the device analogue of parser.views()
+(parser.mojo:253-258).  Same oracle, same corpus, same fuzz generators as the batch path; the outputs compared are the
+RecordOffsets columns and the stripped-id spans."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as O
+from fastq_fuzz import rand_stream
+from gpu_util import make_pair, check_views_against_oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CORPUS = json.load(open(os.path.join(HERE, "golden", "corpus_expected.json")))
+
+
+def test_views_inline_known_answers():
+    ctx, oc = make_pair(views_only=True, single_pass=False)
+    for data in (b"@r1\nACGT\n+\n!!!!\n@r2\nTGCA\n+\n####\n", b"", b"\n", b"@", b"@a\nA\n+\n!\n",
+                 b"r1\nACGT\n+\n!!!!\n", b"@r1\nACGT\n+\n!!!\n", b"@r1\nACGT\n-\n!!!!\n",
+                 b"@a\nAC\n+\n!!\n@b\nACGT\n+\n!!", b"@a\nAC\n+\n!!\n@b\nAC\n+\n \t", b"@a\nAC\n+\n!!\n\n",
+                 b"@only\nACGT", b"@a\nAC\n+\n!!\n@only\nACGT", b"@id\r\nACGT\r\n+\r\n!!!!\r\n",
+                 b"@ \t id with spaces \t\nAC\n+\n!!\n@\nAC\n+\n!!\n@   \nAC\n+\n!!\n", b"\n\n\n\n", b"\n\n\n\n\n\n\n\n\n"):
+        check_views_against_oracle(ctx, oc, data, what=repr(data[:20]))
+
+
+@pytest.mark.parametrize("cfgname", ["default", "validated_generic", "validated_schema", "validated_schema_simd32", "cap64", "cap64_growth"])
+def test_views_corpus(cfgname, corpus_dir):
+    for name, e in sorted(CORPUS.items()):
+        data = open(os.path.join(corpus_dir, name), "rb").read()
+        sc = e["schema"]
+        kw = {"default": {}, "validated_generic": dict(check_ascii=True, check_quality=True),
+              "validated_schema": dict(check_ascii=True, check_quality=True, quality_schema=sc),
+              "validated_schema_simd32": dict(check_ascii=True, check_quality=True, quality_schema=sc, compat_simd_width=32),
+              "cap64": dict(buffer_capacity=64),
+              "cap64_growth": dict(buffer_capacity=64, buffer_growth_enabled=True, buffer_max_capacity=1 << 20)}[cfgname]
+        ctx, oc = make_pair(views_only=True, single_pass=False, **kw)
+        res, f = check_views_against_oracle(ctx, oc, data, what=f"{name}/{cfgname}")
+        g = e[cfgname]
+        assert (int(res.n_records), res.status, ctx.format_error().decode("latin-1") if res.status else "") == \
+               (g["n_records"], g["term_code"], g["term_msg"]), name
+        ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_views_fuzz(seed):
+    rng = np.random.default_rng(7000 + seed)
+    for rep in range(5):
+        big = rep == 4
+        data = rand_stream(rng, n_records=int(rng.integers(0, 60)) if not big else int(rng.integers(300, 3000)),
+                           max_len=int(rng.integers(1, 80)) if not big else int(rng.choice([30, 150, 5000, 40000]) if seed % 2 else 150),
+                           dirty=float(rng.choice([0.0, 0.02, 0.1])) if not big else float(rng.choice([0, 0.001])),
+                           crlf=bool(rng.random() < 0.15))
+        for kw in (dict(), dict(check_ascii=True, check_quality=True),
+                   dict(check_ascii=True, check_quality=True, quality_schema="solexa", compat_simd_width=16),
+                   dict(buffer_capacity=48), dict(buffer_capacity=48, buffer_growth_enabled=True, buffer_max_capacity=200)):
+            ctx, oc = make_pair(views_only=True, single_pass=False, batch_size=int(rng.choice([1, 3, 4096])), **kw)
+            check_views_against_oracle(ctx, oc, data, what=f"seed{seed}/{rep}/{kw}")
+            check_views_against_oracle(ctx, oc, data, is_eof=False, what=f"chunk seed{seed}/{rep}/{kw}")
+            if rep in (0, 4):
+                ctx.set_option("force_dense", 1)
+                check_views_against_oracle(ctx, oc, data, what=f"dense seed{seed}/{kw}")
+            ctx.close()
+
+
+def test_views_api_and_spans():
+    """bzq_views: zero-copy spans of a record range; the spans hold the record's bytes."""
+    import ctypes as C
+    import torch
+    import blazeseq_amd as B
+    from blazeseq_amd import _lib as L
+    data = O.generate_synthetic(5000, 30, 200, 0, 40, "sanger")
+    f = O.flat_parse(data, O.make_config())
+    ctx = B.Context(B.ParserConfig(views_only=True), "generic", 4096, 0)
+    t = torch.from_numpy(data.copy()).cuda()
+    ctx.submit_device(t.data_ptr(), t.numel(), 0, True)
+    res = ctx.result()
+    assert int(res.n_records) == 5000 and res.status == 6 and not res.d_seq and not res.d_ends
+    v = L.BzqDeviceViews()
+    assert L.lib().bzq_views(ctx.h, 1000, 64, C.byref(v)) == 0
+    assert v.num_records == 64 and v.chunk == t.data_ptr() and v.first_record == 1000
+    ss, se, qs, re_ = (np.empty(64, dtype=np.int64) for _ in range(4))
+    for arr, ptr in ((ss, v.seq_start), (se, v.sep_start), (qs, v.qual_start), (re_, v.record_end)):
+        ctx.copy_to_host(arr, ptr, 64 * 8)
+    e0 = np.concatenate([[0], f.ends])
+    for k in range(64):
+        r = 1000 + k
+        assert data[ss[k]:se[k] - 1].tobytes() == f.seq_bytes[e0[r]:e0[r + 1]].tobytes()
+        assert data[qs[k]:re_[k]].tobytes() == f.qual_bytes[e0[r]:e0[r + 1]].tobytes()
+    b = L.BzqDeviceBatch()
+    assert L.lib().bzq_batch_view(ctx.h, 0, 10, C.byref(b)) < 0      # no columns in this mode
+    ctx.close()
