@@ -76,7 +76,7 @@ struct bzq_ctx {
     DevBuf in, seq, qual, id;
     DevBuf ends, id_ends, rec_end, b_ends, b_id_ends, off[4], view_e, view_i;
     int64_t rec_cap = 0;
-    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, gen_prefix, id_start, id_len;
+    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, gen_prefix, id_start, id_len, entries, tile_list;
     int64_t tile_cap = 0;
     ChunkState* d_state = nullptr;
     ChunkState* h_state = nullptr; // pinned
@@ -84,6 +84,7 @@ struct bzq_ctx {
     std::vector<hipEvent_t> ev_detail;
     // options
     int ablate = 0;
+    int views_bytes = 0;   // option: views mode through the two-read kernels even without validation (cross-check)
     int force_dense = 0, timing_detail = 0, single_pass = 0, v2 = 1, num_cu = 256;
     bool ran_single_pass = false;
     // current chunk
@@ -147,6 +148,8 @@ int ensure_chunk_arenas(bzq_ctx* c, uint64_t n, bool need_input) {
             return rc;
         c->tile_cap = nt;
     }
+    if (c->cfg.views_only && ((rc = ensure(c, c->entries, (size_t)nt * ENT_STRIDE * 4)) || (rc = ensure(c, c->tile_list, (size_t)nt * 8))))
+        return rc;
     return 0;
 }
 
@@ -296,11 +299,26 @@ void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, int pass) {
     hipLaunchKernelGGL(k_scan_down, dim3((unsigned)ng), dim3(SG_THREADS), 0, c->stream, s);
 }
 
+// views mode without validation: pass A leaves a 4-byte entry per line and pass B never reads the input again
+bool views_meta(const bzq_ctx* c) { return c->cfg.views_only && !c->cfg.check_ascii && !c->cfg.check_quality && !c->views_bytes; }
+
 void launch_views(bzq_ctx* c, dim3 grid, int64_t tb, int64_t te) {
     ViewArgs v{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (const int64_t*)c->tileP.p,
                (int64_t*)c->off[0].p, (int64_t*)c->off[1].p, (int64_t*)c->off[2].p, (int64_t*)c->off[3].p,
-               (int64_t*)c->rec_end.p, (int64_t*)c->id_start.p, (int32_t*)c->id_len.p, c->rec_cap, c->d_state,
-               (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper, c->force_dense};
+               (int64_t*)c->rec_end.p, (int64_t*)c->id_start.p, (int32_t*)c->id_len.p, nullptr, c->rec_cap, c->d_state,
+               (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper, c->force_dense, nullptr};
+    if (views_meta(c)) {
+        MetaArgs m{c->cur, c->cur_prev_byte, (int64_t)c->cur_n, tb, te, (const uint32_t*)c->tile_c.p, (const u64*)c->tile_idc.p, (const int64_t*)c->tileP.p,
+                   (const uint32_t*)c->entries.p, (int64_t*)c->off[0].p, (int64_t*)c->off[1].p, (int64_t*)c->off[2].p,
+                   (int64_t*)c->off[3].p, (int64_t*)c->rec_end.p, (int64_t*)c->id_start.p, (int64_t*)c->ends.p, c->rec_cap,
+                   c->d_state};
+        hipLaunchKernelGGL(k_views_meta, dim3((unsigned)((te - tb + META_TILES - 1) / META_TILES)), dim3(BLOCK), 0, c->stream, m);
+        // tiles with more newlines than entries fit (or force_dense): byte-level kernel over the list, usually empty
+        v.id_end = (int64_t*)c->ends.p; v.list = (const int64_t*)c->tile_list.p;
+        hipLaunchKernelGGL((k_views<false, false>), dim3((unsigned)std::min<int64_t>(te - tb, (int64_t)c->num_cu * 4)), dim3(BLOCK), 0,
+                           c->stream, v);
+        return;
+    }
     const bool ca = c->cfg.check_ascii != 0, cq = c->cfg.check_quality != 0;
     if (ca && cq) hipLaunchKernelGGL((k_views<true, true>), grid, dim3(BLOCK), 0, c->stream, v);
     else if (ca) hipLaunchKernelGGL((k_views<true, false>), grid, dim3(BLOCK), 0, c->stream, v);
@@ -334,7 +352,11 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
             if (!skip_aggregate_mid) {
                 AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p,
                           (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
-                if (c->cfg.views_only) hipLaunchKernelGGL(k_tile_count, grid, dim3(BLOCK), 0, c->stream, a);
+                if (views_meta(c)) {
+                    LineArgs la{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
+                                (u64*)c->tile_idc.p, (uint32_t*)c->entries.p, (int64_t*)c->tile_list.p, c->d_state, c->force_dense};
+                    hipLaunchKernelGGL(k_tile_lines, grid, dim3(BLOCK), 0, c->stream, la);
+                } else if (c->cfg.views_only) hipLaunchKernelGGL(k_tile_count, grid, dim3(BLOCK), 0, c->stream, a);
                 else if (c->v2) hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
                 else hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
             }
@@ -381,7 +403,9 @@ void enqueue_rebase(bzq_ctx* c) {
         ViewCheckArgs va{(const int64_t*)c->off[0].p, (const int64_t*)c->off[1].p, (const int64_t*)c->off[2].p,
                          (const int64_t*)c->off[3].p, (const int64_t*)c->rec_end.p, c->cur_first_header,
                          growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->rec_cap, c->d_state, c->cur,
-                         c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper};
+                         c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper,
+                         views_meta(c) ? (int64_t*)c->id_start.p : nullptr, views_meta(c) ? (const int64_t*)c->ends.p : nullptr,
+                         (int32_t*)c->id_len.p, (int64_t)c->cur_n, c->cur_prev_byte};
         hipLaunchKernelGGL(k_views_check, dim3((unsigned)(c->num_cu * 8)), dim3(BLOCK), 0, c->stream, va);
         return;
     }
@@ -576,7 +600,7 @@ void bzq_destroy(bzq_ctx* c) {
     DevBuf* bufs[] = {&c->in, &c->seq, &c->qual, &c->id, &c->ends, &c->id_ends, &c->rec_end, &c->b_ends,
                       &c->b_id_ends, &c->off[0], &c->off[1], &c->off[2], &c->off[3], &c->view_e, &c->view_i,
                       &c->tile_c, &c->tile_a,
-                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc, &c->consumer_scratch, &c->gen_prefix, &c->id_start, &c->id_len};
+                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc, &c->consumer_scratch, &c->gen_prefix, &c->id_start, &c->id_len, &c->entries, &c->tile_list};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->d_state) hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);
@@ -612,6 +636,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "single_pass")) c->single_pass = (int)value;
     else if (!strcmp(key, "kernels_v2")) c->v2 = (int)value;
     else if (!strcmp(key, "ablate")) c->ablate = (int)value;
+    else if (!strcmp(key, "views_bytes")) c->views_bytes = (int)value;
     else if (!strcmp(key, "overlap")) c->overlap = (int)value;
     else if (!strcmp(key, "pass_bytes")) c->cfg.pass_bytes = value > 0 ? std::max<int64_t>(TILE, (value / TILE) * TILE) : 0;
     else { c->err = std::string("unknown option ") + key; return BZQ_ERR_ARG; }

@@ -66,6 +66,8 @@ struct ChunkState {
     // running totals between the passes of one chunk (pass_bytes): P, S, Q, I, last tile with a newline + 1;
     // pass k reads slot k & 1 and leaves slot (k + 1) & 1
     int64_t pass_carry[2][5];
+    // views mode: number of tiles on the list of tiles that must take the byte-level kernel (too many newlines)
+    unsigned long long listed_tiles;
 };
 
 __device__ __forceinline__ bool is_posix_space(uint32_t c) {

@@ -27,11 +27,174 @@ struct ViewArgs {
     int64_t* rec_end;
     int64_t* id_start;
     int32_t* id_len;
+    int64_t* id_end;       // metadata pipeline only (else nullptr)
     int64_t rec_cap;
     ChunkState* st;
     uint32_t q_lower, q_upper;
     int32_t force_dense;
+    const int64_t* list;   // != nullptr: process the tiles list[0 .. st->listed_tiles) (grid-stride), always byte by byte
 };
+
+// ---- line entries: what pass A leaves behind for every newline, so that pass B never looks at the bytes again ----------
+// bits 0-13  tile offset of the newline
+// bit  14/15 the byte after it (the first byte of the next line) is '@' / '+'
+// bits 16-23 number of POSIX-space bytes that follow that first byte (the next line's leading id spaces), saturating
+// bits 24-31 number of POSIX-space bytes just before the newline (this line's trailing id spaces), saturating
+constexpr int ENT_STRIDE = 1024;           // entries per tile; slot 1023 of tile 0 describes the line that starts the chunk
+constexpr int MAXE = 1020;                 // more newlines in a tile: the tile goes on the list for the byte-level kernel
+constexpr int64_t ID_SAT = (int64_t)1 << 62;   // marks an id boundary whose space run saturated: recomputed from the bytes
+
+struct LineArgs {
+    const uint8_t* g;
+    int64_t n;
+    uint32_t prev_byte;
+    int64_t tile_begin, tile_end;
+    uint32_t* tile_c;
+    u64* tile_a;
+    u64* tile_idc;
+    uint32_t* entries;     // [tiles][ENT_STRIDE]
+    int64_t* list;         // tiles for the byte-level kernel
+    ChunkState* st;
+    int32_t force_dense;
+};
+
+__device__ __forceinline__ uint32_t line_start_info(const ByteSrc& b, int64_t s) {   // s = first byte of a line
+    if (s >= b.n) return 0u;
+    const uint32_t c0 = b.at(s);
+    uint32_t lead = 0;
+    for (int64_t p = s + 1; p < b.n && lead < 255u; ++p) {
+        const uint32_t c = b.at(p);
+        if (c == 10u || !is_posix_space(c)) break;
+        ++lead;
+    }
+    return (c0 == 64u ? 1u << 14 : 0u) | (c0 == 43u ? 1u << 15 : 0u) | (lead << 16);
+}
+
+// Pass A of the metadata pipeline: the ONLY kernel that reads the input.  One workgroup per tile; every thread owns the
+// newlines of its 64 bytes.
+__global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
+    __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
+    __shared__ uint32_t s_w[BLOCK / 64];
+    uint8_t* s_tile = s_tile_raw + 16;
+    const int tid = threadIdx.x;
+    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    if (t >= a.tile_end) return;
+    const int64_t t0 = t * TILE;
+    const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+    uint4 r[4];
+    tile_fetch(a.g, a.n, t0, valid, r);
+    tile_stage<true>(r, valid, s_mask, s_tile);
+    ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
+    __syncthreads();
+    const u64 m64 = reinterpret_cast<const u64*>(s_mask)[tid];
+    uint32_t c = 0;
+    const uint32_t excl = block_exclusive_scan<uint32_t, BLOCK / 64>((uint32_t)__popcll(m64), s_w, c);
+    const bool listed = ((int)c > MAXE) || a.force_dense;
+    if (tid == 0) {
+        a.tile_c[t] = c; a.tile_a[t] = 0ull; a.tile_idc[t] = listed ? 1ull : 0ull;   // tile_idc doubles as the 'listed' mark
+        if (listed) a.list[atomicAdd(&a.st->listed_tiles, 1ull)] = t;
+        if (t == 0) a.entries[ENT_STRIDE - 1] = line_start_info(bs, 0);   // the line that starts the chunk
+    }
+    if (listed) return;
+    u64 m = m64;
+    uint32_t idx = excl;
+    while (m) {
+        const int bit = __builtin_ctzll(m);
+        m &= m - 1;
+        const int pos = tid * 64 + bit;
+        const int64_t gp = t0 + pos;
+        uint32_t trail = 0;
+        for (int64_t p = gp - 1; trail < 255u; --p) {
+            const uint32_t ch = bs.at(p);
+            if (ch == 10u || !is_posix_space(ch)) break;
+            ++trail;
+        }
+        a.entries[t * ENT_STRIDE + idx] = (uint32_t)pos | line_start_info(bs, gp + 1) | (trail << 24);
+        ++idx;
+    }
+}
+
+struct MetaArgs {
+    const uint8_t* g;      // only for the seam behind a listed tile (below)
+    uint32_t prev_byte;
+    int64_t n;
+    int64_t tile_begin, tile_end;
+    const uint32_t* tile_c;
+    const u64* tile_listed;
+    const int64_t* tileP;
+    const uint32_t* entries;
+    int64_t* o_hdr;
+    int64_t* o_seq;
+    int64_t* o_sep;
+    int64_t* o_qual;
+    int64_t* rec_end;
+    int64_t* id_start;     // first kept id byte (| ID_SAT)
+    int64_t* id_end;       // one past the last kept id byte (| ID_SAT)
+    int64_t rec_cap;
+    ChunkState* st;
+};
+
+constexpr int META_TILES = 8;
+
+// Pass B of the metadata pipeline: record indices meet the line entries.  Touches 4 bytes per line, writes the offsets.
+__global__ __launch_bounds__(BLOCK) void k_views_meta(MetaArgs a) {
+    const int tid = threadIdx.x;
+    u64 e_struct = ~0ull;
+    bool overflow = false;
+    // META_TILES consecutive tiles per workgroup: a tile is only ~200 lines of 4 bytes
+  for (int64_t t = a.tile_begin + (int64_t)blockIdx.x * META_TILES, te = t + META_TILES; t < te && t < a.tile_end; ++t) {
+    const int c = (int)a.tile_c[t];
+    if (a.tile_listed[t]) continue;   // on the list: the byte-level kernel does this tile
+    const int64_t P = a.tileP[t], t0 = t * TILE;
+    // the line that starts at global offset s (first byte info in `e`): global line index L
+    auto start_side = [&](int64_t L, int64_t s, uint32_t e) {
+        if (L < 0 || s >= a.n) return;
+        const int64_t rec = L >> 2;
+        if (rec >= a.rec_cap) { overflow = true; return; }
+        switch ((int)(L & 3)) {
+            case 0: {
+                a.o_hdr[rec] = s;
+                if (!(e & (1u << 14))) { const u64 k = ((u64)rec << 3) | 1ull; e_struct = k < e_struct ? k : e_struct; }
+                const uint32_t lead = (e >> 16) & 0xFFu;
+                a.id_start[rec] = (s + 1 + (int64_t)lead) | (lead == 255u ? ID_SAT : 0);
+                break;
+            }
+            case 1: a.o_seq[rec] = s; break;
+            case 2:
+                a.o_sep[rec] = s;
+                if (!(e & (1u << 15))) { const u64 k = ((u64)rec << 3) | 2ull; e_struct = k < e_struct ? k : e_struct; }
+                break;
+            default: a.o_qual[rec] = s; break;
+        }
+    };
+    if (t == 0 && tid == 0) start_side(P, 0, a.entries[ENT_STRIDE - 1]);
+    // seam: a line that starts on this tile's first byte is announced by the newline that ends the PREVIOUS tile; when
+    // that tile is on the list (the byte-level kernel only writes the lines that start inside its own tile) it is
+    // taken from the bytes here
+    if (t > 0 && tid == 0 && a.tile_listed[t - 1] && a.g[t0 - 1] == 10u) {
+        ByteSrc bs{a.g, a.n, a.prev_byte, nullptr, 0, 0};
+        start_side(P, t0, line_start_info(bs, t0));
+    }
+    for (int j = tid; j < c; j += BLOCK) {
+        const uint32_t e = a.entries[t * ENT_STRIDE + j];
+        const int64_t gp = t0 + (int64_t)(e & 0x3FFFu);
+        const int64_t L = P + j;               // the line this newline ends
+        if (L >= 0) {
+            const int64_t rec = L >> 2;
+            if (rec >= a.rec_cap) overflow = true;
+            else if ((L & 3) == 3) a.rec_end[rec] = gp;
+            else if ((L & 3) == 0) {
+                const uint32_t trail = e >> 24;
+                a.id_end[rec] = (gp - (int64_t)trail) | (trail == 255u ? ID_SAT : 0);
+            }
+        }
+        start_side(L + 1, gp + 1, e);
+    }
+  }
+    if (e_struct != ~0ull) atomicMin(&a.st->err_struct, e_struct);
+    if (overflow) atomicOr(&a.st->rec_overflow, 1);
+}
 
 __global__ __launch_bounds__(BLOCK) void k_tile_count(AggArgs a) {
     __shared__ uint32_t s_w[BLOCK / 64];
@@ -103,8 +266,12 @@ __global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
     __shared__ uint16_t s_pline[(CA || CQ) ? PIECES : 1];
     uint8_t* s_tile = s_tile_raw + 16;
     const int tid = threadIdx.x;
-    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
-    if (t >= a.tile_end) return;
+  for (int64_t li = blockIdx.x;; li += gridDim.x) {
+    int64_t t = a.tile_begin + li;
+    if (a.list) {
+        if (li >= (int64_t)a.st->listed_tiles) return;
+        t = a.list[li];
+    } else if (li >= (int64_t)gridDim.x || t >= a.tile_end) return;
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     const int64_t P = a.tileP[t];
@@ -119,7 +286,7 @@ __global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
     const u64 m64 = s_mask64[tid];
     uint32_t c = 0;
     const uint32_t excl = block_exclusive_scan<uint32_t, BLOCK / 64>((uint32_t)__popcll(m64), s_w, c);
-    const bool dense = ((int)c > MAXL_V) || a.force_dense;
+    const bool dense = ((int)c > MAXL_V) || a.force_dense || a.list != nullptr;
     ErrAcc err{~0ull, ~0ull};
     bool overflow = false;
     if ((CA || CQ) && !dense) {
@@ -144,12 +311,22 @@ __global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
                 if (s_tile[start] != 64) err.structure(rec, 1);   // '@', utils.mojo:454
                 if (in_cap) a.o_hdr[rec] = ls;
             }
+            if (sin && !end_in && a.id_end) {
+                // metadata pipeline, listed tile: the line ends in a later tile whose entries only know its END
+                int64_t lo = ls + 1;
+                while (lo < a.n && bs.at(lo) != 10u && is_posix_space(bs.at(lo))) ++lo;
+                if (in_cap) a.id_start[rec] = lo;
+            }
             if (end_in) {   // the header line ends here: its stripped id as a span of the chunk
                 int64_t h0 = ls;
                 if (!sknown) { h0 = t0; while (bs.at(h0 - 1) != 10u) --h0; }   // started in an earlier tile
                 int64_t lo, hi;
                 id_span(bs, h0, t0 + end, lo, hi);
-                if (in_cap) { a.id_start[rec] = lo; a.id_len[rec] = (int32_t)(hi - lo); }
+                if (in_cap) {
+                    a.id_start[rec] = lo;
+                    if (a.id_end) a.id_end[rec] = hi;   // metadata pipeline: k_views_check turns (start, end) into a length
+                    else a.id_len[rec] = (int32_t)(hi - lo);
+                }
             }
             if (CA) {   // ascii covers the kept id bytes only: their range within this tile
                 int64_t lo = ls, hi = ls;
@@ -240,6 +417,9 @@ __global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
     if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
     if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
     if (overflow) atomicOr(&a.st->rec_overflow, 1);
+    if (!a.list) return;
+    __syncthreads();   // next listed tile: everyone is done with the LDS tile
+  }
 }
 
 struct ViewCheckArgs {
@@ -253,6 +433,12 @@ struct ViewCheckArgs {
     const uint8_t* g;
     int32_t compat_w;
     uint32_t q_upper;
+    // metadata pipeline: id_start / id_end (with ID_SAT marks) -> id_start, id_len; nullptr otherwise
+    int64_t* id_start;
+    const int64_t* id_end;
+    int32_t* id_len;
+    int64_t n;
+    uint32_t prev_byte;
 };
 
 // Grid-stride over the complete records (their count comes from the device state, like k_rebase).
@@ -266,6 +452,16 @@ __global__ __launch_bounds__(BLOCK) void k_views_check(ViewCheckArgs a) {
         if (seq_len != qual_len) atomicMin(&a.st->err_struct, ((u64)r << 3) | 3ull);   // utils.mojo:458-461
         const int64_t prev = r ? a.rec_end[r - 1] : a.first_header - 1;
         if (re - prev > a.len_limit) atomicMin(&a.st->err_buf, (u64)r << 3);
+        if (a.id_end) {
+            int64_t lo = a.id_start[r], hi = a.id_end[r];
+            if ((lo | hi) & ID_SAT) {   // a space run of 255+ bytes: recompute the span from the bytes
+                ByteSrc bs{a.g, a.n, a.prev_byte, nullptr, 0, 0};
+                id_span(bs, a.o_hdr[r], a.o_seq[r] - 1, lo, hi);
+            }
+            if (hi < lo) hi = lo;        // an id of nothing but spaces: the two runs overlap
+            a.id_start[r] = lo;
+            a.id_len[r] = (int32_t)(hi - lo);
+        }
         if (a.compat_w > 0) {   // SIMD-width quirk of the quality check, as in k_rebase
             const int64_t qs = re - qual_len, body = (qual_len / a.compat_w) * a.compat_w;
             for (int64_t i = 0; i < body; ++i)
@@ -277,6 +473,19 @@ __global__ __launch_bounds__(BLOCK) void k_views_check(ViewCheckArgs a) {
         a.st->last_record_end = n_rec ? a.rec_end[n_rec - 1] : a.first_header - 1;
         a.st->last_ends = 0;
         a.st->last_id_ends = 0;
+        // the record after the complete ones may still be delivered (unterminated last record, parser.mojo:464-475):
+        // its header line is complete whenever at least one more newline follows
+        if (a.id_end && lines > 4 * n_rec && n_rec < a.rec_cap) {
+            const int64_t r = n_rec;
+            int64_t lo = a.id_start[r], hi = a.id_end[r];
+            if ((lo | hi) & ID_SAT) {
+                ByteSrc bs{a.g, a.n, a.prev_byte, nullptr, 0, 0};
+                id_span(bs, a.o_hdr[r], a.o_seq[r] - 1, lo, hi);
+            }
+            if (hi < lo) hi = lo;
+            a.id_start[r] = lo;
+            a.id_len[r] = (int32_t)(hi - lo);
+        }
     }
 }
 

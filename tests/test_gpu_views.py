@@ -17,8 +17,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CORPUS = json.load(open(os.path.join(HERE, "golden", "corpus_expected.json")))
 
 
-def test_views_inline_known_answers():
+@pytest.mark.parametrize("bytes_path", [0, 1])
+def test_views_inline_known_answers(bytes_path):
     ctx, oc = make_pair(views_only=True, single_pass=False)
+    ctx.set_option("views_bytes", bytes_path)   # 0: line entries left by pass A (one read of the input); 1: two reads
     for data in (b"@r1\nACGT\n+\n!!!!\n@r2\nTGCA\n+\n####\n", b"", b"\n", b"@", b"@a\nA\n+\n!\n",
                  b"r1\nACGT\n+\n!!!!\n", b"@r1\nACGT\n+\n!!!\n", b"@r1\nACGT\n-\n!!!!\n",
                  b"@a\nAC\n+\n!!\n@b\nACGT\n+\n!!", b"@a\nAC\n+\n!!\n@b\nAC\n+\n \t", b"@a\nAC\n+\n!!\n\n",
@@ -38,6 +40,8 @@ def test_views_corpus(cfgname, corpus_dir):
               "cap64": dict(buffer_capacity=64),
               "cap64_growth": dict(buffer_capacity=64, buffer_growth_enabled=True, buffer_max_capacity=1 << 20)}[cfgname]
         ctx, oc = make_pair(views_only=True, single_pass=False, **kw)
+        if cfgname in ("cap64",):
+            ctx.set_option("views_bytes", 1)
         res, f = check_views_against_oracle(ctx, oc, data, what=f"{name}/{cfgname}")
         g = e[cfgname]
         assert (int(res.n_records), res.status, ctx.format_error().decode("latin-1") if res.status else "") == \
@@ -58,11 +62,57 @@ def test_views_fuzz(seed):
                    dict(check_ascii=True, check_quality=True, quality_schema="solexa", compat_simd_width=16),
                    dict(buffer_capacity=48), dict(buffer_capacity=48, buffer_growth_enabled=True, buffer_max_capacity=200)):
             ctx, oc = make_pair(views_only=True, single_pass=False, batch_size=int(rng.choice([1, 3, 4096])), **kw)
+            ctx.set_option("views_bytes", int(rng.random() < 0.3))
             check_views_against_oracle(ctx, oc, data, what=f"seed{seed}/{rep}/{kw}")
             check_views_against_oracle(ctx, oc, data, is_eof=False, what=f"chunk seed{seed}/{rep}/{kw}")
             if rep in (0, 4):
                 ctx.set_option("force_dense", 1)
                 check_views_against_oracle(ctx, oc, data, what=f"dense seed{seed}/{kw}")
+            ctx.close()
+
+
+def test_views_long_space_runs_saturate_the_line_entries():
+    """Id space runs of 255+ bytes do not fit a line entry: the span is recomputed from the bytes."""
+    recs = []
+    for i, (lead, trail) in enumerate([(0, 0), (254, 3), (255, 0), (0, 255), (300, 700), (5000, 1), (20000, 20000), (256, 256)]):
+        recs.append(b"@" + b" " * lead + (b"id%d" % i if i != 6 else b"") + b"\t" * trail + b"\nACGT\n+\nIIII\n")
+    data = b"".join(recs)
+    for bp in (0, 1):
+        ctx, oc = make_pair(views_only=True, single_pass=False)
+        ctx.set_option("views_bytes", bp)
+        res, f = check_views_against_oracle(ctx, oc, data, what="space runs")
+        assert f.n_records == 8
+        ctx.close()
+
+
+def test_views_seams_between_listed_and_entry_tiles():
+    """Found by tests/fuzz_campaign.py --views (seed 37): a tile with more newlines than line entries fit goes through
+    the byte-level kernel, its neighbours through the entries; lines (and header ids) that straddle such a seam, or
+    start exactly on it, must be written by exactly one of them."""
+    rec = b"@r\nACGT\n+\nIIII\n"                      # 15 bytes, 4 newlines: ~4400 newlines per tile -> listed
+    sparse = b"@read with a long id %d\n" + b"ACGT" * 40 + b"\n+\n" + b"I" * 160 + b"\n"
+    for role in range(4):
+        ends = [2, 7, 9, 14]
+        body = rec * (16384 // 15 - 2)
+        need = 16383 - (len(body) + ends[role])
+        dense = b"@" + b"x" * (need - 14) + b"\nACGT\n+\nIIII\n" + body + rec   # newline of line `role` of the last rec on byte 16383
+        data = dense + b"".join(sparse % i for i in range(200)) + rec * 3000 + b"".join(sparse % i for i in range(100))
+        d = np.frombuffer(data, dtype=np.uint8)
+        assert d[16383] == 10
+        for bp in (0, 1):
+            ctx, oc = make_pair(views_only=True, single_pass=False)
+            ctx.set_option("views_bytes", bp)
+            check_views_against_oracle(ctx, oc, d, what=f"seam role {role}")
+            ctx.close()
+    # header lines that start in a listed tile and end in an entry tile, and the reverse, with space runs in the id
+    for shift in range(0, 40, 3):
+        head = rec * ((16384 - 20 - shift) // 15)
+        hdr = b"@" + b" " * 7 + b"id across the seam" + b"\t" * 9 + b"\nACGT\n+\nIIII\n"
+        data = head + hdr + b"".join(sparse % i for i in range(120)) + hdr * 3 + rec * 1200
+        for bp in (0, 1):
+            ctx, oc = make_pair(views_only=True, single_pass=False)
+            ctx.set_option("views_bytes", bp)
+            check_views_against_oracle(ctx, oc, np.frombuffer(data, dtype=np.uint8), what=f"seam header {shift}")
             ctx.close()
 
 
