@@ -84,6 +84,8 @@ struct bzq_ctx {
     std::vector<hipEvent_t> ev_detail;
     // options
     int ablate = 0;
+    int64_t pool_slots = 0;
+    bool views_bytes_once = false;   // this chunk is being repeated on the byte-level kernels (pool ran out)
     int views_bytes = 0;   // option: views mode through the two-read kernels even without validation (cross-check)
     int force_dense = 0, timing_detail = 0, single_pass = 0, v2 = 1, num_cu = 256;
     bool ran_single_pass = false;
@@ -148,8 +150,10 @@ int ensure_chunk_arenas(bzq_ctx* c, uint64_t n, bool need_input) {
             return rc;
         c->tile_cap = nt;
     }
-    if (c->cfg.views_only && ((rc = ensure(c, c->entries, (size_t)nt * ENT_STRIDE * 4)) || (rc = ensure(c, c->tile_list, (size_t)nt * 8))))
-        return rc;
+    if (c->cfg.views_only) {   // line entries: a 4 KiB slot per tile + a pool of 64 KiB slots for tiles of tiny records
+        c->pool_slots = std::max<int64_t>(16, nt / 8);
+        if ((rc = ensure(c, c->entries, (size_t)nt * ENT_STRIDE * 4)) || (rc = ensure(c, c->tile_list, (size_t)c->pool_slots * TILE * 4))) return rc;
+    }
     return 0;
 }
 
@@ -300,25 +304,25 @@ void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, int pass) {
 }
 
 // views mode without validation: pass A leaves a 4-byte entry per line and pass B never reads the input again
-bool views_meta(const bzq_ctx* c) { return c->cfg.views_only && !c->cfg.check_ascii && !c->cfg.check_quality && !c->views_bytes; }
+bool views_meta(const bzq_ctx* c) {
+    return c->cfg.views_only && !c->cfg.check_ascii && !c->cfg.check_quality && !c->views_bytes && !c->views_bytes_once;
+}
 
 void launch_views(bzq_ctx* c, dim3 grid, int64_t tb, int64_t te) {
-    ViewArgs v{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (const int64_t*)c->tileP.p,
-               (int64_t*)c->off[0].p, (int64_t*)c->off[1].p, (int64_t*)c->off[2].p, (int64_t*)c->off[3].p,
-               (int64_t*)c->rec_end.p, (int64_t*)c->id_start.p, (int32_t*)c->id_len.p, nullptr, c->rec_cap, c->d_state,
-               (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper, c->force_dense, nullptr};
     if (views_meta(c)) {
-        MetaArgs m{c->cur, c->cur_prev_byte, (int64_t)c->cur_n, tb, te, (const uint32_t*)c->tile_c.p, (const u64*)c->tile_idc.p, (const int64_t*)c->tileP.p,
-                   (const uint32_t*)c->entries.p, (int64_t*)c->off[0].p, (int64_t*)c->off[1].p, (int64_t*)c->off[2].p,
-                   (int64_t*)c->off[3].p, (int64_t*)c->rec_end.p, (int64_t*)c->id_start.p, (int64_t*)c->ends.p, c->rec_cap,
-                   c->d_state};
-        hipLaunchKernelGGL(k_views_meta, dim3((unsigned)((te - tb + META_TILES - 1) / META_TILES)), dim3(BLOCK), 0, c->stream, m);
-        // tiles with more newlines than entries fit (or force_dense): byte-level kernel over the list, usually empty
-        v.id_end = (int64_t*)c->ends.p; v.list = (const int64_t*)c->tile_list.p;
-        hipLaunchKernelGGL((k_views<false, false>), dim3((unsigned)std::min<int64_t>(te - tb, (int64_t)c->num_cu * 4)), dim3(BLOCK), 0,
-                           c->stream, v);
+        const bool growth = c->cfg.buffer_growth_enabled != 0;
+        JoinArgs j{c->cur, c->cur_prev_byte, (int64_t)c->cur_n, tb, te, tiles_for(c->cur_n), (const uint32_t*)c->tile_c.p,
+                   (const u64*)c->tile_idc.p, (const int64_t*)c->tileP.p, (const uint32_t*)c->entries.p,
+                   (const uint32_t*)c->tile_list.p, (int64_t*)c->off[0].p, (int64_t*)c->off[1].p, (int64_t*)c->off[2].p,
+                   (int64_t*)c->off[3].p, (int64_t*)c->rec_end.p, (int64_t*)c->id_start.p, (int32_t*)c->id_len.p, c->rec_cap,
+                   c->cur_first_header, growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->d_state};
+        hipLaunchKernelGGL(k_views_join, dim3((unsigned)((te - tb + JOIN_TILES - 1) / JOIN_TILES)), dim3(BLOCK), 0, c->stream, j);
         return;
     }
+    ViewArgs v{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (const int64_t*)c->tileP.p,
+               (int64_t*)c->off[0].p, (int64_t*)c->off[1].p, (int64_t*)c->off[2].p, (int64_t*)c->off[3].p,
+               (int64_t*)c->rec_end.p, (int64_t*)c->id_start.p, (int32_t*)c->id_len.p, c->rec_cap, c->d_state,
+               (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper, c->force_dense};
     const bool ca = c->cfg.check_ascii != 0, cq = c->cfg.check_quality != 0;
     if (ca && cq) hipLaunchKernelGGL((k_views<true, true>), grid, dim3(BLOCK), 0, c->stream, v);
     else if (ca) hipLaunchKernelGGL((k_views<true, false>), grid, dim3(BLOCK), 0, c->stream, v);
@@ -354,7 +358,8 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
                           (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
                 if (views_meta(c)) {
                     LineArgs la{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
-                                (u64*)c->tile_idc.p, (uint32_t*)c->entries.p, (int64_t*)c->tile_list.p, c->d_state, c->force_dense};
+                                (u64*)c->tile_idc.p, (uint32_t*)c->entries.p, (uint32_t*)c->tile_list.p, c->pool_slots, c->d_state,
+                                c->force_dense};
                     hipLaunchKernelGGL(k_tile_lines, grid, dim3(BLOCK), 0, c->stream, la);
                 } else if (c->cfg.views_only) hipLaunchKernelGGL(k_tile_count, grid, dim3(BLOCK), 0, c->stream, a);
                 else if (c->v2) hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
@@ -399,13 +404,12 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
 
 void enqueue_rebase(bzq_ctx* c) {
     const bool growth = c->cfg.buffer_growth_enabled != 0;
+    if (views_meta(c)) return;   // the join kernel did the per-record checks and the chunk totals
     if (c->cfg.views_only) {
         ViewCheckArgs va{(const int64_t*)c->off[0].p, (const int64_t*)c->off[1].p, (const int64_t*)c->off[2].p,
                          (const int64_t*)c->off[3].p, (const int64_t*)c->rec_end.p, c->cur_first_header,
                          growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->rec_cap, c->d_state, c->cur,
-                         c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper,
-                         views_meta(c) ? (int64_t*)c->id_start.p : nullptr, views_meta(c) ? (const int64_t*)c->ends.p : nullptr,
-                         (int32_t*)c->id_len.p, (int64_t)c->cur_n, c->cur_prev_byte};
+                         c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper};
         hipLaunchKernelGGL(k_views_check, dim3((unsigned)(c->num_cu * 8)), dim3(BLOCK), 0, c->stream, va);
         return;
     }
@@ -424,6 +428,7 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     if ((rc = ensure_chunk_arenas(c, n, false))) return rc;
     int64_t want = (int64_t)(n / (uint64_t)std::max(4, c->cfg.min_record_bytes)) + 1024;
     if ((rc = ensure_record_arenas(c, want))) return rc;
+    c->views_bytes_once = false;
     c->cur = d_data; c->cur_n = n; c->cur_stream_pos = stream_pos; c->cur_is_eof = is_eof;
     c->cur_prev_byte = prev_byte; c->cur_first_header = first_header;
     for (hipEvent_t e : c->ev_detail) hipEventDestroy(e);
@@ -690,6 +695,23 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
         int rc;
         c->ran_single_pass = false;
+        if ((rc = enqueue_passes(c, false, false))) return rc;
+        hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)c->cur_n, c->d_state);
+        enqueue_rebase(c);
+        HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (h->views_fallback && c->cur_n > 0) {
+        // views mode, a chunk of records of a few bytes: more tiles needed a big entry slot than the pool has.  Same
+        // chunk again on the byte-level views kernels (two reads of the input).
+        ChunkState fresh = *h;
+        fresh.P = fresh.P0; fresh.S = fresh.S0; fresh.Q = fresh.Q0; fresh.I = fresh.I0;
+        fresh.last_nl_tile = -1; fresh.rec_overflow = 0; fresh.views_fallback = 0; fresh.listed_tiles = 0; fresh.dense_tiles = 0;
+        fresh.err_struct = ~0ull; fresh.err_valid = ~0ull; fresh.err_buf = ~0ull;
+        *h = fresh;
+        HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
+        int rc;
+        c->views_bytes_once = true;
         if ((rc = enqueue_passes(c, false, false))) return rc;
         hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)c->cur_n, c->d_state);
         enqueue_rebase(c);

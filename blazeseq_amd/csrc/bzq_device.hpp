@@ -66,8 +66,11 @@ struct ChunkState {
     // running totals between the passes of one chunk (pass_bytes): P, S, Q, I, last tile with a newline + 1;
     // pass k reads slot k & 1 and leaves slot (k + 1) & 1
     int64_t pass_carry[2][5];
-    // views mode: number of tiles on the list of tiles that must take the byte-level kernel (too many newlines)
+    // views mode: pool slots handed to tiles with more newlines than an ordinary entry slot holds; views_fallback: the
+    // pool ran out (a chunk of records of a few bytes), the host repeats the chunk on the byte-level kernels
     unsigned long long listed_tiles;
+    int32_t views_fallback;
+    int32_t _pad2;
 };
 
 __device__ __forceinline__ bool is_posix_space(uint32_t c) {

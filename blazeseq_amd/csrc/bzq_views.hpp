@@ -14,6 +14,8 @@
 
 namespace bzq {
 
+__device__ inline void id_span(const ByteSrc& b, int64_t ls, int64_t le, int64_t& lo, int64_t& hi);
+
 struct ViewArgs {
     const uint8_t* g;
     int64_t n;
@@ -27,12 +29,10 @@ struct ViewArgs {
     int64_t* rec_end;
     int64_t* id_start;
     int32_t* id_len;
-    int64_t* id_end;       // metadata pipeline only (else nullptr)
     int64_t rec_cap;
     ChunkState* st;
     uint32_t q_lower, q_upper;
     int32_t force_dense;
-    const int64_t* list;   // != nullptr: process the tiles list[0 .. st->listed_tiles) (grid-stride), always byte by byte
 };
 
 // ---- line entries: what pass A leaves behind for every newline, so that pass B never looks at the bytes again ----------
@@ -40,9 +40,8 @@ struct ViewArgs {
 // bit  14/15 the byte after it (the first byte of the next line) is '@' / '+'
 // bits 16-23 number of POSIX-space bytes that follow that first byte (the next line's leading id spaces), saturating
 // bits 24-31 number of POSIX-space bytes just before the newline (this line's trailing id spaces), saturating
-constexpr int ENT_STRIDE = 1024;           // entries per tile; slot 1023 of tile 0 describes the line that starts the chunk
-constexpr int MAXE = 1020;                 // more newlines in a tile: the tile goes on the list for the byte-level kernel
-constexpr int64_t ID_SAT = (int64_t)1 << 62;   // marks an id boundary whose space run saturated: recomputed from the bytes
+constexpr int ENT_STRIDE = 1024;   // entries per ordinary tile; slot 1023 of tile 0 describes the line that starts the chunk
+constexpr int MAXE = 1020;         // a tile with more newlines (records of a few bytes) takes a 16384-entry slot of the pool
 
 struct LineArgs {
     const uint8_t* g;
@@ -51,11 +50,12 @@ struct LineArgs {
     int64_t tile_begin, tile_end;
     uint32_t* tile_c;
     u64* tile_a;
-    u64* tile_idc;
+    u64* tile_idc;         // views mode: 0 = entries in the tile's own slot, k + 1 = in pool slot k
     uint32_t* entries;     // [tiles][ENT_STRIDE]
-    int64_t* list;         // tiles for the byte-level kernel
+    uint32_t* pool;        // [pool_slots][TILE]
+    int64_t pool_slots;
     ChunkState* st;
-    int32_t force_dense;
+    int32_t force_dense;   // test switch: every tile through the pool
 };
 
 __device__ __forceinline__ uint32_t line_start_info(const ByteSrc& b, int64_t s) {   // s = first byte of a line
@@ -76,6 +76,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
     __shared__ uint32_t s_w[BLOCK / 64];
+    __shared__ int64_t s_slot;
     uint8_t* s_tile = s_tile_raw + 16;
     const int tid = threadIdx.x;
     const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
@@ -90,13 +91,20 @@ __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
     const u64 m64 = reinterpret_cast<const u64*>(s_mask)[tid];
     uint32_t c = 0;
     const uint32_t excl = block_exclusive_scan<uint32_t, BLOCK / 64>((uint32_t)__popcll(m64), s_w, c);
-    const bool listed = ((int)c > MAXE) || a.force_dense;
+    const bool pooled = ((int)c > MAXE) || a.force_dense;
     if (tid == 0) {
-        a.tile_c[t] = c; a.tile_a[t] = 0ull; a.tile_idc[t] = listed ? 1ull : 0ull;   // tile_idc doubles as the 'listed' mark
-        if (listed) a.list[atomicAdd(&a.st->listed_tiles, 1ull)] = t;
+        int64_t slot = -1;
+        if (pooled) {
+            slot = (int64_t)atomicAdd(&a.st->listed_tiles, 1ull);
+            if (slot >= a.pool_slots) { slot = -2; a.st->views_fallback = 1; }   // the host repeats the chunk on the byte-level kernels
+        }
+        s_slot = slot;
+        a.tile_c[t] = c; a.tile_a[t] = 0ull; a.tile_idc[t] = slot >= 0 ? (u64)(slot + 1) : 0ull;
         if (t == 0) a.entries[ENT_STRIDE - 1] = line_start_info(bs, 0);   // the line that starts the chunk
     }
-    if (listed) return;
+    __syncthreads();
+    if (s_slot == -2) return;
+    uint32_t* out = s_slot >= 0 ? a.pool + s_slot * TILE : a.entries + t * ENT_STRIDE;
     u64 m = m64;
     uint32_t idx = excl;
     while (m) {
@@ -110,89 +118,134 @@ __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
             if (ch == 10u || !is_posix_space(ch)) break;
             ++trail;
         }
-        a.entries[t * ENT_STRIDE + idx] = (uint32_t)pos | line_start_info(bs, gp + 1) | (trail << 24);
+        out[idx] = (uint32_t)pos | line_start_info(bs, gp + 1) | (trail << 24);
         ++idx;
     }
 }
 
-struct MetaArgs {
-    const uint8_t* g;      // only for the seam behind a listed tile (below)
+struct JoinArgs {
+    const uint8_t* g;      // only for id space runs that saturated an entry
     uint32_t prev_byte;
     int64_t n;
-    int64_t tile_begin, tile_end;
+    int64_t tile_begin, tile_end, n_tiles;
     const uint32_t* tile_c;
-    const u64* tile_listed;
+    const u64* tile_slot;  // tile_idc
     const int64_t* tileP;
     const uint32_t* entries;
+    const uint32_t* pool;
     int64_t* o_hdr;
     int64_t* o_seq;
     int64_t* o_sep;
     int64_t* o_qual;
     int64_t* rec_end;
-    int64_t* id_start;     // first kept id byte (| ID_SAT)
-    int64_t* id_end;       // one past the last kept id byte (| ID_SAT)
-    int64_t rec_cap;
+    int64_t* id_start;
+    int32_t* id_len;
+    int64_t rec_cap, first_header, len_limit;
     ChunkState* st;
 };
 
-constexpr int META_TILES = 8;
+constexpr int JOIN_TILES = 4;   // tiles per workgroup of the join
 
-// Pass B of the metadata pipeline: record indices meet the line entries.  Touches 4 bytes per line, writes the offsets.
-__global__ __launch_bounds__(BLOCK) void k_views_meta(MetaArgs a) {
+// Pass B of the metadata pipeline: one thread per RECORD.  Record r owns the newlines 4r-1 .. 4r+3 (global line index);
+// each is found by its tile (the tile prefixes of the scan) and its rank inside it; the five entries give every offset,
+// both structure bytes, the id span and the length / buffer checks -- 20 bytes read, 52 written, all arrays coalesced.
+// A workgroup takes the records whose LAST newline lies in its JOIN_TILES tiles.
+__global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
+    __shared__ int64_t s_P[JOIN_TILES + 1];
+    __shared__ u64 s_slot[JOIN_TILES];
     const int tid = threadIdx.x;
-    u64 e_struct = ~0ull;
+    const int64_t ta = a.tile_begin + (int64_t)blockIdx.x * JOIN_TILES;
+    if (ta >= a.tile_end) return;
+    const int64_t tb = ta + JOIN_TILES < a.tile_end ? ta + JOIN_TILES : a.tile_end;
+    const int nt = (int)(tb - ta);
+    if (tid < nt) { s_P[tid] = a.tileP[ta + tid]; s_slot[tid] = a.tile_slot[ta + tid]; }
+    if (tid == nt) s_P[nt] = a.tileP[tb - 1] + (int64_t)a.tile_c[tb - 1];
+    __syncthreads();
+    const int64_t Gbeg = s_P[0], Gend = s_P[nt];            // newline indices [Gbeg, Gend) live in this window
+    const int64_t P0 = a.st->P0, lines = a.st->P;             // P0 + all newlines of the chunk
+    u64 e_struct = ~0ull, e_buf = ~0ull;
     bool overflow = false;
-    // META_TILES consecutive tiles per workgroup: a tile is only ~200 lines of 4 bytes
-  for (int64_t t = a.tile_begin + (int64_t)blockIdx.x * META_TILES, te = t + META_TILES; t < te && t < a.tile_end; ++t) {
-    const int c = (int)a.tile_c[t];
-    if (a.tile_listed[t]) continue;   // on the list: the byte-level kernel does this tile
-    const int64_t P = a.tileP[t], t0 = t * TILE;
-    // the line that starts at global offset s (first byte info in `e`): global line index L
-    auto start_side = [&](int64_t L, int64_t s, uint32_t e) {
-        if (L < 0 || s >= a.n) return;
-        const int64_t rec = L >> 2;
-        if (rec >= a.rec_cap) { overflow = true; return; }
-        switch ((int)(L & 3)) {
-            case 0: {
-                a.o_hdr[rec] = s;
-                if (!(e & (1u << 14))) { const u64 k = ((u64)rec << 3) | 1ull; e_struct = k < e_struct ? k : e_struct; }
-                const uint32_t lead = (e >> 16) & 0xFFu;
-                a.id_start[rec] = (s + 1 + (int64_t)lead) | (lead == 255u ? ID_SAT : 0);
-                break;
-            }
-            case 1: a.o_seq[rec] = s; break;
-            case 2:
-                a.o_sep[rec] = s;
-                if (!(e & (1u << 15))) { const u64 k = ((u64)rec << 3) | 2ull; e_struct = k < e_struct ? k : e_struct; }
-                break;
-            default: a.o_qual[rec] = s; break;
+
+    // entry and absolute position of newline G (P0 - 1 = the virtual newline before the chunk's first line)
+    auto locate = [&](int64_t G, int64_t hint, uint32_t& e) -> int64_t {
+        if (G < P0) { e = a.entries[ENT_STRIDE - 1]; return -1; }
+        int64_t tt, j;
+        u64 slot;
+        if (G >= Gbeg) {                                     // inside the window: prefixes and slots are in LDS
+            int w = 0;
+#pragma unroll
+            for (int k = 1; k < JOIN_TILES; ++k) if (k < nt && s_P[k] <= G) w = k;
+            tt = ta + w; j = G - s_P[w]; slot = s_slot[w];
+            (void)hint;
+        } else {                                             // a record that began before the window: a few tiles back
+            tt = ta - 1;
+            while (a.tileP[tt] > G) --tt;
+            j = G - a.tileP[tt]; slot = a.tile_slot[tt];
         }
+        e = slot ? a.pool[(int64_t)(slot - 1) * TILE + j] : a.entries[tt * ENT_STRIDE + j];
+        return tt * TILE + (int64_t)(e & 0x3FFFu);
     };
-    if (t == 0 && tid == 0) start_side(P, 0, a.entries[ENT_STRIDE - 1]);
-    // seam: a line that starts on this tile's first byte is announced by the newline that ends the PREVIOUS tile; when
-    // that tile is on the list (the byte-level kernel only writes the lines that start inside its own tile) it is
-    // taken from the bytes here
-    if (t > 0 && tid == 0 && a.tile_listed[t - 1] && a.g[t0 - 1] == 10u) {
-        ByteSrc bs{a.g, a.n, a.prev_byte, nullptr, 0, 0};
-        start_side(P, t0, line_start_info(bs, t0));
-    }
-    for (int j = tid; j < c; j += BLOCK) {
-        const uint32_t e = a.entries[t * ENT_STRIDE + j];
-        const int64_t gp = t0 + (int64_t)(e & 0x3FFFu);
-        const int64_t L = P + j;               // the line this newline ends
-        if (L >= 0) {
-            const int64_t rec = L >> 2;
-            if (rec >= a.rec_cap) overflow = true;
-            else if ((L & 3) == 3) a.rec_end[rec] = gp;
-            else if ((L & 3) == 0) {
-                const uint32_t trail = e >> 24;
-                a.id_end[rec] = (gp - (int64_t)trail) | (trail == 255u ? ID_SAT : 0);
-            }
+    auto id_of = [&](int64_t hs, uint32_t e_hs, int64_t nl0, uint32_t e_nl0, int64_t& lo, int64_t& hi) {
+        const uint32_t lead = (e_hs >> 16) & 0xFFu, trail = e_nl0 >> 24;
+        lo = hs + 1 + (int64_t)lead; hi = nl0 - (int64_t)trail;
+        if (lead == 255u || trail == 255u) {                 // a space run too long for an entry: from the bytes
+            ByteSrc bs{a.g, a.n, a.prev_byte, nullptr, 0, 0};
+            id_span(bs, hs, nl0, lo, hi);
         }
-        start_side(L + 1, gp + 1, e);
+        if (hi < lo) hi = lo;                                // nothing but spaces: the two runs overlap
+    };
+
+    // complete records whose quality newline 4r+3 is in [Gbeg, Gend)
+    const int64_t r_lo = Gbeg <= 3 ? 0 : (Gbeg - 3 + 3) >> 2;      // ceil((Gbeg - 3) / 4), >= 0
+    const int64_t r_hi = (Gend - 4) >> 2;                           // floor((Gend - 4) / 4), may be < r_lo
+    for (int64_t r = r_lo + tid; r <= r_hi; r += BLOCK) {
+        if (r >= a.rec_cap) { overflow = true; continue; }
+        const int64_t G3 = 4 * r + 3, t3 = ta;
+        uint32_t e3, e2, e1, e0, ep;
+        const int64_t p3 = locate(G3, t3, e3), p2 = locate(G3 - 1, t3, e2), p1 = locate(G3 - 2, t3, e1),
+                      p0 = locate(G3 - 3, t3, e0), pp = locate(G3 - 4, t3, ep);
+        const int64_t hs = pp + 1;
+        a.o_hdr[r] = hs; a.o_seq[r] = p0 + 1; a.o_sep[r] = p1 + 1; a.o_qual[r] = p2 + 1; a.rec_end[r] = p3;
+        int64_t lo, hi;
+        id_of(hs, ep, p0, e0, lo, hi);
+        a.id_start[r] = lo; a.id_len[r] = (int32_t)(hi - lo);
+        // utils.mojo:448-462 in the reference's order: '@', '+', lengths
+        u64 k = ~0ull;
+        if (!(ep & (1u << 14))) k = ((u64)r << 3) | 1ull;
+        else if (!(e1 & (1u << 15))) k = ((u64)r << 3) | 2ull;
+        else if ((p1 - p0 - 1) != (p3 - p2 - 1)) k = ((u64)r << 3) | 3ull;
+        e_struct = k < e_struct ? k : e_struct;
+        const int64_t prev_end = r ? pp : a.first_header - 1;
+        if (p3 - prev_end > a.len_limit) { const u64 kb = (u64)r << 3; e_buf = kb < e_buf ? kb : e_buf; }
     }
-  }
+    // the last workgroup: chunk totals, and the lines of the record that stays incomplete (an unterminated last record
+    // may still be delivered, parser.mojo:464-475)
+    if (tb == a.tile_end && tid == 0) {
+        int64_t n_rec = lines > 0 ? (lines >> 2) : 0;
+        if (n_rec > a.rec_cap) n_rec = a.rec_cap;
+        uint32_t e;
+        a.st->n_complete = n_rec;
+        a.st->last_record_end = n_rec ? locate(4 * n_rec - 1, tb - 1, e) : a.first_header - 1;
+        a.st->last_ends = 0; a.st->last_id_ends = 0;
+        const int64_t r = lines > 0 ? (lines >> 2) : 0;
+        const int k = lines > 0 ? (int)(lines & 3) : 0;      // newlines of the incomplete record
+        if (r < a.rec_cap && lines >= 0) {
+            uint32_t ep, e0, e1, e2;
+            const int64_t pp = locate(4 * r - 1, tb - 1, ep);
+            if (pp + 1 < a.n) a.o_hdr[r] = pp + 1;
+            if (k >= 1) {
+                const int64_t p0 = locate(4 * r, tb - 1, e0);
+                if (p0 + 1 < a.n) a.o_seq[r] = p0 + 1;
+                int64_t lo, hi;
+                id_of(pp + 1, ep, p0, e0, lo, hi);
+                a.id_start[r] = lo; a.id_len[r] = (int32_t)(hi - lo);
+                if (k >= 2) { const int64_t p1 = locate(4 * r + 1, tb - 1, e1); if (p1 + 1 < a.n) a.o_sep[r] = p1 + 1; }
+                if (k >= 3) { const int64_t p2 = locate(4 * r + 2, tb - 1, e2); if (p2 + 1 < a.n) a.o_qual[r] = p2 + 1; }
+            }
+        } else if (r >= a.rec_cap) overflow = true;
+    }
     if (e_struct != ~0ull) atomicMin(&a.st->err_struct, e_struct);
+    if (e_buf != ~0ull) atomicMin(&a.st->err_buf, e_buf);
     if (overflow) atomicOr(&a.st->rec_overflow, 1);
 }
 
@@ -266,12 +319,8 @@ __global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
     __shared__ uint16_t s_pline[(CA || CQ) ? PIECES : 1];
     uint8_t* s_tile = s_tile_raw + 16;
     const int tid = threadIdx.x;
-  for (int64_t li = blockIdx.x;; li += gridDim.x) {
-    int64_t t = a.tile_begin + li;
-    if (a.list) {
-        if (li >= (int64_t)a.st->listed_tiles) return;
-        t = a.list[li];
-    } else if (li >= (int64_t)gridDim.x || t >= a.tile_end) return;
+    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    if (t >= a.tile_end) return;
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     const int64_t P = a.tileP[t];
@@ -286,7 +335,7 @@ __global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
     const u64 m64 = s_mask64[tid];
     uint32_t c = 0;
     const uint32_t excl = block_exclusive_scan<uint32_t, BLOCK / 64>((uint32_t)__popcll(m64), s_w, c);
-    const bool dense = ((int)c > MAXL_V) || a.force_dense || a.list != nullptr;
+    const bool dense = ((int)c > MAXL_V) || a.force_dense;
     ErrAcc err{~0ull, ~0ull};
     bool overflow = false;
     if ((CA || CQ) && !dense) {
@@ -311,22 +360,12 @@ __global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
                 if (s_tile[start] != 64) err.structure(rec, 1);   // '@', utils.mojo:454
                 if (in_cap) a.o_hdr[rec] = ls;
             }
-            if (sin && !end_in && a.id_end) {
-                // metadata pipeline, listed tile: the line ends in a later tile whose entries only know its END
-                int64_t lo = ls + 1;
-                while (lo < a.n && bs.at(lo) != 10u && is_posix_space(bs.at(lo))) ++lo;
-                if (in_cap) a.id_start[rec] = lo;
-            }
             if (end_in) {   // the header line ends here: its stripped id as a span of the chunk
                 int64_t h0 = ls;
                 if (!sknown) { h0 = t0; while (bs.at(h0 - 1) != 10u) --h0; }   // started in an earlier tile
                 int64_t lo, hi;
                 id_span(bs, h0, t0 + end, lo, hi);
-                if (in_cap) {
-                    a.id_start[rec] = lo;
-                    if (a.id_end) a.id_end[rec] = hi;   // metadata pipeline: k_views_check turns (start, end) into a length
-                    else a.id_len[rec] = (int32_t)(hi - lo);
-                }
+                if (in_cap) { a.id_start[rec] = lo; a.id_len[rec] = (int32_t)(hi - lo); }
             }
             if (CA) {   // ascii covers the kept id bytes only: their range within this tile
                 int64_t lo = ls, hi = ls;
@@ -417,9 +456,6 @@ __global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
     if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
     if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
     if (overflow) atomicOr(&a.st->rec_overflow, 1);
-    if (!a.list) return;
-    __syncthreads();   // next listed tile: everyone is done with the LDS tile
-  }
 }
 
 struct ViewCheckArgs {
@@ -433,12 +469,6 @@ struct ViewCheckArgs {
     const uint8_t* g;
     int32_t compat_w;
     uint32_t q_upper;
-    // metadata pipeline: id_start / id_end (with ID_SAT marks) -> id_start, id_len; nullptr otherwise
-    int64_t* id_start;
-    const int64_t* id_end;
-    int32_t* id_len;
-    int64_t n;
-    uint32_t prev_byte;
 };
 
 // Grid-stride over the complete records (their count comes from the device state, like k_rebase).
@@ -452,16 +482,6 @@ __global__ __launch_bounds__(BLOCK) void k_views_check(ViewCheckArgs a) {
         if (seq_len != qual_len) atomicMin(&a.st->err_struct, ((u64)r << 3) | 3ull);   // utils.mojo:458-461
         const int64_t prev = r ? a.rec_end[r - 1] : a.first_header - 1;
         if (re - prev > a.len_limit) atomicMin(&a.st->err_buf, (u64)r << 3);
-        if (a.id_end) {
-            int64_t lo = a.id_start[r], hi = a.id_end[r];
-            if ((lo | hi) & ID_SAT) {   // a space run of 255+ bytes: recompute the span from the bytes
-                ByteSrc bs{a.g, a.n, a.prev_byte, nullptr, 0, 0};
-                id_span(bs, a.o_hdr[r], a.o_seq[r] - 1, lo, hi);
-            }
-            if (hi < lo) hi = lo;        // an id of nothing but spaces: the two runs overlap
-            a.id_start[r] = lo;
-            a.id_len[r] = (int32_t)(hi - lo);
-        }
         if (a.compat_w > 0) {   // SIMD-width quirk of the quality check, as in k_rebase
             const int64_t qs = re - qual_len, body = (qual_len / a.compat_w) * a.compat_w;
             for (int64_t i = 0; i < body; ++i)
@@ -473,19 +493,6 @@ __global__ __launch_bounds__(BLOCK) void k_views_check(ViewCheckArgs a) {
         a.st->last_record_end = n_rec ? a.rec_end[n_rec - 1] : a.first_header - 1;
         a.st->last_ends = 0;
         a.st->last_id_ends = 0;
-        // the record after the complete ones may still be delivered (unterminated last record, parser.mojo:464-475):
-        // its header line is complete whenever at least one more newline follows
-        if (a.id_end && lines > 4 * n_rec && n_rec < a.rec_cap) {
-            const int64_t r = n_rec;
-            int64_t lo = a.id_start[r], hi = a.id_end[r];
-            if ((lo | hi) & ID_SAT) {
-                ByteSrc bs{a.g, a.n, a.prev_byte, nullptr, 0, 0};
-                id_span(bs, a.o_hdr[r], a.o_seq[r] - 1, lo, hi);
-            }
-            if (hi < lo) hi = lo;
-            a.id_start[r] = lo;
-            a.id_len[r] = (int32_t)(hi - lo);
-        }
     }
 }
 
