@@ -283,6 +283,25 @@ def main():
                        "kernels_total": round(ms_kernels / steps, 4)},
             },
         }
+        if world == 1 and not args.views and not args.ablate and not sharded_mode:
+            # the same input through views mode (parser.views(): offsets + id spans into the chunk, no columns), as an
+            # extra figure next to the headline batch-mode `value`
+            vcfg = B.ParserConfig(check_ascii=args.validate, check_quality=args.validate,
+                                  quality_schema="sanger" if args.validate else None, views_only=True)
+            vctx = B.Context(vcfg, "generic", 4096, local_rank)
+            for _ in range(max(1, args.warmup)):
+                vctx.submit_device(shard.data_ptr(), n, 0, True); vres = vctx.result()
+            torch.cuda.synchronize()
+            tv = time.perf_counter()
+            for _ in range(args.steps):
+                vctx.submit_device(shard.data_ptr(), n, 0, True); vres = vctx.result()
+            torch.cuda.synchronize()
+            tv = (time.perf_counter() - tv) / args.steps
+            assert int(vres.n_records) == recs and vres.status == L.EOF
+            out["views_mode"] = {"value": round(n / tv / 1e9, 3), "unit": "GB/s", "mrecords_per_s": round(recs / tv / 1e6, 3),
+                                 "ms_per_step": round(tv * 1e3, 4), "algorithmic_bytes_per_record": round((n + 52 * recs) / recs, 1),
+                                 "note": "config.views_only: RecordOffsets + id spans into the chunk, no columns; one read of the input"}
+            vctx.close()
         if world == 1 and not args.no_cpu_baseline:
             k = min(args.cpu_reads, recs)
             host = shard[:k * rec_bytes].cpu().numpy() if not args.long_reads else shard[:n].cpu().numpy()
