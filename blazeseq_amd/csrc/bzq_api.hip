@@ -1082,6 +1082,7 @@ int32_t bzq_submit_shard(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t
                          uint8_t prev_last_byte, uint64_t stream_pos, int32_t is_last_shard) {
     if (!c || (!d_data && n)) return BZQ_ERR_ARG;
     if (((uintptr_t)d_data & 15u) != 0) { c->err = "device shard must be 16-byte aligned"; return BZQ_ERR_ARG; }
+    if (c->cfg.views_only) { c->err = "bzq_submit_shard: views mode is a single-chunk mode (shards deliver batch columns)"; return BZQ_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     const bool reuse = (c->agg_ptr == d_data && c->agg_n == n && n >= (uint64_t)TILE &&
                         tiles_for(n + halo_bytes) + 1 <= c->tile_cap);

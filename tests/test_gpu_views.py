@@ -61,7 +61,8 @@ def test_views_fuzz(seed):
         for kw in (dict(), dict(check_ascii=True, check_quality=True),
                    dict(check_ascii=True, check_quality=True, quality_schema="solexa", compat_simd_width=16),
                    dict(buffer_capacity=48), dict(buffer_capacity=48, buffer_growth_enabled=True, buffer_max_capacity=200)):
-            ctx, oc = make_pair(views_only=True, single_pass=False, batch_size=int(rng.choice([1, 3, 4096])), **kw)
+            ctx, oc = make_pair(views_only=True, single_pass=False, batch_size=int(rng.choice([1, 3, 4096])),
+                                pass_bytes=int(rng.choice([0, 0, 16 * 1024, 64 * 1024])) if not big else 0, **kw)
             ctx.set_option("views_bytes", int(rng.random() < 0.3))
             check_views_against_oracle(ctx, oc, data, what=f"seed{seed}/{rep}/{kw}")
             check_views_against_oracle(ctx, oc, data, is_eof=False, what=f"chunk seed{seed}/{rep}/{kw}")
