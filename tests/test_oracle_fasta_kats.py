@@ -1,0 +1,240 @@
+"""The reference's FASTA known-answer tests replayed against both oracle restatements (oracle/fasta.py streaming,
+oracle/fasta_oracle.c flat).  Each test names the reference test it transcribes
+(/root/reference/tests/fasta/test_fasta_parser.mojo unless stated)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fasta as F
+from fasta_fuzz import rand_fasta, rand_soup
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "fasta")
+
+
+def both(data: bytes, check_ascii=False, chunk_size=1 << 30, capacity=F.DEFAULT_CAPACITY):
+    """Parse with the streaming and the flat restatement, insist they agree, return (records, code, message)."""
+    recs, code, msg = F.StreamFastaParser(data, check_ascii, capacity, chunk_size).all_records()
+    f = F.flat_parse(data, check_ascii, capacity, True)
+    assert f.records() == recs
+    assert f.status == code, (f.status, code, f.message, msg)
+    if code != F.EOF:
+        assert f.message == msg
+    return recs, code, msg
+
+
+def test_single_record_single_line():   # :90
+    assert both(b">id1\nACGT\n")[0] == [(b"id1", b"ACGT")]
+
+
+def test_single_record_multiline():   # :109
+    assert both(b">id1\nAC\nGT\n")[0] == [(b"id1", b"ACGT")]
+
+
+def test_multiple_records_back_to_back():   # :123
+    assert both(b">id1\nACGT\n>id2\nTTAA\n")[0] == [(b"id1", b"ACGT"), (b"id2", b"TTAA")]
+
+
+def test_record_end_at_eof_without_newline():   # :140
+    assert both(b">id1\nACGT")[0] == [(b"id1", b"ACGT")]
+
+
+@pytest.mark.parametrize("data", [b"ACGT\n>id1\nACGT\n", b"ACGTACGT\n"])
+def test_invalid_first_line_not_header(data):   # :153, :695, :791
+    recs, code, msg = both(data)
+    assert recs == [] and code == F.NO_HEADER and "does not start with" in msg
+    assert msg == "FASTA: sequence id line does not start with '>'\n  Line number: 1"
+
+
+def test_ascii_validation():   # :208, :219
+    for data in (b">id\x80\nACGT\n", b">id1\nAC\x80GT\n"):
+        recs, code, msg = both(data, check_ascii=True)
+        assert recs == [] and code == F.ASCII_INVALID and "Non ASCII" in msg
+        assert len(both(data, check_ascii=False)[0]) == 1
+
+
+def test_records_iterator():   # :230
+    assert both(b">id1\nAC\nGT\n>id2\nTT\nAA\n")[0] == [(b"id1", b"ACGT"), (b"id2", b"TTAA")]
+
+
+def test_ten_records_and_exhaustion():   # :252, :269, :289, :307, :320
+    data = b"".join(b">seq%d\nACGT\n" % i for i in range(10))
+    recs, code, _ = both(data)
+    assert len(recs) == 10 and all(s == b"ACGT" for _, s in recs) and code == F.EOF
+    p = F.StreamFastaParser(b">id1\nACGT\n")
+    assert p.has_more()
+    p.next_record()
+    assert not p.has_more()
+    with pytest.raises(F._EOF):
+        p.next_record()
+
+
+def test_iterator_five_records_ids_and_sequences():   # :336
+    data = b">alpha\nAAAA\n>beta\nCCCC\n>gamma\nGGGG\n>delta\nTTTT\n>epsilon\nACGT\n"
+    assert both(data)[0] == [(b"alpha", b"AAAA"), (b"beta", b"CCCC"), (b"gamma", b"GGGG"), (b"delta", b"TTTT"), (b"epsilon", b"ACGT")]
+
+
+@pytest.mark.parametrize("data,chunk,want", [
+    (b">id1\nACGTACGT\n", 4, [(b"id1", b"ACGTACGT")]),                       # :372
+    (b">long_identifier_name\nACGT\n", 5, [(b"long_identifier_name", b"ACGT")]),   # :393
+    (b">id1\n" + b"ACGT" * 25 + b"\n", 7, [(b"id1", b"ACGT" * 25)]),          # :412
+    (b">id1\n" + b"ACGTACGTAC\nGTACGTACGT\n" * 3, 8, [(b"id1", b"ACGT" * 15)]),   # :433
+    (b">r1\nAAAA\n>r2\nCCCC\n>r3\nGGGG\n", 6, [(b"r1", b"AAAA"), (b"r2", b"CCCC"), (b"r3", b"GGGG")]),   # :454
+    (b">ab\nACGT\n", 4, [(b"ab", b"ACGT")]),                                 # :473
+    (b">id\nACGT\n", 3, [(b"id", b"ACGT")]),                                 # :486
+    (b">longseq\n" + b"ACGT" * 50 + b"\n", 9, [(b"longseq", b"ACGT" * 50)]),   # :499
+])
+def test_records_broken_across_chunks(data, chunk, want):
+    assert both(data, chunk_size=chunk)[0] == want
+
+
+@pytest.mark.parametrize("data,want", [
+    (b"\n\n\n>id1\nACGT\n", [(b"id1", b"ACGT")]),                            # :527
+    (b">id1\nACGT\n\n\n>id2\nTTAA\n", [(b"id1", b"ACGT"), (b"id2", b"TTAA")]),   # :538
+    (b">id1\r\nACGT\r\n", [(b"id1", b"ACGT")]),                              # :553
+    (b">id1\r\nACGT\r\n>id2\r\nTTAA\r\n", [(b"id1", b"ACGT"), (b"id2", b"TTAA")]),   # :565
+    (b">  spaced_id\nACGT\n", [(b"spaced_id", b"ACGT")]),                    # :578
+    (b">seq_id   \nACGT\n", [(b"seq_id", b"ACGT")]),                         # :592
+    (b">\ttab_id\t\nACGT\n", [(b"tab_id", b"ACGT")]),                        # :606
+    (b">\nACGT\n", [(b"", b"ACGT")]),                                        # :620
+    (b">id1\nA\n", [(b"id1", b"A")]),                                        # :631
+    (b">id1\nacgt\n", [(b"id1", b"acgt")]),                                  # :642
+    (b">id1\nAcGtAcGt\n", [(b"id1", b"AcGtAcGt")]),                          # :652
+    (b">id1\nA\nC\nG\nT\nA\nC\nG\nT\n", [(b"id1", b"ACGTACGT")]),            # :662
+    (b">id1\nACG\nTTA", [(b"id1", b"ACGTTA")]),                              # :676
+])
+def test_format_valid(data, want):
+    recs, code, _ = both(data)
+    assert recs == want and code == F.EOF
+
+
+def test_format_invalid_empty_sequence():   # :714, :734, :810
+    recs, code, msg = both(b">id1\n")
+    assert recs == [] and code == F.EMPTY_SEQUENCE and "empty sequence" in msg
+    assert msg == "FASTA record has empty sequence\n  Record number: 1\n  Line number: 2\n  File position: 5"
+    recs, code, msg = both(b">id1\n>id2\nACGT\n")
+    assert recs == [] and code == F.EMPTY_SEQUENCE
+    assert msg == "FASTA record has empty sequence\n  Record number: 1\n  Line number: 2\n  File position: 5"
+    recs, code, msg = both(b">id1\nACGT\n>id2\n>id3\nGGGG\n")
+    assert recs == [(b"id1", b"ACGT")] and code == F.EMPTY_SEQUENCE
+    assert msg == "FASTA record has empty sequence\n  Record number: 2\n  Line number: 4\n  File position: 15"
+
+
+@pytest.mark.parametrize("data", [b"", b"\n\n   \n\t\n"])
+def test_format_invalid_empty_and_whitespace_only_files(data):   # :757, :774
+    recs, code, _ = both(data)
+    assert recs == [] and code == F.EOF
+
+
+def test_line_of_capacity_bytes_raises():   # buffered.mojo:634-636, 737-765
+    for cap in (16, 64):
+        ok = b">x\n" + b"A" * (cap - 1) + b"\n"
+        assert both(ok, capacity=cap)[0] == [(b"x", b"A" * (cap - 1))]
+        recs, code, msg = both(b">x\nAC\n>y\n" + b"A" * cap + b"\nAC\n", capacity=cap)
+        assert recs == [(b"x", b"AC")] and code == F.LINE_TOO_LONG and msg == "Line exceeds buffer capacity of %d bytes" % cap
+        # a header line that is too long is read while the record before it is still open
+        recs, code, _ = both(b">x\nAC\n>" + b"y" * cap + b"\nAC\n", capacity=cap)
+        assert recs == [] and code == F.LINE_TOO_LONG
+        # the last line without '\n': exactly capacity bytes never sees the zero-length read that sets EOF
+        recs, code, _ = both(b">x\n" + b"A" * cap, capacity=cap)
+        assert recs == [] and code == F.LINE_TOO_LONG
+        assert both(b">x\n" + b"A" * (cap - 1), capacity=cap)[0] == [(b"x", b"A" * (cap - 1))]
+
+
+# ---- tests/fasta/test_fasta_parser_correctness.mojo (Biopython Tests/Fasta) ------------------------------------------
+
+def _file(name):
+    with open(os.path.join(GOLD, name), "rb") as fh:
+        return both(fh.read())
+
+
+def test_biopython_seqio_files():   # :27-100
+    recs, code, _ = _file("f001")
+    assert len(recs) == 1 and code == F.EOF and b"gi|3318709|pdb|1A91|" in recs[0][0]
+    assert recs[0][1] == b"MENLNMDLLYMAAAVMMGLAAIGAAIGIGILGGKFLEGAARQPDLIPLLRTQFFIVMGLVDAIPMIAVGLGLYVMFAVA"
+    recs, _, _ = _file("f002")
+    assert len(recs) == 3 and b"gi|1348912|gb|G26680|" in recs[0][0] and b"gi|1592936|gb|G29385|" in recs[2][0]
+    assert b"CGGACCAGACGGACACAGGGAGAAGCTAGTTTCTTTCATGTGATTGA" in recs[0][1] and len(recs[0][1]) > 100
+    recs, _, _ = _file("f003.fa")
+    assert recs == [(b"gi|3318709|pdb|1A91|", b"MENLNMDLLYMAAAVMMGLAAIGAAIGIGILGGKFLEGAARQPDLIPLLRTQFFIVMGLVDAIPMIAVGLGLYVMFAVA"),
+                    (b"gi|whatever|whatever", b"MENLNMDLLYMAAAVMMGLAAIGAAIGIGILGG")]
+    recs, _, _ = _file("fa01")
+    assert [r[0] for r in recs] == [b"AK1H_ECOLI/1-378", b"AKH_HAEIN/1-382"]
+    assert b"-" in recs[0][1] and b"CPDSINAALICRGEKMSIAIMAGVLEARGH" in recs[0][1] and b"VEDAVKATIDCRGEKLSIAMMKAWFEARGY" in recs[1][1]
+
+
+@pytest.mark.parametrize("name,id_part,seq_part", [
+    ("aster.pro", b"gi|3298468|dbj|BAA31520.1|", b""),
+    ("aster_no_wrap.pro", b"", b""),
+    ("loveliesbleeding.pro", b"gi|2781234|pdb|1JLY|", b""),
+    ("rose.pro", b"gi|4959044|gb|AAD34209.1|", b"MENSDSNDKGSDQSAAQRRSQMDRLDREEAFYQFVNNLSEEDYRLMRDNNLLGTPGESTEEELLRRLQQI"),
+    ("rosemary.pro", b"gi|671626|emb|CAA85685.1|", b"MSPQTETKASVGFKAGVKEYKLTYYTPEYETKDTDILAAFRVTPQPGVPPEEAGAAVAAESSTGTWTTVW"),
+    ("centaurea.nu", b"", b""),
+    ("elderberry.nu", b"", b"ATGAAGTTAAGCACTCTTCTCATCTTATCTTTTCCTTTCCTGCTCGGTACTATTGTCTTTGCAGATGATG"),
+    ("lavender.nu", b"", b""),
+    ("lupine.nu", b"", b"GAAAATTCATTTTCTTTGG"),
+    ("phlox.nu", b"", b"TCGAAACCTGCCTAGCAGAACGACCCGCGAACTTGTATTCAAAACTTGGGTTGTGCGTGCTTCTGCTTCG"),
+    ("sweetpea.nu", b"", b""),
+    ("wisteria.nu", b"", b"GCTCCATTTTTTACACATTTCTATGAACTAATTGGTTCATCCATACCATCGGTAGGGTTTGTAAGACCAC"),
+])
+def test_biopython_pro_and_nu_files(name, id_part, seq_part):   # :103-240
+    recs, code, _ = _file(name)
+    assert len(recs) >= 1 and code == F.EOF
+    assert len(recs[0][0]) > 0 and len(recs[0][1]) > 0
+    assert id_part in recs[0][0] and seq_part in recs[0][1]
+
+
+# ---- generator (utils.mojo:1033-1139) and the two restatements against each other ------------------------------------
+
+def test_generator_shape_and_parse():
+    data = F.generate_synthetic(50, 5, 200, 60).tobytes()
+    recs, code, _ = both(data)
+    assert code == F.EOF and len(recs) == 50
+    for i, (rid, seq) in enumerate(recs):
+        assert rid == b"read_%02d" % i and len(seq) == 5 + (i * 31 + 7) % 196 and set(seq) <= set(b"ACGT")
+    lines = data.split(b"\n")
+    assert max(len(l) for l in lines) == 60
+    # a sequence length that is a multiple of the line width does not get a second newline
+    assert F.generate_synthetic(1, 120, 120, 60).tobytes().count(b"\n") == 3
+    n = F.compute_num_reads_for_size(1 << 20, 200, 3800, 60)
+    assert abs(len(F.generate_synthetic(n, 200, 3800, 60)) - (1 << 20)) < (1 << 20) * 0.05
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_stream_and_flat_agree_on_random_streams(seed):
+    rng = np.random.default_rng(7000 + seed)
+    for _ in range(15):
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            data = rand_fasta(rng, int(rng.integers(1, 12)), 40, 4, dirty=float(rng.choice([0, 0.05, 0.3])), crlf=bool(rng.integers(0, 2)),
+                              tail_newline=bool(rng.integers(0, 2)), lead_blank=int(rng.integers(0, 3)))
+        else:
+            data = rand_soup(rng, int(rng.integers(0, 300)))
+        cap = int(rng.choice([8, 24, 64, 1 << 18]))
+        both(data, check_ascii=bool(rng.integers(0, 2)), chunk_size=int(rng.choice([1, 3, 7, 64, 1 << 30])), capacity=cap)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_flat_chunk_mode_concatenates_to_the_whole_parse(seed):
+    """Chunk mode (is_eof=0) is what a streaming caller of the GPU path uses: parse, carry from `consumed`, repeat."""
+    rng = np.random.default_rng(9000 + seed)
+    data = rand_fasta(rng, int(rng.integers(1, 40)), 30, 4, dirty=float(rng.choice([0, 0.05, 0.2])), crlf=bool(rng.integers(0, 2)),
+                      tail_newline=bool(rng.integers(0, 2)), lead_blank=int(rng.integers(0, 3)))
+    check = bool(rng.integers(0, 2))
+    whole = F.flat_parse(data, check, 1 << 18, True)
+    got, pos, lines, nrec, size = [], 0, 0, 0, int(rng.integers(8, 200))
+    while True:
+        end = min(len(data), pos + size)
+        eof = end == len(data)
+        f = F.flat_parse(data[pos:end], check, 1 << 18, eof, nrec, lines, pos)
+        got += f.records()
+        nrec += f.n_records
+        if f.status == F.NEED_MORE and f.consumed == 0:
+            size *= 2
+            continue
+        if f.status not in (F.OK, F.NEED_MORE):
+            assert f.status == whole.status and f.message == whole.message
+            break
+        pos += f.consumed
+        lines += f.lines_consumed
+    assert got == whole.records()
