@@ -100,6 +100,24 @@ class BzqIngestStats(C.Structure):
     ]
 
 
+class BzqFastaConfig(C.Structure):
+    _fields_ = [("check_ascii", C.c_int32), ("_pad", C.c_int32), ("line_capacity", C.c_int64)]
+
+
+class BzqFastaChunk(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("_pad", C.c_int32),
+        ("n_records", C.c_int64), ("bytes_consumed", C.c_uint64), ("lines_consumed", C.c_int64),
+        ("seq_bytes", C.c_int64), ("id_bytes", C.c_int64),
+        ("d_seq_bytes", C.c_void_p), ("d_id_bytes", C.c_void_p), ("d_seq_ends", C.c_void_p), ("d_id_ends", C.c_void_p),
+        ("d_hdr_pos", C.c_void_p),
+        ("err_record_number", C.c_int64), ("err_line_number", C.c_int64), ("err_file_position", C.c_int64),
+        ("kernel_ms", C.c_double),
+    ]
+
+
+FASTA_NO_HEADER, FASTA_EMPTY_SEQUENCE, FASTA_NEED_MORE = 1, 11, 12
+
 SYMBOLS = {
     "bzq_abi_version": (C.c_int32, []),
     "bzq_config_default": (None, [C.POINTER(BzqConfig)]),
@@ -140,6 +158,15 @@ SYMBOLS = {
     "bzq_batch_nw_scores": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.c_char_p, C.c_int32, C.c_void_p]),
     "bzq_batch_quality_sums": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.c_void_p]),
     "bzq_column_histogram": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "bzq_fasta_create": (C.c_int32, [C.c_int32, C.POINTER(BzqFastaConfig), C.POINTER(C.c_void_p)]),
+    "bzq_fasta_destroy": (None, [C.c_void_p]),
+    "bzq_fasta_last_error": (C.c_char_p, [C.c_void_p]),
+    "bzq_fasta_parse": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
+                                    C.POINTER(BzqFastaChunk)]),
+    "bzq_fasta_format_error": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "bzq_fasta_copy_to_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bzq_fasta_generate_synthetic_device": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                                        C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None

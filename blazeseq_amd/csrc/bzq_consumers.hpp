@@ -34,7 +34,7 @@ __device__ __forceinline__ int wave_prefix_max(int v, int lane) {
 }
 
 // One wave per record; 4 records per workgroup.
-__global__ __launch_bounds__(BLOCK) void k_nw_scores(const uint8_t* __restrict__ ref, int ref_len,
+static __global__ __launch_bounds__(BLOCK) void k_nw_scores(const uint8_t* __restrict__ ref, int ref_len,
                                                       const uint8_t* __restrict__ seq, const int64_t* __restrict__ ends,
                                                       int64_t num_records, int32_t* __restrict__ scores) {
     const int lane = threadIdx.x & 63;
@@ -121,7 +121,7 @@ __device__ __forceinline__ uint4 keep_first(uint4 v, int k) {
 // record by a binary search over the 257 record boundaries kept in LDS, is split where it straddles boundaries, and is
 // added to that record's LDS accumulator (v_sad_u8 sums four bytes per instruction).  A thread-per-record version with
 // the same loads ran at 1.07 TB/s: neighbouring lanes are a record (150 B) apart, so every line was fetched ~8 times.
-__global__ __launch_bounds__(BLOCK) void k_quality_sums_block(const uint8_t* __restrict__ qual, const int64_t* __restrict__ ends,
+static __global__ __launch_bounds__(BLOCK) void k_quality_sums_block(const uint8_t* __restrict__ qual, const int64_t* __restrict__ ends,
                                                                int64_t num_records, int64_t col_len, int offset,
                                                                int64_t* __restrict__ sums) {
     __shared__ int64_t s_e[BLOCK + 1];   // s_e[k] = start of record r0 + k
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(BLOCK) void k_quality_sums_block(const uint8_t* __r
 }
 
 // LONG reads: one wave per record, 16 bytes per lane per step (1 KiB per wave instruction).
-__global__ __launch_bounds__(BLOCK) void k_quality_sums(const uint8_t* __restrict__ qual, const int64_t* __restrict__ ends,
+static __global__ __launch_bounds__(BLOCK) void k_quality_sums(const uint8_t* __restrict__ qual, const int64_t* __restrict__ ends,
                                                          int64_t num_records, int64_t col_len, int offset, int64_t* __restrict__ sums) {
     const int lane = threadIdx.x & 63;
     const int64_t rec = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(BLOCK) void k_quality_sums(const uint8_t* __restric
 // hist[256] += byte counts of col[0, n).  Grid-stride, 16 bytes per lane per step.  LDS histograms: one per wave AND
 // per lane-residue mod 8 (a 5-letter alphabet would otherwise pile 64 lanes onto 5 addresses); bank = bin + replica.
 constexpr int HIST_REP = 8;
-__global__ __launch_bounds__(BLOCK) void k_byte_histogram(const uint8_t* __restrict__ col, int64_t n, u64* __restrict__ hist) {
+static __global__ __launch_bounds__(BLOCK) void k_byte_histogram(const uint8_t* __restrict__ col, int64_t n, u64* __restrict__ hist) {
     __shared__ uint32_t s_h[BLOCK / 64][HIST_REP][256 + 1];   // +1: replicas of one bin land in different banks
     const int tid = threadIdx.x, wave = tid >> 6, rep = tid & (HIST_REP - 1);
     for (int i = tid; i < (BLOCK / 64) * HIST_REP * 257; i += BLOCK) (&s_h[0][0][0])[i] = 0u;

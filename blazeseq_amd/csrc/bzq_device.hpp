@@ -334,7 +334,7 @@ struct AggArgs {
     u64* tile_idc;      // 4 x u16: id bytes per class if that class were the header role
 };
 
-__global__ __launch_bounds__(BLOCK) void k_tile_aggregate(AggArgs a) {
+static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate(AggArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[TILE];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
     __shared__ uint32_t s_w[4];
@@ -419,7 +419,7 @@ __device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t* s_r) {
     return t;
 }
 
-__global__ __launch_bounds__(SG_THREADS) void k_scan_reduce(ScanArgs a) {
+static __global__ __launch_bounds__(SG_THREADS) void k_scan_reduce(ScanArgs a) {
     constexpr int NW = SG_THREADS / 64;
     __shared__ int64_t s_w[NW];
     __shared__ int64_t s_acc[NW][9];
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(SG_THREADS) void k_scan_reduce(ScanArgs a) {
     }
 }
 
-__global__ __launch_bounds__(SG_THREADS) void k_scan_down(ScanArgs a) {
+static __global__ __launch_bounds__(SG_THREADS) void k_scan_down(ScanArgs a) {
     constexpr int NW = SG_THREADS / 64;
     __shared__ int64_t s_w[NW];
     const int tid = threadIdx.x;
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(SG_THREADS) void k_scan_down(ScanArgs a) {
 // Tail after the last newline: where it starts and whether it is more than blanks
 // (_check_end_qual, blazeseq/utils.mojo:292-329).  One workgroup; the last tile with a newline is read as 16-byte
 // pieces like every other tile.
-__global__ __launch_bounds__(BLOCK) void k_tail(const uint8_t* __restrict__ g, int64_t n, ChunkState* st) {
+static __global__ __launch_bounds__(BLOCK) void k_tail(const uint8_t* __restrict__ g, int64_t n, ChunkState* st) {
     __shared__ int s_pos;
     __shared__ int s_nb;
     const int tid = threadIdx.x;
@@ -737,7 +737,7 @@ __device__ __forceinline__ void gather_role(uint8_t* __restrict__ col, int64_t D
 }
 
 template <bool CA, bool CQ, bool OFFS>
-__global__ __launch_bounds__(BLOCK) void k_tile_emit(EmitArgs a) {
+static __global__ __launch_bounds__(BLOCK) void k_tile_emit(EmitArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
     __shared__ uint16_t s_src[3][SEGS], s_len[3][SEGS], s_dst[3][SEGS];
@@ -944,7 +944,7 @@ struct RebaseArgs {
 // b_ends[r] = ends[r] - ends[first record of r's batch - 1].  Also finds the first record the
 // reference could not hold in its buffer (parser.mojo:484-492).  Grid-stride over the records; the
 // record count is read from the device state, so the host can enqueue this without a sync.
-__global__ __launch_bounds__(BLOCK) void k_rebase(RebaseArgs a) {
+static __global__ __launch_bounds__(BLOCK) void k_rebase(RebaseArgs a) {
     const int64_t lines = a.st->P;
     int64_t n_rec = lines > 0 ? (lines >> 2) : 0;
     if (n_rec > a.rec_cap) n_rec = a.rec_cap; // overflow: the host re-sizes and re-runs
@@ -974,7 +974,7 @@ __global__ __launch_bounds__(BLOCK) void k_rebase(RebaseArgs a) {
 }
 
 // Rebased ends for an arbitrary record range (a next_batch call that is not batch aligned).
-__global__ __launch_bounds__(BLOCK) void k_rebase_range(const int64_t* ends, const int64_t* id_ends, int64_t first,
+static __global__ __launch_bounds__(BLOCK) void k_rebase_range(const int64_t* ends, const int64_t* id_ends, int64_t first,
                                                         int64_t count, int64_t* out_e, int64_t* out_i) {
     const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= count) return;
@@ -985,7 +985,7 @@ __global__ __launch_bounds__(BLOCK) void k_rebase_range(const int64_t* ends, con
 
 // Writes the per-record outputs of a last record that has no trailing newline (parser.mojo:464-475,
 // utils.mojo:327-329): the columns already hold its bytes.
-__global__ void k_fix_last(int64_t rec, int64_t n, int64_t batch, int64_t* ends, int64_t* id_ends,
+static __global__ void k_fix_last(int64_t rec, int64_t n, int64_t batch, int64_t* ends, int64_t* id_ends,
                            int64_t* rec_end, int64_t* b_ends, int64_t* b_id_ends, const ChunkState* st) {
     if (threadIdx.x || blockIdx.x) return;
     ends[rec] = st->Q; id_ends[rec] = st->I; rec_end[rec] = n;
@@ -997,7 +997,7 @@ __global__ void k_fix_last(int64_t rec, int64_t n, int64_t batch, int64_t* ends,
 // =================================================================================== shard stitch
 // Offsets of the first four newlines of a shard (one workgroup; a record is a few hundred bytes to
 // a few tens of kB, so this touches a handful of 4 KiB steps).
-__global__ __launch_bounds__(BLOCK) void k_first_newlines(const uint8_t* __restrict__ g, int64_t n, ChunkState* st) {
+static __global__ __launch_bounds__(BLOCK) void k_first_newlines(const uint8_t* __restrict__ g, int64_t n, ChunkState* st) {
     __shared__ uint32_t s_w[4];
     __shared__ int s_found;
     const int tid = threadIdx.x;
@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(BLOCK) void k_first_newlines(const uint8_t* __restr
 
 // Column offsets that make the first OWNED record of a shard start at 0: the head lines (the
 // straddling record's remainder, owned by the previous shard) get negative offsets.
-__global__ void k_head(const uint8_t* __restrict__ g, int64_t n, uint32_t prev_byte, int head_lines, ChunkState* st) {
+static __global__ void k_head(const uint8_t* __restrict__ g, int64_t n, uint32_t prev_byte, int head_lines, ChunkState* st) {
     if (threadIdx.x || blockIdx.x) return;
     ByteSrc bs{g, n, prev_byte, nullptr, 0, 0};
     int64_t s0 = 0, q0 = 0, i0 = 0;
@@ -1068,7 +1068,7 @@ struct GenArgs {
     const int64_t* len_prefix;   // [period + 1] prefix sums of one period's lengths (device)
 };
 
-__global__ __launch_bounds__(BLOCK) void k_generate(GenArgs a) {
+static __global__ __launch_bounds__(BLOCK) void k_generate(GenArgs a) {
     const int64_t idx = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (idx >= a.count) return;
     const int64_t i = a.first + idx;

@@ -233,7 +233,7 @@ __device__ __forceinline__ void copy16(uint8_t* __restrict__ col, int64_t gaddr,
 // and a register-prefetching persistent variant measured 10% SLOWER -- this kernel is bound by HBM traffic, not by
 // reads in flight: capping it at 4 or 5 workgroups per CU instead of 6 does not change its time).
 template <bool CA, bool CQ, bool OFFS, bool LB>
-__global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
+static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];   // newline bitmap, 16 bits per 16-byte piece
     __shared__ uint16_t s_nl[MAXL + 4];
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
 // thread; 20 KiB of LDS and < 64 VGPRs so that eight workgroups fit a CU (this pass lives on occupancy: its time
 // falls 1.09 / 0.89 / 0.78 / 0.70 ms at 3 / 4 / 5 / 6 workgroups per CU).  Same output as k_tile_aggregate.
 constexpr int MAXL_A = 1012;   // s_nl sized so the kernel's LDS is 8 x 20480 B per CU; more newlines -> serial path
-__global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
+static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[TILE];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
     __shared__ uint16_t s_nl[MAXL_A];

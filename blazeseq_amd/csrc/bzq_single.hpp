@@ -196,7 +196,7 @@ __device__ inline void service_cols(const SingleArgs& a, int lane) {
 }
 
 template <bool CA, bool CQ, bool OFFS, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_single(SingleArgs sa) {
+static __global__ __launch_bounds__(BLOCK) void k_single(SingleArgs sa) {
     const FusedArgs& a = sa.f;
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];

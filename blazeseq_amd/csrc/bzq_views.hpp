@@ -72,7 +72,7 @@ __device__ __forceinline__ uint32_t line_start_info(const ByteSrc& b, int64_t s)
 
 // Pass A of the metadata pipeline: the ONLY kernel that reads the input.  One workgroup per tile; every thread owns the
 // newlines of its 64 bytes.
-__global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
+static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
     __shared__ uint32_t s_w[BLOCK / 64];
@@ -150,7 +150,7 @@ constexpr int JOIN_TILES = 8;   // tiles per workgroup of the join (4 / 8 / 16: 
 // each is found by its tile (the tile prefixes of the scan) and its rank inside it; the five entries give every offset,
 // both structure bytes, the id span and the length / buffer checks -- 20 bytes read, 52 written, all arrays coalesced.
 // A workgroup takes the records whose LAST newline lies in its JOIN_TILES tiles.
-__global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
+static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
     __shared__ int64_t s_P[JOIN_TILES + 1];
     __shared__ u64 s_slot[JOIN_TILES];
     const int tid = threadIdx.x;
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
     if (overflow) atomicOr(&a.st->rec_overflow, 1);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_tile_count(AggArgs a) {
+static __global__ __launch_bounds__(BLOCK) void k_tile_count(AggArgs a) {
     __shared__ uint32_t s_w[BLOCK / 64];
     const int tid = threadIdx.x;
     const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
@@ -310,7 +310,7 @@ __device__ __forceinline__ void check_bytes(const uint8_t* s_tile, int a, int b,
 constexpr int MAXL_V = 980;   // more newlines in a tile -> the serial path
 
 template <bool CA, bool CQ>
-__global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
+static __global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
     __shared__ uint16_t s_nl[MAXL_V];   // sized so that the kernel's LDS is 8 x 20480 B per CU
@@ -472,7 +472,7 @@ struct ViewCheckArgs {
 };
 
 // Grid-stride over the complete records (their count comes from the device state, like k_rebase).
-__global__ __launch_bounds__(BLOCK) void k_views_check(ViewCheckArgs a) {
+static __global__ __launch_bounds__(BLOCK) void k_views_check(ViewCheckArgs a) {
     const int64_t lines = a.st->P;
     int64_t n_rec = lines > 0 ? (lines >> 2) : 0;
     if (n_rec > a.rec_cap) n_rec = a.rec_cap;

@@ -332,6 +332,61 @@ int32_t bzq_generate_synthetic_device_var(bzq_ctx* ctx, int64_t num_reads, int64
                                           int32_t min_len, int32_t max_len, int32_t min_phred, int32_t max_phred,
                                           const char* schema, uint8_t* d_out, uint64_t cap, uint64_t* out_bytes);
 
+/* ---- FASTA records --------------------------------------------
+ * Replaces FastaParser.next_record for a whole chunk at a time (blazeseq/fasta/parser.mojo:122-203 over
+ * LineIterator.next_line, blazeseq/io/buffered.mojo:600-638): every line stripped of posix spaces, '>' lines open a
+ * record, all other lines concatenated into its sequence.  Output is the FastqBatch layout without the quality column:
+ * id and sequence bytes back to back + inclusive running sums.  No CPU fallback. */
+typedef struct bzq_fasta bzq_fasta;
+
+enum {
+    BZQ_FASTA_NO_HEADER = 1,       /* "FASTA: sequence id line does not start with '>'" (parser.mojo:196-200) */
+    BZQ_FASTA_EMPTY_SEQUENCE = 11, /* "FASTA record has empty sequence" (parser.mojo:157-165) */
+    BZQ_FASTA_NEED_MORE = 12       /* not the last chunk and no record is closed inside it: resubmit with more bytes */
+    /* also used: BZQ_OK (more input expected), BZQ_EOF (clean end), BZQ_ASCII_INVALID, BZQ_BUFFER_EXCEEDED
+     * ("Line exceeds buffer capacity of N bytes", buffered.mojo:737-765) */
+};
+
+typedef struct bzq_fasta_config {
+    int32_t check_ascii;     /* fasta ParserConfig.check_ascii (parser.mojo:24-35) */
+    int32_t _pad;
+    int64_t line_capacity;   /* LineIterator capacity: a line of this many bytes or more is an error.  0 = the
+                              * reference's DEFAULT_CAPACITY, 256 KiB (CONSTS.mojo:26); minimum 32768 */
+} bzq_fasta_config;
+
+typedef struct bzq_fasta_chunk {
+    int32_t status;          /* BZQ_OK / BZQ_EOF / BZQ_FASTA_NEED_MORE, or the code of the first error */
+    int32_t _pad;
+    int64_t n_records;       /* records delivered: all of them before the first error */
+    uint64_t bytes_consumed; /* carry data[bytes_consumed, n) in front of the next chunk (n at EOF) */
+    int64_t lines_consumed;  /* '\n' count in [0, bytes_consumed) */
+    int64_t seq_bytes, id_bytes;   /* column bytes of the n_records */
+    const uint8_t* d_seq_bytes;    /* device; valid until the next bzq_fasta_parse on this handle */
+    const uint8_t* d_id_bytes;
+    const int64_t* d_seq_ends;     /* [n_records] inclusive running sums of sequence lengths */
+    const int64_t* d_id_ends;
+    const int64_t* d_hdr_pos;      /* [n_records] chunk offset of each record's '>' */
+    int64_t err_record_number, err_line_number, err_file_position;   /* ParseContext of the error, stream-global */
+    double kernel_ms;        /* HIP-event time of the kernels of this chunk */
+} bzq_fasta_chunk;
+
+int32_t bzq_fasta_create(int32_t device, const bzq_fasta_config* cfg, bzq_fasta** out);
+void bzq_fasta_destroy(bzq_fasta* h);
+const char* bzq_fasta_last_error(const bzq_fasta* h);   /* h may be NULL: last create() failure */
+/* Parses one chunk that starts at a line start.  `data` may be host memory (copied in) or device memory (used in
+ * place).  stream_pos / line_base / record_base: bytes, lines and records before this chunk, for error text.
+ * Synchronous.  Returns 0 and fills *out also when the stream has an error (out->status); < 0 = runtime failure. */
+int32_t bzq_fasta_parse(bzq_fasta* h, const uint8_t* data, uint64_t n, int32_t is_eof, uint64_t stream_pos,
+                        uint64_t line_base, uint64_t record_base, bzq_fasta_chunk* out);
+/* The reference's error text for the last chunk's status (errors.mojo:178-234).  Returns the length. */
+int32_t bzq_fasta_format_error(bzq_fasta* h, char* buf, size_t cap);
+int32_t bzq_fasta_copy_to_host(bzq_fasta* h, void* dst, const void* d_src, size_t bytes);
+/* generate_synthetic_fasta_buffer (blazeseq/utils.mojo:1033-1139), records [first, first+count) of a num_reads-record
+ * file, written into device memory.  d_out == NULL only sizes. */
+int32_t bzq_fasta_generate_synthetic_device(bzq_fasta* h, int64_t num_reads, int64_t first, int64_t count, int32_t min_len,
+                                            int32_t max_len, int32_t line_width, uint8_t* d_out, uint64_t cap,
+                                            uint64_t* out_bytes);
+
 #ifdef __cplusplus
 }
 #endif

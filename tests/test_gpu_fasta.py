@@ -1,0 +1,215 @@
+"""-m gpu: the FASTA path (bzq_fasta_* over csrc/bzq_fasta.hpp) against the oracle (oracle/fasta.py), through the C ABI.
+Bit-exact: columns, ends, '>' offsets, the carry point of a chunk, the first error and its text."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fasta as F
+from fasta_fuzz import rand_fasta, rand_soup
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "fasta")
+TILE = 16384
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    import blazeseq_amd as B
+    made = {}
+
+    def get(check_ascii=False, cap=256 * 1024):
+        key = (check_ascii, cap)
+        if key not in made:
+            made[key] = B.FastaContext(B.FastaParserConfig(check_ascii, cap))
+        return made[key]
+    yield get
+    for c in made.values():
+        c.close()
+
+
+def check_chunk(ctx, data: bytes, is_eof=True, bases=(0, 0, 0)):
+    """One bzq_fasta_parse against the flat oracle with the same arguments."""
+    from blazeseq_amd import _lib as L
+    pos, lines, recs = bases
+    want = F.flat_parse(data, ctx.config.check_ascii, ctx.config.line_capacity, is_eof, recs, lines, pos)
+    res = ctx.parse(data, len(data), is_eof, pos, lines, recs)
+    status = int(res.status)
+    assert status == want.status, (status, want.status, want.message, ctx.error_text())
+    assert int(res.n_records) == want.n_records
+    idb, ide, sqb, sqe, hp = ctx.columns(res)
+    assert ide.tolist() == want.id_ends.tolist()
+    assert sqe.tolist() == want.seq_ends.tolist()
+    assert idb.tobytes() == want.id_bytes.tobytes()
+    assert sqb.tobytes() == want.seq_bytes.tobytes()
+    assert hp.tolist() == want.hdr_pos.tolist()
+    if status in (L.OK, L.FASTA_NEED_MORE):
+        assert int(res.bytes_consumed) == want.consumed and int(res.lines_consumed) == want.lines_consumed
+    elif status != L.EOF:
+        assert ctx.error_text().decode("latin-1") == want.message
+        assert (int(res.err_record_number), int(res.err_line_number), int(res.err_file_position)) == \
+            (want.err_record_number, want.err_line_number, want.err_file_position)
+    return want
+
+
+KATS = [b">id1\nACGT\n", b">id1\nAC\nGT\n", b">id1\nACGT\n>id2\nTTAA\n", b">id1\nACGT", b"ACGT\n>id1\nACGT\n", b"ACGTACGT\n",
+        b">id\x80\nACGT\n", b">id1\nAC\x80GT\n", b">id1\nAC\nGT\n>id2\nTT\nAA\n", b"\n\n\n>id1\nACGT\n", b">id1\nACGT\n\n\n>id2\nTTAA\n",
+        b">id1\r\nACGT\r\n", b">id1\r\nACGT\r\n>id2\r\nTTAA\r\n", b">  spaced_id\nACGT\n", b">seq_id   \nACGT\n", b">\ttab_id\t\nACGT\n",
+        b">\nACGT\n", b">id1\nA\n", b">id1\nA\nC\nG\nT\nA\nC\nG\nT\n", b">id1\nACG\nTTA", b">id1\n", b">id1\n>id2\nACGT\n",
+        b">id1\nACGT\n>id2\n>id3\nGGGG\n", b"", b"\n\n   \n\t\n", b">a>b\nAC>GT\n  >c  d \n A C \n", b" ", b">", b"\n", b">\n>\n", b"x"]
+
+
+@pytest.mark.parametrize("check", [False, True])
+def test_reference_kats_through_the_c_abi(ctxs, check):   # tests/fasta/test_fasta_parser.mojo, see test_oracle_fasta_kats.py
+    ctx = ctxs(check)
+    for data in KATS:
+        check_chunk(ctx, data, True)
+        check_chunk(ctx, data, False)
+        check_chunk(ctx, data, True, bases=(1000, 50, 7))
+
+
+def test_biopython_files(ctxs):   # tests/fasta/test_fasta_parser_correctness.mojo
+    ctx = ctxs(True)
+    for name in sorted(os.listdir(GOLD)):
+        if name.endswith(".md"):
+            continue
+        with open(os.path.join(GOLD, name), "rb") as fh:
+            w = check_chunk(ctx, fh.read(), True)
+        # the two files with leading comment lines are not FASTA to the reference either (it skips them in its tests)
+        assert (w.status == F.NO_HEADER) if name in ("aster_blast.pro", "aster_pearson.pro") else (w.status == F.EOF and w.n_records >= 1)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_fasta_streams(ctxs, seed):
+    rng = np.random.default_rng(100 + seed)
+    ctx = ctxs(bool(seed & 1))
+    for _ in range(12):
+        data = rand_fasta(rng, int(rng.integers(1, 400)), int(rng.choice([20, 70, 300])), int(rng.integers(1, 8)),
+                          dirty=float(rng.choice([0, 0.01, 0.1, 0.4])), crlf=bool(rng.integers(0, 2)), tail_newline=bool(rng.integers(0, 2)),
+                          lead_blank=int(rng.integers(0, 3)))
+        check_chunk(ctx, data, True)
+        cut = int(rng.integers(0, len(data) + 1))
+        check_chunk(ctx, data[:cut], False)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_byte_soup_across_tile_edges(ctxs, seed):
+    """Accidental structure only; long runs of spaces / bytes without '\\n' so that lines, space runs and ids cross the
+    16 KiB tile edges in every state."""
+    rng = np.random.default_rng(500 + seed)
+    ctx = ctxs(bool(seed & 1), 32768 if seed % 3 == 0 else 256 * 1024)
+    weights = [[2, 4, 3, 1, 6, 6, 1, 0.3, 0.3], [1, 0.02, 30, 5, 3, 3, 1, 0.05, 0.5], [0.5, 0.01, 1, 1, 20, 20, 0.2, 0.01, 0.1],
+               [3, 0.3, 10, 2, 1, 1, 1, 0, 1]][seed % 4]
+    for _ in range(6):
+        n = int(rng.choice([100, TILE - 1, TILE, TILE + 1, 3 * TILE + 17, 100_000]))
+        data = rand_soup(rng, n, weights)
+        check_chunk(ctx, data, True)
+        check_chunk(ctx, data, False)
+        # a well-formed frame around the soup so that records exist on both sides of it
+        framed = b">a\nAC\n>b " + data.replace(b">", b"A") + b"\n>c\nGT\n"
+        check_chunk(ctx, framed, True)
+
+
+def test_every_byte_value_is_classified_like_the_reference(ctxs):
+    body = bytes(b for b in range(256) if b not in (10, 62))
+    data = b">" + body + b"\n" + body + b"\n" + b"".join(bytes([b]) + b"\n" for b in range(256)) + b">z\n" + bytes(range(11, 256))
+    for check in (False, True):
+        check_chunk(ctxs(check), data, True)
+    # without the bytes >= 0x80 so that the ascii check passes through to the end
+    low = bytes(b for b in range(128) if b not in (10, 62))
+    check_chunk(ctxs(True), b">" + low + b"\n" + low + b"\n>y\n" + low, True)
+
+
+def test_spaces_and_states_straddling_tile_edges(ctxs):
+    ctx = ctxs(False)
+    for edge_fill in (b" ", b"\t", b"A"):
+        for k in range(-3, 4):
+            # header whose id / trailing spaces / '>' land on the tile edge
+            pad = TILE - 8 + k
+            check_chunk(ctx, b">a\n" + b"C" * (pad - 3 - 1) + b"\n" + b" > id  with  gaps   \n  AC  GT  \n" + edge_fill * 40 + b"\nTT\n", True)
+            # sequence line that is all spaces for more than a tile, then an X or a '\n'
+            for closer in (b"G\n", b"\n", b""):
+                check_chunk(ctx, b">a\nAC" + edge_fill * (2 * TILE + k) + closer + b">b\nT\n", True)
+                check_chunk(ctx, b">" + edge_fill * (TILE + k) + b"id" + b" " * (TILE + 5) + closer + b"ACGT\n", True)
+                check_chunk(ctx, b" " * (TILE + k) + b">x" + b" " * TILE + closer + b"AC\n", True)
+    # single-line records far longer than a tile (long reads as FASTA)
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(30):
+        L = int(rng.integers(1, 120_000))
+        recs.append(b">read%d\n" % i + np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=L)].tobytes() + b"\n")
+    check_chunk(ctx, b"".join(recs), True)
+    check_chunk(ctx, b"".join(recs), False)
+
+
+def test_line_capacity(ctxs):   # buffered.mojo:634-636, 737-765
+    cap = 32768
+    ctx = ctxs(False, cap)
+    ok = b">x\n" + b"A" * (cap - 1) + b"\n"
+    assert check_chunk(ctx, ok, True).status == F.EOF
+    for data in (b">x\nAC\n>y\n" + b"A" * cap + b"\nAC\n",               # inside record 1
+                 b">x\nAC\n>" + b"y" * cap + b"\nAC\n",                  # a header line: record 0 is still open
+                 b">x\n" + b"A" * cap,                                   # last line, no '\n'
+                 b" " * cap + b"\n>x\nAC\n",                             # before any header
+                 b"A" * (cap + 5) + b"\n>x\nAC\n",                       # too long wins over "no header"
+                 b"AC\n" + b"A" * (cap + 5) + b"\n",                     # "no header" comes first
+                 b">x\nAC\n>e\n>y\n" + b"A" * cap + b"\n",               # empty record 1 comes before the long line in record 2
+                 b">x\nAC\n>e\n" + b" " * cap + b"\n>y\nA\n"):           # the long line is read while record 1 is open
+        w = check_chunk(ctx, data, True)
+        assert w.status != F.EOF
+        check_chunk(ctx, data, False)
+    assert check_chunk(ctx, b">x\n" + b"A" * (cap - 1), True).status == F.EOF
+
+
+def test_streaming_parser_matches_whole_file_and_reference_tests(tmp_path):
+    import blazeseq_amd as B
+    rng = np.random.default_rng(77)
+    data = rand_fasta(rng, 3000, 70, 6, dirty=0.0, crlf=False, lead_blank=2)
+    want = F.flat_parse(data).records()
+    for chunk in (1 << 12, 50_000, 1 << 26):
+        p = B.FastaParser(data, chunk_bytes=chunk)
+        got = [(r.id, r.sequence) for r in p.records()]
+        assert got == want
+        assert not p.has_more()
+        with pytest.raises(B.ParseError):
+            p.next_record()
+        p.close()
+    path = tmp_path / "x.fasta"
+    path.write_bytes(data)
+    p = B.FastaParser(str(path), chunk_bytes=100_000)
+    assert [(r.id, r.sequence) for r in p] == want
+    # a record larger than the chunk makes the chunk grow
+    big = b">big\n" + b"ACGT" * 50_000 + b"\n>small\nAC\n"
+    assert [(r.id, len(r)) for r in B.FastaParser(big, chunk_bytes=4096).records()] == [(b"big", 200_000), (b"small", 2)]
+    # errors: text and position are stream-global even when the error is chunks away from the start
+    bad = data + b">empty\n>next\nAC\n"
+    ref = F.flat_parse(bad)
+    p = B.FastaParser(bad, chunk_bytes=30_000)
+    n = 0
+    with pytest.raises(B.ParseError) as e:
+        while True:
+            p.next_record()
+            n += 1
+    assert n == ref.n_records and e.value.message.decode("latin-1") == ref.message and e.value.code == ref.status
+    # FastaRecord surface (tests/fasta/test_fasta_parser.mojo:835-1028)
+    r = B.FastaRecord("id1 desc", "ACGTACGT")
+    assert r.byte_len() == 1 + 8 + 1 + 8 + 1 and len(r) == 8 and r.write(4) == b">id1 desc\nACGT\nACGT\n"
+    assert r == B.FastaRecord("other", "ACGTACGT") and r != B.FastaRecord("id1 desc", "ACGT")
+    assert [(x.id, x.sequence) for x in B.FastaParser(r.write(3)).records()] == [(b"id1 desc", b"ACGTACGT")]
+
+
+def test_device_generator_and_device_input(ctxs):
+    import torch
+    ctx = ctxs(False)
+    want = F.generate_synthetic(3000, 5, 400, 60)
+    t = ctx.generate_synthetic_device(3000, 5, 400, 60)
+    assert bytes(t.cpu().numpy()) == want.tobytes()
+    part = ctx.generate_synthetic_device(3000, 5, 400, 60, first=1234, count=500)
+    whole = want.tobytes()
+    idx = whole.index(b">read_1234\n")
+    assert bytes(part.cpu().numpy()) == whole[idx:idx + part.numel()]
+    res = ctx.parse(int(t.data_ptr()), t.numel(), True)   # device pointer: parsed in place
+    w = F.flat_parse(whole)
+    assert int(res.n_records) == 3000 == w.n_records and int(res.seq_bytes) == w.seq_bytes.size
+    assert ctx.to_host(res.d_seq_bytes, int(res.seq_bytes), np.uint8).tobytes() == w.seq_bytes.tobytes()
+    torch.cuda.synchronize()
