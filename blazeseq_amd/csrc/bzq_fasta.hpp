@@ -63,6 +63,8 @@ __device__ __forceinline__ uint32_t space_flags(uint32_t x) {
                    ge32 = t + 0x60606060u, ge33 = t + 0x5F5F5F5Fu;
     return ((ge9 & ~ge14) | (ge28 & ~ge31) | (ge32 & ~ge33)) & ~x & 0x80808080u;
 }
+// 0x80 in every byte <= 32
+__device__ __forceinline__ uint32_t le32_flags(uint32_t x) { return ~(x | ((x & 0x7F7F7F7Fu) + 0x5F5F5F5Fu)) & 0x80808080u; }
 // 16-bit mask of the bytes equal to B (the v_perm/v_dot4 idiom of nl_mask16, bzq_device.hpp)
 template <uint32_t B>
 __device__ __forceinline__ uint32_t eq_mask16(uint4 v) {
@@ -146,7 +148,11 @@ __device__ __forceinline__ void tile_masks(const uint4 (&r)[4], int valid, uint1
         const uint4 v = r[s];
         uint32_t n = eq_mask16<10u>(v);
         uint32_t g = eq_mask16<62u>(v);
-        uint32_t x = ~flag_mask16(space_flags(v.x), space_flags(v.y), space_flags(v.z), space_flags(v.w)) & 0xFFFFu;
+        // X = not a posix space.  Almost every piece has no byte <= 32 other than its newlines: then X = ~N and the exact
+        // classification (13 ops per dword) is skipped for the whole wave
+        uint32_t x = ~n & 0xFFFFu;
+        if (flag_mask16(le32_flags(v.x), le32_flags(v.y), le32_flags(v.z), le32_flags(v.w)) != n)
+            x = ~flag_mask16(space_flags(v.x), space_flags(v.y), space_flags(v.z), space_flags(v.w)) & 0xFFFFu;
         uint32_t h = ASCII ? flag_mask16(v.x & 0x80808080u, v.y & 0x80808080u, v.z & 0x80808080u, v.w & 0x80808080u) : 0u;
         if (valid != TILE) {
             const int rem = valid - q * 16;
@@ -202,7 +208,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_tile_sums(SumsArgs a) {
     __shared__ __attribute__((aligned(16))) uint16_t s_n[TILE / 16], s_x[TILE / 16], s_g[TILE / 16];
     __shared__ uint32_t s_slot[4][BLOCK / 64];
     __shared__ u64 s_hasN[BLOCK / 64], s_hasE[BLOCK / 64];
-    __shared__ u64 s_acc[BLOCK / 64][3];
+    __shared__ uint32_t s_acc[BLOCK / 64][6];
     __shared__ uint32_t s_end;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t t = blockIdx.x, t0 = t * TILE;
@@ -236,26 +242,32 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_tile_sums(SumsArgs a) {
     const u64 M1 = n_before ? 0ull : (below_first(m.N) & vmask);
     const u64 M2 = n_after ? 0ull : (above_last(m.N) & vmask);
     const u64 MT = e_after ? 0ull : (above_last(E) & vmask);
-    u64 sumA = (u64)__builtin_popcountll(f.seq) | ((u64)__builtin_popcountll(f.id) << 16) | ((u64)__builtin_popcountll(f.FG) << 32) |
-               ((u64)__builtin_popcountll(m.N) << 48);
-    u64 sumB = (u64)__builtin_popcountll(f.seq & M1) | ((u64)__builtin_popcountll(f.id & M1) << 16) |
-               ((u64)__builtin_popcountll(f.Sa_incl & M1) << 32) | ((u64)__builtin_popcountll(f.Sb_incl & f.Sa_incl & M1) << 48);
-    u64 sumC = (u64)__builtin_popcountll(M1) | ((u64)__builtin_popcountll(M2) << 16) | ((u64)__builtin_popcountll(MT) << 32) |
-               ((u64)__builtin_popcountll(f.FG & M1) << 48) | ((u64)(m.X != 0) << 49);
-    sumA = wave_sum_u64(sumA); sumB = wave_sum_u64(sumB); sumC = wave_sum_u64(sumC);
-    if (lane == 0) { s_acc[wave][0] = sumA; s_acc[wave][1] = sumB; s_acc[wave][2] = sumC; }
+    auto pc = [](u64 x) { return (uint32_t)__builtin_popcountll(x); };
+    // twelve counts, each <= 64 per thread and <= 16384 per tile: two per dword, summed over the wave on DPP
+    uint32_t w[6] = {pc(f.seq) | (pc(f.id) << 16), pc(f.FG) | (pc(m.N) << 16), pc(f.seq & M1) | (pc(f.id & M1) << 16),
+                     pc(f.Sa_incl & M1) | (pc(f.Sb_incl & f.Sa_incl & M1) << 16), pc(M1) | (pc(M2) << 16),
+                     pc(MT) | ((pc(f.FG & M1) + ((uint32_t)(m.X != 0) << 1)) << 16)};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        w[k] = dpp_scan_u32(w[k]);
+        if (lane == 63) s_acc[wave][k] = w[k];
+    }
     if (tid == BLOCK - 1) s_end = state_of(f.end_sb, f.end_hdr, f.end_x2);
     const uint32_t lead_x = (uint32_t)(f.Sa_incl & 1ull);   // thread 0: an X comes before the first '\n'
     __syncthreads();
     if (tid == 0) {
-        u64 A = 0, B = 0, C = 0;
+        uint32_t t6[6];
 #pragma unroll
-        for (int i = 0; i < BLOCK / 64; ++i) { A += s_acc[i][0]; B += s_acc[i][1]; C += s_acc[i][2]; }
-        const u64 c0hdr = (C >> 48) & 1ull, anyx = (C >> 49) != 0;
-        const u64 flags = c0hdr | (anyx << 1) | ((u64)lead_x << 2) | ((u64)s_end << 3);
-        a.sums[3 * t + 0] = A;
-        a.sums[3 * t + 1] = B;
-        a.sums[3 * t + 2] = (C & 0xFFFFFFFFFFFFull) | (flags << 48);
+        for (int k = 0; k < 6; ++k) {
+            t6[k] = 0;
+#pragma unroll
+            for (int i = 0; i < BLOCK / 64; ++i) t6[k] += s_acc[i][k];
+        }
+        const u64 c0hdr_anyx = t6[5] >> 16;
+        const u64 flags = (c0hdr_anyx & 1ull) | ((u64)((c0hdr_anyx >> 1) != 0) << 1) | ((u64)lead_x << 2) | ((u64)s_end << 3);
+        a.sums[3 * t + 0] = (u64)(t6[0] & 0xFFFF) | ((u64)(t6[0] >> 16) << 16) | ((u64)(t6[1] & 0xFFFF) << 32) | ((u64)(t6[1] >> 16) << 48);
+        a.sums[3 * t + 1] = (u64)(t6[2] & 0xFFFF) | ((u64)(t6[2] >> 16) << 16) | ((u64)(t6[3] & 0xFFFF) << 32) | ((u64)(t6[3] >> 16) << 48);
+        a.sums[3 * t + 2] = (u64)(t6[4] & 0xFFFF) | ((u64)(t6[4] >> 16) << 16) | ((u64)(t6[5] & 0xFFFF) << 32) | (flags << 48);
     }
 }
 
