@@ -49,7 +49,7 @@ struct FaState {
     unsigned long long nohdr_pos;   // smallest offset of a sequence byte that comes before any header
     unsigned long long ascii_rec;   // smallest record with a byte >= 0x80 in id or sequence
     unsigned long long empty_rec;   // smallest closed record without sequence bytes
-    int64_t n_closed;               // records closed inside this chunk (all headers at EOF, all but the last otherwise)
+    int64_t n_closed;               // records closed inside this chunk (all at EOF; otherwise those followed by a header in a complete line)
     int64_t consumed, lines_consumed;
     int64_t last_line_start;        // offset after the last '\n' (0 if none)
     int64_t query[4];               // cold-path answers (k_fa_query)
@@ -116,15 +116,19 @@ __device__ __forceinline__ WaveChain chain_wave(u64 set, u64 clear, uint32_t* s_
 }
 template <bool REV>
 __device__ __forceinline__ uint32_t chain_cin(const WaveChain& w, const uint32_t* s_slot, uint32_t tile_cin) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // everything up to the per-lane bit pick is wave-uniform: keep it on the scalar unit
     uint32_t c = tile_cin;
     if (!REV) {
 #pragma unroll
-        for (int i = 0; i < BLOCK / 64; ++i) { const uint32_t v = s_slot[i]; if (i < wave && v != 2u) c = v; }
+        for (int i = 0; i < BLOCK / 64; ++i) { const uint32_t v = __builtin_amdgcn_readfirstlane(s_slot[i]); if (i < wave && v != 2u) c = v; }
+        c = __builtin_amdgcn_readfirstlane(c);
         return (uint32_t)(chain64(w.S, w.C, c).excl >> lane) & 1u;
     } else {
 #pragma unroll
-        for (int i = BLOCK / 64 - 1; i >= 0; --i) { const uint32_t v = s_slot[i]; if (i > wave && v != 2u) c = v; }
+        for (int i = BLOCK / 64 - 1; i >= 0; --i) { const uint32_t v = __builtin_amdgcn_readfirstlane(s_slot[i]); if (i > wave && v != 2u) c = v; }
+        c = __builtin_amdgcn_readfirstlane(c);
         return (uint32_t)(chain64(__builtin_bitreverse64(w.S), __builtin_bitreverse64(w.C), c).excl >> (63 - lane)) & 1u;
     }
 }
@@ -513,14 +517,18 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_finish(FinishArgs a) {
             lls = j * (int64_t)TILE + vj - (int64_t)((a.sums[3 * j + 2] >> 16) & 0xFFFF);
         }
         st->last_line_start = lls;
-        int64_t closed = a.is_eof ? H : (H > 0 ? H - 1 : 0);
+        // a chunk that is not the last one: a line without its '\n' yet is not looked at (it may still turn out too long),
+        // so a header in it neither closes the record before it nor opens one
+        int64_t Hc = H;
+        if (!a.is_eof && H > 0 && H - 1 < a.rec_cap && a.hdr_pos[H - 1] >= lls) Hc = H - 1;
+        int64_t closed = a.is_eof ? H : (Hc > 0 ? Hc - 1 : 0);
         st->n_closed = closed;
         if (a.is_eof && H > 0 && H - 1 < a.rec_cap) { a.seq_ends[H - 1] = st->seq_total; a.id_ends[H - 1] = st->id_total; }
         // where the next chunk starts: the line of the last header (the open record), or after the last blank line
         int64_t p = a.n;
         if (!a.is_eof) {
-            if (H > 0) {
-                p = H - 1 < a.rec_cap ? a.hdr_pos[H - 1] : 0;
+            if (Hc > 0) {
+                p = Hc - 1 < a.rec_cap ? a.hdr_pos[Hc - 1] : 0;
                 while (p > 0 && a.data[p - 1] != 10) --p;
             } else {
                 p = lls;

@@ -163,6 +163,12 @@ class FastaParser:
         if isinstance(source, (str, os.PathLike)):
             self._fh = open(source, "rb")
             self._own_file = True
+            if self._fh.read(2) == b"\x1f\x8b":   # gzip / BGZF, like the reference's GZFile reader (io/readers.mojo:283-377)
+                import gzip
+                self._fh.close()
+                self._fh = gzip.open(source, "rb")
+            else:
+                self._fh.seek(0)
         elif hasattr(source, "read"):
             self._fh = source
         else:

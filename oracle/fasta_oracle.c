@@ -109,15 +109,9 @@ int fa_flat_parse(const uint8_t* d, int64_t n, int check_ascii, int64_t line_cap
         const int64_t line_start = i;
         const uint8_t* nl = (const uint8_t*)memchr(d + i, '\n', (size_t)(n - i));
         const int64_t j = nl ? (int64_t)(nl - d) : n;
-        if (!nl && !is_eof) {
-            /* chunk mode: the last line is not finished.  If its first non-space byte is already there and is '>'
-             * it closes the open record; anything else waits for the next chunk. */
-            int64_t lo = line_start, hi = j;
-            fa_strip(d, &lo, &hi);
-            if (!(lo < hi && d[lo] == '>')) break;
-        }
+        if (!nl && !is_eof) break;   /* chunk mode: a line without its '\n' yet is not looked at (it may still turn out too long) */
         ++line_no;
-        if (j - line_start >= line_cap && (nl || is_eof)) {   /* buffered.mojo:634-636 */
+        if (j - line_start >= line_cap) {   /* buffered.mojo:634-636 */
             snprintf(f->message, sizeof f->message, "Line exceeds buffer capacity of %lld bytes", (long long)line_cap);
             f->status = FA_LINE_TOO_LONG;
             f->err_record = cur;

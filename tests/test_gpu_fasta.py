@@ -159,6 +159,12 @@ def test_line_capacity(ctxs):   # buffered.mojo:634-636, 737-765
         assert w.status != F.EOF
         check_chunk(ctx, data, False)
     assert check_chunk(ctx, b">x\n" + b"A" * (cap - 1), True).status == F.EOF
+    # a header line that is too long: "too long" is met while the line is read, before it can close the record before it
+    # (found by tests/fuzz_campaign_fasta.py: a chunk that ends inside that line must not close the record early)
+    data = b"\r\n" * 50 + b">id\n" + b" >" * 20000 + b"\nAC\n"
+    assert check_chunk(ctx, data, True).status == F.LINE_TOO_LONG
+    for cut in (110, 128, 20000, len(data) - 4, len(data) - 3):
+        check_chunk(ctx, data[:cut], False)
 
 
 def test_streaming_parser_matches_whole_file_and_reference_tests(tmp_path):
@@ -178,6 +184,10 @@ def test_streaming_parser_matches_whole_file_and_reference_tests(tmp_path):
     path.write_bytes(data)
     p = B.FastaParser(str(path), chunk_bytes=100_000)
     assert [(r.id, r.sequence) for r in p] == want
+    import gzip
+    gz = tmp_path / "x.fasta.gz"
+    gz.write_bytes(gzip.compress(data[:100_000], 1) + gzip.compress(data[100_000:], 6))   # two members, cut mid-record
+    assert [(r.id, r.sequence) for r in B.FastaParser(str(gz), chunk_bytes=64_000)] == want
     # a record larger than the chunk makes the chunk grow
     big = b">big\n" + b"ACGT" * 50_000 + b"\n>small\nAC\n"
     assert [(r.id, len(r)) for r in B.FastaParser(big, chunk_bytes=4096).records()] == [(b"big", 200_000), (b"small", 2)]
