@@ -250,6 +250,25 @@ class FastqRecord:
         return len(self.sequence)
 
 
+class FastqView:
+    """``FastqView`` (blazeseq/fastq/record.mojo:431-550): three spans into the parser's buffer, valid until the parser
+    moves to its next chunk (the reference: until the next parser call).  The spans are ``memoryview`` slices of the
+    host copy of the chunk; WHERE they are comes from the device (views mode, csrc/bzq_views.hpp)."""
+    __slots__ = ("id", "sequence", "quality", "phred_offset")
+
+    def __init__(self, id, sequence, quality, phred_offset=33):
+        self.id, self.sequence, self.quality, self.phred_offset = id, sequence, quality, phred_offset
+
+    def __len__(self):   # record.mojo:474-476: the sequence length
+        return len(self.sequence)
+
+    def byte_len(self) -> int:   # record.mojo:478-487
+        return 1 + len(self.id) + len(self.sequence) + len(self.quality) + 5
+
+    def to_record(self) -> FastqRecord:
+        return FastqRecord(bytes(self.id), bytes(self.sequence), bytes(self.quality), self.phred_offset)
+
+
 class DeviceFastqBatch:
     """blazeseq/fastq/record_batch.mojo:210-220: five device buffers + four scalars.  The buffers are
     device pointers (ints) into the parser's chunk columns."""
@@ -476,7 +495,7 @@ class FastqParser:
         # a plain file goes through the native ingest pipeline (reader threads + pinned double buffers);
         # bytes / arrays / file objects through the Reader.read_to_buffer-style loop below
         self._ingest: Optional[Ingest] = None
-        if native_ingest and isinstance(source, (str, os.PathLike)) and os.path.isfile(source):
+        if native_ingest and not self.config.views_only and isinstance(source, (str, os.PathLike)) and os.path.isfile(source):
             self._ingest = Ingest(self._ctx, os.fspath(source), max(int(chunk_bytes), 1 << 16), reader_threads)
             self._src = None
         else:
@@ -626,13 +645,58 @@ class FastqParser:
         r.phred_offset = self._ctx.quality_offset_schema
         return r
 
-    next_view = next_record
+    # ------------------------------------------------------------------ views (parser.mojo:159-170, 253-258, 628-661)
+    def _view_chunk(self):
+        """Host copies of the current chunk's RecordOffsets / id spans (views mode: the device wrote nothing else)."""
+        res = self._chunk
+        if getattr(res, "_view_cols", None) is None:
+            res._view_cols = (res.seq_start(), res.sep_start(), res.qual_start(), res.record_end(), res.id_start(), res.id_len(),
+                              memoryview(self._chunk_data))
+        return res._view_cols
+
+    def next_view(self) -> "FastqView":
+        """parser.mojo:159-170.  With ``config.views_only`` the spans are zero-copy slices of the chunk at offsets the
+        views-mode kernels produced; otherwise a view of a 1-record batch (plumbing)."""
+        if not self.config.views_only:
+            r = self.next_record()
+            return FastqView(r.id, r.sequence, r.quality, r.phred_offset)
+        while True:
+            if self._chunk is None:
+                if self._terminal is not None:
+                    break
+                self._load_chunk(1)
+            if self._next < int(self._chunk.n_records):
+                ss, sp, qs, re, ids, idl, mv = self._view_chunk()
+                r = self._next
+                self._next += 1
+                return FastqView(mv[ids[r]:ids[r] + idl[r]], mv[ss[r]:sp[r] - 1], mv[qs[r]:re[r]], self._ctx.quality_offset_schema)
+            if self._terminal is not None:
+                break
+            self._retire_chunk()
+        self._eof_seen = True
+        code, msg = self._terminal
+        raise (EOFError_ if code == L.EOF else ParseError)(code, msg if code != L.EOF else b"EOF")
+
+    def views(self) -> Iterator["FastqView"]:
+        """parser.mojo:253-258 + _FastqParserViewIter 628-661: EOF ends the iteration, any other error is printed first."""
+        if not self.config.views_only:
+            for r in self.records():
+                yield FastqView(r.id, r.sequence, r.quality, r.phred_offset)
+            return
+        while True:
+            try:
+                yield self.next_view()
+            except EOFError_:
+                return
+            except ParseError as e:
+                print(e.message.decode("latin-1"))
+                return
 
     def records(self) -> Iterator[FastqRecord]:
         """parser.mojo:260-265 + _FastqParserRecordIter 664-697: errors are printed and end the iteration."""
         while self.has_more():
             try:
-                b = self.next_batch(self._batch_size)
+                b = self.next_batch(self._batch_size, partial_ok=True)   # the records before a failing one still come out
             except ParseError as e:
                 print(e.message.decode("latin-1"))
                 return
@@ -642,4 +706,3 @@ class FastqParser:
                 r.phred_offset = self._ctx.quality_offset_schema
                 yield r
 
-    views = records

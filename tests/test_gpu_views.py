@@ -144,3 +144,46 @@ def test_views_api_and_spans():
     b = L.BzqDeviceBatch()
     assert L.lib().bzq_batch_view(ctx.h, 0, 10, C.byref(b)) < 0      # no columns in this mode
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_parser_views_iteration_matches_the_streaming_oracle(seed, capsys):
+    """FastqParser(config=ParserConfig(views_only=True)).views() / next_view(): zero-copy spans of the host chunk at the
+    offsets the views-mode kernels found, record by record like the reference's view iterator (parser.mojo:159-170,
+    253-258, 628-661) -- same views, same terminal error as the streaming oracle."""
+    import blazeseq_amd as B
+    rng = np.random.default_rng(4200 + seed)
+    data = rand_stream(rng, n_records=int(rng.integers(200, 2000)), max_len=150, dirty=[0.0, 0.0, 0.002, 0.0][seed], tail=[0, 3, 0, 1][seed])
+    check = bool(seed & 1)
+    ocfg = O.make_config(check_ascii=check, check_quality=check)
+    sp = O.StreamParser(np.frombuffer(data, dtype=np.uint8), ocfg)
+    want, werr = [], None
+    while True:
+        try:
+            v = sp.next_view()
+        except O.OracleError as e:
+            werr = e
+            break
+        want.append((v.id, v.seq, v.qual))
+    for chunk in (1 << 16, 1 << 26):
+        p = B.FastqParser(data, config=B.ParserConfig(check_ascii=check, check_quality=check, views_only=True), chunk_bytes=chunk)
+        got, gerr = [], None
+        while True:
+            try:
+                v = p.next_view()
+            except B.ParseError as e:
+                gerr = e
+                break
+            got.append((bytes(v.id), bytes(v.sequence), bytes(v.quality)))
+            assert len(v) == len(v.sequence) and v.byte_len() == 1 + len(v.id) + len(v.sequence) + len(v.quality) + 5
+        assert got == want, (len(got), len(want))
+        assert gerr.code == werr.code
+        if werr.code != O.EOF:
+            assert gerr.message.decode("latin-1") == str(werr)
+        # the iterator form ends on any error (printing it unless it is EOF)
+        p = B.FastqParser(data, config=B.ParserConfig(check_ascii=check, check_quality=check, views_only=True), chunk_bytes=chunk)
+        assert sum(1 for _ in p.views()) == len(want)
+        capsys.readouterr()
+    # without views_only the same call is plumbing over batches
+    assert [(bytes(v.id), bytes(v.sequence), bytes(v.quality)) for v in B.FastqParser(data, config=B.ParserConfig(check_ascii=check, check_quality=check)).views()] == want
+    capsys.readouterr()
