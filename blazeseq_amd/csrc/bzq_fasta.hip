@@ -162,11 +162,10 @@ int32_t bzq_fasta_parse(bzq_fasta* h, const uint8_t* data, uint64_t n, int32_t i
     int rc;
     const int64_t nt = (int64_t)((n + TILE - 1) / TILE);
     const int64_t ng = (nt + BLOCK - 1) / BLOCK;
-    const int64_t rec_cap = (int64_t)(n / 4) + 2;   // a record with sequence bytes takes at least 4 bytes
+    int64_t rec_cap = 0;   // sized from the header count once pass 1 and the scan are through (below)
     const bool on_device = n && is_device_pointer(data);
     if ((!on_device && (rc = ensure(h, h->in, (size_t)n + 64))) || (rc = ensure(h, h->seq, (size_t)n + 64)) ||
-        (rc = ensure(h, h->id, (size_t)n + 64)) || (rc = ensure(h, h->seq_ends, (size_t)rec_cap * 8)) ||
-        (rc = ensure(h, h->id_ends, (size_t)rec_cap * 8)) || (rc = ensure(h, h->hdr_pos, (size_t)rec_cap * 8)) ||
+        (rc = ensure(h, h->id, (size_t)n + 64)) ||
         (rc = ensure(h, h->sums, (size_t)(nt + 1) * 24)) || (rc = ensure(h, h->tile_in, (size_t)(nt + 1) * 4)) ||
         (rc = ensure(h, h->tile_cnt, (size_t)(nt + 1) * 16)) || (rc = ensure(h, h->grp, (size_t)(ng + 1) * 32)) ||
         (rc = ensure(h, h->base, (size_t)(nt + 1) * 32)))
@@ -193,17 +192,40 @@ int32_t bzq_fasta_parse(bzq_fasta* h, const uint8_t* data, uint64_t n, int32_t i
         hipLaunchKernelGGL(k_fa_resolve, dim3((unsigned)ng), dim3(BLOCK), 0, h->stream, ra);
         BasesArgs ba{(const uint32_t*)h->tile_cnt.p, (const int64_t*)h->grp.p, nt, ng, (int64_t*)h->base.p, h->d_state};
         hipLaunchKernelGGL(k_fa_bases, dim3((unsigned)ng), dim3(BLOCK), 0, h->stream, ba);
-        fa::EmitArgs ea{d, (int64_t)n, (const uint32_t*)h->tile_in.p, (const int64_t*)h->base.p, (uint8_t*)h->seq.p, (uint8_t*)h->id.p,
-                    (int64_t*)h->seq_ends.p, (int64_t*)h->id_ends.p, (int64_t*)h->hdr_pos.p, rec_cap, h->d_state};
-        if (h->cfg.check_ascii) hipLaunchKernelGGL(k_fa_emit<true>, dim3((unsigned)nt), dim3(BLOCK), 0, h->stream, ea);
-        else hipLaunchKernelGGL(k_fa_emit<false>, dim3((unsigned)nt), dim3(BLOCK), 0, h->stream, ea);
-        FinishArgs fa{d, (int64_t)n, is_eof, (const u64*)h->sums.p, (const int64_t*)h->base.p, nt, (int64_t*)h->seq_ends.p,
-                      (int64_t*)h->id_ends.p, (const int64_t*)h->hdr_pos.p, rec_cap, h->d_state};
-        hipLaunchKernelGGL(k_fa_finish, dim3(1), dim3(BLOCK), 0, h->stream, fa);
-        EmptyArgs ema{(const int64_t*)h->seq_ends.p, h->d_state, rec_cap};
-        hipLaunchKernelGGL(k_fa_empty, dim3(512), dim3(BLOCK), 0, h->stream, ema);
+        // per-record arrays: a guess first (one record per 64 input bytes, or what the last chunk needed); the kernels
+        // never write past rec_cap, and in the rare case the chunk holds more headers pass 2 is repeated with arrays of
+        // the right size (a bound from the chunk size alone would be n/4 records = 6 bytes of arrays per input byte)
+        rec_cap = std::max<int64_t>({(int64_t)(h->seq_ends.cap / 8), (int64_t)(n / 64) + 1024});
+        if ((rc = ensure(h, h->seq_ends, (size_t)rec_cap * 8)) || (rc = ensure(h, h->id_ends, (size_t)rec_cap * 8)) ||
+            (rc = ensure(h, h->hdr_pos, (size_t)rec_cap * 8)))
+            return rc;
+        h->rec_cap = rec_cap;
+        auto pass2 = [&]() {
+            fa::EmitArgs ea{d, (int64_t)n, (const uint32_t*)h->tile_in.p, (const int64_t*)h->base.p, (uint8_t*)h->seq.p, (uint8_t*)h->id.p,
+                            (int64_t*)h->seq_ends.p, (int64_t*)h->id_ends.p, (int64_t*)h->hdr_pos.p, rec_cap, h->d_state};
+            if (h->cfg.check_ascii) hipLaunchKernelGGL(k_fa_emit<true>, dim3((unsigned)nt), dim3(BLOCK), 0, h->stream, ea);
+            else hipLaunchKernelGGL(k_fa_emit<false>, dim3((unsigned)nt), dim3(BLOCK), 0, h->stream, ea);
+            FinishArgs fa{d, (int64_t)n, is_eof, (const u64*)h->sums.p, (const int64_t*)h->base.p, nt, (int64_t*)h->seq_ends.p,
+                          (int64_t*)h->id_ends.p, (const int64_t*)h->hdr_pos.p, rec_cap, h->d_state};
+            hipLaunchKernelGGL(k_fa_finish, dim3(1), dim3(BLOCK), 0, h->stream, fa);
+            EmptyArgs ema{(const int64_t*)h->seq_ends.p, h->d_state, rec_cap};
+            hipLaunchKernelGGL(k_fa_empty, dim3(512), dim3(BLOCK), 0, h->stream, ema);
+            (void)hipEventRecord(h->ev1, h->stream);
+        };
+        pass2();
+        FACHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(FaState), hipMemcpyDeviceToHost, h->stream));
+        FACHK(h, hipStreamSynchronize(h->stream));
+        if (h->h_state->n_headers + 2 > rec_cap) {   // more records than guessed: arrays of the right size, pass 2 again
+            rec_cap = h->h_state->n_headers + 2;
+            if ((rc = ensure(h, h->seq_ends, (size_t)rec_cap * 8)) || (rc = ensure(h, h->id_ends, (size_t)rec_cap * 8)) ||
+                (rc = ensure(h, h->hdr_pos, (size_t)rec_cap * 8)))
+                return rc;
+            h->rec_cap = rec_cap;
+            pass2();
+        }
+    } else {
+        FACHK(h, hipEventRecord(h->ev1, h->stream));
     }
-    FACHK(h, hipEventRecord(h->ev1, h->stream));
     FACHK(h, hipMemcpyAsync(h->h_state, h->d_state, sizeof(FaState), hipMemcpyDeviceToHost, h->stream));
     FACHK(h, hipStreamSynchronize(h->stream));
     FACHK(h, hipGetLastError());

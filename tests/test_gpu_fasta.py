@@ -223,3 +223,15 @@ def test_device_generator_and_device_input(ctxs):
     assert int(res.n_records) == 3000 == w.n_records and int(res.seq_bytes) == w.seq_bytes.size
     assert ctx.to_host(res.d_seq_bytes, int(res.seq_bytes), np.uint8).tobytes() == w.seq_bytes.tobytes()
     torch.cuda.synchronize()
+
+
+def test_more_records_than_the_first_guess(ctxs):
+    """Tiny records: far more headers than one per 64 bytes, so pass 2 is repeated with larger per-record arrays."""
+    import blazeseq_amd as B
+    ctx = B.FastaContext(B.FastaParserConfig(True))   # a fresh handle: nothing sized yet
+    data = b"".join(b">%d\nA\n" % (i % 10) for i in range(200_000))
+    w = check_chunk(ctx, data, True)
+    assert w.n_records == 200_000
+    check_chunk(ctx, data[:-1] + b"\n>\n", False)
+    check_chunk(ctx, b">a\n" + b">\n" * 100_000, True)   # and an error far beyond the guess
+    ctx.close()
