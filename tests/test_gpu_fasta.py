@@ -235,3 +235,51 @@ def test_more_records_than_the_first_guess(ctxs):
     check_chunk(ctx, data[:-1] + b"\n>\n", False)
     check_chunk(ctx, b">a\n" + b">\n" * 100_000, True)   # and an error far beyond the guess
     ctx.close()
+
+
+def test_full_benchmark_size_properties(ctxs):
+    """The reference's FASTA benchmark input at full size (1.5 M records of 200-3800 bp wrapped at 60 = 3.07 GB, generated on
+    the device): every per-record number against its closed form, and windows of the columns against an independent
+    parse of just those records (which the oracle checks byte for byte at this size in test_device_generator...)."""
+    import torch
+    ctx = ctxs(True)
+    N, lo, hi, lw = 1_500_000, 200, 3800, 60
+    t = ctx.generate_synthetic_device(N, lo, hi, lw)
+    res = ctx.parse(int(t.data_ptr()), t.numel(), True)
+    assert int(res.status) == F.EOF and int(res.n_records) == N
+    i = np.arange(N, dtype=np.int64)
+    L = lo + (i * 31 + 7) % (hi - lo + 1)
+    seq_ends = ctx.to_host(res.d_seq_ends, N, np.int64)
+    id_ends = ctx.to_host(res.d_id_ends, N, np.int64)
+    hdr_pos = ctx.to_host(res.d_hdr_pos, N, np.int64)
+    assert np.array_equal(seq_ends, np.cumsum(L))
+    assert np.array_equal(id_ends, 12 * (i + 1))                      # "read_%07d"
+    rec_bytes = 14 + L + (L + lw - 1) // lw                              # header line + bases + one '\n' per line
+    assert np.array_equal(hdr_pos, np.cumsum(rec_bytes) - rec_bytes) and int(rec_bytes.sum()) == t.numel()
+    assert int(res.seq_bytes) == int(L.sum()) and int(res.id_bytes) == 12 * N
+    # newline-free, ACGT-only sequence column; id column = the headers without '>' and '\n'
+    seq = _as_cuda(res.d_seq_bytes, int(res.seq_bytes))
+    hist = torch.bincount(seq[: 1 << 28].to(torch.int64), minlength=256)
+    assert int(hist.sum()) == int(hist[[65, 67, 71, 84]].sum())
+    ctx2 = ctxs(False)
+    for first in (0, 777_777, N - 1000):
+        part = ctx2.generate_synthetic_device(N, lo, hi, lw, first=first, count=1000)
+        r2 = ctx2.parse(int(part.data_ptr()), part.numel(), True)
+        assert int(r2.n_records) == 1000
+        s0 = int(seq_ends[first - 1]) if first else 0
+        a = ctx.to_host(res.d_seq_bytes + s0, int(r2.seq_bytes), np.uint8)
+        b = ctx2.to_host(r2.d_seq_bytes, int(r2.seq_bytes), np.uint8)
+        assert np.array_equal(a, b)
+        ia = ctx.to_host(res.d_id_bytes + 12 * first, 12000, np.uint8)
+        assert ia.tobytes() == b"".join(b"read_%07d" % k for k in range(first, first + 1000))
+    torch.cuda.synchronize()
+
+
+def _as_cuda(ptr, nbytes):
+    """A device pointer as a DLPack-able object (torch tensor view, no copy)."""
+    import torch
+
+    class _Holder:
+        def __init__(self):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+    return torch.as_tensor(_Holder(), device="cuda")
