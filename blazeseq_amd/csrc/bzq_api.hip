@@ -106,6 +106,10 @@ struct bzq_ctx {
     const uint8_t* agg_ptr = nullptr;  // shard whose tile aggregates are already in the arenas
     uint64_t agg_n = 0;
     int head_lines = 0;
+    // stream parsed in several chunks: absolute record ends of everything delivered so far (8 B per record), so that the
+    // reference's window can be replayed from the stream's first byte when the stream ends in bytes that are not a record
+    DevBuf tail_log;
+    int64_t records_before = -1;   // option "records_before": records delivered by earlier chunks; < 0 = no log
 };
 
 namespace {
@@ -131,6 +135,24 @@ int ensure(bzq_ctx* c, DevBuf& b, size_t bytes) {
     }
     b.cap = bytes;
     return 0;
+}
+
+// grows a buffer keeping its first `keep` bytes
+int ensure_keep(bzq_ctx* c, DevBuf& b, size_t bytes, size_t keep) {
+    if (bytes <= b.cap) return 0;
+    void* np = nullptr;
+    const size_t want = bytes + bytes / 2 + 4096;
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess) { c->err = "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e); return BZQ_ERR_NOMEM; }
+    if (b.p && keep) HIPCHK(c, hipMemcpyAsync(np, b.p, std::min(keep, b.cap), hipMemcpyDeviceToDevice, c->stream));
+    if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); }
+    b.p = np; b.cap = want;
+    return 0;
+}
+
+static __global__ void k_log_ends(const int64_t* __restrict__ rec_end, int64_t n, int64_t stream_pos, int64_t* __restrict__ log) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) log[r] = stream_pos + rec_end[r];
 }
 
 int64_t tiles_for(uint64_t n) { return (int64_t)((n + TILE - 1) / TILE); }
@@ -462,10 +484,10 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
 // Replays the reference's BufferedReader over the delivered records to learn the window state at
 // the moment the parser reaches the trailing non-record bytes, then classifies them exactly as
 // _next_ref_complete does (parser.mojo:451-522).  Cold path: only for a stream that ends in junk.
-int classify_tail(bzq_ctx* c, const std::vector<int64_t>& rec_end, int64_t first_header, int64_t consumed,
+int classify_tail(bzq_ctx* c, const std::vector<int64_t>& rec_end, int64_t N, int64_t first_header, int64_t consumed,
                   int tail_phase, bool tail_nonblank, bool* accept_last, int* phase_out, int64_t* cap_out) {
     Window s;
-    s.N = (int64_t)c->cur_n; s.cap = c->cfg.buffer_capacity; s.w = 0; s.end = 0; s.eof = false;
+    s.N = N; s.cap = c->cfg.buffer_capacity; s.w = 0; s.end = 0; s.eof = false;
     s.fill(); // BufferedReader.__init__, buffered.mojo:149
     const bool growth = c->cfg.buffer_growth_enabled != 0;
     const int64_t maxcap = c->cfg.buffer_max_capacity;
@@ -602,7 +624,7 @@ void bzq_destroy(bzq_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->in, &c->seq, &c->qual, &c->id, &c->ends, &c->id_ends, &c->rec_end, &c->b_ends,
+    DevBuf* bufs[] = {&c->tail_log, &c->in, &c->seq, &c->qual, &c->id, &c->ends, &c->id_ends, &c->rec_end, &c->b_ends,
                       &c->b_id_ends, &c->off[0], &c->off[1], &c->off[2], &c->off[3], &c->view_e, &c->view_i,
                       &c->tile_c, &c->tile_a,
                       &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc, &c->consumer_scratch, &c->gen_prefix, &c->id_start, &c->id_len, &c->entries, &c->tile_list};
@@ -643,6 +665,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "ablate")) c->ablate = (int)value;
     else if (!strcmp(key, "views_bytes")) c->views_bytes = (int)value;
     else if (!strcmp(key, "overlap")) c->overlap = (int)value;
+    else if (!strcmp(key, "records_before")) c->records_before = value;
     else if (!strcmp(key, "pass_bytes")) c->cfg.pass_bytes = value > 0 ? std::max<int64_t>(TILE, (value / TILE) * TILE) : 0;
     else { c->err = std::string("unknown option ") + key; return BZQ_ERR_ARG; }
     return 0;
@@ -753,6 +776,12 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     r.status = BZQ_OK;
     c->term_phase = 0; c->term_cap = c->cfg.buffer_capacity;
 
+    if (c->records_before >= 0 && !c->shard_mode && n_complete > 0) {
+        int rc2;
+        if ((rc2 = ensure_keep(c, c->tail_log, (size_t)(c->records_before + n_complete) * 8, (size_t)c->records_before * 8))) return rc2;
+        hipLaunchKernelGGL(k_log_ends, dim3((unsigned)((n_complete + 255) / 256)), dim3(256), 0, c->stream, (const int64_t*)c->rec_end.p,
+                           n_complete, (int64_t)c->cur_stream_pos, (int64_t*)c->tail_log.p + c->records_before);
+    }
     auto key_rec = [](u64 k) { return (int64_t)(k >> 3); };
     // first failing record among the complete ones; same record: buffer < structure < validation
     u64 best = ~0ull;
@@ -771,11 +800,20 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         if (consumed >= n) {
             r.status = BZQ_EOF;
         } else {
-            std::vector<int64_t> re((size_t)n_complete);
-            if (n_complete) HIPCHK(c, hipMemcpy(re.data(), c->rec_end.p, (size_t)n_complete * 8, hipMemcpyDeviceToHost));
+            // the records the window has passed over: this chunk's, or -- for a stream that came in several chunks and
+            // was logged -- every record since the stream's first byte, in stream offsets
+            const int64_t rb = c->records_before > 0 ? c->records_before : 0;
+            std::vector<int64_t> re((size_t)(rb + n_complete));
+            int64_t N = (int64_t)n, cons = consumed, fh = c->cur_first_header;
+            if (rb > 0) {
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+                HIPCHK(c, hipMemcpy(re.data(), c->tail_log.p, re.size() * 8, hipMemcpyDeviceToHost));
+                N += (int64_t)c->cur_stream_pos; cons += (int64_t)c->cur_stream_pos; fh = 0;
+            } else if (n_complete) {
+                HIPCHK(c, hipMemcpy(re.data(), c->rec_end.p, (size_t)n_complete * 8, hipMemcpyDeviceToHost));
+            }
             int ph = 0; int64_t cap = c->cfg.buffer_capacity;
-            int code = classify_tail(c, re, c->cur_first_header, consumed, tail_phase, h->tail_nonblank != 0,
-                                     &accept_last, &ph, &cap);
+            int code = classify_tail(c, re, N, fh, cons, tail_phase, h->tail_nonblank != 0, &accept_last, &ph, &cap);
             c->term_phase = ph; c->term_cap = cap;
             if (accept_last) {
                 // last record without trailing newline (Q4): structure check skipped, validation still applies
@@ -1273,6 +1311,7 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
     const uint64_t n = carry + s.len;
     const uint64_t spos = s.file_off - carry;
     c->shard_mode = false;
+    c->records_before = (int64_t)g->stats.records;   // records handed out so far: the tail log stays in stream order
     int rc = submit_common(c, s.dev + off, n, spos, s.eof ? 1 : 0, 0, 0, 0, 0, 10u, 0);
     if (rc < 0) return rc;
     rc = bzq_chunk_result(c, out);

@@ -543,6 +543,9 @@ class FastqParser:
                 have += blk.size
             if len(parts) > 1:
                 data = np.concatenate(parts)
+            # records delivered so far: the library keeps the stream's record ends so that the tail of a stream parsed in
+            # several chunks is judged with the reference's window where it really is (io/buffered.mojo:239-290)
+            self._ctx.set_option("records_before", self._records_before)
             self._ctx.submit_host(data, self._stream_pos, self._src_eof)
             res = self._ctx.result()
             if res.status == L.OK and int(res.n_records) < min_records:

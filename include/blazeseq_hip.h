@@ -195,7 +195,11 @@ int32_t bzq_set_stream(bzq_ctx* ctx, void* hip_stream);
 int32_t bzq_get_config(const bzq_ctx* ctx, bzq_config* out);
 /* Run-time knobs that are not part of ParserConfig: "pass_bytes" (bytes per kernel round),
  * "timing_detail" (per-kernel hipEvent timing in bzq_chunk), "force_dense" (tests: route every
- * tile through the serial in-kernel path). */
+ * tile through the serial in-kernel path), "records_before" (a stream submitted in SEVERAL chunks: the
+ * number of records delivered from earlier chunks, set before each bzq_submit_chunk_*; the ctx then keeps
+ * the stream's record ends -- 8 bytes per record on the device -- so that trailing bytes that are not a
+ * record are judged with the reference's BufferedReader window where it really sits, io/buffered.mojo:
+ * 239-290; -1 (default) = each chunk is judged as a stream of its own; bzq_ingest_next sets it itself). */
 int32_t bzq_set_option(bzq_ctx* ctx, const char* key, int64_t value);
 
 /* DeviceContext.enqueue_create_host_buffer (record_batch.mojo:316-323): pinned staging the host

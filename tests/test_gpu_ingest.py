@@ -189,3 +189,55 @@ def test_truncated_gzip_is_a_runtime_error_not_a_parse_result(tmp_path):
         path.write_bytes(comp[: len(comp) // 2])
         with pytest.raises(RuntimeError, match="gzread|BGZF"):
             list(B.FastqParser(str(path), batch_size=1000).batches())
+
+
+# ---- the reference's window at the end of a stream that came in several chunks ----------------------------------------
+
+@pytest.mark.parametrize("source", ["memory", "file"])
+def test_tail_of_a_multi_chunk_stream_is_judged_with_the_reference_window(source, tmp_path):
+    """An unterminated last record is accepted when the reference's window already reaches EOF and refused with
+    BUFFER_EXCEEDED when the record straddles the window's end (io/buffered.mojo:239-290, parser.mojo:451-522); junk
+    flips between UNEXPECTED_EOF and BUFFER_EXCEEDED the same way.  Where that window sits depends on every record since
+    the first byte, so a stream parsed in several chunks keeps a log of its record ends (option "records_before").  A
+    small buffer_capacity makes the refusing alignment common enough to meet it in a few dozen streams."""
+    import blazeseq_amd as B
+    cap = 4096
+    classes = set()
+    for seed in range(48):
+        rng = np.random.default_rng(8800 + seed)
+        tail = [1, 2, 3, 5][seed % 4]
+        data = rand_stream(rng, n_records=int(rng.integers(900, 1500)), max_len=150, dirty=0.0, tail=tail)
+        ocfg = O.make_config(buffer_capacity=cap, batch_size=256)
+        sp = O.StreamParser(np.frombuffer(data, dtype=np.uint8), ocfg)
+        want, werr = [], None
+        while True:
+            try:
+                b = sp.next_batch(256)
+            except O.OracleError as e:
+                werr = (e.code, str(e))
+                break
+            if len(b) == 0:
+                break
+            want.append((b.seq_bytes, b.ends))
+        if source == "file":
+            path = tmp_path / "s.fastq"
+            path.write_bytes(data)
+            src = str(path)
+        else:
+            src = data
+        p = B.FastqParser(src, batch_size=256, config=B.ParserConfig(buffer_capacity=cap), chunk_bytes=1 << 16)
+        got, gerr = [], None
+        while True:
+            try:
+                b = p.next_batch(256)
+            except B.ParseError as e:
+                gerr = (e.code, e.message.decode("latin-1"))
+                break
+            if len(b) == 0:
+                break
+            got.append((b._sequence_bytes.tobytes(), b._ends.tolist()))
+        assert len(data) > (1 << 16) + 4096                    # really several chunks
+        assert got == want, (seed, len(got), len(want))
+        assert gerr == werr, (seed, gerr, werr)
+        classes.add(werr[0] if werr else 0)
+    assert len(classes) >= 3, classes                          # accepted, refused (BUFFER_EXCEEDED) and UNEXPECTED_EOF all met
