@@ -394,6 +394,23 @@ def main():
                                  "ms_per_step": round(tv * 1e3, 4), "algorithmic_bytes_per_record": round((n + 52 * recs) / recs, 1),
                                  "note": "config.views_only: RecordOffsets + id spans into the chunk, no columns; one read of the input"}
             vctx.close()
+        if world == 1 and not args.views and not args.ablate and not sharded_mode and not args.long_reads:
+            # the FASTA path (`bench.py --fasta` is its own full line) on the reference's FASTA benchmark
+            # input, a third of the size, as one more figure next to the headline
+            fctx = B.FastaContext(B.FastaParserConfig(check_ascii=args.validate), local_rank)
+            ft = fctx.generate_synthetic_device(500_000, 200, 3800, 60)
+            fms = []
+            for _ in range(args.warmup + min(args.steps, 5)):
+                fres = fctx.parse(int(ft.data_ptr()), ft.numel(), True)
+                fms.append(fres.kernel_ms)
+            assert int(fres.status) == 6 and int(fres.n_records) == 500_000
+            fk = sum(fms[args.warmup:]) / len(fms[args.warmup:]) / 1e3
+            fA = ft.numel() + int(fres.seq_bytes) + int(fres.id_bytes) + 16 * 500_000
+            out["fasta_mode"] = {"value": round(ft.numel() / fk / 1e9, 3), "unit": "GB/s", "mrecords_per_s": round(0.5 / fk, 3),
+                                 "kernels_ms": round(fk * 1e3, 4), "roofline_frac": round(fA / fk / 1e9 / HBM_PEAK_GBS, 4),
+                                 "note": "FastaParser path, 500 k records of 200-3800 bp wrapped at 60 (1.02 GB) resident in HBM; kernel time"}
+            del ft
+            fctx.close()
         if world == 1 and not args.no_cpu_baseline:
             k = min(args.cpu_reads, recs)
             host = shard[:k * rec_bytes].cpu().numpy() if not args.long_reads else shard[:n].cpu().numpy()
