@@ -1095,12 +1095,12 @@ int32_t bzq_shard_scan(bzq_ctx* c, const uint8_t* d_data, uint64_t n, bzq_shard_
     hipLaunchKernelGGL(k_tile_aggregate2, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
     launch_scan(c, 0, nt, 0);
     hipLaunchKernelGGL(k_first_newlines, dim3(1), dim3(BLOCK), 0, c->stream, d_data, (int64_t)n, c->d_state);
+    // the whole summary comes back with the state: one copy into pinned memory, one synchronisation
+    HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost));
     out->n_newlines = (uint64_t)h->P;
     for (int i = 0; i < 4; ++i) out->first_nl[i] = h->first_nl[i];
-    HIPCHK(c, hipMemcpy(&out->first_byte, d_data, 1, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(&out->last_byte, d_data + (n - 1), 1, hipMemcpyDeviceToHost));
+    out->first_byte = h->edge_first; out->last_byte = h->edge_last;
     c->agg_ptr = d_data; c->agg_n = n;
     return 0;
 }

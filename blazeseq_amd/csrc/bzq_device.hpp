@@ -70,7 +70,8 @@ struct ChunkState {
     // pool ran out (a chunk of records of a few bytes), the host repeats the chunk on the byte-level kernels
     unsigned long long listed_tiles;
     int32_t views_fallback;
-    int32_t _pad2;
+    // shard scan: the shard's first and last byte (k_first_newlines), so that the summary is one copy back
+    uint8_t edge_first, edge_last, _pad2[2];
 };
 
 __device__ __forceinline__ bool is_posix_space(uint32_t c) {
@@ -1002,7 +1003,7 @@ static __global__ __launch_bounds__(BLOCK) void k_first_newlines(const uint8_t* 
     __shared__ int s_found;
     const int tid = threadIdx.x;
     if (tid < 4) st->first_nl[tid] = -1;
-    if (tid == 0) s_found = 0;
+    if (tid == 0) { s_found = 0; st->edge_first = n > 0 ? g[0] : 10; st->edge_last = n > 0 ? g[n - 1] : 10; }
     __syncthreads();
     for (int64_t base = 0; base < n; base += BLOCK * 16) {
         const int64_t pos = base + (int64_t)tid * 16;

@@ -101,13 +101,35 @@ def exchange_halo(shard: torch.Tensor, n: int, plan: ShardPlan, group=None) -> N
             w.wait()
 
 
+_gather_bufs = {}
+
+
 def _gather_rows(row: Sequence[int], device, group=None) -> List[List[int]]:
-    """One all_gather_into_tensor of a few int64 per rank and one copy to the host."""
+    """One all_gather_into_tensor of a few int64 per rank and one copy to the host.  The exchange is pure latency, so on
+    a GPU the four small tensors (pinned staging on both sides) are made once per (device, width, world) -- 35 us per
+    call instead of 52 us with a fresh tensor and a pageable copy back (scripts/gather_ab.py)."""
     world = dist.get_world_size(group)
-    mine = torch.tensor(list(row), dtype=torch.int64, device=device)
-    out = torch.empty(world * len(row), dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(out, mine, group=group)
-    return out.cpu().view(world, len(row)).tolist()
+    device = torch.device(device)
+    if device.type != "cuda":   # gloo on CPU tensors (the protocol tests)
+        mine = torch.tensor(list(row), dtype=torch.int64)
+        out = torch.empty(world * len(row), dtype=torch.int64)
+        dist.all_gather_into_tensor(out, mine, group=group)
+        return out.view(world, len(row)).tolist()
+    key = (device.index, len(row), world, id(group))
+    bufs = _gather_bufs.get(key)
+    if bufs is None:
+        h_in = torch.empty(len(row), dtype=torch.int64, pin_memory=True)
+        h_out = torch.empty(world * len(row), dtype=torch.int64, pin_memory=True)
+        bufs = (h_in, h_in.numpy(), torch.empty(len(row), dtype=torch.int64, device=device),
+                torch.empty(world * len(row), dtype=torch.int64, device=device), h_out, h_out.numpy())
+        _gather_bufs[key] = bufs
+    h_in, h_in_np, d_in, d_out, h_out, h_out_np = bufs
+    h_in_np[:] = list(row)
+    d_in.copy_(h_in, non_blocking=True)
+    dist.all_gather_into_tensor(d_out, d_in, group=group)
+    h_out.copy_(d_out, non_blocking=True)
+    torch.cuda.current_stream(device).synchronize()
+    return h_out_np.reshape(world, len(row)).tolist()
 
 
 def reduce_counts(records: int, bases: int, nbytes: int, first_error_global: int, device, group=None):
