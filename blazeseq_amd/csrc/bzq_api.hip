@@ -76,7 +76,7 @@ struct bzq_ctx {
     DevBuf in, seq, qual, id;
     DevBuf ends, id_ends, rec_end, b_ends, b_id_ends, off[4], view_e, view_i;
     int64_t rec_cap = 0;
-    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, gen_prefix, id_start, id_len, entries, tile_list;
+    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, gen_prefix, id_start, id_len, entries, tile_list, tile_vf;
     int64_t tile_cap = 0;
     ChunkState* d_state = nullptr;
     ChunkState* h_state = nullptr; // pinned
@@ -174,7 +174,9 @@ int ensure_chunk_arenas(bzq_ctx* c, uint64_t n, bool need_input) {
     }
     if (c->cfg.views_only) {   // line entries: a 4 KiB slot per tile + a pool of 64 KiB slots for tiles of tiny records
         c->pool_slots = std::max<int64_t>(16, nt / 8);
-        if ((rc = ensure(c, c->entries, (size_t)nt * ENT_STRIDE * 4)) || (rc = ensure(c, c->tile_list, (size_t)c->pool_slots * TILE * 4))) return rc;
+        if ((rc = ensure(c, c->entries, (size_t)nt * ENT_STRIDE * 4)) || (rc = ensure(c, c->tile_list, (size_t)c->pool_slots * TILE * 4)) ||
+            (rc = ensure(c, c->tile_vf, (size_t)nt + 64)))
+            return rc;
     }
     return 0;
 }
@@ -325,9 +327,14 @@ void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, int pass) {
     hipLaunchKernelGGL(k_scan_down, dim3((unsigned)ng), dim3(SG_THREADS), 0, c->stream, s);
 }
 
-// views mode without validation: pass A leaves a 4-byte entry per line and pass B never reads the input again
+// views mode through line entries: pass A leaves a 4-byte entry per line and pass B never reads the input again.  With
+// validation the entries carry two flag bits per line (non-ascii byte, byte outside the quality range); only the
+// reference's SIMD-width quirk of the quality check (compat_simd_width) depends on WHERE in a line a byte
+// sits and keeps the byte-level kernels.
+bool views_validating(const bzq_ctx* c) { return c->cfg.check_ascii || c->cfg.check_quality; }
 bool views_meta(const bzq_ctx* c) {
-    return c->cfg.views_only && !c->cfg.check_ascii && !c->cfg.check_quality && !c->views_bytes && !c->views_bytes_once;
+    return c->cfg.views_only && !c->views_bytes && !c->views_bytes_once &&
+           !(c->cfg.check_quality && c->cfg.compat_simd_width != 0);
 }
 
 void launch_views(bzq_ctx* c, dim3 grid, int64_t tb, int64_t te) {
@@ -337,8 +344,11 @@ void launch_views(bzq_ctx* c, dim3 grid, int64_t tb, int64_t te) {
                    (const u64*)c->tile_idc.p, (const int64_t*)c->tileP.p, (const uint32_t*)c->entries.p,
                    (const uint32_t*)c->tile_list.p, (int64_t*)c->off[0].p, (int64_t*)c->off[1].p, (int64_t*)c->off[2].p,
                    (int64_t*)c->off[3].p, (int64_t*)c->rec_end.p, (int64_t*)c->id_start.p, (int32_t*)c->id_len.p, c->rec_cap,
-                   c->cur_first_header, growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->d_state};
-        hipLaunchKernelGGL(k_views_join, dim3((unsigned)((te - tb + JOIN_TILES - 1) / JOIN_TILES)), dim3(BLOCK), 0, c->stream, j);
+                   c->cur_first_header, growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->d_state,
+                   (const uint8_t*)c->tile_vf.p, c->cfg.check_ascii, c->cfg.check_quality};
+        const dim3 jg((unsigned)((te - tb + JOIN_TILES - 1) / JOIN_TILES));
+        if (views_validating(c)) hipLaunchKernelGGL(k_views_join<true>, jg, dim3(BLOCK), 0, c->stream, j);
+        else hipLaunchKernelGGL(k_views_join<false>, jg, dim3(BLOCK), 0, c->stream, j);
         return;
     }
     ViewArgs v{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (const int64_t*)c->tileP.p,
@@ -381,8 +391,9 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
                 if (views_meta(c)) {
                     LineArgs la{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
                                 (u64*)c->tile_idc.p, (uint32_t*)c->entries.p, (uint32_t*)c->tile_list.p, c->pool_slots, c->d_state,
-                                c->force_dense};
-                    hipLaunchKernelGGL(k_tile_lines, grid, dim3(BLOCK), 0, c->stream, la);
+                                c->force_dense, (uint8_t*)c->tile_vf.p, (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper};
+                    if (views_validating(c)) hipLaunchKernelGGL(k_tile_lines<true>, grid, dim3(BLOCK), 0, c->stream, la);
+                    else hipLaunchKernelGGL(k_tile_lines<false>, grid, dim3(BLOCK), 0, c->stream, la);
                 } else if (c->cfg.views_only) hipLaunchKernelGGL(k_tile_count, grid, dim3(BLOCK), 0, c->stream, a);
                 else if (c->v2) hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
                 else hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
@@ -627,7 +638,7 @@ void bzq_destroy(bzq_ctx* c) {
     DevBuf* bufs[] = {&c->tail_log, &c->in, &c->seq, &c->qual, &c->id, &c->ends, &c->id_ends, &c->rec_end, &c->b_ends,
                       &c->b_id_ends, &c->off[0], &c->off[1], &c->off[2], &c->off[3], &c->view_e, &c->view_i,
                       &c->tile_c, &c->tile_a,
-                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc, &c->consumer_scratch, &c->gen_prefix, &c->id_start, &c->id_len, &c->entries, &c->tile_list};
+                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc, &c->consumer_scratch, &c->gen_prefix, &c->id_start, &c->id_len, &c->entries, &c->tile_list, &c->tile_vf};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->d_state) hipFree(c->d_state);
     if (c->h_state) hipHostFree(c->h_state);

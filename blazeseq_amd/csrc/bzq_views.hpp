@@ -10,6 +10,7 @@
 //   k_views_check    per record: sequence / quality length check (utils.mojo:458-461) from the offsets, the
 //                    buffer-capacity refusal, and the chunk totals the host reads
 #pragma once
+#include "bzq_chain.hpp"
 #include "bzq_fused.hpp"
 
 namespace bzq {
@@ -38,8 +39,14 @@ struct ViewArgs {
 // ---- line entries: what pass A leaves behind for every newline, so that pass B never looks at the bytes again ----------
 // bits 0-13  tile offset of the newline
 // bit  14/15 the byte after it (the first byte of the next line) is '@' / '+'
-// bits 16-23 number of POSIX-space bytes that follow that first byte (the next line's leading id spaces), saturating
-// bits 24-31 number of POSIX-space bytes just before the newline (this line's trailing id spaces), saturating
+// bits 16-22 number of POSIX-space bytes that follow that first byte (the next line's leading id spaces), saturating at 127
+// bit  23    validation: a byte >= 0x80 between the previous newline OF THIS TILE (or the tile's first byte) and this one
+// bits 24-30 number of POSIX-space bytes just before the newline (this line's trailing id spaces), saturating at 127
+// bit  31    validation: a byte outside [q_lower, q_upper] in the same stretch
+// (validation also keeps one byte per tile, tile_vf: the two flags of the stretch AFTER the tile's last newline -- the
+// whole tile when it has none -- so that a line is judged from the entry of its newline, the tail byte of the tile its
+// previous newline sits in, and the bytes of the newline-free tiles in between)
+constexpr uint32_t ENT_SAT = 127u;
 constexpr int ENT_STRIDE = 1024;   // entries per ordinary tile; slot 1023 of tile 0 describes the line that starts the chunk
 constexpr int MAXE = 1020;         // a tile with more newlines (records of a few bytes) takes a 16384-entry slot of the pool
 
@@ -56,13 +63,15 @@ struct LineArgs {
     int64_t pool_slots;
     ChunkState* st;
     int32_t force_dense;   // test switch: every tile through the pool
+    uint8_t* tile_vf;      // validation: per tile, bit 0 / 1 = non-ascii / out-of-range byte after the tile's last newline
+    uint32_t q_lower, q_upper;
 };
 
 __device__ __forceinline__ uint32_t line_start_info(const ByteSrc& b, int64_t s) {   // s = first byte of a line
     if (s >= b.n) return 0u;
     const uint32_t c0 = b.at(s);
     uint32_t lead = 0;
-    for (int64_t p = s + 1; p < b.n && lead < 255u; ++p) {
+    for (int64_t p = s + 1; p < b.n && lead < ENT_SAT; ++p) {
         const uint32_t c = b.at(p);
         if (c == 10u || !is_posix_space(c)) break;
         ++lead;
@@ -72,9 +81,19 @@ __device__ __forceinline__ uint32_t line_start_info(const ByteSrc& b, int64_t s)
 
 // Pass A of the metadata pipeline: the ONLY kernel that reads the input.  One workgroup per tile; every thread owns the
 // newlines of its 64 bytes.
+// 0x80 in every byte outside [lo, hi] (hi < 128)
+__device__ __forceinline__ uint32_t out_of_range_flags(uint32_t x, uint32_t lo, uint32_t hi) {
+    const uint32_t t = x & 0x7F7F7F7Fu;
+    const uint32_t ge_lo = t + (0x80u - lo) * 0x01010101u, gt_hi = t + (0x7Fu - hi) * 0x01010101u;
+    return (~ge_lo | gt_hi | x) & 0x80808080u;
+}
+
+template <bool VAL>
 static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
+    __shared__ __attribute__((aligned(16))) uint16_t s_hi[VAL ? PIECES : 4], s_out[VAL ? PIECES : 4];
+    __shared__ uint32_t s_chain[2][BLOCK / 64];
     __shared__ uint32_t s_w[BLOCK / 64];
     __shared__ int64_t s_slot;
     uint8_t* s_tile = s_tile_raw + 16;
@@ -86,9 +105,36 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
     uint4 r[4];
     tile_fetch(a.g, a.n, t0, valid, r);
     tile_stage<true>(r, valid, s_mask, s_tile);
+    if (VAL) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int q = tid + BLOCK * s;
+            uint32_t h = fa::flag_mask16(r[s].x & 0x80808080u, r[s].y & 0x80808080u, r[s].z & 0x80808080u, r[s].w & 0x80808080u);
+            uint32_t o = fa::flag_mask16(out_of_range_flags(r[s].x, a.q_lower, a.q_upper), out_of_range_flags(r[s].y, a.q_lower, a.q_upper),
+                                         out_of_range_flags(r[s].z, a.q_lower, a.q_upper), out_of_range_flags(r[s].w, a.q_lower, a.q_upper));
+            if (valid != TILE) {
+                const int rem = valid - q * 16;
+                const uint32_t keep = rem >= 16 ? 0xFFFFu : (rem > 0 ? ((1u << rem) - 1u) : 0u);
+                h &= keep; o &= keep;
+            }
+            s_hi[q] = (uint16_t)h; s_out[q] = (uint16_t)o;
+        }
+    }
     ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
     __syncthreads();
     const u64 m64 = reinterpret_cast<const u64*>(s_mask)[tid];
+    // validation: "such a byte since the last newline of this tile", read just before every newline
+    u64 na_before = 0, or_before = 0;
+    if (VAL) {
+        const u64 hi64 = reinterpret_cast<const u64*>(s_hi)[tid], out64 = reinterpret_cast<const u64*>(s_out)[tid] & ~m64;
+        const fa::WaveChain wh = fa::chain_wave<false>(hi64, m64, s_chain[0]);
+        const fa::WaveChain wo = fa::chain_wave<false>(out64, m64, s_chain[1]);
+        __syncthreads();
+        const fa::Chain ch = fa::chain64(hi64, m64, fa::chain_cin<false>(wh, s_chain[0], 0u));
+        const fa::Chain co = fa::chain64(out64, m64, fa::chain_cin<false>(wo, s_chain[1], 0u));
+        na_before = ch.excl; or_before = co.excl;
+        if (tid == BLOCK - 1) a.tile_vf[t] = (uint8_t)((ch.incl >> 63) | ((co.incl >> 63) << 1));
+    }
     uint32_t c = 0;
     const uint32_t excl = block_exclusive_scan<uint32_t, BLOCK / 64>((uint32_t)__popcll(m64), s_w, c);
     const bool pooled = ((int)c > MAXE) || a.force_dense;
@@ -113,12 +159,14 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
         const int pos = tid * 64 + bit;
         const int64_t gp = t0 + pos;
         uint32_t trail = 0;
-        for (int64_t p = gp - 1; trail < 255u; --p) {
+        for (int64_t p = gp - 1; trail < ENT_SAT; --p) {
             const uint32_t ch = bs.at(p);
             if (ch == 10u || !is_posix_space(ch)) break;
             ++trail;
         }
-        out[idx] = (uint32_t)pos | line_start_info(bs, gp + 1) | (trail << 24);
+        uint32_t e = (uint32_t)pos | line_start_info(bs, gp + 1) | (trail << 24);
+        if (VAL) e |= ((uint32_t)((na_before >> bit) & 1ull) << 23) | ((uint32_t)((or_before >> bit) & 1ull) << 31);
+        out[idx] = e;
         ++idx;
     }
 }
@@ -142,6 +190,8 @@ struct JoinArgs {
     int32_t* id_len;
     int64_t rec_cap, first_header, len_limit;
     ChunkState* st;
+    const uint8_t* tile_vf;   // validation (see the entry layout)
+    int32_t check_ascii, check_quality;
 };
 
 constexpr int JOIN_TILES = 8;   // tiles per workgroup of the join (4 / 8 / 16: 0.216 / 0.206 / 0.204 ms)
@@ -150,6 +200,7 @@ constexpr int JOIN_TILES = 8;   // tiles per workgroup of the join (4 / 8 / 16: 
 // each is found by its tile (the tile prefixes of the scan) and its rank inside it; the five entries give every offset,
 // both structure bytes, the id span and the length / buffer checks -- 20 bytes read, 52 written, all arrays coalesced.
 // A workgroup takes the records whose LAST newline lies in its JOIN_TILES tiles.
+template <bool VAL>
 static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
     __shared__ int64_t s_P[JOIN_TILES + 1];
     __shared__ u64 s_slot[JOIN_TILES];
@@ -163,12 +214,13 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
     __syncthreads();
     const int64_t Gbeg = s_P[0], Gend = s_P[nt];            // newline indices [Gbeg, Gend) live in this window
     const int64_t P0 = a.st->P0, lines = a.st->P;             // P0 + all newlines of the chunk
-    u64 e_struct = ~0ull, e_buf = ~0ull;
+    u64 e_struct = ~0ull, e_buf = ~0ull, e_valid = ~0ull;
     bool overflow = false;
+    int64_t loc_tile = -1;   // tile of the newline the last locate() found (-1: the virtual one before the chunk)
 
     // entry and absolute position of newline G (P0 - 1 = the virtual newline before the chunk's first line)
     auto locate = [&](int64_t G, int64_t hint, uint32_t& e) -> int64_t {
-        if (G < P0) { e = a.entries[ENT_STRIDE - 1]; return -1; }
+        if (G < P0) { e = a.entries[ENT_STRIDE - 1]; loc_tile = -1; return -1; }
         int64_t tt, j;
         u64 slot;
         if (G >= Gbeg) {                                     // inside the window: prefixes and slots are in LDS
@@ -183,12 +235,21 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
             j = G - a.tileP[tt]; slot = a.tile_slot[tt];
         }
         e = slot ? a.pool[(int64_t)(slot - 1) * TILE + j] : a.entries[tt * ENT_STRIDE + j];
+        loc_tile = tt;
         return tt * TILE + (int64_t)(e & 0x3FFFu);
     };
+    // validation flags (bit 0 non-ascii, bit 1 out of range) of the line between two consecutive newlines: the entry of
+    // the closing one covers its own tile; the line's earlier tiles are the tail of the opening newline's tile and
+    // newline-free tiles
+    auto line_flags = [&](int64_t tile_open, int64_t tile_close, uint32_t e_close) -> uint32_t {
+        uint32_t f = ((e_close >> 23) & 1u) | (((e_close >> 31) & 1u) << 1);
+        for (int64_t t = tile_open < 0 ? 0 : tile_open; t < tile_close; ++t) f |= a.tile_vf[t];
+        return f;
+    };
     auto id_of = [&](int64_t hs, uint32_t e_hs, int64_t nl0, uint32_t e_nl0, int64_t& lo, int64_t& hi) {
-        const uint32_t lead = (e_hs >> 16) & 0xFFu, trail = e_nl0 >> 24;
+        const uint32_t lead = (e_hs >> 16) & 0x7Fu, trail = (e_nl0 >> 24) & 0x7Fu;
         lo = hs + 1 + (int64_t)lead; hi = nl0 - (int64_t)trail;
-        if (lead == 255u || trail == 255u) {                 // a space run too long for an entry: from the bytes
+        if (lead == ENT_SAT || trail == ENT_SAT) {           // a space run too long for an entry: from the bytes
             ByteSrc bs{a.g, a.n, a.prev_byte, nullptr, 0, 0};
             id_span(bs, hs, nl0, lo, hi);
         }
@@ -202,8 +263,11 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
         if (r >= a.rec_cap) { overflow = true; continue; }
         const int64_t G3 = 4 * r + 3, t3 = ta;
         uint32_t e3, e2, e1, e0, ep;
-        const int64_t p3 = locate(G3, t3, e3), p2 = locate(G3 - 1, t3, e2), p1 = locate(G3 - 2, t3, e1),
-                      p0 = locate(G3 - 3, t3, e0), pp = locate(G3 - 4, t3, ep);
+        const int64_t p3 = locate(G3, t3, e3); const int64_t T3 = loc_tile;
+        const int64_t p2 = locate(G3 - 1, t3, e2); const int64_t T2 = loc_tile;
+        const int64_t p1 = locate(G3 - 2, t3, e1); const int64_t T1 = loc_tile;
+        const int64_t p0 = locate(G3 - 3, t3, e0); const int64_t T0 = loc_tile;
+        const int64_t pp = locate(G3 - 4, t3, ep); const int64_t TP = loc_tile;
         const int64_t hs = pp + 1;
         a.o_hdr[r] = hs; a.o_seq[r] = p0 + 1; a.o_sep[r] = p1 + 1; a.o_qual[r] = p2 + 1; a.rec_end[r] = p3;
         int64_t lo, hi;
@@ -215,6 +279,14 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
         else if (!(e1 & (1u << 15))) k = ((u64)r << 3) | 2ull;
         else if ((p1 - p0 - 1) != (p3 - p2 - 1)) k = ((u64)r << 3) | 3ull;
         e_struct = k < e_struct ? k : e_struct;
+        if (VAL) {   // Validator._validate (record.mojo:162-172): ascii over id, sequence, quality, then the quality range
+            const uint32_t fh = line_flags(TP, T0, e0), fs = line_flags(T0, T1, e1), fq = line_flags(T2, T3, e3);
+            u64 kv = ~0ull;
+            if (a.check_ascii && ((fh | fs | fq) & 1u)) kv = ((u64)r << 3) | 4ull;
+            else if (a.check_quality && (fq & 2u)) kv = ((u64)r << 3) | 5ull;
+            e_valid = kv < e_valid ? kv : e_valid;
+        }
+        (void)T1; (void)T2; (void)T3; (void)T0; (void)TP;
         const int64_t prev_end = r ? pp : a.first_header - 1;
         if (p3 - prev_end > a.len_limit) { const u64 kb = (u64)r << 3; e_buf = kb < e_buf ? kb : e_buf; }
     }
@@ -241,11 +313,28 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
                 a.id_start[r] = lo; a.id_len[r] = (int32_t)(hi - lo);
                 if (k >= 2) { const int64_t p1 = locate(4 * r + 1, tb - 1, e1); if (p1 + 1 < a.n) a.o_sep[r] = p1 + 1; }
                 if (k >= 3) { const int64_t p2 = locate(4 * r + 2, tb - 1, e2); if (p2 + 1 < a.n) a.o_qual[r] = p2 + 1; }
+                if (VAL && k == 3) {
+                    // an unterminated last record may be delivered (parser.mojo:464-475) and is validated like any other:
+                    // its quality line is everything after the chunk's last newline
+                    uint32_t x;
+                    (void)locate(4 * r - 1, tb - 1, x); const int64_t tp = loc_tile;
+                    (void)locate(4 * r, tb - 1, x); const int64_t t0l = loc_tile;
+                    (void)locate(4 * r + 1, tb - 1, x); const int64_t t1l = loc_tile;
+                    (void)locate(4 * r + 2, tb - 1, x); const int64_t t2l = loc_tile;
+                    const uint32_t fh = line_flags(tp, t0l, e0), fs = line_flags(t0l, t1l, e1);
+                    uint32_t fq = 0;
+                    for (int64_t t = t2l < 0 ? 0 : t2l; t < a.n_tiles; ++t) fq |= a.tile_vf[t];
+                    u64 kv = ~0ull;
+                    if (a.check_ascii && ((fh | fs | fq) & 1u)) kv = ((u64)r << 3) | 4ull;
+                    else if (a.check_quality && (fq & 2u)) kv = ((u64)r << 3) | 5ull;
+                    e_valid = kv < e_valid ? kv : e_valid;
+                }
             }
         } else if (r >= a.rec_cap) overflow = true;
     }
     if (e_struct != ~0ull) atomicMin(&a.st->err_struct, e_struct);
     if (e_buf != ~0ull) atomicMin(&a.st->err_buf, e_buf);
+    if (VAL && e_valid != ~0ull) atomicMin(&a.st->err_valid, e_valid);
     if (overflow) atomicOr(&a.st->rec_overflow, 1);
 }
 

@@ -106,3 +106,34 @@ def test_config4_full_size_checksum_of_checksums():
     h[ord("\n")] += 4 * reads; h[ord("@")] += reads; h[ord("+")] += reads
     np.testing.assert_array_equal(h, h_in)
     ctx.close()
+
+
+@pytest.mark.parametrize("validate", [False, True])
+def test_config2_and_3_full_size_views_mode(validate):
+    """The same 10 M records through views mode (offsets + id spans, no columns; with validation: the line entries carry
+    the two validation flags and the input is still read once): every offset is an arithmetic progression, and the
+    config-3 byte flips stop at exactly that record with exactly that code."""
+    import torch
+    import blazeseq_amd as B
+    cfg = B.ParserConfig(check_ascii=validate, check_quality=validate, quality_schema="sanger" if validate else None, views_only=True)
+    ctx = B.Context(cfg, "generic", 4096, 0)
+    t, n = _gen(ctx, R2, 150, 33, 73, "generic")
+    ctx.submit_device(t.data_ptr(), n, 0, True)
+    res = ctx.result()
+    assert int(res.n_records) == R2 and res.status == 6 and int(res.bytes_consumed) == n
+    r = torch.arange(R2, dtype=torch.int64, device="cuda")
+    for ptr, off in ((res.d_header_start, 0), (res.d_seq_start, 14), (res.d_sep_start, 165), (res.d_qual_start, 167), (res.d_record_end, 317),
+                     (res.d_id_start, 1)):
+        assert torch.equal(_view(ptr, 8 * R2, torch.int64), 318 * r + off)
+    del r
+    if validate:
+        for rec, off, val, code in ((R2 - 1, 14 + 70, 0x80, 4), (4096, 167 + 3, 0x1F, 5), (4095, 14 + 149, 0x80, 4), (0, 167 + 149, 0x1F, 5),
+                                    (5_000_000, 3, 0x80, 4), (7, 167, 0x7F, 5)):
+            pos = rec * 318 + off
+            keep = int(t[pos].item())
+            t[pos] = val
+            ctx.submit_device(t.data_ptr(), n, 0, True)
+            bad = ctx.result()
+            assert bad.status == code and int(bad.n_records) == rec and int(bad.error_record) == rec, (rec, bad.status, int(bad.n_records))
+            t[pos] = keep
+    ctx.close()
