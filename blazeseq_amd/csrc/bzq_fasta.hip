@@ -72,7 +72,7 @@ bool is_device_pointer(const void* p) {
 // cold path: k_fa_query for one position -> {newlines before, start of its line, headers before}
 int query(bzq_fasta* h, int64_t pos, int64_t out[3]) {
     QueryArgs q{h->cur, (int64_t)h->cur_n, (const int64_t*)h->base.p, (const int64_t*)h->hdr_pos.p,
-                std::min<int64_t>(h->h_state->n_headers, h->rec_cap), pos, h->d_state};
+                std::min<int64_t>(h->h_state->n_headers, h->rec_cap), pos, h->d_state, h->cfg.line_capacity};
     hipLaunchKernelGGL(k_fa_query, dim3(1), dim3(BLOCK), 0, h->stream, q);
     FaState tmp;
     FACHK(h, hipMemcpyAsync(&tmp, h->d_state, sizeof tmp, hipMemcpyDeviceToHost, h->stream));
@@ -180,7 +180,7 @@ int32_t bzq_fasta_parse(bzq_fasta* h, const uint8_t* data, uint64_t n, int32_t i
     h->message.clear();
 
     FaState init{};
-    init.long_pos = init.nohdr_pos = init.ascii_rec = init.empty_rec = NONE;
+    init.long_pos = init.long_tile = init.nohdr_pos = init.ascii_rec = init.empty_rec = NONE;
     *h->h_state = init;
     FACHK(h, hipMemcpyAsync(h->d_state, h->h_state, sizeof(FaState), hipMemcpyHostToDevice, h->stream));
     FACHK(h, hipEventRecord(h->ev0, h->stream));
@@ -206,7 +206,7 @@ int32_t bzq_fasta_parse(bzq_fasta* h, const uint8_t* data, uint64_t n, int32_t i
             if (h->cfg.check_ascii) hipLaunchKernelGGL(k_fa_emit<true>, dim3((unsigned)nt), dim3(BLOCK), 0, h->stream, ea);
             else hipLaunchKernelGGL(k_fa_emit<false>, dim3((unsigned)nt), dim3(BLOCK), 0, h->stream, ea);
             FinishArgs fa{d, (int64_t)n, is_eof, (const u64*)h->sums.p, (const int64_t*)h->base.p, nt, (int64_t*)h->seq_ends.p,
-                          (int64_t*)h->id_ends.p, (const int64_t*)h->hdr_pos.p, rec_cap, h->d_state};
+                          (int64_t*)h->id_ends.p, (const int64_t*)h->hdr_pos.p, rec_cap, h->d_state, h->cfg.line_capacity};
             hipLaunchKernelGGL(k_fa_finish, dim3(1), dim3(BLOCK), 0, h->stream, fa);
             EmptyArgs ema{(const int64_t*)h->seq_ends.p, h->d_state, rec_cap};
             hipLaunchKernelGGL(k_fa_empty, dim3(512), dim3(BLOCK), 0, h->stream, ema);
@@ -243,6 +243,14 @@ int32_t bzq_fasta_parse(bzq_fasta* h, const uint8_t* data, uint64_t n, int32_t i
     // ---- the first error, in the order the reference meets them (oracle/fasta_oracle.c) ----
     // a line of >= capacity bytes: one with its '\n' (k_fa_resolve), or the last line of the input
     int64_t long_pos = st.long_pos == NONE ? -1 : (int64_t)st.long_pos;
+    if (st.long_tile != NONE) {   // a line so long that pass 1's bounded walk lost its start: find it (cold)
+        LongStartArgs la{(const u64*)h->sums.p, (int64_t)st.long_tile, h->d_state};
+        hipLaunchKernelGGL(k_fa_long_start, dim3(1), dim3(BLOCK), 0, h->stream, la);
+        FaState tmp;
+        FACHK(h, hipMemcpyAsync(&tmp, h->d_state, sizeof tmp, hipMemcpyDeviceToHost, h->stream));
+        FACHK(h, hipStreamSynchronize(h->stream));
+        if (long_pos < 0 || tmp.query[3] < long_pos) long_pos = tmp.query[3];
+    }
     if (nt && is_eof && (int64_t)n - st.last_line_start >= cap && (long_pos < 0 || st.last_line_start < long_pos)) long_pos = st.last_line_start;
     int64_t killed = INT64_MAX;   // the record that is open when the error is met; -1 = before any header
     int code = 0;

@@ -46,6 +46,7 @@ constexpr unsigned long long NONE = ~0ull;
 struct FaState {
     int64_t n_headers, seq_total, id_total, nl_total;   // k_fa_bases
     unsigned long long long_pos;    // smallest start offset of a line of >= line_cap bytes that has its '\n' (NONE)
+    unsigned long long long_tile;   // smallest tile whose first '\n' ends a line that began more than line_cap bytes earlier (NONE)
     unsigned long long nohdr_pos;   // smallest offset of a sequence byte that comes before any header
     unsigned long long ascii_rec;   // smallest record with a byte >= 0x80 in id or sequence
     unsigned long long empty_rec;   // smallest closed record without sequence bytes
@@ -288,21 +289,30 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_resolve(ResolveArgs a) {
     int64_t v[4] = {0, 0, 0, 0};
     if (t < a.n_tiles) {
         const TileView me(a.sums, t);
-        // the state of the line that enters tile t: the nearest earlier tile with a '\n' fixes it, tiles without one map it
+        // the state of the line that enters tile t: the nearest earlier tile with a '\n' fixes it, tiles without one map it.
+        // Both walks stop after line_cap bytes: a line that long is an error whatever its state (the host then finds its
+        // start with k_fa_long_start), and an unbounded walk would be quadratic on a file that is one giant line.
+        const int64_t W = a.line_cap / TILE + 2;
         int64_t j = t - 1;
-        while (j >= 0 && (uint32_t)(a.sums[3 * j] >> 48) == 0u) --j;
+        while (j >= 0 && t - j <= W && (uint32_t)(a.sums[3 * j] >> 48) == 0u) --j;
+        const bool lost = j >= 0 && (uint32_t)(a.sums[3 * j] >> 48) == 0u;
         uint32_t s = 0u;
         uint32_t post_j = 0u;
-        if (j >= 0) { const TileView tj(a.sums, j); s = tj.out0; post_j = tj.post; }
-        for (int64_t k = j + 1; k < t; ++k) s = TileView(a.sums, k).out(s);
+        if (!lost) {
+            if (j >= 0) { const TileView tj(a.sums, j); s = tj.out0; post_j = tj.post; }
+            for (int64_t k = j + 1; k < t; ++k) s = TileView(a.sums, k).out(s);
+        }
         // a line that ends at this tile's first '\n' and is line_cap bytes or longer (buffered.mojo:634-636)
         if (me.nl) {
-            const int64_t len = (int64_t)me.pre + (t - 1 - j) * (int64_t)TILE + (int64_t)post_j;
-            if (len >= a.line_cap) atomicMin(&a.st->long_pos, (unsigned long long)(t * (int64_t)TILE + me.pre - len));
+            if (lost) atomicMin(&a.st->long_tile, (unsigned long long)t);
+            else {
+                const int64_t len = (int64_t)me.pre + (t - 1 - j) * (int64_t)TILE + (int64_t)post_j;
+                if (len >= a.line_cap) atomicMin(&a.st->long_pos, (unsigned long long)(t * (int64_t)TILE + me.pre - len));
+            }
         }
         // does an X follow this tile's last byte before the next '\n'?  (skips tiles that are spaces only)
         bool xf = false;
-        for (int64_t k = t + 1; k < a.n_tiles; ++k) {
+        for (int64_t k = t + 1; k < a.n_tiles && k - t <= W; ++k) {
             const TileView tk(a.sums, k);
             if (tk.all_space()) continue;
             xf = tk.lead_x != 0u;
@@ -483,6 +493,7 @@ struct FinishArgs {
     const u64* sums; const int64_t* base; int64_t n_tiles;
     int64_t* seq_ends; int64_t* id_ends; const int64_t* hdr_pos; int64_t rec_cap;
     FaState* st;
+    int64_t line_cap;
 };
 
 static __global__ __launch_bounds__(BLOCK) void k_fa_finish(FinishArgs a) {
@@ -490,10 +501,18 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_finish(FinishArgs a) {
     __shared__ int64_t s_p;
     FaState* st = a.st;
     const int64_t H = st->n_headers;
+    // the last tile with a newline (all threads look, strided from the end; a file that is one giant line has none)
+    __shared__ int64_t s_last;
+    if (threadIdx.x == 0) s_last = -1;
+    __syncthreads();
+    for (int64_t base = a.n_tiles - 1; base >= 0 && s_last < 0; base -= BLOCK) {
+        const int64_t j = base - threadIdx.x;
+        if (j >= 0 && (uint32_t)(a.sums[3 * j] >> 48) != 0u) atomicMax((long long*)&s_last, (long long)j);
+        __syncthreads();
+    }
     if (threadIdx.x == 0) {
         // offset after the last '\n'
-        int64_t j = a.n_tiles - 1;
-        while (j >= 0 && (uint32_t)(a.sums[3 * j] >> 48) == 0u) --j;
+        const int64_t j = s_last;
         int64_t lls = 0;
         if (j >= 0) {
             const int64_t vj = (a.n - j * (int64_t)TILE) < TILE ? (a.n - j * (int64_t)TILE) : TILE;
@@ -502,8 +521,14 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_finish(FinishArgs a) {
         st->last_line_start = lls;
         // a chunk that is not the last one: a line without its '\n' yet is not looked at (it may still turn out too long),
         // so a header in it neither closes the record before it nor opens one
+        // (counted by position: inside a line that outran the bounded walks of k_fa_resolve the states are not meaningful
+        // and more than one '>' may have been taken for a header)
         int64_t Hc = H;
-        if (!a.is_eof && H > 0 && H - 1 < a.rec_cap && a.hdr_pos[H - 1] >= lls) Hc = H - 1;
+        if (!a.is_eof) {
+            int64_t lo = 0, hi = H < a.rec_cap ? H : a.rec_cap;
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.hdr_pos[mid] < lls) lo = mid + 1; else hi = mid; }
+            Hc = lo;
+        }
         int64_t closed = a.is_eof ? H : (Hc > 0 ? Hc - 1 : 0);
         st->n_closed = closed;
         if (a.is_eof && H > 0 && H - 1 < a.rec_cap) { a.seq_ends[H - 1] = st->seq_total; a.id_ends[H - 1] = st->id_total; }
@@ -512,7 +537,8 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_finish(FinishArgs a) {
         if (!a.is_eof) {
             if (Hc > 0) {
                 p = Hc - 1 < a.rec_cap ? a.hdr_pos[Hc - 1] : 0;
-                while (p > 0 && a.data[p - 1] != 10) --p;
+                // (at most line_cap spaces: a header line with more in front of its '>' is a too-long line, which the host reports)
+                for (int64_t i = 0; i < a.line_cap && p > 0 && a.data[p - 1] != 10; ++i) --p;
             } else {
                 p = lls;
             }
@@ -542,7 +568,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_empty(EmptyArgs a) {
 
 // Cold path (error text): query[0] = newlines in [0, pos); query[1] = start of the line that holds pos;
 // query[2] = headers whose '>' is before pos
-struct QueryArgs { const uint8_t* data; int64_t n; const int64_t* base; const int64_t* hdr_pos; int64_t n_headers; int64_t pos; FaState* st; };
+struct QueryArgs { const uint8_t* data; int64_t n; const int64_t* base; const int64_t* hdr_pos; int64_t n_headers; int64_t pos; FaState* st; int64_t line_cap; };
 static __global__ __launch_bounds__(BLOCK) void k_fa_query(QueryArgs a) {
     __shared__ int64_t s_r[BLOCK / 64];
     const int64_t pos = a.pos < a.n ? a.pos : a.n;
@@ -555,11 +581,29 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_query(QueryArgs a) {
     if (threadIdx.x == 0) {
         a.st->query[0] = lines;
         int64_t p = pos;
-        while (p > 0 && a.data[p - 1] != 10) --p;
+        for (int64_t i = 0; i <= a.line_cap && p > 0 && a.data[p - 1] != 10; ++i) --p;   // (callers ask about lines shorter than line_cap)
         a.st->query[1] = p;
         int64_t lo = 0, hi = a.n_headers;
         while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (a.hdr_pos[mid] < a.pos) lo = mid + 1; else hi = mid; }
         a.st->query[2] = lo;
+    }
+}
+
+// Cold path: the start of the line that ends at the first newline of tile `tile` (k_fa_resolve gave up walking back):
+// the nearest earlier tile with a newline, searched by the whole workgroup; query[3] = offset after that newline (0 if none)
+struct LongStartArgs { const u64* sums; int64_t tile; FaState* st; };
+static __global__ __launch_bounds__(BLOCK) void k_fa_long_start(LongStartArgs a) {
+    __shared__ int64_t s_last;
+    if (threadIdx.x == 0) s_last = -1;
+    __syncthreads();
+    for (int64_t base = a.tile - 1; base >= 0 && s_last < 0; base -= BLOCK) {
+        const int64_t j = base - threadIdx.x;
+        if (j >= 0 && (uint32_t)(a.sums[3 * j] >> 48) != 0u) atomicMax((long long*)&s_last, (long long)j);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int64_t j = s_last;
+        a.st->query[3] = j < 0 ? 0 : j * (int64_t)TILE + TILE - (int64_t)((a.sums[3 * j + 2] >> 16) & 0xFFFF);
     }
 }
 

@@ -283,3 +283,21 @@ def _as_cuda(ptr, nbytes):
         def __init__(self):
             self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
     return torch.as_tensor(_Holder(), device="cuda")
+
+
+def test_giant_lines_do_not_make_the_tile_walks_quadratic(ctxs):
+    """One line of hundreds of megabytes (a chromosome on one line, or a file of spaces): the reference refuses it
+    ("Line exceeds buffer capacity"); here every tile walk is bounded by the line capacity, so it is also refused fast."""
+    import time
+    ctx = ctxs(False)
+    big = 600 * 1000 * 1000
+    for data, status in ((b">chr1\n" + b"A" * big + b"\n>next\nACGT\n", F.LINE_TOO_LONG),
+                         (b">a\nAC\n>b\nGT\n" + b" " * big + b"\n>c\nA\n", F.LINE_TOO_LONG),
+                         (b">a\nAC\n" + b" " * big + b">late\nA\n", F.LINE_TOO_LONG),
+                         (b">a\nAC\n>b\n" + b"T" * big, F.LINE_TOO_LONG)):
+        t0 = time.time()
+        w = check_chunk(ctx, data, True)
+        assert w.status == status
+        check_chunk(ctx, data, False)   # as a chunk that is not the last one
+        assert time.time() - t0 < 60, time.time() - t0
+        del data
