@@ -15,6 +15,6 @@ __all__ = ["ParserConfig", "FastqParser", "FastqBatch", "DeviceFastqBatch", "Fas
 from .pyapi import parser, create_parser, PyParser, PyFastqBatch, PyFastqRecord  # noqa: E402
 
 __all__ += ["parser", "create_parser"]
-from .fasta import FastaParser, FastaRecord, FastaParserConfig, FastaContext, Definition  # noqa: E402
+from .fasta import FastaParser, FastaRecord, FastaParserConfig, FastaContext, FastaIngest, Definition  # noqa: E402
 
-__all__ += ["FastaParser", "FastaRecord", "FastaParserConfig", "FastaContext", "Definition"]
+__all__ += ["FastaParser", "FastaRecord", "FastaParserConfig", "FastaContext", "FastaIngest", "Definition"]

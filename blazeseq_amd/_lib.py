@@ -165,6 +165,10 @@ SYMBOLS = {
                                     C.POINTER(BzqFastaChunk)]),
     "bzq_fasta_format_error": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "bzq_fasta_copy_to_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bzq_fasta_ingest_open": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "bzq_fasta_ingest_next": (C.c_int32, [C.c_void_p, C.POINTER(BzqFastaChunk), C.POINTER(C.c_uint64)]),
+    "bzq_fasta_ingest_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(BzqIngestStats)]),
+    "bzq_fasta_ingest_close": (None, [C.c_void_p]),
     "bzq_fasta_generate_synthetic_device": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                                         C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
 }

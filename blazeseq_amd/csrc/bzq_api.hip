@@ -1207,20 +1207,21 @@ int32_t bzq_generate_synthetic_device(bzq_ctx* c, int64_t num_reads, int64_t fir
 
 // ---- host ingest pipeline (bzq_ingest.hpp) ---------------------------------------------------------------------
 
-int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int32_t n_threads, bzq_ingest** out) {
-    if (!c || !path || !out) return BZQ_ERR_ARG;
+// shared by the FASTQ and the FASTA ingest: file, pinned + device double buffers, compression sniffing, producer thread
+static int32_t ingest_open_common(int device, std::string& err, const char* who, const char* path, uint64_t chunk_bytes,
+                                  int32_t n_threads, bzq_ingest** out) {
     *out = nullptr;
-    HIPCHK(c, hipSetDevice(c->device));
+    if (hipSetDevice(device) != hipSuccess) { err = std::string(who) + ": hipSetDevice failed"; return BZQ_ERR_HIP; }
     const int fd = open(path, O_RDONLY);
-    if (fd < 0) { c->err = std::string("bzq_ingest_open: cannot open ") + path; return BZQ_ERR_IO; }
+    if (fd < 0) { err = std::string(who) + ": cannot open " + path; return BZQ_ERR_IO; }
     struct stat st;
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
         close(fd);
-        c->err = std::string("bzq_ingest_open: not a regular file: ") + path;
+        err = std::string(who) + ": not a regular file: " + path;
         return BZQ_ERR_IO;
     }
     bzq_ingest* g = new bzq_ingest();
-    g->ctx = c; g->device = c->device; g->fd = fd; g->file_size = (uint64_t)st.st_size;
+    g->device = device; g->fd = fd; g->file_size = (uint64_t)st.st_size;
     g->chunk_bytes = chunk_bytes ? ((chunk_bytes + 4095) & ~4095ull) : (256ull << 20);
     g->reserve = std::max<uint64_t>(16ull << 20, g->chunk_bytes / 8);   // room for the carry in front of a chunk
     g->n_threads = n_threads > 0 ? n_threads : 8;
@@ -1234,7 +1235,7 @@ int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int3
              hipEventCreateWithFlags(&g->dev_free[i], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {
-        c->err = "bzq_ingest_open: allocating the pinned / device chunk buffers failed";
+        err = std::string(who) + ": allocating the pinned / device chunk buffers failed";
         bzq::ingest_free(g);
         return BZQ_ERR_NOMEM;
     }
@@ -1249,7 +1250,7 @@ int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int3
             g->gz = fd2 >= 0 ? gzdopen(fd2, "rb") : nullptr;
             if (!g->gz) {
                 if (fd2 >= 0) close(fd2);
-                c->err = std::string("bzq_ingest_open: gzdopen failed for ") + path;
+                err = std::string(who) + ": gzdopen failed for " + path;
                 bzq::ingest_free(g);
                 return BZQ_ERR_IO;
             }
@@ -1259,6 +1260,13 @@ int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int3
     g->producer = std::thread(bzq::ingest_producer, g);
     *out = g;
     return 0;
+}
+
+int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int32_t n_threads, bzq_ingest** out) {
+    if (!c || !path || !out) return BZQ_ERR_ARG;
+    const int32_t rc = ingest_open_common(c->device, c->err, "bzq_ingest_open", path, chunk_bytes, n_threads, out);
+    if (rc == 0) (*out)->ctx = c;
+    return rc;
 }
 
 // Parses the next chunk of the file.  `records_taken` = how many records of the PREVIOUS chunk the caller consumed
@@ -1352,6 +1360,115 @@ int32_t bzq_ingest_get_stats(const bzq_ingest* g, bzq_ingest_stats* out) {
 }
 
 void bzq_ingest_close(bzq_ingest* g) { bzq::ingest_free(g); }
+
+// ---- the same pipeline in front of the FASTA parser (bzq_fasta.hip) -----------------------------------------------------
+
+// internal accessors of the other translation unit
+int32_t bzq_fasta_device_(const bzq_fasta* h);
+void bzq_fasta_set_error_(bzq_fasta* h, const char* msg);
+
+struct bzq_fasta_ingest {
+    bzq_ingest* g = nullptr;
+    bzq_fasta* h = nullptr;
+    hipStream_t aux = nullptr;          // orders the carry copy behind the chunk's H2D
+    uint64_t prev_consumed = 0, line_base = 0, record_base = 0;
+    std::string err;
+};
+
+int32_t bzq_fasta_ingest_open(bzq_fasta* h, const char* path, uint64_t chunk_bytes, int32_t n_threads, bzq_fasta_ingest** out) {
+    if (!h || !path || !out) return BZQ_ERR_ARG;
+    *out = nullptr;
+    bzq_fasta_ingest* f = new bzq_fasta_ingest();
+    f->h = h;
+    const int32_t rc = ingest_open_common(bzq_fasta_device_(h), f->err, "bzq_fasta_ingest_open", path, chunk_bytes, n_threads, &f->g);
+    if (rc != 0 || hipStreamCreateWithFlags(&f->aux, hipStreamNonBlocking) != hipSuccess) {
+        bzq_fasta_set_error_(h, rc ? f->err.c_str() : "bzq_fasta_ingest_open: stream creation failed");
+        if (f->g) bzq::ingest_free(f->g);
+        delete f;
+        return rc ? rc : BZQ_ERR_HIP;
+    }
+    *out = f;
+    return 0;
+}
+
+void bzq_fasta_ingest_close(bzq_fasta_ingest* f) {
+    if (!f) return;
+    if (f->g) { (void)hipSetDevice(f->g->device); bzq::ingest_free(f->g); }
+    if (f->aux) (void)hipStreamDestroy(f->aux);
+    delete f;
+}
+
+int32_t bzq_fasta_ingest_get_stats(const bzq_fasta_ingest* f, bzq_ingest_stats* out) {
+    if (!f || !out) return BZQ_ERR_ARG;
+    *out = f->g->stats;
+    return 0;
+}
+
+// The next chunk of the file through bzq_fasta_parse (same result struct, offsets relative to the chunk; *stream_pos = file
+// offset of its first byte).  Every record a chunk delivers is taken; the bytes of the open record are carried in front
+// of the next chunk on the device.  BZQ_FASTA_NEED_MORE never comes out: the next piece of the file is appended instead.
+int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* f, bzq_fasta_chunk* out, uint64_t* stream_pos) {
+    if (!f || !out) return BZQ_ERR_ARG;
+    bzq_ingest* g = f->g;
+    auto fail = [&](const std::string& m, int32_t code) { bzq_fasta_set_error_(f->h, m.c_str()); return code; };
+    if (hipSetDevice(g->device) != hipSuccess) return fail("bzq_fasta_ingest_next: hipSetDevice failed", BZQ_ERR_HIP);
+    if (g->finished) {
+        memset(out, 0, sizeof(*out));
+        out->status = g->final_status;
+        return 0;
+    }
+    for (;;) {
+        const int64_t k = g->next_k;
+        uint64_t carry = 0, carry_src = 0;
+        if (g->have_prev) {
+            carry = g->prev_n - f->prev_consumed;
+            carry_src = g->prev_off + f->prev_consumed;
+            if (carry > g->reserve)
+                return fail("bzq_fasta_ingest_next: a record of more than " + std::to_string(g->reserve) +
+                            " bytes does not fit the carry reserve (open with a larger chunk)", BZQ_ERR_NOMEM);
+        }
+        const auto tw = std::chrono::steady_clock::now();
+        {
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->cv.wait(lk, [&] { return g->produced > k || g->stop; });
+            if (g->produced <= k) return fail("bzq_fasta_ingest_next: " + (g->io_error.empty() ? std::string("reader stopped") : g->io_error), BZQ_ERR_IO);
+        }
+        bzq::IngestSlot& s = g->slot[k & 1];
+        bool ok = hipStreamWaitEvent(f->aux, s.h2d_done, 0) == hipSuccess;
+        const uint64_t off = g->reserve - carry;
+        if (ok && carry) ok = hipMemcpyAsync(s.dev + off, g->slot[(k - 1) & 1].dev + carry_src, carry, hipMemcpyDeviceToDevice, f->aux) == hipSuccess;
+        if (ok && g->have_prev) {   // the previous chunk's device buffer may now be refilled (behind the carry copy)
+            ok = hipEventRecord(g->dev_free[(k - 1) & 1], f->aux) == hipSuccess;
+            std::unique_lock<std::mutex> lk(g->mu);
+            g->dev_free_valid[(k - 1) & 1] = true;
+            g->released = k;
+            g->cv.notify_all();
+        }
+        if (!ok || hipStreamSynchronize(f->aux) != hipSuccess) return fail("bzq_fasta_ingest_next: a HIP call failed", BZQ_ERR_HIP);
+        const uint64_t n = carry + s.len, spos = s.file_off - carry;
+        const int32_t rc = bzq_fasta_parse(f->h, s.dev + off, n, s.eof ? 1 : 0, spos, f->line_base, f->record_base, out);
+        g->stats.wait_s += bzq::seconds_since(tw);
+        if (rc < 0) return rc;
+        if (stream_pos) *stream_pos = spos;
+        g->stats.chunks += 1;
+        g->stats.total_s = bzq::seconds_since(g->t_open);
+        g->have_prev = true; g->prev_n = n; g->prev_off = off; g->prev_stream_pos = spos;
+        g->next_k = k + 1;
+        g->stats.records += (uint64_t)out->n_records;
+        f->record_base += (uint64_t)out->n_records;
+        if (out->status == BZQ_OK || out->status == BZQ_FASTA_NEED_MORE) {
+            f->prev_consumed = out->bytes_consumed;
+            f->line_base += (uint64_t)out->lines_consumed;
+            if (out->status == BZQ_OK) return 0;
+            continue;   // no record closed inside this chunk: take the next piece of the file behind it
+        }
+        g->finished = true; g->final_status = out->status;
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->stop = true;
+        g->cv.notify_all();
+        return 0;
+    }
+}
 
 // ---- upload of a host FastqBatch (record_batch.mojo:308-411) ---------------------------------------------------
 

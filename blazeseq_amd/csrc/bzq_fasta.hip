@@ -146,6 +146,10 @@ void bzq_fasta_destroy(bzq_fasta* h) {
 
 const char* bzq_fasta_last_error(const bzq_fasta* h) { return h ? h->err.c_str() : g_fa_create_error.c_str(); }
 
+// internal (bzq_api.hip: the ingest pipeline in front of this parser)
+int32_t bzq_fasta_device_(const bzq_fasta* h) { return h ? h->device : 0; }
+void bzq_fasta_set_error_(bzq_fasta* h, const char* msg) { if (h) h->err = msg ? msg : ""; }
+
 int32_t bzq_fasta_copy_to_host(bzq_fasta* h, void* dst, const void* d_src, size_t bytes) {
     if (!h || (bytes && (!dst || !d_src))) return BZQ_ERR_ARG;
     if (!bytes) return 0;

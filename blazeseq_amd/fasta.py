@@ -149,18 +149,54 @@ class FastaContext:
         return t[: int(nbytes.value)]
 
 
+class FastaIngest:
+    """``bzq_fasta_ingest_*``: the native file -> pinned -> device pipeline (reader threads, gzip / BGZF inflated on the
+    way) in front of the FASTA parser.  ``next()`` parses the next chunk of the file; every record it delivers is taken."""
+
+    def __init__(self, ctx: FastaContext, path: str, chunk_bytes: int = 256 << 20, n_threads: int = 0):
+        self._ctx = ctx
+        self._g = C.c_void_p()
+        rc = ctx._lib.bzq_fasta_ingest_open(ctx._h, os.fspath(path).encode(), int(chunk_bytes), int(n_threads), C.byref(self._g))
+        if rc != 0:
+            raise RuntimeError(ctx._lib.bzq_fasta_last_error(ctx._h).decode())
+        self.stream_pos = 0
+
+    def next(self) -> L.BzqFastaChunk:
+        out, pos = L.BzqFastaChunk(), C.c_uint64()
+        self._ctx._check(self._ctx._lib.bzq_fasta_ingest_next(self._g, C.byref(out), C.byref(pos)))
+        self.stream_pos = int(pos.value)
+        return out
+
+    def stats(self) -> L.BzqIngestStats:
+        st = L.BzqIngestStats()
+        self._ctx._lib.bzq_fasta_ingest_get_stats(self._g, C.byref(st))
+        return st
+
+    def close(self):
+        if getattr(self, "_g", None) is not None and self._g:
+            self._ctx._lib.bzq_fasta_ingest_close(self._g)
+            self._g = C.c_void_p()
+
+    __del__ = close
+
+
 class FastaParser:
     """``FastaParser[R, config]`` (fasta/parser.mojo:60-203): ``next_record()``, ``has_more()``, ``records()`` /
     iteration.  ``source``: bytes-like, a path, or a binary file object.  Records come out of the device columns a chunk
     at a time; a record longer than the chunk makes the chunk grow."""
 
     def __init__(self, source, config: FastaParserConfig = FastaParserConfig(), chunk_bytes: int = DEFAULT_CHUNK_BYTES, device: int = 0,
-                 check_ascii: Optional[bool] = None):
+                 check_ascii: Optional[bool] = None, native_ingest: bool = True, reader_threads: int = 0):
         if check_ascii is not None:
             config = FastaParserConfig(check_ascii, config.line_capacity)
         self._ctx = FastaContext(config, device)
         self._own_file = False
-        if isinstance(source, (str, os.PathLike)):
+        self._ingest: Optional[FastaIngest] = None
+        self._fh = None
+        if native_ingest and isinstance(source, (str, os.PathLike)) and os.path.isfile(source):
+            # a file goes through the native pipeline (plain, gzip and BGZF alike)
+            self._ingest = FastaIngest(self._ctx, source, max(int(chunk_bytes), 1 << 16), reader_threads)
+        elif isinstance(source, (str, os.PathLike)):
             self._fh = open(source, "rb")
             self._own_file = True
             if self._fh.read(2) == b"\x1f\x8b":   # gzip / BGZF, like the reference's GZFile reader (io/readers.mojo:283-377)
@@ -185,14 +221,41 @@ class FastaParser:
         self._pending_error: Optional[ParseError] = None
 
     def close(self):
+        if self._ingest is not None:
+            self._ingest.close()
+            self._ingest = None
         if self._own_file:
             self._fh.close()
             self._own_file = False
         self._ctx.close()
 
+    def _take(self, res) -> int:
+        """Records of a chunk result into the queue."""
+        n = int(res.n_records)
+        if n:
+            idb, ide, sqb, sqe, _ = self._ctx.columns(res)
+            i0 = s0 = 0
+            recs = []
+            for r in range(n):
+                i1, s1 = int(ide[r]), int(sqe[r])
+                recs.append(FastaRecord(idb[i0:i1].tobytes(), sqb[s0:s1].tobytes()))
+                i0, s0 = i1, s1
+            self._queue, self._qi = recs, 0
+            self._record_number += n
+        return n
+
     def _fill(self):
         """Parse the next chunk into the record queue (or set the terminal state)."""
-        while not self._done and self._qi >= len(self._queue):
+        while self._ingest is not None and not self._done and self._qi >= len(self._queue):
+            res = self._ingest.next()
+            self._take(res)
+            status = int(res.status)
+            if status == L.EOF:
+                self._done = True
+            elif status != L.OK:
+                self._done = True
+                self._pending_error = ParseError(status, self._ctx.error_text())
+        while self._ingest is None and not self._done and self._qi >= len(self._queue):
             want = self._chunk - len(self._carry)
             fresh = b"" if self._src_eof or want <= 0 else self._fh.read(want)
             if not self._src_eof and want > 0 and len(fresh) < want:
@@ -205,17 +268,7 @@ class FastaParser:
             data = self._carry + fresh
             res = self._ctx.parse(data, len(data), self._src_eof, self._pos, self._lines, self._record_number)
             status = int(res.status)
-            n = int(res.n_records)
-            if n:
-                idb, ide, sqb, sqe, _ = self._ctx.columns(res)
-                i0 = s0 = 0
-                recs = []
-                for r in range(n):
-                    i1, s1 = int(ide[r]), int(sqe[r])
-                    recs.append(FastaRecord(idb[i0:i1].tobytes(), sqb[s0:s1].tobytes()))
-                    i0, s0 = i1, s1
-                self._queue, self._qi = recs, 0
-                self._record_number += n
+            self._take(res)
             if status in (L.OK, L.FASTA_NEED_MORE):
                 used = int(res.bytes_consumed)
                 self._carry = data[used:]

@@ -385,6 +385,16 @@ int32_t bzq_fasta_parse(bzq_fasta* h, const uint8_t* data, uint64_t n, int32_t i
 /* The reference's error text for the last chunk's status (errors.mojo:178-234).  Returns the length. */
 int32_t bzq_fasta_format_error(bzq_fasta* h, char* buf, size_t cap);
 int32_t bzq_fasta_copy_to_host(bzq_fasta* h, void* dst, const void* d_src, size_t bytes);
+/* The host ingest pipeline (bzq_ingest_*: reader threads -> pinned double buffers -> copy stream -> device, gzip / BGZF
+ * inflated on the way) in front of the FASTA parser: replaces FileReader / GZFile + BufferedReader + LineIterator refills
+ * (io/readers.mojo:86-137, 283-443, io/buffered.mojo:239-290, 600-638).  Every record of a chunk is delivered; the bytes of
+ * the open record are carried on the device.  out->status is never BZQ_FASTA_NEED_MORE. */
+typedef struct bzq_fasta_ingest bzq_fasta_ingest;
+int32_t bzq_fasta_ingest_open(bzq_fasta* h, const char* path, uint64_t chunk_bytes, int32_t n_threads, bzq_fasta_ingest** out);
+int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* g, bzq_fasta_chunk* out, uint64_t* stream_pos);
+int32_t bzq_fasta_ingest_get_stats(const bzq_fasta_ingest* g, bzq_ingest_stats* out);
+void bzq_fasta_ingest_close(bzq_fasta_ingest* g);
+
 /* generate_synthetic_fasta_buffer (blazeseq/utils.mojo:1033-1139), records [first, first+count) of a num_reads-record
  * file, written into device memory.  d_out == NULL only sizes. */
 int32_t bzq_fasta_generate_synthetic_device(bzq_fasta* h, int64_t num_reads, int64_t first, int64_t count, int32_t min_len,

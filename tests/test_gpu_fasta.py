@@ -301,3 +301,60 @@ def test_giant_lines_do_not_make_the_tile_walks_quadratic(ctxs):
         check_chunk(ctx, data, False)   # as a chunk that is not the last one
         assert time.time() - t0 < 60, time.time() - t0
         del data
+
+
+def _bgzf(data: bytes, block: int = 65280) -> bytes:
+    """BGZF writer (SAM spec 4.1): independent gzip members with a 'BC' extra subfield + the empty EOF block."""
+    import struct
+    import zlib
+    out = []
+    for i in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if i is None else data[i:i + block]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        out.append(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(body) + 8 - 1)
+                   + body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("kind", ["plain", "gzip", "bgzf"])
+def test_files_through_the_native_ingest(kind, tmp_path):
+    """A path goes through bzq_fasta_ingest_* (reader threads -> pinned double buffers -> device, carry on the device):
+    same records, same terminal event and text as the oracle on the file's bytes, whatever the chunk size."""
+    import gzip
+    import blazeseq_amd as B
+    rng = np.random.default_rng(31 + len(kind))
+    for trial in range(4):
+        data = rand_fasta(rng, int(rng.integers(2000, 6000)), int(rng.choice([60, 70, 200])), 6, dirty=[0.0, 0.0, 0.01, 0.0][trial],
+                          crlf=bool(trial & 1), tail_newline=trial != 3, lead_blank=trial)
+        if trial == 2:
+            data += b">empty\n>after\nAC\n"
+        comp = data if kind == "plain" else (gzip.compress(data[: len(data) // 3], 1) + gzip.compress(data[len(data) // 3:], 6) if kind == "gzip"
+                                             else _bgzf(data))
+        path = tmp_path / ("t%d.fa%s" % (trial, "" if kind == "plain" else ".gz"))
+        path.write_bytes(comp)
+        want = F.flat_parse(data, True)
+        for chunk in (1 << 16, 200_000, 1 << 26):
+            p = B.FastaParser(str(path), B.FastaParserConfig(True), chunk_bytes=chunk, reader_threads=3)
+            assert p._ingest is not None
+            got, err = [], None
+            try:
+                while True:
+                    r = p.next_record()
+                    got.append((r.id, r.sequence))
+            except B.ParseError as e:
+                err = e
+            assert got == want.records(), (kind, trial, chunk, len(got), want.n_records)
+            assert err.code == want.status
+            if want.status != F.EOF:
+                assert err.message.decode("latin-1") == want.message
+            st = p._ingest.stats()
+            assert st.records == want.n_records and st.file_bytes == len(comp)
+            p.close()
+    # a record larger than a chunk: the open record is carried on the device until its end arrives
+    big = b">big\n" + (b"ACGT" * 15 + b"\n") * 6667 + b">small\nAC\n"
+    path = tmp_path / "big.fa"
+    path.write_bytes(big)
+    assert [(r.id, len(r)) for r in B.FastaParser(str(path), chunk_bytes=1 << 16).records()] == [(b"big", 60 * 6667), (b"small", 2)]
+    with pytest.raises(RuntimeError, match="cannot open"):
+        B.FastaIngest(B.FastaContext(), str(tmp_path / "nope.fa"))
