@@ -80,3 +80,36 @@ def test_c_driver_reproduces_the_oracle(case, tmp_path):
         assert b"status=5" in r.stdout and b"Record number: 1" in r.stdout
         return
     assert r.stdout == _expect(data, batch, bool(check))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["clean_multi_chunk", "error_late", "ascii", "no_trailing_newline"])
+def test_fasta_driver_reproduces_the_oracle(case, tmp_path):
+    """tests/c_driver/bzq_facat.c: bzq_fasta_create -> bzq_fasta_ingest_open / _next -> bzq_fasta_copy_to_host ->
+    bzq_fasta_format_error from plain C."""
+    _build()
+    exe = os.path.join(DRV, "bzq_facat")
+    from oracle import fasta as F
+    from fasta_fuzz import rand_fasta
+    rng = np.random.default_rng(99)
+    check, chunk = 0, 1 << 16
+    if case == "clean_multi_chunk":
+        data = rand_fasta(rng, 4000, 70, 5, dirty=0.0, lead_blank=1)
+    elif case == "error_late":
+        data = rand_fasta(rng, 3000, 60, 4, dirty=0.0) + b">empty\n>next\nAC\n"
+    elif case == "ascii":
+        data = rand_fasta(rng, 1500, 60, 4, dirty=0.0) + b">bad\nAC\x80GT\n>after\nAC\n"
+        check = 1
+    else:
+        data = rand_fasta(rng, 2000, 60, 4, dirty=0.0, tail_newline=False, crlf=True)
+    path = tmp_path / "in.fasta"
+    path.write_bytes(data)
+    r = subprocess.run([exe, str(path), str(chunk), str(check)], capture_output=True, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()
+    w = F.flat_parse(data, bool(check))
+    lines = r.stdout.split(b"\n")
+    recs = [tuple(l.split(b"\t")) for l in lines if l and not l.startswith(b"#") and b"\t" in l]
+    assert recs == [(i, s) for i, s in w.records()]
+    assert (b"# records=%d " % w.n_records) in r.stdout and (b"status=%d" % w.status) in r.stdout
+    if w.status != F.EOF:
+        assert r.stdout.split(b"# error: ", 1)[1].rstrip(b"\n").decode("latin-1") == w.message
