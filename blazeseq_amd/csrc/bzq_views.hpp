@@ -270,8 +270,9 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
         const int64_t pp = locate(G3 - 4, t3, ep); const int64_t TP = loc_tile;
         const int64_t hs = pp + 1;
         a.o_hdr[r] = hs; a.o_seq[r] = p0 + 1; a.o_sep[r] = p1 + 1; a.o_qual[r] = p2 + 1; a.rec_end[r] = p3;
-        int64_t lo, hi;
-        id_of(hs, ep, p0, e0, lo, hi);
+        int64_t lo = hs + 1 < p0 ? hs + 1 : p0, hi = lo;
+        // (a record beyond the buffer limit is refused below; its id is not worth a walk over megabytes of spaces)
+        if (p3 - (r ? pp : a.first_header - 1) <= a.len_limit) id_of(hs, ep, p0, e0, lo, hi);
         a.id_start[r] = lo; a.id_len[r] = (int32_t)(hi - lo);
         // utils.mojo:448-462 in the reference's order: '@', '+', lengths
         u64 k = ~0ull;
