@@ -358,3 +358,32 @@ def test_files_through_the_native_ingest(kind, tmp_path):
     assert [(r.id, len(r)) for r in B.FastaParser(str(path), chunk_bytes=1 << 16).records()] == [(b"big", 60 * 6667), (b"small", 2)]
     with pytest.raises(RuntimeError, match="cannot open"):
         B.FastaIngest(B.FastaContext(), str(tmp_path / "nope.fa"))
+
+
+def test_committed_golden_vectors(ctxs):
+    """tests/golden/fasta_expected.json through the C ABI: digest of all five outputs, terminal status and text."""
+    import hashlib
+    import json
+    import importlib.util
+    here = os.path.dirname(__file__)
+    spec = importlib.util.spec_from_file_location("make_golden_fasta", os.path.join(here, "golden", "make_golden_fasta.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = json.load(open(os.path.join(here, "golden", "fasta_expected.json")))
+    for key, want in gold.items():
+        kind, name = key.split(":", 1)
+        data = (open(os.path.join(GOLD, name), "rb").read() if kind == "file" else mg.CONSTRUCTED[name] if kind == "stream"
+                else F.generate_synthetic(2000, 5, 400, 60).tobytes())
+        for cfg, check in (("plain", False), ("check_ascii", True)):
+            if cfg not in want:
+                continue
+            ctx = ctxs(check)
+            res = ctx.parse(data, len(data), True)
+            idb, ide, sqb, sqe, hp = ctx.columns(res)
+            h = hashlib.sha256()
+            for a in (idb, ide, sqb, sqe, hp):
+                h.update(a.tobytes())
+            w = want[cfg]
+            assert (int(res.n_records), int(res.status), h.hexdigest()) == (w["n_records"], w["status"], w["digest"]), (key, cfg)
+            if w["status"] != F.EOF:
+                assert ctx.error_text().decode("latin-1") == w["message"]

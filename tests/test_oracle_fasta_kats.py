@@ -238,3 +238,31 @@ def test_flat_chunk_mode_concatenates_to_the_whole_parse(seed):
         pos += f.consumed
         lines += f.lines_consumed
     assert got == whole.records()
+
+
+def test_oracle_against_committed_golden_vectors():
+    """tests/golden/fasta_expected.json (made by tests/golden/make_golden_fasta.py): the flat oracle, the streaming
+    restatement and the generator have not drifted from the committed vectors."""
+    import hashlib
+    import json
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_fasta", os.path.join(os.path.dirname(__file__), "golden", "make_golden_fasta.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fasta_expected.json")))
+    assert len(gold) >= 25
+    for key, want in gold.items():
+        kind, name = key.split(":", 1)
+        if kind == "file":
+            data = open(os.path.join(GOLD, name), "rb").read()
+        elif kind == "stream":
+            data = mg.CONSTRUCTED[name]
+        else:
+            data = F.generate_synthetic(2000, 5, 400, 60).tobytes()
+            assert hashlib.sha256(data).hexdigest() == want["sha256"] and len(data) == want["bytes"]
+        for cfg, check in (("plain", False), ("check_ascii", True)):
+            if cfg not in want:
+                continue
+            assert mg.entry(data, check) == want[cfg], (key, cfg)
+            recs, code, msg = both(data, check_ascii=check)
+            assert len(recs) == want[cfg]["n_records"] and code == want[cfg]["status"]
