@@ -387,3 +387,22 @@ def test_committed_golden_vectors(ctxs):
             assert (int(res.n_records), int(res.status), h.hexdigest()) == (w["n_records"], w["status"], w["digest"]), (key, cfg)
             if w["status"] != F.EOF:
                 assert ctx.error_text().decode("latin-1") == w["message"]
+
+
+def test_sequence_column_feeds_the_device_consumers(ctxs):
+    """The FASTA columns are ordinary device arrays: the byte-histogram consumer of the FASTQ side (bzq_column_histogram,
+    SURVEY 8f rank 2: GC / base counts) runs on the sequence column where it lies, no host round trip."""
+    import ctypes as C
+    import blazeseq_amd as B
+    from blazeseq_amd import _lib as L
+    ctx = ctxs(False)
+    data = F.generate_synthetic(20_000, 50, 900, 60).tobytes()
+    res = ctx.parse(data, len(data), True)
+    want = F.flat_parse(data)
+    fq = B.Context(B.ParserConfig(), "generic", 4096, 0)
+    hist = (C.c_uint64 * 256)()
+    assert L.lib().bzq_column_histogram(fq.h, C.c_void_p(res.d_seq_bytes), int(res.seq_bytes), hist) == 0
+    assert np.array_equal(np.frombuffer(hist, dtype=np.uint64).astype(np.int64), np.bincount(want.seq_bytes, minlength=256))
+    gc = (hist[ord("G")] + hist[ord("C")]) / int(res.seq_bytes)
+    assert 0.45 < gc < 0.55   # gc_bias = 0.5 in the generator
+    fq.close()
