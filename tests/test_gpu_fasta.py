@@ -406,3 +406,36 @@ def test_sequence_column_feeds_the_device_consumers(ctxs):
     gc = (hist[ord("G")] + hist[ord("C")]) / int(res.seq_bytes)
     assert 0.45 < gc < 0.55   # gc_bias = 0.5 in the generator
     fq.close()
+
+
+def test_reference_record_tests_through_the_gpu_parser():
+    """tests/fasta/test_fasta_parser.mojo:835-1028 with the records coming from the GPU parser: byte_len / len / write /
+    read -> write -> read fidelity (the host-only half is tests/test_fasta_record_host.py)."""
+    import blazeseq_amd as B
+
+    def records(data):
+        p = B.FastaParser(data)
+        out = list(p.records())
+        p.close()
+        return out
+    assert records(b">abc\nACGT\n")[0].byte_len() == 10
+    assert len(records(b">id1\nACGT\nACGT\n")[0]) == 8
+    assert records(b">id1\nACGT\n")[0].write() == b">id1\nACGT\n"
+    assert records(b">id\nAC\nGT\n")[0].byte_len() == 9
+    r = records(b">myid\nGATTACA\n")[0]
+    assert (r.id, r.sequence, len(r), r.byte_len()) == (b"myid", b"GATTACA", 7, 14)
+    for data in (b">id1\nACGT\n", b">id1\nACGT\n>id2\nTTAA\n>id3\nGGCC\n", b">id1 description here\nACGT\n", b">seq1\nACG\nTTA\nGG\n",
+                 b">long\n" + b"ACGT" * 100 + b"\n"):
+        original = records(data)
+        again = records(b"".join(x.write() for x in original))
+        assert [(x.id, x.sequence) for x in original] == [(x.id, x.sequence) for x in again] and len(original) >= 1
+    assert records(b">id1 description here\nACGT\n")[0].id == b"id1 description here"
+    # has_more / exhaustion (:289, :307)
+    p = B.FastaParser(b">id1\nACGT\n")
+    assert p.has_more()
+    p.next_record()
+    assert not p.has_more()
+    with pytest.raises(B.ParseError) as e:
+        p.next_record()
+    assert e.value.code == F.EOF
+    p.close()
