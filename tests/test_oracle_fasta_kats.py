@@ -266,3 +266,34 @@ def test_oracle_against_committed_golden_vectors():
             assert mg.entry(data, check) == want[cfg], (key, cfg)
             recs, code, msg = both(data, check_ascii=check)
             assert len(recs) == want[cfg]["n_records"] and code == want[cfg]["status"]
+
+
+# Independent cross-check (not the oracle): record / base counts of the reference tree's own C parser
+# (benchmark/fastq-parser/kseq_runner/main.c, built into oracle/_ref/ from its two files; kseq reads FASTA as well).
+# Obtained once with that binary; re-run live when it is present (this container; the GPU box gets the prebuilt file).
+KSEQ_FASTA = {"f001": (1, 79), "f002": (3, 1517), "f003.fa": (2, 112), "fa01": (2, 760)}
+# (the .pro / .nu files pad their lines with a trailing space: kseq appends whole lines, spaces included, while the
+# reference strips every line -- 108 vs 107 bases for aster.pro -- so they are no cross-check; neither are the two files
+# that start with a comment line, which the reference refuses)
+
+
+def test_counts_agree_with_the_reference_trees_kseq_parser():
+    import subprocess
+    exe = os.path.join(os.path.dirname(__file__), "..", "oracle", "_ref", "kseq_runner")
+    for name, (n, bases) in KSEQ_FASTA.items():
+        path = os.path.join(GOLD, name)
+        f = F.flat_parse(open(path, "rb").read())
+        assert (f.n_records, int(f.seq_bytes.size)) == (n, bases), name
+        if os.access(exe, os.X_OK):
+            out = subprocess.run([exe, path], capture_output=True, timeout=30).stdout.split()
+            assert (int(out[0]), int(out[1])) == (n, bases), name
+    # and on the synthetic benchmark shape
+    data = F.generate_synthetic(3000, 200, 3800, 60).tobytes()
+    f = F.flat_parse(data)
+    if os.access(exe, os.X_OK):
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".fasta") as tf:
+            tf.write(data)
+            tf.flush()
+            out = subprocess.run([exe, tf.name], capture_output=True, timeout=60).stdout.split()
+        assert (int(out[0]), int(out[1])) == (f.n_records, int(f.seq_bytes.size))
