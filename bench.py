@@ -26,8 +26,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# rocprofv3 PMC, emit kernel, 10 M x 150 bp (profiles/r1_final3_summary.txt): FETCH_SIZE 1613745 KB (x2 on gfx950) + WRITE_SIZE 3424127 KB per launch
-MEASURED_TRAFFIC_B_PER_RECORD = (1613744.9 * 2 + 3424126.5) * 1024 / 1e7
+# rocprofv3 PMC, emit kernel, 10 M x 150 bp (profiles/r1_final4_summary.txt): FETCH_SIZE 1613745 KB (x2 on gfx950) + WRITE_SIZE 3424127 KB per launch
+MEASURED_TRAFFIC_B_PER_RECORD = (1613742.3 * 2 + 3465084.1) * 1024 / 1e7
 
 
 def cpu_baseline(data, reads: int, read_len: int, check: bool):
@@ -360,7 +360,7 @@ def main():
                             if (args.read_len == 150 and not args.long_reads and not args.views and not args.validate and not args.single_pass and not args.service
                                 and not args.hier and not args.kernels_v1) else None),
                 "traffic_unit": "GB per launch",
-                "traffic_source": "profiles/r1_final3_summary.txt: k_fused FETCH_SIZE*2 + WRITE_SIZE",
+                "traffic_source": "profiles/r1_final4_summary.txt: k_fused FETCH_SIZE*2 + WRITE_SIZE",
                 "algorithmic_gb_per_launch": round(A_total / 1e9, 3),
                 "algorithmic_bytes_per_record": round(A, 1),
                 "avg_launch_ms": round(ms_emit / steps / max(1, int(res.n_passes)), 4),
