@@ -1543,13 +1543,29 @@ int32_t bzq_batch_quality_sums(bzq_ctx* c, const bzq_device_batch* b, int64_t* d
     if (n <= 0) return 0;
     // short reads: a workgroup per 256 records (coalesced span + LDS accumulators); long reads: a wave per record
     if (b->seq_len / n < 1024)
-        hipLaunchKernelGGL(k_quality_sums_block, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream,
+        hipLaunchKernelGGL(k_quality_sums_block<false>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream,
                            b->qual_buffer, b->ends, n, b->seq_len, (int)b->quality_offset, d_sums);
     else
-        hipLaunchKernelGGL(k_quality_sums, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, c->stream,
+        hipLaunchKernelGGL(k_quality_sums<false>, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, c->stream,
                            b->qual_buffer, b->ends, n, b->seq_len, (int)b->quality_offset, d_sums);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->err = std::string("k_quality_sums: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
+    return 0;
+}
+
+int32_t bzq_column_gc_counts(bzq_ctx* c, const uint8_t* d_col, const int64_t* d_ends, int64_t n, int64_t col_len, int64_t* d_counts) {
+    if (!c || n < 0 || (n && (!d_col || !d_ends || !d_counts))) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (n == 0) return 0;
+    if (col_len / n < 1024)
+        hipLaunchKernelGGL(k_quality_sums_block<true>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, d_col, d_ends, n,
+                           col_len, 0, d_counts);
+    else
+        hipLaunchKernelGGL(k_quality_sums<true>, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, c->stream, d_col, d_ends,
+                           n, col_len, 0, d_counts);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { c->err = std::string("k_quality_sums<GC>: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -116,11 +116,22 @@ __device__ __forceinline__ uint4 keep_first(uint4 v, int k) {
     return make_uint4((uint32_t)l, (uint32_t)(l >> 32), (uint32_t)h, (uint32_t)(h >> 32));
 }
 
-// Per-record sum of (quality byte - offset).  SHORT reads: one workgroup per 256 consecutive records.  Their bytes are
+// 1 in every byte that is G, C, g or c; 0 elsewhere (exact zero-byte test on x ^ 'g' and x ^ 'c' after folding the case bit)
+__device__ __forceinline__ uint32_t gc_ones32(uint32_t x) {
+    const uint32_t y = x | 0x20202020u, a = y ^ 0x67676767u, b = y ^ 0x63636363u;
+    const uint32_t fa = ~(((a & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | a | 0x7F7F7F7Fu), fb = ~(((b & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | b | 0x7F7F7F7Fu);
+    return (fa | fb) >> 7;
+}
+__device__ __forceinline__ uint4 gc_ones(uint4 v) { return make_uint4(gc_ones32(v.x), gc_ones32(v.y), gc_ones32(v.z), gc_ones32(v.w)); }
+
+// Per-record sum of (quality byte - offset) -- or, with GC, per-record count of G/C bases (GC / base
+// counts; any byte column with inclusive running sums as record boundaries: a FastqBatch's or a FASTA chunk's sequence
+// column).  SHORT reads: one workgroup per 256 consecutive records.  Their bytes are
 // one contiguous span of the column, read fully coalesced (16 bytes per lane per step); each 16-byte piece finds its
 // record by a binary search over the 257 record boundaries kept in LDS, is split where it straddles boundaries, and is
 // added to that record's LDS accumulator (v_sad_u8 sums four bytes per instruction).  A thread-per-record version with
 // the same loads ran at 1.07 TB/s: neighbouring lanes are a record (150 B) apart, so every line was fetched ~8 times.
+template <bool GC>
 static __global__ __launch_bounds__(BLOCK) void k_quality_sums_block(const uint8_t* __restrict__ qual, const int64_t* __restrict__ ends,
                                                                int64_t num_records, int64_t col_len, int offset,
                                                                int64_t* __restrict__ sums) {
@@ -154,7 +165,7 @@ static __global__ __launch_bounds__(BLOCK) void k_quality_sums_block(const uint8
             else if (drop < 8) { slo = (vlo >> (8 * drop)) | (vhi << (64 - 8 * drop)); shi = vhi >> (8 * drop); }
             else { slo = vhi >> (8 * (drop - 8)); shi = 0; }
             const uint4 part = keep_first(make_uint4((uint32_t)slo, (uint32_t)(slo >> 32), (uint32_t)shi, (uint32_t)(shi >> 32)), keep);
-            atomicAdd(&s_sum[k], (u64)sum_bytes16(part, 0u));
+            atomicAdd(&s_sum[k], (u64)sum_bytes16(GC ? gc_ones(part) : part, 0u));
             lo = e;
         }
     }
@@ -163,6 +174,7 @@ static __global__ __launch_bounds__(BLOCK) void k_quality_sums_block(const uint8
 }
 
 // LONG reads: one wave per record, 16 bytes per lane per step (1 KiB per wave instruction).
+template <bool GC>
 static __global__ __launch_bounds__(BLOCK) void k_quality_sums(const uint8_t* __restrict__ qual, const int64_t* __restrict__ ends,
                                                          int64_t num_records, int64_t col_len, int offset, int64_t* __restrict__ sums) {
     const int lane = threadIdx.x & 63;
@@ -174,7 +186,8 @@ static __global__ __launch_bounds__(BLOCK) void k_quality_sums(const uint8_t* __
     int steps = 0;
     for (int64_t p = q0 + 16 * lane; p < q1; p += 1024) {
         const uint4 v = load16_tail(qual, p, col_len);
-        acc = sum_bytes16(p + 16 <= q1 ? v : keep_first(v, (int)(q1 - p)), acc);
+        const uint4 u = p + 16 <= q1 ? v : keep_first(v, (int)(q1 - p));
+        acc = sum_bytes16(GC ? gc_ones(u) : u, acc);
         if (++steps == (1 << 19)) { acc64 += acc; acc = 0; steps = 0; }
     }
     acc64 += acc;

@@ -321,6 +321,12 @@ int32_t bzq_batch_quality_sums(bzq_ctx* ctx, const bzq_device_batch* b, int64_t*
 /* 256-bin byte histogram of a device column (base composition of sequence_buffer, quality distribution of
  * qual_buffer; the v0.1 quality_distribution example, CHANGELOG.md:73).  hist: host uint64[256]. */
 int32_t bzq_column_histogram(bzq_ctx* ctx, const uint8_t* d_col, uint64_t n, uint64_t* hist);
+/* Per-record count of G / C bases (either case) of a device byte column whose records are delimited by inclusive running
+ * sums d_ends[n_records] (a bzq_device_batch's sequence_buffer + ends, a bzq_fasta_chunk's d_seq_bytes + d_seq_ends):
+ * the GC-content consumer of SURVEY 8f rank 2.  d_counts: device int64[n_records]; col_len = d_ends[n_records-1].
+ * Synchronous. */
+int32_t bzq_column_gc_counts(bzq_ctx* ctx, const uint8_t* d_col, const int64_t* d_ends, int64_t n_records, int64_t col_len,
+                             int64_t* d_counts);
 
 /* ---- synthetic input (measurement only) ----------------------------------------------------- */
 

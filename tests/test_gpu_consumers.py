@@ -84,3 +84,42 @@ def test_consumers_on_an_empty_batch_and_odd_sizes():
     q = torch.zeros(1, dtype=torch.int64, device="cuda")
     d.quality_sums(q.data_ptr()); torch.cuda.synchronize()
     assert q.item() == 0
+
+
+def test_gc_counts_per_record_on_fastq_and_fasta_columns():
+    """bzq_column_gc_counts: G/C bases per record of any device byte column delimited by inclusive running sums -- a
+    FastqBatch's sequence column (short reads: the block kernel; long reads: the wave kernel) and a FASTA chunk's."""
+    import ctypes as C
+    import torch
+    import blazeseq_amd as B
+    from blazeseq_amd import _lib as L
+    from oracle import fasta as F
+
+    def gc_of(seq_bytes, ends):
+        isgc = np.isin(seq_bytes, np.frombuffer(b"GCgc", dtype=np.uint8)).astype(np.int64)
+        cs = np.concatenate([[0], np.cumsum(isgc)])
+        e = np.concatenate([[0], ends])
+        return cs[e[1:]] - cs[e[:-1]]
+
+    ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
+    for lo, hi, n in ((1, 300, 20_000), (2000, 9000, 600)):
+        data = O.generate_synthetic(n, lo, hi, 0, 40, "sanger")
+        f = O.flat_parse(data, O.make_config())
+        t = torch.from_numpy(data.copy()).cuda()
+        ctx.submit_device(t.data_ptr(), t.numel(), 0, True)
+        res = ctx.result()
+        out = torch.empty(n, dtype=torch.int64, device="cuda")
+        assert L.lib().bzq_column_gc_counts(ctx.h, C.c_void_p(res.d_seq), C.c_void_p(res.d_ends), n, int(res.seq_bytes), C.c_void_p(out.data_ptr())) == 0
+        assert np.array_equal(out.cpu().numpy(), gc_of(f.seq_bytes, f.ends))
+    # a FASTA chunk: mixed case, N and gaps in the sequences, an empty-ish tail record
+    fa = B.FastaContext()
+    rng = np.random.default_rng(3)
+    alphabet = np.frombuffer(b"ACGTacgtN-", dtype=np.uint8)
+    data = b"".join(b">r%d\n" % i + alphabet[rng.integers(0, 10, size=int(rng.integers(1, 500)))].tobytes() + b"\n" for i in range(5000))
+    r = fa.parse(data, len(data), True)
+    w = F.flat_parse(data)
+    out = torch.empty(int(r.n_records), dtype=torch.int64, device="cuda")
+    assert L.lib().bzq_column_gc_counts(ctx.h, C.c_void_p(r.d_seq_bytes), C.c_void_p(r.d_seq_ends), int(r.n_records), int(r.seq_bytes), C.c_void_p(out.data_ptr())) == 0
+    assert np.array_equal(out.cpu().numpy(), gc_of(w.seq_bytes, w.seq_ends))
+    fa.close()
+    ctx.close()
