@@ -8,10 +8,13 @@ the timed region starts.  One "step" = one pass of the whole hot path over that 
 delimiter scan -> record table -> FastqBatch columns (+ per-batch ends), i.e. everything
 ``for batch in parser.batches(4096): batch.to_device()`` does in the reference.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): a single stream of N x 10 M reads is
-cut into N byte ranges (not record aligned); each step also does the shard scan, the summary
-all_gather, the halo send/recv of the straddling record over RCCL and the count reductions
-(blazeseq_amd/sharded.py).  Weak scaling.
+N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[4]'s shard shape --
+78.125 M reads = 25 GB per GPU of ONE synthetic stream with 9-digit headers (320 B/record; at N = 8 that is
+the 625 M-read, 200 GB file), cut into N byte ranges whose interior cuts sit 144 bytes into a record
+(not record aligned).  Each step is the whole protocol of bzq_shard_stitch (C ABI, RCCL bound by the
+library itself): shard scan, summary all-gather, the straddling record's remainder sent to its owner,
+parse, outcome all-gather.  Weak scaling.  torch.distributed only launches the ranks, hands out the
+ncclUniqueId and takes the max of the times.
 
 Prints ONE JSON line (rank 0).
 """
@@ -26,8 +29,36 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-# rocprofv3 PMC, emit kernel, 10 M x 150 bp (profiles/r1_final4_summary.txt): FETCH_SIZE 1613745 KB (x2 on gfx950) + WRITE_SIZE 3424127 KB per launch
-MEASURED_TRAFFIC_B_PER_RECORD = (1613742.3 * 2 + 3465084.1) * 1024 / 1e7
+# HBM traffic of the dominant kernel per launch: NOT measured in this run (PMC counters need rocprofv3 around the process)
+# but READ from the committed rocprofv3 summary of this very command (scripts/gpu_profile.sh -> profiles/<tag>_summary.txt),
+# so the number printed is by construction the one in the cited file (tests/test_bench_contract.py pins the parse).
+# FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md (HBM section).
+TRAFFIC_PROFILE = "profiles/r1_final4_summary.txt"
+TRAFFIC_KERNEL = "k_fused<false, false, false, false>"
+TRAFFIC_RECORDS = 10_000_000   # the profiled launch: 10 M x 150 bp
+
+
+def profile_traffic(path=TRAFFIC_PROFILE, kernel=TRAFFIC_KERNEL):
+    """(FETCH_SIZE, WRITE_SIZE) per dispatch of `kernel`, in the counter's unit (KiB), from a scripts/summarize_prof.py text."""
+    vals, section, cur = {}, None, None
+    try:
+        lines = open(os.path.join(ROOT, path)).read().splitlines()
+    except OSError:
+        return None
+    for ln in lines:
+        if ln.startswith("== "):
+            section = ln.split()[1].rstrip(":")
+        elif section in ("pmc_fetch", "pmc_write") and ln.startswith("  ") and not ln.startswith("      "):
+            cur = ln.strip().rsplit("  (dispatches", 1)[0]
+        elif section in ("pmc_fetch", "pmc_write") and cur == kernel and ln.strip().startswith(("FETCH_SIZE", "WRITE_SIZE")):
+            k, v = ln.split()
+            vals[k] = float(v)
+    return (vals["FETCH_SIZE"], vals["WRITE_SIZE"]) if len(vals) == 2 else None
+
+
+def measured_traffic_bytes_per_record():
+    t = profile_traffic()
+    return None if t is None else (2 * t[0] + t[1]) * 1024 / TRAFFIC_RECORDS
 
 
 def cpu_baseline(data, reads: int, read_len: int, check: bool):
@@ -100,6 +131,9 @@ def fasta_main(args, world, rank, local_rank, dev, distributed):
     def step():
         return ctx.parse(int(shard.data_ptr()), n, True)
     for _ in range(args.warmup):
+        res = step()
+    t_w = time.perf_counter()
+    while args.warmup and time.perf_counter() - t_w < args.min_seconds and not distributed:   # clocks settle
         res = step()
     if distributed:
         dist.barrier()
@@ -176,7 +210,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=10_000_000, help="reads per GPU")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: 10 M at --gpus 1 = BASELINE config 2; 78.125 M at --gpus N > 1 = config 5's shard)")
+    ap.add_argument("--min-seconds", type=float, default=0.5, help="warm up for at least this long (and at least --warmup steps): clocks settle")
+    ap.add_argument("--exchange", choices=["native", "torch"], default="native",
+                    help="sharded mode: bzq_shard_stitch over the library's own RCCL binding (default) or the torch.distributed cross-check")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("--validate", action="store_true", help="config 3: check_ascii + check_quality, sanger")
     ap.add_argument("--views", action="store_true",
@@ -219,15 +256,19 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    config5 = world > 1 and not args.long_reads and not args.fasta and args.reads == 0
+    if args.reads == 0:
+        args.reads = 78_125_000 if config5 else 10_000_000
     if args.fasta:
         return fasta_main(args, world, rank, local_rank, dev, sharded_mode)
 
     cfg = B.ParserConfig(check_ascii=args.validate, check_quality=args.validate,
                          quality_schema="sanger" if args.validate else None, views_only=args.views)
-    ctx = B.Context(cfg, "generic", 4096, local_rank, pass_bytes=args.pass_bytes)
+    ctx = B.Context(cfg, "generic", 4096, local_rank, pass_bytes=args.pass_bytes, min_record_bytes=256 if not args.long_reads and args.read_len >= 100 else 32)
     ctx.set_option("timing_detail", 1)
-    ctx.set_option("single_pass", 3 if args.hier else 2 if args.service else (1 if (args.single_pass and not args.kernels_v1) else 0))
-    ctx.set_option("kernels_v2", 0 if args.kernels_v1 else 1)
+    if args.hier or args.service or args.single_pass or args.kernels_v1:   # EXPERIMENTS build only (BLAZESEQ_HIP_LIB=.../libblazeseq_hip_exp.so)
+        ctx.set_option("single_pass", 3 if args.hier else 2 if args.service else (1 if (args.single_pass and not args.kernels_v1) else 0))
+        ctx.set_option("kernels_v2", 0 if args.kernels_v1 else 1)
     if args.ablate:
         ctx.set_option("ablate", args.ablate)
     ctx.set_option("overlap", args.overlap)
@@ -245,46 +286,76 @@ def main():
                                              d_out, cap, first=first, count=count, max_len=gen["max_len"])
 
     slack = 1 << 20  # room for the halo (one record) behind the shard
+    SHIFT = 144      # interior cuts of the byte-range shards sit 144 bytes into a record: never record aligned
     if args.long_reads:
         # variable record sizes: every rank takes an equal number of records (record-aligned shards)
         total_bytes = generate(count=total_reads)
         lo = generate(count=rank * args.reads) if rank else 0
         n = generate(first=rank * args.reads, count=args.reads)
         rec_bytes = n // args.reads   # mean, for the workload description only
-        shard = torch.empty(n + slack, dtype=torch.uint8, device=dev)
-        generate(shard.data_ptr(), shard.numel(), first=rank * args.reads, count=args.reads)
-        i0 = i1 = 0
+        buf = torch.empty(n + slack, dtype=torch.uint8, device=dev)
+        generate(buf.data_ptr(), buf.numel(), first=rank * args.reads, count=args.reads)
+        shard = buf
     else:
         rec_bytes = generate(count=1)
         total_bytes = rec_bytes * total_reads
-        lo = total_bytes * rank // world
-        hi = total_bytes * (rank + 1) // world
+        shift = SHIFT if (world > 1 and rec_bytes > 2 * SHIFT) else 0
+        lo = total_bytes * rank // world + (shift if rank else 0)
+        hi = total_bytes * (rank + 1) // world + (shift if rank + 1 < world else 0)
         n = hi - lo
-        shard = torch.empty(n + slack, dtype=torch.uint8, device=dev)
-        i0, i1 = lo // rec_bytes, (hi + rec_bytes - 1) // rec_bytes
-    if args.long_reads:
-        pass
-    elif lo == i0 * rec_bytes:
-        ctx.generate_synthetic_device(total_reads, args.read_len, 33, 73, "generic", shard.data_ptr(),
-                                      shard.numel(), first=i0, count=min(i1, total_reads) - i0)
-    else:
-        tmp = torch.empty((i1 - i0) * rec_bytes + 64, dtype=torch.uint8, device=dev)
-        ctx.generate_synthetic_device(total_reads, args.read_len, 33, 73, "generic", tmp.data_ptr(), tmp.numel(),
-                                      first=i0, count=i1 - i0)
+        # records that overlap [lo, hi + one record): generated in place, the shard is a 16-byte aligned view of them
+        i0, i1 = lo // rec_bytes, min(total_reads, (hi + rec_bytes - 1) // rec_bytes + 1)
         off = lo - i0 * rec_bytes
-        shard[:n].copy_(tmp[off:off + n])
-        del tmp
+        pad = (-off) % 16
+        buf = torch.empty(pad + (i1 - i0) * rec_bytes + slack, dtype=torch.uint8, device=dev)
+        ctx.generate_synthetic_device(total_reads, args.read_len, 33, 73, "generic", buf.data_ptr() + pad, buf.numel() - pad,
+                                      first=i0, count=i1 - i0)
+        shard = buf[pad + off:]
+        assert shard.data_ptr() % 16 == 0 and shard.numel() >= n + slack
     torch.cuda.synchronize()
+
+    exchange = None
+    if sharded_mode:
+        exchange = args.exchange
+        if exchange == "native":
+            try:   # the library binds librccl itself; torch only hands the id around
+                box = [B.Context.comm_unique_id() if rank == 0 else None]
+                if world > 1:
+                    dist.broadcast_object_list(box, src=0)
+                ctx.comm_init(rank, world, box[0])
+            except Exception as e:   # noqa: BLE001 -- said out loud in the JSON line, never silent
+                exchange = f"torch (native communicator failed: {str(e)[:200]})"
+                print(f"[bench] rank {rank}: {exchange}", file=sys.stderr)
+        if world > 1:   # all ranks must take the same path
+            flags = [None] * world
+            dist.all_gather_object(flags, exchange)
+            exchange = "native" if all(f == "native" for f in flags) else next(f for f in flags if f != "native")
 
     def step():
         if not sharded_mode:
             ctx.submit_device(shard.data_ptr(), n, 0, True)
             return ctx.result(), None, None
+        if exchange == "native":
+            sr = ctx.shard_stitch(shard.data_ptr(), n, shard.numel())
+            return sr.chunk, [sr.global_records, sr.global_bases, sr.global_bytes], (sr.first_error_record if sr.first_error_record >= 0 else sharded.NO_ERROR)
         res, plan, totals, first_err = sharded.parse_sharded(ctx, shard, n, lo)
         return res, totals, first_err
 
+    # warm-up: at least --warmup steps AND at least --min-seconds of them (a 10 ms warm-up leaves the clocks unsettled);
+    # in sharded mode every rank must run the same number of steps (the protocol is collective)
+    warm_done = 0
     for _ in range(args.warmup):
-        step()
+        step(); warm_done += 1
+    torch.cuda.synchronize()
+    if warm_done:
+        t_w = time.perf_counter(); step(); torch.cuda.synchronize(); one = max(1e-5, time.perf_counter() - t_w); warm_done += 1
+        extra = int(min(5000, max(0.0, args.min_seconds) / one))
+        if sharded_mode and world > 1:
+            tx = torch.tensor([extra], dtype=torch.int64, device=dev)
+            dist.all_reduce(tx, op=dist.ReduceOp.MAX)
+            extra = int(tx.item())
+        for _ in range(extra):
+            step(); warm_done += 1
     torch.cuda.synchronize()
     if sharded_mode:
         dist.barrier()
@@ -334,19 +405,21 @@ def main():
             "value": round(global_bytes / sec_per_step / 1e9, 3),
             "unit": "GB/s",
             "mrecords_per_s": round(global_records / sec_per_step / 1e6, 3),
-            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "warmup_steps_run": warm_done,
             "ms_per_step": round(sec_per_step * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": (f"synthetic long reads 200..19800 bases (BASELINE config 4), {args.reads} reads/GPU "
                                     f"(mean {rec_bytes} B/record), batches(4096), validation " if args.long_reads else
+                                    (f"BASELINE config 5 shard shape: {total_reads} reads of one synthetic stream "
+                                     f"({total_bytes / 1e9:.1f} GB), byte-range shards cut {SHIFT} B into a record; " if config5 else "") +
                                     f"synthetic {args.read_len} bp Illumina FASTQ, {args.reads} reads/GPU "
                                     f"({rec_bytes} B/record), {'views() mode (offsets + id spans, no columns)' if args.views else 'batches(4096)'}, validation ")
                                    + f"{'ascii+quality (sanger)' if args.validate else 'off'}, input resident in HBM",
                        "records_per_gpu": args.reads, "record_bytes": rec_bytes, "batch_size": 4096,
                        "parallelism": (f"{'record-aligned' if args.long_reads else 'byte-range'} shards x{world}"
                                        if world > 1 else "single GPU"),
-                       "pass_bytes": args.pass_bytes},
+                       "pass_bytes": args.pass_bytes, "exchange": exchange},
             "fraction_of_hbm_peak_input_rate": round(global_bytes / world / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {
                 "bound": "hbm", "kernel": "k_views" if args.views else "k_tile_emit" if args.kernels_v1 else ("k_single<look-back>" if args.hier else "k_single<service>" if args.service else ("k_fused<LB=true>" if args.single_pass else "k_fused<LB=false>")),
@@ -356,11 +429,11 @@ def main():
                 # HBM bytes per launch from the PMC counters of the same command (rocprofv3, separate --pmc passes;
                 # FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md), committed under profiles/.
                 # Only quoted for the profiled configuration (150 bp, validation off, two-pass default).
-                "traffic": (round(MEASURED_TRAFFIC_B_PER_RECORD * per_rank_records / 1e9, 3)
-                            if (args.read_len == 150 and not args.long_reads and not args.views and not args.validate and not args.single_pass and not args.service
-                                and not args.hier and not args.kernels_v1) else None),
+                "traffic": (round(measured_traffic_bytes_per_record() * per_rank_records / 1e9, 3)
+                            if (measured_traffic_bytes_per_record() and args.read_len == 150 and not args.long_reads and not args.views and not args.validate
+                                and not args.single_pass and not args.service and not args.hier and not args.kernels_v1) else None),
                 "traffic_unit": "GB per launch",
-                "traffic_source": "profiles/r1_final4_summary.txt: k_fused FETCH_SIZE*2 + WRITE_SIZE",
+                "traffic_source": f"{TRAFFIC_PROFILE}: {TRAFFIC_KERNEL} FETCH_SIZE*2 + WRITE_SIZE (KiB), scaled per record; read from the file at run time, not measured in this run",
                 "algorithmic_gb_per_launch": round(A_total / 1e9, 3),
                 "algorithmic_bytes_per_record": round(A, 1),
                 "avg_launch_ms": round(ms_emit / steps / max(1, int(res.n_passes)), 4),

@@ -100,6 +100,27 @@ class BzqIngestStats(C.Structure):
     ]
 
 
+class BzqShardPlan(C.Structure):
+    _fields_ = [
+        ("lines_before", C.c_uint64), ("head_bytes", C.c_uint64), ("halo_bytes", C.c_uint64), ("halo_offset", C.c_uint64),
+        ("head_dst", C.c_int32), ("halo_first_src", C.c_int32), ("halo_n_src", C.c_int32),
+        ("prev_last_byte", C.c_uint8), ("is_last", C.c_uint8), ("_pad", C.c_uint8 * 2),
+    ]
+
+
+class BzqShardResult(C.Structure):
+    _fields_ = [
+        ("chunk", BzqChunk), ("plan", BzqShardPlan),
+        ("stream_pos", C.c_uint64), ("records_before", C.c_uint64),
+        ("global_records", C.c_uint64), ("global_bases", C.c_uint64), ("global_bytes", C.c_uint64),
+        ("first_error_record", C.c_int64), ("stream_status", C.c_int32), ("error_rank", C.c_int32),
+    ]
+
+
+class BzqNcclId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
 class BzqFastaConfig(C.Structure):
     _fields_ = [("check_ascii", C.c_int32), ("_pad", C.c_int32), ("line_capacity", C.c_int64)]
 
@@ -127,10 +148,14 @@ SYMBOLS = {
     "bzq_destroy": (None, [C.c_void_p]),
     "bzq_last_error": (C.c_char_p, [C.c_void_p]),
     "bzq_set_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "bzq_set_consumer_stream": (C.c_int32, [C.c_void_p, C.c_void_p]),
     "bzq_get_config": (C.c_int32, [C.c_void_p, C.POINTER(BzqConfig)]),
     "bzq_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
     "bzq_pinned_alloc": (C.c_int32, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "bzq_pinned_free": (C.c_int32, [C.c_void_p]),
+    "bzq_device_alloc": (C.c_int32, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "bzq_device_free": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "bzq_copy_to_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bzq_submit_chunk_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32]),
     "bzq_submit_chunk_device": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32]),
     "bzq_chunk_result": (C.c_int32, [C.c_void_p, C.POINTER(BzqChunk)]),
@@ -143,6 +168,13 @@ SYMBOLS = {
     "bzq_submit_shard": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint8,
                                       C.c_uint64, C.c_int32]),
     "bzq_shard_head_bytes": (C.c_int32, [C.POINTER(BzqShardSummary), C.c_uint64, C.c_uint8, C.POINTER(C.c_uint64)]),
+    "bzq_comm_get_unique_id": (C.c_int32, [C.POINTER(BzqNcclId)]),
+    "bzq_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "bzq_comm_init_shm": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_uint64]),
+    "bzq_comm_destroy": (C.c_int32, [C.c_void_p]),
+    "bzq_plan_shards": (C.c_int32, [C.POINTER(BzqShardSummary), C.c_int32, C.POINTER(BzqShardPlan)]),
+    "bzq_shard_stitch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(BzqShardResult)]),
+    "bzq_global_counts": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "bzq_generate_synthetic_device": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                                   C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_uint64,
                                                   C.POINTER(C.c_uint64)]),

@@ -7,7 +7,12 @@
 // three synchronisations per 4096 records.  There is NO CPU fallback: without a gfx950 device
 // bzq_create fails.
 #include "../../include/blazeseq_hip.h"
-#include "bzq_single.hpp"
+#ifndef BZQ_EXPERIMENTS
+#define BZQ_EXPERIMENTS 0
+#endif
+#if BZQ_EXPERIMENTS
+#include "bzq_single.hpp"   // single-launch variants + first-generation kernels: cross-checks and negative results only
+#endif
 #include "bzq_views.hpp"
 
 #include <algorithm>
@@ -61,6 +66,18 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// The device memory one parsed chunk's results live in (see bzq_ctx::out).
+struct OutSet {
+    DevBuf seq, qual, id;
+    DevBuf ends, id_ends, rec_end, b_ends, b_id_ends, off[4], id_start, id_len;
+    int64_t rec_cap = 0;
+    // rebased ends / id_ends of bzq_batch_view ranges that are not batch aligned: bump-allocated blocks that are never
+    // moved or freed while the chunk is live, so every view handed out keeps its own storage
+    std::vector<DevBuf> view_blocks;
+    size_t view_used = 0;          // bytes used in view_blocks.back()
+    size_t view_next = 4u << 20;   // size of the next block
+};
+
 } // namespace
 
 struct bzq_ctx {
@@ -72,11 +89,19 @@ struct bzq_ctx {
     int overlap = 0;
     bool own_stream = true;
     std::string err;
-    // arenas
-    DevBuf in, seq, qual, id;
-    DevBuf ends, id_ends, rec_end, b_ends, b_id_ends, off[4], view_e, view_i;
-    int64_t rec_cap = 0;
-    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, gen_prefix, id_start, id_len, entries, tile_list, tile_vf;
+    // arenas.  Everything a bzq_chunk / bzq_device_batch / bzq_device_views points at lives in an OutSet; there are two
+    // of them and submit k writes set k & 1, so a chunk's results stay valid until the SECOND following bzq_submit_* (a
+    // consumer kernel on another stream may still read chunk k while chunk k+1 is parsed).  Set 1 is allocated by the
+    // first submit that needs it.
+    DevBuf in;
+    OutSet out[2];
+    int cur_set = 0;
+    OutSet& o() { return out[cur_set]; }
+    const OutSet& o() const { return out[cur_set]; }
+    int64_t n_submits = 0;
+    int double_buffer = 1;   // option "double_buffer": 0 = one set (results valid until the next submit), half the memory
+    hipStream_t consumer_stream = nullptr;   // bzq_set_consumer_stream: where the bzq_batch_* / bzq_column_* kernels run (default: the ctx stream)
+    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, gen_prefix, entries, tile_list, tile_vf;
     int64_t tile_cap = 0;
     ChunkState* d_state = nullptr;
     ChunkState* h_state = nullptr; // pinned
@@ -106,9 +131,19 @@ struct bzq_ctx {
     const uint8_t* agg_ptr = nullptr;  // shard whose tile aggregates are already in the arenas
     uint64_t agg_n = 0;
     int head_lines = 0;
+    // last shard's trailing bytes (see bzq_chunk_result): 0 decide locally, 1 defer to the protocol, 2 decided by it
+    int tail_mode = 0;
+    bool tail_pending = false, tail_accept = false;
+    int tail_code = 0, tail_phase_dec = 0;
+    int64_t tail_cap_dec = 0;
+    struct bzq_comm* comm = nullptr;   // multi-GPU exchange (bzq_comm.hpp), owned
+    uint64_t shard_totals[3] = {0, 0, 0};   // records, bases, bytes over all ranks after the last bzq_shard_stitch
+    bool have_shard_totals = false;
+    float ms_scan_shard = 0.f;         // kernels of the bzq_shard_scan that preceded this submit (pass A + scan)
     // stream parsed in several chunks: absolute record ends of everything delivered so far (8 B per record), so that the
     // reference's window can be replayed from the stream's first byte when the stream ends in bytes that are not a record
-    DevBuf tail_log;
+    // Kept in fixed-size blocks that are never moved (no reallocation, no copy, no stall on the hot path).
+    std::vector<DevBuf> tail_log;
     int64_t records_before = -1;   // option "records_before": records delivered by earlier chunks; < 0 = no log
 };
 
@@ -137,39 +172,54 @@ int ensure(bzq_ctx* c, DevBuf& b, size_t bytes) {
     return 0;
 }
 
-// grows a buffer keeping its first `keep` bytes
-int ensure_keep(bzq_ctx* c, DevBuf& b, size_t bytes, size_t keep) {
-    if (bytes <= b.cap) return 0;
-    void* np = nullptr;
-    const size_t want = bytes + bytes / 2 + 4096;
-    hipError_t e = hipMalloc(&np, want);
-    if (e != hipSuccess) { c->err = "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e); return BZQ_ERR_NOMEM; }
-    if (b.p && keep) HIPCHK(c, hipMemcpyAsync(np, b.p, std::min(keep, b.cap), hipMemcpyDeviceToDevice, c->stream));
-    if (b.p) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipFree(b.p)); }
-    b.p = np; b.cap = want;
-    return 0;
-}
-
 static __global__ void k_log_ends(const int64_t* __restrict__ rec_end, int64_t n, int64_t stream_pos, int64_t* __restrict__ log) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n) log[r] = stream_pos + rec_end[r];
 }
 
+// The stream's record-end log (option records_before): fixed blocks of LOG_BLOCK records, allocated as the stream grows
+// and never moved, so logging a chunk costs one small kernel per block it touches and nothing else.
+constexpr int64_t LOG_BLOCK = 1ll << 20;   // records per block (8 MiB)
+int log_record_ends(bzq_ctx* c, int64_t first, int64_t n, const int64_t* d_rec_end, int64_t stream_pos) {
+    int64_t done = 0;
+    while (done < n) {
+        const int64_t idx = first + done, blk = idx / LOG_BLOCK, in = idx - blk * LOG_BLOCK;
+        while ((int64_t)c->tail_log.size() <= blk) {
+            DevBuf b;
+            int rc;
+            if ((rc = ensure(c, b, (size_t)LOG_BLOCK * 8))) return rc;
+            c->tail_log.push_back(b);
+        }
+        const int64_t m = std::min(n - done, LOG_BLOCK - in);
+        hipLaunchKernelGGL(k_log_ends, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, d_rec_end + done, m, stream_pos,
+                           (int64_t*)c->tail_log[(size_t)blk].p + in);
+        done += m;
+    }
+    return 0;
+}
+int fetch_record_ends(bzq_ctx* c, int64_t n, int64_t* dst) {   // cold path: the first n logged record ends to the host
+    for (int64_t done = 0; done < n; done += LOG_BLOCK) {
+        const int64_t m = std::min(n - done, LOG_BLOCK);
+        HIPCHK(c, hipMemcpy(dst + done, c->tail_log[(size_t)(done / LOG_BLOCK)].p, (size_t)m * 8, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
 int64_t tiles_for(uint64_t n) { return (int64_t)((n + TILE - 1) / TILE); }
 
-int ensure_chunk_arenas(bzq_ctx* c, uint64_t n, bool need_input) {
+// per-tile summaries and prefixes (shared by both output sets: they only live between the kernels of one chunk)
+int ensure_tile_arenas(bzq_ctx* c, uint64_t n) {
     int rc;
-    const size_t col = (size_t)n + 64;
-    if (need_input && (rc = ensure(c, c->in, (size_t)n + 64))) return rc;
-    if ((rc = ensure(c, c->seq, col)) || (rc = ensure(c, c->qual, col)) || (rc = ensure(c, c->id, col))) return rc;
     const int64_t nt = tiles_for(n) + 1;
     if (nt > c->tile_cap) {
         if ((rc = ensure(c, c->tile_c, nt * 4)) || (rc = ensure(c, c->tile_a, nt * 8)) ||
             (rc = ensure(c, c->tile_idc, nt * 8)) || (rc = ensure(c, c->tileP, nt * 8)) ||
             (rc = ensure(c, c->tileS, nt * 8)) || (rc = ensure(c, c->tileQ, nt * 8)) ||
-            (rc = ensure(c, c->tileI, nt * 8)) || (rc = ensure(c, c->grp, (nt / SG_TILES + 2) * 80)) ||
-            (rc = ensure(c, c->desc, (nt * 6 + (nt / 64 + 2) * 4 + 16) * 8)))
+            (rc = ensure(c, c->tileI, nt * 8)) || (rc = ensure(c, c->grp, (nt / SG_TILES + 2) * 80)))
             return rc;
+#if BZQ_EXPERIMENTS
+        if ((rc = ensure(c, c->desc, (nt * 6 + (nt / 64 + 2) * 4 + 16) * 8))) return rc;   // single-launch variants only
+#endif
         c->tile_cap = nt;
     }
     if (c->cfg.views_only) {   // line entries: a 4 KiB slot per tile + a pool of 64 KiB slots for tiles of tiny records
@@ -181,18 +231,60 @@ int ensure_chunk_arenas(bzq_ctx* c, uint64_t n, bool need_input) {
     return 0;
 }
 
+// the three columns of the current output set
+int ensure_col_arenas(bzq_ctx* c, uint64_t n) {
+    if (c->cfg.views_only) return 0;   // views mode packs nothing
+    int rc;
+    const size_t col = (size_t)n + 64;
+    if ((rc = ensure(c, c->o().seq, col)) || (rc = ensure(c, c->o().qual, col)) || (rc = ensure(c, c->o().id, col))) return rc;
+    return 0;
+}
+
+// A new chunk is about to be parsed: move to the other output set (its previous contents -- the chunk before the
+// previous one -- are no longer valid) and recycle its view storage.
+int begin_submit(bzq_ctx* c) {
+    if (c->pending) HIPCHK(c, hipStreamSynchronize(c->stream)); // h_state is reused
+    if (c->double_buffer) c->cur_set = (int)(c->n_submits & 1);
+    c->n_submits += 1;
+    OutSet& o = c->o();
+    if (o.view_blocks.size() > 1) {   // settle on one block as large as everything the last chunk needed
+        size_t total = 0;
+        for (DevBuf& b : o.view_blocks) { total += b.cap; if (b.p) HIPCHK(c, hipFree(b.p)); }
+        o.view_blocks.clear();
+        o.view_next = std::max(o.view_next, total);
+    }
+    o.view_used = 0;
+    return 0;
+}
+
+// storage for the rebased ends of one unaligned batch view: stays where it is until the set is recycled
+int view_alloc(bzq_ctx* c, size_t bytes, void** out) {
+    OutSet& o = c->o();
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (o.view_blocks.empty() || o.view_used + bytes > o.view_blocks.back().cap) {
+        DevBuf b;
+        int rc;
+        if ((rc = ensure(c, b, std::max(bytes, o.view_next)))) return rc;
+        o.view_blocks.push_back(b);
+        o.view_used = 0;
+    }
+    *out = (uint8_t*)o.view_blocks.back().p + o.view_used;
+    o.view_used += bytes;
+    return 0;
+}
+
 int ensure_record_arenas(bzq_ctx* c, int64_t recs) {
-    if (recs <= c->rec_cap) return 0;
+    if (recs <= c->o().rec_cap) return 0;
     int rc;
     const size_t b = (size_t)recs * 8;
-    if ((rc = ensure(c, c->ends, b)) || (rc = ensure(c, c->id_ends, b)) || (rc = ensure(c, c->rec_end, b)) ||
-        (rc = ensure(c, c->b_ends, b)) || (rc = ensure(c, c->b_id_ends, b)))
+    if ((rc = ensure(c, c->o().ends, b)) || (rc = ensure(c, c->o().id_ends, b)) || (rc = ensure(c, c->o().rec_end, b)) ||
+        (rc = ensure(c, c->o().b_ends, b)) || (rc = ensure(c, c->o().b_id_ends, b)))
         return rc;
     if (c->cfg.emit_offsets || c->cfg.views_only)
         for (int i = 0; i < 4; ++i)
-            if ((rc = ensure(c, c->off[i], b))) return rc;
-    if (c->cfg.views_only && ((rc = ensure(c, c->id_start, b)) || (rc = ensure(c, c->id_len, b / 2)))) return rc;
-    c->rec_cap = recs;
+            if ((rc = ensure(c, c->o().off[i], b))) return rc;
+    if (c->cfg.views_only && ((rc = ensure(c, c->o().id_start, b)) || (rc = ensure(c, c->o().id_len, b / 2)))) return rc;
+    c->o().rec_cap = recs;
     return 0;
 }
 
@@ -203,6 +295,7 @@ int64_t pass_tiles(const bzq_ctx* c) {
     return t < 1 ? 1 : t;
 }
 
+#if BZQ_EXPERIMENTS
 template <bool CA, bool CQ>
 void launch_emit_off(bool offs, dim3 grid, hipStream_t s, const EmitArgs& a) {
     if (offs) hipLaunchKernelGGL((k_tile_emit<CA, CQ, true>), grid, dim3(BLOCK), 0, s, a);
@@ -221,15 +314,17 @@ EmitArgs make_emit_args(bzq_ctx* c) {
     e.g = c->cur; e.n = (int64_t)c->cur_n; e.prev_byte = c->cur_prev_byte;
     e.tileP = (const int64_t*)c->tileP.p; e.tileS = (const int64_t*)c->tileS.p;
     e.tileQ = (const int64_t*)c->tileQ.p; e.tileI = (const int64_t*)c->tileI.p;
-    e.col_seq = (uint8_t*)c->seq.p; e.col_qual = (uint8_t*)c->qual.p; e.col_id = (uint8_t*)c->id.p;
-    e.ends = (int64_t*)c->ends.p; e.id_ends = (int64_t*)c->id_ends.p; e.rec_end = (int64_t*)c->rec_end.p;
-    e.rec_cap = c->rec_cap;
-    e.o_hdr = (int64_t*)c->off[0].p; e.o_seq = (int64_t*)c->off[1].p;
-    e.o_sep = (int64_t*)c->off[2].p; e.o_qual = (int64_t*)c->off[3].p;
+    e.col_seq = (uint8_t*)c->o().seq.p; e.col_qual = (uint8_t*)c->o().qual.p; e.col_id = (uint8_t*)c->o().id.p;
+    e.ends = (int64_t*)c->o().ends.p; e.id_ends = (int64_t*)c->o().id_ends.p; e.rec_end = (int64_t*)c->o().rec_end.p;
+    e.rec_cap = c->o().rec_cap;
+    e.o_hdr = (int64_t*)c->o().off[0].p; e.o_seq = (int64_t*)c->o().off[1].p;
+    e.o_sep = (int64_t*)c->o().off[2].p; e.o_qual = (int64_t*)c->o().off[3].p;
     e.st = c->d_state; e.q_lower = c->cfg.q_lower; e.q_upper = c->cfg.q_upper;
     e.force_dense = c->force_dense;
     return e;
 }
+
+#endif
 
 template <bool CA, bool CQ, bool OFFS, bool LB>
 void launch_fused_one(const bzq_ctx* c, dim3 grid, const FusedArgs& a) {
@@ -253,15 +348,16 @@ FusedArgs make_fused_args(bzq_ctx* c) {
     f.g = c->cur; f.n = (int64_t)c->cur_n; f.prev_byte = c->cur_prev_byte; f.n_tiles = tiles_for(c->cur_n);
     f.tileP = (const int64_t*)c->tileP.p; f.tileS = (const int64_t*)c->tileS.p;
     f.tileQ = (const int64_t*)c->tileQ.p; f.tileI = (const int64_t*)c->tileI.p;
-    f.col_seq = (uint8_t*)c->seq.p; f.col_qual = (uint8_t*)c->qual.p; f.col_id = (uint8_t*)c->id.p;
-    f.ends = (int64_t*)c->ends.p; f.id_ends = (int64_t*)c->id_ends.p; f.rec_end = (int64_t*)c->rec_end.p;
-    f.rec_cap = c->rec_cap;
-    f.o_hdr = (int64_t*)c->off[0].p; f.o_seq = (int64_t*)c->off[1].p;
-    f.o_sep = (int64_t*)c->off[2].p; f.o_qual = (int64_t*)c->off[3].p;
+    f.col_seq = (uint8_t*)c->o().seq.p; f.col_qual = (uint8_t*)c->o().qual.p; f.col_id = (uint8_t*)c->o().id.p;
+    f.ends = (int64_t*)c->o().ends.p; f.id_ends = (int64_t*)c->o().id_ends.p; f.rec_end = (int64_t*)c->o().rec_end.p;
+    f.rec_cap = c->o().rec_cap;
+    f.o_hdr = (int64_t*)c->o().off[0].p; f.o_seq = (int64_t*)c->o().off[1].p;
+    f.o_sep = (int64_t*)c->o().off[2].p; f.o_qual = (int64_t*)c->o().off[3].p;
     f.st = c->d_state; f.q_lower = c->cfg.q_lower; f.q_upper = c->cfg.q_upper; f.force_dense = c->force_dense; f.ablate = c->ablate;
     return f;
 }
 
+#if BZQ_EXPERIMENTS
 // One launch for the whole chunk (single-pass kernel, bzq_fused.hpp).
 int enqueue_fused(bzq_ctx* c) {
     const int64_t nt = tiles_for(c->cur_n);
@@ -317,6 +413,17 @@ int enqueue_single(bzq_ctx* c) {
     return 0;
 }
 
+#endif
+
+int enqueue_single_launch(bzq_ctx* c) {
+#if BZQ_EXPERIMENTS
+    return c->single_pass >= 2 ? enqueue_single(c) : enqueue_fused(c);
+#else
+    c->err = "single-launch variants exist only in an EXPERIMENTS build";
+    return BZQ_ERR_ARG;
+#endif
+}
+
 void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, int pass) {
     ScanArgs s{tb, te, (const uint32_t*)c->tile_c.p, (const u64*)c->tile_a.p, (const u64*)c->tile_idc.p,
                (int64_t*)c->tileP.p, (int64_t*)c->tileS.p, (int64_t*)c->tileQ.p, (int64_t*)c->tileI.p,
@@ -342,8 +449,8 @@ void launch_views(bzq_ctx* c, dim3 grid, int64_t tb, int64_t te) {
         const bool growth = c->cfg.buffer_growth_enabled != 0;
         JoinArgs j{c->cur, c->cur_prev_byte, (int64_t)c->cur_n, tb, te, tiles_for(c->cur_n), (const uint32_t*)c->tile_c.p,
                    (const u64*)c->tile_idc.p, (const int64_t*)c->tileP.p, (const uint32_t*)c->entries.p,
-                   (const uint32_t*)c->tile_list.p, (int64_t*)c->off[0].p, (int64_t*)c->off[1].p, (int64_t*)c->off[2].p,
-                   (int64_t*)c->off[3].p, (int64_t*)c->rec_end.p, (int64_t*)c->id_start.p, (int32_t*)c->id_len.p, c->rec_cap,
+                   (const uint32_t*)c->tile_list.p, (int64_t*)c->o().off[0].p, (int64_t*)c->o().off[1].p, (int64_t*)c->o().off[2].p,
+                   (int64_t*)c->o().off[3].p, (int64_t*)c->o().rec_end.p, (int64_t*)c->o().id_start.p, (int32_t*)c->o().id_len.p, c->o().rec_cap,
                    c->cur_first_header, growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->d_state,
                    (const uint8_t*)c->tile_vf.p, c->cfg.check_ascii, c->cfg.check_quality};
         const dim3 jg((unsigned)((te - tb + JOIN_TILES - 1) / JOIN_TILES));
@@ -352,8 +459,8 @@ void launch_views(bzq_ctx* c, dim3 grid, int64_t tb, int64_t te) {
         return;
     }
     ViewArgs v{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (const int64_t*)c->tileP.p,
-               (int64_t*)c->off[0].p, (int64_t*)c->off[1].p, (int64_t*)c->off[2].p, (int64_t*)c->off[3].p,
-               (int64_t*)c->rec_end.p, (int64_t*)c->id_start.p, (int32_t*)c->id_len.p, c->rec_cap, c->d_state,
+               (int64_t*)c->o().off[0].p, (int64_t*)c->o().off[1].p, (int64_t*)c->o().off[2].p, (int64_t*)c->o().off[3].p,
+               (int64_t*)c->o().rec_end.p, (int64_t*)c->o().id_start.p, (int32_t*)c->o().id_len.p, c->o().rec_cap, c->d_state,
                (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper, c->force_dense};
     const bool ca = c->cfg.check_ascii != 0, cq = c->cfg.check_quality != 0;
     if (ca && cq) hipLaunchKernelGGL((k_views<true, true>), grid, dim3(BLOCK), 0, c->stream, v);
@@ -395,8 +502,10 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
                     if (views_validating(c)) hipLaunchKernelGGL(k_tile_lines<true>, grid, dim3(BLOCK), 0, c->stream, la);
                     else hipLaunchKernelGGL(k_tile_lines<false>, grid, dim3(BLOCK), 0, c->stream, la);
                 } else if (c->cfg.views_only) hipLaunchKernelGGL(k_tile_count, grid, dim3(BLOCK), 0, c->stream, a);
-                else if (c->v2) hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
-                else hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
+#if BZQ_EXPERIMENTS
+                else if (!c->v2) hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
+#endif
+                else hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
             }
             if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
             launch_scan(c, tb, te, (int)passes);
@@ -404,7 +513,13 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
         }
         if (c->cfg.views_only) {
             launch_views(c, grid, tb, te);
-        } else if (c->v2) {
+#if BZQ_EXPERIMENTS
+        } else if (!c->v2) {
+            EmitArgs e = make_emit_args(c);
+            e.tile_begin = tb;
+            launch_emit(c, grid, e);
+#endif
+        } else {
             FusedArgs f = make_fused_args(c);
             f.tile_begin = tb; f.tile_end = te;
             if (c->overlap && !emit_only) {
@@ -420,10 +535,6 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
             } else {
                 launch_fused<false>(c, grid, f);
             }
-        } else {
-            EmitArgs e = make_emit_args(c);
-            e.tile_begin = tb;
-            launch_emit(c, grid, e);
         }
         if (!emit_only && c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
     }
@@ -439,16 +550,16 @@ void enqueue_rebase(bzq_ctx* c) {
     const bool growth = c->cfg.buffer_growth_enabled != 0;
     if (views_meta(c)) return;   // the join kernel did the per-record checks and the chunk totals
     if (c->cfg.views_only) {
-        ViewCheckArgs va{(const int64_t*)c->off[0].p, (const int64_t*)c->off[1].p, (const int64_t*)c->off[2].p,
-                         (const int64_t*)c->off[3].p, (const int64_t*)c->rec_end.p, c->cur_first_header,
-                         growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->rec_cap, c->d_state, c->cur,
+        ViewCheckArgs va{(const int64_t*)c->o().off[0].p, (const int64_t*)c->o().off[1].p, (const int64_t*)c->o().off[2].p,
+                         (const int64_t*)c->o().off[3].p, (const int64_t*)c->o().rec_end.p, c->cur_first_header,
+                         growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->o().rec_cap, c->d_state, c->cur,
                          c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper};
         hipLaunchKernelGGL(k_views_check, dim3((unsigned)(c->num_cu * 8)), dim3(BLOCK), 0, c->stream, va);
         return;
     }
-    RebaseArgs ra{(const int64_t*)c->ends.p, (const int64_t*)c->id_ends.p, (const int64_t*)c->rec_end.p,
-                  (int64_t*)c->b_ends.p, (int64_t*)c->b_id_ends.p, (int64_t)c->cfg.batch_size, c->cur_first_header,
-                  growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->rec_cap, c->d_state, c->cur,
+    RebaseArgs ra{(const int64_t*)c->o().ends.p, (const int64_t*)c->o().id_ends.p, (const int64_t*)c->o().rec_end.p,
+                  (int64_t*)c->o().b_ends.p, (int64_t*)c->o().b_id_ends.p, (int64_t)c->cfg.batch_size, c->cur_first_header,
+                  growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->o().rec_cap, c->d_state, c->cur,
                   c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper};
     hipLaunchKernelGGL(k_rebase, dim3((unsigned)(c->num_cu * 8)), dim3(BLOCK), 0, c->stream, ra);
 }
@@ -457,14 +568,14 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
                   int64_t P0, int64_t S0, int64_t Q0, int64_t I0, uint32_t prev_byte, int64_t first_header,
                   const int64_t* first_nl = nullptr, int head_lines = 0, bool reuse_aggregates = false) {
     int rc;
-    if (c->pending) HIPCHK(c, hipStreamSynchronize(c->stream)); // h_state is reused
-    if ((rc = ensure_chunk_arenas(c, n, false))) return rc;
+    if ((rc = begin_submit(c))) return rc;
+    if ((rc = ensure_tile_arenas(c, n)) || (rc = ensure_col_arenas(c, n))) return rc;
     int64_t want = (int64_t)(n / (uint64_t)std::max(4, c->cfg.min_record_bytes)) + 1024;
     if ((rc = ensure_record_arenas(c, want))) return rc;
-    c->views_bytes_once = false;
+    c->views_bytes_once = false; c->tail_pending = false;
     c->cur = d_data; c->cur_n = n; c->cur_stream_pos = stream_pos; c->cur_is_eof = is_eof;
     c->cur_prev_byte = prev_byte; c->cur_first_header = first_header;
-    for (hipEvent_t e : c->ev_detail) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_detail) (void)hipEventDestroy(e);
     c->ev_detail.clear();
     ChunkState* h = c->h_state;
     memset(h, 0, sizeof(*h));
@@ -479,7 +590,7 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
         hipLaunchKernelGGL(k_head, dim3(1), dim3(64), 0, c->stream, d_data, (int64_t)n, prev_byte, head_lines, c->d_state);
     if (n > 0) {
         c->ran_single_pass = c->single_pass != 0 && !c->cfg.views_only;   // views mode has only the two-pass kernels
-        if (c->ran_single_pass) { if ((rc = (c->single_pass >= 2 ? enqueue_single(c) : enqueue_fused(c)))) return rc; }
+        if (c->ran_single_pass) { if ((rc = enqueue_single_launch(c))) return rc; }
         else if ((rc = enqueue_passes(c, false, reuse_aggregates))) return rc;
         hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state);
     }
@@ -495,16 +606,18 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
 // Replays the reference's BufferedReader over the delivered records to learn the window state at
 // the moment the parser reaches the trailing non-record bytes, then classifies them exactly as
 // _next_ref_complete does (parser.mojo:451-522).  Cold path: only for a stream that ends in junk.
-int classify_tail(bzq_ctx* c, const std::vector<int64_t>& rec_end, int64_t N, int64_t first_header, int64_t consumed,
-                  int tail_phase, bool tail_nonblank, bool* accept_last, int* phase_out, int64_t* cap_out) {
-    Window s;
-    s.N = N; s.cap = c->cfg.buffer_capacity; s.w = 0; s.end = 0; s.eof = false;
+// In two halves so that the multi-GPU protocol can walk the window through the ranks' records in rank order
+// (bzq_shard_stitch): window_walk advances (s, head) over a run of record ends, window_classify judges the tail.
+void window_start(Window& s, const bzq_config& cfg, int64_t N) {
+    s = Window();
+    s.N = N; s.cap = cfg.buffer_capacity; s.w = 0; s.end = 0; s.eof = false;
     s.fill(); // BufferedReader.__init__, buffered.mojo:149
-    const bool growth = c->cfg.buffer_growth_enabled != 0;
-    const int64_t maxcap = c->cfg.buffer_max_capacity;
-    int64_t head = first_header;
-    for (size_t r = 0; r < rec_end.size(); ++r) {
-        const int64_t E = rec_end[r];
+}
+void window_walk(Window& s, int64_t& head, const int64_t* rec_end, size_t n, int64_t offset, const bzq_config& cfg) {
+    const bool growth = cfg.buffer_growth_enabled != 0;
+    const int64_t maxcap = cfg.buffer_max_capacity;
+    for (size_t r = 0; r < n; ++r) {
+        const int64_t E = rec_end[r] + offset;
         if (head == s.end) { s.w = head; s.fill(); }
         while (!(E < s.end)) {
             if (head == s.w) {
@@ -517,8 +630,12 @@ int classify_tail(bzq_ctx* c, const std::vector<int64_t>& rec_end, int64_t N, in
         }
         head = E + 1;
     }
+}
+int window_classify(Window& s, int64_t head, const bzq_config& cfg, int tail_phase, bool tail_nonblank, bool* accept_last,
+                    int* phase_out, int64_t* cap_out) {
+    const bool growth = cfg.buffer_growth_enabled != 0;
+    const int64_t maxcap = cfg.buffer_max_capacity;
     *accept_last = false;
-    head = consumed;
     if (head == s.end) { s.w = head; s.fill(); }
     if (head == s.end && s.eof) return BZQ_EOF;
     for (;;) {
@@ -542,6 +659,14 @@ int classify_tail(bzq_ctx* c, const std::vector<int64_t>& rec_end, int64_t N, in
         const int64_t filled = s.fill();
         if (filled == 0 && s.end - head == 0) return BZQ_EOF;
     }
+}
+int classify_tail(bzq_ctx* c, const std::vector<int64_t>& rec_end, int64_t N, int64_t first_header, int64_t consumed,
+                  int tail_phase, bool tail_nonblank, bool* accept_last, int* phase_out, int64_t* cap_out) {
+    Window s;
+    window_start(s, c->cfg, N);
+    int64_t head = first_header;
+    window_walk(s, head, rec_end.data(), rec_end.size(), 0, c->cfg);
+    return window_classify(s, consumed, c->cfg, tail_phase, tail_nonblank, accept_last, phase_out, cap_out);
 }
 
 void sb_put(std::string& s, const char* label, long long v) {
@@ -619,7 +744,12 @@ int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
     CRT(hipSetDevice(device));
     {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+            g_create_error = std::string("bzq_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only (no other code path exists)";
+            delete c;
+            return BZQ_ERR_NO_DEVICE;
+        }
+        if (prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
     }
     CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     CRT(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
@@ -631,22 +761,30 @@ int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
     return 0;
 }
 
+int32_t bzq_comm_destroy(bzq_ctx* c);
+
 void bzq_destroy(bzq_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->tail_log, &c->in, &c->seq, &c->qual, &c->id, &c->ends, &c->id_ends, &c->rec_end, &c->b_ends,
-                      &c->b_id_ends, &c->off[0], &c->off[1], &c->off[2], &c->off[3], &c->view_e, &c->view_i,
-                      &c->tile_c, &c->tile_a,
-                      &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc, &c->consumer_scratch, &c->gen_prefix, &c->id_start, &c->id_len, &c->entries, &c->tile_list, &c->tile_vf};
-    for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
-    if (c->d_state) hipFree(c->d_state);
-    if (c->h_state) hipHostFree(c->h_state);
-    for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
-    for (hipEvent_t e : c->ev_detail) hipEventDestroy(e);
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
-    if (c->stream2) hipStreamDestroy(c->stream2);
-    for (hipEvent_t e : c->ev_pipe) hipEventDestroy(e);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)bzq_comm_destroy(c);
+    std::vector<DevBuf*> bufs = {&c->in, &c->tile_c, &c->tile_a, &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc,
+                                 &c->consumer_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf};
+    for (OutSet& o : c->out) {
+        for (DevBuf* b : {&o.seq, &o.qual, &o.id, &o.ends, &o.id_ends, &o.rec_end, &o.b_ends, &o.b_id_ends, &o.off[0], &o.off[1],
+                          &o.off[2], &o.off[3], &o.id_start, &o.id_len})
+            bufs.push_back(b);
+        for (DevBuf& b : o.view_blocks) bufs.push_back(&b);
+    }
+    for (DevBuf& b : c->tail_log) bufs.push_back(&b);
+    for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    if (c->d_state) (void)hipFree(c->d_state);
+    if (c->h_state) (void)hipHostFree(c->h_state);
+    for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t e : c->ev_detail) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    for (hipEvent_t e : c->ev_pipe) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -655,9 +793,15 @@ const char* bzq_last_error(const bzq_ctx* c) { return c ? c->err.c_str() : g_cre
 int32_t bzq_set_stream(bzq_ctx* c, void* hip_stream) {
     if (!c) return BZQ_ERR_ARG;
     if (c->pending) { c->err = "bzq_set_stream while a chunk is in flight"; return BZQ_ERR_ARG; }
-    if (c->own_stream && c->stream) hipStreamDestroy(c->stream);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)hip_stream;
     c->own_stream = false;
+    return 0;
+}
+
+int32_t bzq_set_consumer_stream(bzq_ctx* c, void* hip_stream) {
+    if (!c) return BZQ_ERR_ARG;
+    c->consumer_stream = (hipStream_t)hip_stream;
     return 0;
 }
 
@@ -671,8 +815,17 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return BZQ_ERR_ARG;
     if (!strcmp(key, "force_dense")) c->force_dense = (int)value;
     else if (!strcmp(key, "timing_detail")) c->timing_detail = (int)value;
-    else if (!strcmp(key, "single_pass")) c->single_pass = (int)value;
-    else if (!strcmp(key, "kernels_v2")) c->v2 = (int)value;
+    else if (!strcmp(key, "single_pass") || !strcmp(key, "kernels_v2")) {
+        // the single-launch variants and the first-generation kernels are cross-checks, compiled only with EXPERIMENTS=1
+        const bool dflt = !strcmp(key, "single_pass") ? value == 0 : value != 0;
+        if (!BZQ_EXPERIMENTS && !dflt) { c->err = std::string("option ") + key + " needs a library built with EXPERIMENTS=1"; return BZQ_ERR_ARG; }
+        if (!strcmp(key, "single_pass")) c->single_pass = (int)value; else c->v2 = (int)value;
+    }
+    else if (!strcmp(key, "double_buffer")) {
+        if (c->pending) { c->err = "double_buffer cannot change while a chunk is in flight"; return BZQ_ERR_ARG; }
+        c->double_buffer = value != 0;
+    }
+    else if (!strcmp(key, "experiments")) return BZQ_EXPERIMENTS ? 0 : BZQ_ERR_ARG;   // query: is this an EXPERIMENTS build?
     else if (!strcmp(key, "ablate")) c->ablate = (int)value;
     else if (!strcmp(key, "views_bytes")) c->views_bytes = (int)value;
     else if (!strcmp(key, "overlap")) c->overlap = (int)value;
@@ -688,6 +841,27 @@ int32_t bzq_pinned_alloc(size_t bytes, void** out) {
 }
 int32_t bzq_pinned_free(void* p) { return hipHostFree(p) == hipSuccess ? 0 : BZQ_ERR_HIP; }
 
+int32_t bzq_device_alloc(bzq_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    *out = nullptr;
+    const hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    if (e != hipSuccess) { c->err = "bzq_device_alloc(" + std::to_string(bytes) + "): " + hipGetErrorString(e); return BZQ_ERR_NOMEM; }
+    return 0;
+}
+int32_t bzq_device_free(bzq_ctx* c, void* p) {
+    if (!c) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (p) HIPCHK(c, hipFree(p));
+    return 0;
+}
+int32_t bzq_copy_to_device(bzq_ctx* c, void* d_dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!d_dst || !src))) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (bytes) HIPCHK(c, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
 int32_t bzq_submit_chunk_device(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream_pos, int32_t is_eof) {
     if (!c || (!d_data && n)) return BZQ_ERR_ARG;
     if (((uintptr_t)d_data & 15u) != 0) { c->err = "device chunk must be 16-byte aligned"; return BZQ_ERR_ARG; }
@@ -700,7 +874,8 @@ int32_t bzq_submit_chunk_host(bzq_ctx* c, const uint8_t* data, uint64_t n, uint6
     if (!c || (!data && n)) return BZQ_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = ensure_chunk_arenas(c, n, true))) return rc;
+    if (c->pending) HIPCHK(c, hipStreamSynchronize(c->stream));   // the previous chunk may still be reading c->in
+    if ((rc = ensure(c, c->in, (size_t)n + 64))) return rc;
     if (n) HIPCHK(c, hipMemcpyAsync(c->in.p, data, n, hipMemcpyHostToDevice, c->stream));
     c->shard_mode = false;
     return submit_common(c, (const uint8_t*)c->in.p, n, stream_pos, is_eof, 0, 0, 0, 0, 10u, 0);
@@ -763,7 +938,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         if (c->ran_single_pass) { fresh.last_nl_tile = -1; }
         *h = fresh;
         HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
-        if (c->ran_single_pass) { if ((rc = (c->single_pass >= 2 ? enqueue_single(c) : enqueue_fused(c)))) return rc; }
+        if (c->ran_single_pass) { if ((rc = enqueue_single_launch(c))) return rc; }
         else if ((rc = enqueue_passes(c, true, false))) return rc;
         enqueue_rebase(c);
         HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
@@ -789,9 +964,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
 
     if (c->records_before >= 0 && !c->shard_mode && n_complete > 0) {
         int rc2;
-        if ((rc2 = ensure_keep(c, c->tail_log, (size_t)(c->records_before + n_complete) * 8, (size_t)c->records_before * 8))) return rc2;
-        hipLaunchKernelGGL(k_log_ends, dim3((unsigned)((n_complete + 255) / 256)), dim3(256), 0, c->stream, (const int64_t*)c->rec_end.p,
-                           n_complete, (int64_t)c->cur_stream_pos, (int64_t*)c->tail_log.p + c->records_before);
+        if ((rc2 = log_record_ends(c, c->records_before, n_complete, (const int64_t*)c->o().rec_end.p, (int64_t)c->cur_stream_pos))) return rc2;
     }
     auto key_rec = [](u64 k) { return (int64_t)(k >> 3); };
     // first failing record among the complete ones; same record: buffer < structure < validation
@@ -818,23 +991,24 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
             int64_t N = (int64_t)n, cons = consumed, fh = c->cur_first_header;
             if (rb > 0) {
                 HIPCHK(c, hipStreamSynchronize(c->stream));
-                HIPCHK(c, hipMemcpy(re.data(), c->tail_log.p, re.size() * 8, hipMemcpyDeviceToHost));
+                int rc3;
+                if ((rc3 = fetch_record_ends(c, (int64_t)re.size(), re.data()))) return rc3;
                 N += (int64_t)c->cur_stream_pos; cons += (int64_t)c->cur_stream_pos; fh = 0;
             } else if (n_complete) {
-                HIPCHK(c, hipMemcpy(re.data(), c->rec_end.p, (size_t)n_complete * 8, hipMemcpyDeviceToHost));
+                HIPCHK(c, hipMemcpy(re.data(), c->o().rec_end.p, (size_t)n_complete * 8, hipMemcpyDeviceToHost));
             }
             int ph = 0; int64_t cap = c->cfg.buffer_capacity;
             int code = classify_tail(c, re, N, fh, cons, tail_phase, h->tail_nonblank != 0, &accept_last, &ph, &cap);
             c->term_phase = ph; c->term_cap = cap;
             if (accept_last) {
                 // last record without trailing newline (Q4): structure check skipped, validation still applies
-                if (n_complete + 1 > c->rec_cap) {
+                if (n_complete + 1 > c->o().rec_cap) {
                     c->err = "record arrays too small for the unterminated last record";
                     return BZQ_ERR_NOMEM;
                 }
                 hipLaunchKernelGGL(k_fix_last, dim3(1), dim3(64), 0, c->stream, n_complete, n, batch,
-                                   (int64_t*)c->ends.p, (int64_t*)c->id_ends.p, (int64_t*)c->rec_end.p,
-                                   (int64_t*)c->b_ends.p, (int64_t*)c->b_id_ends.p, (const ChunkState*)c->d_state);
+                                   (int64_t*)c->o().ends.p, (int64_t*)c->o().id_ends.p, (int64_t*)c->o().rec_end.p,
+                                   (int64_t*)c->o().b_ends.p, (int64_t*)c->o().b_id_ends.p, (const ChunkState*)c->d_state);
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 if (h->err_valid != ~0ull && key_rec(h->err_valid) == n_complete) {
                     // ... and fails it: the record is not delivered, the stream stops behind the last complete one
@@ -851,22 +1025,32 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
             }
         }
     } else if (c->cur_is_eof && c->shard_mode) {
-        // last shard: the window-alignment quirk of the reference is not replayed
-        // across shards; trailing bytes get the outcome the reference gives when its window holds
-        // them completely (probability 1 - tail/buffer_capacity on a large file)
-        if (consumed >= n) r.status = BZQ_EOF;
-        else if (tail_phase == 3 && h->tail_nonblank) {
-            if (n_complete + 1 > c->rec_cap) { c->err = "record arrays too small"; return BZQ_ERR_NOMEM; }
+        // last shard.  Which outcome the reference gives for trailing bytes that are not a record depends on where its
+        // BufferedReader window sits, i.e. on every record since the stream's first byte:
+        //   tail_mode 1  (bzq_shard_stitch, first look): the decision is deferred -- the protocol walks the window through
+        //                the ranks' records in rank order and comes back with it (tail_mode 2);
+        //   tail_mode 0  (bare bzq_submit_shard): the outcome the reference gives when its window holds the tail completely.
+        int code = BZQ_OK;
+        bool acc = false;
+        if (consumed >= n) code = BZQ_EOF;
+        else if (c->tail_mode == 1) { c->tail_pending = true; code = BZQ_OK; }
+        else if (c->tail_mode == 2) { code = c->tail_code; acc = c->tail_accept; c->term_phase = c->tail_phase_dec; c->term_cap = c->tail_cap_dec; }
+        else if (tail_phase == 3 && h->tail_nonblank) acc = true;
+        else if (tail_phase == 3) code = BZQ_OTHER;
+        else { code = BZQ_UNEXPECTED_EOF; c->term_phase = tail_phase; }
+        if (acc) {
+            if (n_complete + 1 > c->o().rec_cap) { c->err = "record arrays too small"; return BZQ_ERR_NOMEM; }
             hipLaunchKernelGGL(k_fix_last, dim3(1), dim3(64), 0, c->stream, n_complete, n, batch,
-                               (int64_t*)c->ends.p, (int64_t*)c->id_ends.p, (int64_t*)c->rec_end.p,
-                               (int64_t*)c->b_ends.p, (int64_t*)c->b_id_ends.p, (const ChunkState*)c->d_state);
+                               (int64_t*)c->o().ends.p, (int64_t*)c->o().id_ends.p, (int64_t*)c->o().rec_end.p,
+                               (int64_t*)c->o().b_ends.p, (int64_t*)c->o().b_id_ends.p, (const ChunkState*)c->d_state);
             HIPCHK(c, hipStreamSynchronize(c->stream));
             accept_last = true;
             if (h->err_valid != ~0ull && key_rec(h->err_valid) == n_complete) {
                 r.status = (int)(h->err_valid & 7); r.error_record = n_complete;
             } else { r.status = BZQ_EOF; n_records = n_complete + 1; consumed = n; }
-        } else if (tail_phase == 3) { r.status = BZQ_OTHER; r.error_record = n_complete; }
-        else { r.status = BZQ_UNEXPECTED_EOF; r.error_record = n_complete; c->term_phase = tail_phase; }
+        } else if (code == BZQ_EOF || (code == BZQ_OK && c->tail_pending)) {
+            r.status = code;
+        } else { r.status = code; r.error_record = n_complete; }
     }
 
     r.n_records = (uint64_t)n_records;
@@ -874,7 +1058,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         // consumed = end of the last delivered record
         if (n_records > 0) {
             int64_t le = 0;
-            HIPCHK(c, hipMemcpy(&le, (const int64_t*)c->rec_end.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&le, (const int64_t*)c->o().rec_end.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
             consumed = le + 1;
         } else consumed = c->cur_first_header;
     }
@@ -882,40 +1066,40 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     if (n_records > 0 && !c->cfg.views_only) {
         int64_t e2[2] = {h->last_ends, h->last_id_ends};
         if (n_records != n_complete) { // truncated by an error, or extended by the unterminated last record
-            HIPCHK(c, hipMemcpy(&e2[0], (const int64_t*)c->ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(&e2[1], (const int64_t*)c->id_ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&e2[0], (const int64_t*)c->o().ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&e2[1], (const int64_t*)c->o().id_ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
         }
         r.qual_bytes = (uint64_t)e2[0];
         r.seq_bytes = accept_last && r.status == BZQ_EOF ? (uint64_t)h->S : (uint64_t)e2[0];
         r.id_bytes = (uint64_t)e2[1];
     }
     if (!c->cfg.views_only) {
-        r.d_seq = (const uint8_t*)c->seq.p; r.d_qual = (const uint8_t*)c->qual.p; r.d_id = (const uint8_t*)c->id.p;
-        r.d_ends = (const int64_t*)c->ends.p; r.d_id_ends = (const int64_t*)c->id_ends.p;
-        r.d_batch_ends = (const int64_t*)c->b_ends.p; r.d_batch_id_ends = (const int64_t*)c->b_id_ends.p;
+        r.d_seq = (const uint8_t*)c->o().seq.p; r.d_qual = (const uint8_t*)c->o().qual.p; r.d_id = (const uint8_t*)c->o().id.p;
+        r.d_ends = (const int64_t*)c->o().ends.p; r.d_id_ends = (const int64_t*)c->o().id_ends.p;
+        r.d_batch_ends = (const int64_t*)c->o().b_ends.p; r.d_batch_id_ends = (const int64_t*)c->o().b_id_ends.p;
     } else {
-        r.d_id_start = (const int64_t*)c->id_start.p; r.d_id_len = (const int32_t*)c->id_len.p;
+        r.d_id_start = (const int64_t*)c->o().id_start.p; r.d_id_len = (const int32_t*)c->o().id_len.p;
     }
-    r.d_record_end = (const int64_t*)c->rec_end.p;
+    r.d_record_end = (const int64_t*)c->o().rec_end.p;
     if (c->cfg.emit_offsets || c->cfg.views_only) {
-        r.d_header_start = (const int64_t*)c->off[0].p; r.d_seq_start = (const int64_t*)c->off[1].p;
-        r.d_sep_start = (const int64_t*)c->off[2].p; r.d_qual_start = (const int64_t*)c->off[3].p;
+        r.d_header_start = (const int64_t*)c->o().off[0].p; r.d_seq_start = (const int64_t*)c->o().off[1].p;
+        r.d_sep_start = (const int64_t*)c->o().off[2].p; r.d_qual_start = (const int64_t*)c->o().off[3].p;
     }
     float ms0 = 0.f, ms1 = 0.f;
-    hipEventElapsedTime(&ms0, c->ev[0], c->ev[1]);
-    hipEventElapsedTime(&ms1, c->ev[2], c->ev[3]);
+    if (hipEventElapsedTime(&ms0, c->ev[0], c->ev[1]) != hipSuccess) ms0 = 0.f;
+    if (hipEventElapsedTime(&ms1, c->ev[2], c->ev[3]) != hipSuccess) ms1 = 0.f;
     r.ms_total = ms0 + ms1;
     r.ms_rebase = ms1;
+    if (c->shard_mode) { r.ms_total += c->ms_scan_shard; r.ms_aggregate += c->ms_scan_shard; }   // pass A ran in bzq_shard_scan
     if (c->timing_detail && c->ran_single_pass && c->ev_detail.size() >= 2) {
         float d = 0;
-        hipEventElapsedTime(&d, c->ev_detail[c->ev_detail.size() - 2], c->ev_detail[c->ev_detail.size() - 1]);
-        r.ms_emit = d;
+        if (hipEventElapsedTime(&d, c->ev_detail[c->ev_detail.size() - 2], c->ev_detail[c->ev_detail.size() - 1]) == hipSuccess) r.ms_emit = d;
     } else if (c->timing_detail && c->ev_detail.size() >= 4) {
         for (size_t i = 0; i + 3 < c->ev_detail.size(); i += 4) {
             float a = 0, b = 0, d = 0;
-            hipEventElapsedTime(&a, c->ev_detail[i], c->ev_detail[i + 1]);
-            hipEventElapsedTime(&b, c->ev_detail[i + 1], c->ev_detail[i + 2]);
-            hipEventElapsedTime(&d, c->ev_detail[i + 2], c->ev_detail[i + 3]);
+            if (hipEventElapsedTime(&a, c->ev_detail[i], c->ev_detail[i + 1]) != hipSuccess) a = 0;
+            if (hipEventElapsedTime(&b, c->ev_detail[i + 1], c->ev_detail[i + 2]) != hipSuccess) b = 0;
+            if (hipEventElapsedTime(&d, c->ev_detail[i + 2], c->ev_detail[i + 3]) != hipSuccess) d = 0;
             r.ms_aggregate += a; r.ms_scan += b; r.ms_emit += d;
         }
     }
@@ -959,14 +1143,16 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
         out->ends = c->res.d_batch_ends + first_record;
         out->id_ends = c->res.d_batch_id_ends + first_record;
     } else {
+        // its own storage: a view handed out earlier keeps its ends (they stay valid as long as the chunk's columns)
         int rc;
-        if ((rc = ensure(c, c->view_e, nrec * 8)) || (rc = ensure(c, c->view_i, nrec * 8))) return rc;
+        void* ve = nullptr;
+        if ((rc = view_alloc(c, (size_t)nrec * 16, &ve))) return rc;
+        int64_t* e = (int64_t*)ve;
         hipLaunchKernelGGL(k_rebase_range, dim3((unsigned)((nrec + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream,
-                           c->res.d_ends, c->res.d_id_ends, (int64_t)first_record, (int64_t)nrec,
-                           (int64_t*)c->view_e.p, (int64_t*)c->view_i.p);
+                           c->res.d_ends, c->res.d_id_ends, (int64_t)first_record, (int64_t)nrec, e, e + nrec);
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        out->ends = (const int64_t*)c->view_e.p;
-        out->id_ends = (const int64_t*)c->view_i.p;
+        out->ends = e;
+        out->id_ends = e + nrec;
     }
     return 0;
 }
@@ -1025,17 +1211,21 @@ int64_t bzq_format_error(bzq_ctx* c, uint64_t records_before, char* buf, size_t 
         // the failing record's bytes: [start, record_end]
         const int64_t rec = r.error_record;
         int64_t start = c->cur_first_header, end = 0;
+        // a failed copy must not format garbage into the text: the call then fails as a whole (-1, text in bzq_last_error)
+        auto fetch_fail = [&](hipError_t e) { c->err = std::string("bzq_format_error: device read failed: ") + hipGetErrorString(e); return (int64_t)-1; };
+        hipError_t ce;
         if (rec > 0) {
-            hipMemcpy(&start, r.d_record_end + (rec - 1), 8, hipMemcpyDeviceToHost);
+            if ((ce = hipMemcpy(&start, r.d_record_end + (rec - 1), 8, hipMemcpyDeviceToHost)) != hipSuccess) return fetch_fail(ce);
             start += 1;
         }
-        if ((uint64_t)rec < (uint64_t)(c->h_state->P >> 2)) hipMemcpy(&end, r.d_record_end + rec, 8, hipMemcpyDeviceToHost);
-        else end = (int64_t)c->cur_n - 1; // unterminated last record
+        if ((uint64_t)rec < (uint64_t)(c->h_state->P >> 2)) {
+            if ((ce = hipMemcpy(&end, r.d_record_end + rec, 8, hipMemcpyDeviceToHost)) != hipSuccess) return fetch_fail(ce);
+        } else end = (int64_t)c->cur_n - 1; // unterminated last record
         int64_t len = end - start + 1;
         if (len < 0) len = 0;
         const int64_t fetch = std::min<int64_t>(len, 1 << 20);
         std::vector<uint8_t> raw((size_t)fetch);
-        if (fetch) hipMemcpy(raw.data(), c->cur + start, (size_t)fetch, hipMemcpyDeviceToHost);
+        if (fetch && (ce = hipMemcpy(raw.data(), c->cur + start, (size_t)fetch, hipMemcpyDeviceToHost)) != hipSuccess) return fetch_fail(ce);
         const long long recno = (long long)(records_before + (uint64_t)rec + 1);
         s = message_for_code(code);
         if (code <= BZQ_SEQ_QUAL_LEN_MISMATCH) {
@@ -1081,38 +1271,53 @@ int64_t bzq_format_error(bzq_ctx* c, uint64_t records_before, char* buf, size_t 
     return (int64_t)s.size();
 }
 
+// The scan of a shard in two halves, so that bzq_shard_stitch can put the summary all-gather on the stream between them:
+// enqueue = pass A + tile scan + first newlines + the state's copy back (ev[4] .. ev[5] time the kernels), finish = read
+// the summary out of the pinned state once the stream has been synchronised.
+static int shard_scan_enqueue(bzq_ctx* c, const uint8_t* d_data, uint64_t n) {
+    int rc;
+    if (c->pending) HIPCHK(c, hipStreamSynchronize(c->stream));   // h_state is reused
+    if ((rc = ensure_tile_arenas(c, n + (64u << 20)))) return rc; // room for the halo tiles too
+    ChunkState* h = c->h_state;
+    memset(h, 0, sizeof(*h));
+    h->last_nl_tile = -1;
+    h->err_struct = ~0ull; h->err_valid = ~0ull; h->err_buf = ~0ull;
+    for (int i = 0; i < 4; ++i) h->first_nl[i] = -1;
+    h->edge_first = 10; h->edge_last = 10;
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    if (n > 0) {
+        HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
+        const int64_t nt = tiles_for(n);
+        AggArgs a{d_data, (int64_t)n, 10u, 0, nt, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
+        hipLaunchKernelGGL(k_tile_aggregate2, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
+        launch_scan(c, 0, nt, 0);
+        hipLaunchKernelGGL(k_first_newlines, dim3(1), dim3(BLOCK), 0, c->stream, d_data, (int64_t)n, c->d_state);
+    }
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    // the whole summary comes back with the state: one copy into pinned memory
+    if (n > 0) HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+static void shard_scan_finish(bzq_ctx* c, const uint8_t* d_data, uint64_t n, bzq_shard_summary* out) {
+    const ChunkState* h = c->h_state;
+    memset(out, 0, sizeof(*out));
+    out->n_bytes = n;
+    out->n_newlines = n ? (uint64_t)h->P : 0;
+    for (int i = 0; i < 4; ++i) out->first_nl[i] = n ? h->first_nl[i] : -1;
+    out->first_byte = n ? h->edge_first : 10; out->last_byte = n ? h->edge_last : 10;
+    c->agg_ptr = d_data; c->agg_n = n;
+    c->ms_scan_shard = 0.f;
+    if (n && hipEventElapsedTime(&c->ms_scan_shard, c->ev[4], c->ev[5]) != hipSuccess) c->ms_scan_shard = 0.f;
+}
+
 int32_t bzq_shard_scan(bzq_ctx* c, const uint8_t* d_data, uint64_t n, bzq_shard_summary* out) {
     if (!c || !out || (!d_data && n)) return BZQ_ERR_ARG;
     if (((uintptr_t)d_data & 15u) != 0) { c->err = "device shard must be 16-byte aligned"; return BZQ_ERR_ARG; }
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = ensure_chunk_arenas(c, n + (64u << 20), false))) return rc; // room for the halo tiles too
-    memset(out, 0, sizeof(*out));
-    out->n_bytes = n;
-    for (int i = 0; i < 4; ++i) out->first_nl[i] = -1;
-    if (n == 0) {
-        out->first_byte = 10; out->last_byte = 10;
-        for (int i = 0; i < 4; ++i) c->h_state->first_nl[i] = -1;
-        c->agg_ptr = d_data; c->agg_n = 0;
-        return 0;
-    }
-    ChunkState* h = c->h_state;
-    memset(h, 0, sizeof(*h));
-    h->last_nl_tile = -1;
-    h->err_struct = ~0ull; h->err_valid = ~0ull; h->err_buf = ~0ull;
-    HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
-    const int64_t nt = tiles_for(n);
-    AggArgs a{d_data, (int64_t)n, 10u, 0, nt, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
-    hipLaunchKernelGGL(k_tile_aggregate2, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
-    launch_scan(c, 0, nt, 0);
-    hipLaunchKernelGGL(k_first_newlines, dim3(1), dim3(BLOCK), 0, c->stream, d_data, (int64_t)n, c->d_state);
-    // the whole summary comes back with the state: one copy into pinned memory, one synchronisation
-    HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
+    if ((rc = shard_scan_enqueue(c, d_data, n))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    out->n_newlines = (uint64_t)h->P;
-    for (int i = 0; i < 4; ++i) out->first_nl[i] = h->first_nl[i];
-    out->first_byte = h->edge_first; out->last_byte = h->edge_last;
-    c->agg_ptr = d_data; c->agg_n = n;
+    shard_scan_finish(c, d_data, n, out);
     return 0;
 }
 
@@ -1205,6 +1410,8 @@ int32_t bzq_generate_synthetic_device(bzq_ctx* c, int64_t num_reads, int64_t fir
                                              d_out, cap, out_bytes);
 }
 
+#include "bzq_comm.hpp"
+
 // ---- host ingest pipeline (bzq_ingest.hpp) ---------------------------------------------------------------------
 
 // shared by the FASTQ and the FASTA ingest: file, pinned + device double buffers, compression sniffing, producer thread
@@ -1262,6 +1469,29 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
     return 0;
 }
 
+// Where chunk k (carry + body) is assembled on the device: in front of the slot's body when the carry fits the reserve
+// (no copy of the body), otherwise in big[k & 1], grown to fit (the caller then also copies the body there).  `quiesce`:
+// the stream whose work may still touch an old big[] buffer.
+static int ingest_place(bzq_ingest* g, int64_t k, uint64_t carry, hipStream_t quiesce, std::string& err, uint8_t** dst, bool* body_moves) {
+    bzq::IngestSlot& s = g->slot[k & 1];
+    if (carry <= g->reserve) { *dst = s.dev + (g->reserve - carry); *body_moves = false; return 0; }
+    const uint64_t need = carry + s.len + 64;
+    const int b = (int)(k & 1);
+    if (g->big_cap[b] < need) {
+        if (g->big[b]) { (void)hipStreamSynchronize(quiesce); (void)hipFree(g->big[b]); g->big[b] = nullptr; g->big_cap[b] = 0; }
+        const uint64_t want = need + need / 4;
+        if (hipMalloc((void**)&g->big[b], want) != hipSuccess) {
+            (void)hipGetLastError();
+            err = "ingest: cannot allocate " + std::to_string(want) + " bytes for a chunk whose carry (" + std::to_string(carry) + " bytes) exceeds the reserve";
+            return BZQ_ERR_NOMEM;
+        }
+        g->big_cap[b] = want;
+    }
+    *dst = g->big[b];
+    *body_moves = true;
+    return 0;
+}
+
 int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int32_t n_threads, bzq_ingest** out) {
     if (!c || !path || !out) return BZQ_ERR_ARG;
     const int32_t rc = ingest_open_common(c->device, c->err, "bzq_ingest_open", path, chunk_bytes, n_threads, out);
@@ -1297,13 +1527,8 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
             }
         }
         carry = g->prev_n - cut;
-        carry_src = g->prev_off + cut;
+        carry_src = cut;
         g->stats.records += std::min<uint64_t>(records_taken, g->prev_res.n_records);
-        if (carry > g->reserve) {
-            c->err = "bzq_ingest_next: " + std::to_string(carry) + " bytes to carry exceed the reserve of " +
-                     std::to_string(g->reserve) + " (open with a larger chunk)";
-            return BZQ_ERR_NOMEM;
-        }
     }
     // ---- wait for this chunk's H2D to be enqueued, then order the ctx stream behind it ---------------------------
     const auto tw = std::chrono::steady_clock::now();
@@ -1314,11 +1539,14 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
     }
     bzq::IngestSlot& s = g->slot[k & 1];
     HIPCHK(c, hipStreamWaitEvent(c->stream, s.h2d_done, 0));
-    const uint64_t off = g->reserve - carry;
-    if (carry) {
-        const bzq::IngestSlot& p = g->slot[(k - 1) & 1];
-        HIPCHK(c, hipMemcpyAsync(s.dev + off, p.dev + carry_src, carry, hipMemcpyDeviceToDevice, c->stream));
+    uint8_t* dst = nullptr;
+    bool body_moves = false;
+    {
+        int prc;
+        if ((prc = ingest_place(g, k, carry, c->stream, c->err, &dst, &body_moves))) return prc;
     }
+    if (carry) HIPCHK(c, hipMemcpyAsync(dst, g->prev_ptr + carry_src, carry, hipMemcpyDeviceToDevice, c->stream));
+    if (body_moves && s.len) HIPCHK(c, hipMemcpyAsync(dst + carry, s.dev + g->reserve, s.len, hipMemcpyDeviceToDevice, c->stream));
     if (g->have_prev) {   // the previous chunk's device buffer may now be refilled (behind the carry copy)
         HIPCHK(c, hipEventRecord(g->dev_free[(k - 1) & 1], c->stream));
         std::unique_lock<std::mutex> lk(g->mu);
@@ -1331,7 +1559,7 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
     const uint64_t spos = s.file_off - carry;
     c->shard_mode = false;
     c->records_before = (int64_t)g->stats.records;   // records handed out so far: the tail log stays in stream order
-    int rc = submit_common(c, s.dev + off, n, spos, s.eof ? 1 : 0, 0, 0, 0, 0, 10u, 0);
+    int rc = submit_common(c, dst, n, spos, s.eof ? 1 : 0, 0, 0, 0, 0, 10u, 0);
     if (rc < 0) return rc;
     rc = bzq_chunk_result(c, out);
     g->stats.wait_s += bzq::seconds_since(tw);
@@ -1339,7 +1567,7 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
     if (stream_pos) *stream_pos = spos;
     g->stats.chunks += 1;
     g->stats.total_s = bzq::seconds_since(g->t_open);
-    g->have_prev = true; g->prev_res = *out; g->prev_n = n; g->prev_off = off; g->prev_stream_pos = spos;
+    g->have_prev = true; g->prev_res = *out; g->prev_n = n; g->prev_ptr = dst; g->prev_stream_pos = spos;
     g->next_k = k + 1;
     if (out->status != BZQ_OK) {   // terminal: EOF or the first failing record
         g->finished = true; g->final_status = out->status == BZQ_EOF ? BZQ_EOF : out->status;
@@ -1422,10 +1650,7 @@ int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* f, bzq_fasta_chunk* out, uint64_
         uint64_t carry = 0, carry_src = 0;
         if (g->have_prev) {
             carry = g->prev_n - f->prev_consumed;
-            carry_src = g->prev_off + f->prev_consumed;
-            if (carry > g->reserve)
-                return fail("bzq_fasta_ingest_next: a record of more than " + std::to_string(g->reserve) +
-                            " bytes does not fit the carry reserve (open with a larger chunk)", BZQ_ERR_NOMEM);
+            carry_src = f->prev_consumed;
         }
         const auto tw = std::chrono::steady_clock::now();
         {
@@ -1435,8 +1660,15 @@ int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* f, bzq_fasta_chunk* out, uint64_
         }
         bzq::IngestSlot& s = g->slot[k & 1];
         bool ok = hipStreamWaitEvent(f->aux, s.h2d_done, 0) == hipSuccess;
-        const uint64_t off = g->reserve - carry;
-        if (ok && carry) ok = hipMemcpyAsync(s.dev + off, g->slot[(k - 1) & 1].dev + carry_src, carry, hipMemcpyDeviceToDevice, f->aux) == hipSuccess;
+        uint8_t* dst = nullptr;
+        bool body_moves = false;
+        {   // a record longer than the reserve (a chromosome): the chunk is assembled in a buffer grown to fit
+            std::string perr;
+            const int prc = ingest_place(g, k, carry, f->aux, perr, &dst, &body_moves);
+            if (prc) return fail("bzq_fasta_ingest_next: " + perr, prc);
+        }
+        if (ok && carry) ok = hipMemcpyAsync(dst, g->prev_ptr + carry_src, carry, hipMemcpyDeviceToDevice, f->aux) == hipSuccess;
+        if (ok && body_moves && s.len) ok = hipMemcpyAsync(dst + carry, s.dev + g->reserve, s.len, hipMemcpyDeviceToDevice, f->aux) == hipSuccess;
         if (ok && g->have_prev) {   // the previous chunk's device buffer may now be refilled (behind the carry copy)
             ok = hipEventRecord(g->dev_free[(k - 1) & 1], f->aux) == hipSuccess;
             std::unique_lock<std::mutex> lk(g->mu);
@@ -1446,13 +1678,13 @@ int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* f, bzq_fasta_chunk* out, uint64_
         }
         if (!ok || hipStreamSynchronize(f->aux) != hipSuccess) return fail("bzq_fasta_ingest_next: a HIP call failed", BZQ_ERR_HIP);
         const uint64_t n = carry + s.len, spos = s.file_off - carry;
-        const int32_t rc = bzq_fasta_parse(f->h, s.dev + off, n, s.eof ? 1 : 0, spos, f->line_base, f->record_base, out);
+        const int32_t rc = bzq_fasta_parse(f->h, dst, n, s.eof ? 1 : 0, spos, f->line_base, f->record_base, out);
         g->stats.wait_s += bzq::seconds_since(tw);
         if (rc < 0) return rc;
         if (stream_pos) *stream_pos = spos;
         g->stats.chunks += 1;
         g->stats.total_s = bzq::seconds_since(g->t_open);
-        g->have_prev = true; g->prev_n = n; g->prev_off = off; g->prev_stream_pos = spos;
+        g->have_prev = true; g->prev_n = n; g->prev_ptr = dst; g->prev_stream_pos = spos;
         g->next_k = k + 1;
         g->stats.records += (uint64_t)out->n_records;
         f->record_base += (uint64_t)out->n_records;
@@ -1524,29 +1756,31 @@ int32_t bzq_release_batch(bzq_ctx* c, bzq_device_batch* b) {
 int32_t bzq_batch_nw_scores(bzq_ctx* c, const bzq_device_batch* b, const uint8_t* ref, int32_t ref_len, int32_t* d_scores) {
     if (!c || !b || ref_len < 0 || (ref_len && !ref) || (b->num_records && !d_scores)) return BZQ_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t cs = c->consumer_stream ? c->consumer_stream : c->stream;
     if (b->num_records <= 0) return 0;
     int rc;
     if ((rc = ensure(c, c->consumer_scratch, 4096))) return rc;
     const int copy = ref_len > NW_MAX_LEN ? NW_MAX_LEN : ref_len;   // longer references score 0 like the example
-    if (copy) HIPCHK(c, hipMemcpyAsync(c->consumer_scratch.p, ref, (size_t)copy, hipMemcpyHostToDevice, c->stream));
+    if (copy) HIPCHK(c, hipMemcpyAsync(c->consumer_scratch.p, ref, (size_t)copy, hipMemcpyHostToDevice, cs));
     const int64_t n = b->num_records;
-    hipLaunchKernelGGL(k_nw_scores, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, c->stream,
+    hipLaunchKernelGGL(k_nw_scores, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, cs,
                        (const uint8_t*)c->consumer_scratch.p, (int)ref_len, b->sequence_buffer, b->ends, n, d_scores);
-    HIPCHK(c, hipStreamSynchronize(c->stream));   // the host reference bytes may go away after the call
+    HIPCHK(c, hipStreamSynchronize(cs));   // the host reference bytes may go away after the call
     return 0;
 }
 
 int32_t bzq_batch_quality_sums(bzq_ctx* c, const bzq_device_batch* b, int64_t* d_sums) {
     if (!c || !b || (b->num_records && !d_sums)) return BZQ_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t cs = c->consumer_stream ? c->consumer_stream : c->stream;
     const int64_t n = b->num_records;
     if (n <= 0) return 0;
     // short reads: a workgroup per 256 records (coalesced span + LDS accumulators); long reads: a wave per record
     if (b->seq_len / n < 1024)
-        hipLaunchKernelGGL(k_quality_sums_block<false>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream,
+        hipLaunchKernelGGL(k_quality_sums_block<false>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, cs,
                            b->qual_buffer, b->ends, n, b->seq_len, (int)b->quality_offset, d_sums);
     else
-        hipLaunchKernelGGL(k_quality_sums<false>, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, c->stream,
+        hipLaunchKernelGGL(k_quality_sums<false>, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, cs,
                            b->qual_buffer, b->ends, n, b->seq_len, (int)b->quality_offset, d_sums);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->err = std::string("k_quality_sums: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
@@ -1556,33 +1790,35 @@ int32_t bzq_batch_quality_sums(bzq_ctx* c, const bzq_device_batch* b, int64_t* d
 int32_t bzq_column_gc_counts(bzq_ctx* c, const uint8_t* d_col, const int64_t* d_ends, int64_t n, int64_t col_len, int64_t* d_counts) {
     if (!c || n < 0 || (n && (!d_col || !d_ends || !d_counts))) return BZQ_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t cs = c->consumer_stream ? c->consumer_stream : c->stream;
     if (n == 0) return 0;
     if (col_len / n < 1024)
-        hipLaunchKernelGGL(k_quality_sums_block<true>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, d_col, d_ends, n,
+        hipLaunchKernelGGL(k_quality_sums_block<true>, dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, cs, d_col, d_ends, n,
                            col_len, 0, d_counts);
     else
-        hipLaunchKernelGGL(k_quality_sums<true>, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, c->stream, d_col, d_ends,
+        hipLaunchKernelGGL(k_quality_sums<true>, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, cs, d_col, d_ends,
                            n, col_len, 0, d_counts);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->err = std::string("k_quality_sums<GC>: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(cs));
     return 0;
 }
 
 int32_t bzq_column_histogram(bzq_ctx* c, const uint8_t* d_col, uint64_t n, uint64_t* hist) {
     if (!c || !hist || (n && !d_col)) return BZQ_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t cs = c->consumer_stream ? c->consumer_stream : c->stream;
     int rc;
     if ((rc = ensure(c, c->consumer_scratch, 4096))) return rc;
     u64* d_h = (u64*)c->consumer_scratch.p + 64;   // behind the reference bytes
-    HIPCHK(c, hipMemsetAsync(d_h, 0, 256 * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(d_h, 0, 256 * 8, cs));
     if (n) {
         const uint64_t steps = (n + (uint64_t)BLOCK * 16 - 1) / ((uint64_t)BLOCK * 16);
         const unsigned grid = (unsigned)std::min<uint64_t>(steps, (uint64_t)c->num_cu * 8);
-        hipLaunchKernelGGL(k_byte_histogram, dim3(grid), dim3(BLOCK), 0, c->stream, d_col, (int64_t)n, d_h);
+        hipLaunchKernelGGL(k_byte_histogram, dim3(grid), dim3(BLOCK), 0, cs, d_col, (int64_t)n, d_h);
     }
-    HIPCHK(c, hipMemcpyAsync(hist, d_h, 256 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(hist, d_h, 256 * 8, hipMemcpyDeviceToHost, cs));
+    HIPCHK(c, hipStreamSynchronize(cs));
     return 0;
 }
 

@@ -1,0 +1,437 @@
+// bzq_comm.hpp -- the multi-GPU shard protocol behind the C ABI (SURVEY.md 8b last row, 8e): bzq_comm_init /
+// bzq_shard_stitch / bzq_global_counts.  New design; the reference is a single process.  A host in any language reaches
+// it the way the reference reaches libz (blazeseq/io/readers.mojo:226-280: OwnedDLHandle + get_function, raw pointers and
+// sizes, negative int = error) -- and this file binds RCCL the same way: librccl.so.1 is dlopen'ed when a communicator is
+// created, so a process that never shards does not need it.
+//
+// One process per GPU, the stream cut into contiguous BYTE ranges (not record aligned), rank r holds range r:
+//   1. every rank scans its shard once (pass A + tile scan + first four newlines)        -> all-gather of 8 x int64 per rank
+//   2. every rank plans (bzq_plan_shards, a pure function of the gathered summaries): the line index of its first byte, the
+//      leading bytes that belong to a record an earlier rank owns (its "head"), the bytes it receives behind its own (its
+//      "halo" = the heads of the following ranks up to the end of its last record -- more than one rank when a record is
+//      longer than a whole shard)                                                       -> one grouped send/recv per rank
+//   3. every rank parses [own bytes + halo] (pass A of step 1 is reused)                 -> all-gather of 8 x int64 per rank
+//   4. only when the stream ends in bytes that are not a record: the reference's BufferedReader window is walked through
+//      the ranks' record ends in rank order, so that BUFFER_EXCEEDED / UNEXPECTED_EOF / accepted-last-record come out
+//      exactly where the sequential parser gives them (parser.mojo:464-510, buffered.mojo:276-279)
+// No bulk data crosses xGMI: messages are bytes to kilobytes, latency bound.
+//
+// Transports: RCCL (ncclAllGather / ncclSend / ncclRecv on the ctx stream, one GPU per rank) and "shm" -- the same three
+// steps through a POSIX shared-memory segment on the host (SURVEY.md 8e "fallback via host"): same-node ranks under any
+// GPU assignment, including several ranks on ONE GPU, which RCCL refuses ("Duplicate GPU detected") and which is how the
+// two-process tests run on a one-GPU box.
+//
+// Included by bzq_api.hip inside its extern "C" block.
+#pragma once
+
+#include <dlfcn.h>
+#include <sched.h>
+#include <sys/mman.h>
+
+struct bzq_comm {
+    int rank = 0, nranks = 1;
+    int kind = 0;   // 1 RCCL, 2 shm
+    // ---- RCCL, bound at run time
+    void* dl = nullptr;
+    void* nccl = nullptr;   // ncclComm_t
+    int (*p_CommInitRank)(void**, int, bzq_nccl_id, int) = nullptr;
+    int (*p_CommDestroy)(void*) = nullptr;
+    int (*p_AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*p_Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*p_Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*p_GroupStart)() = nullptr;
+    int (*p_GroupEnd)() = nullptr;
+    const char* (*p_GetErrorString)(int) = nullptr;
+    int64_t* d_row = nullptr;   // [ROW]
+    int64_t* d_all = nullptr;   // [nranks * ROW]
+    int64_t* h_row = nullptr;   // pinned
+    int64_t* h_all = nullptr;   // pinned
+    // ---- shm
+    int shm_fd = -1;
+    uint8_t* seg = nullptr;
+    size_t seg_bytes = 0;
+    uint64_t halo_cap = 0;
+    std::string shm_name;
+};
+
+namespace {
+
+constexpr int COMM_ROW = 8;   // int64 words per rank and exchange
+constexpr int NCCL_U8 = 1, NCCL_I64 = 4;   // ncclUint8, ncclInt64 (rccl.h)
+
+struct ShmHeader {
+    std::atomic<uint32_t> magic, count, gen;
+    uint32_t nranks;
+    uint64_t halo_cap;
+    uint8_t pad[40];
+};
+static_assert(sizeof(ShmHeader) == 64, "ShmHeader is one cache line");
+constexpr uint32_t SHM_MAGIC = 0x425A5131u;   // "BZQ1"
+
+int64_t* shm_rows(bzq_comm* m) { return (int64_t*)(m->seg + sizeof(ShmHeader)); }
+uint8_t* shm_halo(bzq_comm* m, int r) { return m->seg + sizeof(ShmHeader) + (size_t)m->nranks * COMM_ROW * 8 + (size_t)r * m->halo_cap; }
+
+int shm_barrier(bzq_ctx* c, bzq_comm* m) {
+    ShmHeader* h = (ShmHeader*)m->seg;
+    const uint32_t g = h->gen.load(std::memory_order_acquire);
+    if (h->count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)m->nranks) {
+        h->count.store(0, std::memory_order_relaxed);
+        h->gen.store(g + 1, std::memory_order_release);
+        return 0;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; h->gen.load(std::memory_order_acquire) == g; ++spins) {
+        if ((spins & 63) == 63) sched_yield();
+        if ((spins & 0xFFFF) == 0xFFFF && bzq::seconds_since(t0) > 120.0) { c->err = "bzq_comm(shm): a peer did not reach the barrier within 120 s"; return BZQ_ERR_IO; }
+    }
+    return 0;
+}
+
+#define NCCLCHK(c, m, call)                                                                                         \
+    do {                                                                                                            \
+        const int r_ = (call);                                                                                      \
+        if (r_ != 0) {                                                                                              \
+            (c)->err = std::string(#call) + ": " + ((m)->p_GetErrorString ? (m)->p_GetErrorString(r_) : "RCCL error"); \
+            return BZQ_ERR_HIP;                                                                                     \
+        }                                                                                                           \
+    } while (0)
+
+// all-gather of COMM_ROW int64 per rank, host to host.  `row` may be nullptr when d_row already holds the row on the
+// stream (RCCL only: the scan packed it there).
+int comm_gather(bzq_ctx* c, const int64_t* row, int64_t* all) {
+    bzq_comm* m = c->comm;
+    if (!m) { if (row) memcpy(all, row, COMM_ROW * 8); return 0; }
+    if (m->kind == 1) {
+        if (row) {
+            memcpy(m->h_row, row, COMM_ROW * 8);
+            HIPCHK(c, hipMemcpyAsync(m->d_row, m->h_row, COMM_ROW * 8, hipMemcpyHostToDevice, c->stream));
+        }
+        NCCLCHK(c, m, m->p_AllGather(m->d_row, m->d_all, COMM_ROW, NCCL_I64, m->nccl, c->stream));
+        HIPCHK(c, hipMemcpyAsync(m->h_all, m->d_all, (size_t)m->nranks * COMM_ROW * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        memcpy(all, m->h_all, (size_t)m->nranks * COMM_ROW * 8);
+        return 0;
+    }
+    int rc;
+    memcpy(shm_rows(m) + (size_t)m->rank * COMM_ROW, row, COMM_ROW * 8);
+    if ((rc = shm_barrier(c, m))) return rc;
+    memcpy(all, shm_rows(m), (size_t)m->nranks * COMM_ROW * 8);
+    return shm_barrier(c, m);   // nobody overwrites its row before everybody has read
+}
+
+static __global__ void k_pack_summary(const ChunkState* st, int64_t n, int64_t* row) {
+    if (threadIdx.x || blockIdx.x) return;
+    row[0] = n; row[1] = st->P;
+    for (int i = 0; i < 4; ++i) row[2 + i] = st->first_nl[i];
+    row[6] = st->edge_first; row[7] = st->edge_last;
+}
+
+void comm_free(bzq_comm* m) {
+    if (!m) return;
+    if (m->kind == 1) {
+        if (m->nccl && m->p_CommDestroy) (void)m->p_CommDestroy(m->nccl);
+        if (m->d_row) (void)hipFree(m->d_row);
+        if (m->d_all) (void)hipFree(m->d_all);
+        if (m->h_row) (void)hipHostFree(m->h_row);
+        if (m->h_all) (void)hipHostFree(m->h_all);
+        // the library handle stays open: RCCL keeps process-wide state and is shared with other users (torch)
+    } else if (m->kind == 2) {
+        if (m->seg) munmap(m->seg, m->seg_bytes);
+        if (m->shm_fd >= 0) close(m->shm_fd);
+        if (m->rank == 0 && !m->shm_name.empty()) shm_unlink(m->shm_name.c_str());
+    }
+    delete m;
+}
+
+} // namespace
+
+// ---- planning: a pure function of the gathered summaries (CPU-testable; tests/test_shard_plan.py) -----------------------
+
+int32_t bzq_plan_shards(const bzq_shard_summary* all, int32_t nranks, bzq_shard_plan* out) {
+    if (!all || !out || nranks <= 0) return BZQ_ERR_ARG;
+    uint64_t lines = 0;
+    uint8_t prev_byte = 10;
+    int owner = -1, last_owner = -1;
+    for (int r = 0; r < nranks; ++r) {
+        const bzq_shard_summary& s = all[r];
+        bzq_shard_plan& p = out[r];
+        memset(&p, 0, sizeof(p));
+        p.lines_before = lines; p.prev_last_byte = prev_byte; p.head_dst = -1; p.halo_first_src = -1;
+        if (s.n_bytes == 0) continue;
+        uint64_t head = 0;
+        const int p0 = (int)(lines & 3);
+        if (!(prev_byte == 10 && p0 == 0)) {
+            const int k = 4 - p0;   // newlines left of the record that started in an earlier shard
+            head = s.first_nl[k - 1] >= 0 ? (uint64_t)s.first_nl[k - 1] + 1 : s.n_bytes;   // the whole shard: the record goes on
+        }
+        p.head_bytes = head;
+        if (head > 0) {
+            if (owner < 0) return BZQ_ERR_ARG;   // cannot happen: the stream's first byte starts a record
+            bzq_shard_plan& o = out[owner];
+            p.head_dst = owner;
+            p.halo_offset = o.halo_bytes;
+            o.halo_bytes += head;
+            if (o.halo_first_src < 0) o.halo_first_src = r;
+            o.halo_n_src = r - o.halo_first_src + 1;
+        }
+        if (head < s.n_bytes) { owner = r; last_owner = r; }
+        lines += s.n_newlines;
+        prev_byte = s.last_byte;
+    }
+    out[last_owner >= 0 ? last_owner : 0].is_last = 1;
+    return 0;
+}
+
+// ---- communicators --------------------------------------------------------------------------------------------------------
+
+int32_t bzq_comm_get_unique_id(bzq_nccl_id* id_out) {
+    if (!id_out) return BZQ_ERR_ARG;
+    void* dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!dl) dl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!dl) return BZQ_ERR_IO;
+    auto f = (int (*)(bzq_nccl_id*))dlsym(dl, "ncclGetUniqueId");
+    return f && f(id_out) == 0 ? 0 : BZQ_ERR_HIP;
+}
+
+int32_t bzq_comm_destroy(bzq_ctx* c) {
+    if (!c) return BZQ_ERR_ARG;
+    if (c->comm) { (void)hipSetDevice(c->device); (void)hipStreamSynchronize(c->stream); comm_free(c->comm); c->comm = nullptr; }
+    return 0;
+}
+
+int32_t bzq_comm_init(bzq_ctx* c, int32_t rank, int32_t nranks, const void* nccl_id) {
+    if (!c || nranks <= 0 || rank < 0 || rank >= nranks || !nccl_id) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    (void)bzq_comm_destroy(c);
+    bzq_comm* m = new bzq_comm();
+    m->rank = rank; m->nranks = nranks; m->kind = 1;
+    {
+        m->dl = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!m->dl) m->dl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!m->dl) { c->err = std::string("bzq_comm_init: cannot load librccl.so.1: ") + dlerror(); delete m; return BZQ_ERR_IO; }
+#define BZQ_SYM(field, name) *(void**)(&m->field) = dlsym(m->dl, name)
+        BZQ_SYM(p_CommInitRank, "ncclCommInitRank"); BZQ_SYM(p_CommDestroy, "ncclCommDestroy"); BZQ_SYM(p_AllGather, "ncclAllGather");
+        BZQ_SYM(p_Send, "ncclSend"); BZQ_SYM(p_Recv, "ncclRecv"); BZQ_SYM(p_GroupStart, "ncclGroupStart"); BZQ_SYM(p_GroupEnd, "ncclGroupEnd");
+        BZQ_SYM(p_GetErrorString, "ncclGetErrorString");
+#undef BZQ_SYM
+        if (!m->p_CommInitRank || !m->p_CommDestroy || !m->p_AllGather || !m->p_Send || !m->p_Recv || !m->p_GroupStart || !m->p_GroupEnd) {
+            c->err = "bzq_comm_init: librccl.so.1 lacks a required symbol"; delete m; return BZQ_ERR_IO;
+        }
+        bzq_nccl_id id;
+        memcpy(&id, nccl_id, sizeof(id));
+        const int r = m->p_CommInitRank(&m->nccl, nranks, id, rank);
+        if (r != 0) {
+            c->err = std::string("ncclCommInitRank: ") + (m->p_GetErrorString ? m->p_GetErrorString(r) : "failed");
+            m->nccl = nullptr; comm_free(m);
+            return BZQ_ERR_HIP;
+        }
+        if (hipMalloc((void**)&m->d_row, COMM_ROW * 8) != hipSuccess || hipMalloc((void**)&m->d_all, (size_t)nranks * COMM_ROW * 8) != hipSuccess ||
+            hipHostMalloc((void**)&m->h_row, COMM_ROW * 8, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&m->h_all, (size_t)nranks * COMM_ROW * 8, hipHostMallocDefault) != hipSuccess) {
+            c->err = "bzq_comm_init: staging buffers"; comm_free(m); return BZQ_ERR_NOMEM;
+        }
+    }
+    c->comm = m;
+    return 0;
+}
+
+int32_t bzq_comm_init_shm(bzq_ctx* c, int32_t rank, int32_t nranks, const char* name, uint64_t halo_capacity) {
+    if (!c || nranks <= 0 || rank < 0 || rank >= nranks || !name || !*name) return BZQ_ERR_ARG;
+    (void)bzq_comm_destroy(c);
+    bzq_comm* m = new bzq_comm();
+    m->rank = rank; m->nranks = nranks; m->kind = 2;
+    m->halo_cap = halo_capacity ? halo_capacity : (4ull << 20);
+    m->shm_name = std::string("/bzq_") + name;
+    m->seg_bytes = sizeof(ShmHeader) + (size_t)nranks * COMM_ROW * 8 + (size_t)nranks * m->halo_cap;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (rank == 0) {
+        shm_unlink(m->shm_name.c_str());   // a stale segment of a crashed run
+        m->shm_fd = shm_open(m->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (m->shm_fd < 0 || ftruncate(m->shm_fd, (off_t)m->seg_bytes) != 0) { c->err = "bzq_comm_init_shm: cannot create " + m->shm_name; comm_free(m); return BZQ_ERR_IO; }
+    } else {
+        for (;;) {   // wait for rank 0 to create and size it
+            m->shm_fd = shm_open(m->shm_name.c_str(), O_RDWR, 0600);
+            struct stat st;
+            if (m->shm_fd >= 0 && fstat(m->shm_fd, &st) == 0 && (size_t)st.st_size >= m->seg_bytes) break;
+            if (m->shm_fd >= 0) { close(m->shm_fd); m->shm_fd = -1; }
+            if (bzq::seconds_since(t0) > 120.0) { c->err = "bzq_comm_init_shm: rank 0 never created " + m->shm_name; comm_free(m); return BZQ_ERR_IO; }
+            usleep(1000);
+        }
+    }
+    void* p = mmap(nullptr, m->seg_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, m->shm_fd, 0);
+    if (p == MAP_FAILED) { c->err = "bzq_comm_init_shm: mmap failed"; m->seg = nullptr; comm_free(m); return BZQ_ERR_IO; }
+    m->seg = (uint8_t*)p;
+    ShmHeader* h = (ShmHeader*)m->seg;
+    if (rank == 0) {
+        h->count.store(0); h->gen.store(0); h->nranks = (uint32_t)nranks; h->halo_cap = m->halo_cap;
+        h->magic.store(SHM_MAGIC, std::memory_order_release);
+    } else {
+        while (h->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
+            if (bzq::seconds_since(t0) > 120.0) { c->err = "bzq_comm_init_shm: segment never initialised"; comm_free(m); return BZQ_ERR_IO; }
+            usleep(1000);
+        }
+        if (h->nranks != (uint32_t)nranks || h->halo_cap != m->halo_cap) { c->err = "bzq_comm_init_shm: ranks disagree on nranks / halo capacity"; comm_free(m); return BZQ_ERR_ARG; }
+    }
+    c->comm = m;
+    return shm_barrier(c, m);   // everybody is attached (rank 0 may unlink the name only after all have opened it)
+}
+
+// ---- the protocol ---------------------------------------------------------------------------------------------------------
+
+int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capacity, bzq_shard_result* out) {
+    if (!c || !out || (!d_shard && n) || capacity < n) return BZQ_ERR_ARG;
+    if (((uintptr_t)d_shard & 15u) != 0) { c->err = "device shard must be 16-byte aligned"; return BZQ_ERR_ARG; }
+    if (c->cfg.views_only) { c->err = "bzq_shard_stitch: views mode is a single-chunk mode (shards deliver batch columns)"; return BZQ_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    bzq_comm* m = c->comm;
+    const int P = m ? m->nranks : 1, me = m ? m->rank : 0;
+    memset(out, 0, sizeof(*out));
+    out->first_error_record = -1; out->error_rank = -1;
+    int rc;
+
+    // 1. scan + summary all-gather (RCCL: the row is packed on the device, one synchronisation for both)
+    std::vector<bzq_shard_summary> sums((size_t)P);
+    std::vector<int64_t> all((size_t)P * COMM_ROW);
+    if ((rc = shard_scan_enqueue(c, d_shard, n))) return rc;
+    if (m && m->kind == 1 && n > 0) {
+        hipLaunchKernelGGL(k_pack_summary, dim3(1), dim3(1), 0, c->stream, (const ChunkState*)c->d_state, (int64_t)n, m->d_row);
+        if ((rc = comm_gather(c, nullptr, all.data()))) return rc;
+        shard_scan_finish(c, d_shard, n, &sums[(size_t)me]);
+    } else {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        shard_scan_finish(c, d_shard, n, &sums[(size_t)me]);
+        const bzq_shard_summary& s = sums[(size_t)me];
+        int64_t row[COMM_ROW] = {(int64_t)s.n_bytes, (int64_t)s.n_newlines, s.first_nl[0], s.first_nl[1], s.first_nl[2], s.first_nl[3],
+                                 s.first_byte, s.last_byte};
+        if ((rc = comm_gather(c, row, all.data()))) return rc;
+    }
+    uint64_t stream_pos = 0, total_bytes = 0;
+    for (int r = 0; r < P; ++r) {
+        const int64_t* w = &all[(size_t)r * COMM_ROW];
+        bzq_shard_summary& s = sums[(size_t)r];
+        s.n_bytes = (uint64_t)w[0]; s.n_newlines = (uint64_t)w[1];
+        for (int i = 0; i < 4; ++i) s.first_nl[i] = w[2 + i];
+        s.first_byte = (uint8_t)w[6]; s.last_byte = (uint8_t)w[7];
+        if (r < me) stream_pos += s.n_bytes;
+        total_bytes += s.n_bytes;
+    }
+
+    // 2. plan
+    std::vector<bzq_shard_plan> plans((size_t)P);
+    if ((rc = bzq_plan_shards(sums.data(), P, plans.data()))) { c->err = "bzq_shard_stitch: inconsistent shard summaries"; return rc; }
+    const bzq_shard_plan pl = plans[(size_t)me];
+    out->plan = pl;
+    if (n + pl.halo_bytes > capacity) {
+        c->err = "bzq_shard_stitch: the shard buffer has no room for the halo (" + std::to_string(pl.halo_bytes) + " bytes behind " + std::to_string(n) + ")";
+        return BZQ_ERR_ARG;   // every rank still holds a consistent plan; nothing has been exchanged yet
+    }
+
+    // 3. heads travel to their owners
+    if (m && m->kind == 1 && P > 1) {
+        NCCLCHK(c, m, m->p_GroupStart());
+        if (pl.head_bytes > 0) NCCLCHK(c, m, m->p_Send(d_shard, (size_t)pl.head_bytes, NCCL_U8, pl.head_dst, m->nccl, c->stream));
+        for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
+            if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
+                NCCLCHK(c, m, m->p_Recv(d_shard + n + plans[(size_t)q].halo_offset, (size_t)plans[(size_t)q].head_bytes, NCCL_U8, q, m->nccl, c->stream));
+        NCCLCHK(c, m, m->p_GroupEnd());
+    } else if (m && P > 1) {
+        if (pl.head_bytes > m->halo_cap) { c->err = "bzq_shard_stitch(shm): a head of " + std::to_string(pl.head_bytes) + " bytes exceeds the halo capacity the communicator was created with"; return BZQ_ERR_ARG; }
+        if (pl.head_bytes > 0) HIPCHK(c, hipMemcpy(shm_halo(m, me), d_shard, (size_t)pl.head_bytes, hipMemcpyDeviceToHost));
+        if ((rc = shm_barrier(c, m))) return rc;
+        for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
+            if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
+                HIPCHK(c, hipMemcpy(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice));
+        if ((rc = shm_barrier(c, m))) return rc;
+    }
+
+    // 4. parse own bytes + halo (a rank whose whole shard is the middle of somebody else's record delivers nothing)
+    const bool owner = n > 0 && pl.head_bytes < n;
+    bzq_chunk res{};
+    res.error_record = -1;
+    c->tail_mode = 0;
+    if (owner) {
+        c->tail_mode = pl.is_last ? 1 : 0;
+        rc = bzq_submit_shard(c, d_shard, n, pl.halo_bytes, pl.lines_before, pl.prev_last_byte, stream_pos, pl.is_last);
+        if (rc < 0) { c->tail_mode = 0; return rc; }
+        rc = bzq_chunk_result(c, &res);
+        if (rc < 0) { c->tail_mode = 0; return rc; }
+    } else if (pl.is_last) {
+        res.status = BZQ_EOF;   // an empty stream
+    }
+
+    // 5. outcomes
+    auto gather_outcomes = [&](std::vector<int64_t>& rows) {
+        const bool failed = res.status > 0 && res.status != BZQ_EOF;
+        int64_t row[COMM_ROW] = {(int64_t)res.n_records, (int64_t)res.seq_bytes, (int64_t)n, failed ? res.error_record : -1, res.status,
+                                 owner && c->tail_pending ? 1 : 0, owner ? 1 : 0, 0};
+        rows.assign((size_t)P * COMM_ROW, 0);
+        return comm_gather(c, row, rows.data());
+    };
+    std::vector<int64_t> oc;
+    if ((rc = gather_outcomes(oc))) { c->tail_mode = 0; return rc; }
+    bool walk = false;
+    for (int r = 0; r < P; ++r) {
+        const int64_t* w = &oc[(size_t)r * COMM_ROW];
+        if (w[3] >= 0) { walk = false; break; }   // an earlier failing record ends the stream before its tail is looked at
+        if (w[5]) walk = true;
+    }
+
+    // 6. cold path: the reference's window, walked through every rank's record ends in rank order
+    if (walk) {
+        int64_t st_row[COMM_ROW] = {0, 0, 0, 0, 0, 0, 0, 0};   // w, end, cap, eof, head, valid
+        std::vector<int64_t> st_all((size_t)P * COMM_ROW);
+        Window s;
+        int64_t head = 0;
+        bool have = false;
+        for (int round = 0; round < P; ++round) {
+            if (round == me && owner) {
+                if (!have) { window_start(s, c->cfg, (int64_t)total_bytes); head = (int64_t)stream_pos + c->cur_first_header; }
+                const int64_t nrec = c->h_state->P > 0 ? (c->h_state->P >> 2) : 0;   // complete records of this rank
+                std::vector<int64_t> re((size_t)std::min<int64_t>(nrec, (int64_t)res.n_records));   // the records this rank delivered
+                if (!re.empty()) HIPCHK(c, hipMemcpy(re.data(), c->o().rec_end.p, re.size() * 8, hipMemcpyDeviceToHost));
+                window_walk(s, head, re.data(), re.size(), (int64_t)stream_pos, c->cfg);
+                if (c->tail_pending) {
+                    bool acc = false; int ph = 0; int64_t cap = c->cfg.buffer_capacity;
+                    const int code = window_classify(s, head, c->cfg, res.tail_phase, c->h_state->tail_nonblank != 0, &acc, &ph, &cap);
+                    c->tail_mode = 2; c->tail_code = code; c->tail_accept = acc; c->tail_phase_dec = ph; c->tail_cap_dec = cap;
+                }
+                st_row[0] = s.w; st_row[1] = s.end; st_row[2] = s.cap; st_row[3] = s.eof ? 1 : 0; st_row[4] = head; st_row[5] = 1;
+            }
+            if ((rc = comm_gather(c, st_row, st_all.data()))) { c->tail_mode = 0; return rc; }
+            const int64_t* w = &st_all[(size_t)round * COMM_ROW];
+            if (w[5] && round != me) { s = Window(); s.N = (int64_t)total_bytes; s.w = w[0]; s.end = w[1]; s.cap = w[2]; s.eof = w[3] != 0; head = w[4]; have = true; }
+        }
+        if (owner && c->tail_mode == 2) {   // the last owner: the same chunk again, now with the decision
+            c->pending = true; c->have_result = false;
+            rc = bzq_chunk_result(c, &res);
+            if (rc < 0) { c->tail_mode = 0; return rc; }
+        }
+        if ((rc = gather_outcomes(oc))) { c->tail_mode = 0; return rc; }
+    }
+    c->tail_mode = 0;
+
+    // 7. everything global, derived identically on every rank
+    uint64_t acc_rec = 0;
+    int last_owner = -1;
+    for (int r = 0; r < P; ++r) {
+        const int64_t* w = &oc[(size_t)r * COMM_ROW];
+        if (r == me) out->records_before = acc_rec;
+        if (w[3] >= 0 && out->first_error_record < 0) { out->first_error_record = (int64_t)acc_rec + w[3]; out->error_rank = r; out->stream_status = (int32_t)w[4]; }
+        acc_rec += (uint64_t)w[0];
+        out->global_records += (uint64_t)w[0]; out->global_bases += (uint64_t)w[1]; out->global_bytes += (uint64_t)w[2];
+        if (w[6]) last_owner = r;
+    }
+    if (out->first_error_record < 0) out->stream_status = last_owner >= 0 ? (int32_t)oc[(size_t)last_owner * COMM_ROW + 4] : BZQ_EOF;
+    out->chunk = res;
+    out->stream_pos = stream_pos;
+    c->shard_totals[0] = out->global_records; c->shard_totals[1] = out->global_bases; c->shard_totals[2] = out->global_bytes;
+    c->have_shard_totals = true;
+    return 0;
+}
+
+int32_t bzq_global_counts(bzq_ctx* c, uint64_t out[3]) {
+    if (!c || !out) return BZQ_ERR_ARG;
+    if (!c->have_shard_totals) { c->err = "bzq_global_counts: no bzq_shard_stitch has completed on this ctx"; return BZQ_ERR_ARG; }
+    for (int i = 0; i < 3; ++i) out[i] = c->shard_totals[i];
+    return 0;
+}

@@ -29,6 +29,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The first-generation two-pass kernels (k_tile_aggregate / k_tile_emit) and the single-launch variants are kept as
+// independent implementations for cross-checks; they are compiled only into an EXPERIMENTS build (make EXPERIMENTS=1 ->
+// libblazeseq_hip_exp.so), never into the product library.
+#ifndef BZQ_EXPERIMENTS
+#define BZQ_EXPERIMENTS 0
+#endif
+
 namespace bzq {
 
 constexpr int TILE = 16384;         // bytes per workgroup tile
@@ -335,6 +342,7 @@ struct AggArgs {
     u64* tile_idc;      // 4 x u16: id bytes per class if that class were the header role
 };
 
+#if BZQ_EXPERIMENTS
 static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate(AggArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[TILE];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
@@ -376,6 +384,8 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate(AggArgs a) {
         a.tile_idc[t] = (u64)s_idc[0] | ((u64)s_idc[1] << 16) | ((u64)s_idc[2] << 32) | ((u64)s_idc[3] << 48);
     }
 }
+
+#endif   // BZQ_EXPERIMENTS
 
 // =================================================================================== tile scan
 // Two small kernels over the per-tile summaries (20 B per 16 KiB tile):
@@ -599,6 +609,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tail(const uint8_t* __restrict
     if (tid == 0) { st->tail_start = tail; st->tail_nonblank = s_nb; }
 }
 
+#if BZQ_EXPERIMENTS
 // =================================================================================== pass B
 struct EmitArgs {
     const uint8_t* g;
@@ -624,6 +635,8 @@ struct EmitArgs {
     uint32_t q_lower, q_upper;
     int32_t force_dense;
 };
+
+#endif   // BZQ_EXPERIMENTS
 
 struct ErrAcc {
     u64 e_struct, e_valid;
@@ -657,6 +670,7 @@ __device__ __forceinline__ bool any_out_of_range(uint32_t x, uint32_t lower, uin
     return (less | more) != 0u;
 }
 
+#if BZQ_EXPERIMENTS
 // Gather one role's byte stream of this tile into its packed column.
 //   stream coordinate o in [0, n_role): the o-th byte of this role inside the tile;
 //   segment k: bytes [seg_dst[k], seg_dst[k]+seg_len[k]) of the stream come from tile offset seg_src[k].
@@ -922,6 +936,8 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_emit(EmitArgs a) {
     if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
     if (overflow) atomicOr(&a.st->rec_overflow, 1);
 }
+
+#endif   // BZQ_EXPERIMENTS
 
 // =================================================================================== per record
 struct RebaseArgs {

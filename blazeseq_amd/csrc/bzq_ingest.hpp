@@ -59,7 +59,11 @@ struct bzq_ingest {
     bool have_prev = false, finished = false;
     int32_t final_status = 0;
     uint64_t prev_n = 0;           // bytes of the previous chunk as submitted (carry + body)
-    uint64_t prev_off = 0;         // offset of its first byte inside the slot's device buffer
+    const uint8_t* prev_ptr = nullptr;   // its first byte on the device (inside a slot, or in big[])
+    // a carry larger than the reserve in front of a slot's body (a record or a batch longer than chunk/8): the chunk is
+    // assembled in a buffer of its own, grown on demand -- the reference has no record-size limit either
+    uint8_t* big[2] = {nullptr, nullptr};
+    uint64_t big_cap[2] = {0, 0};
     uint64_t prev_stream_pos = 0;
     bzq_chunk prev_res{};
     bzq_ingest_stats stats{};
@@ -188,12 +192,21 @@ inline bool read_compressed_chunk(bzq_ingest* g, uint8_t* dst, uint64_t cap, uin
 }
 
 inline void ingest_producer(bzq_ingest* g) {
-    (void)hipSetDevice(g->device);
+    // a failed HIP call stops the pipeline with an error the consumer reports: a chunk is never published unless its copy
+    // was enqueued successfully
+    auto fail = [&](const char* what, hipError_t e) {
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->io_error = std::string(what) + ": " + hipGetErrorString(e);
+        g->stop = true;
+        g->cv.notify_all();
+    };
+    hipError_t he;
+    if ((he = hipSetDevice(g->device)) != hipSuccess) return fail("reader: hipSetDevice", he);
     uint64_t off = 0;   // offset in the (decompressed) stream
     for (int64_t k = 0;; ++k) {
         IngestSlot& s = g->slot[k & 1];
         // the pinned buffer of this slot was last used by chunk k-2: its H2D must have finished
-        if (k >= 2) (void)hipEventSynchronize(s.h2d_done);
+        if (k >= 2 && (he = hipEventSynchronize(s.h2d_done)) != hipSuccess) return fail("reader: waiting for the previous copy", he);
         {
             std::unique_lock<std::mutex> lk(g->mu);
             if (g->stop) return;
@@ -222,10 +235,12 @@ inline void ingest_producer(bzq_ingest* g) {
             g->stats.bytes_read += len;
             g->cv.wait(lk, [&] { return g->stop || g->released >= k - 1; });
             if (g->stop) return;
-            if (g->dev_free_valid[k & 1]) (void)hipStreamWaitEvent(g->copy_stream, g->dev_free[k & 1], 0);
+            he = g->dev_free_valid[k & 1] ? hipStreamWaitEvent(g->copy_stream, g->dev_free[k & 1], 0) : hipSuccess;
         }
-        if (len) (void)hipMemcpyAsync(s.dev + g->reserve, s.pinned + g->reserve, len, hipMemcpyHostToDevice, g->copy_stream);
-        (void)hipEventRecord(s.h2d_done, g->copy_stream);
+        if (he != hipSuccess) return fail("reader: hipStreamWaitEvent", he);
+        if (len && (he = hipMemcpyAsync(s.dev + g->reserve, s.pinned + g->reserve, len, hipMemcpyHostToDevice, g->copy_stream)) != hipSuccess)
+            return fail("reader: host to device copy", he);
+        if ((he = hipEventRecord(s.h2d_done, g->copy_stream)) != hipSuccess) return fail("reader: hipEventRecord", he);
         s.file_off = off; s.len = len; s.eof = eof;
         off += len;
         {
@@ -250,6 +265,7 @@ inline void ingest_free(bzq_ingest* g) {
     for (int i = 0; i < 2; ++i) {
         if (g->slot[i].pinned) (void)hipHostFree(g->slot[i].pinned);
         if (g->slot[i].dev) (void)hipFree(g->slot[i].dev);
+        if (g->big[i]) (void)hipFree(g->big[i]);
         if (g->slot[i].h2d_done) (void)hipEventDestroy(g->slot[i].h2d_done);
         if (g->dev_free[i]) (void)hipEventDestroy(g->dev_free[i]);
     }

@@ -227,6 +227,39 @@ class Context:
                "bzq_generate_synthetic_device_var")
         return nb.value
 
+    # ---- the multi-GPU protocol behind the C ABI (bzq_comm.hpp) ------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId through the C ABI: rank 0 creates it, the host hands it to the other ranks."""
+        nid = L.BzqNcclId()
+        rc = L.lib().bzq_comm_get_unique_id(C.byref(nid))
+        if rc != 0:
+            raise RuntimeError(f"bzq_comm_get_unique_id failed ({rc})")
+        return bytes(nid)
+
+    def comm_init(self, rank: int, nranks: int, nccl_id: Optional[bytes] = None):
+        buf = C.create_string_buffer(nccl_id, 128) if nccl_id is not None else None
+        _check(self.h, L.lib().bzq_comm_init(self.h, rank, nranks, buf), "bzq_comm_init")
+
+    def comm_init_shm(self, rank: int, nranks: int, name: str, halo_capacity: int = 0):
+        _check(self.h, L.lib().bzq_comm_init_shm(self.h, rank, nranks, name.encode(), halo_capacity), "bzq_comm_init_shm")
+
+    def comm_destroy(self):
+        _check(self.h, L.lib().bzq_comm_destroy(self.h), "bzq_comm_destroy")
+
+    def shard_stitch(self, d_ptr: int, n: int, capacity: int) -> "ShardResult":
+        raw = L.BzqShardResult()
+        _check(self.h, L.lib().bzq_shard_stitch(self.h, C.c_void_p(d_ptr), n, capacity, C.byref(raw)), "bzq_shard_stitch")
+        return ShardResult(self, raw)
+
+    def global_counts(self):
+        out = (C.c_uint64 * 3)()
+        _check(self.h, L.lib().bzq_global_counts(self.h, out), "bzq_global_counts")
+        return [int(x) for x in out]
+
+    def set_consumer_stream(self, hip_stream: int):
+        _check(self.h, L.lib().bzq_set_consumer_stream(self.h, C.c_void_p(hip_stream)), "bzq_set_consumer_stream")
+
     def shard_scan(self, d_ptr: int, n: int) -> L.BzqShardSummary:
         s = L.BzqShardSummary()
         _check(self.h, L.lib().bzq_shard_scan(self.h, C.c_void_p(d_ptr), n, C.byref(s)), "bzq_shard_scan")
@@ -236,6 +269,18 @@ class Context:
                      stream_pos: int, is_last: bool):
         _check(self.h, L.lib().bzq_submit_shard(self.h, C.c_void_p(d_ptr), n, halo_bytes, lines_before,
                                                prev_last_byte, stream_pos, int(is_last)), "bzq_submit_shard")
+
+
+class ShardResult:
+    """bzq_shard_result: this rank's ChunkResult plus everything global the protocol derived."""
+
+    def __init__(self, ctx: "Context", raw: L.BzqShardResult):
+        self.raw = raw
+        self.chunk = ChunkResult(ctx, raw.chunk)
+        self.plan = raw.plan
+        for name in ("stream_pos", "records_before", "global_records", "global_bases", "global_bytes", "first_error_record",
+                     "stream_status", "error_rank"):
+            setattr(self, name, int(getattr(raw, name)))
 
 
 @dataclass
@@ -460,6 +505,9 @@ class _Source:
         self._mv = None
         self._f = None
         self._pos = 0
+        if isinstance(src, str) and src and "\n" not in src and not src.startswith("@") and not os.path.exists(src):
+            # a str with no newline that does not start a FASTQ record is a (mistyped) path, not content
+            raise FileNotFoundError(f"FastqParser: no such file: {src!r} (pass bytes for in-memory FASTQ content)")
         if isinstance(src, (bytes, bytearray, memoryview, np.ndarray, str)) and not (isinstance(src, str) and os.path.exists(src)):
             self._mv = _as_u8(src)
         elif isinstance(src, (str, os.PathLike)):

@@ -11,9 +11,14 @@
  *     bzq_last_error), > 0 = a FastxErrorCode (blazeseq/errors.mojo:33-68) where documented.
  *   - one bzq_ctx per host thread (the reference parser is single-threaded, README.md:113); a ctx
  *     owns its HIP stream, its device arenas and the result of the most recent chunk.
- *   - device pointers returned in bzq_chunk / bzq_device_batch are owned by the ctx and stay valid
- *     until the next bzq_submit_* on that ctx (the device analogue of "FastqView is valid until the
- *     next parser call", blazeseq/fastq/record.mojo:437-440).
+ *   - device pointers returned in bzq_chunk / bzq_device_batch / bzq_device_views are owned by the ctx and
+ *     stay valid until the SECOND following bzq_submit_* / bzq_ingest_next on that ctx: the ctx keeps two
+ *     sets of output arenas and alternates between them, so a consumer kernel on another stream may
+ *     still read chunk k while chunk k+1 is parsed (the device analogue of "FastqView is valid until
+ *     the next parser call", blazeseq/fastq/record.mojo:437-440, one chunk deeper).  The INPUT bytes a
+ *     bzq_device_views points into belong to the caller (bzq_submit_chunk_device) or are valid until the
+ *     next submit (bzq_submit_chunk_host).  Option "double_buffer" = 0 keeps one set (half the memory,
+ *     results valid until the next submit).
  *   - all positions are int64 byte offsets relative to the first byte of the submitted chunk.
  */
 #ifndef BLAZESEQ_HIP_H
@@ -125,7 +130,7 @@ typedef struct bzq_chunk {
 /* Views of records [first_record, first_record + num_records) of the current chunk (views mode): FastqView
  * (record.mojo:431-550) for many records at once -- spans into the chunk instead of copies.  Record r (relative to
  * first_record): id = chunk[id_start[r] .. +id_len[r]); sequence = chunk[seq_start[r] .. sep_start[r] - 1);
- * quality = chunk[qual_start[r] .. record_end[r]).  Valid until the next bzq_submit_* on the ctx. */
+ * quality = chunk[qual_start[r] .. record_end[r]).  The offset arrays follow the two-chunk lifetime rule above. */
 typedef struct bzq_device_views {
     int64_t num_records;
     const uint8_t* chunk;          /* the submitted chunk on the device */
@@ -192,6 +197,9 @@ void bzq_destroy(bzq_ctx* ctx);
 const char* bzq_last_error(const bzq_ctx* ctx);   /* ctx may be NULL: last create() failure */
 /* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the ctx's own. */
 int32_t bzq_set_stream(bzq_ctx* ctx, void* hip_stream);
+/* The stream the bzq_batch_* / bzq_column_* consumer kernels are launched on (NULL = the ctx stream).  With a stream
+ * of its own a consumer of chunk k overlaps the parse of chunk k+1 (the results of chunk k stay valid, see above). */
+int32_t bzq_set_consumer_stream(bzq_ctx* ctx, void* hip_stream);
 int32_t bzq_get_config(const bzq_ctx* ctx, bzq_config* out);
 /* Run-time knobs that are not part of ParserConfig: "pass_bytes" (bytes per kernel round),
  * "timing_detail" (per-kernel hipEvent timing in bzq_chunk), "force_dense" (tests: route every
@@ -199,13 +207,20 @@ int32_t bzq_get_config(const bzq_ctx* ctx, bzq_config* out);
  * number of records delivered from earlier chunks, set before each bzq_submit_chunk_*; the ctx then keeps
  * the stream's record ends -- 8 bytes per record on the device -- so that trailing bytes that are not a
  * record are judged with the reference's BufferedReader window where it really sits, io/buffered.mojo:
- * 239-290; -1 (default) = each chunk is judged as a stream of its own; bzq_ingest_next sets it itself). */
+ * 239-290; -1 (default) = each chunk is judged as a stream of its own; bzq_ingest_next sets it itself);
+ * "double_buffer" (1 default / 0: number of output sets, see the lifetime rule at the top). */
 int32_t bzq_set_option(bzq_ctx* ctx, const char* key, int64_t value);
 
 /* DeviceContext.enqueue_create_host_buffer (record_batch.mojo:316-323): pinned staging the host
  * fills with Reader.read_to_buffer semantics (io/readers.mojo:71-76). */
 int32_t bzq_pinned_alloc(size_t bytes, void** out);
 int32_t bzq_pinned_free(void* p);
+
+/* Device memory for hosts that have no HIP binding of their own (the plain-C drivers under tests/c_driver; a Mojo host
+ * would hand over DeviceContext buffers, record_batch.mojo:364-401): allocation on the ctx's GPU, synchronous copy in. */
+int32_t bzq_device_alloc(bzq_ctx* ctx, size_t bytes, void** out);
+int32_t bzq_device_free(bzq_ctx* ctx, void* p);
+int32_t bzq_copy_to_device(bzq_ctx* ctx, void* d_dst, const void* src, size_t bytes);
 
 /* ---- the hot path --------------------------------------------------------------------------- */
 
@@ -228,8 +243,9 @@ int32_t bzq_chunk_result(bzq_ctx* ctx, bzq_chunk* out);
 /* next_batch (parser.mojo:239-251) + to_device (record_batch.mojo:89-90): records
  * [first_record, first_record+max_records) of the current chunk.  When first_record is a multiple
  * of config.batch_size and max_records <= batch_size (the batches() iteration) the view is zero
- * copy; any other range gets its rebased `ends` from a small kernel into ctx scratch that is valid
- * until the next bzq_batch_view. */
+ * copy; any other range gets its rebased `ends` / `id_ends` from a small kernel into storage of its
+ * own inside the chunk's output set: every view handed out stays valid exactly as long as the
+ * chunk's columns, however many views are taken in between. */
 int32_t bzq_batch_view(bzq_ctx* ctx, uint64_t first_record, uint32_t max_records, bzq_device_batch* out);
 /* DeviceFastqBatch.copy_to_host (record_batch.mojo:222-244) */
 int32_t bzq_batch_to_host(bzq_ctx* ctx, const bzq_device_batch* batch, bzq_host_batch* out);
@@ -267,6 +283,58 @@ int32_t bzq_submit_shard(bzq_ctx* ctx, const uint8_t* d_data, uint64_t n, uint64
 /* Number of leading bytes of this shard that belong to the previous rank's last record. */
 int32_t bzq_shard_head_bytes(const bzq_shard_summary* s, uint64_t lines_before, uint8_t prev_last_byte,
                              uint64_t* head_bytes);
+
+/* ---- the whole multi-GPU protocol behind the C ABI (SURVEY.md 8b last row, 8e) ------------------
+ * One process per GPU; the stream is cut into contiguous BYTE ranges, rank r holds range r in device memory.  A host in
+ * any language drives it like the reference drives libz (blazeseq/io/readers.mojo:226-280): no Python, no torch. */
+
+/* ncclUniqueId (rccl.h): created by one rank, handed to the others by the host's own means (a file, MPI, a store). */
+typedef struct bzq_nccl_id { char internal[128]; } bzq_nccl_id;
+int32_t bzq_comm_get_unique_id(bzq_nccl_id* id_out);
+/* RCCL communicator of the ctx (ncclCommInitRank on the ctx's device; librccl.so.1 is bound at this call).  Collectives
+ * run on the ctx stream.  One GPU per rank (RCCL refuses two ranks on one device). */
+int32_t bzq_comm_init(bzq_ctx* ctx, int32_t rank, int32_t nranks, const void* nccl_id);
+/* The same protocol through a POSIX shared-memory segment on the host ("/bzq_<name>"; SURVEY.md 8e fallback via host):
+ * same-node ranks under any GPU assignment, several ranks per GPU included.  halo_capacity: largest head a rank may send
+ * (0 = 4 MiB); all ranks must pass the same value. */
+int32_t bzq_comm_init_shm(bzq_ctx* ctx, int32_t rank, int32_t nranks, const char* name, uint64_t halo_capacity);
+int32_t bzq_comm_destroy(bzq_ctx* ctx);
+
+/* What a rank skips, sends and receives; a pure function of the gathered summaries (bzq_plan_shards). */
+typedef struct bzq_shard_plan {
+    uint64_t lines_before;    /* global line index of the shard's first (possibly partial) line */
+    uint64_t head_bytes;      /* leading bytes that belong to a record an earlier rank owns (== n_bytes: the whole shard) */
+    uint64_t halo_bytes;      /* bytes received behind the own bytes: the heads of the following ranks, in rank order */
+    uint64_t halo_offset;     /* where this rank's head lands in its owner's halo */
+    int32_t head_dst;         /* the owner our head goes to, -1 = none */
+    int32_t halo_first_src;   /* first rank we receive from (-1 = none) ... */
+    int32_t halo_n_src;       /* ... and how many consecutive ranks may contribute (those with head_dst == this rank) */
+    uint8_t prev_last_byte;   /* byte preceding the shard in the stream (0x0A for the stream's first byte) */
+    uint8_t is_last;          /* no record starts behind this rank's bytes: its parse sees the end of the stream */
+    uint8_t _pad[2];
+} bzq_shard_plan;
+int32_t bzq_plan_shards(const bzq_shard_summary* all, int32_t nranks, bzq_shard_plan* out);
+
+typedef struct bzq_shard_result {
+    bzq_chunk chunk;              /* this rank's records (index 0 = its first OWNED record); chunk.status is the rank's own */
+    bzq_shard_plan plan;
+    uint64_t stream_pos;          /* stream offset of the shard's first byte */
+    uint64_t records_before;      /* global index of this rank's record 0 */
+    uint64_t global_records, global_bases, global_bytes;   /* sums over all ranks */
+    int64_t first_error_record;   /* global index of the stream's first failing record, -1 = none */
+    int32_t stream_status;        /* BZQ_EOF, or the FastxErrorCode the sequential parser raises at first_error_record */
+    int32_t error_rank;           /* rank that holds the failing record, -1 = none */
+} bzq_shard_result;
+
+/* scan -> summary all-gather -> plan -> heads to their owners -> parse [own + halo] -> outcome all-gather, and, only when
+ * the stream ends in bytes that are not a record, the reference's BufferedReader window walked through all ranks' record
+ * ends in rank order (parser.mojo:464-510, buffered.mojo:276-279) so that BUFFER_EXCEEDED / UNEXPECTED_EOF / an accepted
+ * last record come out exactly where the sequential parser gives them.  d_shard: `capacity` >= n + halo bytes of device
+ * memory, 16-byte aligned, the rank's n bytes at its start.  Collective: every rank calls it once per step.  Without a
+ * communicator (or nranks == 1) the same code runs with no exchange. */
+int32_t bzq_shard_stitch(bzq_ctx* ctx, uint8_t* d_shard, uint64_t n, uint64_t capacity, bzq_shard_result* out);
+/* records, bases (sequence bytes), bytes over all ranks after the last bzq_shard_stitch */
+int32_t bzq_global_counts(bzq_ctx* ctx, uint64_t out[3]);
 
 /* ---- host ingest pipeline ---------------------------------------------- */
 

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE); sys.path.insert(0, os.path.dirname(HERE))
 import numpy as np
 from fastq_fuzz import rand_stream, rand_record
-from gpu_util import make_pair, check_against_oracle, check_views_against_oracle
+from gpu_util import make_pair, check_against_oracle, check_views_against_oracle, EXPERIMENTS
 
 
 def make_stream(rng):
@@ -88,7 +88,7 @@ for seed in range(lo, hi):
     if rng.random() < 0.15:
         kw["compat_simd_width"] = int(rng.choice([16, 32, 64]))
     bs = int(rng.choice([1, 7, 100, 4096]))
-    sp = [False, True, "v1"][int(rng.integers(0, 3))] if (rng.random() < 0.3 and not args.views) else False
+    sp = [False, True, "v1"][int(rng.integers(0, 3))] if (EXPERIMENTS and rng.random() < 0.3 and not args.views) else False
     key = (bs, sp, tuple(sorted(kw.items())))
     if key not in pairs:
         if len(pairs) > 40:

@@ -9,6 +9,7 @@ import numpy as np
 from fastq_fuzz import rand_stream
 from oracle import oracle as O
 from test_gpu_parity import _run_shards_on_one_gpu
+from gpu_util import EXPERIMENTS
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=180)
@@ -33,7 +34,7 @@ while time.time() - t0 < args.seconds:
         continue
     cuts = sorted(set(int(x) for x in rng.integers(lo, data.size - lo, P - 1)))
     cuts = [c for i, c in enumerate(cuts) if i == 0 or c - cuts[i - 1] > lo]
-    mode = [True, False, 2, 3][int(rng.integers(0, 4))] if rng.random() < 0.3 else False
+    mode = [True, False, 2, 3][int(rng.integers(0, 4))] if (EXPERIMENTS and rng.random() < 0.3) else False
     try:
         total, ids, seqs, quals, ends = _run_shards_on_one_gpu(data, cuts, oc, single_pass=mode, **kw)
         ok = (total == whole.n_records and np.array_equal(ids, whole.id_bytes) and np.array_equal(seqs, whole.seq_bytes)

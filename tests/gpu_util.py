@@ -1,4 +1,6 @@
 """Helpers for the -m gpu parity tests: run the HIP path through the C ABI, compare with the oracle."""
+import os
+
 import numpy as np
 
 import blazeseq_amd as B
@@ -6,7 +8,17 @@ from blazeseq_amd import _lib as L
 from oracle import oracle as O
 
 
-def make_pair(batch_size=4096, schema="generic", pass_bytes=0, min_record_bytes=32, single_pass=True, **kw):
+# The product library holds ONE batch-mode implementation (aggregate + scan + emit, "False" below).  The single-launch
+# variants (True = look-back, "svc" = prefix-service workgroup, "hier" = two-level look-back) and the first-generation
+# kernels ("v1") are independent implementations kept as cross-checks in an EXPERIMENTS build (libblazeseq_hip_exp.so):
+# tests/test_gpu_experiments.py re-runs the parity files against that library with BZQ_TEST_EXPERIMENTS=1.
+EXPERIMENTS = os.environ.get("BZQ_TEST_EXPERIMENTS", "0") == "1"
+VARIANTS = [False] + ([True, "v1", "svc", "hier"] if EXPERIMENTS else [])
+VARIANTS_LB = [False] + ([True] if EXPERIMENTS else [])
+SHARD_VARIANTS = [False] + ([True, 2, 3] if EXPERIMENTS else [])
+
+
+def make_pair(batch_size=4096, schema="generic", pass_bytes=0, min_record_bytes=32, single_pass=False, **kw):
     """(Context, oracle config) with the same ParserConfig."""
     okw = {k: v for k, v in kw.items() if k not in ("compat_simd_width", "emit_offsets", "views_only")}
     cfg = B.ParserConfig(**kw)
@@ -14,8 +26,9 @@ def make_pair(batch_size=4096, schema="generic", pass_bytes=0, min_record_bytes=
     ctx = B.Context(cfg, schema, batch_size, 0, pass_bytes=pass_bytes, min_record_bytes=min_record_bytes)
     # single_pass: True = one fused launch with in-kernel look-back; False = aggregate + scan + emit
     # (table-driven v2 kernels); "v1" = the first-generation two-pass kernels
-    ctx.set_option("single_pass", {"svc": 2, "hier": 3}.get(single_pass, int(single_pass is True)))
-    ctx.set_option("kernels_v2", 0 if single_pass == "v1" else 1)
+    if single_pass is not False:
+        ctx.set_option("single_pass", {"svc": 2, "hier": 3}.get(single_pass, int(single_pass is True)))
+        ctx.set_option("kernels_v2", 0 if single_pass == "v1" else 1)
     okw.pop("quality_schema", None)
     ocfg = O.make_config(quality_schema=name, simd_width=kw.get("compat_simd_width", 0), batch_size=batch_size, **okw)
     return ctx, ocfg

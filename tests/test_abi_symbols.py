@@ -32,7 +32,8 @@ def test_struct_sizes_match_header(tmp_path):
     from blazeseq_amd import _lib
     structs = {"bzq_config": _lib.BzqConfig, "bzq_chunk": _lib.BzqChunk, "bzq_device_batch": _lib.BzqDeviceBatch,
                "bzq_host_batch": _lib.BzqHostBatch, "bzq_shard_summary": _lib.BzqShardSummary,
-               "bzq_ingest_stats": _lib.BzqIngestStats,
+               "bzq_ingest_stats": _lib.BzqIngestStats, "bzq_shard_plan": _lib.BzqShardPlan,
+               "bzq_shard_result": _lib.BzqShardResult, "bzq_nccl_id": _lib.BzqNcclId,
                "bzq_fasta_config": _lib.BzqFastaConfig, "bzq_fasta_chunk": _lib.BzqFastaChunk}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "blazeseq_hip.h"', "int main(void) {"]
     for cname, ct in structs.items():

@@ -113,3 +113,100 @@ def test_fasta_driver_reproduces_the_oracle(case, tmp_path):
     assert (b"# records=%d " % w.n_records) in r.stdout and (b"status=%d" % w.status) in r.stdout
     if w.status != F.EOF:
         assert r.stdout.split(b"# error: ", 1)[1].rstrip(b"\n").decode("latin-1") == w.message
+
+
+def _run_ranks(args_per_rank, timeout=180):
+    procs = [subprocess.Popen(a, stdout=subprocess.PIPE, stderr=subprocess.PIPE) for a in args_per_rank]
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, e.decode()
+        outs.append(o)
+    return outs
+
+
+def _check_sharded_outputs(outs, data: bytes, check: bool, bufcap: int):
+    """Every rank's records, in rank order and cut at the stream's first failing record, are the sequential parser's
+    records; totals, terminal status and error text are the oracle's for the WHOLE stream."""
+    from oracle import oracle as O
+    kw = dict(check_ascii=check, check_quality=check)
+    if bufcap:
+        kw["buffer_capacity"] = bufcap
+    f = O.flat_parse(np.frombuffer(data, dtype=np.uint8), O.make_config(**kw), is_eof=True)
+    want, e0, i0 = [], 0, 0
+    for r in range(f.n_records):
+        e1, i1 = int(f.ends[r]), int(f.id_ends[r])
+        s1 = f.seq_bytes.size if r + 1 == f.n_records else e1
+        want.append(f.id_bytes[i0:i1].tobytes() + b"\t" + f.seq_bytes[e0:s1].tobytes() + b"\t" + f.qual_bytes[e0:e1].tobytes())
+        e0, i0 = e1, i1
+    got, metas, errors = [], [], []
+    for o in outs:
+        lines = o.split(b"\n")
+        recs = [l for l in lines if l and not l.startswith(b"#")]
+        meta = dict(kv.split(b"=") for kv in [l for l in lines if l.startswith(b"# rank=")][0][2:].split())
+        metas.append({k.decode(): int(v) for k, v in meta.items()})
+        errors += [o.split(b"# error: ", 1)[1].rstrip(b"\n")] if b"# error: " in o else []
+        first_error = metas[-1]["first_error"]
+        before = metas[-1]["before"]
+        keep = len(recs) if first_error < 0 else max(0, min(len(recs), first_error - before))
+        got += recs[:keep]
+    assert got == want, (len(got), len(want))
+    assert all(m["stream_status"] == f.term_code for m in metas), ([m["stream_status"] for m in metas], f.term_code, f.term_msg)
+    assert len({(m["global_records"], m["global_bases"], m["global_bytes"], m["first_error"], m["error_rank"]) for m in metas}) == 1
+    assert metas[0]["global_bytes"] == len(data)
+    if f.term_code != 6:
+        assert errors == [f.term_msg], (errors, f.term_msg)
+    else:
+        assert not errors and metas[0]["global_records"] == f.n_records
+
+
+def _shard_cases():
+    rng = np.random.default_rng(2024)
+    clean = b"".join(b"@read_%04d extra\n%s\n+\n%s\n" % (i, b"ACGTN"[i % 5:i % 5 + 1] * (20 + i % 37), b"I" * (20 + i % 37)) for i in range(2000))
+    cases = {
+        "clean": (clean, 3, 0, 0),
+        "unterminated_last_record": (clean[:-1], 2, 0, 0),
+        "error_in_rank0": (clean.replace(b"@read_0100 ", b"xread_0100 ", 1), 3, 0, 0),
+        "error_in_last_rank": (clean.replace(b"\n+\n", b"\n-\n", 1900).replace(b"\n-\n", b"\n+\n", 1899), 2, 0, 0),
+        "bad_quality_validated": (clean[:len(clean) // 2] + b"@bad\nACGT\n+\nII I\n" + clean[len(clean) // 2:], 2, 1, 0),
+        "record_longer_than_a_shard": (b"@a\nAC\n+\nII\n@long\n" + b"A" * 3000 + b"\n+\n" + b"I" * 3000 + b"\n@z\nG\n+\nI\n", 4, 0, 0),
+    }
+    # trailing bytes that are not a record, with a small buffer: where the reference's window sits decides between
+    # BUFFER_EXCEEDED, UNEXPECTED_EOF and an accepted last record (the three outcomes of tests/test_gpu_ingest.py)
+    body = b"".join(b"@r%03d\n%s\n+\n%s\n" % (i, b"ACGT" * (3 + i % 5), b"IIII" * (3 + i % 5)) for i in range(300))
+    for k, tail in enumerate([b"@junk\nACGTACGT", b"@last\nACGTAC\n+\nIIIIII", b"@x\nAC\n+\n \t", b"@q\nACGTACGTACGTACGTACGT\n+"]):
+        for cap in (256, 320, 389):
+            cases[f"tail{k}_cap{cap}"] = (body + tail, 3, 0, cap)
+    return cases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(_shard_cases()))
+def test_shard_protocol_from_plain_c_processes(case, tmp_path):
+    """tests/c_driver/bzq_shard.c, one process per rank, all on GPU 0 through the host (shm) transport of the C ABI: the
+    HIP shard path on every rank, no Python in those processes."""
+    _build()
+    exe = os.path.join(DRV, "bzq_shard")
+    data, nranks, check, cap = _shard_cases()[case]
+    path = tmp_path / "in.fastq"
+    path.write_bytes(data)
+    name = f"t{os.getpid()}_{abs(hash(case)) % 100000}"
+    outs = _run_ranks([[exe, "shm", str(r), str(nranks), name, str(path), "0", str(check), str(cap)] for r in range(nranks)])
+    _check_sharded_outputs(outs, data, bool(check), cap)
+
+
+@pytest.mark.gpu
+def test_shard_protocol_over_rccl_world_1(tmp_path):
+    """The RCCL transport at world size 1 (one GPU box): librccl is bound and the communicator-less path runs."""
+    _build()
+    exe = os.path.join(DRV, "bzq_shard")
+    data = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(1000))
+    path = tmp_path / "in.fastq"
+    path.write_bytes(data)
+    outs = _run_ranks([[exe, "rccl", "0", "1", str(tmp_path / "id"), str(path)]])
+    _check_sharded_outputs(outs, data, False, 0)

@@ -1,0 +1,164 @@
+"""-m gpu: lifetime and size rules of the boundary.
+ * every unaligned bzq_batch_view keeps its own ends storage (a batch held across later next_batch() calls used to read
+   the later batch's ends);
+ * a chunk's results stay valid until the SECOND following submit (double-buffered output sets), so a consumer kernel on
+   another stream overlaps the next chunk's parse;
+ * the ingest carries records / batches larger than its reserve (FASTQ: next_batch(n) spanning many chunks; FASTA: a
+   record of tens of MB -- the reference has no record-size limit, fasta/parser.mojo:122-172)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_batches(data: bytes, bs: int):
+    sp = O.StreamParser(np.frombuffer(data, dtype=np.uint8), O.make_config(batch_size=bs))
+    out = []
+    while True:
+        b = sp.next_batch(bs)
+        if len(b) == 0:
+            return out
+        out.append(b)
+
+
+def _same(b, ob):
+    assert len(b) == len(ob)
+    np.testing.assert_array_equal(b._ends, ob.ends)
+    np.testing.assert_array_equal(b._id_ends, ob.id_ends)
+    np.testing.assert_array_equal(b._sequence_bytes, ob.seq_bytes)
+    np.testing.assert_array_equal(b._quality_bytes, ob.qual_bytes)
+    np.testing.assert_array_equal(b._id_bytes, ob.id_bytes)
+
+
+def test_unaligned_batches_held_before_reading_any_of_them():
+    import blazeseq_amd as B
+    data = O.generate_synthetic(3000, 20, 180, 0, 40, "sanger").tobytes()   # variable-length reads
+    want = _oracle_batches(data, 100)
+    p = B.FastqParser(data, batch_size=4096)        # ctx batch size 4096, next_batch(100): never batch aligned after the first
+    held = [p.next_batch(100) for _ in range(7)]    # nothing fetched yet
+    held += [p.next_batch(37), p.next_batch(100)]
+    for b, ob in zip(held[:7], want[:7]):
+        _same(b, ob)
+    assert len(held[7]) == 37 and len(held[8]) == 100
+    d = [b.to_device() for b in held[:3]]           # DeviceFastqBatch.ends of an unaligned view: its own storage as well
+    e = np.empty(100, dtype=np.int64)
+    for k in (2, 0, 1):
+        p._ctx.copy_to_host(e, d[k].ends, 800)
+        np.testing.assert_array_equal(e, want[k].ends)
+
+
+def test_python_surface_batches_of_100_on_variable_length_reads(tmp_path):
+    import blazeseq_amd as B
+    from blazeseq_amd import pyapi
+    data = O.generate_synthetic(2500, 15, 120, 0, 40, "sanger").tobytes()
+    path = tmp_path / "v.fastq"
+    path.write_bytes(data)
+    got = list(pyapi.parser(str(path)).batches)     # list() holds every batch before any of them is read
+    want = _oracle_batches(data, 100)
+    assert [b.num_records() for b in got] == [len(w) for w in want]
+    for b, w in zip(got, want):
+        recs = [(r.id, r.sequence, r.quality) for r in b]
+        i0 = s0 = 0
+        for k, (rid, seq, qual) in enumerate(recs):
+            i1, s1 = int(w.id_ends[k]), int(w.ends[k])
+            assert (rid.encode("latin-1"), seq.encode("latin-1"), qual.encode("latin-1")) == \
+                   (w.id_bytes[i0:i1].tobytes(), w.seq_bytes[s0:s1].tobytes(), w.qual_bytes[s0:s1].tobytes())
+            i0, s0 = i1, s1
+
+
+def test_results_stay_valid_through_the_next_submit_and_consumers_overlap_it():
+    import torch
+    import blazeseq_amd as B
+    a = O.generate_synthetic(60_000, 150, 150, 0, 40, "sanger")
+    b = O.generate_synthetic(50_000, 100, 100, 5, 35, "sanger")
+    ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
+    da, db = torch.from_numpy(a.copy()).cuda(), torch.from_numpy(b.copy()).cuda()
+    side = torch.cuda.Stream()
+    ctx.set_consumer_stream(side.cuda_stream)
+    fa = O.flat_parse(a, O.make_config())
+    fb = O.flat_parse(b, O.make_config())
+
+    ctx.submit_device(da.data_ptr(), da.numel(), 0, True)
+    ra = ctx.result()
+    view_a = ctx.batch_view(100, 50_000)                    # unaligned: its ends live in chunk A's output set
+    sums = torch.zeros(50_000, dtype=torch.int64, device="cuda")
+    dba = B.DeviceFastqBatch(ctx, view_a)
+    dba.quality_sums(sums.data_ptr())                       # on the side stream ...
+    ctx.submit_device(db.data_ptr(), db.numel(), 0, True)   # ... while chunk B is parsed on the ctx stream
+    rb = ctx.result()
+    side.synchronize()
+    q = fa.qual_bytes.astype(np.int64) - 33
+    cs = np.concatenate([[0], np.cumsum(q)])
+    want = cs[fa.ends[100:50_100]] - cs[np.concatenate([[fa.ends[99]], fa.ends[100:50_099]])]
+    np.testing.assert_array_equal(sums.cpu().numpy(), want)
+    # chunk A's columns are still what they were, chunk B's are B's
+    np.testing.assert_array_equal(ra.seq(), fa.seq_bytes)
+    np.testing.assert_array_equal(ra.ends(), fa.ends)
+    np.testing.assert_array_equal(rb.seq(), fb.seq_bytes)
+    np.testing.assert_array_equal(rb.qual(), fb.qual_bytes)
+    e = np.empty(50_000, dtype=np.int64)
+    ctx.copy_to_host(e, view_a.ends, e.nbytes)
+    np.testing.assert_array_equal(e, fa.ends[100:50_100] - fa.ends[99])
+    # the third submit recycles chunk A's set
+    ctx.submit_device(da.data_ptr(), da.numel(), 0, True)
+    rc = ctx.result()
+    assert rc.d_seq == ra.d_seq and rc.d_seq != rb.d_seq
+    # one set only: results are replaced by the next submit
+    ctx.set_option("double_buffer", 0)
+    ctx.submit_device(db.data_ptr(), db.numel(), 0, True)
+    r1 = ctx.result()
+    ctx.submit_device(da.data_ptr(), da.numel(), 0, True)
+    r2 = ctx.result()
+    assert r1.d_seq == r2.d_seq
+    np.testing.assert_array_equal(r2.qual(), fa.qual_bytes)
+    ctx.close()
+
+
+def test_fastq_batch_larger_than_the_ingest_reserve(tmp_path):
+    """next_batch(n) with n records far beyond one chunk AND beyond the 16 MiB carry reserve: the ingest assembles the
+    oversized chunk in a buffer grown to fit (it used to fail with BZQ_ERR_NOMEM)."""
+    import blazeseq_amd as B
+    data = O.generate_synthetic(90_000, 150, 150, 0, 40, "sanger").tobytes()   # 28 MB
+    path = tmp_path / "big.fastq"
+    path.write_bytes(data)
+    p = B.FastqParser(str(path), batch_size=4096, chunk_bytes=2 << 20)
+    b = p.next_batch(80_000)                                                  # 25 MB of records from 2 MiB chunks
+    f = O.flat_parse(np.frombuffer(data, dtype=np.uint8), O.make_config())
+    assert len(b) == 80_000
+    np.testing.assert_array_equal(b._ends, f.ends[:80_000])
+    np.testing.assert_array_equal(b._sequence_bytes, f.seq_bytes[:int(f.ends[79_999])])
+    rest = p.next_batch(80_000)
+    assert len(rest) == 10_000 and not len(p.next_batch(5))
+    np.testing.assert_array_equal(rest._quality_bytes, f.qual_bytes[int(f.ends[79_999]):])
+
+
+def test_fasta_record_larger_than_the_ingest_reserve(tmp_path):
+    """A chromosome-sized record (24 MB, 60 columns) through FastaParser(path) with 1 MiB chunks: more than the 16 MiB
+    reserve has to be carried from chunk to chunk."""
+    import blazeseq_amd as B
+    from oracle import fasta as F
+    rng = np.random.default_rng(5)
+    big = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 24_000_000)
+    lines = np.full((big.size // 60, 61), 10, dtype=np.uint8)
+    lines[:, :60] = big.reshape(-1, 60)
+    data = b">small one\nACGT\nAC\n>chr_big some description\n" + lines.tobytes() + b">after\nGGGG\n"
+    path = tmp_path / "big.fasta"
+    path.write_bytes(data)
+    p = B.FastaParser(str(path), chunk_bytes=1 << 20)
+    recs = list(p.records())
+    assert [r.id for r in recs] == [b"small one", b"chr_big some description", b"after"]
+    assert recs[0].sequence == b"ACGTAC" and recs[2].sequence == b"GGGG"
+    assert len(recs[1].sequence) == big.size and recs[1].sequence == big.tobytes()
+    p.close()
+
+
+def test_a_mistyped_path_is_not_fastq_content():
+    import blazeseq_amd as B
+    with pytest.raises(FileNotFoundError):
+        B.FastqParser("/no/such/dir/reads.fastq")
+    p = B.FastqParser("@r1\nACGT\n+\nIIII\n")            # a str that IS content
+    assert len(p.next_batch(4)) == 1

@@ -12,13 +12,13 @@ pytestmark = pytest.mark.gpu
 
 from oracle import oracle as O
 from fastq_fuzz import rand_stream
-from gpu_util import make_pair, check_against_oracle
+from gpu_util import make_pair, check_against_oracle, EXPERIMENTS, VARIANTS, VARIANTS_LB, SHARD_VARIANTS
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CORPUS = json.load(open(os.path.join(HERE, "golden", "corpus_expected.json")))
 
 
-@pytest.mark.parametrize("single_pass", [True, False, "v1", "svc", "hier"])
+@pytest.mark.parametrize("single_pass", VARIANTS)
 def test_inline_known_answers(single_pass):
     ctx, oc = make_pair(emit_offsets=True, single_pass=single_pass)
     for data in (b"@r1\nACGT\n+\n!!!!\n@r2\nTGCA\n+\n####\n", b"", b"\n", b"@", b"@a\nA\n+\n!\n",
@@ -29,7 +29,7 @@ def test_inline_known_answers(single_pass):
         check_against_oracle(ctx, oc, data, offsets=True, what=repr(data[:20]))
 
 
-@pytest.mark.parametrize("single_pass", [True, False, "v1", "svc", "hier"])
+@pytest.mark.parametrize("single_pass", VARIANTS)
 @pytest.mark.parametrize("cfgname", ["default", "validated_generic", "validated_schema", "validated_schema_simd32",
                                      "cap64", "cap64_growth"])
 def test_corpus(cfgname, single_pass, corpus_dir):
@@ -58,7 +58,7 @@ def test_fuzz_small(seed):
         for kw in (dict(), dict(check_ascii=True, check_quality=True),
                    dict(check_ascii=True, check_quality=True, quality_schema="solexa", compat_simd_width=16),
                    dict(buffer_capacity=48), dict(buffer_capacity=48, buffer_growth_enabled=True, buffer_max_capacity=200)):
-            ctx, oc = make_pair(batch_size=int(rng.choice([1, 3, 4096])), emit_offsets=True, single_pass=[True, False, "v1", "svc", "hier"][rep % 5], **kw)
+            ctx, oc = make_pair(batch_size=int(rng.choice([1, 3, 4096])), emit_offsets=True, single_pass=VARIANTS[rep % len(VARIANTS)], **kw)
             check_against_oracle(ctx, oc, data, offsets=True, what=f"seed{seed}/{rep}/{kw}")
             if rep == 0:
                 ctx.set_option("force_dense", 1)   # every tile through the serial in-kernel path
@@ -76,21 +76,20 @@ def test_fuzz_multi_tile(seed):
     data = rand_stream(rng, n_records=nrec, max_len=max_len, dirty=dirty, crlf=bool(rng.random() < 0.2))
     for kw, pb in ((dict(), 0), (dict(check_ascii=True, check_quality=True), 64 * 1024),
                    (dict(check_ascii=True, check_quality=True), 16 * 1024)):
-        ctx, oc = make_pair(batch_size=int(rng.choice([7, 4096])), pass_bytes=pb, emit_offsets=True, single_pass=(pb == 0), **kw)
+        ctx, oc = make_pair(batch_size=int(rng.choice([7, 4096])), pass_bytes=pb, emit_offsets=True, **kw)
         check_against_oracle(ctx, oc, data, offsets=True, what=f"mt seed{seed} {kw} pass={pb}")
-        ctx.set_option("single_pass", 1)
-        check_against_oracle(ctx, oc, data, offsets=True, what=f"mt single-pass seed{seed} {kw}")
-        ctx.set_option("single_pass", 2)
-        check_against_oracle(ctx, oc, data, offsets=True, what=f"mt service seed{seed} {kw}")
-        ctx.set_option("single_pass", 3)
-        check_against_oracle(ctx, oc, data, offsets=True, what=f"mt two-level look-back seed{seed} {kw}")
+        if EXPERIMENTS:   # the single-launch variants of an EXPERIMENTS build
+            for mode, name in ((1, "look-back"), (2, "service"), (3, "two-level look-back")):
+                ctx.set_option("single_pass", mode)
+                check_against_oracle(ctx, oc, data, offsets=True, what=f"mt {name} seed{seed} {kw}")
+            ctx.set_option("single_pass", 0)
         check_against_oracle(ctx, oc, data, is_eof=False, offsets=True, what=f"mt chunk-mode seed{seed}")
         ctx.set_option("force_dense", 1)
         check_against_oracle(ctx, oc, data, offsets=True, what=f"mt dense seed{seed}")
         ctx.close()
 
 
-@pytest.mark.parametrize("single_pass", [False, True])
+@pytest.mark.parametrize("single_pass", VARIANTS_LB)
 def test_every_byte_value_is_classified_exactly(single_pass):
     """All 255 non-newline byte values at every alignment in id, sequence and quality lines: the newline
     detector (v_perm with the data as selector) and the strip logic must not mistake any of them."""
@@ -110,7 +109,7 @@ def test_unterminated_last_record_that_fails_validation_is_not_consumed():
     """Found by tests/fuzz_campaign.py (seed 8002): the last record has no trailing newline (accepted, Q4) but its
     quality is out of range for the schema -- it must not be delivered and bytes_consumed stops before it."""
     data = b"@Tq_\nAGCGN\n+\n?hxj{\n@zbg\nNNAGAGGNACT\n+zbg\n8x+;@W4-)6z"
-    for sp in (False, True):
+    for sp in VARIANTS_LB:
         ctx, ocfg = make_pair(batch_size=7, single_pass=sp, check_ascii=True, check_quality=True, quality_schema="solexa")
         res, f = check_against_oracle(ctx, ocfg, data, what="unterminated + invalid")
         assert f.n_records == 1 and f.term_code == 5 and f.consumed == 19 and int(res.bytes_consumed) == 19
@@ -128,7 +127,7 @@ def test_space_runs_across_tile_edges():
         parts.append(b"@" + lead + rid + trail + b"\n" + b"A" * L + b"\n+\n" + b"I" * L + b"\n")
     data = b"".join(parts)
     for dense in (0, 1):
-        for sp in (True, False, "v1", "svc", "hier"):
+        for sp in VARIANTS:
             ctx, oc = make_pair(emit_offsets=True, check_ascii=True, check_quality=True, single_pass=sp)
             ctx.set_option("force_dense", dense)
             check_against_oracle(ctx, oc, data, offsets=True, what=f"space runs dense={dense} single_pass={sp}")
@@ -139,7 +138,7 @@ def test_tiny_records_take_serial_path_and_resize():
     """> 1020 newlines in a 16 KiB tile (records of 4-12 bytes): serial in-kernel path, and the
     per-record arrays are re-sized transparently."""
     data = b"@\n\n+\n\n" * 9000 + b"@a\nC\n+\n!\n" * 3000
-    for sp in (True, False, "v1", "svc", "hier"):
+    for sp in VARIANTS:
         ctx, oc = make_pair(emit_offsets=True, check_ascii=True, check_quality=True, single_pass=sp)
         res, f = check_against_oracle(ctx, oc, data, offsets=True, what=f"tiny single_pass={sp}")
         assert res._pad > 0  # dense tiles were used
@@ -171,7 +170,7 @@ def test_device_generator_matches_oracle():
     ctx.close()
 
 
-@pytest.mark.parametrize("single_pass", [True, False, "v1", "svc", "hier"])
+@pytest.mark.parametrize("single_pass", VARIANTS)
 @pytest.mark.parametrize("validate", [False, True])
 def test_synthetic_150bp_medium(validate, single_pass):
     """Config 2/3 shape at a size the oracle parses in a second: 150k reads (47.7 MB)."""
@@ -271,7 +270,7 @@ def test_streaming_chunks_equal_one_shot():
         assert n == len(ref)
 
 
-def _run_shards_on_one_gpu(data: np.ndarray, cuts, ocfg, single_pass=True, **kw):
+def _run_shards_on_one_gpu(data: np.ndarray, cuts, ocfg, single_pass=False, **kw):
     """Every shard goes through bzq_shard_scan / bzq_submit_shard on the one GPU; the halo exchange that
     RCCL does between ranks is a device-to-device copy here."""
     import torch
@@ -285,7 +284,8 @@ def _run_shards_on_one_gpu(data: np.ndarray, cuts, ocfg, single_pass=True, **kw)
         t = torch.zeros(n + (1 << 17), dtype=torch.uint8, device="cuda")
         t[:n] = torch.from_numpy(data[bounds[r]:bounds[r + 1]].copy()).cuda()
         ctx = B.Context(B.ParserConfig(**kw), "generic", 4096, 0)
-        ctx.set_option("single_pass", int(single_pass))
+        if single_pass:
+            ctx.set_option("single_pass", int(single_pass))
         s = ctx.shard_scan(t.data_ptr(), n)
         ctxs.append(ctx); bufs.append(t)
         sums.append([int(s.n_bytes), int(s.n_newlines), *[int(x) for x in s.first_nl], int(s.first_byte), int(s.last_byte)])
@@ -311,7 +311,7 @@ def _run_shards_on_one_gpu(data: np.ndarray, cuts, ocfg, single_pass=True, **kw)
     return total, cat(ids, np.uint8), cat(seqs, np.uint8), cat(quals, np.uint8), cat([e for e in ends if e.size], np.int64)
 
 
-@pytest.mark.parametrize("single_pass", [True, False, 2, 3])
+@pytest.mark.parametrize("single_pass", SHARD_VARIANTS)
 @pytest.mark.parametrize("seed", range(6))
 def test_shards_on_one_gpu(seed, single_pass):
     """bzq_shard_scan + k_head + bzq_submit_shard: byte-range shards cut anywhere reproduce the whole parse."""
