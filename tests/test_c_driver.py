@@ -147,10 +147,10 @@ def _check_sharded_outputs(outs, data: bytes, check: bool, bufcap: int):
     got, metas, errors = [], [], []
     for o in outs:
         lines = o.split(b"\n")
-        recs = [l for l in lines if l and not l.startswith(b"#")]
+        recs = [l for l in lines if l.count(b"\t") == 2 and not l.startswith(b"#")]   # (RCCL prints a version banner on stdout)
         meta = dict(kv.split(b"=") for kv in [l for l in lines if l.startswith(b"# rank=")][0][2:].split())
         metas.append({k.decode(): int(v) for k, v in meta.items()})
-        errors += [o.split(b"# error: ", 1)[1].rstrip(b"\n")] if b"# error: " in o else []
+        errors += [o.split(b"# error: ", 1)[1][:-1]] if b"# error: " in o else []   # the text may itself end in a newline (snippet)
         first_error = metas[-1]["first_error"]
         before = metas[-1]["before"]
         keep = len(recs) if first_error < 0 else max(0, min(len(recs), first_error - before))
