@@ -13,6 +13,7 @@
 #if BZQ_EXPERIMENTS
 #include "bzq_single.hpp"   // single-launch variants + first-generation kernels: cross-checks and negative results only
 #endif
+#include "bzq_stream.hpp"
 #include "bzq_views.hpp"
 
 #include <algorithm>
@@ -114,6 +115,9 @@ struct bzq_ctx {
     int views_bytes = 0;   // option: views mode through the two-read kernels even without validation (cross-check)
     int force_dense = 0, timing_detail = 0, single_pass = 0, v2 = 1, num_cu = 256;
     bool ran_single_pass = false;
+    int use_stream = 1;        // option "stream": batch mode through the single-read kernel (k_stream); 0 = two-pass kernels
+    bool ran_stream = false;
+    int64_t stream_fallbacks = 0;
     // current chunk
     const uint8_t* cur = nullptr;
     uint64_t cur_n = 0, cur_stream_pos = 0;
@@ -415,6 +419,36 @@ int enqueue_single(bzq_ctx* c) {
 
 #endif
 
+// Batch mode with one read of the input: one launch of k_stream (bzq_stream.hpp) for the whole chunk.
+template <bool CA, bool CQ>
+void launch_stream_off(const bzq_ctx* c, bool offs, dim3 grid, const StreamArgs& a) {
+    if (offs) hipLaunchKernelGGL((k_stream<CA, CQ, true>), grid, dim3(BLOCK), 0, c->stream, a);
+    else hipLaunchKernelGGL((k_stream<CA, CQ, false>), grid, dim3(BLOCK), 0, c->stream, a);
+}
+int enqueue_stream(bzq_ctx* c) {
+    const int64_t nt = tiles_for(c->cur_n);
+    const int64_t n_wg = (nt + ST - 1) / ST, n_grp = (n_wg + SGRP - 1) / SGRP;
+    const size_t words = (size_t)n_wg * WD_WORDS + (size_t)n_grp * GD_WORDS;
+    int rc;
+    if ((rc = ensure(c, c->desc, words * 8))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->desc.p, 0, words * 8, c->stream));
+    StreamArgs sa{};
+    sa.f = make_fused_args(c);
+    sa.wd = (u64*)c->desc.p; sa.gd = sa.wd + (size_t)n_wg * WD_WORDS; sa.n_wg = n_wg;
+    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    const dim3 grid((unsigned)n_wg);
+    const bool ca = c->cfg.check_ascii != 0, cq = c->cfg.check_quality != 0, off = c->cfg.emit_offsets != 0;
+    if (ca && cq) launch_stream_off<true, true>(c, off, grid, sa);
+    else if (ca) launch_stream_off<true, false>(c, off, grid, sa);
+    else if (cq) launch_stream_off<false, true>(c, off, grid, sa);
+    else launch_stream_off<false, false>(c, off, grid, sa);
+    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    c->n_passes = 1;
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { c->err = std::string("kernel launch: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
+    return 0;
+}
+
 int enqueue_single_launch(bzq_ctx* c) {
 #if BZQ_EXPERIMENTS
     return c->single_pass >= 2 ? enqueue_single(c) : enqueue_fused(c);
@@ -590,7 +624,12 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
         hipLaunchKernelGGL(k_head, dim3(1), dim3(64), 0, c->stream, d_data, (int64_t)n, prev_byte, head_lines, c->d_state);
     if (n > 0) {
         c->ran_single_pass = c->single_pass != 0 && !c->cfg.views_only;   // views mode has only the two-pass kernels
+        // one read of the input (k_stream) unless the caller asked for sub-chunk passes, or this is a shard (its pass A
+        // already ran in bzq_shard_scan and its first lines belong to the previous rank)
+        c->ran_stream = !c->ran_single_pass && c->use_stream && !c->cfg.views_only && c->cfg.pass_bytes == 0 && head_lines == 0 &&
+                        !reuse_aggregates && !first_nl;
         if (c->ran_single_pass) { if ((rc = enqueue_single_launch(c))) return rc; }
+        else if (c->ran_stream) { if ((rc = enqueue_stream(c))) return rc; }
         else if ((rc = enqueue_passes(c, false, reuse_aggregates))) return rc;
         hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state);
     }
@@ -821,6 +860,8 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
         if (!BZQ_EXPERIMENTS && !dflt) { c->err = std::string("option ") + key + " needs a library built with EXPERIMENTS=1"; return BZQ_ERR_ARG; }
         if (!strcmp(key, "single_pass")) c->single_pass = (int)value; else c->v2 = (int)value;
     }
+    else if (!strcmp(key, "stream")) c->use_stream = value != 0;
+    else if (!strcmp(key, "stream_fallbacks")) return (int32_t)std::min<int64_t>(c->stream_fallbacks, 0x7FFFFFFF);   // query: chunks repeated on the two-pass kernels
     else if (!strcmp(key, "double_buffer")) {
         if (c->pending) { c->err = "double_buffer cannot change while a chunk is in flight"; return BZQ_ERR_ARG; }
         c->double_buffer = value != 0;
@@ -903,7 +944,8 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         *h = fresh;
         HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
         int rc;
-        c->ran_single_pass = false;
+        c->ran_single_pass = false; c->ran_stream = false; c->stream_fallbacks += 1;
+        if ((rc = ensure_tile_arenas(c, c->cur_n))) return rc;
         if ((rc = enqueue_passes(c, false, false))) return rc;
         hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)c->cur_n, c->d_state);
         enqueue_rebase(c);
@@ -935,10 +977,11 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         ChunkState fresh = *h;
         fresh.rec_overflow = 0; fresh.err_struct = ~0ull; fresh.err_valid = ~0ull; fresh.err_buf = ~0ull;
         fresh.dense_tiles = 0;
-        if (c->ran_single_pass) { fresh.last_nl_tile = -1; }
+        if (c->ran_single_pass || c->ran_stream) { fresh.last_nl_tile = -1; }
         *h = fresh;
         HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
         if (c->ran_single_pass) { if ((rc = enqueue_single_launch(c))) return rc; }
+        else if (c->ran_stream) { if ((rc = enqueue_stream(c))) return rc; }
         else if ((rc = enqueue_passes(c, true, false))) return rc;
         enqueue_rebase(c);
         HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
@@ -1091,7 +1134,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     r.ms_total = ms0 + ms1;
     r.ms_rebase = ms1;
     if (c->shard_mode) { r.ms_total += c->ms_scan_shard; r.ms_aggregate += c->ms_scan_shard; }   // pass A ran in bzq_shard_scan
-    if (c->timing_detail && c->ran_single_pass && c->ev_detail.size() >= 2) {
+    if (c->timing_detail && (c->ran_single_pass || c->ran_stream) && c->ev_detail.size() >= 2) {
         float d = 0;
         if (hipEventElapsedTime(&d, c->ev_detail[c->ev_detail.size() - 2], c->ev_detail[c->ev_detail.size() - 1]) == hipSuccess) r.ms_emit = d;
     } else if (c->timing_detail && c->ev_detail.size() >= 4) {
