@@ -225,6 +225,7 @@ def main():
     ap.add_argument("--service", action="store_true", help="one launch, prefix-service workgroup (bzq_single.hpp)")
     ap.add_argument("--hier", action="store_true", help="one launch, two-level decoupled look-back (bzq_single.hpp)")
     ap.add_argument("--two-pass", action="store_true", help="(default) aggregate + scan + emit kernels")
+    ap.add_argument("--stream", action="store_true", help="EXPERIMENTS build: k_stream, one read of the input (profiles/r2_single_read.md)")
     ap.add_argument("--kernels-v1", action="store_true", help="two-pass mode with the first-generation kernels")
     ap.add_argument("--overlap", type=int, default=0, help="overlap pass A of sub-chunk k+1 with the emit of sub-chunk k (needs --pass-bytes)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU shard protocol even with one rank")
@@ -269,6 +270,8 @@ def main():
     if args.hier or args.service or args.single_pass or args.kernels_v1:   # EXPERIMENTS build only (BLAZESEQ_HIP_LIB=.../libblazeseq_hip_exp.so)
         ctx.set_option("single_pass", 3 if args.hier else 2 if args.service else (1 if (args.single_pass and not args.kernels_v1) else 0))
         ctx.set_option("kernels_v2", 0 if args.kernels_v1 else 1)
+    if args.stream:
+        ctx.set_option("stream", 1)
     if args.ablate:
         ctx.set_option("ablate", args.ablate)
     ctx.set_option("overlap", args.overlap)
@@ -422,7 +425,7 @@ def main():
                        "pass_bytes": args.pass_bytes, "exchange": exchange},
             "fraction_of_hbm_peak_input_rate": round(global_bytes / world / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
             "roofline": {
-                "bound": "hbm", "kernel": "k_views" if args.views else "k_tile_emit" if args.kernels_v1 else ("k_single<look-back>" if args.hier else "k_single<service>" if args.service else ("k_fused<LB=true>" if args.single_pass else "k_fused<LB=false>")),
+                "bound": "hbm", "kernel": "k_stream" if args.stream else "k_views" if args.views else "k_tile_emit" if args.kernels_v1 else ("k_single<look-back>" if args.hier else "k_single<service>" if args.service else ("k_fused<LB=true>" if args.single_pass else "k_fused<LB=false>")),
                 "achieved": round(A_total / emit_s / 1e9, 2) if emit_s > 0 else None,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(A_total / emit_s / 1e9 / HBM_PEAK_GBS, 4) if emit_s > 0 else None,

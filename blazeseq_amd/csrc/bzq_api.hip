@@ -12,8 +12,8 @@
 #endif
 #if BZQ_EXPERIMENTS
 #include "bzq_single.hpp"   // single-launch variants + first-generation kernels: cross-checks and negative results only
+#include "bzq_stream.hpp"   // k_stream: one read of the input with super-tiles staged in registers (correct, 2x slower: profiles/r2_single_read.md)
 #endif
-#include "bzq_stream.hpp"
 #include "bzq_views.hpp"
 
 #include <algorithm>
@@ -115,7 +115,7 @@ struct bzq_ctx {
     int views_bytes = 0;   // option: views mode through the two-read kernels even without validation (cross-check)
     int force_dense = 0, timing_detail = 0, single_pass = 0, v2 = 1, num_cu = 256;
     bool ran_single_pass = false;
-    int use_stream = 1;        // option "stream": batch mode through the single-read kernel (k_stream); 0 = two-pass kernels
+    int use_stream = 0;        // option "stream" (EXPERIMENTS build): batch mode through the single-read kernel k_stream
     bool ran_stream = false;
     int64_t stream_fallbacks = 0;
     // current chunk
@@ -419,6 +419,7 @@ int enqueue_single(bzq_ctx* c) {
 
 #endif
 
+#if BZQ_EXPERIMENTS
 // Batch mode with one read of the input: one launch of k_stream (bzq_stream.hpp) for the whole chunk.
 template <bool CA, bool CQ>
 void launch_stream_off(const bzq_ctx* c, bool offs, dim3 grid, const StreamArgs& a) {
@@ -428,13 +429,13 @@ void launch_stream_off(const bzq_ctx* c, bool offs, dim3 grid, const StreamArgs&
 int enqueue_stream(bzq_ctx* c) {
     const int64_t nt = tiles_for(c->cur_n);
     const int64_t n_wg = (nt + ST - 1) / ST, n_grp = (n_wg + SGRP - 1) / SGRP;
-    const size_t words = (size_t)n_wg * WD_WORDS + (size_t)n_grp * GD_WORDS;
+    const size_t words = (size_t)n_wg * WD_WORDS + (size_t)n_grp * GD_WORDS + 8;
     int rc;
     if ((rc = ensure(c, c->desc, words * 8))) return rc;
     HIPCHK(c, hipMemsetAsync(c->desc.p, 0, words * 8, c->stream));
     StreamArgs sa{};
     sa.f = make_fused_args(c);
-    sa.wd = (u64*)c->desc.p; sa.gd = sa.wd + (size_t)n_wg * WD_WORDS; sa.n_wg = n_wg;
+    sa.wd = (u64*)c->desc.p; sa.gd = sa.wd + (size_t)n_wg * WD_WORDS; sa.ticket = sa.gd + (size_t)n_grp * GD_WORDS; sa.n_wg = n_wg;
     if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
     const dim3 grid((unsigned)n_wg);
     const bool ca = c->cfg.check_ascii != 0, cq = c->cfg.check_quality != 0, off = c->cfg.emit_offsets != 0;
@@ -448,6 +449,10 @@ int enqueue_stream(bzq_ctx* c) {
     if (le != hipSuccess) { c->err = std::string("kernel launch: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
     return 0;
 }
+
+#else
+int enqueue_stream(bzq_ctx* c) { c->err = "k_stream exists only in an EXPERIMENTS build"; return BZQ_ERR_ARG; }
+#endif
 
 int enqueue_single_launch(bzq_ctx* c) {
 #if BZQ_EXPERIMENTS
@@ -860,7 +865,10 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
         if (!BZQ_EXPERIMENTS && !dflt) { c->err = std::string("option ") + key + " needs a library built with EXPERIMENTS=1"; return BZQ_ERR_ARG; }
         if (!strcmp(key, "single_pass")) c->single_pass = (int)value; else c->v2 = (int)value;
     }
-    else if (!strcmp(key, "stream")) c->use_stream = value != 0;
+    else if (!strcmp(key, "stream")) {
+        if (!BZQ_EXPERIMENTS && value) { c->err = "option stream needs a library built with EXPERIMENTS=1"; return BZQ_ERR_ARG; }
+        c->use_stream = value != 0;
+    }
     else if (!strcmp(key, "stream_fallbacks")) return (int32_t)std::min<int64_t>(c->stream_fallbacks, 0x7FFFFFFF);   // query: chunks repeated on the two-pass kernels
     else if (!strcmp(key, "double_buffer")) {
         if (c->pending) { c->err = "double_buffer cannot change while a chunk is in flight"; return BZQ_ERR_ARG; }

@@ -1,36 +1,41 @@
-// bzq_stream.hpp -- batch mode with ONE read of the input (k_stream): the default FASTQ batch-parse kernel.
+// bzq_stream.hpp -- batch mode with ONE read of the input (k_stream).  EXPERIMENTS build only: correct on the whole parity
+// suite, and 2x SLOWER than the two-pass path on MI355X (4.0 ms vs 1.9 ms per 3.18 GB; profiles/r2_single_read.md has the
+// numbers and the probes).  Kept as the measured answer to "why does batch mode read its input twice".
 //
 // The two-pass path (k_tile_aggregate2 -> tile scan -> k_fused<LB=false>) reads every input byte twice because a tile's
-// output positions depend on everything before it.  Measured on MI355X (profiles/r2_emit_bound.txt, scripts/probes/
-// hop_probe.hip): both passes run at the rate of the XCD <-> memory fabric (~5.6-5.9 TB/s, reads + writes together,
-// Infinity-Cache hits included), so the second read costs its full 0.54 ms; a look-back hop between workgroups costs
-// 1.5-2 us and a wait for ALL earlier contemporaries ~5-6 us (their loads land with that much jitter) -- more than a
-// 16 KiB tile may stay in LDS without halving the tile rate (LDS capacity is what limits tiles in flight: 6 x 27 KiB per
-// CU).  The register file is three times the LDS and two thirds of it were idle (56 VGPRs of 512 / 6 waves).  So:
+// output positions depend on everything before it.  Both passes run at the rate of the XCD <-> memory fabric (~5.6-5.9 TB/s,
+// reads + writes together, Infinity-Cache hits included: profiles/r2_emit_bound.md), so the second read costs its full
+// 0.54 ms.  This kernel removes it:
 //
-//   * a workgroup owns a SUPER-TILE of ST consecutive 16 KiB tiles.  All ST tiles are fetched into registers at once
-//     (16 VGPRs per tile), so 2-3x the bytes are in flight per LDS byte;
+//   * a workgroup owns a SUPER-TILE of ST consecutive 16 KiB tiles, all fetched into registers at once (16 VGPRs per tile:
+//     the register file is three times the LDS and the emit kernel leaves two thirds of it idle), so that more bytes are in
+//     flight per LDS byte while workgroups wait for each other;
 //   * phase A (per tile, no LDS copy of the bytes): newline bitmap -> newline count and line lengths per line CLASS
 //     (line index mod 4: the line phase is not known yet), assuming that no header line loses bytes to _strip_spaces --
 //     "hypothesis H"; the ST summaries are merged and published as three 8-byte {flag, value} granules;
-//   * one decoupled look-back per SUPER-TILE (wave 0): level 1 over the <= 63 earlier workgroups of its group of 64
-//     (one wave-wide sc1 load of their granules), level 2 over the groups before (each group = one 64-byte line holding its
-//     aggregate and, once resolved, its inclusive prefix).  Class-form aggregates are merged with the rotation the line
-//     counts imply, so line phase and the three column offsets come out of the same walk;
+//   * workgroups are numbered by an atomic ticket: blockIdx order is NOT start order across the 8 XCDs (they drift apart by
+//     10-40 us, scripts/probes/order_probe.hip; waiting for a blockIdx predecessor cost 60 us per workgroup);
+//   * one decoupled look-back per SUPER-TILE (wave 0): level 1 over the <= 63 earlier workgroups of its group of 64, level 2
+//     by the group's first workgroup over the groups before (each group = one 64-byte line holding its aggregate and, once
+//     resolved, its inclusive prefix), the other 63 poll that one line.  Class-form aggregates are merged with the rotation
+//     the line counts imply, so line phase and the three column offsets come out of the same walk;
 //   * phase B (per tile, through the ONE 16 KiB LDS buffer of the workgroup): exactly the emit of the two-pass path
 //     (emit_tile below is that code), now with known roles; header lines are measured exactly (header_kept), and if any
 //     of them contradicts hypothesis H the chunk is flagged and the host repeats it on the two-pass kernels.  Only ids with
 //     leading / trailing posix spaces do that (the reference strips them, utils.mojo:221-242; real data has none).
 //
-// Workgroup w waits only on workgroups < w, which the dispatcher started earlier (observed in-order dispatch, not a
-// contract): every spin is bounded and a timeout also falls back to the two-pass kernels.  No atomics on the data path.
+// Why it loses: a workgroup waits 9 us for its group's earlier workgroups (their loads land with that much jitter) and
+// 13 us more for the group prefix; to hide 20+ us of waiting a CU would have to hold ~3x the tiles it can (LDS: 6 x 27 KiB),
+// and staging them in registers means one workgroup works through its tiles one after the other at 16 waves per CU, where
+// every barrier-separated step of the emit is latency-bound (8.5 us per tile instead of 1.5 us of CU time).
+// Every spin is bounded; a timeout also falls back to the two-pass kernels.  No atomics on the data path but the ticket.
 #pragma once
 #include "bzq_fused.hpp"
 
 namespace bzq {
 
 #ifndef BZQ_STREAM_ST
-#define BZQ_STREAM_ST 2
+#define BZQ_STREAM_ST 4
 #endif
 constexpr int ST = BZQ_STREAM_ST;   // 16 KiB tiles per workgroup
 constexpr int SGRP = 64;            // workgroups per look-back group
@@ -42,6 +47,7 @@ struct StreamArgs {
     FusedArgs f;
     u64* wd;          // [n_wg * WD_WORDS], zeroed before the launch
     u64* gd;          // [n_groups * GD_WORDS], zeroed before the launch
+    u64* ticket;      // one word, zeroed before the launch
     int64_t n_wg;
 };
 
@@ -438,7 +444,17 @@ static __global__ __launch_bounds__(BLOCK) void k_stream(StreamArgs sa) {
     const FusedArgs& a = sa.f;
     __shared__ EmitShared sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t w = blockIdx.x;
+    // Which super-tile?  NOT blockIdx: workgroups are handed to the 8 XCDs round-robin (block b runs on XCD b % 8) and every
+    // XCD works through its own blocks in order, but the XCDs drift apart by 10-40 us (scripts/probes/order_probe.hip), so
+    // a workgroup that waits for its blockIdx predecessor waits for another XCD to catch up (measured: 60 us per
+    // workgroup).  A ticket makes the index order the START order on the whole chip: a workgroup only ever waits for
+    // workgroups that started before it.  One returning atomic per super-tile (~40 per us at ST = 4) is below what one
+    // counter sustains (~85 per us; with one 16 KiB tile per workgroup it was the bottleneck).
+    if (tid == 0) sh.bcast[0] = (int64_t)atomicAdd(sa.ticket, 1ull);
+    __syncthreads();
+    const int64_t w = sh.bcast[0];
+    __syncthreads();
+    if (w >= sa.n_wg) return;
     const int64_t tb = w * ST;                      // first tile of this workgroup
     // ---- fetch: all ST tiles into registers
     uint4 r[ST][4];
@@ -471,6 +487,11 @@ static __global__ __launch_bounds__(BLOCK) void k_stream(StreamArgs sa) {
     // ---- publish + look-back (wave 0)
     const int64_t grp = w / SGRP;
     const int gi = (int)(w - grp * SGRP);
+    // EXPERIMENTS build, option ablate bit 64: where does a workgroup's time go (10 ns ticks, one workgroup in 64)?
+    const bool probe = BZQ_ABLATE(64) && tid == 0 && gi == 37;
+    u64 tk0 = 0, tk1 = 0, tk2 = 0, tk3 = 0, pl1 = 0, pl2 = 0;
+    (void)tk3;
+    if (BZQ_ABLATE(64)) tk0 = wall_clock64();
     const bool last_in_group = gi == SGRP - 1 || w == sa.n_wg - 1;
     if (wave == 0) {
         if (lane == 0) {
@@ -485,18 +506,23 @@ static __global__ __launch_bounds__(BLOCK) void k_stream(StreamArgs sa) {
             const int64_t q = grp * SGRP + lane;
             const bool want = lane < gi;
             u64 g0 = 0, g1 = 0, g2 = 0;
+            bool ok = !want;
             int spins = 0;
             for (;;) {
-                if (want) { g0 = ld_agent(&sa.wd[q * WD_WORDS + 0]); g1 = ld_agent(&sa.wd[q * WD_WORDS + 1]); g2 = ld_agent(&sa.wd[q * WD_WORDS + 2]); }
-                const bool ok = !want || (g_set(g0) && g_set(g1) && g_set(g2));
+                if (!ok) {   // only the lanes still waiting load again: polls must not eat the bandwidth the tiles need
+                    g0 = ld_agent(&sa.wd[q * WD_WORDS + 0]); g1 = ld_agent(&sa.wd[q * WD_WORDS + 1]); g2 = ld_agent(&sa.wd[q * WD_WORDS + 2]);
+                    ok = g_set(g0) && g_set(g1) && g_set(g2);
+                }
+                ++pl1;
                 if (__ballot(!ok) == 0) break;
-                __builtin_amdgcn_s_sleep(4);
+                __builtin_amdgcn_s_sleep(32);
                 if (++spins > SPIN_LIMIT) { timeout = true; break; }
             }
             // bytes of workgroup q: full super-tiles except possibly the chunk's last one (which is never a predecessor)
             ClassSum v = want && !timeout ? wd_unpack(g0, g1, g2, (int64_t)ST * TILE) : cs_zero();
             before = wave_merge(v);
         }
+        if (BZQ_ABLATE(64)) tk1 = wall_clock64();
         const ClassSum through = cs_merge(before, mine);   // group start .. end of this workgroup
         if (last_in_group && lane == 0) {
             u64* gd = &sa.gd[grp * GD_WORDS];
@@ -505,10 +531,27 @@ static __global__ __launch_bounds__(BLOCK) void k_stream(StreamArgs sa) {
             st_agent(&gd[2], F_SET | (u64)through.d[0] | ((u64)through.d[1] << 31));
             st_agent(&gd[3], F_SET | (u64)through.d[2] | ((u64)through.d[3] << 31));
         }
-        // level 2: groups before this one, nearest first (lane L <-> group base - L): everything up to the nearest group
-        // whose inclusive prefix is published
+        // level 2: the prefix at the start of this group.  The group's FIRST workgroup resolves it -- it walks the groups
+        // before, nearest first (lane L <-> group base - L), up to the nearest one whose inclusive prefix is published, adding
+        // the aggregates in between -- and publishes it as the inclusive prefix of the previous group; the other 63 workgroups
+        // of the group only poll that one line (a walk by every workgroup cost more fabric requests than the tiles themselves).
         Prefix x{a.st->P0, a.st->S0, a.st->Q0, a.st->I0};   // prefix at the start of this group
-        if (grp > 0 && !timeout) {
+        if (grp > 0 && gi > 0 && !timeout) {
+            const u64* gp = &sa.gd[(grp - 1) * GD_WORDS + 4];
+            u64 v = 0;
+            int spins = 0;
+            for (;;) {
+                if (lane < 4) v = ld_agent(&gp[lane]);
+                ++pl2;
+                if ((__ballot(lane < 4 && g_set(v)) & 0xFull) == 0xFull) break;
+                __builtin_amdgcn_s_sleep(32);
+                if (++spins > SPIN_LIMIT) { timeout = true; break; }
+            }
+            auto lane_val = [&](int l) { return (int64_t)(((u64)(uint32_t)__shfl((int)(uint32_t)v, l, 64)) | ((u64)(uint32_t)__shfl((int)(uint32_t)(v >> 32), l, 64) << 32)); };
+            const u64 vp = (u64)lane_val(0), vs = (u64)lane_val(1), vq = (u64)lane_val(2), vi = (u64)lane_val(3);
+            x.P = (int64_t)g_val(vp) - DESC_BIAS; x.S = (int64_t)g_val(vs) - DESC_BIAS; x.Q = (int64_t)g_val(vq) - DESC_BIAS; x.I = (int64_t)g_val(vi) - DESC_BIAS;
+        }
+        if (grp > 0 && gi == 0 && !timeout) {
             ClassSum run = cs_zero();                      // groups (base, grp) not yet covered by a prefix, merged oldest first
             int64_t base = grp - 1;
             int spins = 0;
@@ -531,7 +574,7 @@ static __global__ __launch_bounds__(BLOCK) void k_stream(StreamArgs sa) {
                 const int f = pm ? __builtin_ctzll(pm) : 64;                 // nearest lane with a prefix
                 const u64 need = f >= 64 ? ~0ull : ((1ull << f) - 1ull);     // nearer lanes must at least have their aggregate
                 if ((am & need) != need) {
-                    __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_s_sleep(32);
                     if (++spins > SPIN_LIMIT) { timeout = true; break; }
                     continue;
                 }
@@ -567,6 +610,11 @@ static __global__ __launch_bounds__(BLOCK) void k_stream(StreamArgs sa) {
                 }
                 base -= 64;
             }
+            if (lane == 0 && !timeout) {   // = the inclusive prefix of the previous group (its last workgroup writes the same values)
+                u64* gd = &sa.gd[(grp - 1) * GD_WORDS];
+                st_agent(&gd[4], F_SET | (u64)(x.P + DESC_BIAS)); st_agent(&gd[5], F_SET | (u64)(x.S + DESC_BIAS));
+                st_agent(&gd[6], F_SET | (u64)(x.Q + DESC_BIAS)); st_agent(&gd[7], F_SET | (u64)(x.I + DESC_BIAS));
+            }
         }
         if (last_in_group && lane == 0 && !timeout) {
             const Prefix e = prefix_advance(x, through);
@@ -575,7 +623,12 @@ static __global__ __launch_bounds__(BLOCK) void k_stream(StreamArgs sa) {
             st_agent(&gd[6], F_SET | (u64)(e.Q + DESC_BIAS)); st_agent(&gd[7], F_SET | (u64)(e.I + DESC_BIAS));
         }
         const Prefix p = prefix_advance(x, before);          // at this workgroup's first byte
+        if (BZQ_ABLATE(64)) tk2 = wall_clock64();
         if (lane == 0) {
+            if (probe) {
+                atomicAdd(&a.st->phase_cycles[0], tk1 - tk0); atomicAdd(&a.st->phase_cycles[1], tk2 - tk1);
+                atomicAdd(&a.st->phase_cycles[4], pl1); atomicAdd(&a.st->phase_cycles[5], pl2); atomicAdd(&a.st->phase_cycles[6], 1ull);
+            }
             sh.bcast[0] = p.P; sh.bcast[1] = p.S; sh.bcast[2] = p.Q; sh.bcast[3] = p.I; sh.bcast[4] = timeout ? 1 : 0;
             if (timeout) a.st->lookback_timeout = 1;
         }
@@ -596,6 +649,7 @@ static __global__ __launch_bounds__(BLOCK) void k_stream(StreamArgs sa) {
         p = prefix_advance(p, cs_from_packed(tc[s], tpa[s], tpd[s]));
         __syncthreads();
     }
+    if (probe) { tk3 = wall_clock64(); atomicAdd(&a.st->phase_cycles[2], tk3 - tk0); }
     if (w == sa.n_wg - 1 && tid == 0 && !dead) { a.st->P = p.P; a.st->S = p.S; a.st->Q = p.Q; a.st->I = p.I; }
     if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
     if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);

@@ -13,10 +13,10 @@ from oracle import oracle as O
 # kernels ("v1") are independent implementations kept as cross-checks in an EXPERIMENTS build (libblazeseq_hip_exp.so):
 # tests/test_gpu_experiments.py re-runs the parity files against that library with BZQ_TEST_EXPERIMENTS=1.
 EXPERIMENTS = os.environ.get("BZQ_TEST_EXPERIMENTS", "0") == "1"
-# False = the product default (batch mode through the single-read kernel k_stream, which itself falls back to the two-pass
-# kernels when an id has leading / trailing spaces); "twopass" = option stream=0: aggregate + scan + emit kernels directly.
-VARIANTS = [False, "twopass"] + ([True, "v1", "svc", "hier"] if EXPERIMENTS else [])
-VARIANTS_LB = [False, "twopass"] + ([True] if EXPERIMENTS else [])
+# "stream" = k_stream (bzq_stream.hpp): one read of the input, super-tiles staged in registers, ticket-ordered class-form
+# look-back; falls back to the two-pass kernels when an id has leading / trailing spaces.  Also EXPERIMENTS only.
+VARIANTS = [False] + ([True, "v1", "svc", "hier", "stream"] if EXPERIMENTS else [])
+VARIANTS_LB = [False] + ([True, "stream"] if EXPERIMENTS else [])
 SHARD_VARIANTS = [False] + ([True, 2, 3] if EXPERIMENTS else [])
 
 
@@ -28,8 +28,8 @@ def make_pair(batch_size=4096, schema="generic", pass_bytes=0, min_record_bytes=
     ctx = B.Context(cfg, schema, batch_size, 0, pass_bytes=pass_bytes, min_record_bytes=min_record_bytes)
     # single_pass: True = one fused launch with in-kernel look-back; False = aggregate + scan + emit
     # (table-driven v2 kernels); "v1" = the first-generation two-pass kernels
-    if single_pass == "twopass":
-        ctx.set_option("stream", 0)
+    if single_pass == "stream":
+        ctx.set_option("stream", 1)
     elif single_pass is not False:
         ctx.set_option("single_pass", {"svc": 2, "hier": 3}.get(single_pass, int(single_pass is True)))
         ctx.set_option("kernels_v2", 0 if single_pass == "v1" else 1)
