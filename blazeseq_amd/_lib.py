@@ -97,6 +97,7 @@ class BzqIngestStats(C.Structure):
     _fields_ = [
         ("file_bytes", C.c_uint64), ("bytes_read", C.c_uint64), ("chunks", C.c_uint64), ("records", C.c_uint64),
         ("read_s", C.c_double), ("wait_s", C.c_double), ("total_s", C.c_double),
+        ("direct_io", C.c_int32), ("numa_node", C.c_int32),
     ]
 
 
@@ -144,6 +145,7 @@ SYMBOLS = {
     "bzq_config_default": (None, [C.POINTER(BzqConfig)]),
     "bzq_schema_from_name": (C.c_int32, [C.c_char_p, C.POINTER(C.c_uint8), C.POINTER(C.c_uint8), C.POINTER(C.c_uint8)]),
     "bzq_message_for_code": (C.c_char_p, [C.c_int32]),
+    "bzq_host_simd_width": (C.c_int32, []),
     "bzq_create": (C.c_int32, [C.c_int32, C.POINTER(BzqConfig), C.POINTER(C.c_void_p)]),
     "bzq_destroy": (None, [C.c_void_p]),
     "bzq_last_error": (C.c_char_p, [C.c_void_p]),
@@ -189,6 +191,7 @@ SYMBOLS = {
     "bzq_release_batch": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch)]),
     "bzq_batch_nw_scores": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.c_char_p, C.c_int32, C.c_void_p]),
     "bzq_batch_quality_sums": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.c_void_p]),
+    "bzq_batch_quality_by_position": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.c_int32, C.POINTER(C.c_uint64)]),
     "bzq_column_histogram": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "bzq_column_gc_counts": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "bzq_fasta_create": (C.c_int32, [C.c_int32, C.POINTER(BzqFastaConfig), C.POINTER(C.c_void_p)]),

@@ -102,7 +102,7 @@ struct bzq_ctx {
     int64_t n_submits = 0;
     int double_buffer = 1;   // option "double_buffer": 0 = one set (results valid until the next submit), half the memory
     hipStream_t consumer_stream = nullptr;   // bzq_set_consumer_stream: where the bzq_batch_* / bzq_column_* kernels run (default: the ctx stream)
-    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, gen_prefix, entries, tile_list, tile_vf;
+    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, qpos_scratch, gen_prefix, entries, tile_list, tile_vf;
     int64_t tile_cap = 0;
     ChunkState* d_state = nullptr;
     ChunkState* h_state = nullptr; // pinned
@@ -115,6 +115,7 @@ struct bzq_ctx {
     int views_bytes = 0;   // option: views mode through the two-read kernels even without validation (cross-check)
     int force_dense = 0, timing_detail = 0, single_pass = 0, v2 = 1, num_cu = 256;
     bool ran_single_pass = false;
+    int ingest_direct = 0, ingest_numa = 1;   // options "ingest_direct" (O_DIRECT reads), "ingest_numa" (bind readers to the GPU's node)
     int use_stream = 0;        // option "stream" (EXPERIMENTS build): batch mode through the single-read kernel k_stream
     bool ran_stream = false;
     int64_t stream_fallbacks = 0;
@@ -754,6 +755,15 @@ int32_t bzq_schema_from_name(const char* name, uint8_t* lower, uint8_t* upper, u
 
 const char* bzq_message_for_code(int32_t code) { return message_for_code(code); }
 
+int32_t bzq_host_simd_width(void) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_cpu_init();
+    if (__builtin_cpu_supports("avx512bw")) return 64;
+    if (__builtin_cpu_supports("avx2")) return 32;
+#endif
+    return 16;
+}
+
 int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
     if (!cfg || !out) return BZQ_ERR_ARG;
     *out = nullptr;
@@ -813,7 +823,7 @@ void bzq_destroy(bzq_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)bzq_comm_destroy(c);
     std::vector<DevBuf*> bufs = {&c->in, &c->tile_c, &c->tile_a, &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc,
-                                 &c->consumer_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf};
+                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf};
     for (OutSet& o : c->out) {
         for (DevBuf* b : {&o.seq, &o.qual, &o.id, &o.ends, &o.id_ends, &o.rec_end, &o.b_ends, &o.b_id_ends, &o.off[0], &o.off[1],
                           &o.off[2], &o.off[3], &o.id_start, &o.id_len})
@@ -870,6 +880,8 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
         c->use_stream = value != 0;
     }
     else if (!strcmp(key, "stream_fallbacks")) return (int32_t)std::min<int64_t>(c->stream_fallbacks, 0x7FFFFFFF);   // query: chunks repeated on the two-pass kernels
+    else if (!strcmp(key, "ingest_direct")) c->ingest_direct = value != 0;
+    else if (!strcmp(key, "ingest_numa")) c->ingest_numa = value != 0;
     else if (!strcmp(key, "double_buffer")) {
         if (c->pending) { c->err = "double_buffer cannot change while a chunk is in flight"; return BZQ_ERR_ARG; }
         c->double_buffer = value != 0;
@@ -1466,8 +1478,37 @@ int32_t bzq_generate_synthetic_device(bzq_ctx* c, int64_t num_reads, int64_t fir
 // ---- host ingest pipeline (bzq_ingest.hpp) ---------------------------------------------------------------------
 
 // shared by the FASTQ and the FASTA ingest: file, pinned + device double buffers, compression sniffing, producer thread
+// CPUs of the NUMA node the GPU hangs off (sysfs), so that the reader threads fill the pinned buffers from the near socket
+static void gpu_numa_cpus(int device, int* node_out, std::vector<int>& cpus) {
+    *node_out = -1;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, sizeof bdf, device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char* p = bdf; *p; ++p) *p = (char)tolower(*p);
+    char path[256];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bdf);
+    FILE* f = fopen(path, "r");
+    int node = -1;
+    if (!f || fscanf(f, "%d", &node) != 1) node = -1;
+    if (f) fclose(f);
+    if (node < 0) return;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return;
+    int a, b;
+    for (;;) {   // "0-31,64-95"
+        if (fscanf(f, "%d", &a) != 1) break;
+        b = a;
+        int ch = fgetc(f);
+        if (ch == '-') { if (fscanf(f, "%d", &b) != 1) break; ch = fgetc(f); }
+        for (int c = a; c <= b; ++c) cpus.push_back(c);
+        if (ch != ',') break;
+    }
+    fclose(f);
+    if (!cpus.empty()) *node_out = node;
+}
+
 static int32_t ingest_open_common(int device, std::string& err, const char* who, const char* path, uint64_t chunk_bytes,
-                                  int32_t n_threads, bzq_ingest** out) {
+                                  int32_t n_threads, bzq_ingest** out, int direct = 0, int numa = 1) {
     *out = nullptr;
     if (hipSetDevice(device) != hipSuccess) { err = std::string(who) + ": hipSetDevice failed"; return BZQ_ERR_HIP; }
     const int fd = open(path, O_RDONLY);
@@ -1485,6 +1526,10 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
     g->n_threads = n_threads > 0 ? n_threads : 8;
     g->t_open = std::chrono::steady_clock::now();
     g->stats.file_bytes = g->file_size;
+    if (direct) g->fd_direct = open(path, O_RDONLY | O_DIRECT);   // refused by some filesystems (tmpfs): reads stay buffered
+    if (numa) gpu_numa_cpus(device, &g->numa_node, g->numa_cpus);
+    g->stats.direct_io = g->fd_direct >= 0 ? 1 : 0;
+    g->stats.numa_node = g->numa_node;
     bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i) {
         ok = hipHostMalloc((void**)&g->slot[i].pinned, g->reserve + g->chunk_bytes, hipHostMallocDefault) == hipSuccess &&
@@ -1545,7 +1590,7 @@ static int ingest_place(bzq_ingest* g, int64_t k, uint64_t carry, hipStream_t qu
 
 int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int32_t n_threads, bzq_ingest** out) {
     if (!c || !path || !out) return BZQ_ERR_ARG;
-    const int32_t rc = ingest_open_common(c->device, c->err, "bzq_ingest_open", path, chunk_bytes, n_threads, out);
+    const int32_t rc = ingest_open_common(c->device, c->err, "bzq_ingest_open", path, chunk_bytes, n_threads, out, c->ingest_direct, c->ingest_numa);
     if (rc == 0) (*out)->ctx = c;
     return rc;
 }
@@ -1851,6 +1896,24 @@ int32_t bzq_column_gc_counts(bzq_ctx* c, const uint8_t* d_col, const int64_t* d_
                            n, col_len, 0, d_counts);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->err = std::string("k_quality_sums<GC>: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
+    HIPCHK(c, hipStreamSynchronize(cs));
+    return 0;
+}
+
+int32_t bzq_batch_quality_by_position(bzq_ctx* c, const bzq_device_batch* b, int32_t max_positions, uint64_t* counts) {
+    if (!c || !b || max_positions <= 0 || !counts) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t cs = c->consumer_stream ? c->consumer_stream : c->stream;
+    const size_t bytes = (size_t)max_positions * QP_BINS * 8;
+    int rc;
+    if ((rc = ensure(c, c->qpos_scratch, bytes))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->qpos_scratch.p, 0, bytes, cs));
+    if (b->num_records > 0) {
+        const dim3 grid((unsigned)((max_positions + QP_POS - 1) / QP_POS), (unsigned)((b->num_records + QP_RECS - 1) / QP_RECS));
+        hipLaunchKernelGGL(k_quality_by_position, grid, dim3(BLOCK), 0, cs, b->qual_buffer, b->ends, b->num_records, (int)max_positions,
+                           (u64*)c->qpos_scratch.p);
+    }
+    HIPCHK(c, hipMemcpyAsync(counts, c->qpos_scratch.p, bytes, hipMemcpyDeviceToHost, cs));
     HIPCHK(c, hipStreamSynchronize(cs));
     return 0;
 }

@@ -229,4 +229,35 @@ static __global__ __launch_bounds__(BLOCK) void k_byte_histogram(const uint8_t* 
     if (t) atomicAdd(&hist[tid], (u64)t);
 }
 
+// Quality distribution per READ POSITION (cycle): counts[p][v] = number of records whose quality byte at position p is v
+// (the per-base quality plot of every FASTQ QC tool; the v0.1 `quality_distribution` example / quality prefix-sum kernel of
+// the reference, CHANGELOG.md:73, on the DeviceFastqBatch layout).  A workgroup takes 64 consecutive positions and a block of
+// records: lane = position, so a wave reads 64 contiguous quality bytes of one record per step (coalesced) and every lane
+// adds into ITS OWN row of an LDS table -- rows are 129 words apart, which puts equal values of different lanes into different
+// banks.  Bytes >= 128 count in bin 127.  One flush of the table per workgroup (global atomics on 64 x 128 counters).
+constexpr int QP_POS = 64, QP_BINS = 128, QP_RECS = 2048;
+static __global__ __launch_bounds__(BLOCK) void k_quality_by_position(const uint8_t* __restrict__ qual, const int64_t* __restrict__ ends,
+                                                                      int64_t num_records, int max_pos, u64* __restrict__ counts) {
+    __shared__ uint32_t s_h[QP_POS][QP_BINS + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < QP_POS * (QP_BINS + 1); i += BLOCK) (&s_h[0][0])[i] = 0u;
+    __syncthreads();
+    const int p = (int)blockIdx.x * QP_POS + lane;
+    const int64_t r0 = (int64_t)blockIdx.y * QP_RECS, r1 = r0 + QP_RECS < num_records ? r0 + QP_RECS : num_records;
+    for (int64_t r = r0 + wave; r < r1; r += BLOCK / 64) {
+        const int64_t q0 = r ? ends[r - 1] : 0, q1 = ends[r];
+        if (p < max_pos && q0 + p < q1) {
+            const uint32_t v = qual[q0 + p];
+            atomicAdd(&s_h[lane][v < 128u ? v : 127u], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < QP_POS * QP_BINS; i += BLOCK) {
+        const int row = i / QP_BINS, bin = i % QP_BINS;
+        const uint32_t t = s_h[row][bin];
+        const int pp = (int)blockIdx.x * QP_POS + row;
+        if (t && pp < max_pos) atomicAdd(&counts[(int64_t)pp * QP_BINS + bin], (u64)t);
+    }
+}
+
 } // namespace bzq

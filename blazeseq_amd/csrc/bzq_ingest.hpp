@@ -14,7 +14,9 @@
 #include <mutex>
 #include <thread>
 
+#include <errno.h>
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -36,6 +38,9 @@ struct bzq_ingest {
     bzq_ctx* ctx = nullptr;
     int device = 0;                // copied at open: close must not look at a ctx that may already be gone
     int fd = -1;
+    int fd_direct = -1;            // the same file opened O_DIRECT (option "ingest_direct"): reads bypass the page cache
+    int numa_node = -1;            // NUMA node of the GPU (reader threads are bound to its CPUs), -1 = unknown
+    std::vector<int> numa_cpus;
     uint64_t file_size = 0, chunk_bytes = 0, reserve = 0;
     int n_threads = 4;
     // compressed input (the reference's GZFile / RapidgzipReader, io/readers.mojo:283-443): 0 plain, 1 gzip stream
@@ -76,21 +81,45 @@ inline double seconds_since(std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
-// Fill dst[0, len) from the file at off with n_threads pread() workers (slices of >= 8 MiB).
-inline bool parallel_pread(int fd, uint8_t* dst, uint64_t off, uint64_t len, int n_threads, std::string& err) {
+// bind the calling thread to the CPUs of the GPU's NUMA node (the pinned buffers live there; best effort)
+inline void bind_to_cpus(const std::vector<int>& cpus) {
+    if (cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : cpus) if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+    (void)sched_setaffinity(0, sizeof(set), &set);
+}
+
+// Fill dst[0, len) from the file at off with n_threads pread() workers (slices of >= 8 MiB, 4 KiB aligned).  fd_direct >= 0:
+// whole 4 KiB blocks are read O_DIRECT (no page-cache copy: storage DMA lands in the pinned buffer, which is page aligned and
+// has room up to the next block boundary); a filesystem that refuses O_DIRECT reads (EINVAL) gets buffered reads instead.
+inline bool parallel_pread(int fd, uint8_t* dst, uint64_t off, uint64_t len, int n_threads, std::string& err, int fd_direct = -1,
+                           const std::vector<int>* cpus = nullptr) {
     if (len == 0) return true;
     const uint64_t min_slice = 8ull << 20;
     int nt = (int)std::min<uint64_t>((uint64_t)std::max(1, n_threads), (len + min_slice - 1) / min_slice);
     std::atomic<bool> ok{true};
+    const bool direct_ok = fd_direct >= 0 && (off & 4095u) == 0 && ((uintptr_t)dst & 4095u) == 0;
     auto work = [&](uint64_t a, uint64_t b) {
+        if (cpus) bind_to_cpus(*cpus);
+        bool direct = direct_ok;
         while (a < b) {
-            const ssize_t r = pread(fd, dst + a, (size_t)std::min<uint64_t>(b - a, 1ull << 30), (off_t)(off + a));
+            ssize_t r;
+            if (direct) {   // length rounded up to whole blocks: a read that reaches EOF just returns fewer bytes
+                const uint64_t want = (std::min<uint64_t>(b - a, 1ull << 30) + 4095u) & ~4095ull;
+                r = pread(fd_direct, dst + a, (size_t)want, (off_t)(off + a));
+                if (r < 0 && errno == EINVAL) { direct = false; continue; }
+                if (r > (ssize_t)(b - a)) r = (ssize_t)(b - a);
+            } else {
+                r = pread(fd, dst + a, (size_t)std::min<uint64_t>(b - a, 1ull << 30), (off_t)(off + a));
+            }
             if (r <= 0) { ok = false; return; }
             a += (uint64_t)r;
+            if (direct && (a & 4095u)) direct = false;   // short read: finish the tail buffered
         }
     };
     std::vector<std::thread> th;
-    const uint64_t per = (len + nt - 1) / nt;
+    const uint64_t per = (((len + nt - 1) / nt) + 4095u) & ~4095ull;
     for (int i = 1; i < nt; ++i) th.emplace_back(work, std::min(len, per * i), std::min(len, per * (i + 1)));
     work(0, std::min(len, per));
     for (auto& t : th) t.join();
@@ -201,6 +230,7 @@ inline void ingest_producer(bzq_ingest* g) {
         g->cv.notify_all();
     };
     hipError_t he;
+    bind_to_cpus(g->numa_cpus);
     if ((he = hipSetDevice(g->device)) != hipSuccess) return fail("reader: hipSetDevice", he);
     uint64_t off = 0;   // offset in the (decompressed) stream
     for (int64_t k = 0;; ++k) {
@@ -217,7 +247,7 @@ inline void ingest_producer(bzq_ingest* g) {
         std::string err;
         if (g->compression == 0) {
             len = std::min<uint64_t>(g->chunk_bytes, g->file_size - off);
-            ok = parallel_pread(g->fd, s.pinned + g->reserve, off, len, g->n_threads, err);
+            ok = parallel_pread(g->fd, s.pinned + g->reserve, off, len, g->n_threads, err, g->fd_direct, &g->numa_cpus);
             eof = off + len >= g->file_size;
         } else {
             ok = read_compressed_chunk(g, s.pinned + g->reserve, g->chunk_bytes, &len, &eof, err);
@@ -271,6 +301,7 @@ inline void ingest_free(bzq_ingest* g) {
     }
     if (g->gz) gzclose(g->gz);
     if (g->fd >= 0) close(g->fd);
+    if (g->fd_direct >= 0) close(g->fd_direct);
     delete g;
 }
 

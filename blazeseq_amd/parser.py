@@ -65,7 +65,8 @@ class ParserConfig:
     check_ascii: bool = False
     check_quality: bool = False
     quality_schema: Optional[str] = None
-    compat_simd_width: int = 0     # reproduce the host-SIMD-width quirk of the quality check
+    compat_simd_width: int = 0     # reproduce the host-SIMD-width quirk of the quality check (16 / 32 / 64);
+                                   # -1 = this host's width (bzq_host_simd_width): bit-exact with the reference binary run here
     emit_offsets: bool = False     # also materialise the RecordOffsets columns
     views_only: bool = False       # views() mode: no columns, records as offsets + id spans into the chunk
 
@@ -144,7 +145,7 @@ class Context:
         name = self.config.quality_schema if self.config.quality_schema else schema
         c.q_lower, c.q_upper, c.q_offset, _ = quality_schema(name)
         c.batch_size = batch_size
-        c.compat_simd_width = self.config.compat_simd_width
+        c.compat_simd_width = lib.bzq_host_simd_width() if self.config.compat_simd_width < 0 else self.config.compat_simd_width
         c.emit_offsets = int(self.config.emit_offsets)
         c.views_only = int(self.config.views_only)
         c.pass_bytes = pass_bytes
@@ -364,6 +365,13 @@ class DeviceFastqBatch:
         """Per-record sum of Phred scores into device int64[num_records] (asynchronous on the ctx stream)."""
         _check(self._ctx.h, L.lib().bzq_batch_quality_sums(self._ctx.h, C.byref(self.raw), C.c_void_p(d_sums)),
                "bzq_batch_quality_sums")
+
+    def quality_by_position(self, max_positions: int) -> np.ndarray:
+        """counts[p, v]: records whose quality byte at read position p is v (uint64 [max_positions, 128])."""
+        out = np.zeros((int(max_positions), 128), dtype=np.uint64)
+        _check(self._ctx.h, L.lib().bzq_batch_quality_by_position(self._ctx.h, C.byref(self.raw), int(max_positions),
+                                                                  out.ctypes.data_as(C.POINTER(C.c_uint64))), "bzq_batch_quality_by_position")
+        return out
 
     def histogram(self, column: str = "sequence") -> np.ndarray:
         """256-bin byte histogram of the sequence or quality column of this batch."""

@@ -185,6 +185,10 @@ void bzq_config_default(bzq_config* cfg);
 /* _parse_schema, blazeseq/utils.mojo:612-637.  Returns 1 for a known name, 0 when it fell back to
  * generic (the reference prints a warning and continues). */
 int32_t bzq_schema_from_name(const char* name, uint8_t* lower, uint8_t* upper, uint8_t* offset);
+/* What `simd_width_of[DType.uint8]()` is on THIS host (64 with AVX-512BW, 32 with AVX2, else 16): the W of the reference's
+ * SIMD quality check (record.mojo:76-104).  A host that wants to be bit-exact with the reference BINARY running on the same
+ * machine passes it as bzq_config.compat_simd_width; the library default 0 keeps the documented inclusive bounds. */
+int32_t bzq_host_simd_width(void);
 /* FastxErrorCode.message(), blazeseq/errors.mojo:71-90 */
 const char* bzq_message_for_code(int32_t code);
 
@@ -352,9 +356,14 @@ typedef struct bzq_ingest_stats {
     double read_s;         /* producer: seconds inside pread() */
     double wait_s;         /* consumer: seconds inside bzq_ingest_next (waiting for H2D + kernels) */
     double total_s;        /* open -> most recent bzq_ingest_next */
+    int32_t direct_io;     /* 1: the file is read O_DIRECT (option "ingest_direct" and the filesystem allows it) */
+    int32_t numa_node;     /* NUMA node of the GPU the reader threads are bound to, -1 = unknown / not bound */
 } bzq_ingest_stats;
 
-/* chunk_bytes 0 = 256 MiB; n_threads <= 0 = 8.  The ctx must outlive the ingest and is used by it. */
+/* chunk_bytes 0 = 256 MiB; n_threads <= 0 = 8.  The ctx must outlive the ingest and is used by it.  Options of the ctx read
+ * at open: "ingest_direct" = 1: O_DIRECT reads of whole 4 KiB blocks straight into the pinned buffers (files that are not in
+ * the page cache; a filesystem that refuses O_DIRECT is read buffered); "ingest_numa" (default 1): the reader threads run on
+ * the CPUs of the GPU's NUMA node. */
 int32_t bzq_ingest_open(bzq_ctx* ctx, const char* path, uint64_t chunk_bytes, int32_t n_threads, bzq_ingest** out);
 /* Parse the next chunk.  records_taken: how many records of the PREVIOUS chunk the caller consumed (ignored on the
  * first call); the remaining records and the bytes behind them are carried in front of this chunk.  Returns like
@@ -386,6 +395,12 @@ int32_t bzq_batch_nw_scores(bzq_ctx* ctx, const bzq_device_batch* b, const uint8
  * the v0.1 "quality prefix-sum kernel", CHANGELOG.md:73).  d_sums: device int64[num_records].  Asynchronous on the
  * ctx stream. */
 int32_t bzq_batch_quality_sums(bzq_ctx* ctx, const bzq_device_batch* b, int64_t* d_sums);
+/* Quality distribution per read position (the per-base quality plot; the v0.1 `quality_distribution` example and quality
+ * prefix-sum kernel, CHANGELOG.md:73): counts[p * 128 + v] = number of records of the batch whose quality byte at position p
+ * (0-based, p < max_positions) equals v (bytes >= 128 count as 127).  counts: host uint64[max_positions * 128].  From it
+ * follow the per-position mean / quantiles of Phred (v - quality_offset) and the read-length distribution
+ * (records reaching position p = sum over v).  Synchronous. */
+int32_t bzq_batch_quality_by_position(bzq_ctx* ctx, const bzq_device_batch* b, int32_t max_positions, uint64_t* counts);
 /* 256-bin byte histogram of a device column (base composition of sequence_buffer, quality distribution of
  * qual_buffer; the v0.1 quality_distribution example, CHANGELOG.md:73).  hist: host uint64[256]. */
 int32_t bzq_column_histogram(bzq_ctx* ctx, const uint8_t* d_col, uint64_t n, uint64_t* hist);

@@ -87,3 +87,16 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"(from|import)\s+oracle|bzq_oracle|libbzq_oracle|orc_[a-z_]+\(", text):
                     bad.append(os.path.join(dirpath, fn))
     assert not bad, bad
+
+
+def test_host_simd_width_is_one_of_the_reference_widths():
+    """bzq_host_simd_width = simd_width_of[DType.uint8]() of this host: what the Mojo shim passes as compat_simd_width to be
+    bit-exact with the reference binary on the same machine (record.mojo:76-104)."""
+    from blazeseq_amd import _lib
+    w = _lib.lib().bzq_host_simd_width()
+    assert w in (16, 32, 64)
+    flags = open("/proc/cpuinfo").read() if os.path.exists("/proc/cpuinfo") else ""
+    if " avx512bw" in flags:
+        assert w == 64
+    elif " avx2" in flags:
+        assert w == 32

@@ -123,3 +123,27 @@ def test_gc_counts_per_record_on_fastq_and_fasta_columns():
     assert np.array_equal(out.cpu().numpy(), gc_of(w.seq_bytes, w.seq_ends))
     fa.close()
     ctx.close()
+
+
+def test_quality_distribution_per_read_position():
+    """counts[p, v] against numpy on variable-length reads (lengths 1..240 and a few empty), positions beyond max_positions
+    ignored, every record's byte at every position counted exactly once."""
+    import blazeseq_amd as B
+    rng = np.random.default_rng(11)
+    recs, quals = [], []
+    for i in range(9000):
+        L = int(rng.integers(0, 241)) if i % 50 else 0
+        q = bytes(rng.integers(33, 127, L).astype(np.uint8))
+        quals.append(q)
+        recs.append(b"@r%d\n" % i + b"A" * L + b"\n+\n" + q + b"\n")
+    p = B.FastqParser(b"".join(recs), batch_size=len(recs))
+    b = p.next_batch(len(recs))
+    d = b.to_device()
+    for max_pos in (1, 64, 100, 240, 300):
+        got = d.quality_by_position(max_pos)
+        want = np.zeros((max_pos, 128), dtype=np.uint64)
+        for q in quals:
+            a = np.frombuffer(q, dtype=np.uint8)[:max_pos]
+            np.add.at(want, (np.arange(a.size), a), 1)
+        np.testing.assert_array_equal(got, want)
+    assert int(d.quality_by_position(240).sum()) == sum(len(q) for q in quals)

@@ -241,3 +241,36 @@ def test_tail_of_a_multi_chunk_stream_is_judged_with_the_reference_window(source
         assert gerr == werr, (seed, gerr, werr)
         classes.add(werr[0] if werr else 0)
     assert len(classes) >= 3, classes                          # accepted, refused (BUFFER_EXCEEDED) and UNEXPECTED_EOF all met
+
+
+@pytest.mark.parametrize("chunk", [1 << 16, 1 << 20])
+def test_o_direct_reads_give_the_same_stream(chunk, tmp_path):
+    """Option "ingest_direct": whole 4 KiB blocks read O_DIRECT into the pinned buffers, the tail and
+    filesystems without O_DIRECT buffered.  Same records either way; the stats say which path the file took."""
+    import blazeseq_amd as B
+    data = O.generate_synthetic(40_000, 30, 170, 0, 40, "sanger")   # size not a multiple of 4096
+    assert data.size % 4096
+    path = tmp_path / "direct.fastq"
+    path.write_bytes(bytes(data))
+    f = O.flat_parse(data, O.make_config())
+    outs = []
+    for direct in (0, 1):
+        ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
+        ctx.set_option("ingest_direct", direct)
+        ing = B.Ingest(ctx, str(path), chunk, 3)
+        seqs, n, taken = [], 0, 0
+        while True:
+            res = ing.next(taken)
+            taken = int(res.n_records)
+            n += taken
+            seqs.append(res.seq().tobytes())
+            if res.status != 0:
+                assert res.status == 6
+                break
+        st = ing.stats()
+        assert st.direct_io in (0, 1) and (direct or st.direct_io == 0) and int(st.bytes_read) == data.size
+        outs.append((n, b"".join(seqs), int(st.direct_io), int(st.numa_node)))
+        ing.close(); ctx.close()
+    assert outs[0][0] == outs[1][0] == f.n_records
+    assert outs[0][1] == outs[1][1] == f.seq_bytes.tobytes()
+    print("direct_io:", outs[1][2], "numa node:", outs[1][3])
