@@ -348,6 +348,9 @@ void launch_fused(const bzq_ctx* c, dim3 grid, const FusedArgs& f) {
     else if (cq) launch_fused_off<false, true, LB>(c, off, grid, f);
     else launch_fused_off<false, false, LB>(c, off, grid, f);
 }
+// how far header_kept may walk outside its tile: the longest record the reference's buffer can hold
+int64_t walk_limit_of(const bzq_ctx* c) { return c->cfg.buffer_growth_enabled ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity; }
+
 FusedArgs make_fused_args(bzq_ctx* c) {
     FusedArgs f{};
     f.g = c->cur; f.n = (int64_t)c->cur_n; f.prev_byte = c->cur_prev_byte; f.n_tiles = tiles_for(c->cur_n);
@@ -359,6 +362,7 @@ FusedArgs make_fused_args(bzq_ctx* c) {
     f.o_hdr = (int64_t*)c->o().off[0].p; f.o_seq = (int64_t*)c->o().off[1].p;
     f.o_sep = (int64_t*)c->o().off[2].p; f.o_qual = (int64_t*)c->o().off[3].p;
     f.st = c->d_state; f.q_lower = c->cfg.q_lower; f.q_upper = c->cfg.q_upper; f.force_dense = c->force_dense; f.ablate = c->ablate;
+    f.walk_limit = walk_limit_of(c);
     return f;
 }
 
@@ -519,7 +523,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
         // shard whose aggregates exist already (bzq_shard_scan): only tile 0 (prev byte now known)
         // and the tiles touched by the appended halo change
         AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, 0, 1, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
-                  (u64*)c->tile_idc.p};
+                  (u64*)c->tile_idc.p, walk_limit_of(c)};
         hipLaunchKernelGGL(k_tile_aggregate2, dim3(1), dim3(BLOCK), 0, c->stream, a);
         const int64_t tb = std::max<int64_t>(1, (int64_t)(c->agg_n / TILE));
         if (tb < nt) {
@@ -534,7 +538,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
             if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
             if (!skip_aggregate_mid) {
                 AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p,
-                          (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
+                          (u64*)c->tile_a.p, (u64*)c->tile_idc.p, walk_limit_of(c)};
                 if (views_meta(c)) {
                     LineArgs la{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
                                 (u64*)c->tile_idc.p, (uint32_t*)c->entries.p, (uint32_t*)c->tile_list.p, c->pool_slots, c->d_state,
@@ -1351,7 +1355,7 @@ static int shard_scan_enqueue(bzq_ctx* c, const uint8_t* d_data, uint64_t n) {
     if (n > 0) {
         HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
         const int64_t nt = tiles_for(n);
-        AggArgs a{d_data, (int64_t)n, 10u, 0, nt, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p, (u64*)c->tile_idc.p};
+        AggArgs a{d_data, (int64_t)n, 10u, 0, nt, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p, (u64*)c->tile_idc.p, walk_limit_of(c)};
         hipLaunchKernelGGL(k_tile_aggregate2, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
         launch_scan(c, 0, nt, 0);
         hipLaunchKernelGGL(k_first_newlines, dim3(1), dim3(BLOCK), 0, c->stream, d_data, (int64_t)n, c->d_state);

@@ -143,6 +143,10 @@ struct ByteSrc {
     const uint8_t* lds; // this tile staged in LDS (bytes [t0, t0+valid)), or nullptr
     int64_t t0;
     int valid;
+    // header_kept never walks further than this from the tile: a space run longer than the reference's buffer limit lies in
+    // a record the reference refuses (BUFFER_EXCEEDED / AT_MAX, caught by the length check in k_rebase) -- none of its bytes
+    // is delivered, so any answer will do as long as both passes give the same one
+    int64_t walk_limit = (int64_t)1 << 62;
     __device__ __forceinline__ uint32_t at(int64_t pos) const {
         const int64_t d = pos - t0;
         if (lds && d >= 0 && d < valid) return lds[d];
@@ -170,6 +174,7 @@ __device__ inline void header_kept(const ByteSrc& b, int64_t ls, int64_t le, boo
         int64_t p = ls - 1;
         in_lead = false;
         for (;;) {
+            if (ls - p > b.walk_limit) break;                    // see ByteSrc::walk_limit
             uint32_t c = b.at(p);
             if (c == 10u) { in_lead = true; break; }           // p+1 was header_start and a space
             if (!is_posix_space(c)) {                            // non-space: only fine at header_start
@@ -187,7 +192,7 @@ __device__ inline void header_kept(const ByteSrc& b, int64_t ls, int64_t le, boo
             // the line continues past this tile: trailing run only if everything up to '\n' is space
             int64_t p = tile_end;
             trailing = false;
-            while (p < b.n) {
+            while (p < b.n && p - tile_end <= b.walk_limit) {
                 uint32_t c = b.at(p);
                 if (c == 10u) { trailing = true; break; }
                 if (!is_posix_space(c)) break;
@@ -340,6 +345,7 @@ struct AggArgs {
     uint32_t* tile_c;   // newlines per tile
     u64* tile_a;        // 4 x u16: non-newline bytes per line class (local line index & 3)
     u64* tile_idc;      // 4 x u16: id bytes per class if that class were the header role
+    int64_t walk_limit; // ByteSrc::walk_limit (0 = none)
 };
 
 #if BZQ_EXPERIMENTS

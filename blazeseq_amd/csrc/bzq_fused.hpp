@@ -67,6 +67,7 @@ struct FusedArgs {
     ChunkState* st;
     uint32_t q_lower, q_upper;
     int32_t force_dense;
+    int64_t walk_limit;   // ByteSrc::walk_limit (0 = none)
     int32_t ablate;   // timing experiments, compiled in only with -DBZQ_EXPERIMENTS=1 (make EXPERIMENTS=1): see BZQ_ABLATE uses
 };
 
@@ -289,6 +290,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     const bool first_starts = prevb == 10u;
     tile_stage<true>(r, valid, s_mask, s_tile);   // r[] also stays in registers for the scatter
     ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
+    if (a.walk_limit > 0) bs.walk_limit = a.walk_limit;
     __syncthreads();
     phase_mark(0);   // tile loaded, masks built, staged
     if (!LB && BZQ_ABLATE(128)) return;   // experiment: stop here
@@ -619,6 +621,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
     tile_fetch(a.g, a.n, t0, valid, r);
     tile_stage<true>(r, valid, s_mask, s_tile);
     ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
+    if (a.walk_limit > 0) bs.walk_limit = a.walk_limit;
     const bool first_starts = (prev_b == 10u);
     __syncthreads();
     const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);

@@ -109,6 +109,7 @@ __device__ __forceinline__ void emit_tile(const FusedArgs& a, EmitShared& sh, in
     const bool first_starts = prevb == 10u;
     tile_stage<true>(r, valid, sh.mask, s_tile);
     ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
+    if (a.walk_limit > 0) bs.walk_limit = a.walk_limit;
     __syncthreads();
     const u64* s_mask64 = reinterpret_cast<const u64*>(sh.mask);
     const u64 m64 = s_mask64[tid];
