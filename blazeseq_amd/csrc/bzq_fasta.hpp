@@ -64,8 +64,10 @@ __device__ __forceinline__ uint32_t space_flags(uint32_t x) {
                    ge32 = t + 0x60606060u, ge33 = t + 0x5F5F5F5Fu;
     return ((ge9 & ~ge14) | (ge28 & ~ge31) | (ge32 & ~ge33)) & ~x & 0x80808080u;
 }
-// 0x80 in every byte <= 32
-__device__ __forceinline__ uint32_t le32_flags(uint32_t x) { return ~(x | ((x & 0x7F7F7F7Fu) + 0x5F5F5F5Fu)) & 0x80808080u; }
+// 0x80 in every byte <= 32 (bytes >= 0x80 never flagged).  Two instructions (v_sub + v_bfi-like and-not) and conservative: the
+// borrow of a byte below 0x21 may also flag a 0x21 right above it -- callers only use it to decide whether the exact
+// classification is needed, so a false positive costs time, never a result.
+__device__ __forceinline__ uint32_t le32_flags(uint32_t x) { return (x - 0x21212121u) & ~x & 0x80808080u; }
 // 16-bit mask of the bytes equal to B (the v_perm/v_dot4 idiom of nl_mask16, bzq_device.hpp)
 template <uint32_t B>
 __device__ __forceinline__ uint32_t eq_mask16(uint4 v) {
@@ -78,7 +80,7 @@ __device__ __forceinline__ uint32_t eq_mask16(uint4 v) {
     return (((uint32_t)hi << 8) | (uint32_t)lo) ^ 0x8080u;
 }
 // ---- tile front end: bytes -> per-thread 64-bit masks of the thread's 64 contiguous bytes --------------------------
-struct Masks { u64 N, X, G, H; };
+struct Masks { u64 N, X, H; };   // '>' is looked up only where a line's first X sits (line_facts)
 
 // newline mask and X (= not a posix space) mask of one 16-byte piece.  Almost every piece has no byte <= 32 other than
 // its newlines: then X = ~N and the exact classification (13 ops per dword) is skipped for the whole wave.
@@ -97,7 +99,7 @@ __device__ __forceinline__ void piece_nx(const uint4 v, uint32_t& n, uint32_t& x
 }
 
 template <bool ASCII, bool STAGE>
-__device__ __forceinline__ void tile_masks(const uint4 (&r)[4], int valid, uint16_t* s_n, uint16_t* s_x, uint16_t* s_g,
+__device__ __forceinline__ void tile_masks(const uint4 (&r)[4], int valid, uint16_t* s_n, uint16_t* s_x,
                                            uint16_t* s_h, uint8_t* s_tile) {
     const int tid = threadIdx.x;
 #pragma unroll
@@ -106,14 +108,13 @@ __device__ __forceinline__ void tile_masks(const uint4 (&r)[4], int valid, uint1
         const uint4 v = r[s];
         uint32_t n, x;
         piece_nx(v, n, x);
-        uint32_t g = eq_mask16<62u>(v);
         uint32_t h = ASCII ? flag_mask16(v.x & 0x80808080u, v.y & 0x80808080u, v.z & 0x80808080u, v.w & 0x80808080u) : 0u;
         if (valid != TILE) {
             const int rem = valid - q * 16;
             const uint32_t keep = rem >= 16 ? 0xFFFFu : (rem > 0 ? ((1u << rem) - 1u) : 0u);
-            n &= keep; g &= keep; x &= keep; h &= keep;
+            n &= keep; x &= keep; h &= keep;
         }
-        s_n[q] = (uint16_t)n; s_x[q] = (uint16_t)x; s_g[q] = (uint16_t)g;
+        s_n[q] = (uint16_t)n; s_x[q] = (uint16_t)x;
         if (ASCII) s_h[q] = (uint16_t)h;
         if (STAGE) *reinterpret_cast<uint4*>(s_tile + q * 16) = v;
     }
@@ -140,20 +141,19 @@ __device__ __forceinline__ void tile_to_own(const uint4 (&r)[4], uint8_t* s_tile
 
 template <bool ASCII>
 __device__ __forceinline__ Masks own_masks(const uint4 (&own)[4], int valid) {
-    Masks m{0, 0, 0, 0};
+    Masks m{0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint4 v = own[k];
         uint32_t n, x;
         piece_nx(v, n, x);
-        const uint32_t g = eq_mask16<62u>(v);
-        m.N |= (u64)n << (16 * k); m.X |= (u64)x << (16 * k); m.G |= (u64)g << (16 * k);
+        m.N |= (u64)n << (16 * k); m.X |= (u64)x << (16 * k);
         if (ASCII) m.H |= (u64)flag_mask16(v.x & 0x80808080u, v.y & 0x80808080u, v.z & 0x80808080u, v.w & 0x80808080u) << (16 * k);
     }
     if (valid != TILE) {   // the last tile: bytes at or beyond the end of the chunk are nothing
         const int rem = valid - (int)threadIdx.x * 64;
         const u64 keep = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull);
-        m.N &= keep; m.X &= keep; m.G &= keep; m.H &= keep;
+        m.N &= keep; m.X &= keep; m.H &= keep;
     }
     return m;
 }
@@ -161,8 +161,10 @@ __device__ __forceinline__ Masks own_masks(const uint4 (&own)[4], int valid) {
 // The four facts for this thread's 64 bytes.  cin_* are the tile-level carries (pass 1: all zero).
 struct Facts { u64 seq, id, FG, Sb_incl, Sa_incl; uint32_t end_sb, end_hdr, end_x2; };
 
+// byte_at(p): byte p (0..63) of this thread's 64 bytes, from LDS
+template <typename ByteAt>
 __device__ __forceinline__ Facts line_facts(const Masks& m, uint32_t cin_sb, uint32_t cin_hdr, uint32_t cin_x2, uint32_t cin_sa,
-                                            uint32_t (*s_slot)[BLOCK / 64]) {
+                                            uint32_t (*s_slot)[BLOCK / 64], ByteAt&& byte_at) {
     // round 1: Sb forwards, Sa backwards
     const WaveChain wb = chain_wave<false>(m.X, m.N, s_slot[0]);
     const WaveChain wa = chain_wave<true>(m.X, m.N, s_slot[1]);
@@ -170,8 +172,15 @@ __device__ __forceinline__ Facts line_facts(const Masks& m, uint32_t cin_sb, uin
     const Chain sb = chain64(m.X, m.N, chain_cin<false>(wb, s_slot[0], cin_sb));
     const Chain sa = chain64_rev(m.X, m.N, chain_cin<true>(wa, s_slot[1], cin_sa));
     const u64 F = m.X & ~sb.excl;   // a line's first X
+    // '>' matters only at a line's first X: one LDS byte per line instead of an equality mask over every byte
+    u64 FG = 0;
+    for (u64 ff = F; ff;) {
+        const int p = __builtin_ctzll(ff);
+        ff &= ff - 1;
+        if (byte_at(p) == 62u) FG |= 1ull << p;
+    }
     // round 2: hdr is decided at F; X2 is set by every other X
-    const u64 hs = F & m.G, hc = (F & ~m.G) | m.N, xs = m.X & ~F;
+    const u64 hs = FG, hc = (F & ~FG) | m.N, xs = m.X & ~F;
     const WaveChain wh = chain_wave<false>(hs, hc, s_slot[2]);
     const WaveChain wx = chain_wave<false>(xs, m.N, s_slot[3]);
     __syncthreads();
@@ -213,7 +222,8 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_tile_sums(SumsArgs a) {
     const u64 E = m.N | m.X;
     const u64 bN = __ballot(m.N != 0), bE = __ballot(E != 0);
     if (lane == 0) { s_hasN[wave] = bN; s_hasE[wave] = bE; }
-    const Facts f = line_facts(m, 0u, 0u, 0u, 0u, s_slot);   // (its barriers also publish s_hasN / s_hasE)
+    const int pos_own = tid * 64;
+    const Facts f = line_facts(m, 0u, 0u, 0u, 0u, s_slot, [&](int p) { return (uint32_t)s_tile[lds_at(pos_own + p)]; });   // (its barriers also publish s_hasN / s_hasE)
     // bytes before the first '\n' of the tile, after its last '\n', after its last event
     const u64 below = lane ? (~0ull >> (64 - lane)) : 0ull, above = lane < 63 ? (~0ull << (lane + 1)) : 0ull;
     bool n_before = (bN & below) != 0, n_after = (bN & above) != 0, e_after = (bE & above) != 0;
@@ -411,7 +421,7 @@ __device__ __forceinline__ void emit_run_edges(u64 own, u64 prev, u64 next, int 
 template <bool ASCII>
 static __global__ __launch_bounds__(BLOCK) void k_fa_emit(EmitArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[16 + TILE + 16];
-    __shared__ __attribute__((aligned(16))) uint16_t s_n[TILE / 16], s_x[TILE / 16], s_g[TILE / 16], s_h[ASCII ? TILE / 16 : 8];
+    __shared__ __attribute__((aligned(16))) uint16_t s_n[TILE / 16], s_x[TILE / 16], s_h[ASCII ? TILE / 16 : 8];
     __shared__ uint32_t s_slot[4][BLOCK / 64];
     __shared__ u64 s_seq[BLOCK + 2], s_id[BLOCK + 2], s_rank[BLOCK];
     __shared__ u64 s_w[BLOCK / 64];
@@ -421,7 +431,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_emit(EmitArgs a) {
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     uint4 r[4];
     tile_fetch(a.data, a.n, t0, valid, r);
-    tile_masks<ASCII, true>(r, valid, s_n, s_x, s_g, s_h, s_tile);
+    tile_masks<ASCII, true>(r, valid, s_n, s_x, s_h, s_tile);
     const uint32_t tin = a.tile_in[t];
     const uint32_t s = tin & 3u, xf = (tin >> 2) & 1u;
     const int64_t seq_base = a.base[t * 4 + 0], id_base = a.base[t * 4 + 1], rec_base = a.base[t * 4 + 2];
@@ -429,9 +439,8 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_emit(EmitArgs a) {
     Masks m;
     m.N = reinterpret_cast<const u64*>(s_n)[tid];
     m.X = reinterpret_cast<const u64*>(s_x)[tid];
-    m.G = reinterpret_cast<const u64*>(s_g)[tid];
     m.H = ASCII ? reinterpret_cast<const u64*>(s_h)[tid] : 0ull;
-    const Facts f = line_facts(m, s != 0u, s == 1u || s == 2u, s == 2u, xf, s_slot);
+    const Facts f = line_facts(m, s != 0u, s == 1u || s == 2u, s == 2u, xf, s_slot, [&](int p) { return (uint32_t)s_tile[tid * 64 + p]; });
     // tile-local ranks of this thread's first byte in both columns and among the headers
     u64 tot;
     const u64 packed = (u64)__builtin_popcountll(f.seq) | ((u64)__builtin_popcountll(f.id) << 16) | ((u64)__builtin_popcountll(f.FG) << 32);

@@ -100,3 +100,14 @@ def test_host_simd_width_is_one_of_the_reference_widths():
         assert w == 64
     elif " avx2" in flags:
         assert w == 32
+
+
+def test_integration_md_config_struct_matches_the_header():
+    """The Mojo `BzqConfig` sketched in INTEGRATION.md lists the fields of `bzq_config` in the header's order (it went stale
+    once: `_pad1` where the header had grown `views_only`)."""
+    import re
+    from blazeseq_amd import _lib
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = md[md.index("struct BzqConfig"):md.index("struct HipFastq")]
+    mojo_fields = re.findall(r"^\s+var (\w+):", block, re.M)
+    assert mojo_fields == [f[0] for f in _lib.BzqConfig._fields_]

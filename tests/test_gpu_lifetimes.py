@@ -66,7 +66,7 @@ def test_python_surface_batches_of_100_on_variable_length_reads(tmp_path):
         for k, (rid, seq, qual) in enumerate(recs):
             i1, s1 = int(w.id_ends[k]), int(w.ends[k])
             assert (rid.encode("latin-1"), seq.encode("latin-1"), qual.encode("latin-1")) == \
-                   (w.id_bytes[i0:i1].tobytes(), w.seq_bytes[s0:s1].tobytes(), w.qual_bytes[s0:s1].tobytes())
+                   (bytes(w.id_bytes[i0:i1]), bytes(w.seq_bytes[s0:s1]), bytes(w.qual_bytes[s0:s1]))
             i0, s0 = i1, s1
 
 
