@@ -116,6 +116,9 @@ struct bzq_ctx {
     int force_dense = 0, timing_detail = 0, single_pass = 0, v2 = 1, num_cu = 256;
     bool ran_single_pass = false;
     int ingest_direct = 0, ingest_numa = 1;   // options "ingest_direct" (O_DIRECT reads), "ingest_numa" (bind readers to the GPU's node)
+    int pass_a_h = 1;          // option "pass_a_h": pass A from the newline bitmap alone (k_tile_aggregate_h), verified by the emit
+    bool exact_pass_a = false; // this chunk is being repeated with the exact pass A
+    bool used_h = false;
     int use_stream = 0;        // option "stream" (EXPERIMENTS build): batch mode through the single-read kernel k_stream
     bool ran_stream = false;
     int64_t stream_fallbacks = 0;
@@ -363,6 +366,7 @@ FusedArgs make_fused_args(bzq_ctx* c) {
     f.o_sep = (int64_t*)c->o().off[2].p; f.o_qual = (int64_t*)c->o().off[3].p;
     f.st = c->d_state; f.q_lower = c->cfg.q_lower; f.q_upper = c->cfg.q_upper; f.force_dense = c->force_dense; f.ablate = c->ablate;
     f.walk_limit = walk_limit_of(c);
+    f.check_h = c->used_h ? 1 : 0;
     return f;
 }
 
@@ -549,6 +553,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
 #if BZQ_EXPERIMENTS
                 else if (!c->v2) hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
 #endif
+                else if (c->pass_a_h && !c->exact_pass_a) { hipLaunchKernelGGL(k_tile_aggregate_h, grid, dim3(BLOCK), 0, c->stream, a); c->used_h = true; }
                 else hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
             }
             if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
@@ -617,6 +622,7 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     int64_t want = (int64_t)(n / (uint64_t)std::max(4, c->cfg.min_record_bytes)) + 1024;
     if ((rc = ensure_record_arenas(c, want))) return rc;
     c->views_bytes_once = false; c->tail_pending = false;
+    if (!reuse_aggregates) c->used_h = false;   // (a shard's aggregates come from bzq_shard_scan, which says how it made them)
     c->cur = d_data; c->cur_n = n; c->cur_stream_pos = stream_pos; c->cur_is_eof = is_eof;
     c->cur_prev_byte = prev_byte; c->cur_first_header = first_header;
     for (hipEvent_t e : c->ev_detail) (void)hipEventDestroy(e);
@@ -884,6 +890,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
         c->use_stream = value != 0;
     }
     else if (!strcmp(key, "stream_fallbacks")) return (int32_t)std::min<int64_t>(c->stream_fallbacks, 0x7FFFFFFF);   // query: chunks repeated on the two-pass kernels
+    else if (!strcmp(key, "pass_a_h")) c->pass_a_h = value != 0;
     else if (!strcmp(key, "ingest_direct")) c->ingest_direct = value != 0;
     else if (!strcmp(key, "ingest_numa")) c->ingest_numa = value != 0;
     else if (!strcmp(key, "double_buffer")) {
@@ -970,7 +977,10 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         int rc;
         c->ran_single_pass = false; c->ran_stream = false; c->stream_fallbacks += 1;
         if ((rc = ensure_tile_arenas(c, c->cur_n))) return rc;
-        if ((rc = enqueue_passes(c, false, false))) return rc;
+        c->exact_pass_a = true; c->used_h = false;
+        rc = enqueue_passes(c, false, false);
+        c->exact_pass_a = false;
+        if (rc) return rc;
         hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)c->cur_n, c->d_state);
         enqueue_rebase(c);
         HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
@@ -1356,7 +1366,9 @@ static int shard_scan_enqueue(bzq_ctx* c, const uint8_t* d_data, uint64_t n) {
         HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
         const int64_t nt = tiles_for(n);
         AggArgs a{d_data, (int64_t)n, 10u, 0, nt, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p, (u64*)c->tile_idc.p, walk_limit_of(c)};
-        hipLaunchKernelGGL(k_tile_aggregate2, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
+        c->used_h = c->pass_a_h != 0;
+        if (c->used_h) hipLaunchKernelGGL(k_tile_aggregate_h, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
+        else hipLaunchKernelGGL(k_tile_aggregate2, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
         launch_scan(c, 0, nt, 0);
         hipLaunchKernelGGL(k_first_newlines, dim3(1), dim3(BLOCK), 0, c->stream, d_data, (int64_t)n, c->d_state);
     }

@@ -68,6 +68,7 @@ struct FusedArgs {
     uint32_t q_lower, q_upper;
     int32_t force_dense;
     int64_t walk_limit;   // ByteSrc::walk_limit (0 = none)
+    int32_t check_h;      // pass A was k_tile_aggregate_h: flag every header line whose kept range is not "all but the '@'"
     int32_t ablate;   // timing experiments, compiled in only with -DBZQ_EXPERIMENTS=1 (make EXPERIMENTS=1): see BZQ_ABLATE uses
 };
 
@@ -331,7 +332,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     if (!LB && BZQ_ABLATE(256)) return;   // experiment: stop here
     const int64_t P = LB ? s_bcast[1] : cP;
     ErrAcc err{~0ull, ~0ull};
-    bool overflow = false;
+    bool overflow = false, h_bad = false;
     const int ph = (int)(P & 3);
 
     // walks every line of the tile serially (any input): used by the dense path, count then emit
@@ -352,6 +353,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                 }
                 int64_t lo = ls, hi = ls;
                 if (end > start) header_kept(bs, ls, le, start_in, end_in, t0 + valid, lo, hi);
+                if (emit && a.check_h && (hi - lo) != (int64_t)(end - start) - ((start_in && end > start) ? 1 : 0)) h_bad = true;
                 if (emit)
                     for (int64_t p = lo; p < hi; ++p) {
                         const uint8_t ch = s_tile[p - t0];
@@ -439,6 +441,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                 }
                 int64_t lo = ls, hi = ls;
                 if (end > start) header_kept(bs, ls, t0 + end, sknown, end_in, t0 + valid, lo, hi);
+                if (a.check_h && (hi - lo) != (int64_t)(end - start) - ((sknown && end > start) ? 1 : 0)) h_bad = true;
                 reinterpret_cast<uint32_t*>(&s_seg[0][k])[0] = (uint32_t)(lo - t0) | ((uint32_t)(hi - lo) << 16);
             } else if (role == 2) {
                 if (sin) {
@@ -597,6 +600,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
     if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
     if (overflow) atomicOr(&a.st->rec_overflow, 1);
+    if (h_bad) a.st->lookback_timeout = 2;   // an id lost bytes to the strip: pass A's hypothesis was wrong, the host repeats the chunk with the exact pass A
 }
 
 
@@ -683,6 +687,79 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
         }
     }
     // block sum of the packed fields (every field total <= 16384, no carry between fields)
+    pa = wave_sum_u64(pa); pi = wave_sum_u64(pi);
+    if (lane == 0) { atomicAdd(&s_sum[0], pa); atomicAdd(&s_sum[1], pi); }
+    __syncthreads();
+    if (tid == 0) {
+        a.tile_c[t] = c;
+        a.tile_a[t] = s_sum[0];
+        a.tile_idc[t] = s_sum[1];
+    }
+}
+
+// Pass A from the newline bitmap ALONE (the default): no LDS copy of the bytes, no byte lookups -- line lengths per class come
+// out of the newline positions, and the id bytes per class under the hypothesis that no header line loses bytes to
+// _strip_spaces (utils.mojo:221-242): kept = length - 1 for a line that starts in the tile ('@' dropped), the whole piece for
+// the continuation of a line that started earlier.  Real FASTQ ids have no leading / trailing posix spaces, so this is exact;
+// the emit kernel measures every header line exactly (header_kept) anyway and flags the chunk when a line contradicts the
+// hypothesis (FusedArgs::check_h) -- the host then repeats it with k_tile_aggregate2.  4 KiB of LDS instead of 20, half the
+// instructions: the pass runs at the rate of a bare read of the input.  Same output format as k_tile_aggregate2.
+static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate_h(AggArgs a) {
+    __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
+    __shared__ uint16_t s_nl[MAXL_A];
+    __shared__ __attribute__((aligned(8))) uint32_t s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    if (t >= a.tile_end) return;
+    const int64_t t0 = t * TILE;
+    const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+    const uint32_t prev_b = t0 > 0 ? (uint32_t)a.g[t0 - 1] : a.prev_byte;
+    uint4 r[4];
+    tile_fetch(a.g, a.n, t0, valid, r);
+    tile_stage<false>(r, valid, s_mask, nullptr);
+    const bool first_starts = (prev_b == 10u);
+    __syncthreads();
+    const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);
+    const u64 m64 = s_mask64[tid];
+    uint32_t c = 0;
+    const uint32_t excl = block_exclusive_scan<uint32_t, 4>((uint32_t)__popcll(m64), s_w, c);
+    u64* s_sum = reinterpret_cast<u64*>(s_w);
+    if (tid < 2) s_sum[tid] = 0;
+    u64 pa = 0, pi = 0; // 4 x 16-bit fields: bytes / id bytes per class
+    auto add_line = [&](int j, int start, int end) {
+        const int len = end - start;
+        if (len <= 0) return;
+        pa += (u64)len << (16 * (j & 3));
+        pi += (u64)(len - ((j > 0 || first_starts) ? 1 : 0)) << (16 * (j & 3));
+    };
+    if ((int)c <= MAXL_A) {
+        u64 m = m64;
+        int idx = 0;
+        while (m) {
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1;
+            s_nl[excl + idx] = (uint16_t)(tid * 64 + bit);
+            ++idx;
+        }
+        __syncthreads();
+        for (int j = tid; j <= (int)c; j += BLOCK) add_line(j, j ? (int)s_nl[j - 1] + 1 : 0, j < (int)c ? (int)s_nl[j] : valid);
+    } else {
+        __syncthreads();
+        if (tid == 0) {   // more newlines than the table holds: one thread walks the bitmap
+            int j = 0, line_start = 0;
+            for (int w = 0; w < BLOCK; ++w) {
+                u64 m = s_mask64[w];
+                while (m) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    add_line(j, line_start, w * 64 + bit);
+                    line_start = w * 64 + bit + 1;
+                    ++j;
+                }
+            }
+            add_line(j, line_start, valid);
+        }
+    }
     pa = wave_sum_u64(pa); pi = wave_sum_u64(pi);
     if (lane == 0) { atomicAdd(&s_sum[0], pa); atomicAdd(&s_sum[1], pi); }
     __syncthreads();

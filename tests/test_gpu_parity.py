@@ -349,3 +349,25 @@ def test_shards_record_aligned_and_header_cut():
         assert total == whole.n_records, cut
         np.testing.assert_array_equal(ids, whole.id_bytes)
         np.testing.assert_array_equal(quals, whole.qual_bytes)
+
+
+def test_bitmap_only_pass_a_falls_back_exactly_when_an_id_is_stripped():
+    """Pass A works from the newline bitmap alone under the hypothesis that no id loses bytes to _strip_spaces
+    (utils.mojo:221-242); the emit measures every header line exactly and, when one contradicts the hypothesis, the host
+    repeats the chunk with the exact pass A.  Clean ids (spaces INSIDE an id included) never fall back; a leading or a
+    trailing space does, once; results are the oracle's either way, and identical with the option off."""
+    from blazeseq_amd import _lib as L
+    clean = b"".join(b"@read %d some description\n%s\n+\n%s\n" % (i, b"ACGT" * 30, b"IIII" * 30) for i in range(4000))
+    lead = clean.replace(b"@read 2500 ", b"@ read 2500 ", 1)
+    trail = clean.replace(b"@read 3999 some description\n", b"@read 3999 some description \t\n", 1)
+    allsp = clean.replace(b"@read 17 some description\n", b"@   \n", 1)
+    for data, want_fallbacks in ((clean, 0), (lead, 1), (trail, 1), (allsp, 1)):
+        ctx, oc = make_pair(emit_offsets=True)
+        check_against_oracle(ctx, oc, data, offsets=True, what="bitmap pass A")
+        assert L.lib().bzq_set_option(ctx.h, b"stream_fallbacks", 0) == want_fallbacks
+        check_against_oracle(ctx, oc, data, is_eof=False, offsets=True, what="bitmap pass A, chunk mode")
+        ctx.set_option("pass_a_h", 0)
+        before = L.lib().bzq_set_option(ctx.h, b"stream_fallbacks", 0)
+        check_against_oracle(ctx, oc, data, offsets=True, what="exact pass A")
+        assert L.lib().bzq_set_option(ctx.h, b"stream_fallbacks", 0) == before
+        ctx.close()
