@@ -9,7 +9,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
 BENCH="python bench.py --no-cpu-baseline $*"
-LONG="--steps 10 --warmup 3"; SHORT="--steps 2 --warmup 1"
+LONG="--steps 10 --warmup 3"; SHORT="--steps 2 --warmup 1 --min-seconds 0"   # PMC passes: no time-based warm-up (the counter databases grow with every dispatch)
 # another command under the same passes (e.g. scripts/bench_fasta.py): BZQ_PROFILE_CMD="python scripts/bench_fasta.py 0"
 if [ -n "${BZQ_PROFILE_CMD:-}" ]; then BENCH="$BZQ_PROFILE_CMD"; LONG=""; SHORT=""; fi
 (timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/kt -o $TAG -- $BENCH $LONG) > $OUT/kt.log 2>&1; echo "kt rc=$?"
