@@ -443,7 +443,7 @@ def main():
                 "launches_per_step": int(res.n_passes),
             },
             "roofline_path": {
-                "note": "whole hot path (aggregate + scan + emit + rebase kernels), hipEvent time on the ctx stream",
+                "note": "whole hot path (pass A k_tile_aggregate_h + scan + emit k_fused + k_rebase), hipEvent time on the ctx stream",
                 "achieved": round(A_total / path_s / 1e9, 2) if path_s > 0 else None,
                 "frac": round(A_total / path_s / 1e9 / HBM_PEAK_GBS, 4) if path_s > 0 else None,
                 "ms": {"aggregate": round(ms_agg / steps, 4), "scan": round(ms_scan / steps, 4),
