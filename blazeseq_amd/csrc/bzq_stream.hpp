@@ -38,7 +38,10 @@ namespace bzq {
 #define BZQ_STREAM_ST 4
 #endif
 constexpr int ST = BZQ_STREAM_ST;   // 16 KiB tiles per workgroup
-constexpr int SGRP = 64;            // workgroups per look-back group
+#ifndef BZQ_STREAM_SGRP
+#define BZQ_STREAM_SGRP 64
+#endif
+constexpr int SGRP = BZQ_STREAM_SGRP;   // workgroups per look-back group (<= 64: one lane per workgroup in level 1)
 constexpr int WD_WORDS = 4;         // u64 granules per workgroup descriptor (3 used)
 constexpr int GD_WORDS = 8;         // u64 granules per group descriptor: 4 aggregate + 4 prefix = one 64-byte line
 constexpr u64 F_SET = 2ull << 62;   // granule flag: value present
