@@ -105,9 +105,16 @@ __device__ __forceinline__ uint32_t nl_mask16(uint4 v) {
 // 16 bytes from global memory at ANY byte address, in one global_load_dwordx4 (gfx950 loads unaligned).  Typed as
 // unaligned on purpose: a chunk handed over by the ingest pipeline starts wherever its carry starts, and behind an
 // aligned vector type the compiler would be entitled to assume otherwise.
-struct __attribute__((packed, aligned(1))) G16B { uint32_t x, y, z, w; };
+// NT = non-temporal.  Worth it in the kernels that ONLY read the input (pass A, the views line pass, FASTA pass 1: 0.527 ->
+// 0.47 ms for the FASTQ pass A, same-box A/B; a tile-shaped copy probe, scripts/probes/copy_probe.hip, shows the same: 6.23 TB/s
+// against 5.89).  NOT in the emit kernels: there nt loads cost 5 % (1.23 -> 1.30 ms) and slow the following k_rebase.
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef v4u32 v4u32_any __attribute__((aligned(1)));
+template <bool NT = false>
 __device__ __forceinline__ uint4 load16_any(const uint8_t* __restrict__ p) {
-    const G16B v = *reinterpret_cast<const G16B*>(p);
+    v4u32 v;
+    if (NT) v = __builtin_nontemporal_load(reinterpret_cast<const v4u32_any*>(p));
+    else v = *reinterpret_cast<const v4u32_any*>(p);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
@@ -265,12 +272,13 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* s_w, T& total) {
 // tile_fetch: coalesced 16 B per lane, 4 rounds (piece q = tid + 256*s), into registers.
 // tile_stage: newline bitmap s_mask[q] (16-bit mask of piece q; read back as one u64 per thread = the
 // 64 contiguous bytes [64*tid, 64*tid+64)) and, optionally, the bytes themselves into LDS.
+template <bool NT = false>
 __device__ __forceinline__ void tile_fetch(const uint8_t* __restrict__ g, int64_t n, int64_t t0, int valid, uint4 (&r)[4]) {
     const int tid = threadIdx.x;
     if (valid == TILE) {   // every tile but the last: no guards
         const uint8_t* __restrict__ p = g + t0 + tid * 16;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) r[s] = load16_any(p + BLOCK * 16 * s);
+        for (int s = 0; s < 4; ++s) r[s] = load16_any<NT>(p + BLOCK * 16 * s);
         return;
     }
 #pragma unroll

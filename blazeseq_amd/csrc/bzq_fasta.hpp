@@ -216,7 +216,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_tile_sums(SumsArgs a) {
     const int64_t t = blockIdx.x, t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     uint4 r[4], own[4];
-    tile_fetch(a.data, a.n, t0, valid, r);
+    tile_fetch<true>(a.data, a.n, t0, valid, r);
     tile_to_own(r, s_tile, own);
     const Masks m = own_masks<false>(own, valid);
     const u64 E = m.N | m.X;

@@ -622,7 +622,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     const uint32_t prev_b = t0 > 0 ? (uint32_t)a.g[t0 - 1] : a.prev_byte;
     uint4 r[4];
-    tile_fetch(a.g, a.n, t0, valid, r);
+    tile_fetch<true>(a.g, a.n, t0, valid, r);
     tile_stage<true>(r, valid, s_mask, s_tile);
     ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
     if (a.walk_limit > 0) bs.walk_limit = a.walk_limit;
@@ -715,7 +715,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate_h(AggArgs a) {
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     const uint32_t prev_b = t0 > 0 ? (uint32_t)a.g[t0 - 1] : a.prev_byte;
     uint4 r[4];
-    tile_fetch(a.g, a.n, t0, valid, r);
+    tile_fetch<true>(a.g, a.n, t0, valid, r);
     tile_stage<false>(r, valid, s_mask, nullptr);
     const bool first_starts = (prev_b == 10u);
     __syncthreads();

@@ -103,7 +103,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     uint4 r[4];
-    tile_fetch(a.g, a.n, t0, valid, r);
+    tile_fetch<true>(a.g, a.n, t0, valid, r);
     tile_stage<true>(r, valid, s_mask, s_tile);
     if (VAL) {
 #pragma unroll
@@ -347,7 +347,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_count(AggArgs a) {
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     uint4 r[4];
-    tile_fetch(a.g, a.n, t0, valid, r);
+    tile_fetch<true>(a.g, a.n, t0, valid, r);
     uint32_t cnt = 0;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
