@@ -74,6 +74,12 @@ struct OutSet {
     int64_t rec_cap = 0;
     // rebased ends / id_ends of bzq_batch_view ranges that are not batch aligned: bump-allocated blocks that are never
     // moved or freed while the chunk is live, so every view handed out keeps its own storage
+    // ends / id_ends at every batch boundary (k_rebase), mirrored on the host by bzq_chunk_result: an aligned bzq_batch_view
+    // then needs no device copy at all
+    DevBuf bb;
+    int64_t bb_cap = 0;
+    std::vector<int64_t> h_bb;     // 2 x int64 per batch of the chunk's COMPLETE records; empty = not available
+    int64_t h_bb_records = 0;      // complete records the table covers
     std::vector<DevBuf> view_blocks;
     size_t view_used = 0;          // bytes used in view_blocks.back()
     size_t view_next = 4u << 20;   // size of the next block
@@ -188,6 +194,7 @@ static __global__ void k_log_ends(const int64_t* __restrict__ rec_end, int64_t n
 // The stream's record-end log (option records_before): fixed blocks of LOG_BLOCK records, allocated as the stream grows
 // and never moved, so logging a chunk costs one small kernel per block it touches and nothing else.
 constexpr int64_t LOG_BLOCK = 1ll << 20;   // records per block (8 MiB)
+constexpr int64_t BB_MAX_BATCHES = 1ll << 20;   // batch-boundary table kept for chunks of at most this many batches (16 MiB)
 int log_record_ends(bzq_ctx* c, int64_t first, int64_t n, const int64_t* d_rec_end, int64_t stream_pos) {
     int64_t done = 0;
     while (done < n) {
@@ -606,10 +613,16 @@ void enqueue_rebase(bzq_ctx* c) {
         hipLaunchKernelGGL(k_views_check, dim3((unsigned)(c->num_cu * 8)), dim3(BLOCK), 0, c->stream, va);
         return;
     }
+    // batch boundaries for bzq_batch_view (host cache): only while the table stays small (batch sizes of a few records on a
+    // huge chunk fall back to per-view copies)
+    const int64_t nb_max = c->o().rec_cap / std::max<int64_t>(1, c->cfg.batch_size) + 2;
+    int64_t* bb = nullptr;
+    if (nb_max <= BB_MAX_BATCHES && ensure(c, c->o().bb, (size_t)nb_max * 16) == 0) bb = (int64_t*)c->o().bb.p;
+    c->o().bb_cap = bb ? nb_max : 0;
     RebaseArgs ra{(const int64_t*)c->o().ends.p, (const int64_t*)c->o().id_ends.p, (const int64_t*)c->o().rec_end.p,
                   (int64_t*)c->o().b_ends.p, (int64_t*)c->o().b_id_ends.p, (int64_t)c->cfg.batch_size, c->cur_first_header,
                   growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->o().rec_cap, c->d_state, c->cur,
-                  c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper};
+                  c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper, bb, c->o().bb_cap};
     hipLaunchKernelGGL(k_rebase, dim3((unsigned)(c->num_cu * 8)), dim3(BLOCK), 0, c->stream, ra);
 }
 
@@ -836,7 +849,7 @@ void bzq_destroy(bzq_ctx* c) {
                                  &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf};
     for (OutSet& o : c->out) {
         for (DevBuf* b : {&o.seq, &o.qual, &o.id, &o.ends, &o.id_ends, &o.rec_end, &o.b_ends, &o.b_id_ends, &o.off[0], &o.off[1],
-                          &o.off[2], &o.off[3], &o.id_start, &o.id_len})
+                          &o.off[2], &o.off[3], &o.id_start, &o.id_len, &o.bb})
             bufs.push_back(b);
         for (DevBuf& b : o.view_blocks) bufs.push_back(&b);
     }
@@ -1180,6 +1193,17 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
             r.ms_aggregate += a; r.ms_scan += b; r.ms_emit += d;
         }
     }
+    // the batch-boundary table of the complete records (one copy per chunk; bzq_batch_view reads it instead of the device)
+    {
+        OutSet& o = c->o();
+        o.h_bb.clear(); o.h_bb_records = 0;
+        const int64_t nb = (n_complete + batch - 1) / batch;
+        if (!c->cfg.views_only && o.bb_cap > 0 && nb > 0 && nb <= o.bb_cap) {
+            o.h_bb.resize((size_t)nb * 2);
+            if (hipMemcpy(o.h_bb.data(), o.bb.p, (size_t)nb * 16, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); o.h_bb.clear(); }
+            else o.h_bb_records = n_complete;
+        }
+    }
     r.n_passes = (uint32_t)c->n_passes;
     r._pad = (uint32_t)h->dense_tiles;
     c->res = r;
@@ -1200,12 +1224,23 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
     const uint64_t nrec = std::min<uint64_t>(max_records, c->res.n_records - first_record);
     HIPCHK(c, hipSetDevice(c->device));
     int64_t base[2] = {0, 0}, last[2] = {0, 0};
-    if (first_record > 0) {
-        HIPCHK(c, hipMemcpy(&base[0], c->res.d_ends + (first_record - 1), 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(&base[1], c->res.d_id_ends + (first_record - 1), 8, hipMemcpyDeviceToHost));
+    const OutSet& os = c->o();
+    const uint64_t lastrec = first_record + nrec - 1;
+    // batch aligned inside the complete records: both ends come from the host copy of the batch-boundary table
+    const bool cached = !os.h_bb.empty() && first_record % bs == 0 && lastrec < (uint64_t)os.h_bb_records &&
+                        ((lastrec + 1) % bs == 0 || lastrec + 1 == (uint64_t)os.h_bb_records) && nrec <= bs;
+    if (cached) {
+        const uint64_t k = first_record / bs;
+        if (k > 0) { base[0] = os.h_bb[2 * (k - 1)]; base[1] = os.h_bb[2 * (k - 1) + 1]; }
+        last[0] = os.h_bb[2 * k]; last[1] = os.h_bb[2 * k + 1];
+    } else {
+        if (first_record > 0) {
+            HIPCHK(c, hipMemcpy(&base[0], c->res.d_ends + (first_record - 1), 8, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&base[1], c->res.d_id_ends + (first_record - 1), 8, hipMemcpyDeviceToHost));
+        }
+        HIPCHK(c, hipMemcpy(&last[0], c->res.d_ends + lastrec, 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&last[1], c->res.d_id_ends + lastrec, 8, hipMemcpyDeviceToHost));
     }
-    HIPCHK(c, hipMemcpy(&last[0], c->res.d_ends + (first_record + nrec - 1), 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(&last[1], c->res.d_id_ends + (first_record + nrec - 1), 8, hipMemcpyDeviceToHost));
     out->num_records = (int64_t)nrec;
     out->seq_len = last[0] - base[0];
     out->total_id_bytes = last[1] - base[1];

@@ -969,6 +969,10 @@ struct RebaseArgs {
     const uint8_t* g;
     int32_t compat_w;
     uint32_t q_upper;
+    // ends / id_ends at the last record of every batch (and of the chunk): bb[2k], bb[2k+1] -- one small copy to the host per
+    // chunk instead of four 8-byte copies per bzq_batch_view; nullptr or bb_cap batches exceeded: not written
+    int64_t* bb;
+    int64_t bb_cap;
 };
 
 // FastqBatch._ends / _id_ends restart at every batch (record_batch.mojo:77-87 via parser.mojo:243):
@@ -982,9 +986,13 @@ static __global__ __launch_bounds__(BLOCK) void k_rebase(RebaseArgs a) {
     for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < n_rec; r += (int64_t)gridDim.x * BLOCK) {
         const int64_t b0 = (r / a.batch) * a.batch;
         const int64_t e0 = b0 ? a.ends[b0 - 1] : 0, i0 = b0 ? a.id_ends[b0 - 1] : 0;
-        const int64_t e = a.ends[r];
+        const int64_t e = a.ends[r], ie = a.id_ends[r];
         a.b_ends[r] = e - e0;
-        a.b_id_ends[r] = a.id_ends[r] - i0;
+        a.b_id_ends[r] = ie - i0;
+        if (a.bb && ((r + 1) % a.batch == 0 || r == n_rec - 1)) {
+            const int64_t k = r / a.batch;
+            if (k < a.bb_cap) { a.bb[2 * k] = e; a.bb[2 * k + 1] = ie; }
+        }
         const int64_t re = a.rec_end[r];
         const int64_t prev = r ? a.rec_end[r - 1] : a.first_header - 1;
         if (re - prev > a.len_limit) atomicMin(&a.st->err_buf, (u64)r << 3); // header_start .. '\n' inclusive
