@@ -5,7 +5,8 @@ Workload (BASELINE.json configs[1]): synthetic 150 bp Illumina FASTQ from the re
 (blazeseq/utils.mojo:831-917, args (num_reads, 150, 150, 33, 73, "generic")), 10 M reads per GPU,
 batches(4096), validation off.  The input is generated on the device and is resident in HBM when
 the timed region starts.  One "step" = one pass of the whole hot path over that input:
-delimiter scan -> record table -> FastqBatch columns (+ per-batch ends), i.e. everything
+delimiter scan -> record table -> FastqBatch columns (+ per-batch ends) -> every DeviceFastqBatch of the
+chunk handed out (bzq_batches: 2442 zero-copy views), i.e. everything
 ``for batch in parser.batches(4096): batch.to_device()`` does in the reference.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): BASELINE.json configs[4]'s shard shape --
@@ -334,10 +335,19 @@ def main():
             dist.all_gather_object(flags, exchange)
             exchange = "native" if all(f == "native" for f in flags) else next(f for f in flags if f != "native")
 
+    import ctypes as C
+    nb_cap = args.reads // 4096 + 2
+    batch_arr = (L.BzqDeviceBatch * nb_cap)()     # the step hands out every DeviceFastqBatch of the chunk (batches(4096))
+    nb_out = C.c_uint64()
+
     def step():
         if not sharded_mode:
             ctx.submit_device(shard.data_ptr(), n, 0, True)
-            return ctx.result(), None, None
+            res = ctx.result()
+            if not args.views:
+                rc = L.lib().bzq_batches(ctx.h, 4096, batch_arr, nb_cap, C.byref(nb_out))
+                assert rc == 0
+            return res, None, None
         if exchange == "native":
             sr = ctx.shard_stitch(shard.data_ptr(), n, shard.numel())
             return sr.chunk, [sr.global_records, sr.global_bases, sr.global_bytes], (sr.first_error_record if sr.first_error_record >= 0 else sharded.NO_ERROR)
@@ -384,6 +394,10 @@ def main():
     elif not sharded_mode:
         assert recs == args.reads and res.status == L.EOF, (recs, res.status, ctx.format_error())
         assert args.views or (int(res.seq_bytes) == int(res.qual_bytes) and (args.long_reads or int(res.seq_bytes) == args.read_len * recs))
+        if not args.views:   # every batch handed out: 4096 records each, the last one the remainder, seq_len = the batch's quality bytes
+            assert nb_out.value == (recs + 4095) // 4096 and batch_arr[0].num_records == min(4096, recs)
+            assert batch_arr[nb_out.value - 1].num_records == recs - 4096 * (nb_out.value - 1)
+            assert args.long_reads or batch_arr[0].seq_len == args.read_len * batch_arr[0].num_records
         global_records, global_bytes = recs, n
     else:
         assert totals[0] == total_reads and first_err == sharded.NO_ERROR, (totals, first_err)

@@ -1269,6 +1269,18 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
     return 0;
 }
 
+int32_t bzq_batches(bzq_ctx* c, uint32_t max_records, bzq_device_batch* out, uint64_t cap, uint64_t* n_out) {
+    if (!c || !n_out || (cap && !out) || !c->have_result) { if (c) c->err = "bzq_batches: no parsed chunk"; return BZQ_ERR_ARG; }
+    if (max_records == 0) { c->err = "bzq_batches: max_records must be > 0"; return BZQ_ERR_ARG; }
+    const uint64_t n = c->res.n_records, nb = (n + max_records - 1) / max_records;
+    *n_out = nb;
+    for (uint64_t k = 0; k < nb && k < cap; ++k) {
+        const int32_t rc = bzq_batch_view(c, k * (uint64_t)max_records, max_records, &out[k]);
+        if (rc < 0) return rc;
+    }
+    return 0;
+}
+
 int32_t bzq_views(bzq_ctx* c, uint64_t first_record, uint32_t max_records, bzq_device_views* out) {
     if (!c || !out || !c->have_result) { if (c) c->err = "bzq_views: no parsed chunk"; return BZQ_ERR_ARG; }
     if (!c->cfg.views_only) { c->err = "bzq_views: the ctx is not in views mode (config.views_only)"; return BZQ_ERR_ARG; }

@@ -213,6 +213,14 @@ class Context:
         _check(self.h, L.lib().bzq_batch_view(self.h, first_record, max_records, C.byref(b)), "bzq_batch_view")
         return b
 
+    def batches(self, max_records: int):
+        """bzq_batches: every batch of the current chunk (a ctypes array of bzq_device_batch) in one call."""
+        n = C.c_uint64()
+        _check(self.h, L.lib().bzq_batches(self.h, max_records, None, 0, C.byref(n)), "bzq_batches")
+        arr = (L.BzqDeviceBatch * max(1, n.value))()
+        _check(self.h, L.lib().bzq_batches(self.h, max_records, arr, n.value, C.byref(n)), "bzq_batches")
+        return arr, int(n.value)
+
     def generate_synthetic_device(self, num_reads: int, read_len: int, min_phred: int, max_phred: int,
                                   schema: str, d_out: int = 0, cap: int = 0, first: int = 0,
                                   count: Optional[int] = None, max_len: Optional[int] = None) -> int:

@@ -251,6 +251,10 @@ int32_t bzq_chunk_result(bzq_ctx* ctx, bzq_chunk* out);
  * own inside the chunk's output set: every view handed out stays valid exactly as long as the
  * chunk's columns, however many views are taken in between. */
 int32_t bzq_batch_view(bzq_ctx* ctx, uint64_t first_record, uint32_t max_records, bzq_device_batch* out);
+/* batches() (parser.mojo:267-274, _FastqParserBatchIter 700-735) over the current chunk in one call: out[k] = the k-th batch of
+ * `max_records` records (the last one shorter), exactly what successive bzq_batch_view(k * max_records, max_records) calls
+ * return.  cap = entries available in `out`; *n_out = batches the chunk holds (may exceed cap: only cap are written). */
+int32_t bzq_batches(bzq_ctx* ctx, uint32_t max_records, bzq_device_batch* out, uint64_t cap, uint64_t* n_out);
 /* DeviceFastqBatch.copy_to_host (record_batch.mojo:222-244) */
 int32_t bzq_batch_to_host(bzq_ctx* ctx, const bzq_device_batch* batch, bzq_host_batch* out);
 /* Copy any device range of the current chunk's arrays to the host (tests, error snippets). */

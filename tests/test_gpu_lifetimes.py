@@ -162,3 +162,29 @@ def test_a_mistyped_path_is_not_fastq_content():
         B.FastqParser("/no/such/dir/reads.fastq")
     p = B.FastqParser("@r1\nACGT\n+\nIIII\n")            # a str that IS content
     assert len(p.next_batch(4)) == 1
+
+
+def test_all_batches_in_one_call_equal_successive_views():
+    """bzq_batches(ctx, n) = the batches() iteration over the current chunk: the same structs as successive bzq_batch_view
+    calls, for a batch size equal to the ctx's (zero copy, host-cached boundaries) and for one that is not (own storage)."""
+    import blazeseq_amd as B
+    data = O.generate_synthetic(10_000, 20, 180, 0, 40, "sanger")
+    ctx = B.Context(B.ParserConfig(), "generic", 512, 0)
+    res = ctx.parse(data, 0, True)
+    f = O.flat_parse(data, O.make_config(batch_size=512))
+    for bs in (512, 300):
+        arr, nb = ctx.batches(bs)
+        assert nb == (f.n_records + bs - 1) // bs
+        e = np.empty(bs, dtype=np.int64)
+        for k in range(nb):
+            v = ctx.batch_view(k * bs, bs)
+            a = arr[k]
+            assert (a.num_records, a.seq_len, a.total_id_bytes, a.qual_buffer, a.sequence_buffer, a.id_buffer, a.first_record) == \
+                   (v.num_records, v.seq_len, v.total_id_bytes, v.qual_buffer, v.sequence_buffer, v.id_buffer, v.first_record)
+            lo = k * bs
+            base = int(f.ends[lo - 1]) if lo else 0
+            m = int(a.num_records)
+            assert m == min(bs, f.n_records - lo) and int(a.seq_len) == int(f.ends[lo + m - 1]) - base
+            ctx.copy_to_host(e[:m], a.ends, 8 * m)
+            np.testing.assert_array_equal(e[:m], f.ends[lo:lo + m] - base)
+    ctx.close()
