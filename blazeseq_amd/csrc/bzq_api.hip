@@ -78,7 +78,9 @@ struct OutSet {
     // then needs no device copy at all
     DevBuf bb;
     int64_t bb_cap = 0;
-    std::vector<int64_t> h_bb;     // 2 x int64 per batch of the chunk's COMPLETE records; empty = not available
+    int64_t* h_bb = nullptr;       // pinned mirror of bb, filled by an async copy behind k_rebase (arrives with the chunk state)
+    int64_t h_bb_cap = 0;          // entries (batches) the mirror can hold
+    int64_t h_bb_batches = 0;      // batches copied for the current chunk (0 = not available)
     int64_t h_bb_records = 0;      // complete records the table covers
     std::vector<DevBuf> view_blocks;
     size_t view_used = 0;          // bytes used in view_blocks.back()
@@ -624,6 +626,19 @@ void enqueue_rebase(bzq_ctx* c) {
                   growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->o().rec_cap, c->d_state, c->cur,
                   c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper, bb, c->o().bb_cap};
     hipLaunchKernelGGL(k_rebase, dim3((unsigned)(c->num_cu * 8)), dim3(BLOCK), 0, c->stream, ra);
+    // mirror the batch-boundary table into pinned memory on the stream: it arrives with the chunk state, no extra synchronisation
+    OutSet& o = c->o();
+    o.h_bb_batches = 0;
+    if (bb) {
+        if (o.h_bb_cap < nb_max) {
+            if (o.h_bb) (void)hipHostFree(o.h_bb);
+            o.h_bb = nullptr; o.h_bb_cap = 0;
+            if (hipHostMalloc((void**)&o.h_bb, (size_t)nb_max * 16, hipHostMallocDefault) == hipSuccess) o.h_bb_cap = nb_max;
+            else (void)hipGetLastError();
+        }
+        // (at most what the chunk can hold: n / min_record_bytes records; the count is only known after the kernels)
+        if (o.h_bb && hipMemcpyAsync(o.h_bb, bb, (size_t)nb_max * 16, hipMemcpyDeviceToHost, c->stream) == hipSuccess) o.h_bb_batches = nb_max;
+    }
 }
 
 int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream_pos, int is_eof,
@@ -852,6 +867,7 @@ void bzq_destroy(bzq_ctx* c) {
                           &o.off[2], &o.off[3], &o.id_start, &o.id_len, &o.bb})
             bufs.push_back(b);
         for (DevBuf& b : o.view_blocks) bufs.push_back(&b);
+        if (o.h_bb) (void)hipHostFree(o.h_bb);
     }
     for (DevBuf& b : c->tail_log) bufs.push_back(&b);
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
@@ -1193,16 +1209,11 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
             r.ms_aggregate += a; r.ms_scan += b; r.ms_emit += d;
         }
     }
-    // the batch-boundary table of the complete records (one copy per chunk; bzq_batch_view reads it instead of the device)
+    // the batch-boundary table of the complete records came back with the state (async copy behind k_rebase)
     {
         OutSet& o = c->o();
-        o.h_bb.clear(); o.h_bb_records = 0;
         const int64_t nb = (n_complete + batch - 1) / batch;
-        if (!c->cfg.views_only && o.bb_cap > 0 && nb > 0 && nb <= o.bb_cap) {
-            o.h_bb.resize((size_t)nb * 2);
-            if (hipMemcpy(o.h_bb.data(), o.bb.p, (size_t)nb * 16, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); o.h_bb.clear(); }
-            else o.h_bb_records = n_complete;
-        }
+        o.h_bb_records = (!c->cfg.views_only && o.h_bb && nb > 0 && nb <= o.h_bb_batches) ? n_complete : 0;
     }
     r.n_passes = (uint32_t)c->n_passes;
     r._pad = (uint32_t)h->dense_tiles;
@@ -1222,13 +1233,13 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
     out->first_record = first_record;
     if (first_record >= c->res.n_records) return 0; // empty batch: the iterator stops (parser.mojo:727-729)
     const uint64_t nrec = std::min<uint64_t>(max_records, c->res.n_records - first_record);
-    HIPCHK(c, hipSetDevice(c->device));
     int64_t base[2] = {0, 0}, last[2] = {0, 0};
     const OutSet& os = c->o();
     const uint64_t lastrec = first_record + nrec - 1;
     // batch aligned inside the complete records: both ends come from the host copy of the batch-boundary table
-    const bool cached = !os.h_bb.empty() && first_record % bs == 0 && lastrec < (uint64_t)os.h_bb_records &&
+    const bool cached = os.h_bb_records > 0 && first_record % bs == 0 && lastrec < (uint64_t)os.h_bb_records &&
                         ((lastrec + 1) % bs == 0 || lastrec + 1 == (uint64_t)os.h_bb_records) && nrec <= bs;
+    if (!cached || first_record % bs != 0 || max_records > bs) HIPCHK(c, hipSetDevice(c->device));
     if (cached) {
         const uint64_t k = first_record / bs;
         if (k > 0) { base[0] = os.h_bb[2 * (k - 1)]; base[1] = os.h_bb[2 * (k - 1) + 1]; }
