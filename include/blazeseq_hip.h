@@ -304,7 +304,8 @@ int32_t bzq_comm_get_unique_id(bzq_nccl_id* id_out);
 int32_t bzq_comm_init(bzq_ctx* ctx, int32_t rank, int32_t nranks, const void* nccl_id);
 /* The same protocol through a POSIX shared-memory segment on the host ("/bzq_<name>"; SURVEY.md 8e fallback via host):
  * same-node ranks under any GPU assignment, several ranks per GPU included.  halo_capacity: largest head a rank may send
- * (0 = 4 MiB); all ranks must pass the same value. */
+ * (0 = 4 MiB); all ranks must pass the same value.  `name` must be unique per job (rank 0 creates the segment and removes
+ * it at bzq_comm_destroy; a segment left behind by a crashed job of the same name is replaced). */
 int32_t bzq_comm_init_shm(bzq_ctx* ctx, int32_t rank, int32_t nranks, const char* name, uint64_t halo_capacity);
 int32_t bzq_comm_destroy(bzq_ctx* ctx);
 
