@@ -14,9 +14,13 @@ ap.add_argument("--reads", type=int, default=10_000_000)
 ap.add_argument("--threads", type=int, nargs="+", default=[4, 8, 16])
 ap.add_argument("--chunk-mib", type=int, nargs="+", default=[256])
 ap.add_argument("--dir", default="/dev/shm")
+ap.add_argument("--direct", action="store_true", help="option ingest_direct: O_DIRECT reads (needs --dir on a real filesystem; tmpfs refuses O_DIRECT)")
+ap.add_argument("--drop-caches", action="store_true", help="echo 3 > /proc/sys/vm/drop_caches before every run (cold file)")
 args = ap.parse_args()
 
 ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
+if args.direct:
+    ctx.set_option("ingest_direct", 1)
 rec = ctx.generate_synthetic_device(args.reads, 150, 33, 73, "generic", count=1)
 n = rec * args.reads
 buf = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
@@ -40,6 +44,12 @@ for chunk in args.chunk_mib:
     for th in args.threads:
         best = None
         for rep in range(3):
+            if args.drop_caches:
+                os.sync()
+                try:
+                    open("/proc/sys/vm/drop_caches", "w").write("3\n")
+                except OSError as e:
+                    print("drop_caches:", e)
             t0 = time.perf_counter()
             ing = B.Ingest(ctx, path, chunk_bytes=chunk << 20, n_threads=th)
             t1 = time.perf_counter()
@@ -56,7 +66,7 @@ for chunk in args.chunk_mib:
             assert total == args.reads, (total, args.reads)
             r = (n / dt / 1e9, dt, st.read_s, st.wait_s, t1 - t0)
             if best is None or r[0] > best[0]: best = r
-        print(f"chunk {chunk} MiB, {th} reader threads: {best[0]:.1f} GB/s end to end ({best[1]*1e3:.0f} ms; reader busy {best[2]*1e3:.0f} ms, "
+        print(f"[direct_io={int(st.direct_io)} numa_node={int(st.numa_node)}] chunk {chunk} MiB, {th} reader threads: {best[0]:.1f} GB/s end to end ({best[1]*1e3:.0f} ms; reader busy {best[2]*1e3:.0f} ms, "
               f"consumer waiting {best[3]*1e3:.0f} ms, open {best[4]*1e3:.0f} ms)", flush=True)
 os.remove(path)
 
