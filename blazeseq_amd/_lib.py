@@ -138,6 +138,22 @@ class BzqFastaChunk(C.Structure):
     ]
 
 
+class BzqFastaShardSummary(C.Structure):
+    _fields_ = [("n_bytes", C.c_uint64), ("first_header", C.c_int64), ("lead_kind", C.c_int32), ("last_byte", C.c_int32),
+                ("tail_open", C.c_int64)]
+
+
+class BzqFastaShardPlan(C.Structure):
+    _fields_ = [("stream_pos", C.c_uint64), ("head_bytes", C.c_uint64), ("halo_bytes", C.c_uint64), ("halo_offset", C.c_uint64),
+                ("head_dst", C.c_int32), ("halo_first_src", C.c_int32), ("halo_n_src", C.c_int32), ("is_last", C.c_int32)]
+
+
+class BzqFastaShardResult(C.Structure):
+    _fields_ = [("chunk", BzqFastaChunk), ("plan", BzqFastaShardPlan), ("records_before", C.c_uint64),
+                ("global_records", C.c_uint64), ("first_error_record", C.c_int64), ("stream_status", C.c_int32),
+                ("error_rank", C.c_int32)]
+
+
 FASTA_NO_HEADER, FASTA_EMPTY_SEQUENCE, FASTA_NEED_MORE = 1, 11, 12
 
 SYMBOLS = {
@@ -202,6 +218,10 @@ SYMBOLS = {
                                     C.POINTER(BzqFastaChunk)]),
     "bzq_fasta_format_error": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "bzq_fasta_copy_to_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bzq_fasta_plan_shards": (C.c_int32, [C.POINTER(BzqFastaShardSummary), C.c_int32, C.POINTER(BzqFastaShardPlan)]),
+    "bzq_fasta_shard_scan": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(BzqFastaShardSummary)]),
+    "bzq_fasta_shard_stitch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                           C.POINTER(BzqFastaShardResult)]),
     "bzq_fasta_ingest_open": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p)]),
     "bzq_fasta_ingest_next": (C.c_int32, [C.c_void_p, C.POINTER(BzqFastaChunk), C.POINTER(C.c_uint64)]),
     "bzq_fasta_ingest_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(BzqIngestStats)]),

@@ -2010,4 +2010,6 @@ int32_t bzq_column_histogram(bzq_ctx* c, const uint8_t* d_col, uint64_t n, uint6
     return 0;
 }
 
+#include "bzq_fasta_shard.hpp"
+
 } // extern "C"

@@ -27,7 +27,7 @@ struct bzq_fasta {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::string err;
-    Buf in, seq, id, seq_ends, id_ends, hdr_pos, sums, tile_in, tile_cnt, grp, base, gen_prefix;
+    Buf in, seq, id, seq_ends, id_ends, hdr_pos, sums, tile_in, tile_cnt, grp, base, gen_prefix, probe;
     FaState* d_state = nullptr;
     FaState* h_state = nullptr;   // pinned
     // last chunk
@@ -35,6 +35,8 @@ struct bzq_fasta {
     uint64_t cur_n = 0, stream_pos = 0, line_base = 0, record_base = 0;
     int64_t rec_cap = 0, n_tiles = 0;
     bzq_fasta_chunk res{};
+    int64_t killed = INT64_MAX;   // last chunk with an error: the record that was open when it was met (-1 = before any header)
+    int64_t n_headers = 0;
     std::string message;
 };
 
@@ -134,7 +136,7 @@ void bzq_fasta_destroy(bzq_fasta* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (Buf* b : {&h->in, &h->seq, &h->id, &h->seq_ends, &h->id_ends, &h->hdr_pos, &h->sums, &h->tile_in, &h->tile_cnt, &h->grp,
-                   &h->base, &h->gen_prefix})
+                   &h->base, &h->gen_prefix, &h->probe})
         if (b->p) (void)hipFree(b->p);
     if (h->d_state) (void)hipFree(h->d_state);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -315,9 +317,66 @@ int32_t bzq_fasta_parse(bzq_fasta* h, const uint8_t* data, uint64_t n, int32_t i
         r.seq_bytes = ends[0]; r.id_bytes = ends[1];
     }
     h->res = r;
+    h->killed = code ? killed : INT64_MAX;
+    h->n_headers = H;
     *out = r;
     return 0;
 }
+
+// internal (bzq_api.hip, bzq_fasta_shard_stitch): what this byte range tells the other ranks -- row = {n, first_header
+// (-1 none), lead_kind, tail_open, last_byte} (bzq_fasta.hpp "byte-range shards")
+int32_t bzq_fasta_shard_probe_(bzq_fasta* h, const uint8_t* d, uint64_t n, int64_t row[5]) {
+    if (!h || (n && !d)) return BZQ_ERR_ARG;
+    FACHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->probe, sizeof(ProbeOut)))) return rc;
+    ProbeOut po{};
+    po.first_header = NONE; po.lead_kind = 3; po.tail_open = -1; po.last_byte = 10;
+    if (n > 0) {
+        FACHK(h, hipMemcpyAsync(h->probe.p, &po, sizeof po, hipMemcpyHostToDevice, h->stream));
+        ProbeArgs a{d, (int64_t)n, (ProbeOut*)h->probe.p};
+        const int64_t nt = (int64_t)((n + TILE - 1) / TILE);
+        for (int64_t lo = 0, span = 8; lo < nt; lo += span, span *= 8) {
+            ProbeHdrArgs ha{d, (int64_t)n, (ProbeOut*)h->probe.p, lo};
+            hipLaunchKernelGGL(k_fa_probe_headers, dim3((unsigned)std::min<int64_t>(span, nt - lo)), dim3(BLOCK), 0, h->stream, ha);
+        }
+        hipLaunchKernelGGL(k_fa_probe_edges, dim3(1), dim3(BLOCK), 0, h->stream, a);
+        FACHK(h, hipMemcpyAsync(&po, h->probe.p, sizeof po, hipMemcpyDeviceToHost, h->stream));
+        FACHK(h, hipStreamSynchronize(h->stream));
+        FACHK(h, hipGetLastError());
+    }
+    row[0] = (int64_t)n; row[1] = po.first_header == NONE ? -1 : (int64_t)po.first_header; row[2] = po.lead_kind; row[3] = po.tail_open;
+    row[4] = po.last_byte;
+    return 0;
+}
+
+// internal, cold: '\n' count of d[0, n)
+int32_t bzq_fasta_count_newlines_(bzq_fasta* h, const uint8_t* d, uint64_t n, int64_t* out) {
+    if (!h || !out || (n && !d)) return BZQ_ERR_ARG;
+    *out = 0;
+    if (!n) return 0;
+    FACHK(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->probe, sizeof(ProbeOut)))) return rc;
+    ProbeOut po{};
+    FACHK(h, hipMemcpyAsync(h->probe.p, &po, sizeof po, hipMemcpyHostToDevice, h->stream));
+    ProbeArgs a{d, (int64_t)n, (ProbeOut*)h->probe.p};
+    hipLaunchKernelGGL(k_fa_count_newlines, dim3((unsigned)std::min<uint64_t>((n + BLOCK * 16 - 1) / (BLOCK * 16), 4096)), dim3(BLOCK), 0, h->stream, a);
+    FACHK(h, hipMemcpyAsync(&po, h->probe.p, sizeof po, hipMemcpyDeviceToHost, h->stream));
+    FACHK(h, hipStreamSynchronize(h->stream));
+    *out = po.newlines;
+    return 0;
+}
+int32_t bzq_fasta_shard_scan(bzq_fasta* h, const uint8_t* d_shard, uint64_t n, bzq_fasta_shard_summary* out) {
+    if (!out) return BZQ_ERR_ARG;
+    int64_t row[5];
+    const int32_t rc = bzq_fasta_shard_probe_(h, d_shard, n, row);
+    if (rc) return rc;
+    *out = bzq_fasta_shard_summary{(uint64_t)row[0], row[1], (int32_t)row[2], (int32_t)row[4], row[3]};
+    return 0;
+}
+int64_t bzq_fasta_last_killed_(const bzq_fasta* h) { return h ? h->killed : INT64_MAX; }
+int64_t bzq_fasta_last_headers_(const bzq_fasta* h) { return h ? h->n_headers : 0; }
 
 int32_t bzq_fasta_format_error(bzq_fasta* h, char* buf, size_t cap) {
     if (!h || (cap && !buf)) return BZQ_ERR_ARG;

@@ -616,6 +616,127 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_long_start(LongStartArgs a)
     }
 }
 
+// ---- byte-range shards (bzq_fasta_shard_stitch, bzq_api.hip) ------------------------------------------------------
+// What one rank tells the others about its byte range so that every rank can place the record boundaries (new design;
+// the reference is one sequential LineIterator, buffered.mojo:600-638).  A header line is a line whose first byte that
+// is not a posix space is '>' (parser.mojo:181-203 after _strip_spaces); the line STARTS behind a '\n' (or at the
+// stream's first byte), so a '>' is a header exactly when walking back from it over spaces ends at a '\n'.
+//   first_header  smallest line start (offset behind a '\n' of this range) of a header line whose '>' is in this range; NONE
+//   lead_kind     the bytes before the range's first '\n' (all of it when there is none): 0 the first non-space byte is
+//                 not '>', 1 it is '>', 2 only spaces and then a '\n', 3 only spaces to the end of the range
+//   tail_open     start of the range's last line (behind its last '\n') when that line is non-empty and all spaces so
+//                 far -- whether it is a header line is decided by a later rank's lead_kind; -1 otherwise
+struct ProbeOut { unsigned long long first_header; int64_t lead_kind, tail_open, last_byte, newlines; };
+struct ProbeArgs { const uint8_t* data; int64_t n; ProbeOut* out; };
+
+__device__ __forceinline__ bool is_space_byte(uint32_t c) { return c == 32u || (c - 9u) <= 4u || (c - 28u) <= 2u; }
+
+// every '>' of tiles [tile_lo, tile_lo + gridDim.x).  Launched over growing tile ranges (8, 64, 512, ... tiles): a launch
+// whose predecessors found a header returns at once (a later '>' cannot have an earlier line start: the walk back ends
+// at the first '\n'), so a range with a header in its first kilobytes costs a few empty launches and a range without
+// one is read once at streaming speed.  (One grid over everything with an early-exit flag does not work on this part:
+// the flag is one address polled from 8 XCDs -- 0.45 ms for 2048 workgroups, longer than reading 3 GB.)
+struct ProbeHdrArgs { const uint8_t* data; int64_t n; ProbeOut* out; int64_t tile_lo; };
+static __global__ __launch_bounds__(BLOCK) void k_fa_probe_headers(ProbeHdrArgs a) {
+    __shared__ unsigned long long s_min;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_min = a.out->first_header;   // written by earlier launches only
+    __syncthreads();
+    if (s_min != NONE) return;
+    __syncthreads();
+    const int64_t t0 = (a.tile_lo + blockIdx.x) * TILE;
+    const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+    uint4 r[4];
+    tile_fetch<true>(a.data, a.n, t0, valid, r);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int pos = (tid + BLOCK * s) * 16;
+        uint32_t m = eq_mask16<'>'>(r[s]);
+        const int rem = valid - pos;
+        if (rem < 16) m &= rem > 0 ? ((1u << rem) - 1u) : 0u;
+        while (m) {
+            const int bit = __builtin_ctz(m);
+            m &= m - 1;
+            int64_t q = t0 + pos + bit - 1;
+            while (q >= 0 && a.data[q] != 10 && is_space_byte(a.data[q])) --q;
+            if (q >= 0 && a.data[q] == 10) atomicMin(&s_min, (unsigned long long)(q + 1));
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && s_min != NONE) atomicMin(&a.out->first_header, s_min);
+}
+
+// the two ends of the range, one workgroup: forward to the first '\n' or non-space byte, backward to the last
+struct EdgeScan { int first_nl, first_x, last_nl, last_x; };
+static __global__ __launch_bounds__(BLOCK) void k_fa_probe_edges(ProbeArgs a) {
+    __shared__ EdgeScan s_e;
+    const int tid = threadIdx.x;
+    constexpr int SPAN = BLOCK * 16;
+    int64_t lead_kind = 3;
+    for (int64_t b0 = 0; b0 < a.n; b0 += SPAN) {
+        if (tid == 0) { s_e.first_nl = SPAN; s_e.first_x = SPAN; }
+        __syncthreads();
+        const int64_t pos = b0 + tid * 16;
+        if (pos < a.n) {
+            uint32_t nm, xm;
+            piece_nx(load16(a.data, pos, a.n), nm, xm);
+            const int64_t rem = a.n - pos;
+            if (rem < 16) { nm &= (1u << rem) - 1u; xm &= (1u << rem) - 1u; }
+            if (nm) atomicMin(&s_e.first_nl, tid * 16 + __builtin_ctz(nm));
+            if (xm) atomicMin(&s_e.first_x, tid * 16 + __builtin_ctz(xm));
+        }
+        __syncthreads();
+        const int fn = s_e.first_nl, fx = s_e.first_x;
+        __syncthreads();
+        if (fx < fn) { lead_kind = a.data[b0 + fx] == '>' ? 1 : 0; break; }
+        if (fn < SPAN) { lead_kind = 2; break; }
+    }
+    int64_t tail_open = -1;
+    for (int64_t e0 = a.n; e0 > 0; e0 -= SPAN) {   // the span [e0 - SPAN, e0), clipped at 0
+        if (tid == 0) { s_e.last_nl = -1; s_e.last_x = -1; }
+        __syncthreads();
+        const int64_t b0 = e0 - SPAN, pos = b0 + tid * 16;
+        if (pos + 16 > 0) {
+            uint32_t nm = 0, xm = 0;
+            if (pos >= 0) {
+                piece_nx(load16(a.data, pos, a.n), nm, xm);
+                const int64_t rem = a.n - pos;
+                if (rem < 16) { nm &= (1u << rem) - 1u; xm &= (1u << rem) - 1u; }
+            } else {   // the piece that straddles offset 0: byte by byte
+                for (int k = (int)-pos; k < 16; ++k) {
+                    const uint32_t c = a.data[pos + k];
+                    if (c == 10u) nm |= 1u << k; else if (!is_space_byte(c)) xm |= 1u << k;
+                }
+            }
+            if (nm) atomicMax(&s_e.last_nl, tid * 16 + 31 - __builtin_clz(nm));
+            if (xm) atomicMax(&s_e.last_x, tid * 16 + 31 - __builtin_clz(xm));
+        }
+        __syncthreads();
+        const int ln = s_e.last_nl, lx = s_e.last_x;
+        __syncthreads();
+        if (lx > ln) break;                                    // the last line has a non-space byte
+        if (ln >= 0) { if (b0 + ln + 1 < a.n) tail_open = b0 + ln + 1; break; }   // all spaces behind the last '\n' (none: empty line)
+    }
+    if (tid == 0) {
+        a.out->lead_kind = lead_kind; a.out->tail_open = tail_open;
+        a.out->last_byte = a.n > 0 ? a.data[a.n - 1] : 10;
+    }
+}
+
+// cold path (error text needs stream-global line numbers): '\n' count of [0, n)
+static __global__ __launch_bounds__(BLOCK) void k_fa_count_newlines(ProbeArgs a) {
+    __shared__ int64_t s_r[BLOCK / 64];
+    int64_t c = 0;
+    for (int64_t pos = ((int64_t)blockIdx.x * BLOCK + threadIdx.x) * 16; pos < a.n; pos += (int64_t)gridDim.x * BLOCK * 16) {
+        uint32_t m = eq_mask16<10>(load16(a.data, pos, a.n));
+        const int64_t rem = a.n - pos;
+        if (rem < 16) m &= (1u << rem) - 1u;
+        c += __popc(m);
+    }
+    const int64_t tot = block_sum_i64<BLOCK / 64>(c, s_r);
+    if (threadIdx.x == 0 && tot) atomicAdd((unsigned long long*)&a.out->newlines, (unsigned long long)tot);
+}
+
 // generate_synthetic_fasta_buffer (utils.mojo:1033-1139): one thread per record
 struct FaGenArgs {
     uint8_t* out; int64_t first, count; int32_t min_len, num_digits, line_width; int64_t len_range, period;

@@ -117,6 +117,20 @@ class FastaContext:
         del keep
         return out
 
+    def shard_scan(self, d_ptr: int, n: int) -> L.BzqFastaShardSummary:
+        """What one byte range tells the other ranks (bzq_fasta_shard_scan)."""
+        out = L.BzqFastaShardSummary()
+        self._check(self._lib.bzq_fasta_shard_scan(self._h, C.c_void_p(d_ptr), n, C.byref(out)))
+        return out
+
+    def shard_stitch(self, comm_ctx, d_ptr: int, n: int, capacity: int) -> L.BzqFastaShardResult:
+        """bzq_fasta_shard_stitch: this rank's byte range of the stream -> its records + the global outcome.  comm_ctx: the
+        parser.Context that holds the communicator (comm_init / comm_init_shm), or None for one rank."""
+        out = L.BzqFastaShardResult()
+        ch = comm_ctx.h if comm_ctx is not None else None
+        self._check(self._lib.bzq_fasta_shard_stitch(ch, self._h, C.c_void_p(d_ptr), n, capacity, C.byref(out)))
+        return out
+
     def error_text(self) -> bytes:
         n = self._lib.bzq_fasta_format_error(self._h, None, 0)
         buf = C.create_string_buffer(n + 1)

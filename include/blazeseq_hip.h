@@ -489,6 +489,56 @@ int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* g, bzq_fasta_chunk* out, uint64_
 int32_t bzq_fasta_ingest_get_stats(const bzq_fasta_ingest* g, bzq_ingest_stats* out);
 void bzq_fasta_ingest_close(bzq_fasta_ingest* g);
 
+/* ---- FASTA over byte-range shards (SURVEY.md 8e applied to the 8f rank-4 parser) ----------------------------------
+ * New design, the reference is one sequential FastaParser (blazeseq/fasta/parser.mojo:122-203).  The stream is cut into
+ * contiguous BYTE ranges, rank r holds range r.  A record belongs to the rank in whose range its header LINE starts; the
+ * bytes in front of a rank's first header line (its "head") are the rest of a record an earlier rank owns and travel to
+ * that rank (its "halo") -- as many ranks' worth as the record is long.  The stream's first rank owns from offset 0.
+ * Every owner then parses [first header line, end of range + halo) as one complete stream: the result over all ranks is
+ * the sequential parser's, records in rank order. */
+typedef struct bzq_fasta_shard_summary {
+    uint64_t n_bytes;
+    int64_t first_header;   /* start of the first header line that begins behind a '\n' of this range and shows its '>' in it; -1 */
+    int32_t lead_kind;      /* bytes in front of the first '\n' (all, when there is none): 0 first non-space byte is not '>',
+                             * 1 it is '>', 2 only spaces and then the '\n', 3 only spaces to the end of the range */
+    int32_t last_byte;      /* 10 for an empty range */
+    int64_t tail_open;      /* start of the last line when it is non-empty and all spaces so far (a later rank's lead decides
+                             * whether it is a header line); -1 otherwise */
+} bzq_fasta_shard_summary;
+
+typedef struct bzq_fasta_shard_plan {
+    uint64_t stream_pos;       /* stream offset of the range's first byte */
+    uint64_t head_bytes;       /* leading bytes that belong to a record of rank head_dst (n_bytes: the rank owns nothing) */
+    uint64_t halo_bytes;       /* bytes received behind the own ones */
+    uint64_t halo_offset;      /* where this rank's head lands in its owner's halo */
+    int32_t head_dst;          /* -1 = no head */
+    int32_t halo_first_src, halo_n_src;   /* the halo is the heads of ranks [first, first + n) that name this rank */
+    int32_t is_last;           /* the stream's last owner */
+} bzq_fasta_shard_plan;
+
+/* Pure function of the gathered summaries (CPU-testable). */
+int32_t bzq_fasta_plan_shards(const bzq_fasta_shard_summary* all, int32_t nranks, bzq_fasta_shard_plan* out);
+/* Summary of one device-resident range. */
+int32_t bzq_fasta_shard_scan(bzq_fasta* h, const uint8_t* d_shard, uint64_t n, bzq_fasta_shard_summary* out);
+
+typedef struct bzq_fasta_shard_result {
+    bzq_fasta_chunk chunk;        /* this rank's records; chunk.status is the rank's own (BZQ_EOF = its range parsed clean) */
+    bzq_fasta_shard_plan plan;
+    uint64_t records_before;      /* global index of this rank's record 0 */
+    uint64_t global_records;      /* records the sequential parser delivers before it stops */
+    int64_t first_error_record;   /* global index at which the stream fails, -1 = none */
+    int32_t stream_status;        /* BZQ_EOF, or the code the sequential parser raises (its text: bzq_fasta_format_error on
+                                   * rank error_rank, with stream-global record / line / position numbers) */
+    int32_t error_rank;           /* -1 = none */
+} bzq_fasta_shard_result;
+
+/* probe -> summary all-gather -> plan -> heads to their owners -> parse -> outcome all-gather, over the communicator of
+ * `comm_ctx` (bzq_comm_init / bzq_comm_init_shm; NULL or no communicator = one rank).  d_shard: `capacity` >= n + halo
+ * bytes of device memory with the rank's n bytes at its start.  Collective.  A rank behind the stream's first error keeps
+ * chunk.n_records = 0. */
+int32_t bzq_fasta_shard_stitch(bzq_ctx* comm_ctx, bzq_fasta* h, uint8_t* d_shard, uint64_t n, uint64_t capacity,
+                               bzq_fasta_shard_result* out);
+
 /* generate_synthetic_fasta_buffer (blazeseq/utils.mojo:1033-1139), records [first, first+count) of a num_reads-record
  * file, written into device memory.  d_out == NULL only sizes. */
 int32_t bzq_fasta_generate_synthetic_device(bzq_fasta* h, int64_t num_reads, int64_t first, int64_t count, int32_t min_len,

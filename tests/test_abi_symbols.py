@@ -34,7 +34,9 @@ def test_struct_sizes_match_header(tmp_path):
                "bzq_host_batch": _lib.BzqHostBatch, "bzq_shard_summary": _lib.BzqShardSummary,
                "bzq_ingest_stats": _lib.BzqIngestStats, "bzq_shard_plan": _lib.BzqShardPlan,
                "bzq_shard_result": _lib.BzqShardResult, "bzq_nccl_id": _lib.BzqNcclId,
-               "bzq_fasta_config": _lib.BzqFastaConfig, "bzq_fasta_chunk": _lib.BzqFastaChunk}
+               "bzq_fasta_config": _lib.BzqFastaConfig, "bzq_fasta_chunk": _lib.BzqFastaChunk,
+               "bzq_fasta_shard_summary": _lib.BzqFastaShardSummary, "bzq_fasta_shard_plan": _lib.BzqFastaShardPlan,
+               "bzq_fasta_shard_result": _lib.BzqFastaShardResult}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "blazeseq_hip.h"', "int main(void) {"]
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -1,0 +1,76 @@
+"""bzq_fasta_plan_shards (C ABI, blazeseq_amd/csrc/bzq_fasta_shard.hpp) without a GPU: byte ranges cut ANYWHERE, the
+planner's cuts + the outcome rules of bzq_fasta_shard_stitch (restated in tests/fasta_shard_model.py) with the oracle as
+the parser of each owner's region must give the sequential parse of the whole stream: records, status and error text."""
+import numpy as np
+import pytest
+
+from oracle import fasta as FO
+from tests.fasta_fuzz import rand_fasta, rand_soup
+from tests.fasta_shard_model import stitch, summary_of, c_plan
+
+
+def check(data: bytes, cuts, check_ascii=False, line_cap=FO.DEFAULT_CAPACITY):
+    a = np.frombuffer(data, dtype=np.uint8)
+    whole = FO.flat_parse(a, check_ascii=check_ascii, line_cap=line_cap)
+    recs, status, msg = stitch(a, cuts, check_ascii, line_cap)
+    assert recs == whole.records(), (cuts, len(recs), whole.n_records)
+    assert status == whole.status, (cuts, status, whole.status)
+    if whole.status != 6:
+        assert msg == whole.message, (cuts, msg, whole.message)
+
+
+def test_every_cut_of_a_small_stream():
+    data = b"\n  \n>a 1\nACGT\nAC\n \t>b\nTT\n\n>c\n  G  \n>d x\nA"
+    for c in range(len(data) + 1):
+        check(data, [c])
+    for c in range(0, len(data), 3):
+        for d in range(c, len(data) + 1, 2):
+            check(data, [c, d])
+
+
+def test_every_cut_with_errors():
+    for data in (b">a\nAC\n>b\n>c\nA\n", b"ACGT\n>a\nA\n", b">a\nAC\n>b\n", b">a\n\x80\n>b\nA\n", b">a\nAC\n   >\x85b\nAA\n>c\nG\n",
+                 b"   \n\n", b"", b">", b">a\n", b"\n>a\nA"):
+        for c in range(len(data) + 1):
+            check(data, [c], check_ascii=True)
+            check(data, [c, min(len(data), c + 2)], check_ascii=True)
+
+
+def test_long_header_line_kills_the_open_record_of_the_previous_owner():
+    cap = 16
+    # the record before a too-long header line is not delivered; when it would ALSO fail validation, the long line wins
+    for data in (b">a\nAC\n>bbbbbbbbbbbbbbbbbbbbbbbb\nA\n", b">a\nAC\n>b\n>cccccccccccccccccccccc\nA\n", b">a\nAC\n>b\nGGGGGGGGGGGGGGGGGGGGGGGG\n>c\nA\n",
+                 b">a\nAC\n   \n   >bbbbbbbbbbbbbbbbbbbbb\nA\n"):
+        for c in range(len(data) + 1):
+            check(data, [c], line_cap=cap)
+            for d in range(c, len(data) + 1):
+                check(data, [c, d], line_cap=cap)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_cuts(seed):
+    rng = np.random.default_rng(seed)
+    kind = seed % 4
+    if kind == 0:
+        data = rand_fasta(rng, n_records=int(rng.integers(1, 30)), crlf=bool(rng.random() < 0.3), tail_newline=bool(rng.random() < 0.7))
+    elif kind == 1:
+        data = rand_fasta(rng, n_records=int(rng.integers(1, 30)), dirty=0.15, lead_blank=int(rng.integers(0, 3)))
+    else:
+        data = rand_soup(rng, int(rng.integers(1, 400)))
+    cap = int(rng.choice([FO.DEFAULT_CAPACITY, 24, 60]))
+    for _ in range(12):
+        P = int(rng.integers(2, 7))
+        cuts = sorted(int(x) for x in rng.integers(0, len(data) + 1, P - 1))
+        check(data, cuts, check_ascii=bool(rng.random() < 0.5), line_cap=cap)
+
+
+def test_plan_fields():
+    data = np.frombuffer(b">a\nAC\nGT\n>b\nTT\n", dtype=np.uint8)
+    shards = [data[:4], data[4:8], data[8:8], data[8:]]   # ">a\nA" | "C\nGT" | "" | "\n>b\nTT\n"
+    plans = c_plan([summary_of(s) for s in shards])
+    assert [p.head_bytes for p in plans] == [0, 4, 0, 1]
+    assert [p.head_dst for p in plans] == [-1, 0, -1, 0]
+    assert plans[0].halo_bytes == 5 and plans[0].halo_first_src == 1 and plans[0].halo_n_src == 3
+    assert [p.halo_offset for p in plans] == [0, 0, 0, 4]
+    assert [p.is_last for p in plans] == [0, 0, 0, 1]
+    assert [p.stream_pos for p in plans] == [0, 4, 8, 8]
