@@ -210,13 +210,15 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_tile_sums(SumsArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[LDS_TILE];
     __shared__ uint32_t s_slot[4][BLOCK / 64];
     __shared__ u64 s_hasN[BLOCK / 64], s_hasE[BLOCK / 64];
-    __shared__ uint32_t s_acc[BLOCK / 64][6];
+    __shared__ uint32_t s_acc[BLOCK / 64][2];
+    __shared__ uint32_t s_anyx[BLOCK / 64], s_edge[4];
     __shared__ uint32_t s_end;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t t = blockIdx.x, t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     uint4 r[4], own[4];
     tile_fetch<true>(a.data, a.n, t0, valid, r);
+    if (tid < 4) s_edge[tid] = 0u;
     tile_to_own(r, s_tile, own);
     const Masks m = own_masks<false>(own, valid);
     const u64 E = m.N | m.X;
@@ -235,34 +237,44 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_tile_sums(SumsArgs a) {
     const int pos0 = tid * 64;
     u64 vmask = ~0ull;   // bytes of this thread that exist
     if (valid != TILE) { const int rem = valid - pos0; vmask = rem >= 64 ? ~0ull : (rem > 0 ? ((1ull << rem) - 1ull) : 0ull); }
+    auto pc = [](u64 x) { return (uint32_t)__builtin_popcountll(x); };
     auto below_first = [](u64 x) { return x ? ((x & (0 - x)) - 1ull) : ~0ull; };                     // bits under the lowest set bit
     auto above_last = [](u64 x) { return x ? ((x >> 63) ? 0ull : (~0ull << (64 - __builtin_clzll(x)))) : ~0ull; };
-    const u64 M1 = n_before ? 0ull : (below_first(m.N) & vmask);
-    const u64 M2 = n_after ? 0ull : (above_last(m.N) & vmask);
-    const u64 MT = e_after ? 0ull : (above_last(E) & vmask);
-    auto pc = [](u64 x) { return (uint32_t)__builtin_popcountll(x); };
-    // twelve counts, each <= 64 per thread and <= 16384 per tile: two per dword, summed over the wave on DPP
-    uint32_t w[6] = {pc(f.seq) | (pc(f.id) << 16), pc(f.FG) | (pc(m.N) << 16), pc(f.seq & M1) | (pc(f.id & M1) << 16),
-                     pc(f.Sa_incl & M1) | (pc(f.Sb_incl & f.Sa_incl & M1) << 16), pc(M1) | (pc(M2) << 16),
-                     pc(MT) | ((pc(f.FG & M1) + ((uint32_t)(m.X != 0) << 1)) << 16)};
+    // twelve counts, each <= 64 per thread and <= 16384 per tile, two per dword.  Four are sums over every thread (DPP scan per
+    // wave); the eight edge counts live in the few threads in front of the tile's first '\n' and behind its last event: only
+    // those lanes add theirs to LDS, and a wave without such a lane (waves 1 and 2, with lines shorter than 4 KiB) skips them.
+    uint32_t w[2] = {pc(f.seq) | (pc(f.id) << 16), pc(f.FG) | (pc(m.N) << 16)};
+    if (!n_before) {
+        const u64 M1 = below_first(m.N) & vmask;
+        if (M1) {
+            atomicAdd(&s_edge[0], pc(f.seq & M1) | (pc(f.id & M1) << 16));
+            atomicAdd(&s_edge[1], pc(f.Sa_incl & M1) | (pc(f.Sb_incl & f.Sa_incl & M1) << 16));
+            atomicAdd(&s_edge[2], pc(M1));
+            if (f.FG & M1) atomicAdd(&s_edge[3], pc(f.FG & M1) << 16);
+        }
+    }
+    if (!n_after) { const u64 M2 = above_last(m.N) & vmask; if (M2) atomicAdd(&s_edge[2], pc(M2) << 16); }
+    if (!e_after) { const u64 MT = above_last(E) & vmask; if (MT) atomicAdd(&s_edge[3], pc(MT)); }
+    const bool wave_anyx = __ballot(m.X != 0) != 0;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
+    for (int k = 0; k < 2; ++k) {
         w[k] = dpp_scan_u32(w[k]);
         if (lane == 63) s_acc[wave][k] = w[k];
     }
+    if (lane == 63) s_anyx[wave] = wave_anyx;
     if (tid == BLOCK - 1) s_end = state_of(f.end_sb, f.end_hdr, f.end_x2);
     const uint32_t lead_x = (uint32_t)(f.Sa_incl & 1ull);   // thread 0: an X comes before the first '\n'
     __syncthreads();
     if (tid == 0) {
-        uint32_t t6[6];
+        uint32_t t6[6] = {0u, 0u, s_edge[0], s_edge[1], s_edge[2], s_edge[3]};
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            t6[k] = 0;
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int i = 0; i < BLOCK / 64; ++i) t6[k] += s_acc[i][k];
-        }
-        const u64 c0hdr_anyx = t6[5] >> 16;
-        const u64 flags = (c0hdr_anyx & 1ull) | ((u64)((c0hdr_anyx >> 1) != 0) << 1) | ((u64)lead_x << 2) | ((u64)s_end << 3);
+        uint32_t anyx = 0;
+#pragma unroll
+        for (int i = 0; i < BLOCK / 64; ++i) anyx |= s_anyx[i];
+        const u64 flags = (u64)((t6[5] >> 16) & 1u) | ((u64)(anyx != 0u) << 1) | ((u64)lead_x << 2) | ((u64)s_end << 3);
         a.sums[3 * t + 0] = (u64)(t6[0] & 0xFFFF) | ((u64)(t6[0] >> 16) << 16) | ((u64)(t6[1] & 0xFFFF) << 32) | ((u64)(t6[1] >> 16) << 48);
         a.sums[3 * t + 1] = (u64)(t6[2] & 0xFFFF) | ((u64)(t6[2] >> 16) << 16) | ((u64)(t6[3] & 0xFFFF) << 32) | ((u64)(t6[3] >> 16) << 48);
         a.sums[3 * t + 2] = (u64)(t6[4] & 0xFFFF) | ((u64)(t6[4] >> 16) << 16) | ((u64)(t6[5] & 0xFFFF) << 32) | (flags << 48);
