@@ -137,6 +137,7 @@ def fasta_main(args, world, rank, local_rank, dev, distributed):
             if world > 1:
                 dist.broadcast_object_list(box, src=0)
             comm_ctx.comm_init(rank, world, box[0])
+            comm_ctx.comm_selftest()   # one checked ring exchange: a transport that does not work shows here, not inside the timed steps
             sharded = "byte ranges"
         except Exception as e:   # noqa: BLE001 -- said out loud in the JSON line, never silent
             sharded = None
@@ -366,6 +367,7 @@ def main():
                 if world > 1:
                     dist.broadcast_object_list(box, src=0)
                 ctx.comm_init(rank, world, box[0])
+                ctx.comm_selftest()   # one checked ring exchange (send/recv + all-gather) before anything is timed
             except Exception as e:   # noqa: BLE001 -- said out loud in the JSON line, never silent
                 exchange = f"torch (native communicator failed: {str(e)[:200]})"
                 print(f"[bench] rank {rank}: {exchange}", file=sys.stderr)

@@ -190,6 +190,7 @@ SYMBOLS = {
     "bzq_comm_get_unique_id": (C.c_int32, [C.POINTER(BzqNcclId)]),
     "bzq_comm_init": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "bzq_comm_init_shm": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_char_p, C.c_uint64]),
+    "bzq_comm_selftest": (C.c_int32, [C.c_void_p]),
     "bzq_comm_destroy": (C.c_int32, [C.c_void_p]),
     "bzq_plan_shards": (C.c_int32, [C.POINTER(BzqShardSummary), C.c_int32, C.POINTER(BzqShardPlan)]),
     "bzq_shard_stitch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(BzqShardResult)]),

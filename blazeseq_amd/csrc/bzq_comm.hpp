@@ -276,6 +276,64 @@ int32_t bzq_comm_init_shm(bzq_ctx* c, int32_t rank, int32_t nranks, const char* 
     return shm_barrier(c, m);   // everybody is attached (rank 0 may unlink the name only after all have opened it)
 }
 
+// One ring exchange through the communicator's transport, data checked: rank r sends a 4 KiB pattern to rank r+1 and expects
+// rank r-1's (at one rank: to itself), then an all-gather of the verdicts.  A host calls it once after bzq_comm_init, so that a
+// transport that does not work is reported before the first real step instead of inside it.
+static __global__ void k_selftest_fill(uint32_t* p, uint32_t seed, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = seed * 2654435761u + (uint32_t)i * 40503u;
+}
+static __global__ void k_selftest_check(const uint32_t* p, uint32_t seed, int n, int* bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && p[i] != seed * 2654435761u + (uint32_t)i * 40503u) atomicAdd(bad, 1);
+}
+
+int32_t bzq_comm_selftest(bzq_ctx* c) {
+    if (!c) return BZQ_ERR_ARG;
+    bzq_comm* m = c->comm;
+    if (!m) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    constexpr int WORDS = 1024;
+    const int P = m->nranks, me = m->rank, to = (me + 1) % P, from = (me + P - 1) % P;
+    uint32_t* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, 2 * WORDS * 4 + 16));
+    int* d_bad = (int*)(d + 2 * WORDS);
+    int bad = 0, rc = 0;
+    hipLaunchKernelGGL(k_selftest_fill, dim3(WORDS / 256), dim3(256), 0, c->stream, d, (uint32_t)(me + 1), WORDS);
+    (void)hipMemsetAsync(d + WORDS, 0, WORDS * 4 + 16, c->stream);
+    if (m->kind == 1) {
+        auto ex = [&]() -> int {
+            NCCLCHK(c, m, m->p_GroupStart());
+            NCCLCHK(c, m, m->p_Send(d, WORDS * 4, NCCL_U8, to, m->nccl, c->stream));
+            NCCLCHK(c, m, m->p_Recv(d + WORDS, WORDS * 4, NCCL_U8, from, m->nccl, c->stream));
+            NCCLCHK(c, m, m->p_GroupEnd());
+            return 0;
+        };
+        rc = ex();
+    } else {
+        if (WORDS * 4 > (int)m->halo_cap) { (void)hipFree(d); c->err = "bzq_comm_selftest: halo capacity below 4 KiB"; return BZQ_ERR_ARG; }
+        if (hipMemcpy(shm_halo(m, me), d, WORDS * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = BZQ_ERR_HIP;
+        if (!rc) rc = shm_barrier(c, m);
+        if (!rc && hipMemcpy(d + WORDS, shm_halo(m, from), WORDS * 4, hipMemcpyHostToDevice) != hipSuccess) rc = BZQ_ERR_HIP;
+        if (!rc) rc = shm_barrier(c, m);
+    }
+    if (!rc) {
+        hipLaunchKernelGGL(k_selftest_check, dim3(WORDS / 256), dim3(256), 0, c->stream, d + WORDS, (uint32_t)(from + 1), WORDS, d_bad);
+        if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = BZQ_ERR_HIP;
+    }
+    (void)hipFree(d);
+    if (rc) return rc;
+    int64_t row[COMM_ROW] = {bad, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<int64_t> all((size_t)P * COMM_ROW);
+    if ((rc = comm_gather(c, row, all.data()))) return rc;
+    for (int r = 0; r < P; ++r)
+        if (all[(size_t)r * COMM_ROW] != 0) {
+            c->err = "bzq_comm_selftest: rank " + std::to_string(r) + " received " + std::to_string(all[(size_t)r * COMM_ROW]) + " wrong words from rank " + std::to_string((r + P - 1) % P);
+            return BZQ_ERR_IO;
+        }
+    return 0;
+}
+
 // ---- the protocol ---------------------------------------------------------------------------------------------------------
 
 int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capacity, bzq_shard_result* out) {

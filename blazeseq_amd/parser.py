@@ -253,6 +253,10 @@ class Context:
     def comm_init_shm(self, rank: int, nranks: int, name: str, halo_capacity: int = 0):
         _check(self.h, L.lib().bzq_comm_init_shm(self.h, rank, nranks, name.encode(), halo_capacity), "bzq_comm_init_shm")
 
+    def comm_selftest(self):
+        """One checked ring exchange + all-gather over the communicator (collective)."""
+        _check(self.h, L.lib().bzq_comm_selftest(self.h), "bzq_comm_selftest")
+
     def comm_destroy(self):
         _check(self.h, L.lib().bzq_comm_destroy(self.h), "bzq_comm_destroy")
 

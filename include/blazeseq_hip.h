@@ -308,6 +308,10 @@ int32_t bzq_comm_init(bzq_ctx* ctx, int32_t rank, int32_t nranks, const void* nc
  * it at bzq_comm_destroy; a segment left behind by a crashed job of the same name is replaced). */
 int32_t bzq_comm_init_shm(bzq_ctx* ctx, int32_t rank, int32_t nranks, const char* name, uint64_t halo_capacity);
 int32_t bzq_comm_destroy(bzq_ctx* ctx);
+/* One ring exchange over the communicator with the data checked on arrival (rank r -> r+1; one rank: to itself) and an
+ * all-gather of the verdicts: call it once after bzq_comm_init* so that a transport that does not work is reported before the
+ * first step, not inside it.  Collective.  0 = every rank received what its neighbour sent. */
+int32_t bzq_comm_selftest(bzq_ctx* ctx);
 
 /* What a rank skips, sends and receives; a pure function of the gathered summaries (bzq_plan_shards). */
 typedef struct bzq_shard_plan {

@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
     } else if ((rc = bzq_comm_init_shm(ctx, rank, nranks, argv[4], 0)) != 0) {
         fprintf(stderr, "bzq_comm_init_shm failed (%d): %s\n", rc, bzq_last_error(ctx)); return 3;
     }
+    if ((rc = bzq_comm_selftest(ctx)) != 0) { fprintf(stderr, "bzq_comm_selftest failed (%d): %s\n", rc, bzq_last_error(ctx)); return 3; }
     bzq_fasta_config fc;
     memset(&fc, 0, sizeof fc);
     fc.check_ascii = check; fc.line_capacity = linecap;

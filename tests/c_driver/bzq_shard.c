@@ -72,6 +72,8 @@ int main(int argc, char** argv) {
         if ((rc = bzq_comm_init_shm(ctx, rank, nranks, argv[4], 0)) != 0) die(ctx, "bzq_comm_init_shm", rc);
     }
 
+    if ((rc = bzq_comm_selftest(ctx)) != 0) die(ctx, "bzq_comm_selftest", rc);
+
     const uint64_t capacity = n + (4u << 20);   /* room for the halo */
     void* d_shard = NULL;
     if ((rc = bzq_device_alloc(ctx, capacity, &d_shard)) != 0) die(ctx, "bzq_device_alloc", rc);
