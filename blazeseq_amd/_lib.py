@@ -138,6 +138,10 @@ class BzqFastaChunk(C.Structure):
     ]
 
 
+class BzqBgzfBlock(C.Structure):
+    _fields_ = [("comp_offset", C.c_uint64), ("comp_size", C.c_uint32), ("out_size", C.c_uint32), ("out_offset", C.c_uint64)]
+
+
 class BzqFastaShardSummary(C.Structure):
     _fields_ = [("n_bytes", C.c_uint64), ("first_header", C.c_int64), ("lead_kind", C.c_int32), ("last_byte", C.c_int32),
                 ("tail_open", C.c_int64)]
@@ -219,6 +223,9 @@ SYMBOLS = {
                                     C.POINTER(BzqFastaChunk)]),
     "bzq_fasta_format_error": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "bzq_fasta_copy_to_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bzq_bgzf_scan": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(BzqBgzfBlock), C.c_int64, C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "bzq_bgzf_inflate": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(BzqBgzfBlock), C.c_int64, C.c_void_p, C.c_uint64]),
     "bzq_fasta_plan_shards": (C.c_int32, [C.POINTER(BzqFastaShardSummary), C.c_int32, C.POINTER(BzqFastaShardPlan)]),
     "bzq_fasta_shard_scan": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(BzqFastaShardSummary)]),
     "bzq_fasta_shard_stitch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,

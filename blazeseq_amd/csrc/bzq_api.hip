@@ -110,7 +110,7 @@ struct bzq_ctx {
     int64_t n_submits = 0;
     int double_buffer = 1;   // option "double_buffer": 0 = one set (results valid until the next submit), half the memory
     hipStream_t consumer_stream = nullptr;   // bzq_set_consumer_stream: where the bzq_batch_* / bzq_column_* kernels run (default: the ctx stream)
-    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, qpos_scratch, gen_prefix, entries, tile_list, tile_vf;
+    DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, qpos_scratch, gen_prefix, entries, tile_list, tile_vf, inflate_tab;
     int64_t tile_cap = 0;
     ChunkState* d_state = nullptr;
     ChunkState* h_state = nullptr; // pinned
@@ -123,6 +123,7 @@ struct bzq_ctx {
     int views_bytes = 0;   // option: views mode through the two-read kernels even without validation (cross-check)
     int force_dense = 0, timing_detail = 0, single_pass = 0, v2 = 1, num_cu = 256;
     bool ran_single_pass = false;
+    int ingest_gpu_inflate = 1;               // option "ingest_gpu_inflate": BGZF blocks are inflated on the device (bzq_inflate.hpp), 0 = on the reader threads
     int ingest_direct = 0, ingest_numa = 1;   // options "ingest_direct" (O_DIRECT reads), "ingest_numa" (bind readers to the GPU's node)
     int pass_a_h = 1;          // option "pass_a_h": pass A from the newline bitmap alone (k_tile_aggregate_h), verified by the emit
     bool exact_pass_a = false; // this chunk is being repeated with the exact pass A
@@ -762,6 +763,7 @@ void sb_put(std::string& s, const char* label, long long v) {
 // ================================================================================== C ABI
 
 #include "bzq_consumers.hpp"
+#include "bzq_inflate.hpp"
 #include "bzq_ingest.hpp"
 
 extern "C" {
@@ -861,7 +863,7 @@ void bzq_destroy(bzq_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)bzq_comm_destroy(c);
     std::vector<DevBuf*> bufs = {&c->in, &c->tile_c, &c->tile_a, &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc,
-                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf};
+                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf, &c->inflate_tab};
     for (OutSet& o : c->out) {
         for (DevBuf* b : {&o.seq, &o.qual, &o.id, &o.ends, &o.id_ends, &o.rec_end, &o.b_ends, &o.b_id_ends, &o.off[0], &o.off[1],
                           &o.off[2], &o.off[3], &o.id_start, &o.id_len, &o.bb})
@@ -922,6 +924,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "pass_a_h")) c->pass_a_h = value != 0;
     else if (!strcmp(key, "ingest_direct")) c->ingest_direct = value != 0;
     else if (!strcmp(key, "ingest_numa")) c->ingest_numa = value != 0;
+    else if (!strcmp(key, "ingest_gpu_inflate")) c->ingest_gpu_inflate = value != 0;
     else if (!strcmp(key, "double_buffer")) {
         if (c->pending) { c->err = "double_buffer cannot change while a chunk is in flight"; return BZQ_ERR_ARG; }
         c->double_buffer = value != 0;
@@ -941,6 +944,63 @@ int32_t bzq_pinned_alloc(size_t bytes, void** out) {
     return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? 0 : BZQ_ERR_NOMEM;
 }
 int32_t bzq_pinned_free(void* p) { return hipHostFree(p) == hipSuccess ? 0 : BZQ_ERR_HIP; }
+
+// ---- BGZF inflate on the device (bzq_inflate.hpp) -------------------------------------------------------------------------
+
+int32_t bzq_bgzf_scan(const uint8_t* comp, uint64_t n, uint64_t max_out, bzq_bgzf_block* blocks, int64_t cap, int64_t* n_blocks,
+                      uint64_t* consumed, uint64_t* out_bytes) {
+    if (!comp && n) return BZQ_ERR_ARG;
+    if (!n_blocks || !consumed || !out_bytes || (cap > 0 && !blocks)) return BZQ_ERR_ARG;
+    int64_t k = 0;
+    uint64_t off = 0, usum = 0;
+    while (off + 28 <= n && k < cap) {
+        const uint32_t bs = bzq::bgzf_block_size(comp + off);
+        if (!bs || bs < 26) { *n_blocks = k; *consumed = off; *out_bytes = usum; return BZQ_ERR_IO; }
+        if (off + bs > n) break;   // the block is not whole yet
+        const uint8_t* t = comp + off + bs - 4;
+        const uint32_t us = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (us > 65536) { *n_blocks = k; *consumed = off; *out_bytes = usum; return BZQ_ERR_IO; }
+        if (usum + us > max_out) break;
+        blocks[k++] = bzq_bgzf_block{off, bs, us, usum};
+        usum += us; off += bs;
+    }
+    *n_blocks = k; *consumed = off; *out_bytes = usum;
+    return 0;
+}
+
+int32_t bzq_bgzf_inflate(bzq_ctx* c, const uint8_t* d_comp, uint64_t comp_bytes, const bzq_bgzf_block* blocks, int64_t n_blocks,
+                         uint8_t* d_out, uint64_t out_capacity) {
+    if (!c || n_blocks < 0 || (n_blocks && (!d_comp || !blocks || !d_out))) return BZQ_ERR_ARG;
+    if (n_blocks == 0) return 0;
+    HIPCHK(c, hipSetDevice(c->device));
+    std::vector<bzq::inf::DevBlock> hb((size_t)n_blocks);
+    for (int64_t i = 0; i < n_blocks; ++i) {
+        const bzq_bgzf_block& b = blocks[i];
+        if (b.comp_size < 26 || b.comp_offset + b.comp_size > comp_bytes || b.out_size > 65536 || b.out_offset + b.out_size > out_capacity) {
+            c->err = "bzq_bgzf_inflate: block " + std::to_string(i) + " lies outside the buffers";
+            return BZQ_ERR_ARG;
+        }
+        hb[(size_t)i] = bzq::inf::DevBlock{b.comp_offset + 18, b.out_offset, b.comp_size - 26, b.out_size};
+    }
+    int rc;
+    const size_t tbytes = (size_t)n_blocks * sizeof(bzq::inf::DevBlock);
+    if ((rc = ensure(c, c->inflate_tab, tbytes + 16))) return rc;
+    unsigned long long* d_bad = (unsigned long long*)((uint8_t*)c->inflate_tab.p + ((tbytes + 7) & ~(size_t)7));
+    const unsigned long long none = ~0ull;
+    HIPCHK(c, hipMemcpyAsync(c->inflate_tab.p, hb.data(), tbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(d_bad, &none, 8, hipMemcpyHostToDevice, c->stream));
+    bzq::inf::Args a{d_comp, comp_bytes, (const bzq::inf::DevBlock*)c->inflate_tab.p, n_blocks, d_out, d_bad};
+    hipLaunchKernelGGL(bzq::inf::k_bgzf_inflate, dim3((unsigned)((n_blocks + bzq::inf::WAVES - 1) / bzq::inf::WAVES)), dim3(BLOCK), 0, c->stream, a);
+    unsigned long long bad = none;
+    HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    if (bad != none) {
+        c->err = "BGZF block " + std::to_string(bad) + " failed to inflate (corrupt or truncated file)";
+        return BZQ_ERR_IO;
+    }
+    return 0;
+}
 
 int32_t bzq_device_alloc(bzq_ctx* c, size_t bytes, void** out) {
     if (!c || !out) return BZQ_ERR_ARG;
@@ -1582,7 +1642,7 @@ static void gpu_numa_cpus(int device, int* node_out, std::vector<int>& cpus) {
 }
 
 static int32_t ingest_open_common(int device, std::string& err, const char* who, const char* path, uint64_t chunk_bytes,
-                                  int32_t n_threads, bzq_ingest** out, int direct = 0, int numa = 1) {
+                                  int32_t n_threads, bzq_ingest** out, int direct = 0, int numa = 1, int gpu_inflate = 1) {
     *out = nullptr;
     if (hipSetDevice(device) != hipSuccess) { err = std::string(who) + ": hipSetDevice failed"; return BZQ_ERR_HIP; }
     const int fd = open(path, O_RDONLY);
@@ -1621,6 +1681,22 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
     if (g->file_size >= 18 && pread(fd, magic, 18, 0) == 18 && magic[0] == 0x1f && magic[1] == 0x8b) {
         if (bzq::bgzf_block_size(magic)) {
             g->compression = 2;
+            if (gpu_inflate) {   // the compressed bytes travel, the device inflates (bzq_inflate.hpp)
+                g->tab_cap = (int64_t)(g->chunk_bytes / 2048) + 4096;
+                bool gok = hipHostMalloc((void**)&g->bad_pinned, 2 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess &&
+                           hipMalloc((void**)&g->bad_dev, 2 * sizeof(unsigned long long)) == hipSuccess;
+                for (int i = 0; i < 2 && gok; ++i)
+                    gok = hipMalloc((void**)&g->comp_dev[i], g->chunk_bytes + 64) == hipSuccess &&
+                          hipMalloc((void**)&g->tab_dev[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16) == hipSuccess &&
+                          hipHostMalloc((void**)&g->tab_pinned[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16, hipHostMallocDefault) == hipSuccess;
+                if (!gok) {
+                    err = std::string(who) + ": allocating the buffers of the device inflate failed";
+                    bzq::ingest_free(g);
+                    return BZQ_ERR_NOMEM;
+                }
+                g->bad_pinned[0] = g->bad_pinned[1] = ~0ull;
+                g->gpu_inflate = 1;
+            }
         } else {
             g->compression = 1;
             const int fd2 = dup(fd);
@@ -1664,7 +1740,8 @@ static int ingest_place(bzq_ingest* g, int64_t k, uint64_t carry, hipStream_t qu
 
 int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int32_t n_threads, bzq_ingest** out) {
     if (!c || !path || !out) return BZQ_ERR_ARG;
-    const int32_t rc = ingest_open_common(c->device, c->err, "bzq_ingest_open", path, chunk_bytes, n_threads, out, c->ingest_direct, c->ingest_numa);
+    const int32_t rc = ingest_open_common(c->device, c->err, "bzq_ingest_open", path, chunk_bytes, n_threads, out, c->ingest_direct, c->ingest_numa,
+                                          c->ingest_gpu_inflate);
     if (rc == 0) (*out)->ctx = c;
     return rc;
 }
@@ -1734,6 +1811,11 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
     rc = bzq_chunk_result(c, out);
     g->stats.wait_s += bzq::seconds_since(tw);
     if (rc < 0) return rc;
+    if (g->gpu_inflate && g->bad_pinned[k & 1] != ~0ull) {   // (the stream is synchronised: the verdict travelled behind the kernel)
+        c->err = "bzq_ingest_next: BGZF block " + std::to_string(g->bad_pinned[k & 1]) + " of the chunk at stream offset " + std::to_string(s.file_off) +
+                 " failed to inflate (corrupt or truncated file)";
+        return BZQ_ERR_IO;
+    }
     if (stream_pos) *stream_pos = spos;
     g->stats.chunks += 1;
     g->stats.total_s = bzq::seconds_since(g->t_open);
@@ -1847,6 +1929,9 @@ int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* f, bzq_fasta_chunk* out, uint64_
             g->cv.notify_all();
         }
         if (!ok || hipStreamSynchronize(f->aux) != hipSuccess) return fail("bzq_fasta_ingest_next: a HIP call failed", BZQ_ERR_HIP);
+        if (g->gpu_inflate && g->bad_pinned[k & 1] != ~0ull)
+            return fail("bzq_fasta_ingest_next: BGZF block " + std::to_string(g->bad_pinned[k & 1]) + " of the chunk at stream offset " +
+                        std::to_string(s.file_off) + " failed to inflate (corrupt or truncated file)", BZQ_ERR_IO);
         const uint64_t n = carry + s.len, spos = s.file_off - carry;
         const int32_t rc = bzq_fasta_parse(f->h, dst, n, s.eof ? 1 : 0, spos, f->line_base, f->record_base, out);
         g->stats.wait_s += bzq::seconds_since(tw);

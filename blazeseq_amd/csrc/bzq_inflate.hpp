@@ -1,0 +1,242 @@
+// bzq_inflate.hpp -- BGZF blocks inflated ON the GPU (C ABI bzq_bgzf_inflate; the ingest's "ingest_gpu_inflate" option).
+//
+// Replaces, for blocked gzip, the reference's RapidgzipReader / GZFile in front of the parser (blazeseq/io/readers.mojo:283-443):
+// there the host decompresses and the parser sees plain bytes; here the COMPRESSED bytes cross PCIe (3-4x fewer) and every
+// BGZF block -- an independent raw-DEFLATE stream of at most 64 KiB of output (SAM spec 4.1; RFC 1951) -- is decoded by one
+// wave64.  A 3 GB chunk is ~47 000 blocks: the parallelism is across blocks, the decode inside a block is serial, so the wave
+// runs it as UNIFORM code (bit buffer, positions and symbols live in scalar registers) and uses its 64 lanes where DEFLATE
+// offers width:
+//   * the input window: one coalesced load puts 256 bytes of the stream into a VGPR (lane i = dword i); refills of the bit
+//     buffer are v_readlane with a scalar index, no memory latency on the critical path;
+//   * Huffman decode without big tables: canonical codes are ordered by length, so with the next 15 stream bits reversed into
+//     a left-aligned code c, lane L holds the left-aligned upper bound of the codes of length L and ONE compare + ballot +
+//     s_ff1 gives the length; first code and symbol offset of that length are readlanes, the symbol one LDS read
+//     (per wave: 288 + 32 sorted symbols = 640 bytes of LDS instead of kilobytes of lookup tables);
+//   * table construction: lengths histogram by ballots, the sort of the symbols by (length, symbol) by ballots and popcounts;
+//   * literals collect in a VGPR (lane k = k-th pending byte) and leave 64 at a time; matches are copied by all lanes.
+// Output goes straight to the chunk buffer in device memory; matches read it back (same wave, same L1: program order holds).
+// No CRC32 of the output (neither does the host path's raw inflate); ISIZE, every distance and every length are checked, a
+// block that does not decode cleanly fails the whole call.
+#pragma once
+#include "bzq_device.hpp"
+
+namespace bzq {
+namespace inf {
+
+constexpr int WAVES = BLOCK / 64;
+struct DevBlock { uint64_t coff, uoff; uint32_t csize, usize; };   // deflate payload [coff, coff + csize) -> out[uoff, uoff + usize)
+struct Args { const uint8_t* comp; uint64_t comp_bytes; const DevBlock* blocks; int64_t n_blocks; uint8_t* out; unsigned long long* first_bad; };
+
+struct __attribute__((packed, aligned(1))) U32U { uint32_t v; };
+
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// the bit reader of one wave: everything uniform except `win` (lane i = dword win_base + i of the stream)
+struct Bits {
+    const uint8_t* base;    // first byte of the stream
+    int64_t limit;          // bytes that may be read behind base (payload + padding of the buffer)
+    u64 buf; int cnt;
+    int next;               // next dword to enter buf
+    int win_base;
+    uint32_t win;
+    __device__ __forceinline__ void start(const uint8_t* p, int64_t lim) { base = p; limit = lim; buf = 0; cnt = 0; next = 0; win_base = -64; win = 0; }
+    __device__ __forceinline__ void refill() {
+        while (cnt <= 32) {
+            if (next - win_base >= 64) {
+                win_base = next;
+                const int64_t o = 4ll * (win_base + (int)(threadIdx.x & 63));
+                win = o + 4 <= limit ? reinterpret_cast<const U32U*>(base + o)->v : 0u;
+            }
+            buf |= (u64)rdlane(win, next - win_base) << cnt;
+            cnt += 32; ++next;
+        }
+    }
+    __device__ __forceinline__ uint32_t take(int n) { const uint32_t v = (uint32_t)buf & ((1u << n) - 1u); buf >>= n; cnt -= n; return v; }
+    __device__ __forceinline__ int64_t byte_pos() const { return 4ll * next - (cnt >> 3); }   // after discarding to a byte edge
+};
+
+// One canonical Huffman code, spread over the lanes: lane L (1..15) holds, for the codes of length L, the left-aligned (15-bit)
+// upper bound `lim`, the first code `first` and the index of its first symbol in the sorted symbol table `offs`.
+struct Code { uint32_t lim, first, offs; };
+
+// lens[0..n) (LDS, one byte per symbol, 0 = unused) -> Code + symtab (LDS).  Returns false when the lengths over-subscribe the
+// code space.  n <= 320.
+__device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint16_t* symtab, Code& code) {
+    const int lane = threadIdx.x & 63;
+    uint32_t count = 0;      // lane L: number of symbols of length L
+    for (int s0 = 0; s0 < n; s0 += 64) {
+        const int l = s0 + lane < n ? lens[s0 + lane] : 0;
+#pragma unroll
+        for (int L = 1; L <= 15; ++L) {
+            const uint32_t c = (uint32_t)__builtin_popcountll(__ballot(l == L));
+            if (lane == L) count += c;
+        }
+    }
+    // first code, symbol offset, left-aligned limit per length (a 15-step uniform recurrence)
+    uint32_t first = 0, offs = 0, lim = 0, c = 0, o = 0;
+    bool over = false;
+#pragma unroll
+    for (int L = 1; L <= 15; ++L) {
+        const uint32_t n_l = rdlane(count, L);
+        c <<= 1;
+        if (lane == L) { first = c; offs = o; lim = (c + n_l) << (15 - L); }
+        if (c + n_l > (1u << L)) over = true;
+        c += n_l; o += n_l;
+    }
+    code.first = first; code.offs = offs; code.lim = (lane >= 1 && lane <= 15) ? lim : 0u;
+    // symbols sorted by (length, symbol): position = offs[length] + symbols of the same length before it
+    uint32_t run = 0;        // lane L: symbols of length L placed so far
+    for (int s0 = 0; s0 < n; s0 += 64) {
+        const int l = s0 + lane < n ? lens[s0 + lane] : 0;
+        uint32_t pos = 0;
+#pragma unroll
+        for (int L = 1; L <= 15; ++L) {
+            const u64 m = __ballot(l == L);
+            const uint32_t basepos = rdlane(offs, L) + rdlane(run, L);
+            if (l == L) pos = basepos + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+            if (lane == L) run += (uint32_t)__builtin_popcountll(m);
+        }
+        if (l) symtab[pos] = (uint16_t)(s0 + lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return !over;
+}
+
+// next symbol of `code` (uniform); -1 when the bits are no code.  Consumes its bits.
+__device__ __forceinline__ int decode_sym(Bits& b, const Code& code, const uint16_t* symtab) {
+    const uint32_t c = __builtin_bitreverse32((uint32_t)b.buf) >> 17;
+    const u64 m = __ballot(c < code.lim);
+    if (!m) return -1;
+    const int L = __builtin_ctzll(m);
+    const uint32_t idx = rdlane(code.offs, L) + (c >> (15 - L)) - rdlane(code.first, L);
+    b.buf >>= L; b.cnt -= L;
+    return (int)uni(symtab[idx]);
+}
+
+// RFC 1951 3.2.5: base and extra bits of the length codes 257..285 and the distance codes 0..29, lane i = code i
+__device__ __forceinline__ void length_dist_tables(uint32_t& lbase, uint32_t& lext, uint32_t& dbase, uint32_t& dext) {
+    const int i = threadIdx.x & 63;
+    lext = (i < 8 || i >= 28) ? 0u : (uint32_t)((i - 4) >> 2);
+    lbase = i < 8 ? 3u + i : (i >= 28 ? 258u : 3u + ((4u + (uint32_t)(i & 3)) << lext));
+    dext = i < 4 ? 0u : (uint32_t)((i - 2) >> 1);
+    dbase = i < 4 ? 1u + i : 1u + ((2u + (uint32_t)(i & 1)) << dext);
+}
+
+// order in which the lengths of the code length code are stored (RFC 1951 3.2.7)
+static __device__ const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
+    __shared__ uint16_t s_ll[WAVES][288 + 32];   // sorted literal/length symbols, then the distance symbols
+    __shared__ uint8_t s_len[WAVES][320 + 64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t bi = (int64_t)blockIdx.x * WAVES + wave;
+    if (bi >= a.n_blocks) return;
+    const DevBlock blk = a.blocks[bi];
+    uint16_t* const sym_ll = s_ll[wave];
+    uint16_t* const sym_d = s_ll[wave] + 288;
+    uint8_t* const lens = s_len[wave];
+    uint8_t* const out = a.out + blk.uoff;
+    const int usize = (int)blk.usize;
+    uint32_t lbase, lext, dbase, dext;
+    length_dist_tables(lbase, lext, dbase, dext);
+    auto fail = [&]() { if (lane == 0) atomicMin(a.first_bad, (unsigned long long)bi); };
+
+    Bits b;
+    b.start(a.comp + blk.coff, (int64_t)(a.comp_bytes - blk.coff));
+    int pos = 0;             // bytes decoded so far (stored + pending literals)
+    int ns = 0;              // pending literals, lane k holds the k-th
+    uint32_t mylit = 0;
+    auto flush = [&]() {
+        if (lane < ns) out[pos - ns + lane] = (uint8_t)mylit;
+        ns = 0;
+    };
+    for (bool last = false; !last;) {
+        b.refill();
+        last = b.take(1) != 0;
+        const uint32_t type = b.take(2);
+        if (type == 3) return fail();
+        if (type == 0) {   // stored: to the next byte edge, LEN, ~LEN, LEN bytes
+            b.take(b.cnt & 7);
+            b.refill();
+            const uint32_t len = b.take(16), nlen = b.take(16);
+            if ((len ^ nlen) != 0xFFFFu || pos + (int)len > usize) return fail();
+            flush();
+            const int64_t src = b.byte_pos();
+            if (src + (int64_t)len > (int64_t)blk.csize) return fail();
+            for (int i = lane; i < (int)len; i += 64) out[pos + i] = b.base[src + i];
+            pos += (int)len;
+            b.start(b.base + src + len, b.limit - (src + len));
+            continue;
+        }
+        Code ll, dd;
+        if (type == 1) {   // fixed code (RFC 1951 3.2.6)
+            for (int s = lane; s < 288; s += 64) lens[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
+            if (lane < 32) lens[288 + lane] = 5;
+            __builtin_amdgcn_wave_barrier();
+            if (!build_code(lens, 288, sym_ll, ll) || !build_code(lens + 288, 30, sym_d, dd)) return fail();
+        } else {           // dynamic code (3.2.7)
+            const int hlit = (int)b.take(5) + 257, hdist = (int)b.take(5) + 1, hclen = (int)b.take(4) + 4;
+            if (hlit > 286 || hdist > 30) return fail();
+            if (lane < 19) lens[lane] = 0;
+            for (int i = 0; i < hclen; ++i) {
+                b.refill();
+                const uint32_t v = b.take(3);
+                if (lane == 0) lens[CL_ORDER[i]] = (uint8_t)v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            Code cl;
+            if (!build_code(lens, 19, sym_d, cl)) return fail();   // (the distance table is free until its own build)
+            int n = 0;
+            uint32_t prev = 0;
+            const int total = hlit + hdist;
+            while (n < total) {
+                b.refill();
+                const int s = decode_sym(b, cl, sym_d);
+                if (s < 0) return fail();
+                uint32_t val = 0; int rep = 1;
+                if (s < 16) { val = (uint32_t)s; prev = val; }
+                else if (s == 16) { if (n == 0) return fail(); val = prev; rep = 3 + (int)b.take(2); }
+                else if (s == 17) { rep = 3 + (int)b.take(3); prev = 0; }
+                else { rep = 11 + (int)b.take(7); prev = 0; }
+                if (n + rep > total) return fail();
+                // lens of the two codes back to back at 32 (behind the 19 of the code length code, which is still in use)
+                for (int i = lane; i < rep; i += 64) lens[32 + n + i] = (uint8_t)val;
+                n += rep;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lens[32 + 256] == 0) return fail();   // no end-of-block code
+            if (!build_code(lens + 32, hlit, sym_ll, ll) || !build_code(lens + 32 + hlit, hdist, sym_d, dd)) return fail();
+        }
+        for (;;) {
+            b.refill();
+            const int s = decode_sym(b, ll, sym_ll);
+            if (s < 0) return fail();
+            if (s < 256) {
+                if (pos >= usize) return fail();
+                if (lane == ns) mylit = (uint32_t)s;
+                ++ns; ++pos;
+                if (ns == 64) flush();
+                continue;
+            }
+            if (s == 256) break;
+            if (s > 285) return fail();
+            const int len = (int)(rdlane(lbase, s - 257) + b.take((int)rdlane(lext, s - 257)));
+            b.refill();
+            const int ds = decode_sym(b, dd, sym_d);
+            if (ds < 0 || ds > 29) return fail();
+            const int dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));
+            if (dist > pos || pos + len > usize) return fail();
+            flush();
+            // out[pos + i] = out[pos - dist + i]; with dist < len the source repeats with period dist: only bytes in front of
+            // pos are read
+            for (int i = lane; i < len; i += 64) out[pos + i] = out[pos - dist + (dist >= len ? i : i % dist)];
+            pos += len;
+        }
+    }
+    flush();
+    if (pos != usize) return fail();
+}
+
+} // namespace inf
+} // namespace bzq

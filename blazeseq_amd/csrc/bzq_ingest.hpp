@@ -48,6 +48,16 @@ struct bzq_ingest {
     int compression = 0;
     gzFile gz = nullptr;
     uint64_t bgzf_off = 0;         // compressed offset of the next BGZF block
+    // BGZF inflated on the device (bzq_inflate.hpp): the slot's pinned buffer carries the COMPRESSED blocks to comp_dev, the
+    // kernel writes the chunk into the slot's device buffer; first_bad travels back behind it
+    int gpu_inflate = 0;
+    uint8_t* comp_dev[2] = {nullptr, nullptr};
+    bzq::inf::DevBlock* tab_dev[2] = {nullptr, nullptr};
+    bzq::inf::DevBlock* tab_pinned[2] = {nullptr, nullptr};
+    int64_t tab_cap = 0;
+    unsigned long long* bad_dev = nullptr;      // [2]
+    unsigned long long* bad_pinned = nullptr;   // [2]
+    double ratio_est = 0.30;       // compressed / inflated bytes of the last chunk: how much to read for the next one
     bzq::IngestSlot slot[2];
     hipStream_t copy_stream = nullptr;
     hipEvent_t dev_free[2] = {nullptr, nullptr}; // recorded on the ctx stream once slot i's device buffer may be overwritten
@@ -220,6 +230,37 @@ inline bool read_compressed_chunk(bzq_ingest* g, uint8_t* dst, uint64_t cap, uin
     return true;
 }
 
+// Device inflate: the next run of whole BGZF blocks, still COMPRESSED, into `pinned` (capacity cap); their table (payload
+// offsets relative to `pinned`) into tab.  The read is sized from the last chunk's compression ratio; a short read gives a
+// smaller chunk, never a wrong one.
+inline bool read_bgzf_window(bzq_ingest* g, uint8_t* pinned, uint64_t cap, bzq::inf::DevBlock* tab, int64_t* n_blocks, uint64_t* comp_len,
+                             uint64_t* out_len, bool* eof, std::string& err) {
+    *n_blocks = 0; *comp_len = 0; *out_len = 0; *eof = false;
+    const uint64_t remaining = g->file_size - g->bgzf_off;
+    if (remaining == 0) { *eof = true; return true; }
+    uint64_t want = (uint64_t)((double)g->chunk_bytes * g->ratio_est * 1.05) + (2ull << 20);
+    want = std::min<uint64_t>({want, cap, remaining});
+    if (!parallel_pread(g->fd, pinned, g->bgzf_off, want, g->n_threads, err, g->fd_direct, &g->numa_cpus)) return false;
+    uint64_t off = 0, usum = 0;
+    int64_t k = 0;
+    while (off + 28 <= want && k < g->tab_cap) {
+        const uint32_t bs = bgzf_block_size(pinned + off);
+        if (!bs || bs < 26) { if (k == 0) { err = "BGZF: bad block header"; return false; } break; }   // the next call meets it first
+        if (off + bs > want) break;
+        const uint8_t* t = pinned + off + bs - 4;
+        const uint32_t us = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        if (us > 65536) { if (k == 0) { err = "BGZF: block claims more than 64 KiB"; return false; } break; }
+        if (usum + us > g->chunk_bytes) break;
+        tab[k++] = bzq::inf::DevBlock{off + 18, usum, bs - 26, us};
+        usum += us; off += bs;
+    }
+    if (k == 0) { err = want == remaining ? "BGZF: truncated block" : "BGZF: a block does not fit the chunk"; return false; }
+    if (usum) g->ratio_est = std::max(0.02, (double)off / (double)usum);
+    g->bgzf_off += off;
+    *n_blocks = k; *comp_len = off; *out_len = usum; *eof = g->bgzf_off >= g->file_size;
+    return true;
+}
+
 inline void ingest_producer(bzq_ingest* g) {
     // a failed HIP call stops the pipeline with an error the consumer reports: a chunk is never published unless its copy
     // was enqueued successfully
@@ -241,11 +282,14 @@ inline void ingest_producer(bzq_ingest* g) {
             std::unique_lock<std::mutex> lk(g->mu);
             if (g->stop) return;
         }
-        uint64_t len = 0;
+        uint64_t len = 0, comp_len = 0;
+        int64_t n_blocks = 0;
         bool eof = false, ok;
         const auto t0 = std::chrono::steady_clock::now();
         std::string err;
-        if (g->compression == 0) {
+        if (g->gpu_inflate) {
+            ok = read_bgzf_window(g, s.pinned + g->reserve, g->chunk_bytes, g->tab_pinned[k & 1], &n_blocks, &comp_len, &len, &eof, err);
+        } else if (g->compression == 0) {
             len = std::min<uint64_t>(g->chunk_bytes, g->file_size - off);
             ok = parallel_pread(g->fd, s.pinned + g->reserve, off, len, g->n_threads, err, g->fd_direct, &g->numa_cpus);
             eof = off + len >= g->file_size;
@@ -268,7 +312,21 @@ inline void ingest_producer(bzq_ingest* g) {
             he = g->dev_free_valid[k & 1] ? hipStreamWaitEvent(g->copy_stream, g->dev_free[k & 1], 0) : hipSuccess;
         }
         if (he != hipSuccess) return fail("reader: hipStreamWaitEvent", he);
-        if (len && (he = hipMemcpyAsync(s.dev + g->reserve, s.pinned + g->reserve, len, hipMemcpyHostToDevice, g->copy_stream)) != hipSuccess)
+        if (g->gpu_inflate) {
+            const int b = (int)(k & 1);
+            g->bad_pinned[b] = ~0ull;   // (the consumer read the previous verdict of this slot two chunks ago)
+            if (n_blocks) {
+                if ((he = hipMemcpyAsync(g->comp_dev[b], s.pinned + g->reserve, comp_len, hipMemcpyHostToDevice, g->copy_stream)) != hipSuccess ||
+                    (he = hipMemcpyAsync(g->tab_dev[b], g->tab_pinned[b], (size_t)n_blocks * sizeof(bzq::inf::DevBlock), hipMemcpyHostToDevice, g->copy_stream)) != hipSuccess ||
+                    (he = hipMemsetAsync(g->bad_dev + b, 0xFF, sizeof(unsigned long long), g->copy_stream)) != hipSuccess)
+                    return fail("reader: host to device copy (compressed blocks)", he);
+                bzq::inf::Args ia{g->comp_dev[b], comp_len, g->tab_dev[b], n_blocks, s.dev + g->reserve, g->bad_dev + b};
+                hipLaunchKernelGGL(bzq::inf::k_bgzf_inflate, dim3((unsigned)((n_blocks + bzq::inf::WAVES - 1) / bzq::inf::WAVES)), dim3(BLOCK), 0, g->copy_stream, ia);
+                if ((he = hipGetLastError()) != hipSuccess ||
+                    (he = hipMemcpyAsync(g->bad_pinned + b, g->bad_dev + b, sizeof(unsigned long long), hipMemcpyDeviceToHost, g->copy_stream)) != hipSuccess)
+                    return fail("reader: device inflate", he);
+            }
+        } else if (len && (he = hipMemcpyAsync(s.dev + g->reserve, s.pinned + g->reserve, len, hipMemcpyHostToDevice, g->copy_stream)) != hipSuccess)
             return fail("reader: host to device copy", he);
         if ((he = hipEventRecord(s.h2d_done, g->copy_stream)) != hipSuccess) return fail("reader: hipEventRecord", he);
         s.file_off = off; s.len = len; s.eof = eof;
@@ -296,9 +354,14 @@ inline void ingest_free(bzq_ingest* g) {
         if (g->slot[i].pinned) (void)hipHostFree(g->slot[i].pinned);
         if (g->slot[i].dev) (void)hipFree(g->slot[i].dev);
         if (g->big[i]) (void)hipFree(g->big[i]);
+        if (g->comp_dev[i]) (void)hipFree(g->comp_dev[i]);
+        if (g->tab_dev[i]) (void)hipFree(g->tab_dev[i]);
+        if (g->tab_pinned[i]) (void)hipHostFree(g->tab_pinned[i]);
         if (g->slot[i].h2d_done) (void)hipEventDestroy(g->slot[i].h2d_done);
         if (g->dev_free[i]) (void)hipEventDestroy(g->dev_free[i]);
     }
+    if (g->bad_dev) (void)hipFree(g->bad_dev);
+    if (g->bad_pinned) (void)hipHostFree(g->bad_pinned);
     if (g->gz) gzclose(g->gz);
     if (g->fd >= 0) close(g->fd);
     if (g->fd_direct >= 0) close(g->fd_direct);

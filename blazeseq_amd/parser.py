@@ -253,6 +253,21 @@ class Context:
     def comm_init_shm(self, rank: int, nranks: int, name: str, halo_capacity: int = 0):
         _check(self.h, L.lib().bzq_comm_init_shm(self.h, rank, nranks, name.encode(), halo_capacity), "bzq_comm_init_shm")
 
+    def bgzf_scan(self, comp: np.ndarray, max_out: int = 1 << 62, cap: int = 0):
+        """bzq_bgzf_scan over a host buffer -> (blocks, n_blocks, consumed, out_bytes)."""
+        cap = cap or int(comp.size // 28 + 1)
+        blocks = (L.BzqBgzfBlock * cap)()
+        n, consumed, out_bytes = C.c_int64(), C.c_uint64(), C.c_uint64()
+        rc = L.lib().bzq_bgzf_scan(comp.ctypes.data, comp.size, max_out, blocks, cap, C.byref(n), C.byref(consumed), C.byref(out_bytes))
+        if rc < 0:
+            raise RuntimeError(f"bzq_bgzf_scan: not a BGZF block at offset {int(consumed.value)}")
+        return blocks, int(n.value), int(consumed.value), int(out_bytes.value)
+
+    def bgzf_inflate(self, d_comp: int, comp_bytes: int, blocks, n_blocks: int, d_out: int, out_capacity: int):
+        """bzq_bgzf_inflate: device-resident BGZF blocks -> their bytes, in device memory."""
+        _check(self.h, L.lib().bzq_bgzf_inflate(self.h, C.c_void_p(d_comp), comp_bytes, blocks, n_blocks, C.c_void_p(d_out), out_capacity),
+               "bzq_bgzf_inflate")
+
     def comm_selftest(self):
         """One checked ring exchange + all-gather over the communicator (collective)."""
         _check(self.h, L.lib().bzq_comm_selftest(self.h), "bzq_comm_selftest")
@@ -556,10 +571,12 @@ class FastqParser:
 
     def __init__(self, source, schema: str = "generic", batch_size: int = DEFAULT_BATCH_SIZE,
                  config: Optional[ParserConfig] = None, device: int = 0, chunk_bytes: int = DEFAULT_CHUNK_BYTES,
-                 pass_bytes: int = 0, native_ingest: bool = True, reader_threads: int = 0):
+                 pass_bytes: int = 0, native_ingest: bool = True, reader_threads: int = 0, gpu_inflate: bool = True):
         self.config = config if config is not None else ParserConfig()
         self._batch_size = batch_size
         self._ctx = Context(self.config, schema, batch_size, device, pass_bytes=pass_bytes)
+        if not gpu_inflate:   # BGZF files: inflate on the reader threads instead of on the device
+            self._ctx.set_option("ingest_gpu_inflate", 0)
         # a plain file goes through the native ingest pipeline (reader threads + pinned double buffers);
         # bytes / arrays / file objects through the Reader.read_to_buffer-style loop below
         self._ingest: Optional[Ingest] = None

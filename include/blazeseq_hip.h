@@ -349,6 +349,29 @@ int32_t bzq_shard_stitch(bzq_ctx* ctx, uint8_t* d_shard, uint64_t n, uint64_t ca
 /* records, bases (sequence bytes), bytes over all ranks after the last bzq_shard_stitch */
 int32_t bzq_global_counts(bzq_ctx* ctx, uint64_t out[3]);
 
+/* ---- BGZF inflate on the device ("then gzip ingest") ----------------------- */
+
+/* Replaces, for blocked gzip (bgzip / BGZF, SAM spec 4.1), the decompression in front of the parser: RapidgzipReader / GZFile
+ * (blazeseq/io/readers.mojo:283-443).  Every block is an independent raw-DEFLATE stream of at most 64 KiB of output; one
+ * wave64 decodes one block (blazeseq_amd/csrc/bzq_inflate.hpp), so the COMPRESSED bytes are what crosses PCIe. */
+typedef struct bzq_bgzf_block {
+    uint64_t comp_offset;   /* of the block's gzip header in the compressed buffer */
+    uint32_t comp_size;     /* BSIZE + 1: header (18) + deflate payload + CRC32 + ISIZE */
+    uint32_t out_size;      /* ISIZE */
+    uint64_t out_offset;    /* where its output goes */
+} bzq_bgzf_block;
+
+/* Walk the block headers of a HOST buffer: fills blocks[0..*n_blocks) for the whole blocks that fit `n` bytes, `cap` entries
+ * and max_out output bytes; *consumed = compressed bytes they span, *out_bytes = their total output.  BZQ_ERR_IO when the
+ * bytes at an expected block start are not a BGZF header.  Pure host function. */
+int32_t bzq_bgzf_scan(const uint8_t* comp, uint64_t n, uint64_t max_out, bzq_bgzf_block* blocks, int64_t cap, int64_t* n_blocks,
+                      uint64_t* consumed, uint64_t* out_bytes);
+/* Inflate blocks[0..n_blocks) of the device-resident compressed bytes d_comp[0, comp_bytes) (8 readable bytes of padding
+ * behind them are not required) into d_out.  ISIZE, every match distance and length are checked, the CRC32 is not.
+ * Synchronous on the ctx stream.  BZQ_ERR_IO: a block does not decode (bzq_last_error names the first). */
+int32_t bzq_bgzf_inflate(bzq_ctx* ctx, const uint8_t* d_comp, uint64_t comp_bytes, const bzq_bgzf_block* blocks, int64_t n_blocks,
+                         uint8_t* d_out, uint64_t out_capacity);
+
 /* ---- host ingest pipeline ---------------------------------------------- */
 
 /* Replaces FileReader.read_to_buffer + BufferedReader._fill_buffer/_compact_from for plain files

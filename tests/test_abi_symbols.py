@@ -36,7 +36,7 @@ def test_struct_sizes_match_header(tmp_path):
                "bzq_shard_result": _lib.BzqShardResult, "bzq_nccl_id": _lib.BzqNcclId,
                "bzq_fasta_config": _lib.BzqFastaConfig, "bzq_fasta_chunk": _lib.BzqFastaChunk,
                "bzq_fasta_shard_summary": _lib.BzqFastaShardSummary, "bzq_fasta_shard_plan": _lib.BzqFastaShardPlan,
-               "bzq_fasta_shard_result": _lib.BzqFastaShardResult}
+               "bzq_fasta_shard_result": _lib.BzqFastaShardResult, "bzq_bgzf_block": _lib.BzqBgzfBlock}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "blazeseq_hip.h"', "int main(void) {"]
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -1,0 +1,125 @@
+"""bzq_bgzf_inflate (blazeseq_amd/csrc/bzq_inflate.hpp): BGZF blocks inflated by the GPU == the bytes zlib compressed, over
+every DEFLATE block type (stored, fixed, dynamic), strategies that stress the copy (RLE: distance 1, overlapping), sizes from
+0 to 64 KiB, and the FASTQ the ingest sees."""
+import ctypes as C
+import zlib
+
+import numpy as np
+import pytest
+
+from blazeseq_amd import _lib as L
+from blazeseq_amd.parser import Context
+from tests.bgzf_util import bgzf_block, bgzf_compress
+from tests.fastq_fuzz import rand_stream
+
+pytestmark = pytest.mark.gpu
+
+
+def inflate_on_device(ctx, comp: bytes) -> bytes:
+    a = np.frombuffer(comp, dtype=np.uint8)
+    blocks, n, consumed, out_bytes = ctx.bgzf_scan(a)
+    assert consumed == a.size
+    d_c, d_o = C.c_void_p(), C.c_void_p()
+    assert L.lib().bzq_device_alloc(ctx.h, a.size + 64, C.byref(d_c)) == 0
+    assert L.lib().bzq_device_alloc(ctx.h, out_bytes + 64, C.byref(d_o)) == 0
+    try:
+        assert L.lib().bzq_copy_to_device(ctx.h, d_c, a.ctypes.data, a.size) == 0
+        ctx.bgzf_inflate(d_c.value, a.size, blocks, n, d_o.value, out_bytes)
+        out = np.empty(out_bytes, dtype=np.uint8)
+        if out_bytes:
+            assert L.lib().bzq_copy_to_host(ctx.h, out.ctypes.data, d_o, out_bytes) == 0
+        return out.tobytes()
+    finally:
+        L.lib().bzq_device_free(ctx.h, d_c); L.lib().bzq_device_free(ctx.h, d_o)
+
+
+def payloads():
+    rng = np.random.default_rng(11)
+    fq = rand_stream(rng, n_records=3000, max_len=150, dirty=0.0, tail=0)
+    yield "fastq", fq
+    yield "empty", b""
+    yield "one_byte", b"A"
+    yield "same_byte", b"G" * 200000
+    yield "period3", b"ACG" * 70000
+    yield "random", rng.integers(0, 256, 150000, dtype=np.uint8).tobytes()
+    yield "low_entropy", rng.integers(65, 69, 300000, dtype=np.uint8).tobytes()
+    yield "text", (b"the quick brown fox jumps over the lazy dog\n" * 5000)[:180001]
+    yield "long_matches", (bytes(rng.integers(0, 256, 300, dtype=np.uint8)) * 800)
+    yield "far_matches", (bytes(rng.integers(0, 256, 31000, dtype=np.uint8)) * 6)
+
+
+@pytest.mark.parametrize("name,data", list(payloads()), ids=[n for n, _ in payloads()])
+def test_levels_and_strategies(name, data):
+    ctx = Context()
+    for level, strategy in [(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (0, zlib.Z_DEFAULT_STRATEGY),
+                            (6, zlib.Z_FIXED), (6, zlib.Z_RLE), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_FILTERED)]:
+        block = 65280 if level else 60000
+        if name == "random" and level:
+            block = 32000   # incompressible bytes grow a little
+        comp = bgzf_compress(data, block=block, level=level, strategy=strategy)
+        got = inflate_on_device(ctx, comp)
+        assert got == data, (name, level, strategy, len(got), len(data))
+
+
+def test_block_sizes_around_the_edges():
+    ctx = Context()
+    rng = np.random.default_rng(5)
+    base = rand_stream(rng, n_records=700, max_len=150, dirty=0.0, tail=0)
+    parts, want = [], []
+    for n in [0, 1, 2, 3, 63, 64, 65, 255, 256, 257, 258, 259, 4095, 4096, 4097, 65279, 65280, 65535, 65536]:
+        piece = (base * (n // len(base) + 1))[:n]
+        parts.append(bgzf_block(piece)); want.append(piece)
+    assert inflate_on_device(ctx, b"".join(parts)) == b"".join(want)
+
+
+def test_many_blocks_random_mix():
+    ctx = Context()
+    rng = np.random.default_rng(8)
+    parts, want = [], []
+    for i in range(600):
+        kind = int(rng.integers(0, 5))
+        n = int(rng.integers(0, 65000))
+        if kind == 0:
+            piece = rand_stream(rng, n_records=max(1, n // 330), max_len=150, dirty=0.0, tail=0)[:n]
+        elif kind == 1:
+            piece = rng.integers(0, 256, min(n, 30000), dtype=np.uint8).tobytes()
+        elif kind == 2:
+            piece = bytes([int(rng.integers(0, 256))]) * n
+        elif kind == 3:
+            piece = (bytes(rng.integers(0, 4, int(rng.integers(1, 40)), dtype=np.uint8) + 65) * 70000)[:n]
+        else:
+            piece = rng.integers(0, int(rng.integers(2, 200)), n, dtype=np.uint8).tobytes()
+        level = int(rng.choice([0, 1, 4, 6, 9]))
+        strat = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE, zlib.Z_HUFFMAN_ONLY]))
+        parts.append(bgzf_block(piece, level, strat)); want.append(piece)
+    assert inflate_on_device(ctx, b"".join(parts)) == b"".join(want)
+
+
+def test_corrupt_blocks_fail_or_decode_to_the_declared_size():
+    """No CRC check on the device: a damaged payload either fails (bad code, distance, length, size) or yields ISIZE bytes --
+    never a crash, a hang or a write outside the block's output."""
+    ctx = Context()
+    rng = np.random.default_rng(2)
+    data = rand_stream(rng, n_records=190, max_len=150, dirty=0.0, tail=0)
+    good = bgzf_block(data)
+    guard = bgzf_block(b"Z" * 1000)
+    failures = 0
+    for trial in range(60):
+        bad = bytearray(good)
+        for _ in range(int(rng.integers(1, 4))):
+            bad[int(rng.integers(18, len(good) - 8))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            out = inflate_on_device(ctx, bytes(bad) + guard)
+            assert len(out) == len(data) + 1000 and out[-1000:] == b"Z" * 1000
+        except RuntimeError as e:
+            assert "failed to inflate" in str(e)
+            failures += 1
+    assert failures > 10
+    wrong_isize = bytearray(good); wrong_isize[-4:] = (len(data) + 1).to_bytes(4, "little")
+    with pytest.raises(RuntimeError, match="block 0 failed"):
+        inflate_on_device(ctx, bytes(wrong_isize))
+    truncated_payload = bytearray(good); truncated_payload[40:60] = b"\0" * 20
+    try:
+        inflate_on_device(ctx, bytes(truncated_payload))
+    except RuntimeError:
+        pass

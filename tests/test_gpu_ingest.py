@@ -169,8 +169,10 @@ def test_compressed_files_parse_like_the_plain_file(kind, tmp_path):
     path = tmp_path / ("reads.fastq.gz")
     path.write_bytes(comp)
     ref = [b for b in O.StreamParser(np.frombuffer(data, dtype=np.uint8), O.make_config(batch_size=1000)).batches()]
-    for chunk in (1 << 16, 1 << 20, 1 << 28):
-        p = B.FastqParser(str(path), batch_size=1000, chunk_bytes=chunk, reader_threads=3)
+    for chunk, gpu_inflate in ((1 << 16, True), (1 << 20, True), (1 << 28, True), (1 << 20, False)):
+        if not gpu_inflate and kind != "bgzf":
+            continue   # (the switch only concerns BGZF: on the device by default, on the reader threads without it)
+        p = B.FastqParser(str(path), batch_size=1000, chunk_bytes=chunk, reader_threads=3, gpu_inflate=gpu_inflate)
         got = list(p.batches())
         assert [len(b) for b in got] == [len(b) for b in ref]
         for g, r in zip(got, ref):
@@ -187,8 +189,18 @@ def test_truncated_gzip_is_a_runtime_error_not_a_parse_result(tmp_path):
     for comp in (gzip.compress(data, 1), _bgzf(data)):
         path = tmp_path / "cut.fastq.gz"
         path.write_bytes(comp[: len(comp) // 2])
-        with pytest.raises(RuntimeError, match="gzread|BGZF"):
-            list(B.FastqParser(str(path), batch_size=1000).batches())
+        for gpu_inflate in (True, False):
+            with pytest.raises(RuntimeError, match="gzread|BGZF"):
+                list(B.FastqParser(str(path), batch_size=1000, gpu_inflate=gpu_inflate).batches())
+    # a damaged payload inside a whole block: the device decoder refuses it (bad code / distance / size), like zlib does
+    comp = bytearray(_bgzf(data))
+    for off in range(400, 4000, 97):
+        comp[off] ^= 0x5A
+    path = tmp_path / "bad.fastq.gz"
+    path.write_bytes(bytes(comp))
+    for gpu_inflate in (True, False):
+        with pytest.raises(RuntimeError, match="BGZF"):
+            list(B.FastqParser(str(path), batch_size=1000, gpu_inflate=gpu_inflate).batches())
 
 
 # ---- the reference's window at the end of a stream that came in several chunks ----------------------------------------
