@@ -1664,7 +1664,8 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
     if (numa) gpu_numa_cpus(device, &g->numa_node, g->numa_cpus);
     g->stats.direct_io = g->fd_direct >= 0 ? 1 : 0;
     g->stats.numa_node = g->numa_node;
-    bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&g->copy_stream2, hipStreamNonBlocking) == hipSuccess;
     for (int i = 0; i < 2 && ok; ++i) {
         ok = hipHostMalloc((void**)&g->slot[i].pinned, g->reserve + g->chunk_bytes, hipHostMallocDefault) == hipSuccess &&
              hipMalloc((void**)&g->slot[i].dev, g->reserve + g->chunk_bytes + 64) == hipSuccess &&
@@ -1785,22 +1786,25 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
         if (g->produced <= k) { c->err = "bzq_ingest_next: " + (g->io_error.empty() ? std::string("reader stopped") : g->io_error); return BZQ_ERR_IO; }
     }
     bzq::IngestSlot& s = g->slot[k & 1];
-    HIPCHK(c, hipStreamWaitEvent(c->stream, s.h2d_done, 0));
     uint8_t* dst = nullptr;
     bool body_moves = false;
     {
         int prc;
         if ((prc = ingest_place(g, k, carry, c->stream, c->err, &dst, &body_moves))) return prc;
     }
+    // the carry lands in FRONT of this chunk's body (the reserve), which the chunk's own copy / inflate does not touch: it
+    // does not wait for them, and the previous chunk's buffer is released as soon as the carry is out of it -- so that the
+    // producer can start chunk k+1 on the device while chunk k is still arriving (device inflate: two chunks' blocks in flight)
     if (carry) HIPCHK(c, hipMemcpyAsync(dst, g->prev_ptr + carry_src, carry, hipMemcpyDeviceToDevice, c->stream));
-    if (body_moves && s.len) HIPCHK(c, hipMemcpyAsync(dst + carry, s.dev + g->reserve, s.len, hipMemcpyDeviceToDevice, c->stream));
-    if (g->have_prev) {   // the previous chunk's device buffer may now be refilled (behind the carry copy)
+    if (g->have_prev) {
         HIPCHK(c, hipEventRecord(g->dev_free[(k - 1) & 1], c->stream));
         std::unique_lock<std::mutex> lk(g->mu);
         g->dev_free_valid[(k - 1) & 1] = true;
         g->released = k;
         g->cv.notify_all();
     }
+    HIPCHK(c, hipStreamWaitEvent(c->stream, s.h2d_done, 0));
+    if (body_moves && s.len) HIPCHK(c, hipMemcpyAsync(dst + carry, s.dev + g->reserve, s.len, hipMemcpyDeviceToDevice, c->stream));
     // the chunk starts wherever its carry starts: the kernels read the input through unaligned-typed vector loads
     const uint64_t n = carry + s.len;
     const uint64_t spos = s.file_off - carry;
@@ -1911,7 +1915,7 @@ int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* f, bzq_fasta_chunk* out, uint64_
             if (g->produced <= k) return fail("bzq_fasta_ingest_next: " + (g->io_error.empty() ? std::string("reader stopped") : g->io_error), BZQ_ERR_IO);
         }
         bzq::IngestSlot& s = g->slot[k & 1];
-        bool ok = hipStreamWaitEvent(f->aux, s.h2d_done, 0) == hipSuccess;
+        bool ok = true;
         uint8_t* dst = nullptr;
         bool body_moves = false;
         {   // a record longer than the reserve (a chromosome): the chunk is assembled in a buffer grown to fit
@@ -1919,8 +1923,8 @@ int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* f, bzq_fasta_chunk* out, uint64_
             const int prc = ingest_place(g, k, carry, f->aux, perr, &dst, &body_moves);
             if (prc) return fail("bzq_fasta_ingest_next: " + perr, prc);
         }
-        if (ok && carry) ok = hipMemcpyAsync(dst, g->prev_ptr + carry_src, carry, hipMemcpyDeviceToDevice, f->aux) == hipSuccess;
-        if (ok && body_moves && s.len) ok = hipMemcpyAsync(dst + carry, s.dev + g->reserve, s.len, hipMemcpyDeviceToDevice, f->aux) == hipSuccess;
+        // (the carry goes in front of the body and does not wait for the chunk's own copy / inflate: bzq_ingest_next)
+        if (carry) ok = hipMemcpyAsync(dst, g->prev_ptr + carry_src, carry, hipMemcpyDeviceToDevice, f->aux) == hipSuccess;
         if (ok && g->have_prev) {   // the previous chunk's device buffer may now be refilled (behind the carry copy)
             ok = hipEventRecord(g->dev_free[(k - 1) & 1], f->aux) == hipSuccess;
             std::unique_lock<std::mutex> lk(g->mu);
@@ -1928,6 +1932,8 @@ int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* f, bzq_fasta_chunk* out, uint64_
             g->released = k;
             g->cv.notify_all();
         }
+        if (ok) ok = hipStreamWaitEvent(f->aux, s.h2d_done, 0) == hipSuccess;
+        if (ok && body_moves && s.len) ok = hipMemcpyAsync(dst + carry, s.dev + g->reserve, s.len, hipMemcpyDeviceToDevice, f->aux) == hipSuccess;
         if (!ok || hipStreamSynchronize(f->aux) != hipSuccess) return fail("bzq_fasta_ingest_next: a HIP call failed", BZQ_ERR_HIP);
         if (g->gpu_inflate && g->bad_pinned[k & 1] != ~0ull)
             return fail("bzq_fasta_ingest_next: BGZF block " + std::to_string(g->bad_pinned[k & 1]) + " of the chunk at stream offset " +

@@ -51,6 +51,13 @@ struct Bits {
             buf |= (u64)rdlane(win, next - win_base) << cnt;
             cnt += 32; ++next;
         }
+        pin();
+    }
+    // the state is the same in every lane; say so (the compiler otherwise keeps it in vector registers and runs the whole
+    // decoder under exec masks)
+    __device__ __forceinline__ void pin() {
+        cnt = (int)uni((uint32_t)cnt); next = (int)uni((uint32_t)next); win_base = (int)uni((uint32_t)win_base);
+        buf = ((u64)uni((uint32_t)(buf >> 32)) << 32) | uni((uint32_t)buf);
     }
     __device__ __forceinline__ uint32_t take(int n) { const uint32_t v = (uint32_t)buf & ((1u << n) - 1u); buf >>= n; cnt -= n; return v; }
     __device__ __forceinline__ int64_t byte_pos() const { return 4ll * next - (cnt >> 3); }   // after discarding to a byte edge
@@ -126,24 +133,14 @@ __device__ __forceinline__ void length_dist_tables(uint32_t& lbase, uint32_t& le
 // order in which the lengths of the code length code are stored (RFC 1951 3.2.7)
 static __device__ const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
-static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
-    __shared__ uint16_t s_ll[WAVES][288 + 32];   // sorted literal/length symbols, then the distance symbols
-    __shared__ uint8_t s_len[WAVES][320 + 64];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t bi = (int64_t)blockIdx.x * WAVES + wave;
-    if (bi >= a.n_blocks) return;
-    const DevBlock blk = a.blocks[bi];
-    uint16_t* const sym_ll = s_ll[wave];
-    uint16_t* const sym_d = s_ll[wave] + 288;
-    uint8_t* const lens = s_len[wave];
-    uint8_t* const out = a.out + blk.uoff;
-    const int usize = (int)blk.usize;
+// One BGZF block by one wave.  Every branch in here is uniform; false = the stream is not a valid DEFLATE stream of usize bytes.
+__device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_left, int csize, uint8_t* out, int usize,
+                                              uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens) {
+    const int lane = threadIdx.x & 63;
     uint32_t lbase, lext, dbase, dext;
     length_dist_tables(lbase, lext, dbase, dext);
-    auto fail = [&]() { if (lane == 0) atomicMin(a.first_bad, (unsigned long long)bi); };
-
     Bits b;
-    b.start(a.comp + blk.coff, (int64_t)(a.comp_bytes - blk.coff));
+    b.start(comp, comp_left);
     int pos = 0;             // bytes decoded so far (stored + pending literals)
     int ns = 0;              // pending literals, lane k holds the k-th
     uint32_t mylit = 0;
@@ -155,15 +152,15 @@ static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
         b.refill();
         last = b.take(1) != 0;
         const uint32_t type = b.take(2);
-        if (type == 3) return fail();
+        if (type == 3) return false;
         if (type == 0) {   // stored: to the next byte edge, LEN, ~LEN, LEN bytes
             b.take(b.cnt & 7);
             b.refill();
             const uint32_t len = b.take(16), nlen = b.take(16);
-            if ((len ^ nlen) != 0xFFFFu || pos + (int)len > usize) return fail();
+            if ((len ^ nlen) != 0xFFFFu || pos + (int)len > usize) return false;
             flush();
             const int64_t src = b.byte_pos();
-            if (src + (int64_t)len > (int64_t)blk.csize) return fail();
+            if (src + (int64_t)len > (int64_t)csize) return false;
             for (int i = lane; i < (int)len; i += 64) out[pos + i] = b.base[src + i];
             pos += (int)len;
             b.start(b.base + src + len, b.limit - (src + len));
@@ -174,10 +171,10 @@ static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
             for (int s = lane; s < 288; s += 64) lens[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
             if (lane < 32) lens[288 + lane] = 5;
             __builtin_amdgcn_wave_barrier();
-            if (!build_code(lens, 288, sym_ll, ll) || !build_code(lens + 288, 30, sym_d, dd)) return fail();
+            if (!build_code(lens, 288, sym_ll, ll) || !build_code(lens + 288, 30, sym_d, dd)) return false;
         } else {           // dynamic code (3.2.7)
             const int hlit = (int)b.take(5) + 257, hdist = (int)b.take(5) + 1, hclen = (int)b.take(4) + 4;
-            if (hlit > 286 || hdist > 30) return fail();
+            if (hlit > 286 || hdist > 30) return false;
             if (lane < 19) lens[lane] = 0;
             for (int i = 0; i < hclen; ++i) {
                 b.refill();
@@ -186,47 +183,47 @@ static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
             }
             __builtin_amdgcn_wave_barrier();
             Code cl;
-            if (!build_code(lens, 19, sym_d, cl)) return fail();   // (the distance table is free until its own build)
+            if (!build_code(lens, 19, sym_d, cl)) return false;   // (the distance table is free until its own build)
             int n = 0;
             uint32_t prev = 0;
             const int total = hlit + hdist;
             while (n < total) {
                 b.refill();
                 const int s = decode_sym(b, cl, sym_d);
-                if (s < 0) return fail();
+                if (s < 0) return false;
                 uint32_t val = 0; int rep = 1;
                 if (s < 16) { val = (uint32_t)s; prev = val; }
-                else if (s == 16) { if (n == 0) return fail(); val = prev; rep = 3 + (int)b.take(2); }
+                else if (s == 16) { if (n == 0) return false; val = prev; rep = 3 + (int)b.take(2); }
                 else if (s == 17) { rep = 3 + (int)b.take(3); prev = 0; }
                 else { rep = 11 + (int)b.take(7); prev = 0; }
-                if (n + rep > total) return fail();
+                if (n + rep > total) return false;
                 // lens of the two codes back to back at 32 (behind the 19 of the code length code, which is still in use)
                 for (int i = lane; i < rep; i += 64) lens[32 + n + i] = (uint8_t)val;
                 n += rep;
             }
             __builtin_amdgcn_wave_barrier();
-            if (lens[32 + 256] == 0) return fail();   // no end-of-block code
-            if (!build_code(lens + 32, hlit, sym_ll, ll) || !build_code(lens + 32 + hlit, hdist, sym_d, dd)) return fail();
+            if (lens[32 + 256] == 0) return false;   // no end-of-block code
+            if (!build_code(lens + 32, hlit, sym_ll, ll) || !build_code(lens + 32 + hlit, hdist, sym_d, dd)) return false;
         }
         for (;;) {
             b.refill();
             const int s = decode_sym(b, ll, sym_ll);
-            if (s < 0) return fail();
+            if (s < 0) return false;
             if (s < 256) {
-                if (pos >= usize) return fail();
+                if (pos >= usize) return false;
                 if (lane == ns) mylit = (uint32_t)s;
                 ++ns; ++pos;
                 if (ns == 64) flush();
                 continue;
             }
             if (s == 256) break;
-            if (s > 285) return fail();
+            if (s > 285) return false;
             const int len = (int)(rdlane(lbase, s - 257) + b.take((int)rdlane(lext, s - 257)));
             b.refill();
             const int ds = decode_sym(b, dd, sym_d);
-            if (ds < 0 || ds > 29) return fail();
+            if (ds < 0 || ds > 29) return false;
             const int dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));
-            if (dist > pos || pos + len > usize) return fail();
+            if (dist > pos || pos + len > usize) return false;
             flush();
             // out[pos + i] = out[pos - dist + i]; with dist < len the source repeats with period dist: only bytes in front of
             // pos are read
@@ -235,7 +232,19 @@ static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
         }
     }
     flush();
-    if (pos != usize) return fail();
+    return pos == usize;
+}
+
+static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
+    __shared__ uint16_t s_ll[WAVES][288 + 32];   // sorted literal/length symbols, then the distance symbols
+    __shared__ uint8_t s_len[WAVES][320 + 64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t bi = (int64_t)blockIdx.x * WAVES + wave;
+    if (bi >= a.n_blocks) return;
+    const DevBlock blk = a.blocks[bi];
+    const bool ok = inflate_block(a.comp + blk.coff, (int64_t)(a.comp_bytes - blk.coff), (int)blk.csize, a.out + blk.uoff, (int)blk.usize,
+                                  s_ll[wave], s_ll[wave] + 288, s_len[wave]);
+    if (!ok && (threadIdx.x & 63) == 0) atomicMin(a.first_bad, (unsigned long long)bi);
 }
 
 } // namespace inf

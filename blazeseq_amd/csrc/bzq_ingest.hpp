@@ -59,7 +59,8 @@ struct bzq_ingest {
     unsigned long long* bad_pinned = nullptr;   // [2]
     double ratio_est = 0.30;       // compressed / inflated bytes of the last chunk: how much to read for the next one
     bzq::IngestSlot slot[2];
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr;   // H2D of the chunks (and, device inflate, the kernels of the even chunks)
+    hipStream_t copy_stream2 = nullptr;  // device inflate: the odd chunks, so that two chunks' blocks are in flight at once
     hipEvent_t dev_free[2] = {nullptr, nullptr}; // recorded on the ctx stream once slot i's device buffer may be overwritten
     bool dev_free_valid[2] = {false, false};
     std::thread producer;
@@ -284,6 +285,9 @@ inline void ingest_producer(bzq_ingest* g) {
         }
         uint64_t len = 0, comp_len = 0;
         int64_t n_blocks = 0;
+        // one block is decoded by one wave at its own pace (~20 ms for 64 KiB): a chunk is too few blocks to fill the device,
+        // so the inflate kernels of consecutive chunks run side by side on two streams
+        const hipStream_t cs = (g->gpu_inflate && (k & 1)) ? g->copy_stream2 : g->copy_stream;
         bool eof = false, ok;
         const auto t0 = std::chrono::steady_clock::now();
         std::string err;
@@ -309,26 +313,26 @@ inline void ingest_producer(bzq_ingest* g) {
             g->stats.bytes_read += len;
             g->cv.wait(lk, [&] { return g->stop || g->released >= k - 1; });
             if (g->stop) return;
-            he = g->dev_free_valid[k & 1] ? hipStreamWaitEvent(g->copy_stream, g->dev_free[k & 1], 0) : hipSuccess;
+            he = g->dev_free_valid[k & 1] ? hipStreamWaitEvent(cs, g->dev_free[k & 1], 0) : hipSuccess;
         }
         if (he != hipSuccess) return fail("reader: hipStreamWaitEvent", he);
         if (g->gpu_inflate) {
             const int b = (int)(k & 1);
             g->bad_pinned[b] = ~0ull;   // (the consumer read the previous verdict of this slot two chunks ago)
             if (n_blocks) {
-                if ((he = hipMemcpyAsync(g->comp_dev[b], s.pinned + g->reserve, comp_len, hipMemcpyHostToDevice, g->copy_stream)) != hipSuccess ||
-                    (he = hipMemcpyAsync(g->tab_dev[b], g->tab_pinned[b], (size_t)n_blocks * sizeof(bzq::inf::DevBlock), hipMemcpyHostToDevice, g->copy_stream)) != hipSuccess ||
-                    (he = hipMemsetAsync(g->bad_dev + b, 0xFF, sizeof(unsigned long long), g->copy_stream)) != hipSuccess)
+                if ((he = hipMemcpyAsync(g->comp_dev[b], s.pinned + g->reserve, comp_len, hipMemcpyHostToDevice, cs)) != hipSuccess ||
+                    (he = hipMemcpyAsync(g->tab_dev[b], g->tab_pinned[b], (size_t)n_blocks * sizeof(bzq::inf::DevBlock), hipMemcpyHostToDevice, cs)) != hipSuccess ||
+                    (he = hipMemsetAsync(g->bad_dev + b, 0xFF, sizeof(unsigned long long), cs)) != hipSuccess)
                     return fail("reader: host to device copy (compressed blocks)", he);
                 bzq::inf::Args ia{g->comp_dev[b], comp_len, g->tab_dev[b], n_blocks, s.dev + g->reserve, g->bad_dev + b};
-                hipLaunchKernelGGL(bzq::inf::k_bgzf_inflate, dim3((unsigned)((n_blocks + bzq::inf::WAVES - 1) / bzq::inf::WAVES)), dim3(BLOCK), 0, g->copy_stream, ia);
+                hipLaunchKernelGGL(bzq::inf::k_bgzf_inflate, dim3((unsigned)((n_blocks + bzq::inf::WAVES - 1) / bzq::inf::WAVES)), dim3(BLOCK), 0, cs, ia);
                 if ((he = hipGetLastError()) != hipSuccess ||
-                    (he = hipMemcpyAsync(g->bad_pinned + b, g->bad_dev + b, sizeof(unsigned long long), hipMemcpyDeviceToHost, g->copy_stream)) != hipSuccess)
+                    (he = hipMemcpyAsync(g->bad_pinned + b, g->bad_dev + b, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs)) != hipSuccess)
                     return fail("reader: device inflate", he);
             }
-        } else if (len && (he = hipMemcpyAsync(s.dev + g->reserve, s.pinned + g->reserve, len, hipMemcpyHostToDevice, g->copy_stream)) != hipSuccess)
+        } else if (len && (he = hipMemcpyAsync(s.dev + g->reserve, s.pinned + g->reserve, len, hipMemcpyHostToDevice, cs)) != hipSuccess)
             return fail("reader: host to device copy", he);
-        if ((he = hipEventRecord(s.h2d_done, g->copy_stream)) != hipSuccess) return fail("reader: hipEventRecord", he);
+        if ((he = hipEventRecord(s.h2d_done, cs)) != hipSuccess) return fail("reader: hipEventRecord", he);
         s.file_off = off; s.len = len; s.eof = eof;
         off += len;
         {
@@ -350,6 +354,7 @@ inline void ingest_free(bzq_ingest* g) {
     if (g->producer.joinable()) g->producer.join();
     (void)hipSetDevice(g->device);
     if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
+    if (g->copy_stream2) { (void)hipStreamSynchronize(g->copy_stream2); (void)hipStreamDestroy(g->copy_stream2); }
     for (int i = 0; i < 2; ++i) {
         if (g->slot[i].pinned) (void)hipHostFree(g->slot[i].pinned);
         if (g->slot[i].dev) (void)hipFree(g->slot[i].dev);
