@@ -65,7 +65,7 @@ struct Bits {
 
 // One canonical Huffman code, spread over the lanes: lane L (1..15) holds, for the codes of length L, the left-aligned (15-bit)
 // upper bound `lim`, the first code `first` and the index of its first symbol in the sorted symbol table `offs`.
-struct Code { uint32_t lim, first, offs; };
+struct Code { uint32_t lim, first, offs; int n_coded; };
 
 // lens[0..n) (LDS, one byte per symbol, 0 = unused) -> Code + symtab (LDS).  Returns false when the lengths over-subscribe the
 // code space.  n <= 320.
@@ -91,7 +91,7 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint16_t*
         if (c + n_l > (1u << L)) over = true;
         c += n_l; o += n_l;
     }
-    code.first = first; code.offs = offs; code.lim = (lane >= 1 && lane <= 15) ? lim : 0u;
+    code.first = first; code.offs = offs; code.lim = (lane >= 1 && lane <= 15) ? lim : 0u; code.n_coded = (int)o;
     // symbols sorted by (length, symbol): position = offs[length] + symbols of the same length before it
     uint32_t run = 0;        // lane L: symbols of length L placed so far
     for (int s0 = 0; s0 < n; s0 += 64) {
@@ -121,6 +121,32 @@ __device__ __forceinline__ int decode_sym(Bits& b, const Code& code, const uint1
     return (int)uni(symtab[idx]);
 }
 
+// The literal/length code also gets a direct table for its codes of up to LUT_BITS bits (in FASTQ: nearly all of them):
+// lut[next LUT_BITS stream bits] = symbol | length << 12, 0 = a longer code (decode_sym).  One LDS read per symbol instead of
+// compare + ballot + two readlanes + the read.  Filled from the sorted symbols: the code of the symbol at sorted position p is
+// first[l] + (p - offs[l]), its bit-reversed value r selects the entries r + k * 2^l.
+constexpr int LUT_BITS = 10;
+__device__ __forceinline__ void build_lut(const Code& code, const uint16_t* symtab, const uint8_t* lens, uint16_t* lut) {
+    const int lane = threadIdx.x & 63;
+    uint32_t* lut32 = reinterpret_cast<uint32_t*>(lut);
+#pragma unroll
+    for (int i = 0; i < (1 << LUT_BITS) / 2 / 64; ++i) lut32[i * 64 + lane] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (int p0 = 0; p0 < code.n_coded; p0 += 64) {
+        const int p = p0 + lane;
+        const uint32_t sym = p < code.n_coded ? symtab[p] : 0u;
+        const int l = p < code.n_coded ? lens[sym] : 0;
+        // (every lane takes part in the gathers: ds_bpermute reads nothing from a lane that is switched off)
+        const uint32_t f = (uint32_t)__builtin_amdgcn_ds_bpermute(l * 4, (int)code.first), o = (uint32_t)__builtin_amdgcn_ds_bpermute(l * 4, (int)code.offs);
+        if (l >= 1 && l <= LUT_BITS) {
+            const uint32_t r = __builtin_bitreverse32(f + ((uint32_t)p - o)) >> (32 - l);
+            const uint16_t e = (uint16_t)(sym | ((uint32_t)l << 12));
+            for (uint32_t k = r; k < (1u << LUT_BITS); k += 1u << l) lut[k] = e;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // RFC 1951 3.2.5: base and extra bits of the length codes 257..285 and the distance codes 0..29, lane i = code i
 __device__ __forceinline__ void length_dist_tables(uint32_t& lbase, uint32_t& lext, uint32_t& dbase, uint32_t& dext) {
     const int i = threadIdx.x & 63;
@@ -135,7 +161,7 @@ static __device__ const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5
 
 // One BGZF block by one wave.  Every branch in here is uniform; false = the stream is not a valid DEFLATE stream of usize bytes.
 __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_left, int csize, uint8_t* out, int usize,
-                                              uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens) {
+                                              uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens, uint16_t* lut) {
     const int lane = threadIdx.x & 63;
     uint32_t lbase, lext, dbase, dext;
     length_dist_tables(lbase, lext, dbase, dext);
@@ -172,6 +198,7 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             if (lane < 32) lens[288 + lane] = 5;
             __builtin_amdgcn_wave_barrier();
             if (!build_code(lens, 288, sym_ll, ll) || !build_code(lens + 288, 30, sym_d, dd)) return false;
+            build_lut(ll, sym_ll, lens, lut);
         } else {           // dynamic code (3.2.7)
             const int hlit = (int)b.take(5) + 257, hdist = (int)b.take(5) + 1, hclen = (int)b.take(4) + 4;
             if (hlit > 286 || hdist > 30) return false;
@@ -204,16 +231,18 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             __builtin_amdgcn_wave_barrier();
             if (lens[32 + 256] == 0) return false;   // no end-of-block code
             if (!build_code(lens + 32, hlit, sym_ll, ll) || !build_code(lens + 32 + hlit, hdist, sym_d, dd)) return false;
+            build_lut(ll, sym_ll, lens + 32, lut);
         }
         for (;;) {
             b.refill();
-            const int s = decode_sym(b, ll, sym_ll);
-            if (s < 0) return false;
-            if (s < 256) {
-                if (pos >= usize) return false;
+            int s;
+            const uint32_t e = uni(lut[(uint32_t)b.buf & ((1u << LUT_BITS) - 1u)]);
+            if (e) { s = (int)(e & 0xFFFu); const int l = (int)(e >> 12); b.buf >>= l; b.cnt -= l; }
+            else { s = decode_sym(b, ll, sym_ll); if (s < 0) return false; }
+            if (s < 256) {   // (the bound on pos is checked when the literals leave: flush)
                 if (lane == ns) mylit = (uint32_t)s;
                 ++ns; ++pos;
-                if (ns == 64) flush();
+                if (ns == 64) { if (pos > usize) return false; flush(); }
                 continue;
             }
             if (s == 256) break;
@@ -223,7 +252,7 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             const int ds = decode_sym(b, dd, sym_d);
             if (ds < 0 || ds > 29) return false;
             const int dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));
-            if (dist > pos || pos + len > usize) return false;
+            if (dist > pos || pos + len > usize) return false;   // (also covers literals still pending)
             flush();
             // out[pos + i] = out[pos - dist + i]; with dist < len the source repeats with period dist: only bytes in front of
             // pos are read
@@ -231,6 +260,7 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             pos += len;
         }
     }
+    if (pos > usize) return false;
     flush();
     return pos == usize;
 }
@@ -238,12 +268,13 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
 static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
     __shared__ uint16_t s_ll[WAVES][288 + 32];   // sorted literal/length symbols, then the distance symbols
     __shared__ uint8_t s_len[WAVES][320 + 64];
+    __shared__ __attribute__((aligned(4))) uint16_t s_lut[WAVES][1 << LUT_BITS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t bi = (int64_t)blockIdx.x * WAVES + wave;
     if (bi >= a.n_blocks) return;
     const DevBlock blk = a.blocks[bi];
     const bool ok = inflate_block(a.comp + blk.coff, (int64_t)(a.comp_bytes - blk.coff), (int)blk.csize, a.out + blk.uoff, (int)blk.usize,
-                                  s_ll[wave], s_ll[wave] + 288, s_len[wave]);
+                                  s_ll[wave], s_ll[wave] + 288, s_len[wave], s_lut[wave]);
     if (!ok && (threadIdx.x & 63) == 0) atomicMin(a.first_bad, (unsigned long long)bi);
 }
 

@@ -18,6 +18,7 @@ CAMPAIGNS = {
     "parser_level": (["tests/fuzz_campaign_parser.py", "--seconds", BUDGET], "identical"),
     "shards": (["tests/fuzz_campaign_shards.py", "--seconds", BUDGET], "identical to the one-shot parse"),
     "fasta": (["tests/fuzz_campaign_fasta.py", BUDGET, "1"], "identical"),
+    "inflate": (["tests/fuzz_campaign_inflate.py", "--seconds", BUDGET], "identical to the bytes zlib compressed"),
     "fasta_shards": (["tests/fuzz_campaign_fasta_shards.py", "--seconds", BUDGET], "identical to the sequential parse"),
 }
 
