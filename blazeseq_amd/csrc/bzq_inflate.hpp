@@ -122,15 +122,16 @@ __device__ __forceinline__ int decode_sym(Bits& b, const Code& code, const uint1
 }
 
 // The literal/length code also gets a direct table for its codes of up to LUT_BITS bits (in FASTQ: nearly all of them):
-// lut[next LUT_BITS stream bits] = symbol | length << 12, 0 = a longer code (decode_sym).  One LDS read per symbol instead of
+// lut[next LUT_BITS stream bits] = symbol | length << 12, LUT_LONG = a longer code (decode_sym).  One LDS read per symbol instead of
 // compare + ballot + two readlanes + the read.  Filled from the sorted symbols: the code of the symbol at sorted position p is
 // first[l] + (p - offs[l]), its bit-reversed value r selects the entries r + k * 2^l.
 constexpr int LUT_BITS = 10;
+constexpr uint32_t LUT_LONG = 0x100u;   // entry of a code longer than LUT_BITS (bit 8 set like every non-literal, length 0)
 __device__ __forceinline__ void build_lut(const Code& code, const uint16_t* symtab, const uint8_t* lens, uint16_t* lut) {
     const int lane = threadIdx.x & 63;
     uint32_t* lut32 = reinterpret_cast<uint32_t*>(lut);
 #pragma unroll
-    for (int i = 0; i < (1 << LUT_BITS) / 2 / 64; ++i) lut32[i * 64 + lane] = 0u;
+    for (int i = 0; i < (1 << LUT_BITS) / 2 / 64; ++i) lut32[i * 64 + lane] = LUT_LONG * 0x10001u;
     __builtin_amdgcn_wave_barrier();
     for (int p0 = 0; p0 < code.n_coded; p0 += 64) {
         const int p = p0 + lane;
@@ -167,12 +168,12 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
     length_dist_tables(lbase, lext, dbase, dext);
     Bits b;
     b.start(comp, comp_left);
-    int pos = 0;             // bytes decoded so far (stored + pending literals)
-    int ns = 0;              // pending literals, lane k holds the k-th
+    int pos = 0;             // bytes stored so far
+    int ns = 0;              // literals decoded and not yet stored: lane k holds the k-th (pos + ns = bytes decoded)
     uint32_t mylit = 0;
-    auto flush = [&]() {
-        if (lane < ns) out[pos - ns + lane] = (uint8_t)mylit;
-        ns = 0;
+    auto flush = [&]() {     // (callers have checked pos + ns <= usize)
+        if (lane < ns) out[pos + lane] = (uint8_t)mylit;
+        pos += ns; ns = 0;
     };
     for (bool last = false; !last;) {
         b.refill();
@@ -183,7 +184,7 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             b.take(b.cnt & 7);
             b.refill();
             const uint32_t len = b.take(16), nlen = b.take(16);
-            if ((len ^ nlen) != 0xFFFFu || pos + (int)len > usize) return false;
+            if ((len ^ nlen) != 0xFFFFu || pos + ns + (int)len > usize) return false;
             flush();
             const int64_t src = b.byte_pos();
             if (src + (int64_t)len > (int64_t)csize) return false;
@@ -234,15 +235,33 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             build_lut(ll, sym_ll, lens + 32, lut);
         }
         for (;;) {
-            b.refill();
+            // the common case first, as tight as it gets (the decoder is bound by the CU's one scalar unit): a run of
+            // literals through the direct table.  Bit 8 of an entry says "not a literal" (a length code, the end of the
+            // block, or the marker of a code longer than the table).
+            uint32_t e;
+            for (;;) {
+                b.refill();
+                e = uni(lut[(uint32_t)b.buf & ((1u << LUT_BITS) - 1u)]);
+                if (e & 0x100u) break;
+                const int l = (int)(e >> 12);
+                b.buf >>= l; b.cnt -= l;
+                if (lane == ns) mylit = e;
+                if (++ns == 64) {
+                    if (pos + 64 > usize) return false;
+                    out[pos + lane] = (uint8_t)mylit;
+                    pos += 64; ns = 0;
+                }
+            }
             int s;
-            const uint32_t e = uni(lut[(uint32_t)b.buf & ((1u << LUT_BITS) - 1u)]);
-            if (e) { s = (int)(e & 0xFFFu); const int l = (int)(e >> 12); b.buf >>= l; b.cnt -= l; }
+            if (e != LUT_LONG) { s = (int)(e & 0xFFFu); const int l = (int)(e >> 12); b.buf >>= l; b.cnt -= l; }
             else { s = decode_sym(b, ll, sym_ll); if (s < 0) return false; }
-            if (s < 256) {   // (the bound on pos is checked when the literals leave: flush)
+            if (s < 256) {   // a literal with a long code
                 if (lane == ns) mylit = (uint32_t)s;
-                ++ns; ++pos;
-                if (ns == 64) { if (pos > usize) return false; flush(); }
+                if (++ns == 64) {
+                    if (pos + 64 > usize) return false;
+                    out[pos + lane] = (uint8_t)mylit;
+                    pos += 64; ns = 0;
+                }
                 continue;
             }
             if (s == 256) break;
@@ -252,7 +271,7 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             const int ds = decode_sym(b, dd, sym_d);
             if (ds < 0 || ds > 29) return false;
             const int dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));
-            if (dist > pos || pos + len > usize) return false;   // (also covers literals still pending)
+            if (dist > pos + ns || pos + ns + len > usize) return false;
             flush();
             // out[pos + i] = out[pos - dist + i]; with dist < len the source repeats with period dist: only bytes in front of
             // pos are read
@@ -260,7 +279,7 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             pos += len;
         }
     }
-    if (pos > usize) return false;
+    if (pos + ns > usize) return false;
     flush();
     return pos == usize;
 }
