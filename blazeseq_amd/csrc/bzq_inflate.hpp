@@ -168,6 +168,7 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
     length_dist_tables(lbase, lext, dbase, dext);
     Bits b;
     b.start(comp, comp_left);
+    int64_t payload_off = 0;   // bytes of the payload in front of b.base (the reader is re-based behind every stored block)
     int pos = 0;             // bytes stored so far
     int ns = 0;              // literals decoded and not yet stored: lane k holds the k-th (pos + ns = bytes decoded)
     uint32_t mylit = 0;
@@ -187,9 +188,10 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             if ((len ^ nlen) != 0xFFFFu || pos + ns + (int)len > usize) return false;
             flush();
             const int64_t src = b.byte_pos();
-            if (src + (int64_t)len > (int64_t)csize) return false;
+            if (payload_off + src + (int64_t)len > (int64_t)csize) return false;   // the bytes must lie inside this block's payload
             for (int i = lane; i < (int)len; i += 64) out[pos + i] = b.base[src + i];
             pos += (int)len;
+            payload_off += src + len;
             b.start(b.base + src + len, b.limit - (src + len));
             continue;
         }
