@@ -139,7 +139,8 @@ class BzqFastaChunk(C.Structure):
 
 
 class BzqBgzfBlock(C.Structure):
-    _fields_ = [("comp_offset", C.c_uint64), ("comp_size", C.c_uint32), ("out_size", C.c_uint32), ("out_offset", C.c_uint64)]
+    _fields_ = [("comp_offset", C.c_uint64), ("comp_size", C.c_uint32), ("out_size", C.c_uint32), ("crc32", C.c_uint32), ("_pad", C.c_uint32),
+                ("out_offset", C.c_uint64)]
 
 
 class BzqFastaShardSummary(C.Structure):

@@ -961,7 +961,8 @@ int32_t bzq_bgzf_scan(const uint8_t* comp, uint64_t n, uint64_t max_out, bzq_bgz
         const uint32_t us = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
         if (us > 65536) { *n_blocks = k; *consumed = off; *out_bytes = usum; return BZQ_ERR_IO; }
         if (usum + us > max_out) break;
-        blocks[k++] = bzq_bgzf_block{off, bs, us, usum};
+        const uint32_t crc = (uint32_t)t[-4] | ((uint32_t)t[-3] << 8) | ((uint32_t)t[-2] << 16) | ((uint32_t)t[-1] << 24);
+        blocks[k++] = bzq_bgzf_block{off, bs, us, crc, 0u, usum};
         usum += us; off += bs;
     }
     *n_blocks = k; *consumed = off; *out_bytes = usum;
@@ -980,7 +981,7 @@ int32_t bzq_bgzf_inflate(bzq_ctx* c, const uint8_t* d_comp, uint64_t comp_bytes,
             c->err = "bzq_bgzf_inflate: block " + std::to_string(i) + " lies outside the buffers";
             return BZQ_ERR_ARG;
         }
-        hb[(size_t)i] = bzq::inf::DevBlock{b.comp_offset + 18, b.out_offset, b.comp_size - 26, b.out_size};
+        hb[(size_t)i] = bzq::inf::DevBlock{b.comp_offset + 18, b.out_offset, b.comp_size - 26, b.out_size, b.crc32, 0u};
     }
     int rc;
     const size_t tbytes = (size_t)n_blocks * sizeof(bzq::inf::DevBlock);

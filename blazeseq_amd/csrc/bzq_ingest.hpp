@@ -148,7 +148,7 @@ inline uint32_t bgzf_block_size(const uint8_t* p) {
     return (uint32_t)(p[16] | (p[17] << 8)) + 1u;
 }
 
-struct BgzfBlock { uint64_t coff; uint32_t csize, usize; uint64_t uoff; };
+struct BgzfBlock { uint64_t coff; uint32_t csize, usize; uint64_t uoff; uint32_t crc; };
 
 // Inflate a run of BGZF blocks (already read into `comp`) into dst with n_threads workers.
 inline bool bgzf_inflate_blocks(const std::vector<BgzfBlock>& blocks, const uint8_t* comp, uint64_t comp_base, uint8_t* dst,
@@ -171,6 +171,7 @@ inline bool bgzf_inflate_blocks(const std::vector<BgzfBlock>& blocks, const uint
             const int rc = inflate(&zs, Z_FINISH);
             inflateEnd(&zs);
             if (rc != Z_STREAM_END || zs.avail_out != 0) { ok = false; return; }
+            if ((uint32_t)crc32(0L, dst + b.uoff, b.usize) != b.crc) { ok = false; return; }   // RFC 1952 8.: CRC-32 of the uncompressed data
         }
     };
     std::vector<std::thread> th;
@@ -206,16 +207,17 @@ inline bool read_compressed_chunk(bzq_ingest* g, uint8_t* dst, uint64_t cap, uin
     // BGZF: collect whole blocks until the chunk is full
     std::vector<BgzfBlock> blocks;
     uint64_t usum = 0, coff = g->bgzf_off;
-    uint8_t hdr[18], tail[4];
+    uint8_t hdr[18], tail[8];
     while (coff < g->file_size) {
         if (coff + 28 > g->file_size || pread(g->fd, hdr, 18, (off_t)coff) != 18) { err = "BGZF: truncated block header"; return false; }
         const uint32_t bs = bgzf_block_size(hdr);
         if (!bs || bs < 26 || coff + bs > g->file_size) { err = "BGZF: bad block header"; return false; }
-        if (pread(g->fd, tail, 4, (off_t)(coff + bs - 4)) != 4) { err = "BGZF: truncated block"; return false; }
-        const uint32_t us = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+        if (pread(g->fd, tail, 8, (off_t)(coff + bs - 8)) != 8) { err = "BGZF: truncated block"; return false; }
+        const uint32_t crc = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+        const uint32_t us = (uint32_t)tail[4] | ((uint32_t)tail[5] << 8) | ((uint32_t)tail[6] << 16) | ((uint32_t)tail[7] << 24);
         if (us > 65536) { err = "BGZF: block claims more than 64 KiB"; return false; }
         if (usum + us > cap) break;
-        blocks.push_back({coff, bs, us, usum});
+        blocks.push_back({coff, bs, us, usum, crc});
         usum += us;
         coff += bs;
     }
@@ -252,7 +254,8 @@ inline bool read_bgzf_window(bzq_ingest* g, uint8_t* pinned, uint64_t cap, bzq::
         const uint32_t us = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
         if (us > 65536) { if (k == 0) { err = "BGZF: block claims more than 64 KiB"; return false; } break; }
         if (usum + us > g->chunk_bytes) break;
-        tab[k++] = bzq::inf::DevBlock{off + 18, usum, bs - 26, us};
+        const uint32_t crc = (uint32_t)t[-4] | ((uint32_t)t[-3] << 8) | ((uint32_t)t[-2] << 16) | ((uint32_t)t[-1] << 24);
+        tab[k++] = bzq::inf::DevBlock{off + 18, usum, bs - 26, us, crc, 0u};
         usum += us; off += bs;
     }
     if (k == 0) { err = want == remaining ? "BGZF: truncated block" : "BGZF: a block does not fit the chunk"; return false; }

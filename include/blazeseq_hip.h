@@ -358,6 +358,8 @@ typedef struct bzq_bgzf_block {
     uint64_t comp_offset;   /* of the block's gzip header in the compressed buffer */
     uint32_t comp_size;     /* BSIZE + 1: header (18) + deflate payload + CRC32 + ISIZE */
     uint32_t out_size;      /* ISIZE */
+    uint32_t crc32;         /* CRC-32 of the output (the block's trailer, RFC 1952 2.3.1) */
+    uint32_t _pad;
     uint64_t out_offset;    /* where its output goes */
 } bzq_bgzf_block;
 
@@ -367,7 +369,7 @@ typedef struct bzq_bgzf_block {
 int32_t bzq_bgzf_scan(const uint8_t* comp, uint64_t n, uint64_t max_out, bzq_bgzf_block* blocks, int64_t cap, int64_t* n_blocks,
                       uint64_t* consumed, uint64_t* out_bytes);
 /* Inflate blocks[0..n_blocks) of the device-resident compressed bytes d_comp[0, comp_bytes) (8 readable bytes of padding
- * behind them are not required) into d_out.  ISIZE, every match distance and length are checked, the CRC32 is not.
+ * behind them are not required) into d_out.  ISIZE, every match distance and length and the CRC-32 of every block's output are checked.
  * Synchronous on the ctx stream.  BZQ_ERR_IO: a block does not decode (bzq_last_error names the first). */
 int32_t bzq_bgzf_inflate(bzq_ctx* ctx, const uint8_t* d_comp, uint64_t comp_bytes, const bzq_bgzf_block* blocks, int64_t n_blocks,
                          uint8_t* d_out, uint64_t out_capacity);

@@ -41,7 +41,7 @@ tab = (L.BzqBgzfBlock * (n * reps))()
 for r in range(reps):
     for i in range(n):
         s, d = blocks[i], tab[r * n + i]
-        d.comp_offset, d.comp_size, d.out_size, d.out_offset = s.comp_offset, s.comp_size, s.out_size, s.out_offset + r * out_bytes
+        d.comp_offset, d.comp_size, d.out_size, d.crc32, d.out_offset = s.comp_offset, s.comp_size, s.out_size, s.crc32, s.out_offset + r * out_bytes
 d_comp = torch.from_numpy(comp.copy()).cuda()
 d_out = torch.empty(out_bytes * reps + 64, dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
