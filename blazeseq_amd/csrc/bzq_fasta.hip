@@ -337,7 +337,7 @@ int32_t bzq_fasta_shard_probe_(bzq_fasta* h, const uint8_t* d, uint64_t n, int64
         ProbeArgs a{d, (int64_t)n, (ProbeOut*)h->probe.p};
         const int64_t nt = (int64_t)((n + TILE - 1) / TILE);
         for (int64_t lo = 0, span = 8; lo < nt; lo += span, span *= 8) {
-            ProbeHdrArgs ha{d, (int64_t)n, (ProbeOut*)h->probe.p, lo};
+            ProbeHdrArgs ha{d, (int64_t)n, (ProbeOut*)h->probe.p, lo, h->cfg.line_capacity};
             hipLaunchKernelGGL(k_fa_probe_headers, dim3((unsigned)std::min<int64_t>(span, nt - lo)), dim3(BLOCK), 0, h->stream, ha);
         }
         hipLaunchKernelGGL(k_fa_probe_edges, dim3(1), dim3(BLOCK), 0, h->stream, a);

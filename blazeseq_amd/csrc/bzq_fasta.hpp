@@ -648,7 +648,7 @@ __device__ __forceinline__ bool is_space_byte(uint32_t c) { return c == 32u || (
 // at the first '\n'), so a range with a header in its first kilobytes costs a few empty launches and a range without
 // one is read once at streaming speed.  (One grid over everything with an early-exit flag does not work on this part:
 // the flag is one address polled from 8 XCDs -- 0.45 ms for 2048 workgroups, longer than reading 3 GB.)
-struct ProbeHdrArgs { const uint8_t* data; int64_t n; ProbeOut* out; int64_t tile_lo; };
+struct ProbeHdrArgs { const uint8_t* data; int64_t n; ProbeOut* out; int64_t tile_lo, walk_cap; };
 static __global__ __launch_bounds__(BLOCK) void k_fa_probe_headers(ProbeHdrArgs a) {
     __shared__ unsigned long long s_min;
     const int tid = threadIdx.x;
@@ -669,8 +669,11 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_probe_headers(ProbeHdrArgs 
         while (m) {
             const int bit = __builtin_ctz(m);
             m &= m - 1;
+            // (the walk stops after line_capacity bytes: a line that long fails wherever it is parsed, and a hostile run of
+            // spaces in front of a '>' must not cost a serial pass over it)
             int64_t q = t0 + pos + bit - 1;
-            while (q >= 0 && a.data[q] != 10 && is_space_byte(a.data[q])) --q;
+            const int64_t stop = q - a.walk_cap;
+            while (q >= 0 && q > stop && a.data[q] != 10 && is_space_byte(a.data[q])) --q;
             if (q >= 0 && a.data[q] == 10) atomicMin(&s_min, (unsigned long long)(q + 1));
         }
     }

@@ -12,15 +12,16 @@ SPACES = frozenset([9, 10, 11, 12, 13, 28, 29, 30, 32])
 EOF_, TOO_LONG, EMPTY_SEQ, ASCII_BAD = 6, 8, 11, 4
 
 
-def summary_of(piece: np.ndarray):
-    """(n_bytes, first_header, lead_kind, last_byte, tail_open) of one range, byte by byte."""
+def summary_of(piece: np.ndarray, walk_cap: int = 1 << 62):
+    """(n_bytes, first_header, lead_kind, last_byte, tail_open) of one range, byte by byte.  walk_cap: the device stops looking
+    for a '>' line's start after line_capacity bytes of spaces (such a line fails wherever it is parsed)."""
     b = piece.tobytes()
     n = len(b)
     first_header = -1
     for q in range(n):
         if b[q] == 62:   # '>'
             j = q - 1
-            while j >= 0 and b[j] != 10 and b[j] in SPACES:
+            while j >= 0 and j > q - 1 - walk_cap and b[j] != 10 and b[j] in SPACES:
                 j -= 1
             if j >= 0 and b[j] == 10:
                 first_header = j + 1

@@ -85,7 +85,7 @@ while time.time() - t0 < args.seconds:
     def summarize(piece):
         s = fa.shard_scan(upload(piece, 48), piece.size)
         got = (int(s.n_bytes), int(s.first_header), int(s.lead_kind), int(s.last_byte), int(s.tail_open))
-        assert got == summary_of(piece), (got, summary_of(piece))
+        assert got == summary_of(piece, walk_cap=CAP), (got, summary_of(piece, walk_cap=CAP))
         return got
 
     def parse_region(region, pos_base, record_base=0, line_base=0):

@@ -43,7 +43,7 @@ def test_probe_kernels_match_the_restatement():
     fa, ctx = FastaContext(), Context()
     rng = np.random.default_rng(3)
     pieces = [b"", b" ", b"\n", b">", b"  >x", b"\n  ", b"a\n  >b", b"\n\t\x1c >q\n", b"ACGT" * 10, b" " * 5000, b" " * 5000 + b">z",
-              b"x\n" + b" " * 40000 + b">far\nA\n", b"x\n" + b" " * 40000, b"A" * 70000 + b"\n>late\nC", b">a\n" + b"AC\n" * 30000 + b"  "]
+              b"x\n" + b" " * 40000 + b">far\nA\n", b"x\n" + b" " * 40000, b"x\n" + b" " * 300000 + b">too far\nA\n", b"A" * 70000 + b"\n>late\nC", b">a\n" + b"AC\n" * 30000 + b"  "]
     for _ in range(60):
         k = int(rng.integers(0, 3))
         if k == 0:
@@ -56,7 +56,7 @@ def test_probe_kernels_match_the_restatement():
         pieces.append(d[a:b])
     for p in pieces:
         a = np.frombuffer(p, dtype=np.uint8)
-        assert _device_summary(fa, ctx, a) == summary_of(a), p[:80]
+        assert _device_summary(fa, ctx, a) == summary_of(a, walk_cap=256 * 1024), p[:80]
 
 
 def _run(data: bytes, cuts, tmp_path, check=False, cap=0, name="s"):
