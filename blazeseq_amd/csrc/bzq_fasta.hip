@@ -334,7 +334,7 @@ int32_t bzq_fasta_shard_probe_(bzq_fasta* h, const uint8_t* d, uint64_t n, int64
     po.first_header = NONE; po.lead_kind = 3; po.tail_open = -1; po.last_byte = 10;
     if (n > 0) {
         FACHK(h, hipMemcpyAsync(h->probe.p, &po, sizeof po, hipMemcpyHostToDevice, h->stream));
-        ProbeArgs a{d, (int64_t)n, (ProbeOut*)h->probe.p};
+        ProbeArgs a{d, (int64_t)n, (ProbeOut*)h->probe.p, h->cfg.line_capacity};
         const int64_t nt = (int64_t)((n + TILE - 1) / TILE);
         for (int64_t lo = 0, span = 8; lo < nt; lo += span, span *= 8) {
             ProbeHdrArgs ha{d, (int64_t)n, (ProbeOut*)h->probe.p, lo, h->cfg.line_capacity};
@@ -360,7 +360,7 @@ int32_t bzq_fasta_count_newlines_(bzq_fasta* h, const uint8_t* d, uint64_t n, in
     if ((rc = ensure(h, h->probe, sizeof(ProbeOut)))) return rc;
     ProbeOut po{};
     FACHK(h, hipMemcpyAsync(h->probe.p, &po, sizeof po, hipMemcpyHostToDevice, h->stream));
-    ProbeArgs a{d, (int64_t)n, (ProbeOut*)h->probe.p};
+    ProbeArgs a{d, (int64_t)n, (ProbeOut*)h->probe.p, 0};
     hipLaunchKernelGGL(k_fa_count_newlines, dim3((unsigned)std::min<uint64_t>((n + BLOCK * 16 - 1) / (BLOCK * 16), 4096)), dim3(BLOCK), 0, h->stream, a);
     FACHK(h, hipMemcpyAsync(&po, h->probe.p, sizeof po, hipMemcpyDeviceToHost, h->stream));
     FACHK(h, hipStreamSynchronize(h->stream));

@@ -639,7 +639,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_long_start(LongStartArgs a)
 //   tail_open     start of the range's last line (behind its last '\n') when that line is non-empty and all spaces so
 //                 far -- whether it is a header line is decided by a later rank's lead_kind; -1 otherwise
 struct ProbeOut { unsigned long long first_header; int64_t lead_kind, tail_open, last_byte, newlines; };
-struct ProbeArgs { const uint8_t* data; int64_t n; ProbeOut* out; };
+struct ProbeArgs { const uint8_t* data; int64_t n; ProbeOut* out; int64_t walk_cap; };
 
 __device__ __forceinline__ bool is_space_byte(uint32_t c) { return c == 32u || (c - 9u) <= 4u || (c - 28u) <= 2u; }
 
@@ -688,7 +688,8 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_probe_edges(ProbeArgs a) {
     const int tid = threadIdx.x;
     constexpr int SPAN = BLOCK * 16;
     int64_t lead_kind = 3;
-    for (int64_t b0 = 0; b0 < a.n; b0 += SPAN) {
+    // (both scans give up after line_capacity bytes of spaces: that line fails wherever it is parsed, whatever is reported here)
+    for (int64_t b0 = 0; b0 < a.n && b0 <= a.walk_cap; b0 += SPAN) {
         if (tid == 0) { s_e.first_nl = SPAN; s_e.first_x = SPAN; }
         __syncthreads();
         const int64_t pos = b0 + tid * 16;
@@ -707,7 +708,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_probe_edges(ProbeArgs a) {
         if (fn < SPAN) { lead_kind = 2; break; }
     }
     int64_t tail_open = -1;
-    for (int64_t e0 = a.n; e0 > 0; e0 -= SPAN) {   // the span [e0 - SPAN, e0), clipped at 0
+    for (int64_t e0 = a.n; e0 > 0 && a.n - e0 <= a.walk_cap; e0 -= SPAN) {   // the span [e0 - SPAN, e0), clipped at 0
         if (tid == 0) { s_e.last_nl = -1; s_e.last_x = -1; }
         __syncthreads();
         const int64_t b0 = e0 - SPAN, pos = b0 + tid * 16;

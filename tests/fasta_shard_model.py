@@ -26,8 +26,10 @@ def summary_of(piece: np.ndarray, walk_cap: int = 1 << 62):
             if j >= 0 and b[j] == 10:
                 first_header = j + 1
                 break
+    # the two edge scans look at whole 4 KiB spans and give up once they are line_capacity bytes in
+    reach = (walk_cap // 4096 + 1) * 4096 if walk_cap < (1 << 61) else n
     lead_kind = 3
-    for q in range(n):
+    for q in range(min(n, reach)):
         if b[q] == 10:
             lead_kind = 2
             break
@@ -35,7 +37,8 @@ def summary_of(piece: np.ndarray, walk_cap: int = 1 << 62):
             lead_kind = 1 if b[q] == 62 else 0
             break
     tail_open = -1
-    ln = b.rfind(b"\n")
+    lo = max(0, n - reach)
+    ln = b.rfind(b"\n", lo)
     if ln >= 0 and ln + 1 < n and all(c in SPACES for c in b[ln + 1:]):
         tail_open = ln + 1
     return (n, first_header, lead_kind, b[-1] if n else 10, tail_open)

@@ -57,6 +57,13 @@ def test_probe_kernels_match_the_restatement():
     for p in pieces:
         a = np.frombuffer(p, dtype=np.uint8)
         assert _device_summary(fa, ctx, a) == summary_of(a, walk_cap=256 * 1024), p[:80]
+    # the scans give up after line_capacity bytes of spaces (a line that long fails wherever it is parsed)
+    from blazeseq_amd.fasta import FastaParserConfig
+    small = FastaContext(FastaParserConfig(line_capacity=32768))
+    for p in (b" " * 40000 + b">a\nC\n", b"x\n" + b" " * 40000, b"x\n" + b" " * 40000 + b">far\nA\n", b" " * 32768 + b"\n>b\nA", b"AC\n" + b" " * 36863,
+              b"AC\n" + b" " * 36864, b"AC\n" + b" " * 36865, b" " * 36863 + b"G", b" " * 36864 + b"G"):
+        a = np.frombuffer(p, dtype=np.uint8)
+        assert _device_summary(small, ctx, a) == summary_of(a, walk_cap=32768), (len(p), p[:20])
 
 
 def _run(data: bytes, cuts, tmp_path, check=False, cap=0, name="s"):
