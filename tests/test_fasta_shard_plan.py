@@ -9,10 +9,11 @@ from tests.fasta_fuzz import rand_fasta, rand_soup
 from tests.fasta_shard_model import stitch, summary_of, c_plan
 
 
-def check(data: bytes, cuts, check_ascii=False, line_cap=FO.DEFAULT_CAPACITY):
+def check(data: bytes, cuts, check_ascii=False, line_cap=FO.DEFAULT_CAPACITY, bounded=False):
+    """bounded: the probe gives up after line_capacity bytes of spaces, like the device's."""
     a = np.frombuffer(data, dtype=np.uint8)
     whole = FO.flat_parse(a, check_ascii=check_ascii, line_cap=line_cap)
-    recs, status, msg = stitch(a, cuts, check_ascii, line_cap)
+    recs, status, msg = stitch(a, cuts, check_ascii, line_cap, summarize=(lambda s: summary_of(s, walk_cap=line_cap)) if bounded else summary_of)
     assert recs == whole.records(), (cuts, len(recs), whole.n_records)
     assert status == whole.status, (cuts, status, whole.status)
     if whole.status != 6:
@@ -62,6 +63,30 @@ def test_random_cuts(seed):
         P = int(rng.integers(2, 7))
         cuts = sorted(int(x) for x in rng.integers(0, len(data) + 1, P - 1))
         check(data, cuts, check_ascii=bool(rng.random() < 0.5), line_cap=cap)
+
+
+def test_probe_that_gives_up_after_line_capacity_bytes_of_spaces():
+    """A line of >= line_capacity bytes fails wherever it is parsed, so the probe may stop looking for the start of a '>' line,
+    for the end of a lead of spaces or for the start of a trailing run of spaces after that many bytes: whatever it then
+    reports, the stitched result is the sequential parser's."""
+    cap = 24
+    run = b" " * 9000   # longer than the 4 KiB + capacity the edge scans look at
+    streams = [b">a\nAC\n" + run + b">b\nT\n>c\nG\n", b">a\nAC\n" + run + b"\n>b\nT\n", b">a\nAC\n" + run, run + b">a\nAC\n", b">a\nAC" + run + b"\n>b\nT\n",
+               b">a\nAC\n" + b" " * 30 + b">b\nT\n", b">a\nAC\n" + b" " * 23 + b">b\nT\n", b">a\nAC\n" + b" " * 22 + b">b\nT\n"]
+    rng = np.random.default_rng(1)
+    for data in streams:
+        n = len(data)
+        cutsets = [[c] for c in (0, 1, 5, 6, 7, 8, 30, 4000, 4102, 4103, 4104, 8190, 9005, 9006, 9007, 9010, n - 1, n) if c <= n]
+        cutsets += [sorted(int(x) for x in rng.integers(0, n + 1, 3)) for _ in range(25)]
+        for cuts in cutsets:
+            check(data, cuts, line_cap=cap, bounded=True)
+            check(data, cuts, line_cap=cap, bounded=False)
+    for seed in range(300):
+        rng = np.random.default_rng(5000 + seed)
+        data = rand_soup(rng, int(rng.integers(1, 400)), weights=[1, 1.5, 8, 1, 2, 2, 0.5, 0.1, 0.1])
+        for _ in range(6):
+            cuts = sorted(int(x) for x in rng.integers(0, len(data) + 1, int(rng.integers(1, 6))))
+            check(data, cuts, check_ascii=bool(seed & 1), line_cap=int(rng.choice([8, 12, 24])), bounded=True)
 
 
 def test_plan_fields():
