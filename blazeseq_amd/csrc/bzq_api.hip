@@ -1665,14 +1665,8 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
     if (numa) gpu_numa_cpus(device, &g->numa_node, g->numa_cpus);
     g->stats.direct_io = g->fd_direct >= 0 ? 1 : 0;
     g->stats.numa_node = g->numa_node;
-    bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&g->copy_stream2, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 2 && ok; ++i) {
-        ok = hipHostMalloc((void**)&g->slot[i].pinned, g->reserve + g->chunk_bytes, hipHostMallocDefault) == hipSuccess &&
-             hipMalloc((void**)&g->slot[i].dev, g->reserve + g->chunk_bytes + 64) == hipSuccess &&
-             hipEventCreateWithFlags(&g->slot[i].h2d_done, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&g->dev_free[i], hipEventDisableTiming) == hipSuccess;
-    }
+    bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < bzq::INGEST_SLOTS && ok; ++i) ok = bzq::ingest_alloc_slot(g, i);
     if (!ok) {
         err = std::string(who) + ": allocating the pinned / device chunk buffers failed";
         bzq::ingest_free(g);
@@ -1685,19 +1679,15 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
             g->compression = 2;
             if (gpu_inflate) {   // the compressed bytes travel, the device inflates (bzq_inflate.hpp)
                 g->tab_cap = (int64_t)(g->chunk_bytes / 2048) + 4096;
-                bool gok = hipHostMalloc((void**)&g->bad_pinned, 2 * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess &&
-                           hipMalloc((void**)&g->bad_dev, 2 * sizeof(unsigned long long)) == hipSuccess;
-                for (int i = 0; i < 2 && gok; ++i)
-                    gok = hipMalloc((void**)&g->comp_dev[i], g->chunk_bytes + 64) == hipSuccess &&
-                          hipMalloc((void**)&g->tab_dev[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16) == hipSuccess &&
-                          hipHostMalloc((void**)&g->tab_pinned[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16, hipHostMallocDefault) == hipSuccess;
+                g->gpu_inflate = 1;
+                bool gok = hipHostMalloc((void**)&g->bad_pinned, bzq::INGEST_SLOTS * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess &&
+                           hipMalloc((void**)&g->bad_dev, bzq::INGEST_SLOTS * sizeof(unsigned long long)) == hipSuccess;
+                for (int i = 0; i < bzq::INGEST_SLOTS && gok; ++i) { g->bad_pinned[i] = ~0ull; gok = bzq::ingest_alloc_inflate(g, i); }
                 if (!gok) {
                     err = std::string(who) + ": allocating the buffers of the device inflate failed";
                     bzq::ingest_free(g);
                     return BZQ_ERR_NOMEM;
                 }
-                g->bad_pinned[0] = g->bad_pinned[1] = ~0ull;
-                g->gpu_inflate = 1;
             }
         } else {
             g->compression = 1;
@@ -1718,13 +1708,13 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
 }
 
 // Where chunk k (carry + body) is assembled on the device: in front of the slot's body when the carry fits the reserve
-// (no copy of the body), otherwise in big[k & 1], grown to fit (the caller then also copies the body there).  `quiesce`:
+// (no copy of the body), otherwise in big[k % INGEST_SLOTS], grown to fit (the caller then also copies the body there).  `quiesce`:
 // the stream whose work may still touch an old big[] buffer.
 static int ingest_place(bzq_ingest* g, int64_t k, uint64_t carry, hipStream_t quiesce, std::string& err, uint8_t** dst, bool* body_moves) {
-    bzq::IngestSlot& s = g->slot[k & 1];
+    bzq::IngestSlot& s = g->slot[k % bzq::INGEST_SLOTS];
     if (carry <= g->reserve) { *dst = s.dev + (g->reserve - carry); *body_moves = false; return 0; }
     const uint64_t need = carry + s.len + 64;
-    const int b = (int)(k & 1);
+    const int b = (int)(k % bzq::INGEST_SLOTS);
     if (g->big_cap[b] < need) {
         if (g->big[b]) { (void)hipStreamSynchronize(quiesce); (void)hipFree(g->big[b]); g->big[b] = nullptr; g->big_cap[b] = 0; }
         const uint64_t want = need + need / 4;
@@ -1786,7 +1776,7 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
         g->cv.wait(lk, [&] { return g->produced > k || g->stop; });
         if (g->produced <= k) { c->err = "bzq_ingest_next: " + (g->io_error.empty() ? std::string("reader stopped") : g->io_error); return BZQ_ERR_IO; }
     }
-    bzq::IngestSlot& s = g->slot[k & 1];
+    bzq::IngestSlot& s = g->slot[k % bzq::INGEST_SLOTS];
     uint8_t* dst = nullptr;
     bool body_moves = false;
     {
@@ -1798,9 +1788,9 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
     // producer can start chunk k+1 on the device while chunk k is still arriving (device inflate: two chunks' blocks in flight)
     if (carry) HIPCHK(c, hipMemcpyAsync(dst, g->prev_ptr + carry_src, carry, hipMemcpyDeviceToDevice, c->stream));
     if (g->have_prev) {
-        HIPCHK(c, hipEventRecord(g->dev_free[(k - 1) & 1], c->stream));
+        HIPCHK(c, hipEventRecord(g->dev_free[(k - 1) % bzq::INGEST_SLOTS], c->stream));
         std::unique_lock<std::mutex> lk(g->mu);
-        g->dev_free_valid[(k - 1) & 1] = true;
+        g->dev_free_valid[(k - 1) % bzq::INGEST_SLOTS] = true;
         g->released = k;
         g->cv.notify_all();
     }
@@ -1816,8 +1806,8 @@ int32_t bzq_ingest_next(bzq_ingest* g, uint64_t records_taken, bzq_chunk* out, u
     rc = bzq_chunk_result(c, out);
     g->stats.wait_s += bzq::seconds_since(tw);
     if (rc < 0) return rc;
-    if (g->gpu_inflate && g->bad_pinned[k & 1] != ~0ull) {   // (the stream is synchronised: the verdict travelled behind the kernel)
-        c->err = "bzq_ingest_next: BGZF block " + std::to_string(g->bad_pinned[k & 1]) + " of the chunk at stream offset " + std::to_string(s.file_off) +
+    if (g->gpu_inflate && g->bad_pinned[k % bzq::INGEST_SLOTS] != ~0ull) {   // (the stream is synchronised: the verdict travelled behind the kernel)
+        c->err = "bzq_ingest_next: BGZF block " + std::to_string(g->bad_pinned[k % bzq::INGEST_SLOTS]) + " of the chunk at stream offset " + std::to_string(s.file_off) +
                  " failed to inflate (corrupt or truncated file)";
         return BZQ_ERR_IO;
     }
@@ -1915,7 +1905,7 @@ int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* f, bzq_fasta_chunk* out, uint64_
             g->cv.wait(lk, [&] { return g->produced > k || g->stop; });
             if (g->produced <= k) return fail("bzq_fasta_ingest_next: " + (g->io_error.empty() ? std::string("reader stopped") : g->io_error), BZQ_ERR_IO);
         }
-        bzq::IngestSlot& s = g->slot[k & 1];
+        bzq::IngestSlot& s = g->slot[k % bzq::INGEST_SLOTS];
         bool ok = true;
         uint8_t* dst = nullptr;
         bool body_moves = false;
@@ -1927,17 +1917,17 @@ int32_t bzq_fasta_ingest_next(bzq_fasta_ingest* f, bzq_fasta_chunk* out, uint64_
         // (the carry goes in front of the body and does not wait for the chunk's own copy / inflate: bzq_ingest_next)
         if (carry) ok = hipMemcpyAsync(dst, g->prev_ptr + carry_src, carry, hipMemcpyDeviceToDevice, f->aux) == hipSuccess;
         if (ok && g->have_prev) {   // the previous chunk's device buffer may now be refilled (behind the carry copy)
-            ok = hipEventRecord(g->dev_free[(k - 1) & 1], f->aux) == hipSuccess;
+            ok = hipEventRecord(g->dev_free[(k - 1) % bzq::INGEST_SLOTS], f->aux) == hipSuccess;
             std::unique_lock<std::mutex> lk(g->mu);
-            g->dev_free_valid[(k - 1) & 1] = true;
+            g->dev_free_valid[(k - 1) % bzq::INGEST_SLOTS] = true;
             g->released = k;
             g->cv.notify_all();
         }
         if (ok) ok = hipStreamWaitEvent(f->aux, s.h2d_done, 0) == hipSuccess;
         if (ok && body_moves && s.len) ok = hipMemcpyAsync(dst + carry, s.dev + g->reserve, s.len, hipMemcpyDeviceToDevice, f->aux) == hipSuccess;
         if (!ok || hipStreamSynchronize(f->aux) != hipSuccess) return fail("bzq_fasta_ingest_next: a HIP call failed", BZQ_ERR_HIP);
-        if (g->gpu_inflate && g->bad_pinned[k & 1] != ~0ull)
-            return fail("bzq_fasta_ingest_next: BGZF block " + std::to_string(g->bad_pinned[k & 1]) + " of the chunk at stream offset " +
+        if (g->gpu_inflate && g->bad_pinned[k % bzq::INGEST_SLOTS] != ~0ull)
+            return fail("bzq_fasta_ingest_next: BGZF block " + std::to_string(g->bad_pinned[k % bzq::INGEST_SLOTS]) + " of the chunk at stream offset " +
                         std::to_string(s.file_off) + " failed to inflate (corrupt or truncated file)", BZQ_ERR_IO);
         const uint64_t n = carry + s.len, spos = s.file_off - carry;
         const int32_t rc = bzq_fasta_parse(f->h, dst, n, s.eof ? 1 : 0, spos, f->line_base, f->record_base, out);

@@ -23,6 +23,12 @@
 
 namespace bzq {
 
+// chunks in flight between the reader threads and the parser: k is read while k-1 travels / is inflated and is parsed.
+// Two: a third slot was measured (BGZF 15.8 -> 16.0 GB/s end to end: the device inflate is already at 3/4 of its kernel rate
+// with two chunks' blocks in flight) and costs another 288 MiB of pinning in front of a mid-sized file (plain 3 GB file: 50 ->
+// 37 GB/s including the open).
+constexpr int INGEST_SLOTS = 2;
+
 struct IngestSlot {
     uint8_t* pinned = nullptr;     // reserve + chunk_bytes
     uint8_t* dev = nullptr;        // reserve + chunk_bytes + 64
@@ -51,18 +57,18 @@ struct bzq_ingest {
     // BGZF inflated on the device (bzq_inflate.hpp): the slot's pinned buffer carries the COMPRESSED blocks to comp_dev, the
     // kernel writes the chunk into the slot's device buffer; first_bad travels back behind it
     int gpu_inflate = 0;
-    uint8_t* comp_dev[2] = {nullptr, nullptr};
-    bzq::inf::DevBlock* tab_dev[2] = {nullptr, nullptr};
-    bzq::inf::DevBlock* tab_pinned[2] = {nullptr, nullptr};
+    uint8_t* comp_dev[bzq::INGEST_SLOTS] = {};
+    bzq::inf::DevBlock* tab_dev[bzq::INGEST_SLOTS] = {};
+    bzq::inf::DevBlock* tab_pinned[bzq::INGEST_SLOTS] = {};
     int64_t tab_cap = 0;
-    unsigned long long* bad_dev = nullptr;      // [2]
-    unsigned long long* bad_pinned = nullptr;   // [2]
+    unsigned long long* bad_dev = nullptr;      // [INGEST_SLOTS]
+    unsigned long long* bad_pinned = nullptr;   // [INGEST_SLOTS]
     double ratio_est = 0.30;       // compressed / inflated bytes of the last chunk: how much to read for the next one
-    bzq::IngestSlot slot[2];
-    hipStream_t copy_stream = nullptr;   // H2D of the chunks (and, device inflate, the kernels of the even chunks)
-    hipStream_t copy_stream2 = nullptr;  // device inflate: the odd chunks, so that two chunks' blocks are in flight at once
-    hipEvent_t dev_free[2] = {nullptr, nullptr}; // recorded on the ctx stream once slot i's device buffer may be overwritten
-    bool dev_free_valid[2] = {false, false};
+    bzq::IngestSlot slot[bzq::INGEST_SLOTS];
+    hipStream_t copy_stream = nullptr;   // H2D of the chunks
+    hipStream_t inflate_stream[bzq::INGEST_SLOTS] = {};   // device inflate: one stream per slot, so that the chunks' kernels overlap
+    hipEvent_t dev_free[bzq::INGEST_SLOTS] = {}; // recorded on the ctx stream once slot i's device buffer may be overwritten
+    bool dev_free_valid[bzq::INGEST_SLOTS] = {};
     std::thread producer;
     std::mutex mu;
     std::condition_variable cv;
@@ -78,8 +84,8 @@ struct bzq_ingest {
     const uint8_t* prev_ptr = nullptr;   // its first byte on the device (inside a slot, or in big[])
     // a carry larger than the reserve in front of a slot's body (a record or a batch longer than chunk/8): the chunk is
     // assembled in a buffer of its own, grown on demand -- the reference has no record-size limit either
-    uint8_t* big[2] = {nullptr, nullptr};
-    uint64_t big_cap[2] = {0, 0};
+    uint8_t* big[bzq::INGEST_SLOTS] = {};
+    uint64_t big_cap[bzq::INGEST_SLOTS] = {};
     uint64_t prev_stream_pos = 0;
     bzq_chunk prev_res{};
     bzq_ingest_stats stats{};
@@ -233,6 +239,21 @@ inline bool read_compressed_chunk(bzq_ingest* g, uint8_t* dst, uint64_t cap, uin
     return true;
 }
 
+// buffers of slot i (allocated at open: doing it in the reader, when it first gets to the slot, puts the pinning of the second
+// slot on the path of chunk 1 -- 43 instead of 50 GB/s on a 3 GB file)
+inline bool ingest_alloc_inflate(bzq_ingest* g, int i) {
+    return hipStreamCreateWithFlags(&g->inflate_stream[i], hipStreamNonBlocking) == hipSuccess &&
+           hipMalloc((void**)&g->comp_dev[i], g->chunk_bytes + 64) == hipSuccess &&
+           hipMalloc((void**)&g->tab_dev[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16) == hipSuccess &&
+           hipHostMalloc((void**)&g->tab_pinned[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16, hipHostMallocDefault) == hipSuccess;
+}
+inline bool ingest_alloc_slot(bzq_ingest* g, int i) {
+    return hipHostMalloc((void**)&g->slot[i].pinned, g->reserve + g->chunk_bytes, hipHostMallocDefault) == hipSuccess &&
+           hipMalloc((void**)&g->slot[i].dev, g->reserve + g->chunk_bytes + 64) == hipSuccess &&
+           hipEventCreateWithFlags(&g->slot[i].h2d_done, hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&g->dev_free[i], hipEventDisableTiming) == hipSuccess;
+}
+
 // Device inflate: the next run of whole BGZF blocks, still COMPRESSED, into `pinned` (capacity cap); their table (payload
 // offsets relative to `pinned`) into tab.  The read is sized from the last chunk's compression ratio; a short read gives a
 // smaller chunk, never a wrong one.
@@ -279,9 +300,10 @@ inline void ingest_producer(bzq_ingest* g) {
     if ((he = hipSetDevice(g->device)) != hipSuccess) return fail("reader: hipSetDevice", he);
     uint64_t off = 0;   // offset in the (decompressed) stream
     for (int64_t k = 0;; ++k) {
-        IngestSlot& s = g->slot[k & 1];
-        // the pinned buffer of this slot was last used by chunk k-2: its H2D must have finished
-        if (k >= 2 && (he = hipEventSynchronize(s.h2d_done)) != hipSuccess) return fail("reader: waiting for the previous copy", he);
+        const int b = (int)(k % INGEST_SLOTS);
+        IngestSlot& s = g->slot[b];
+        // the pinned buffer of this slot was last used by chunk k - INGEST_SLOTS: its H2D must have finished
+        if (k >= INGEST_SLOTS && (he = hipEventSynchronize(s.h2d_done)) != hipSuccess) return fail("reader: waiting for the previous copy", he);
         {
             std::unique_lock<std::mutex> lk(g->mu);
             if (g->stop) return;
@@ -290,12 +312,12 @@ inline void ingest_producer(bzq_ingest* g) {
         int64_t n_blocks = 0;
         // one block is decoded by one wave at its own pace (~20 ms for 64 KiB): a chunk is too few blocks to fill the device,
         // so the inflate kernels of consecutive chunks run side by side on two streams
-        const hipStream_t cs = (g->gpu_inflate && (k & 1)) ? g->copy_stream2 : g->copy_stream;
+        const hipStream_t cs = g->gpu_inflate ? g->inflate_stream[b] : g->copy_stream;
         bool eof = false, ok;
         const auto t0 = std::chrono::steady_clock::now();
         std::string err;
         if (g->gpu_inflate) {
-            ok = read_bgzf_window(g, s.pinned + g->reserve, g->chunk_bytes, g->tab_pinned[k & 1], &n_blocks, &comp_len, &len, &eof, err);
+            ok = read_bgzf_window(g, s.pinned + g->reserve, g->chunk_bytes, g->tab_pinned[b], &n_blocks, &comp_len, &len, &eof, err);
         } else if (g->compression == 0) {
             len = std::min<uint64_t>(g->chunk_bytes, g->file_size - off);
             ok = parallel_pread(g->fd, s.pinned + g->reserve, off, len, g->n_threads, err, g->fd_direct, &g->numa_cpus);
@@ -309,18 +331,17 @@ inline void ingest_producer(bzq_ingest* g) {
             return;
         }
         const double rs = seconds_since(t0);
-        // the device buffer of this slot was last used by chunk k-2: wait until the consumer released it
+        // the device buffer of this slot was last used by chunk k - INGEST_SLOTS: wait until the consumer released it
         {
             std::unique_lock<std::mutex> lk(g->mu);
             g->stats.read_s += rs;
             g->stats.bytes_read += len;
-            g->cv.wait(lk, [&] { return g->stop || g->released >= k - 1; });
+            g->cv.wait(lk, [&] { return g->stop || g->released >= k - (INGEST_SLOTS - 1); });
             if (g->stop) return;
-            he = g->dev_free_valid[k & 1] ? hipStreamWaitEvent(cs, g->dev_free[k & 1], 0) : hipSuccess;
+            he = g->dev_free_valid[b] ? hipStreamWaitEvent(cs, g->dev_free[b], 0) : hipSuccess;
         }
         if (he != hipSuccess) return fail("reader: hipStreamWaitEvent", he);
         if (g->gpu_inflate) {
-            const int b = (int)(k & 1);
             g->bad_pinned[b] = ~0ull;   // (the consumer read the previous verdict of this slot two chunks ago)
             if (n_blocks) {
                 if ((he = hipMemcpyAsync(g->comp_dev[b], s.pinned + g->reserve, comp_len, hipMemcpyHostToDevice, cs)) != hipSuccess ||
@@ -357,8 +378,8 @@ inline void ingest_free(bzq_ingest* g) {
     if (g->producer.joinable()) g->producer.join();
     (void)hipSetDevice(g->device);
     if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
-    if (g->copy_stream2) { (void)hipStreamSynchronize(g->copy_stream2); (void)hipStreamDestroy(g->copy_stream2); }
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < INGEST_SLOTS; ++i) {
+        if (g->inflate_stream[i]) { (void)hipStreamSynchronize(g->inflate_stream[i]); (void)hipStreamDestroy(g->inflate_stream[i]); }
         if (g->slot[i].pinned) (void)hipHostFree(g->slot[i].pinned);
         if (g->slot[i].dev) (void)hipFree(g->slot[i].dev);
         if (g->big[i]) (void)hipFree(g->big[i]);
