@@ -214,7 +214,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_tile_sums(SumsArgs a) {
     __shared__ uint32_t s_anyx[BLOCK / 64], s_edge[4];
     __shared__ uint32_t s_end;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t t = blockIdx.x, t0 = t * TILE;
+    const int64_t t = xcd_tile(), t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     uint4 r[4], own[4];
     tile_fetch<true>(a.data, a.n, t0, valid, r);
@@ -439,7 +439,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fa_emit(EmitArgs a) {
     __shared__ u64 s_w[BLOCK / 64];
     uint8_t* s_tile = s_raw + 16;
     const int tid = threadIdx.x;
-    const int64_t t = blockIdx.x, t0 = t * TILE;
+    const int64_t t = xcd_tile(), t0 = t * TILE;   // (neighbouring tiles on one XCD: bzq_device.hpp)
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
     uint4 r[4];
     tile_fetch(a.data, a.n, t0, valid, r);

@@ -261,8 +261,12 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         if (tid0 == 0) s_bcast[0] = (int64_t)atomicAdd(a.ticket, 1ull);
         __syncthreads();
     }
-    int64_t t = LB ? s_bcast[0] : a.tile_begin + (int64_t)blockIdx.x;
-    if (!LB && t >= a.tile_end) return;
+    int64_t t;
+    if (LB) t = s_bcast[0];
+    else {
+        t = a.tile_begin + xcd_tile();   // (neighbouring tiles on one XCD: bzq_device.hpp)
+        if (t >= a.tile_end) return;
+    }
     // every global LOAD of a tile is issued by fetch(), before any store of the same loop trip: vmcnt retires in
     // order, so a load waited for after stores would also wait for those stores' round trip
     uint4 r[4];   // four source pieces per thread (q = tid + 256 s)
@@ -616,7 +620,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
     __shared__ uint16_t s_nl[MAXL_A];
     __shared__ __attribute__((aligned(8))) uint32_t s_w[4];   // scan scratch, then the two block sums (2 x u64)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    const int64_t t = a.tile_begin + xcd_tile();
     if (t >= a.tile_end) return;
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
@@ -709,7 +713,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate_h(AggArgs a) {
     __shared__ uint16_t s_nl[MAXL_A];
     __shared__ __attribute__((aligned(8))) uint32_t s_w[4];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    const int64_t t = a.tile_begin + xcd_tile();
     if (t >= a.tile_end) return;
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);

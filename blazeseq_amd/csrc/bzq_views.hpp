@@ -98,7 +98,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
     __shared__ int64_t s_slot;
     uint8_t* s_tile = s_tile_raw + 16;
     const int tid = threadIdx.x;
-    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    const int64_t t = a.tile_begin + xcd_tile();   // (neighbouring tiles on one XCD: bzq_device.hpp)
     if (t >= a.tile_end) return;
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
@@ -205,7 +205,7 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
     __shared__ int64_t s_P[JOIN_TILES + 1];
     __shared__ u64 s_slot[JOIN_TILES];
     const int tid = threadIdx.x;
-    const int64_t ta = a.tile_begin + (int64_t)blockIdx.x * JOIN_TILES;
+    const int64_t ta = a.tile_begin + xcd_tile() * JOIN_TILES;   // (neighbouring windows on one XCD)
     if (ta >= a.tile_end) return;
     const int64_t tb = ta + JOIN_TILES < a.tile_end ? ta + JOIN_TILES : a.tile_end;
     const int nt = (int)(tb - ta);
@@ -342,7 +342,7 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
 static __global__ __launch_bounds__(BLOCK) void k_tile_count(AggArgs a) {
     __shared__ uint32_t s_w[BLOCK / 64];
     const int tid = threadIdx.x;
-    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    const int64_t t = a.tile_begin + xcd_tile();   // (neighbouring tiles on one XCD: bzq_device.hpp)
     if (t >= a.tile_end) return;
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
@@ -409,7 +409,7 @@ static __global__ __launch_bounds__(BLOCK) void k_views(ViewArgs a) {
     __shared__ uint16_t s_pline[(CA || CQ) ? PIECES : 1];
     uint8_t* s_tile = s_tile_raw + 16;
     const int tid = threadIdx.x;
-    const int64_t t = a.tile_begin + (int64_t)blockIdx.x;
+    const int64_t t = a.tile_begin + xcd_tile();   // (neighbouring tiles on one XCD: bzq_device.hpp)
     if (t >= a.tile_end) return;
     const int64_t t0 = t * TILE;
     const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
