@@ -1020,7 +1020,12 @@ int32_t bzq_device_free(bzq_ctx* c, void* p) {
 int32_t bzq_copy_to_device(bzq_ctx* c, void* d_dst, const void* src, size_t bytes) {
     if (!c || (bytes && (!d_dst || !src))) return BZQ_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
-    if (bytes) HIPCHK(c, hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+    // On the ctx stream and waited for: a plain hipMemcpy from pageable memory may return once the bytes are staged, with the
+    // DMA still in flight on the null stream -- which the library's (non-blocking) streams do not wait for
+    if (bytes) {
+        HIPCHK(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     return 0;
 }
 

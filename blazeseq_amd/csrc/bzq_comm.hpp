@@ -314,7 +314,10 @@ int32_t bzq_comm_selftest(bzq_ctx* c) {
         if (WORDS * 4 > (int)m->halo_cap) { (void)hipFree(d); c->err = "bzq_comm_selftest: halo capacity below 4 KiB"; return BZQ_ERR_ARG; }
         if (hipMemcpy(shm_halo(m, me), d, WORDS * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = BZQ_ERR_HIP;
         if (!rc) rc = shm_barrier(c, m);
-        if (!rc && hipMemcpy(d + WORDS, shm_halo(m, from), WORDS * 4, hipMemcpyHostToDevice) != hipSuccess) rc = BZQ_ERR_HIP;
+        // (on the stream and waited for: a plain hipMemcpy from pageable memory may return with the DMA still in flight on the
+        // null stream, which the ctx stream does not wait for)
+        if (!rc && (hipMemcpyAsync(d + WORDS, shm_halo(m, from), WORDS * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+                    hipStreamSynchronize(c->stream) != hipSuccess)) rc = BZQ_ERR_HIP;
         if (!rc) rc = shm_barrier(c, m);
     }
     if (!rc) {
@@ -398,7 +401,8 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
         if ((rc = shm_barrier(c, m))) return rc;
         for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
             if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
-                HIPCHK(c, hipMemcpy(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice));
+                HIPCHK(c, hipMemcpyAsync(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // the bytes have left the segment before a peer may overwrite it, and are on the device before anything reads them
         if ((rc = shm_barrier(c, m))) return rc;
     }
 

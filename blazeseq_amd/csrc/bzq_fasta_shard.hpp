@@ -123,7 +123,8 @@ int32_t bzq_fasta_shard_stitch(bzq_ctx* c, bzq_fasta* h, uint8_t* d_shard, uint6
             if ((rc = shm_barrier(c, m))) return rc;
             for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
                 if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
-                    HIPCHK(c, hipMemcpy(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice));
+                    HIPCHK(c, hipMemcpyAsync(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));   // (on the device before the FASTA handle's stream parses them, out of the segment before a peer overwrites it)
             if ((rc = shm_barrier(c, m))) return rc;
         }
     }
