@@ -7,11 +7,13 @@ constexpr int TILE = 16384, BLOCK = 256;
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 struct __attribute__((packed, aligned(1))) U16B { uint32_t x, y, z, w; };
 
-template <int LD, int ST, int SHIFT, int LDS_KB>
+template <int LD, int ST, int SHIFT, int LDS_KB, int XCD = 0>
 __global__ __launch_bounds__(BLOCK) void k(const uint8_t* __restrict__ in, uint8_t* __restrict__ out) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile[LDS_KB * 1024];
     const int tid = threadIdx.x;
-    const long long t = blockIdx.x;
+    // XCD = 1: workgroup b runs on XCD b % 8; every XCD takes one contiguous eighth of the tiles (the product's xcd_tile())
+    const unsigned q8 = gridDim.x >> 3, r8 = gridDim.x & 7u, x8 = blockIdx.x & 7u;
+    const long long t = XCD ? (long long)x8 * q8 + (x8 < r8 ? x8 : r8) + (blockIdx.x >> 3) : (long long)blockIdx.x;
     const uint8_t* p = in + t * TILE + tid * 16;
     uint4 r[4];
 #pragma unroll
@@ -36,12 +38,12 @@ __global__ __launch_bounds__(BLOCK) void k(const uint8_t* __restrict__ in, uint8
         }
     }
 }
-template <int LD, int ST, int SHIFT, int LDS_KB> void run(const uint8_t* in, uint8_t* out, int nt, const char* name) {
+template <int LD, int ST, int SHIFT, int LDS_KB, int XCD = 0> void run(const uint8_t* in, uint8_t* out, int nt, const char* name) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     float best = 1e9f;
     for (int r = 0; r < 6; ++r) {
         hipEventRecord(a);
-        hipLaunchKernelGGL((k<LD, ST, SHIFT, LDS_KB>), dim3(nt), dim3(BLOCK), 0, 0, in, out);
+        hipLaunchKernelGGL((k<LD, ST, SHIFT, LDS_KB, XCD>), dim3(nt), dim3(BLOCK), 0, 0, in, out);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         if (ms < best) best = ms;
@@ -63,5 +65,11 @@ int main() {
     run<0, 0, 3, 20>(in, out, nt, "plain / unaligned, 20 KiB LDS (8 WG/CU)");
     run<1, 1, 3, 20>(in, out, nt, "nt / nt unaligned, 8 WG/CU");
     run<0, 0, 3, 40>(in, out, nt, "plain / unaligned, 40 KiB LDS (4 WG/CU)");
+    printf("---- the same with one contiguous eighth of the tiles per XCD\n");
+    run<0, 0, 0, 27, 1>(in, out, nt, "plain loads, plain aligned stores, 6 WG/CU   [XCD-contiguous]");
+    run<0, 0, 3, 27, 1>(in, out, nt, "plain loads, plain stores at +3, 6 WG/CU     [XCD-contiguous]");
+    run<1, 0, 3, 27, 1>(in, out, nt, "nt loads, plain stores at +3, 6 WG/CU        [XCD-contiguous]");
+    run<1, 1, 3, 27, 1>(in, out, nt, "nt loads, nt stores at +3, 6 WG/CU           [XCD-contiguous]");
+    run<0, 0, 3, 20, 1>(in, out, nt, "plain / unaligned, 8 WG/CU                   [XCD-contiguous]");
     return 0;
 }
