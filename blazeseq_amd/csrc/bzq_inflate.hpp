@@ -348,7 +348,7 @@ static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
     crc_tables(s_crc_tab, s_x2n);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t bi = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t bi = xcd_tile() * WAVES + wave;   // (neighbouring blocks on one XCD: bzq_device.hpp)
     if (bi >= a.n_blocks) return;
     const DevBlock blk = a.blocks[bi];
     bool ok = inflate_block(a.comp + blk.coff, (int64_t)(a.comp_bytes - blk.coff), (int)blk.csize, a.out + blk.uoff, (int)blk.usize,
