@@ -11,7 +11,8 @@
 //   * Huffman decode without big tables: canonical codes are ordered by length, so with the next 15 stream bits reversed into
 //     a left-aligned code c, lane L holds the left-aligned upper bound of the codes of length L and ONE compare + ballot +
 //     s_ff1 gives the length; first code and symbol offset of that length are readlanes, the symbol one LDS read
-//     (per wave: 288 + 32 sorted symbols = 640 bytes of LDS instead of kilobytes of lookup tables);
+//     (per wave: 288 + 32 sorted symbols = 640 bytes of LDS); the literal/length code also has a 10-bit direct table (2 KiB)
+//     for its short codes, and runs of literals stay in a loop of their own (build_lut, inflate_block);
 //   * table construction: lengths histogram by ballots, the sort of the symbols by (length, symbol) by ballots and popcounts;
 //   * literals collect in a VGPR (lane k = k-th pending byte) and leave 64 at a time; matches are copied by all lanes.
 // Output goes straight to the chunk buffer in device memory; matches read it back (same wave, same L1: program order holds).
