@@ -119,11 +119,12 @@ int comm_gather(bzq_ctx* c, const int64_t* row, int64_t* all) {
     return shm_barrier(c, m);   // nobody overwrites its row before everybody has read
 }
 
-static __global__ void k_pack_summary(const ChunkState* st, int64_t n, int64_t* row) {
+// row = {bytes, newlines, first four newlines, first byte | last byte << 8, room behind the shard's bytes}
+static __global__ void k_pack_summary(const ChunkState* st, int64_t n, int64_t room, int64_t* row) {
     if (threadIdx.x || blockIdx.x) return;
     row[0] = n; row[1] = st->P;
     for (int i = 0; i < 4; ++i) row[2 + i] = st->first_nl[i];
-    row[6] = st->edge_first; row[7] = st->edge_last;
+    row[6] = (int64_t)st->edge_first | ((int64_t)st->edge_last << 8); row[7] = room;
 }
 
 void comm_free(bzq_comm* m) {
@@ -355,7 +356,7 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
     std::vector<int64_t> all((size_t)P * COMM_ROW);
     if ((rc = shard_scan_enqueue(c, d_shard, n))) return rc;
     if (m && m->kind == 1 && n > 0) {
-        hipLaunchKernelGGL(k_pack_summary, dim3(1), dim3(1), 0, c->stream, (const ChunkState*)c->d_state, (int64_t)n, m->d_row);
+        hipLaunchKernelGGL(k_pack_summary, dim3(1), dim3(1), 0, c->stream, (const ChunkState*)c->d_state, (int64_t)n, (int64_t)(capacity - n), m->d_row);
         if ((rc = comm_gather(c, nullptr, all.data()))) return rc;
         shard_scan_finish(c, d_shard, n, &sums[(size_t)me]);
     } else {
@@ -363,7 +364,7 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
         shard_scan_finish(c, d_shard, n, &sums[(size_t)me]);
         const bzq_shard_summary& s = sums[(size_t)me];
         int64_t row[COMM_ROW] = {(int64_t)s.n_bytes, (int64_t)s.n_newlines, s.first_nl[0], s.first_nl[1], s.first_nl[2], s.first_nl[3],
-                                 s.first_byte, s.last_byte};
+                                 (int64_t)s.first_byte | ((int64_t)s.last_byte << 8), (int64_t)(capacity - n)};
         if ((rc = comm_gather(c, row, all.data()))) return rc;
     }
     uint64_t stream_pos = 0, total_bytes = 0;
@@ -372,7 +373,7 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
         bzq_shard_summary& s = sums[(size_t)r];
         s.n_bytes = (uint64_t)w[0]; s.n_newlines = (uint64_t)w[1];
         for (int i = 0; i < 4; ++i) s.first_nl[i] = w[2 + i];
-        s.first_byte = (uint8_t)w[6]; s.last_byte = (uint8_t)w[7];
+        s.first_byte = (uint8_t)(w[6] & 0xFF); s.last_byte = (uint8_t)((w[6] >> 8) & 0xFF);
         if (r < me) stream_pos += s.n_bytes;
         total_bytes += s.n_bytes;
     }
@@ -382,10 +383,14 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
     if ((rc = bzq_plan_shards(sums.data(), P, plans.data()))) { c->err = "bzq_shard_stitch: inconsistent shard summaries"; return rc; }
     const bzq_shard_plan pl = plans[(size_t)me];
     out->plan = pl;
-    if (n + pl.halo_bytes > capacity) {
-        c->err = "bzq_shard_stitch: the shard buffer has no room for the halo (" + std::to_string(pl.halo_bytes) + " bytes behind " + std::to_string(n) + ")";
-        return BZQ_ERR_ARG;   // every rank still holds a consistent plan; nothing has been exchanged yet
-    }
+    // every rank knows every rank's room (row[7]): a halo that does not fit fails the call on ALL ranks, before anything is
+    // exchanged -- a rank that bailed out alone would leave its peers waiting in the send / receive
+    for (int r = 0; r < P; ++r)
+        if ((int64_t)plans[(size_t)r].halo_bytes > all[(size_t)r * COMM_ROW + 7]) {
+            c->err = "bzq_shard_stitch: rank " + std::to_string(r) + "'s shard buffer has no room for its halo (" + std::to_string(plans[(size_t)r].halo_bytes) +
+                     " bytes behind " + std::to_string(sums[(size_t)r].n_bytes) + ", room for " + std::to_string(all[(size_t)r * COMM_ROW + 7]) + ")";
+            return BZQ_ERR_ARG;
+        }
 
     // 3. heads travel to their owners
     if (m && m->kind == 1 && P > 1) {
@@ -396,7 +401,8 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
                 NCCLCHK(c, m, m->p_Recv(d_shard + n + plans[(size_t)q].halo_offset, (size_t)plans[(size_t)q].head_bytes, NCCL_U8, q, m->nccl, c->stream));
         NCCLCHK(c, m, m->p_GroupEnd());
     } else if (m && P > 1) {
-        if (pl.head_bytes > m->halo_cap) { c->err = "bzq_shard_stitch(shm): a head of " + std::to_string(pl.head_bytes) + " bytes exceeds the halo capacity the communicator was created with"; return BZQ_ERR_ARG; }
+        for (int r = 0; r < P; ++r)   // (the capacity is the same on every rank: all of them fail together)
+            if (plans[(size_t)r].head_bytes > m->halo_cap) { c->err = "bzq_shard_stitch(shm): rank " + std::to_string(r) + "'s head of " + std::to_string(plans[(size_t)r].head_bytes) + " bytes exceeds the halo capacity the communicator was created with"; return BZQ_ERR_ARG; }
         if (pl.head_bytes > 0) HIPCHK(c, hipMemcpy(shm_halo(m, me), d_shard, (size_t)pl.head_bytes, hipMemcpyDeviceToHost));
         if ((rc = shm_barrier(c, m))) return rc;
         for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)

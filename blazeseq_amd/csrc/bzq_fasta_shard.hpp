@@ -89,6 +89,7 @@ int32_t bzq_fasta_shard_stitch(bzq_ctx* c, bzq_fasta* h, uint8_t* d_shard, uint6
     // 1. probe + summary all-gather
     int64_t row[COMM_ROW] = {0, 0, 0, 0, 0, 0, 0, 0};
     if ((rc = bzq_fasta_shard_probe_(h, d_shard, n, row))) return rc;
+    row[5] = (int64_t)(capacity - n);   // room behind the range's bytes: every rank checks every rank's halo against it
     std::vector<int64_t> all((size_t)P * COMM_ROW);
     if ((rc = gather(row, all.data()))) return rc;
     std::vector<bzq_fasta_shard_summary> sums((size_t)P);
@@ -102,8 +103,10 @@ int32_t bzq_fasta_shard_stitch(bzq_ctx* c, bzq_fasta* h, uint8_t* d_shard, uint6
     if ((rc = bzq_fasta_plan_shards(sums.data(), P, plans.data()))) return fail("bzq_fasta_shard_stitch: inconsistent shard summaries", rc);
     const bzq_fasta_shard_plan pl = plans[(size_t)me];
     out->plan = pl;
-    if (n + pl.halo_bytes > capacity)   // every rank still holds a consistent plan; nothing has been exchanged yet
-        return fail("bzq_fasta_shard_stitch: the shard buffer has no room for the halo (" + std::to_string(pl.halo_bytes) + " bytes behind " + std::to_string(n) + ")", BZQ_ERR_ARG);
+    for (int r = 0; r < P; ++r)   // fails on ALL ranks, before anything is exchanged (a rank bailing out alone would leave its peers waiting)
+        if ((int64_t)plans[(size_t)r].halo_bytes > all[(size_t)r * COMM_ROW + 5])
+            return fail("bzq_fasta_shard_stitch: rank " + std::to_string(r) + "'s shard buffer has no room for its halo (" + std::to_string(plans[(size_t)r].halo_bytes) +
+                        " bytes behind " + std::to_string(sums[(size_t)r].n_bytes) + ", room for " + std::to_string(all[(size_t)r * COMM_ROW + 5]) + ")", BZQ_ERR_ARG);
 
     // 3. heads travel to their owners
     if (m && P > 1) {
@@ -117,8 +120,9 @@ int32_t bzq_fasta_shard_stitch(bzq_ctx* c, bzq_fasta* h, uint8_t* d_shard, uint6
             NCCLCHK(c, m, m->p_GroupEnd());
             HIPCHK(c, hipStreamSynchronize(c->stream));   // the parse runs on the FASTA handle's stream
         } else {
-            if (pl.head_bytes > m->halo_cap)
-                return fail("bzq_fasta_shard_stitch(shm): a head of " + std::to_string(pl.head_bytes) + " bytes exceeds the halo capacity the communicator was created with", BZQ_ERR_ARG);
+            for (int r = 0; r < P; ++r)   // (the capacity is the same on every rank: all of them fail together)
+                if (plans[(size_t)r].head_bytes > m->halo_cap)
+                    return fail("bzq_fasta_shard_stitch(shm): rank " + std::to_string(r) + "'s head of " + std::to_string(plans[(size_t)r].head_bytes) + " bytes exceeds the halo capacity the communicator was created with", BZQ_ERR_ARG);
             if (pl.head_bytes > 0) HIPCHK(c, hipMemcpy(shm_halo(m, me), d_shard, (size_t)pl.head_bytes, hipMemcpyDeviceToHost));
             if ((rc = shm_barrier(c, m))) return rc;
             for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)

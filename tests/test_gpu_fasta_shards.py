@@ -194,3 +194,27 @@ def test_world_1_over_rccl_and_without_a_communicator(tmp_path):
     np.testing.assert_array_equal(seq, whole.seq_bytes)
     np.testing.assert_array_equal(id_ends, whole.id_ends)
     L.lib().bzq_device_free(ctx.h, d)
+
+
+def test_a_head_that_does_not_fit_fails_on_every_rank_instead_of_hanging(tmp_path):
+    """4 MiB of room behind every range (and 4 MiB halo slots in the shm transport): a record whose continuation in the
+    following ranges is longer fails the call on ALL ranks before anything is exchanged (a rank bailing out alone would leave
+    its peers waiting for ever)."""
+    exe = _exe()
+    data = b">a\nAC\n>long\n" + (b"ACGTACGTAC" * 6 + b"\n") * 160000 + b">z\nT\n"   # ~9.8 MB in one record
+    path = tmp_path / "long.fa"
+    path.write_bytes(data)
+    n = len(data)
+    bounds = [0, 1000, 6_000_000, n]   # rank 1's 6 MB are all the head of rank 0's record
+    shm = f"fa{os.getpid()}_cap"
+    procs = [subprocess.Popen([exe, "shm", str(r), "3", shm, str(path), str(bounds[r]), str(bounds[r + 1])],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(3)]
+    for p in procs:
+        try:
+            _, e = p.communicate(timeout=120)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        # (the driver leaves 4 MiB behind the range: the room check of the plan fires before the transport's own limit)
+        assert p.returncode == 4 and (b"no room for its halo" in e or b"exceeds the halo capacity" in e), (p.returncode, e[-300:])
