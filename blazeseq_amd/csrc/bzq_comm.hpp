@@ -417,12 +417,13 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
     bzq_chunk res{};
     res.error_record = -1;
     c->tail_mode = 0;
+    int local_rc = 0;   // a runtime failure of THIS rank's parse: reported through the outcome gather, so that every rank returns
     if (owner) {
         c->tail_mode = pl.is_last ? 1 : 0;
-        rc = bzq_submit_shard(c, d_shard, n, pl.halo_bytes, pl.lines_before, pl.prev_last_byte, stream_pos, pl.is_last);
-        if (rc < 0) { c->tail_mode = 0; return rc; }
-        rc = bzq_chunk_result(c, &res);
-        if (rc < 0) { c->tail_mode = 0; return rc; }
+        local_rc = bzq_submit_shard(c, d_shard, n, pl.halo_bytes, pl.lines_before, pl.prev_last_byte, stream_pos, pl.is_last);
+        if (local_rc >= 0) local_rc = bzq_chunk_result(c, &res);
+        if (local_rc < 0) { c->tail_mode = 0; res = bzq_chunk{}; res.error_record = -1; }
+        else local_rc = 0;
     } else if (pl.is_last) {
         res.status = BZQ_EOF;   // an empty stream
     }
@@ -431,12 +432,22 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
     auto gather_outcomes = [&](std::vector<int64_t>& rows) {
         const bool failed = res.status > 0 && res.status != BZQ_EOF;
         int64_t row[COMM_ROW] = {(int64_t)res.n_records, (int64_t)res.seq_bytes, (int64_t)n, failed ? res.error_record : -1, res.status,
-                                 owner && c->tail_pending ? 1 : 0, owner ? 1 : 0, 0};
+                                 owner && c->tail_pending && !local_rc ? 1 : 0, owner ? 1 : 0, local_rc};
         rows.assign((size_t)P * COMM_ROW, 0);
         return comm_gather(c, row, rows.data());
     };
     std::vector<int64_t> oc;
-    if ((rc = gather_outcomes(oc))) { c->tail_mode = 0; return rc; }
+    {
+        const std::string own_err = c->err;   // (the gather may overwrite it)
+        if ((rc = gather_outcomes(oc))) { c->tail_mode = 0; return rc; }
+        for (int r = 0; r < P; ++r)
+            if (oc[(size_t)r * COMM_ROW + 7] < 0) {   // some rank could not parse: nobody goes on (no rank is left waiting)
+                c->tail_mode = 0;
+                if (r == me) { c->err = own_err; return local_rc; }
+                c->err = "bzq_shard_stitch: rank " + std::to_string(r) + " failed (" + std::to_string(oc[(size_t)r * COMM_ROW + 7]) + ") while parsing its shard";
+                return BZQ_ERR_IO;
+            }
+    }
     bool walk = false;
     for (int r = 0; r < P; ++r) {
         const int64_t* w = &oc[(size_t)r * COMM_ROW];

@@ -139,13 +139,24 @@ int32_t bzq_fasta_shard_stitch(bzq_ctx* c, bzq_fasta* h, uint8_t* d_shard, uint6
     const uint64_t region_n = owner ? n - pl.head_bytes + pl.halo_bytes : 0;
     bzq_fasta_chunk res{};
     res.status = BZQ_EOF;
-    if (owner && (rc = bzq_fasta_parse(h, region, region_n, 1, pl.stream_pos + pl.head_bytes, 0, 0, &res))) return rc;
+    // (a runtime failure of this rank's parse travels through the outcome gather: every rank returns, nobody is left waiting)
+    int local_rc = 0;
+    if (owner && (local_rc = bzq_fasta_parse(h, region, region_n, 1, pl.stream_pos + pl.head_bytes, 0, 0, &res)) < 0) { res = bzq_fasta_chunk{}; res.status = BZQ_EOF; }
+    else local_rc = 0;
 
-    // 5. outcomes: {records, status, headers, open record at the error (-2 none), owner}
+    // 5. outcomes: {records, status, headers, open record at the error (-2 none), owner, runtime failure}
     const bool failed = owner && res.status != BZQ_EOF;
-    int64_t orow[COMM_ROW] = {(int64_t)res.n_records, res.status, owner ? bzq_fasta_last_headers_(h) : 0, failed ? bzq_fasta_last_killed_(h) : -2, owner ? 1 : 0, 0, 0, 0};
+    int64_t orow[COMM_ROW] = {(int64_t)res.n_records, res.status, owner && !local_rc ? bzq_fasta_last_headers_(h) : 0, failed ? bzq_fasta_last_killed_(h) : -2, owner ? 1 : 0, local_rc, 0, 0};
     std::vector<int64_t> oc((size_t)P * COMM_ROW);
-    if ((rc = gather(orow, oc.data()))) return rc;
+    {
+        const std::string own_err = bzq_fasta_last_error(h);
+        if ((rc = gather(orow, oc.data()))) return rc;
+        for (int r = 0; r < P; ++r)
+            if (oc[(size_t)r * COMM_ROW + 5] < 0) {
+                if (r == me) return fail(own_err, local_rc);
+                return fail("bzq_fasta_shard_stitch: rank " + std::to_string(r) + " failed (" + std::to_string(oc[(size_t)r * COMM_ROW + 5]) + ") while parsing its range", BZQ_ERR_IO);
+            }
+    }
     std::vector<int64_t> n_rec((size_t)P, 0);
     int err_rank = -1, prev_owner = -1;
     auto first_line_too_long = [&](int r) {   // rank r's first line (a header line) is too long: the record before it was still open
