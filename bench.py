@@ -57,12 +57,42 @@ def profile_traffic(path=TRAFFIC_PROFILE, kernel=TRAFFIC_KERNEL):
     return (vals["FETCH_SIZE"], vals["WRITE_SIZE"]) if len(vals) == 2 else None
 
 
-def measured_traffic_bytes_per_record():
+def profile_kernel_avg_ms(path=TRAFFIC_PROFILE, kernel=TRAFFIC_KERNEL):
+    """Average launch duration (ms) of `kernel` in the `== kt` (rocprofv3 --kernel-trace --stats) section of the same summary."""
+    try:
+        lines = open(os.path.join(ROOT, path)).read().splitlines()
+    except OSError:
+        return None
+    section = None
+    for ln in lines:
+        if ln.startswith("== "):
+            section = ln.split()[1].rstrip(":")
+        elif section == "kt" and ln.strip().startswith(kernel + " ") and "avg_us=" in ln:
+            return float(ln.split("avg_us=")[1].split()[0]) / 1e3
+    return None
+
+
+TRAFFIC_MAX_DRIFT = 0.10   # the cited profile must be of THIS kernel: its average launch time within 10 % of this run's
+
+
+def measured_traffic_bytes_per_record(run_avg_launch_ms=None):
+    """Bytes per record from the cited profile, or (None, why) when the profile is missing or stale: a kernel that changed
+    since it was profiled runs at a different speed, and its old traffic figure must not be printed beside the new time."""
     t = profile_traffic()
-    return None if t is None else (2 * t[0] + t[1]) * 1024 / TRAFFIC_RECORDS
+    if t is None:
+        return None, f"{TRAFFIC_PROFILE} is missing or holds no FETCH_SIZE / WRITE_SIZE for {TRAFFIC_KERNEL}"
+    if run_avg_launch_ms is not None:
+        prof_ms = profile_kernel_avg_ms()
+        if prof_ms is None:
+            return None, f"{TRAFFIC_PROFILE} holds no kernel-trace duration for {TRAFFIC_KERNEL}"
+        drift = abs(prof_ms - run_avg_launch_ms) / run_avg_launch_ms
+        if drift > TRAFFIC_MAX_DRIFT:
+            return None, (f"stale profile: {TRAFFIC_KERNEL} averages {prof_ms:.4f} ms in {TRAFFIC_PROFILE} but {run_avg_launch_ms:.4f} ms in this run "
+                          f"({drift * 100:.0f} % apart, limit {TRAFFIC_MAX_DRIFT * 100:.0f} %): re-profile (scripts/gpu_profile.sh)")
+    return (2 * t[0] + t[1]) * 1024 / TRAFFIC_RECORDS, None
 
 
-def cpu_baseline(data, reads: int, read_len: int, check: bool):
+def cpu_baseline(data, reads: int, read_len: int, check: bool, mode: str = "batches", t_budget: float = 12.0):
     """Reference-algorithm CPU baseline: the C restatement of BlazeSeq's streaming parser
     (oracle/bzq_oracle.c), batches(4096) mode, 64 KiB buffer like the reference's own runner
     (benchmark/throughput/run_throughput_blazeseq.mojo:28-40), one core, bounded sample.
@@ -70,18 +100,19 @@ def cpu_baseline(data, reads: int, read_len: int, check: bool):
     from oracle import oracle as O
     cfg = O.make_config(buffer_capacity=64 * 1024, check_ascii=check, check_quality=check, batch_size=4096)
     for _ in range(2):
-        O.bench_run(data, cfg, "batches")
-    t_budget, times, nrec = 12.0, [], 0
+        O.bench_run(data, cfg, mode)
+    times, nrec = [], 0
     t_start = time.perf_counter()
     while time.perf_counter() - t_start < t_budget and len(times) < 15:
         t0 = time.perf_counter()
-        nrec, _ = O.bench_run(data, cfg, "batches")
+        nrec, _ = O.bench_run(data, cfg, mode)
         times.append(time.perf_counter() - t0)
     assert nrec == reads
     best = sum(times) / len(times)
     return {"value": round(data.size / best / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
             "mrecords_per_s": round(reads / best / 1e6, 3),
-            "sample": f"the first {reads} reads of the GPU input ({read_len} bp, {data.size} B), batches(4096), 64 KiB buffer, "
+            "mode": "batches(4096)" if mode == "batches" else "views()",
+            "sample": f"the first {reads} reads of the GPU input ({read_len} bp, {data.size} B), {'batches(4096)' if mode == 'batches' else 'views() (next_view per record, run_throughput_blazeseq.mojo:38-45)'}, 64 KiB buffer, "
                       f"validation {'on' if check else 'off'}, mean of {len(times)} runs, in-memory"}
 
 
@@ -116,7 +147,7 @@ def cpu_baseline_all_cores(data, reads: int, rec_bytes: int, check: bool):
             "sample": f"same bytes, {len(slices)} threads on record-aligned slices, each slice parsed {REPS}x, best of 3"}
 
 
-def fasta_main(args, world, rank, local_rank, dev, distributed):
+def fasta_main(args, world, rank, local_rank, dev, distributed, native_comm, dist_dev):
     """FastaParser over benchmark/fasta-parser/generate_synthetic_fasta.mojo's input
     (200-3800 bp, line width 60).  Records are independent, so ranks take equal record ranges of one synthetic file
     (weak scaling, no data-path collective); a step = one parse of the rank's resident shard."""
@@ -133,11 +164,7 @@ def fasta_main(args, world, rank, local_rank, dev, distributed):
         SHIFT = 144
         try:
             comm_ctx = B.Context(B.ParserConfig(), device=local_rank)
-            box = [B.Context.comm_unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(box, src=0)
-            comm_ctx.comm_init(rank, world, box[0])
-            comm_ctx.comm_selftest()   # one checked ring exchange: a transport that does not work shows here, not inside the timed steps
+            native_comm(comm_ctx)   # (with one checked ring exchange: a transport that does not work shows here, not inside the timed steps)
             sharded = "byte ranges"
         except Exception as e:   # noqa: BLE001 -- said out loud in the JSON line, never silent
             sharded = None
@@ -187,7 +214,7 @@ def fasta_main(args, world, rank, local_rank, dev, distributed):
         dist.barrier()
     dt = time.perf_counter() - t0
     assert int(res.status) == 6 and int(res.n_records) == expect, (res.status, res.n_records)
-    stats = torch.tensor([dt, float(n), float(res.seq_bytes), float(res.id_bytes)], dtype=torch.float64, device=dev)
+    stats = torch.tensor([dt, float(n), float(res.seq_bytes), float(res.id_bytes)], dtype=torch.float64, device=dist_dev)
     if distributed:
         mx = stats.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         sm = stats.clone(); dist.all_reduce(sm, op=dist.ReduceOp.SUM)
@@ -270,6 +297,12 @@ def main():
     ap.add_argument("--kernels-v1", action="store_true", help="two-pass mode with the first-generation kernels")
     ap.add_argument("--overlap", type=int, default=0, help="overlap pass A of sub-chunk k+1 with the emit of sub-chunk k (needs --pass-bytes)")
     ap.add_argument("--force-sharded", action="store_true", help="run the multi-GPU shard protocol even with one rank")
+    ap.add_argument("--ranks-on-one-gpu", type=int, default=0, metavar="N",
+                    help="harness check on a one-GPU box: the N ranks torch.distributed.run started all use device 0, the library's "
+                         "shared-memory transport (bzq_comm_init_shm) replaces RCCL (which refuses two ranks on one GPU) and gloo "
+                         "carries the torch side.  Every world > 1 branch of this file and bzq_shard_stitch with real neighbours run; "
+                         "the figure it prints is N ranks sharing ONE GPU, not a scaling point.  Pass --reads (the default shard is 25 GB).")
+    ap.add_argument("--no-extra-modes", action="store_true", help="skip the validated / long-reads / views / FASTA figures of the default line")
     ap.add_argument("--ablate", type=int, default=0, help="timing experiments only (results are wrong)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--fasta", action="store_true",
@@ -289,24 +322,53 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    one_gpu = args.ranks_on_one_gpu > 0
+    if one_gpu:
+        if args.ranks_on_one_gpu != world:
+            raise SystemExit(f"--ranks-on-one-gpu {args.ranks_on_one_gpu} needs exactly that many ranks (WORLD_SIZE is {world})")
+        if args.reads == 0:
+            raise SystemExit("--ranks-on-one-gpu: pass --reads (the default 25 GB shard per rank does not fit N times on one GPU)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist_dev = torch.device("cpu") if one_gpu else dev   # where the tensors of torch's own collectives live (gloo: host)
     sharded_mode = world > 1 or args.force_sharded
     if sharded_mode:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    config5 = world > 1 and not args.long_reads and not args.fasta and args.reads == 0
+    def native_comm(c):
+        """The library's own communicator on ctx `c`: RCCL (the id travels through torch), or shared memory with --ranks-on-one-gpu."""
+        if one_gpu:
+            box = [f"bench{os.getpid()}_{int(time.time() * 1e3) % 1000000}" if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            c.comm_init_shm(rank, world, box[0], 4 << 20)
+        else:
+            box = [B.Context.comm_unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)
+            c.comm_init(rank, world, box[0])
+        c.comm_selftest()   # one checked ring exchange (send/recv + all-gather) before anything is timed
+
+    config5 = world > 1 and not args.long_reads and not args.fasta
+    default_reads = args.reads == 0
     if args.reads == 0:
         args.reads = 78_125_000 if config5 else 10_000_000
     if args.fasta:
-        return fasta_main(args, world, rank, local_rank, dev, sharded_mode)
+        return fasta_main(args, world, rank, local_rank, dev, sharded_mode, native_comm, dist_dev)
 
     cfg = B.ParserConfig(check_ascii=args.validate, check_quality=args.validate,
                          quality_schema="sanger" if args.validate else None, views_only=args.views)
-    ctx = B.Context(cfg, "generic", 4096, local_rank, pass_bytes=args.pass_bytes, min_record_bytes=256 if not args.long_reads and args.read_len >= 100 else 32)
+    # min_record_bytes only sizes the per-record arrays (8 B per possible record; library default 32): 256 for reads >= 100 bp
+    # keeps them at n / 256 entries instead of n / 32.  Named in config below.
+    min_record_bytes = 256 if not args.long_reads and args.read_len >= 100 else 32
+    ctx = B.Context(cfg, "generic", 4096, local_rank, pass_bytes=args.pass_bytes, min_record_bytes=min_record_bytes)
     ctx.set_option("timing_detail", 1)
     if args.hier or args.service or args.single_pass or args.kernels_v1:   # EXPERIMENTS build only (BLAZESEQ_HIP_LIB=.../libblazeseq_hip_exp.so)
         ctx.set_option("single_pass", 3 if args.hier else 2 if args.service else (1 if (args.single_pass and not args.kernels_v1) else 0))
@@ -363,11 +425,7 @@ def main():
         exchange = args.exchange
         if exchange == "native":
             try:   # the library binds librccl itself; torch only hands the id around
-                box = [B.Context.comm_unique_id() if rank == 0 else None]
-                if world > 1:
-                    dist.broadcast_object_list(box, src=0)
-                ctx.comm_init(rank, world, box[0])
-                ctx.comm_selftest()   # one checked ring exchange (send/recv + all-gather) before anything is timed
+                native_comm(ctx)
             except Exception as e:   # noqa: BLE001 -- said out loud in the JSON line, never silent
                 exchange = f"torch (native communicator failed: {str(e)[:200]})"
                 print(f"[bench] rank {rank}: {exchange}", file=sys.stderr)
@@ -377,6 +435,44 @@ def main():
             exchange = "native" if all(f == "native" for f in flags) else next(f for f in flags if f != "native")
 
     import ctypes as C
+
+    def side_mode(d_buf, nbytes, nrec, validate, what, min_rec=None):
+        """One more BASELINE configuration beside the headline: its own ctx, batch mode, every batch handed out; host-timed
+        steps bracketed by synchronisations, plus the dominant kernel's roofline fraction from the ctx's HIP events."""
+        c2 = B.Context(B.ParserConfig(check_ascii=validate, check_quality=validate, quality_schema="sanger" if validate else None),
+                       "generic", 4096, local_rank, min_record_bytes=min_rec or min_record_bytes)
+        c2.set_option("timing_detail", 1)
+        arr = (L.BzqDeviceBatch * (nrec // 4096 + 2))()
+        nout = C.c_uint64()
+
+        def one():
+            c2.submit_device(d_buf.data_ptr(), nbytes, 0, True)
+            r = c2.result()
+            assert L.lib().bzq_batches(c2.h, 4096, arr, len(arr), C.byref(nout)) == 0
+            return r
+        for _ in range(max(2, args.warmup)):
+            r = one()
+        torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < min(0.25, args.min_seconds):
+            r = one()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        me = mt = 0.0
+        for _ in range(args.steps):
+            r = one()
+            me += r.ms_emit; mt += r.ms_total
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t1) / args.steps
+        assert int(r.n_records) == nrec and r.status == L.EOF and nout.value == (nrec + 4095) // 4096, (r.n_records, r.status, c2.format_error())
+        A2 = nbytes + int(r.seq_bytes) + int(r.qual_bytes) + int(r.id_bytes) + 16 * nrec
+        o = {"value": round(nbytes / dt / 1e9, 3), "unit": "GB/s", "mrecords_per_s": round(nrec / dt / 1e6, 3), "ms_per_step": round(dt * 1e3, 4),
+             "input_gb": round(nbytes / 1e9, 3), "kernels_ms": round(mt / args.steps, 4),
+             "roofline_frac": round(A2 / (me / args.steps / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "roofline_kernel": "k_fused<LB=false> (emit)",
+             "roofline_path_frac": round(A2 / (mt / args.steps / 1e3) / 1e9 / HBM_PEAK_GBS, 4), "note": what}
+        c2.close()
+        return o
+
     nb_cap = args.reads // 4096 + 2
     batch_arr = (L.BzqDeviceBatch * nb_cap)()     # the step hands out every DeviceFastqBatch of the chunk (batches(4096))
     nb_out = C.c_uint64()
@@ -405,7 +501,7 @@ def main():
         t_w = time.perf_counter(); step(); torch.cuda.synchronize(); one = max(1e-5, time.perf_counter() - t_w); warm_done += 1
         extra = int(min(5000, max(0.0, args.min_seconds) / one))
         if sharded_mode and world > 1:
-            tx = torch.tensor([extra], dtype=torch.int64, device=dev)
+            tx = torch.tensor([extra], dtype=torch.int64, device=dist_dev)
             dist.all_reduce(tx, op=dist.ReduceOp.MAX)
             extra = int(tx.item())
         for _ in range(extra):
@@ -424,7 +520,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if sharded_mode:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dist_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -475,12 +571,14 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": (f"synthetic long reads 200..19800 bases (BASELINE config 4), {args.reads} reads/GPU "
                                     f"(mean {rec_bytes} B/record), batches(4096), validation " if args.long_reads else
-                                    (f"BASELINE config 5 shard shape: {total_reads} reads of one synthetic stream "
+                                    (f"BASELINE config 5 shard shape{'' if default_reads else ' (scaled by --reads)'}: {total_reads} reads of one synthetic stream "
                                      f"({total_bytes / 1e9:.1f} GB), byte-range shards cut {SHIFT} B into a record; " if config5 else "") +
                                     f"synthetic {args.read_len} bp Illumina FASTQ, {args.reads} reads/GPU "
                                     f"({rec_bytes} B/record), {'views() mode (offsets + id spans, no columns)' if args.views else 'batches(4096)'}, validation ")
                                    + f"{'ascii+quality (sanger)' if args.validate else 'off'}, input resident in HBM",
                        "records_per_gpu": args.reads, "record_bytes": rec_bytes, "batch_size": 4096,
+                       "min_record_bytes": min_record_bytes,
+                       "ranks_on_one_gpu": (f"{world} ranks share device 0 (harness check: shared-memory transport + gloo, not a scaling point)" if one_gpu else None),
                        "parallelism": (f"{'record-aligned' if args.long_reads else 'byte-range'} shards x{world}"
                                        if world > 1 else "single GPU"),
                        "pass_bytes": args.pass_bytes, "exchange": exchange},
@@ -493,11 +591,10 @@ def main():
                 # HBM bytes per launch from the PMC counters of the same command (rocprofv3, separate --pmc passes;
                 # FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md), committed under profiles/.
                 # Only quoted for the profiled configuration (150 bp, validation off, two-pass default).
-                "traffic": (round(measured_traffic_bytes_per_record() * per_rank_records / 1e9, 3)
-                            if (measured_traffic_bytes_per_record() and args.read_len == 150 and not args.long_reads and not args.views and not args.validate
-                                and not args.single_pass and not args.service and not args.hier and not args.kernels_v1) else None),
+                "traffic": None,   # filled in below, for the profiled configuration only
                 "traffic_unit": "GB per launch",
-                "traffic_source": f"{TRAFFIC_PROFILE}: {TRAFFIC_KERNEL} FETCH_SIZE*2 + WRITE_SIZE (KiB), scaled per record; read from the file at run time, not measured in this run",
+                "traffic_source": f"{TRAFFIC_PROFILE}: {TRAFFIC_KERNEL} FETCH_SIZE*2 + WRITE_SIZE (KiB), scaled per record; read from the file at run time, not measured in this run; "
+                                  f"withheld when the file's kernel-trace duration of that kernel is more than {int(TRAFFIC_MAX_DRIFT * 100)} % from this run's avg_launch_ms",
                 "algorithmic_gb_per_launch": round(dom_bytes / 1e9, 3),
                 "algorithmic_bytes_per_record": round(dom_bytes / max(1, recs), 1),
                 "avg_launch_ms": round(dom_ms / steps / max(1, int(res.n_passes)), 4),
@@ -512,7 +609,16 @@ def main():
                        "kernels_total": round(ms_kernels / steps, 4)},
             },
         }
-        if world == 1 and not args.views and not args.ablate and not sharded_mode:
+        profiled_config = (args.read_len == 150 and not args.long_reads and not args.views and not args.validate and not args.stream
+                           and not args.single_pass and not args.service and not args.hier and not args.kernels_v1)
+        if profiled_config:
+            bpr, why = measured_traffic_bytes_per_record(out["roofline"]["avg_launch_ms"])
+            if bpr is not None:
+                out["roofline"]["traffic"] = round(bpr * per_rank_records / 1e9, 3)
+            else:
+                out["roofline"]["traffic_withheld"] = why
+        extras = world == 1 and not args.ablate and not sharded_mode and not args.no_extra_modes
+        if extras and not args.views:
             # the same input through views mode (parser.views(): offsets + id spans into the chunk, no columns), as an
             # extra figure next to the headline batch-mode `value`
             vcfg = B.ParserConfig(check_ascii=args.validate, check_quality=args.validate,
@@ -531,7 +637,19 @@ def main():
                                  "ms_per_step": round(tv * 1e3, 4), "algorithmic_bytes_per_record": round((n + 52 * recs) / recs, 1),
                                  "note": "config.views_only: RecordOffsets + id spans into the chunk, no columns; one read of the input"}
             vctx.close()
-        if world == 1 and not args.views and not args.ablate and not sharded_mode and not args.long_reads:
+        if extras and not args.views and not args.validate and not args.long_reads and args.read_len == 150:
+            # BASELINE configs[2]: the SAME bytes with ParserConfig(check_ascii=True, check_quality=True), 'sanger' -- batch mode
+            out["validated_mode"] = side_mode(shard, n, recs, True, "BASELINE config 3: same 150 bp input, check_ascii + check_quality, 'sanger'; batches(4096)")
+        if extras and not args.views and not args.long_reads:
+            # BASELINE configs[3]: long reads, 300 000 x 200..19 800 bases (phred 5..30, sanger), irregular record boundaries
+            lr_n = ctx.generate_synthetic_device(300_000, 200, 5, 30, "sanger", 0, 0, first=0, count=300_000, max_len=19_800)
+            lr = torch.empty(lr_n + (1 << 20), dtype=torch.uint8, device=dev)
+            ctx.generate_synthetic_device(300_000, 200, 5, 30, "sanger", lr.data_ptr(), lr.numel(), first=0, count=300_000, max_len=19_800)
+            torch.cuda.synchronize()
+            out["long_reads_mode"] = side_mode(lr, lr_n, 300_000, False, "BASELINE config 4: 300 000 reads of 200..19 800 bases (mean ~10 kb), batches(4096), validation off",
+                                               min_rec=32)
+            del lr
+        if extras and not args.views and not args.long_reads:
             # the FASTA path (`bench.py --fasta` is its own full line) on the reference's FASTA benchmark
             # input, a third of the size, as one more figure next to the headline
             fctx = B.FastaContext(B.FastaParserConfig(check_ascii=args.validate), local_rank)
@@ -552,6 +670,8 @@ def main():
             k = min(args.cpu_reads, recs)
             host = shard[:k * rec_bytes].cpu().numpy() if not args.long_reads else shard[:n].cpu().numpy()
             out["cpu_baseline"] = cpu_baseline(host, k if not args.long_reads else recs, args.read_len, args.validate)
+            # BlazeSeq's other CPU mode (run_throughput_blazeseq.mojo:38-45: `for view in parser.views()`), beside views_mode
+            out["cpu_baseline_views"] = cpu_baseline(host, k if not args.long_reads else recs, args.read_len, args.validate, mode="views", t_budget=8.0)
             if not args.long_reads and not args.views:
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(host, k, rec_bytes, args.validate)
         # RCCL writes a version banner to C stdio; flush it first so that the JSON is the last line

@@ -977,8 +977,15 @@ int32_t bzq_bgzf_inflate(bzq_ctx* c, const uint8_t* d_comp, uint64_t comp_bytes,
     std::vector<bzq::inf::DevBlock> hb((size_t)n_blocks);
     for (int64_t i = 0; i < n_blocks; ++i) {
         const bzq_bgzf_block& b = blocks[i];
-        if (b.comp_size < 26 || b.comp_offset + b.comp_size > comp_bytes || b.out_size > 65536 || b.out_offset + b.out_size > out_capacity) {
+        // (subtraction form: an offset near 2^64 must not wrap past the check)
+        if (b.comp_size < 26 || b.comp_size > comp_bytes || b.comp_offset > comp_bytes - b.comp_size || b.out_size > 65536 || b.out_size > out_capacity ||
+            b.out_offset > out_capacity - b.out_size) {
             c->err = "bzq_bgzf_inflate: block " + std::to_string(i) + " lies outside the buffers";
+            return BZQ_ERR_ARG;
+        }
+        // one wave per block writes its range without looking at the others: the ranges must not overlap
+        if (i > 0 && b.out_offset < blocks[i - 1].out_offset + blocks[i - 1].out_size) {
+            c->err = "bzq_bgzf_inflate: the output range of block " + std::to_string(i) + " overlaps the block before it (out_offset must not decrease)";
             return BZQ_ERR_ARG;
         }
         hb[(size_t)i] = bzq::inf::DevBlock{b.comp_offset + 18, b.out_offset, b.comp_size - 26, b.out_size, b.crc32, 0u};

@@ -63,7 +63,8 @@ struct ShmHeader {
     std::atomic<uint32_t> magic, count, gen;
     uint32_t nranks;
     uint64_t halo_cap;
-    uint8_t pad[40];
+    std::atomic<uint32_t> attached, go;   // the attach handshake of bzq_comm_init_shm
+    uint8_t pad[32];
 };
 static_assert(sizeof(ShmHeader) == 64, "ShmHeader is one cache line");
 constexpr uint32_t SHM_MAGIC = 0x425A5131u;   // "BZQ1"
@@ -236,6 +237,11 @@ int32_t bzq_comm_init(bzq_ctx* c, int32_t rank, int32_t nranks, const void* nccl
     return 0;
 }
 
+// A segment of a crashed run may still carry the name (fully initialised, magic set, the same nranks).  Rank 0 always unlinks
+// the name and creates a fresh segment; a rank > 0 that got there first must not settle on the stale one.  The handshake: a
+// rank > 0 attaches (counter), then waits for `go` to CHANGE -- rank 0 sets it on ITS segment once nranks - 1 ranks have
+// attached there -- and while it waits it keeps checking that the name still leads to the segment it holds (same inode).  On a
+// stale segment `go` never changes and the name moves on as soon as rank 0 arrives: the rank drops it and starts over.
 int32_t bzq_comm_init_shm(bzq_ctx* c, int32_t rank, int32_t nranks, const char* name, uint64_t halo_capacity) {
     if (!c || nranks <= 0 || rank < 0 || rank >= nranks || !name || !*name) return BZQ_ERR_ARG;
     (void)bzq_comm_destroy(c);
@@ -245,33 +251,65 @@ int32_t bzq_comm_init_shm(bzq_ctx* c, int32_t rank, int32_t nranks, const char* 
     m->shm_name = std::string("/bzq_") + name;
     m->seg_bytes = sizeof(ShmHeader) + (size_t)nranks * COMM_ROW * 8 + (size_t)nranks * m->halo_cap;
     const auto t0 = std::chrono::steady_clock::now();
+    auto drop = [&]() {
+        if (m->seg) { munmap(m->seg, m->seg_bytes); m->seg = nullptr; }
+        if (m->shm_fd >= 0) { close(m->shm_fd); m->shm_fd = -1; }
+    };
+    auto fail = [&](const std::string& msg, int32_t code) { c->err = msg; const int r0 = m->rank; if (r0 != 0) m->shm_name.clear(); comm_free(m); return code; };
     if (rank == 0) {
         shm_unlink(m->shm_name.c_str());   // a stale segment of a crashed run
         m->shm_fd = shm_open(m->shm_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
-        if (m->shm_fd < 0 || ftruncate(m->shm_fd, (off_t)m->seg_bytes) != 0) { c->err = "bzq_comm_init_shm: cannot create " + m->shm_name; comm_free(m); return BZQ_ERR_IO; }
+        if (m->shm_fd < 0 || ftruncate(m->shm_fd, (off_t)m->seg_bytes) != 0) return fail("bzq_comm_init_shm: cannot create " + m->shm_name, BZQ_ERR_IO);
+        void* p = mmap(nullptr, m->seg_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, m->shm_fd, 0);
+        if (p == MAP_FAILED) return fail("bzq_comm_init_shm: mmap failed", BZQ_ERR_IO);
+        m->seg = (uint8_t*)p;
+        ShmHeader* h = (ShmHeader*)m->seg;   // (a fresh segment is zero-filled)
+        h->count.store(0); h->gen.store(0); h->attached.store(0); h->go.store(0); h->nranks = (uint32_t)nranks; h->halo_cap = m->halo_cap;
+        h->magic.store(SHM_MAGIC, std::memory_order_release);
+        while (h->attached.load(std::memory_order_acquire) != (uint32_t)(nranks - 1)) {
+            if (bzq::seconds_since(t0) > 120.0) return fail("bzq_comm_init_shm: only " + std::to_string(h->attached.load()) + " of " + std::to_string(nranks - 1) + " peers attached to " + m->shm_name + " within 120 s", BZQ_ERR_IO);
+            usleep(200);
+        }
+        h->go.store(1, std::memory_order_release);
     } else {
-        for (;;) {   // wait for rank 0 to create and size it
+        for (;;) {
+            if (bzq::seconds_since(t0) > 120.0) return fail("bzq_comm_init_shm: rank 0 never offered " + m->shm_name, BZQ_ERR_IO);
+            drop();
             m->shm_fd = shm_open(m->shm_name.c_str(), O_RDWR, 0600);
             struct stat st;
-            if (m->shm_fd >= 0 && fstat(m->shm_fd, &st) == 0 && (size_t)st.st_size >= m->seg_bytes) break;
-            if (m->shm_fd >= 0) { close(m->shm_fd); m->shm_fd = -1; }
-            if (bzq::seconds_since(t0) > 120.0) { c->err = "bzq_comm_init_shm: rank 0 never created " + m->shm_name; comm_free(m); return BZQ_ERR_IO; }
-            usleep(1000);
+            if (m->shm_fd < 0 || fstat(m->shm_fd, &st) != 0 || (size_t)st.st_size < m->seg_bytes) { usleep(1000); continue; }   // not created / not sized yet
+            void* p = mmap(nullptr, m->seg_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, m->shm_fd, 0);
+            if (p == MAP_FAILED) return fail("bzq_comm_init_shm: mmap failed", BZQ_ERR_IO);
+            m->seg = (uint8_t*)p;
+            ShmHeader* h = (ShmHeader*)m->seg;
+            auto name_moved_on = [&]() {   // the name no longer leads to the segment we hold
+                const int fd2 = shm_open(m->shm_name.c_str(), O_RDWR, 0600);
+                if (fd2 < 0) return true;
+                struct stat s2;
+                const bool moved = fstat(fd2, &s2) != 0 || s2.st_ino != st.st_ino || s2.st_dev != st.st_dev;
+                close(fd2);
+                return moved;
+            };
+            bool again = false;
+            while (h->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
+                if (bzq::seconds_since(t0) > 120.0) return fail("bzq_comm_init_shm: segment never initialised", BZQ_ERR_IO);
+                usleep(1000);
+                if (name_moved_on()) { again = true; break; }
+            }
+            if (again) continue;
+            const bool agree = h->nranks == (uint32_t)nranks && h->halo_cap == m->halo_cap;
+            const uint32_t g0 = h->go.load(std::memory_order_acquire);
+            if (agree) h->attached.fetch_add(1, std::memory_order_acq_rel);
+            for (uint32_t spins = 0;; ++spins) {
+                if (agree && h->go.load(std::memory_order_acquire) != g0) break;
+                if ((spins & 15) == 15 && name_moved_on()) { again = true; break; }
+                if (bzq::seconds_since(t0) > 120.0)
+                    return fail(agree ? "bzq_comm_init_shm: rank 0 never completed the handshake on " + m->shm_name
+                                      : std::string("bzq_comm_init_shm: ranks disagree on nranks / halo capacity"), agree ? BZQ_ERR_IO : BZQ_ERR_ARG);
+                usleep(200);
+            }
+            if (!again) break;
         }
-    }
-    void* p = mmap(nullptr, m->seg_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, m->shm_fd, 0);
-    if (p == MAP_FAILED) { c->err = "bzq_comm_init_shm: mmap failed"; m->seg = nullptr; comm_free(m); return BZQ_ERR_IO; }
-    m->seg = (uint8_t*)p;
-    ShmHeader* h = (ShmHeader*)m->seg;
-    if (rank == 0) {
-        h->count.store(0); h->gen.store(0); h->nranks = (uint32_t)nranks; h->halo_cap = m->halo_cap;
-        h->magic.store(SHM_MAGIC, std::memory_order_release);
-    } else {
-        while (h->magic.load(std::memory_order_acquire) != SHM_MAGIC) {
-            if (bzq::seconds_since(t0) > 120.0) { c->err = "bzq_comm_init_shm: segment never initialised"; comm_free(m); return BZQ_ERR_IO; }
-            usleep(1000);
-        }
-        if (h->nranks != (uint32_t)nranks || h->halo_cap != m->halo_cap) { c->err = "bzq_comm_init_shm: ranks disagree on nranks / halo capacity"; comm_free(m); return BZQ_ERR_ARG; }
     }
     c->comm = m;
     return shm_barrier(c, m);   // everybody is attached (rank 0 may unlink the name only after all have opened it)
@@ -340,33 +378,62 @@ int32_t bzq_comm_selftest(bzq_ctx* c) {
 
 // ---- the protocol ---------------------------------------------------------------------------------------------------------
 
+// Failures are collective.  Between the first and the last exchange of a call a rank never returns on its own: a failure that
+// only this rank sees (a HIP error, a refused allocation, a parse that cannot run) is kept in `lrc`, the rank goes on through
+// every exchange of the protocol with empty contributions, and the failure travels in the next gathered row (summary row word 6
+// bits 32.., outcome row word 7); every rank then returns together right after that gather.  Over RCCL there is no timeout, so a
+// rank that bailed out alone would leave its peers in ncclAllGather / ncclRecv for ever.  What cannot be saved is a failing
+// transport itself (comm_gather's own errors).
 int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capacity, bzq_shard_result* out) {
-    if (!c || !out || (!d_shard && n) || capacity < n) return BZQ_ERR_ARG;
-    if (((uintptr_t)d_shard & 15u) != 0) { c->err = "device shard must be 16-byte aligned"; return BZQ_ERR_ARG; }
-    if (c->cfg.views_only) { c->err = "bzq_shard_stitch: views mode is a single-chunk mode (shards deliver batch columns)"; return BZQ_ERR_ARG; }
-    HIPCHK(c, hipSetDevice(c->device));
+    if (!c || !out) return BZQ_ERR_ARG;
     bzq_comm* m = c->comm;
     const int P = m ? m->nranks : 1, me = m ? m->rank : 0;
     memset(out, 0, sizeof(*out));
     out->first_error_record = -1; out->error_rank = -1;
     int rc;
+    int lrc = 0;            // this rank's own failure so far
+    std::string lerr;       // ... and its text
+    auto note = [&](int r) { if (r < 0 && !lrc) { lrc = r; lerr = c->err; } return r; };
+    auto note_hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && !lrc) { lrc = BZQ_ERR_HIP; lerr = std::string(what) + ": " + hipGetErrorString(e); } };
+    auto everybody_fails = [&](const std::vector<int64_t>& rows, int word, int shift, const char* where) -> int {   // 0 = nobody
+        for (int r = 0; r < P; ++r) {
+            const int64_t code = rows[(size_t)r * COMM_ROW + word] >> shift;
+            if (code == 0) continue;
+            c->tail_mode = 0;
+            if (r == me && lrc) { c->err = lerr; return lrc; }
+            c->err = std::string("bzq_shard_stitch: rank ") + std::to_string(r) + " failed (" + std::to_string(shift ? -code : code) + ") " + where;
+            return BZQ_ERR_IO;
+        }
+        return 0;
+    };
+    if ((!d_shard && n) || capacity < n) { c->err = "bzq_shard_stitch: bad shard buffer"; note(BZQ_ERR_ARG); }
+    else if (((uintptr_t)d_shard & 15u) != 0) { c->err = "device shard must be 16-byte aligned"; note(BZQ_ERR_ARG); }
+    else if (c->cfg.views_only) { c->err = "bzq_shard_stitch: views mode is a single-chunk mode (shards deliver batch columns)"; note(BZQ_ERR_ARG); }
+    if (!lrc) note_hip(hipSetDevice(c->device), "hipSetDevice");
 
     // 1. scan + summary all-gather (RCCL: the row is packed on the device, one synchronisation for both)
     std::vector<bzq_shard_summary> sums((size_t)P);
     std::vector<int64_t> all((size_t)P * COMM_ROW);
-    if ((rc = shard_scan_enqueue(c, d_shard, n))) return rc;
-    if (m && m->kind == 1 && n > 0) {
+    if (!lrc) note(shard_scan_enqueue(c, d_shard, n));
+    if (!lrc && m && m->kind == 1 && n > 0) {
         hipLaunchKernelGGL(k_pack_summary, dim3(1), dim3(1), 0, c->stream, (const ChunkState*)c->d_state, (int64_t)n, (int64_t)(capacity - n), m->d_row);
         if ((rc = comm_gather(c, nullptr, all.data()))) return rc;
         shard_scan_finish(c, d_shard, n, &sums[(size_t)me]);
     } else {
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        shard_scan_finish(c, d_shard, n, &sums[(size_t)me]);
-        const bzq_shard_summary& s = sums[(size_t)me];
-        int64_t row[COMM_ROW] = {(int64_t)s.n_bytes, (int64_t)s.n_newlines, s.first_nl[0], s.first_nl[1], s.first_nl[2], s.first_nl[3],
-                                 (int64_t)s.first_byte | ((int64_t)s.last_byte << 8), (int64_t)(capacity - n)};
+        int64_t row[COMM_ROW] = {0, 0, -1, -1, -1, -1, 0, 0};
+        if (!lrc) note_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize(scan)");
+        if (!lrc) {
+            shard_scan_finish(c, d_shard, n, &sums[(size_t)me]);
+            const bzq_shard_summary& s = sums[(size_t)me];
+            const int64_t r2[COMM_ROW] = {(int64_t)s.n_bytes, (int64_t)s.n_newlines, s.first_nl[0], s.first_nl[1], s.first_nl[2], s.first_nl[3],
+                                          (int64_t)s.first_byte | ((int64_t)s.last_byte << 8), (int64_t)(capacity - n)};
+            memcpy(row, r2, sizeof(row));
+        } else {
+            row[6] = (int64_t)(uint32_t)(-lrc) << 32;   // an empty shard that says why
+        }
         if ((rc = comm_gather(c, row, all.data()))) return rc;
     }
+    if ((rc = everybody_fails(all, 6, 32, "before the shards were exchanged"))) return rc;
     uint64_t stream_pos = 0, total_bytes = 0;
     for (int r = 0; r < P; ++r) {
         const int64_t* w = &all[(size_t)r * COMM_ROW];
@@ -378,37 +445,41 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
         total_bytes += s.n_bytes;
     }
 
-    // 2. plan
+    // 2. plan: a pure function of the gathered rows -- whatever it refuses, it refuses on every rank
     std::vector<bzq_shard_plan> plans((size_t)P);
     if ((rc = bzq_plan_shards(sums.data(), P, plans.data()))) { c->err = "bzq_shard_stitch: inconsistent shard summaries"; return rc; }
     const bzq_shard_plan pl = plans[(size_t)me];
     out->plan = pl;
     // every rank knows every rank's room (row[7]): a halo that does not fit fails the call on ALL ranks, before anything is
-    // exchanged -- a rank that bailed out alone would leave its peers waiting in the send / receive
+    // exchanged
     for (int r = 0; r < P; ++r)
         if ((int64_t)plans[(size_t)r].halo_bytes > all[(size_t)r * COMM_ROW + 7]) {
             c->err = "bzq_shard_stitch: rank " + std::to_string(r) + "'s shard buffer has no room for its halo (" + std::to_string(plans[(size_t)r].halo_bytes) +
                      " bytes behind " + std::to_string(sums[(size_t)r].n_bytes) + ", room for " + std::to_string(all[(size_t)r * COMM_ROW + 7]) + ")";
             return BZQ_ERR_ARG;
         }
-
-    // 3. heads travel to their owners
-    if (m && m->kind == 1 && P > 1) {
-        NCCLCHK(c, m, m->p_GroupStart());
-        if (pl.head_bytes > 0) NCCLCHK(c, m, m->p_Send(d_shard, (size_t)pl.head_bytes, NCCL_U8, pl.head_dst, m->nccl, c->stream));
-        for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
-            if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
-                NCCLCHK(c, m, m->p_Recv(d_shard + n + plans[(size_t)q].halo_offset, (size_t)plans[(size_t)q].head_bytes, NCCL_U8, q, m->nccl, c->stream));
-        NCCLCHK(c, m, m->p_GroupEnd());
-    } else if (m && P > 1) {
+    if (m && m->kind == 2 && P > 1)
         for (int r = 0; r < P; ++r)   // (the capacity is the same on every rank: all of them fail together)
             if (plans[(size_t)r].head_bytes > m->halo_cap) { c->err = "bzq_shard_stitch(shm): rank " + std::to_string(r) + "'s head of " + std::to_string(plans[(size_t)r].head_bytes) + " bytes exceeds the halo capacity the communicator was created with"; return BZQ_ERR_ARG; }
-        if (pl.head_bytes > 0) HIPCHK(c, hipMemcpy(shm_halo(m, me), d_shard, (size_t)pl.head_bytes, hipMemcpyDeviceToHost));
+
+    // 3. heads travel to their owners.  A group that was opened is closed whatever happens inside it; a copy that fails is
+    // noted and the barriers are still met.
+    if (m && m->kind == 1 && P > 1) {
+        auto nccl_note = [&](int r, const char* what) { if (r != 0 && !lrc) { lrc = BZQ_ERR_HIP; lerr = std::string(what) + ": " + (m->p_GetErrorString ? m->p_GetErrorString(r) : "RCCL error"); } return r; };
+        if (nccl_note(m->p_GroupStart(), "ncclGroupStart") == 0) {
+            if (pl.head_bytes > 0) nccl_note(m->p_Send(d_shard, (size_t)pl.head_bytes, NCCL_U8, pl.head_dst, m->nccl, c->stream), "ncclSend");
+            for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
+                if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
+                    nccl_note(m->p_Recv(d_shard + n + plans[(size_t)q].halo_offset, (size_t)plans[(size_t)q].head_bytes, NCCL_U8, q, m->nccl, c->stream), "ncclRecv");
+            nccl_note(m->p_GroupEnd(), "ncclGroupEnd");
+        }
+    } else if (m && P > 1) {
+        if (pl.head_bytes > 0) note_hip(hipMemcpy(shm_halo(m, me), d_shard, (size_t)pl.head_bytes, hipMemcpyDeviceToHost), "hipMemcpy(head to segment)");
         if ((rc = shm_barrier(c, m))) return rc;
         for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
             if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
-                HIPCHK(c, hipMemcpyAsync(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));   // the bytes have left the segment before a peer may overwrite it, and are on the device before anything reads them
+                note_hip(hipMemcpyAsync(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync(halo)");
+        note_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize(halo)");   // the bytes have left the segment before a peer may overwrite it, and are on the device before anything reads them
         if ((rc = shm_barrier(c, m))) return rc;
     }
 
@@ -417,37 +488,31 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
     bzq_chunk res{};
     res.error_record = -1;
     c->tail_mode = 0;
-    int local_rc = 0;   // a runtime failure of THIS rank's parse: reported through the outcome gather, so that every rank returns
-    if (owner) {
+    if (owner && !lrc) {
         c->tail_mode = pl.is_last ? 1 : 0;
-        local_rc = bzq_submit_shard(c, d_shard, n, pl.halo_bytes, pl.lines_before, pl.prev_last_byte, stream_pos, pl.is_last);
-        if (local_rc >= 0) local_rc = bzq_chunk_result(c, &res);
-        if (local_rc < 0) { c->tail_mode = 0; res = bzq_chunk{}; res.error_record = -1; }
-        else local_rc = 0;
-    } else if (pl.is_last) {
+        int prc = bzq_submit_shard(c, d_shard, n, pl.halo_bytes, pl.lines_before, pl.prev_last_byte, stream_pos, pl.is_last);
+        if (prc >= 0) prc = bzq_chunk_result(c, &res);
+        if (prc < 0) { note(prc); c->tail_mode = 0; res = bzq_chunk{}; res.error_record = -1; }
+    } else if (pl.is_last && !lrc) {
         res.status = BZQ_EOF;   // an empty stream
     }
+    auto install_empty = [&]() {   // a rank that delivers nothing must not hand out the batches of an earlier step
+        res = bzq_chunk{}; res.error_record = -1; res.status = BZQ_EOF;
+        c->res = res; c->have_result = true; c->pending = false;
+    };
+    if (!owner && !lrc) { const int32_t st = res.status; install_empty(); res.status = st; c->res.status = st; }
 
     // 5. outcomes
     auto gather_outcomes = [&](std::vector<int64_t>& rows) {
         const bool failed = res.status > 0 && res.status != BZQ_EOF;
         int64_t row[COMM_ROW] = {(int64_t)res.n_records, (int64_t)res.seq_bytes, (int64_t)n, failed ? res.error_record : -1, res.status,
-                                 owner && c->tail_pending && !local_rc ? 1 : 0, owner ? 1 : 0, local_rc};
+                                 owner && c->tail_pending && !lrc ? 1 : 0, owner ? 1 : 0, lrc};
         rows.assign((size_t)P * COMM_ROW, 0);
         return comm_gather(c, row, rows.data());
     };
     std::vector<int64_t> oc;
-    {
-        const std::string own_err = c->err;   // (the gather may overwrite it)
-        if ((rc = gather_outcomes(oc))) { c->tail_mode = 0; return rc; }
-        for (int r = 0; r < P; ++r)
-            if (oc[(size_t)r * COMM_ROW + 7] < 0) {   // some rank could not parse: nobody goes on (no rank is left waiting)
-                c->tail_mode = 0;
-                if (r == me) { c->err = own_err; return local_rc; }
-                c->err = "bzq_shard_stitch: rank " + std::to_string(r) + " failed (" + std::to_string(oc[(size_t)r * COMM_ROW + 7]) + ") while parsing its shard";
-                return BZQ_ERR_IO;
-            }
-    }
+    if ((rc = gather_outcomes(oc))) { c->tail_mode = 0; return rc; }
+    if ((rc = everybody_fails(oc, 7, 0, "while parsing its shard"))) return rc;
     bool walk = false;
     for (int r = 0; r < P; ++r) {
         const int64_t* w = &oc[(size_t)r * COMM_ROW];
@@ -463,44 +528,53 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
         int64_t head = 0;
         bool have = false;
         for (int round = 0; round < P; ++round) {
-            if (round == me && owner) {
+            if (round == me && owner && !lrc) {
                 if (!have) { window_start(s, c->cfg, (int64_t)total_bytes); head = (int64_t)stream_pos + c->cur_first_header; }
                 const int64_t nrec = c->h_state->P > 0 ? (c->h_state->P >> 2) : 0;   // complete records of this rank
                 std::vector<int64_t> re((size_t)std::min<int64_t>(nrec, (int64_t)res.n_records));   // the records this rank delivered
-                if (!re.empty()) HIPCHK(c, hipMemcpy(re.data(), c->o().rec_end.p, re.size() * 8, hipMemcpyDeviceToHost));
-                window_walk(s, head, re.data(), re.size(), (int64_t)stream_pos, c->cfg);
-                if (c->tail_pending) {
-                    bool acc = false; int ph = 0; int64_t cap = c->cfg.buffer_capacity;
-                    const int code = window_classify(s, head, c->cfg, res.tail_phase, c->h_state->tail_nonblank != 0, &acc, &ph, &cap);
-                    c->tail_mode = 2; c->tail_code = code; c->tail_accept = acc; c->tail_phase_dec = ph; c->tail_cap_dec = cap;
+                if (!re.empty()) note_hip(hipMemcpy(re.data(), c->o().rec_end.p, re.size() * 8, hipMemcpyDeviceToHost), "hipMemcpy(record ends)");
+                if (!lrc) {
+                    window_walk(s, head, re.data(), re.size(), (int64_t)stream_pos, c->cfg);
+                    if (c->tail_pending) {
+                        bool acc = false; int ph = 0; int64_t cap = c->cfg.buffer_capacity;
+                        const int code = window_classify(s, head, c->cfg, res.tail_phase, c->h_state->tail_nonblank != 0, &acc, &ph, &cap);
+                        c->tail_mode = 2; c->tail_code = code; c->tail_accept = acc; c->tail_phase_dec = ph; c->tail_cap_dec = cap;
+                    }
+                    st_row[0] = s.w; st_row[1] = s.end; st_row[2] = s.cap; st_row[3] = s.eof ? 1 : 0; st_row[4] = head; st_row[5] = 1;
                 }
-                st_row[0] = s.w; st_row[1] = s.end; st_row[2] = s.cap; st_row[3] = s.eof ? 1 : 0; st_row[4] = head; st_row[5] = 1;
             }
             if ((rc = comm_gather(c, st_row, st_all.data()))) { c->tail_mode = 0; return rc; }
             const int64_t* w = &st_all[(size_t)round * COMM_ROW];
             if (w[5] && round != me) { s = Window(); s.N = (int64_t)total_bytes; s.w = w[0]; s.end = w[1]; s.cap = w[2]; s.eof = w[3] != 0; head = w[4]; have = true; }
         }
-        if (owner && c->tail_mode == 2) {   // the last owner: the same chunk again, now with the decision
+        if (owner && c->tail_mode == 2 && !lrc) {   // the last owner: the same chunk again, now with the decision
             c->pending = true; c->have_result = false;
-            rc = bzq_chunk_result(c, &res);
-            if (rc < 0) { c->tail_mode = 0; return rc; }
+            if (note(bzq_chunk_result(c, &res)) < 0) { res = bzq_chunk{}; res.error_record = -1; }
         }
         if ((rc = gather_outcomes(oc))) { c->tail_mode = 0; return rc; }
+        if ((rc = everybody_fails(oc, 7, 0, "while walking the reader's window over its records"))) return rc;
     }
     c->tail_mode = 0;
 
-    // 7. everything global, derived identically on every rank
+    // 7. everything global, derived identically on every rank.  The sequential parser stops at the first failing record: the
+    // sums end there (global_records == first_error_record on a failing stream) and the ranks behind it deliver nothing.
     uint64_t acc_rec = 0;
     int last_owner = -1;
     for (int r = 0; r < P; ++r) {
         const int64_t* w = &oc[(size_t)r * COMM_ROW];
+        out->global_bytes += (uint64_t)w[2];
+        if (out->first_error_record >= 0) continue;
         if (r == me) out->records_before = acc_rec;
-        if (w[3] >= 0 && out->first_error_record < 0) { out->first_error_record = (int64_t)acc_rec + w[3]; out->error_rank = r; out->stream_status = (int32_t)w[4]; }
+        if (w[3] >= 0) { out->first_error_record = (int64_t)acc_rec + w[3]; out->error_rank = r; out->stream_status = (int32_t)w[4]; }
         acc_rec += (uint64_t)w[0];
-        out->global_records += (uint64_t)w[0]; out->global_bases += (uint64_t)w[1]; out->global_bytes += (uint64_t)w[2];
+        out->global_records += (uint64_t)w[0]; out->global_bases += (uint64_t)w[1];
         if (w[6]) last_owner = r;
     }
     if (out->first_error_record < 0) out->stream_status = last_owner >= 0 ? (int32_t)oc[(size_t)last_owner * COMM_ROW + 4] : BZQ_EOF;
+    if (out->error_rank >= 0 && me > out->error_rank) {   // behind the failing record: the sequential parser never got here
+        out->records_before = out->global_records;
+        install_empty();
+    }
     out->chunk = res;
     out->stream_pos = stream_pos;
     c->shard_totals[0] = out->global_records; c->shard_totals[1] = out->global_bases; c->shard_totals[2] = out->global_bytes;

@@ -70,12 +70,13 @@ int32_t bzq_fasta_plan_shards(const bzq_fasta_shard_summary* all, int32_t nranks
     return 0;
 }
 
+// Failures are collective, as in bzq_shard_stitch (bzq_comm.hpp): between the first and the last exchange a rank never returns
+// on its own -- its failure rides in the next gathered row (word 7) and every rank returns together behind that gather.
 int32_t bzq_fasta_shard_stitch(bzq_ctx* c, bzq_fasta* h, uint8_t* d_shard, uint64_t n, uint64_t capacity, bzq_fasta_shard_result* out) {
-    if (!h || !out || (!d_shard && n) || capacity < n) return BZQ_ERR_ARG;
+    if (!h || !out) return BZQ_ERR_ARG;
     bzq_comm* m = c ? c->comm : nullptr;
     const int P = m ? m->nranks : 1, me = m ? m->rank : 0;
     auto fail = [&](const std::string& msg, int32_t code) { bzq_fasta_set_error_(h, msg.c_str()); return code; };
-    if (m && c->device != bzq_fasta_device_(h)) return fail("bzq_fasta_shard_stitch: the communicator's ctx and the FASTA handle are on different devices", BZQ_ERR_ARG);
     auto gather = [&](const int64_t* row, int64_t* all) -> int {
         if (!m) { memcpy(all, row, COMM_ROW * 8); return 0; }
         const int rc = comm_gather(c, row, all);
@@ -85,51 +86,72 @@ int32_t bzq_fasta_shard_stitch(bzq_ctx* c, bzq_fasta* h, uint8_t* d_shard, uint6
     memset(out, 0, sizeof(*out));
     out->first_error_record = -1; out->error_rank = -1;
     int rc;
+    int lrc = 0;          // this rank's own failure so far
+    std::string lerr;     // ... and its text
+    auto note = [&](int r) { if (r < 0 && !lrc) { lrc = r; lerr = bzq_fasta_last_error(h); } return r; };
+    auto note_msg = [&](int code, const std::string& msg) { if (!lrc) { lrc = code; lerr = msg; } };
+    auto note_hip = [&](hipError_t e, const char* what) { if (e != hipSuccess) note_msg(BZQ_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e)); };
+    auto everybody_fails = [&](const std::vector<int64_t>& rows, const char* where) -> int {
+        for (int r = 0; r < P; ++r) {
+            const int64_t code = rows[(size_t)r * COMM_ROW + 7];
+            if (code >= 0) continue;
+            if (r == me && lrc) return fail(lerr, lrc);
+            return fail("bzq_fasta_shard_stitch: rank " + std::to_string(r) + " failed (" + std::to_string(code) + ") " + where, BZQ_ERR_IO);
+        }
+        return 0;
+    };
+    if ((!d_shard && n) || capacity < n) note_msg(BZQ_ERR_ARG, "bzq_fasta_shard_stitch: bad shard buffer");
+    else if (m && c->device != bzq_fasta_device_(h)) note_msg(BZQ_ERR_ARG, "bzq_fasta_shard_stitch: the communicator's ctx and the FASTA handle are on different devices");
 
-    // 1. probe + summary all-gather
-    int64_t row[COMM_ROW] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if ((rc = bzq_fasta_shard_probe_(h, d_shard, n, row))) return rc;
-    row[5] = (int64_t)(capacity - n);   // room behind the range's bytes: every rank checks every rank's halo against it
+    // 1. probe + summary all-gather: {bytes, first header, lead kind, tail open, last byte, room, -, failure}
+    int64_t row[COMM_ROW] = {0, -1, 3, -1, 10, 0, 0, 0};
+    if (!lrc && note(bzq_fasta_shard_probe_(h, d_shard, n, row)) < 0) { const int64_t empty[COMM_ROW] = {0, -1, 3, -1, 10, 0, 0, 0}; memcpy(row, empty, sizeof(row)); }
+    if (!lrc) row[5] = (int64_t)(capacity - n);   // room behind the range's bytes: every rank checks every rank's halo against it
+    row[6] = 0; row[7] = lrc;
     std::vector<int64_t> all((size_t)P * COMM_ROW);
     if ((rc = gather(row, all.data()))) return rc;
+    if ((rc = everybody_fails(all, "before the ranges were exchanged"))) return rc;
     std::vector<bzq_fasta_shard_summary> sums((size_t)P);
     for (int r = 0; r < P; ++r) {
         const int64_t* w = &all[(size_t)r * COMM_ROW];
         sums[(size_t)r] = bzq_fasta_shard_summary{(uint64_t)w[0], w[1], (int32_t)w[2], (int32_t)w[4], w[3]};
     }
 
-    // 2. plan
+    // 2. plan: a pure function of the gathered rows -- whatever it refuses, it refuses on every rank
     std::vector<bzq_fasta_shard_plan> plans((size_t)P);
     if ((rc = bzq_fasta_plan_shards(sums.data(), P, plans.data()))) return fail("bzq_fasta_shard_stitch: inconsistent shard summaries", rc);
     const bzq_fasta_shard_plan pl = plans[(size_t)me];
     out->plan = pl;
-    for (int r = 0; r < P; ++r)   // fails on ALL ranks, before anything is exchanged (a rank bailing out alone would leave its peers waiting)
+    for (int r = 0; r < P; ++r)   // fails on ALL ranks, before anything is exchanged
         if ((int64_t)plans[(size_t)r].halo_bytes > all[(size_t)r * COMM_ROW + 5])
             return fail("bzq_fasta_shard_stitch: rank " + std::to_string(r) + "'s shard buffer has no room for its halo (" + std::to_string(plans[(size_t)r].halo_bytes) +
                         " bytes behind " + std::to_string(sums[(size_t)r].n_bytes) + ", room for " + std::to_string(all[(size_t)r * COMM_ROW + 5]) + ")", BZQ_ERR_ARG);
+    if (m && P > 1 && m->kind == 2)
+        for (int r = 0; r < P; ++r)   // (the capacity is the same on every rank: all of them fail together)
+            if (plans[(size_t)r].head_bytes > m->halo_cap)
+                return fail("bzq_fasta_shard_stitch(shm): rank " + std::to_string(r) + "'s head of " + std::to_string(plans[(size_t)r].head_bytes) + " bytes exceeds the halo capacity the communicator was created with", BZQ_ERR_ARG);
 
-    // 3. heads travel to their owners
+    // 3. heads travel to their owners (an opened group is always closed; a failed copy is noted and the barriers are still met)
     if (m && P > 1) {
-        HIPCHK(c, hipSetDevice(c->device));
+        note_hip(hipSetDevice(c->device), "hipSetDevice");
         if (m->kind == 1) {
-            NCCLCHK(c, m, m->p_GroupStart());
-            if (pl.head_bytes > 0) NCCLCHK(c, m, m->p_Send(d_shard, (size_t)pl.head_bytes, NCCL_U8, pl.head_dst, m->nccl, c->stream));
-            for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
-                if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
-                    NCCLCHK(c, m, m->p_Recv(d_shard + n + plans[(size_t)q].halo_offset, (size_t)plans[(size_t)q].head_bytes, NCCL_U8, q, m->nccl, c->stream));
-            NCCLCHK(c, m, m->p_GroupEnd());
-            HIPCHK(c, hipStreamSynchronize(c->stream));   // the parse runs on the FASTA handle's stream
+            auto nccl_note = [&](int r, const char* what) { if (r != 0) note_msg(BZQ_ERR_HIP, std::string(what) + ": " + (m->p_GetErrorString ? m->p_GetErrorString(r) : "RCCL error")); return r; };
+            if (nccl_note(m->p_GroupStart(), "ncclGroupStart") == 0) {
+                if (pl.head_bytes > 0) nccl_note(m->p_Send(d_shard, (size_t)pl.head_bytes, NCCL_U8, pl.head_dst, m->nccl, c->stream), "ncclSend");
+                for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
+                    if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
+                        nccl_note(m->p_Recv(d_shard + n + plans[(size_t)q].halo_offset, (size_t)plans[(size_t)q].head_bytes, NCCL_U8, q, m->nccl, c->stream), "ncclRecv");
+                nccl_note(m->p_GroupEnd(), "ncclGroupEnd");
+            }
+            note_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize(halo)");   // the parse runs on the FASTA handle's stream
         } else {
-            for (int r = 0; r < P; ++r)   // (the capacity is the same on every rank: all of them fail together)
-                if (plans[(size_t)r].head_bytes > m->halo_cap)
-                    return fail("bzq_fasta_shard_stitch(shm): rank " + std::to_string(r) + "'s head of " + std::to_string(plans[(size_t)r].head_bytes) + " bytes exceeds the halo capacity the communicator was created with", BZQ_ERR_ARG);
-            if (pl.head_bytes > 0) HIPCHK(c, hipMemcpy(shm_halo(m, me), d_shard, (size_t)pl.head_bytes, hipMemcpyDeviceToHost));
-            if ((rc = shm_barrier(c, m))) return rc;
+            if (pl.head_bytes > 0) note_hip(hipMemcpy(shm_halo(m, me), d_shard, (size_t)pl.head_bytes, hipMemcpyDeviceToHost), "hipMemcpy(head to segment)");
+            if ((rc = shm_barrier(c, m))) return fail(c->err, rc);
             for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
                 if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
-                    HIPCHK(c, hipMemcpyAsync(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));   // (on the device before the FASTA handle's stream parses them, out of the segment before a peer overwrites it)
-            if ((rc = shm_barrier(c, m))) return rc;
+                    note_hip(hipMemcpyAsync(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync(halo)");
+            note_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize(halo)");   // (on the device before the FASTA handle's stream parses them, out of the segment before a peer overwrites it)
+            if ((rc = shm_barrier(c, m))) return fail(c->err, rc);
         }
     }
 
@@ -139,24 +161,14 @@ int32_t bzq_fasta_shard_stitch(bzq_ctx* c, bzq_fasta* h, uint8_t* d_shard, uint6
     const uint64_t region_n = owner ? n - pl.head_bytes + pl.halo_bytes : 0;
     bzq_fasta_chunk res{};
     res.status = BZQ_EOF;
-    // (a runtime failure of this rank's parse travels through the outcome gather: every rank returns, nobody is left waiting)
-    int local_rc = 0;
-    if (owner && (local_rc = bzq_fasta_parse(h, region, region_n, 1, pl.stream_pos + pl.head_bytes, 0, 0, &res)) < 0) { res = bzq_fasta_chunk{}; res.status = BZQ_EOF; }
-    else local_rc = 0;
+    if (owner && !lrc && note(bzq_fasta_parse(h, region, region_n, 1, pl.stream_pos + pl.head_bytes, 0, 0, &res)) < 0) { res = bzq_fasta_chunk{}; res.status = BZQ_EOF; }
 
-    // 5. outcomes: {records, status, headers, open record at the error (-2 none), owner, runtime failure}
+    // 5. outcomes: {records, status, headers, open record at the error (-2 none), owner, -, -, runtime failure}
     const bool failed = owner && res.status != BZQ_EOF;
-    int64_t orow[COMM_ROW] = {(int64_t)res.n_records, res.status, owner && !local_rc ? bzq_fasta_last_headers_(h) : 0, failed ? bzq_fasta_last_killed_(h) : -2, owner ? 1 : 0, local_rc, 0, 0};
+    int64_t orow[COMM_ROW] = {(int64_t)res.n_records, res.status, owner && !lrc ? bzq_fasta_last_headers_(h) : 0, failed ? bzq_fasta_last_killed_(h) : -2, owner ? 1 : 0, 0, 0, lrc};
     std::vector<int64_t> oc((size_t)P * COMM_ROW);
-    {
-        const std::string own_err = bzq_fasta_last_error(h);
-        if ((rc = gather(orow, oc.data()))) return rc;
-        for (int r = 0; r < P; ++r)
-            if (oc[(size_t)r * COMM_ROW + 5] < 0) {
-                if (r == me) return fail(own_err, local_rc);
-                return fail("bzq_fasta_shard_stitch: rank " + std::to_string(r) + " failed (" + std::to_string(oc[(size_t)r * COMM_ROW + 5]) + ") while parsing its range", BZQ_ERR_IO);
-            }
-    }
+    if ((rc = gather(orow, oc.data()))) return rc;
+    if ((rc = everybody_fails(oc, "while parsing its range"))) return rc;
     std::vector<int64_t> n_rec((size_t)P, 0);
     int err_rank = -1, prev_owner = -1;
     auto first_line_too_long = [&](int r) {   // rank r's first line (a header line) is too long: the record before it was still open
@@ -192,11 +204,12 @@ int32_t bzq_fasta_shard_stitch(bzq_ctx* c, bzq_fasta* h, uint8_t* d_shard, uint6
     // 6. cold: stream-global numbers in the error text
     if (err_rank >= 0 && out->stream_status != BZQ_BUFFER_EXCEEDED) {
         int64_t nl[2] = {0, 0};
-        if ((rc = bzq_fasta_count_newlines_(h, d_shard, n, &nl[0])) || (rc = bzq_fasta_count_newlines_(h, d_shard, pl.head_bytes, &nl[1]))) return rc;
-        int64_t lrow[COMM_ROW] = {nl[0], nl[1], 0, 0, 0, 0, 0, 0};
+        if (note(bzq_fasta_count_newlines_(h, d_shard, n, &nl[0])) >= 0) note(bzq_fasta_count_newlines_(h, d_shard, pl.head_bytes, &nl[1]));
+        int64_t lrow[COMM_ROW] = {nl[0], nl[1], 0, 0, 0, 0, 0, lrc};
         std::vector<int64_t> la((size_t)P * COMM_ROW);
         if ((rc = gather(lrow, la.data()))) return rc;
-        if (me == err_rank) {
+        if ((rc = everybody_fails(la, "while counting its lines for the error text"))) return rc;
+        if (me == err_rank) {   // (the last exchange is behind us: a failure here is this rank's alone)
             uint64_t line_base = (uint64_t)nl[1];
             for (int r = 0; r < me; ++r) line_base += (uint64_t)la[(size_t)r * COMM_ROW];
             if ((rc = bzq_fasta_parse(h, region, region_n, 1, pl.stream_pos + pl.head_bytes, line_base, out->records_before, &res))) return rc;

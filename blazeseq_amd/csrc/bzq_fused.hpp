@@ -1,15 +1,16 @@
-// bzq_fused.hpp -- single-pass version of the FASTQ batch-parse path (default mode).
+// bzq_fused.hpp -- the emit kernel of the FASTQ batch-parse path: k_fused<..., LB>.
 //
-// One launch, one read of the input: every 16 KiB tile is loaded once (coalesced 16 B/lane into
-// LDS), analysed, and its sequence / quality / id streams are gathered straight into the packed
-// FastqBatch columns.  The two cross-tile dependencies
-//   (1) the line index of the tile's first byte        -> which lines are header/seq/'+'/quality
+// The PRODUCT instantiates only LB = false: pass B of the two-pass path.  Pass A (k_tile_aggregate_h, bzq_device.hpp) and the
+// tile scan have already resolved the two cross-tile dependencies
+//   (1) the line index of the tile's first byte        -> which lines are header / sequence / '+' / quality
 //   (2) the column offsets of the tile's three streams -> where the bytes go
-// are resolved in-kernel by two decoupled look-backs over 8-byte {flag, value} granules (relaxed
-// agent-scope atomics: the data IS the flag, MI355X_MICROARCH.md "R2"), with tiles numbered by an
-// atomic ticket so a workgroup only ever waits on workgroups that have already started.  Spins are
-// bounded: on timeout the kernel flags ChunkState::lookback_timeout and the host re-runs the chunk
-// on the two-pass kernels of bzq_device.hpp (same results, one more read of the input).
+// so every 16 KiB tile is loaded (coalesced 16 B/lane into LDS and registers), analysed, and its sequence / quality / id
+// streams are scattered straight into the packed FastqBatch columns -- no waiting between workgroups.
+//
+// LB = true is the single-read look-back variant of round 1 (both dependencies resolved in-kernel by decoupled look-backs over
+// 8-byte {flag, value} granules, tiles numbered by an atomic ticket, bounded spins with a host fallback).  It is correct and
+// slower than two passes on this part (profiles/r2_single_read.md) and is compiled only into the EXPERIMENTS library
+// (experiments/csrc, `make exp`); the look-back helpers below exist for it.
 //
 // Reference semantics implemented here: see the header of bzq_device.hpp (same citations).
 #pragma once

@@ -222,6 +222,10 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
     uint32_t lbase, lext, dbase, dext;
     length_dist_tables(lbase, lext, dbase, dext);
     Bits b;
+    // The reader sees this block's payload and a few bytes of slack, nothing behind them: bits past it read as zero, so a
+    // crafted payload of endless empty non-final blocks runs into an invalid block within a few hundred bits instead of decoding
+    // on through the rest of the compressed window (zlib refuses such input in linear time as well).
+    if (comp_left > (int64_t)csize + 8) comp_left = (int64_t)csize + 8;
     b.start(comp, comp_left);
     int64_t payload_off = 0;   // bytes of the payload in front of b.base (the reader is re-based behind every stored block)
     int pos = 0;             // bytes stored so far

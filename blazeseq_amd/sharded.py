@@ -90,15 +90,23 @@ def exchange_halo(shard: torch.Tensor, n: int, plan: ShardPlan, group=None) -> N
     """Send our head to the previous owner, receive our halo behind our own bytes.
     ``shard`` is a uint8 tensor with at least n + plan.halo_bytes elements."""
     ops = []
+    # gloo moves host tensors: a device-resident shard is staged through the host (bytes to kilobytes)
+    staged = shard.is_cuda and dist.get_backend(group) == "gloo"
+    recv_buf = None
     if plan.head_dst >= 0 and plan.head_bytes > 0:
-        ops.append(dist.P2POp(dist.isend, shard[:plan.head_bytes], plan.head_dst, group))
+        head = shard[:plan.head_bytes]
+        ops.append(dist.P2POp(dist.isend, head.cpu() if staged else head, plan.head_dst, group))
     if plan.halo_src >= 0 and plan.halo_bytes > 0:
         if shard.numel() < n + plan.halo_bytes:
             raise ValueError("shard tensor has no room for the halo")
-        ops.append(dist.P2POp(dist.irecv, shard[n:n + plan.halo_bytes], plan.halo_src, group))
+        recv_buf = torch.empty(plan.halo_bytes, dtype=torch.uint8) if staged else shard[n:n + plan.halo_bytes]
+        ops.append(dist.P2POp(dist.irecv, recv_buf, plan.halo_src, group))
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    if staged and recv_buf is not None:
+        shard[n:n + plan.halo_bytes].copy_(recv_buf)
+        torch.cuda.synchronize(shard.device)   # the library's own stream reads it next
 
 
 _gather_bufs = {}
@@ -166,15 +174,16 @@ def parse_sharded(ctx, shard: torch.Tensor, n: int, stream_pos: int, group=None)
     """Full protocol for one rank on a device-resident shard.  Returns (ChunkResult, plan, totals,
     first_error_global_record)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    coll_device = "cpu" if dist.get_backend(group) == "gloo" else shard.device   # where the small gathers live
     s = ctx.shard_scan(shard.data_ptr(), n)
     local = [int(s.n_bytes), int(s.n_newlines), *[int(x) for x in s.first_nl], int(s.first_byte), int(s.last_byte)]
-    summaries = gather_summaries(local, shard.device, group)
+    summaries = gather_summaries(local, coll_device, group)
     plan = plan_shards(summaries)[rank]
     exchange_halo(shard, n, plan, group)
     is_last = all(summaries[q][0] == 0 for q in range(rank + 1, world))
     ctx.submit_shard(shard.data_ptr(), n, plan.halo_bytes, plan.lines_before, plan.prev_last_byte, stream_pos, is_last)
     res = ctx.result()
     err_local = int(res.error_record) if res.status not in (0, 6) else -1
-    totals, first_err, before = gather_outcomes(int(res.n_records), int(res.seq_bytes), n, err_local, shard.device, group)
+    totals, first_err, before = gather_outcomes(int(res.n_records), int(res.seq_bytes), n, err_local, coll_device, group)
     plan.records_before = before
     return res, plan, totals, first_err

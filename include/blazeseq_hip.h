@@ -31,6 +31,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: exactly the declarations of this header are exported (BZQ_BUILDING is set
+ * by the library's own Makefile only; a client never sees the pragma). */
+#if defined(BZQ_BUILDING) && defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 #define BZQ_ABI_VERSION 1
 
 /* FastxErrorCode, blazeseq/errors.mojo:33-68 (values are part of the ABI). */
@@ -573,6 +579,10 @@ int32_t bzq_fasta_shard_stitch(bzq_ctx* comm_ctx, bzq_fasta* h, uint8_t* d_shard
 int32_t bzq_fasta_generate_synthetic_device(bzq_fasta* h, int64_t num_reads, int64_t first, int64_t count, int32_t min_len,
                                             int32_t max_len, int32_t line_width, uint8_t* d_out, uint64_t cap,
                                             uint64_t* out_bytes);
+
+#if defined(BZQ_BUILDING) && defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

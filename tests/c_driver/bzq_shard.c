@@ -80,7 +80,11 @@ int main(int argc, char** argv) {
     if ((rc = bzq_copy_to_device(ctx, d_shard, host, n)) != 0) die(ctx, "bzq_copy_to_device", rc);
 
     bzq_shard_result res;
-    if ((rc = bzq_shard_stitch(ctx, (uint8_t*)d_shard, n, capacity, &res)) != 0) die(ctx, "bzq_shard_stitch", rc);
+    /* BZQ_SHARD_INJECT_MISALIGN=R: rank R hands in a pointer the library refuses -- a failure only that rank sees; the call
+     * must fail on EVERY rank (nobody is left waiting in an exchange) */
+    const char* inj = getenv("BZQ_SHARD_INJECT_MISALIGN");
+    uint8_t* shard_ptr = (uint8_t*)d_shard + ((inj && atoi(inj) == rank) ? 1 : 0);
+    if ((rc = bzq_shard_stitch(ctx, shard_ptr, n, capacity, &res)) != 0) die(ctx, "bzq_shard_stitch", rc);
 
     /* this rank's records, the reference's FastqBatch.get_record walk over the chunk columns (record_batch.mojo:116-150) */
     const bzq_chunk* ch = &res.chunk;

@@ -3,6 +3,7 @@
 batch count, terminal status and error text (GPU test)."""
 import os
 import subprocess
+import time
 
 import numpy as np
 import pytest
@@ -159,6 +160,9 @@ def _check_sharded_outputs(outs, data: bytes, check: bool, bufcap: int):
     assert all(m["stream_status"] == f.term_code for m in metas), ([m["stream_status"] for m in metas], f.term_code, f.term_msg)
     assert len({(m["global_records"], m["global_bases"], m["global_bytes"], m["first_error"], m["error_rank"]) for m in metas}) == 1
     assert metas[0]["global_bytes"] == len(data)
+    if metas[0]["first_error"] >= 0:   # the sequential parser stops there: the sums end there, later ranks deliver nothing
+        assert metas[0]["global_records"] == metas[0]["first_error"]
+        assert all(m["records"] == 0 and m["before"] == m["global_records"] for m in metas if m["rank"] > m["error_rank"])
     if f.term_code != 6:
         assert errors == [f.term_msg], (errors, f.term_msg)
     else:
@@ -210,3 +214,49 @@ def test_shard_protocol_over_rccl_world_1(tmp_path):
     path.write_bytes(data)
     outs = _run_ranks([[exe, "rccl", "0", "1", str(tmp_path / "id"), str(path)]])
     _check_sharded_outputs(outs, data, False, 0)
+
+
+@pytest.mark.gpu
+def test_a_failure_only_one_rank_sees_fails_the_call_on_every_rank(tmp_path):
+    """no rank returns alone between two exchanges.  Rank 1 of 3 hands bzq_shard_stitch a pointer the library
+    refuses; ranks 0 and 2 must come back with an error naming rank 1 instead of waiting for it (120 s over shm, for ever over
+    RCCL)."""
+    _build()
+    exe = os.path.join(DRV, "bzq_shard")
+    data = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(3000))
+    path = tmp_path / "in.fastq"
+    path.write_bytes(data)
+    name = f"inj{os.getpid()}"
+    env = dict(os.environ, BZQ_SHARD_INJECT_MISALIGN="1")
+    t0 = time.time()
+    procs = [subprocess.Popen([exe, "shm", str(r), "3", name, str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(3)]
+    res = [p.communicate(timeout=90) for p in procs]
+    assert time.time() - t0 < 60
+    assert [p.returncode for p in procs] == [2, 2, 2]
+    assert b"16-byte aligned" in res[1][1]
+    assert b"rank 1 failed" in res[0][1] and b"rank 1 failed" in res[2][1]
+
+
+@pytest.mark.gpu
+def test_shm_init_ignores_the_stale_segment_of_a_crashed_run(tmp_path):
+    """a fully initialised segment of the same name and shape left behind by a crashed run; rank 1 starts FIRST and
+    finds it.  It must end up on the segment rank 0 creates afterwards."""
+    import struct
+    _build()
+    exe = os.path.join(DRV, "bzq_shard")
+    data = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(1000))
+    path = tmp_path / "in.fastq"
+    path.write_bytes(data)
+    name = f"stale{os.getpid()}"
+    halo = 4 << 20
+    seg = 64 + 2 * 8 * 8 + 2 * halo
+    with open(f"/dev/shm/bzq_{name}", "wb") as f:   # ShmHeader: magic, count, gen, nranks, halo_cap, attached, go
+        f.write(struct.pack("<IIIIQII", 0x425A5131, 1, 7, 2, halo, 1, 1))
+        f.truncate(seg)
+    p1 = subprocess.Popen([exe, "shm", "1", "2", name, str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    time.sleep(1.5)
+    p0 = subprocess.Popen([exe, "shm", "0", "2", name, str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    o0, e0 = p0.communicate(timeout=120)
+    o1, e1 = p1.communicate(timeout=120)
+    assert p0.returncode == 0 and p1.returncode == 0, (e0, e1)
+    _check_sharded_outputs([o0, o1], data, False, 0)

@@ -1,0 +1,63 @@
+"""bench.py's N > 1 harness, executed on a one-GPU box: torch.distributed.run starts N ranks, all of them
+use device 0 (--ranks-on-one-gpu N), the library's shared-memory transport stands in for RCCL (which refuses two ranks on
+one GPU) and gloo carries torch's own collectives.  Every `world > 1` / `rank > 0` branch of bench.py -- shard bounds with the
+144-byte shift, communicator set-up and path agreement, warm-up agreement, config 5's workload text -- and bzq_shard_stitch
+with real neighbours run here; what stays RCCL-only is the transport itself (ncclAllGather / grouped ncclSend / ncclRecv,
+bzq_comm.hpp), covered at world 1 by tests/test_c_driver.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(nranks, extra, reads):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--ranks-on-one-gpu", str(nranks),
+           "--reads", str(reads), "--steps", "3", "--warmup", "1", "--min-seconds", "0.05"] + extra
+    r = subprocess.run(cmd, capture_output=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]   # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_bench_sharded_harness_runs_with_real_neighbours(nranks):
+    reads = 200_000
+    out = _run(nranks, [], reads)
+    assert out["n_gpus"] == nranks and out["steps"] == 3 and out["scaling"] == "weak" and out["unit"] == "GB/s"
+    assert out["metric"].startswith("FASTQ GB/s + Mrecords/s (150 bp synthetic)")
+    cfg = out["config"]
+    assert "BASELINE config 5 shard shape" in cfg["workload"] and f"{reads * nranks} reads of one synthetic stream" in cfg["workload"]
+    assert "cut 144 B into a record" in cfg["workload"]
+    assert cfg["exchange"] == "native" and cfg["parallelism"] == f"byte-range shards x{nranks}"
+    assert cfg["ranks_on_one_gpu"].startswith(f"{nranks} ranks share device 0")
+    # value = the WHOLE stream's bytes per step: records per rank x ranks x record bytes / ms_per_step
+    total_bytes = reads * nranks * cfg["record_bytes"]
+    assert abs(out["value"] - total_bytes / (out["ms_per_step"] * 1e-3) / 1e9) <= 0.01 * out["value"] + 0.01
+    assert abs(out["mrecords_per_s"] - reads * nranks / (out["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * out["mrecords_per_s"] + 0.01
+    assert "cpu_baseline" not in out and "views_mode" not in out   # N = 1 only
+    assert out["roofline"]["frac"] > 0 and out["roofline"]["launches_per_step"] >= 1
+
+
+@pytest.mark.gpu
+def test_bench_sharded_harness_torch_cross_check_and_fasta():
+    """The torch.distributed cross-check protocol (blazeseq_amd/sharded.py over gloo) and the FASTA byte-range shards through
+    the same harness."""
+    out = _run(2, ["--exchange", "torch"], 100_000)
+    assert out["n_gpus"] == 2 and out["config"]["exchange"] == "torch"
+    out = _run(3, ["--fasta"], 20_000)
+    assert out["n_gpus"] == 3 and "byte-range shards over 3 rank(s)" in out["config"]["parallelism"]
