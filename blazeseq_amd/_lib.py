@@ -223,6 +223,7 @@ SYMBOLS = {
     "bzq_fasta_parse": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint64,
                                     C.POINTER(BzqFastaChunk)]),
     "bzq_fasta_format_error": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "bzq_fasta_error_open_record": (C.c_int64, [C.c_void_p]),
     "bzq_fasta_copy_to_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bzq_bgzf_scan": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(BzqBgzfBlock), C.c_int64, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

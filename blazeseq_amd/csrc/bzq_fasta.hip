@@ -375,7 +375,7 @@ int32_t bzq_fasta_shard_scan(bzq_fasta* h, const uint8_t* d_shard, uint64_t n, b
     *out = bzq_fasta_shard_summary{(uint64_t)row[0], row[1], (int32_t)row[2], (int32_t)row[4], row[3]};
     return 0;
 }
-int64_t bzq_fasta_last_killed_(const bzq_fasta* h) { return h ? h->killed : INT64_MAX; }
+int64_t bzq_fasta_error_open_record(const bzq_fasta* h) { return h ? h->killed : INT64_MAX; }
 int64_t bzq_fasta_last_headers_(const bzq_fasta* h) { return h ? h->n_headers : 0; }
 
 int32_t bzq_fasta_format_error(bzq_fasta* h, char* buf, size_t cap) {

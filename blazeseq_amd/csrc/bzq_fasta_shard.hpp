@@ -18,7 +18,6 @@
 
 int32_t bzq_fasta_shard_probe_(bzq_fasta* h, const uint8_t* d, uint64_t n, int64_t row[5]);
 int32_t bzq_fasta_count_newlines_(bzq_fasta* h, const uint8_t* d, uint64_t n, int64_t* out);
-int64_t bzq_fasta_last_killed_(const bzq_fasta* h);
 int64_t bzq_fasta_last_headers_(const bzq_fasta* h);
 
 int32_t bzq_fasta_plan_shards(const bzq_fasta_shard_summary* all, int32_t nranks, bzq_fasta_shard_plan* out) {
@@ -165,7 +164,7 @@ int32_t bzq_fasta_shard_stitch(bzq_ctx* c, bzq_fasta* h, uint8_t* d_shard, uint6
 
     // 5. outcomes: {records, status, headers, open record at the error (-2 none), owner, -, -, runtime failure}
     const bool failed = owner && res.status != BZQ_EOF;
-    int64_t orow[COMM_ROW] = {(int64_t)res.n_records, res.status, owner && !lrc ? bzq_fasta_last_headers_(h) : 0, failed ? bzq_fasta_last_killed_(h) : -2, owner ? 1 : 0, 0, 0, lrc};
+    int64_t orow[COMM_ROW] = {(int64_t)res.n_records, res.status, owner && !lrc ? bzq_fasta_last_headers_(h) : 0, failed ? bzq_fasta_error_open_record(h) : -2, owner ? 1 : 0, 0, 0, lrc};
     std::vector<int64_t> oc((size_t)P * COMM_ROW);
     if ((rc = gather(orow, oc.data()))) return rc;
     if ((rc = everybody_fails(oc, "while parsing its range"))) return rc;

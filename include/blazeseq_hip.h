@@ -511,6 +511,11 @@ const char* bzq_fasta_last_error(const bzq_fasta* h);   /* h may be NULL: last c
  * Synchronous.  Returns 0 and fills *out also when the stream has an error (out->status); < 0 = runtime failure. */
 int32_t bzq_fasta_parse(bzq_fasta* h, const uint8_t* data, uint64_t n, int32_t is_eof, uint64_t stream_pos,
                         uint64_t line_base, uint64_t record_base, bzq_fasta_chunk* out);
+/* Diagnostic for a chunk that stopped on an error: index, within that chunk, of the record that was open when the parser
+ * stopped -- the record FastaParser.next_record (blazeseq/fasta/parser.mojo:135-170) was still assembling; -1 when the
+ * chunk's very first line failed (nothing open yet).  The byte-range shard protocol needs it to restore the sequential
+ * parser's order of events across a cut (bzq_fasta_shard_stitch). */
+int64_t bzq_fasta_error_open_record(const bzq_fasta* h);
 /* The reference's error text for the last chunk's status (errors.mojo:178-234).  Returns the length. */
 int32_t bzq_fasta_format_error(bzq_fasta* h, char* buf, size_t cap);
 int32_t bzq_fasta_copy_to_host(bzq_fasta* h, void* dst, const void* d_src, size_t bytes);

@@ -22,8 +22,8 @@ CAP = 32768
 ctx = Context()
 fas = {ca: FastaContext(FastaParserConfig(check_ascii=ca, line_capacity=CAP)) for ca in (False, True)}
 lib = L.lib()
-lib.bzq_fasta_last_killed_.restype = C.c_int64
-lib.bzq_fasta_last_killed_.argtypes = [C.c_void_p]
+lib.bzq_fasta_error_open_record.restype = C.c_int64
+lib.bzq_fasta_error_open_record.argtypes = [C.c_void_p]
 d_buf = C.c_void_p()
 DCAP = 8 << 20
 assert lib.bzq_device_alloc(ctx.h, DCAP, C.byref(d_buf)) == 0
@@ -38,7 +38,7 @@ def upload(a: np.ndarray, off: int):
 class DevFlat:
     def __init__(self, fa, res):
         self.status, self.n_records = int(res.status), int(res.n_records)
-        k = int(lib.bzq_fasta_last_killed_(fa._h))
+        k = int(lib.bzq_fasta_error_open_record(fa._h))
         self.err_record = k if self.status != 6 else -1
         ids, id_ends, seq, seq_ends, _ = fa.columns(res)
         self._cols = (ids, id_ends, seq, seq_ends)
