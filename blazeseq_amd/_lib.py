@@ -159,6 +159,11 @@ class BzqFastaShardResult(C.Structure):
                 ("error_rank", C.c_int32)]
 
 
+class BzqGzipStats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in ("pieces", "bytes_in", "bytes_consumed", "bytes_out", "chunks", "chunks_with_start", "chain_jobs",
+                                          "fallback_jobs", "members", "pool_retries")]
+
+
 FASTA_NO_HEADER, FASTA_EMPTY_SEQUENCE, FASTA_NEED_MORE = 1, 11, 12
 
 SYMBOLS = {
@@ -228,6 +233,13 @@ SYMBOLS = {
     "bzq_bgzf_scan": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(BzqBgzfBlock), C.c_int64, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "bzq_bgzf_inflate": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(BzqBgzfBlock), C.c_int64, C.c_void_p, C.c_uint64]),
+    "bzq_gzip_open": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bzq_gzip_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
+    "bzq_gzip_decode": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    "bzq_gzip_finished": (C.c_int32, [C.c_void_p]),
+    "bzq_gzip_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(BzqGzipStats)]),
+    "bzq_gzip_last_error": (C.c_char_p, [C.c_void_p]),
+    "bzq_gzip_close": (None, [C.c_void_p]),
     "bzq_fasta_plan_shards": (C.c_int32, [C.POINTER(BzqFastaShardSummary), C.c_int32, C.POINTER(BzqFastaShardPlan)]),
     "bzq_fasta_shard_scan": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(BzqFastaShardSummary)]),
     "bzq_fasta_shard_stitch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,

@@ -764,6 +764,7 @@ void sb_put(std::string& s, const char* label, long long v) {
 
 #include "bzq_consumers.hpp"
 #include "bzq_inflate.hpp"
+#include "bzq_gzip.hpp"
 #include "bzq_ingest.hpp"
 
 extern "C" {
@@ -1009,6 +1010,34 @@ int32_t bzq_bgzf_inflate(bzq_ctx* c, const uint8_t* d_comp, uint64_t comp_bytes,
     }
     return 0;
 }
+
+// ---- any gzip stream on the device (bzq_gzip.hpp) ---------------------------------------------------------------------------------
+int32_t bzq_gzip_open(bzq_ctx* c, bzq_gzip** out) {
+    if (!c || !out) return BZQ_ERR_ARG;
+    return bzq::gz::gz_open(c->device, out, c->err);
+}
+int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value) {
+    if (!h || !key) return BZQ_ERR_ARG;
+    if (!strcmp(key, "chunk_bytes")) {
+        if (value < 4096 || value > (1 << 20)) { h->err = "chunk_bytes must lie in [4096, 1 MiB]"; return BZQ_ERR_ARG; }
+        h->chunk_bytes = (int32_t)value;
+        return 0;
+    }
+    h->err = std::string("unknown option ") + key;
+    return BZQ_ERR_ARG;
+}
+int32_t bzq_gzip_decode(bzq_gzip* h, const uint8_t* comp, uint64_t n, int32_t is_last, uint8_t* d_out, uint64_t out_capacity, uint64_t* out_bytes, int32_t* more) {
+    if (!h || !out_bytes || !more || (n && !comp) || (out_capacity && !d_out)) return BZQ_ERR_ARG;
+    return bzq::gz::gz_decode(h, comp, n, is_last != 0, d_out, out_capacity, out_bytes, more);
+}
+int32_t bzq_gzip_finished(const bzq_gzip* h) { return h && h->finished ? 1 : 0; }
+int32_t bzq_gzip_get_stats(const bzq_gzip* h, bzq_gzip_stats* out) {
+    if (!h || !out) return BZQ_ERR_ARG;
+    *out = h->stats;
+    return 0;
+}
+const char* bzq_gzip_last_error(const bzq_gzip* h) { return h ? h->err.c_str() : "null handle"; }
+void bzq_gzip_close(bzq_gzip* h) { bzq::gz::gz_free(h); }
 
 int32_t bzq_device_alloc(bzq_ctx* c, size_t bytes, void** out) {
     if (!c || !out) return BZQ_ERR_ARG;

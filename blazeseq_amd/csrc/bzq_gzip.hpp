@@ -1,0 +1,847 @@
+// bzq_gzip.hpp -- ANY gzip file inflated on the GPU in parallel (C ABI bzq_gzip_*; the ingest's path for plain .gz files).
+//
+// Replaces the reference's RapidgzipReader in front of the parser (blazeseq/io/readers.mojo:380-443: `RapidgzipFile.open(path,
+// parallelism)` + read_to_buffer; the un-vendored mosafi2/rapidgzip_mojo binding of rapidgzip) -- and GZFile (readers.mojo:283-377,
+// libz gzread) for files that are not BGZF.  A gzip member is ONE DEFLATE stream (RFC 1951/1952): a block can only be decoded
+// once the Huffman tables in its header are known, and its matches reach up to 32 KiB back into whatever the stream produced
+// before it.  rapidgzip's published answer (Knespel & Brunst, HPDC '23) is speculation in two stages, and that is what runs
+// here, stage one and two on the device:
+//
+//   0. the compressed piece is cut into chunks of CH bytes.  FIND (k_gz_find, one wave per chunk): the first position in the
+//      chunk at which a DEFLATE block can start -- 64 lanes test 64 consecutive BIT offsets at once for a non-final dynamic
+//      block header whose code length code is complete (3 + 14 + up to 57 bits), survivors are validated by the whole wave
+//      (all three Huffman codes must be ones zlib accepts); byte positions are also tested for a gzip member header followed by
+//      a valid block header.  A false positive costs time, never correctness (below).
+//   1. DECODE (k_gz_decode, one wave per chunk that has a start): blocks are decoded from the chunk's start until the decoder
+//      arrives EXACTLY at a later chunk's start (a candidate it passes over without meeting it was a false positive and is
+//      dropped), through member trailers and member headers where they come.  What lies more than `pos` bytes back is not
+//      known yet, so the output is 16-bit symbols: 0..255 a byte, 0x8000 | w "the byte at index w of the 32 KiB window in
+//      front of this chunk's output" (rapidgzip's markers); markers are copied by later matches like any symbol.  Output goes
+//      to 128 KiB pages taken from a pool with one atomic (its size is unknown beforehand).
+//   2. the host walks the chain (chunk 0 starts at a known position; every chunk names the chunk it ended on), and the device
+//      finishes: CHAIN (k_gz_chain, one workgroup, sequential over the chain, ~2 us per chunk): the 32 KiB window behind every
+//      chunk from the window in front of it -- the only serial step; RESOLVE (k_gz_resolve, one workgroup per page): every
+//      symbol to its byte, contiguous in the caller's buffer; CRC (k_gz_crc): CRC-32 of every 256 KiB piece of every member,
+//      combined on the host (crc32_combine) and checked against the member trailers together with ISIZE.
+//
+// Correctness does not rest on the speculation: the chain starts at an exact position and only ever follows exact ends, so
+// what is delivered is the sequential decode; a chunk the chain never lands on is ignored.  Streams that defeat the
+// speculation (only fixed-Huffman or stored blocks: nothing to find) decode on fewer waves, in the limit on one.
+// Input that is not a valid gzip stream fails the call (BZQ_ERR_IO) -- never a parse result.
+#pragma once
+#include "bzq_inflate.hpp"
+
+namespace bzq {
+namespace gz {
+
+using inf::Code;
+using inf::U32U;
+using inf::rdlane;
+using inf::uni;
+
+constexpr int WAVES = BLOCK / 64;
+constexpr int PAGE_SHIFT = 16;
+constexpr int PAGE = 1 << PAGE_SHIFT;      // symbols per page (128 KiB of pool)
+constexpr u64 POS_NONE = ~0ull;
+constexpr uint32_t NO_PAGE = 0xFFFFFFFFu;
+constexpr int MAX_PASSED = 4;              // candidates a decoder may pass over before it gives up (a decoder fed garbage passes them all)
+
+// A position in the compressed piece: (bit offset << 1) | kind, kind 0 = a DEFLATE block header starts at that bit, kind 1 = a
+// gzip member header starts there (bit offset a multiple of 8).
+__host__ __device__ inline u64 pos_deflate(u64 bit) { return bit << 1; }
+__host__ __device__ inline u64 pos_header(u64 byte) { return (byte << 4) | 1ull; }
+
+enum : int32_t {
+    ST_EMPTY = 0,        // no start in this chunk
+    ST_TARGET = 1,       // ended exactly on the start of job `next_job`
+    ST_NEED_MORE = 2,    // the input ends inside the block / header / trailer behind `end`
+    ST_END_INPUT = 3,    // a member's trailer ended exactly at the end of the input
+    ST_BAD_HEADER = 4,   // no gzip member header at `end`
+    ST_ERROR = 5,        // invalid DEFLATE data behind `end`
+    ST_POOL_FULL = 6,
+    ST_LOST = 7,         // passed over more than MAX_PASSED candidates: stopped at the block boundary `end`
+    ST_EVENTS_FULL = 8
+};
+
+struct Job { u64 start; int32_t cand_from; int32_t pad; };
+struct JobOut {
+    u64 start, end;            // `end`: the last boundary reached (everything in front of it is decoded and stored)
+    u64 out_syms;              // symbols stored up to `end`
+    u64 err_bit;               // ST_ERROR: where the decoder stood
+    uint32_t first_page, n_pages;
+    int32_t status, next_job;
+    uint32_t n_events, passed;
+};
+struct Event { uint32_t job, seq; u64 out_syms; u64 trailer_byte; };   // a member ended: its trailer's offset in the piece
+struct Args {
+    const uint8_t* comp; int64_t n;          // the piece
+    Job* jobs; JobOut* outs;
+    int32_t job_base, n_jobs;                // this launch runs jobs [job_base, job_base + n_jobs)
+    int32_t n_cand;                          // jobs [0, n_cand) are the chunk starts every decoder compares itself with
+    int32_t chunk_bytes;
+    uint16_t* pool; uint32_t pool_pages; uint32_t* page_next;
+    uint32_t* counters;                      // [0] pages taken, [1] events taken
+    Event* events; uint32_t max_events;
+};
+
+// ---- the bit reader of one wave (cf. inf::Bits), addressed by absolute bit offset in the piece -------------------------------
+struct GBits {
+    const uint8_t* base; int64_t limit;
+    u64 buf; int cnt;
+    int next;               // next dword of the piece to enter buf
+    int win_base;
+    uint32_t win;           // lane i = dword win_base + i
+    int ran_out;            // the reader is well past the end of the input (everything it hands out now is zero bits)
+    __device__ __forceinline__ void start(const uint8_t* p, int64_t lim, int64_t bit) {
+        base = p; limit = lim; buf = 0; cnt = 0; next = (int)(bit >> 5); win_base = next - 64; win = 0; ran_out = 0;
+        refill();
+        take((int)(bit & 31));
+    }
+    __device__ __forceinline__ void refill() {
+        while (cnt <= 32) {
+            if (next - win_base >= 64) {
+                win_base = next;
+                const int64_t o = 4ll * (win_base + (int)(threadIdx.x & 63));
+                win = o + 4 <= limit ? reinterpret_cast<const U32U*>(base + o)->v
+                                     : (o < limit ? (uint32_t)base[o] | (o + 1 < limit ? (uint32_t)base[o + 1] << 8 : 0u) | (o + 2 < limit ? (uint32_t)base[o + 2] << 16 : 0u) : 0u);
+                if (4ll * win_base >= limit + 16) ran_out = 1;
+            }
+            buf |= (u64)rdlane(win, next - win_base) << cnt;
+            cnt += 32; ++next;
+        }
+        pin();
+    }
+    __device__ __forceinline__ void pin() {
+        cnt = (int)uni((uint32_t)cnt); next = (int)uni((uint32_t)next); win_base = (int)uni((uint32_t)win_base); ran_out = (int)uni((uint32_t)ran_out);
+        buf = ((u64)uni((uint32_t)(buf >> 32)) << 32) | uni((uint32_t)buf);
+    }
+    __device__ __forceinline__ uint32_t take(int n) { const uint32_t v = (uint32_t)buf & ((1u << n) - 1u); buf >>= n; cnt -= n; return v; }
+    __device__ __forceinline__ int64_t bitpos() const { return 32ll * next - cnt; }
+    __device__ __forceinline__ bool beyond() const { return ran_out || bitpos() > 8 * limit; }
+};
+
+// ---- the dynamic block header (RFC 1951 3.2.7), with zlib's validity rules ----------------------------------------------------
+// On entry the 3 header bits are consumed.  Builds both codes (and the literal/length direct table when `tables`).
+__device__ __forceinline__ bool read_dynamic(GBits& b, uint8_t* lens, uint16_t* sym_ll, uint16_t* sym_d, uint16_t* lut, Code& ll, Code& dd, bool tables) {
+    const int lane = threadIdx.x & 63;
+    b.refill();
+    const int hlit = (int)b.take(5) + 257, hdist = (int)b.take(5) + 1, hclen = (int)b.take(4) + 4;
+    if (hlit > 286 || hdist > 30) return false;
+    if (lane < 19) lens[lane] = 0;
+    for (int i = 0; i < hclen; ++i) {
+        b.refill();
+        const uint32_t v = b.take(3);
+        if (lane == 0) lens[inf::CL_ORDER[i]] = (uint8_t)v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    Code cl;
+    if (!inf::build_code(lens, 19, sym_d, cl) || !inf::code_valid(cl, false, true)) return false;
+    int n = 0;
+    uint32_t prev = 0;
+    const int total = hlit + hdist;
+    while (n < total) {
+        b.refill();
+        const int s = inf::decode_sym(b, cl, sym_d);
+        if (s < 0) return false;
+        uint32_t val = 0; int rep = 1;
+        if (s < 16) { val = (uint32_t)s; prev = val; }
+        else if (s == 16) { if (n == 0) return false; val = prev; rep = 3 + (int)b.take(2); }
+        else if (s == 17) { rep = 3 + (int)b.take(3); prev = 0; }
+        else { rep = 11 + (int)b.take(7); prev = 0; }
+        if (n + rep > total) return false;
+        for (int i = lane; i < rep; i += 64) lens[32 + n + i] = (uint8_t)val;
+        n += rep;
+        if (b.ran_out) return false;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lens[32 + 256] == 0) return false;   // no end-of-block code
+    if (!inf::build_code(lens + 32, hlit, sym_ll, ll) || !inf::code_valid(ll, false, false)) return false;
+    if (!inf::build_code(lens + 32 + hlit, hdist, sym_d, dd) || !inf::code_valid(dd, true, false)) return false;
+    if (tables) inf::build_lut(ll, sym_ll, lens + 32, lut);
+    return true;
+}
+
+// ---- gzip member header (RFC 1952 2.3) at byte B: > 0 = offset of the DEFLATE data, 0 = the input ends inside it, -1 = none ----
+__device__ __forceinline__ int64_t parse_member_header(const uint8_t* comp, int64_t n, int64_t B) {
+    const int lane = threadIdx.x & 63;
+    auto ub = [&](int64_t i) -> uint32_t { return i < n ? uni((uint32_t)comp[i]) : 0u; };
+    if (B + 2 <= n && (ub(B) != 0x1fu || ub(B + 1) != 0x8bu)) return -1;
+    if (B + 10 > n) return 0;
+    if (ub(B + 2) != 8u) return -1;
+    const uint32_t flg = ub(B + 3);
+    if (flg & 0xE0u) return -1;
+    int64_t p = B + 10;
+    if (flg & 4u) { if (p + 2 > n) return 0; p += 2 + (int64_t)(ub(p) | (ub(p + 1) << 8)); }
+    for (int f = 8; f <= 16; f <<= 1) {   // FNAME, FCOMMENT: zero terminated
+        if (!(flg & (uint32_t)f)) continue;
+        for (;;) {
+            if (p >= n) return 0;
+            const u64 m = __ballot(p + lane < n && comp[p + lane] == 0);
+            if (m) { p += __builtin_ctzll(m) + 1; break; }
+            p += 64;
+        }
+    }
+    if (flg & 2u) p += 2;
+    return p < n ? p : 0;   // (at least the first byte of the DEFLATE data must be there)
+}
+
+// ---- the decoder of one job ----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens, uint16_t* lut) {
+    const int lane = threadIdx.x & 63;
+    const Job job = a.jobs[ji];
+    JobOut o;
+    o.start = job.start; o.end = job.start; o.out_syms = 0; o.err_bit = 0; o.first_page = NO_PAGE; o.n_pages = 0; o.status = ST_EMPTY; o.next_job = -1;
+    o.n_events = 0; o.passed = 0;
+    if (job.start == POS_NONE) { if (lane == 0) a.outs[ji] = o; return; }
+
+    uint32_t lbase, lext, dbase, dext;
+    inf::length_dist_tables(lbase, lext, dbase, dext);
+    // output: stored symbols [0, opos) + ns pending literals (lane k holds the k-th)
+    int64_t opos = 0;
+    int ns = 0;
+    uint32_t mylit = 0;
+    uint16_t *cur = nullptr, *prev = nullptr;
+    int64_t cur_idx = -1;
+    uint32_t cur_page = NO_PAGE;
+    bool pool_full = false;
+    auto ensure = [&](int64_t p_end) -> bool {   // pages for positions < p_end
+        while (((p_end - 1) >> PAGE_SHIFT) > cur_idx) {
+            uint32_t np = 0;
+            if (lane == 0) np = atomicAdd(&a.counters[0], 1u);
+            np = uni(np);
+            if (np >= a.pool_pages) { pool_full = true; return false; }
+            if (lane == 0) { a.page_next[np] = NO_PAGE; if (cur_idx >= 0) a.page_next[cur_page] = np; }
+            if (cur_idx < 0) o.first_page = np;
+            prev = cur; cur = a.pool + ((size_t)np << PAGE_SHIFT); cur_page = np; ++cur_idx; ++o.n_pages;
+        }
+        return true;
+    };
+    auto at = [&](int64_t p) -> uint16_t* { return ((p >> PAGE_SHIFT) == cur_idx ? cur : prev) + (p & (PAGE - 1)); };
+    auto flush = [&]() -> bool {
+        if (ns == 0) return true;
+        if (!ensure(opos + ns)) return false;
+        if (lane < ns) *at(opos + lane) = (uint16_t)mylit;
+        opos += ns; ns = 0;
+        return true;
+    };
+
+    u64 pos = job.start;
+    int j = job.cand_from;
+    GBits b;
+    bool reader_on = false;
+    int32_t status = ST_ERROR;
+    Code ll, dd;
+    for (;;) {
+        // ---- a boundary: everything in front of `pos` is decoded
+        if (!flush()) { status = ST_POOL_FULL; break; }
+        o.end = pos; o.out_syms = (u64)opos;
+        if (pos != job.start) {
+            bool hit = false;
+            while (j < a.n_cand) {
+                const u64 s = a.jobs[j].start;
+                if (s == POS_NONE || s < pos) { if (s != POS_NONE) ++o.passed; ++j; continue; }
+                hit = s == pos;
+                break;
+            }
+            if (hit) { status = ST_TARGET; o.next_job = j; break; }
+            if (o.passed > (uint32_t)MAX_PASSED) { status = ST_LOST; break; }
+        }
+        if (pos & 1ull) {   // a member header
+            const int64_t B = (int64_t)(pos >> 4);
+            if (B >= a.n) { status = ST_END_INPUT; break; }
+            const int64_t d = parse_member_header(a.comp, a.n, B);
+            if (d < 0) { status = ST_BAD_HEADER; break; }
+            if (d == 0) { status = ST_NEED_MORE; break; }
+            pos = pos_deflate(8ull * (u64)d);
+            reader_on = false;
+            continue;
+        }
+        if (!reader_on) { b.start(a.comp, a.n, (int64_t)(pos >> 1)); reader_on = true; }
+
+        // ---- one block
+        bool ok = true;        // false: invalid data (or the input ran out: told apart below)
+        b.refill();
+        const bool last = b.take(1) != 0;
+        const uint32_t type = b.take(2);
+        if (type == 3) ok = false;
+        else if (type == 0) {   // stored: to the next byte edge, LEN, ~LEN, LEN bytes
+            b.take(b.cnt & 7);
+            b.refill();
+            const uint32_t len = b.take(16), nlen = b.take(16);
+            const int64_t src = b.bitpos() >> 3;
+            if ((len ^ nlen) != 0xFFFFu) ok = false;
+            else if (src + (int64_t)len > a.n) { ok = false; b.ran_out = 1; }
+            else {
+                if (!flush()) { status = ST_POOL_FULL; break; }
+                for (int64_t done = 0; done < (int64_t)len && !pool_full;) {
+                    const int64_t p = opos + done;
+                    const int room = PAGE - (int)(p & (PAGE - 1));
+                    const int m = (int)((int64_t)len - done < room ? (int64_t)len - done : room);
+                    if (!ensure(p + m)) break;
+                    uint16_t* dst = cur + (p & (PAGE - 1));
+                    for (int i = lane; i < m; i += 64) dst[i] = a.comp[src + done + i];
+                    done += m;
+                }
+                if (pool_full) { status = ST_POOL_FULL; break; }
+                opos += len;
+                b.start(a.comp, a.n, 8 * (src + (int64_t)len));
+            }
+        } else {
+            if (type == 1) {   // fixed code (RFC 1951 3.2.6)
+                for (int s = lane; s < 288; s += 64) lens[s] = s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8));
+                if (lane < 32) lens[288 + lane] = 5;
+                __builtin_amdgcn_wave_barrier();
+                if (!inf::build_code(lens, 288, sym_ll, ll) || !inf::build_code(lens + 288, 30, sym_d, dd)) ok = false;
+                else inf::build_lut(ll, sym_ll, lens, lut);
+            } else if (!read_dynamic(b, lens, sym_ll, sym_d, lut, ll, dd, true)) ok = false;
+            while (ok) {
+                // a run of literals through the direct table (cf. inf::inflate_block)
+                uint32_t e;
+                for (;;) {
+                    b.refill();
+                    e = uni(lut[(uint32_t)b.buf & ((1u << inf::LUT_BITS) - 1u)]);
+                    if (e & 0x100u) break;
+                    const int l = (int)(e >> 12);
+                    b.buf >>= l; b.cnt -= l;
+                    if (lane == ns) mylit = e & 0xFFu;
+                    if (++ns == 64) {
+                        if (!flush() || b.ran_out) { ok = false; break; }
+                    }
+                }
+                if (!ok) break;
+                int s;
+                if (e != inf::LUT_LONG) { s = (int)(e & 0xFFFu); const int l = (int)(e >> 12); b.buf >>= l; b.cnt -= l; }
+                else { s = inf::decode_sym(b, ll, sym_ll); if (s < 0) { ok = false; break; } }
+                if (s < 256) {   // a literal with a long code
+                    if (lane == ns) mylit = (uint32_t)s;
+                    if (++ns == 64 && (!flush() || b.ran_out)) { ok = false; break; }
+                    continue;
+                }
+                if (s == 256) break;
+                if (s > 285 || b.ran_out) { ok = false; break; }
+                const int len = (int)(rdlane(lbase, s - 257) + b.take((int)rdlane(lext, s - 257)));
+                b.refill();
+                const int ds = inf::decode_sym(b, dd, sym_d);
+                if (ds < 0 || ds > 29) { ok = false; break; }
+                const int dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));
+                if (!flush() || !ensure(opos + len)) { ok = false; break; }
+                if ((int64_t)dist > opos + 32768) { ok = false; break; }   // further back than any window
+                // out[opos + i] = out[opos - dist + i]; with dist < len the source repeats with period dist.  A source in front of
+                // this job's output is not known yet: a marker for index 32768 + (source position) of the window in front of it.
+                for (int i = lane; i < len; i += 64) {
+                    const int64_t q = opos - dist + (dist >= len ? i : i % dist);
+                    *at(opos + i) = q >= 0 ? *at(q) : (uint16_t)(0x8000u | (uint32_t)(32768 + q));
+                }
+                opos += len;
+            }
+        }
+        if (pool_full) { status = ST_POOL_FULL; break; }
+        if (!ok || b.beyond()) {   // invalid data -- unless the reader had run out of input: then the block is just not whole yet
+            status = b.beyond() ? ST_NEED_MORE : ST_ERROR;
+            o.err_bit = (u64)b.bitpos();
+            break;
+        }
+        if (!flush()) { status = ST_POOL_FULL; break; }
+        const int64_t bit = b.bitpos();
+        if (last) {   // member trailer: CRC-32 and ISIZE behind the next byte edge (checked by the host from the event)
+            const int64_t T = (bit + 7) >> 3;
+            if (T + 8 > a.n) { status = ST_NEED_MORE; break; }
+            uint32_t e = 0;
+            if (lane == 0) e = atomicAdd(&a.counters[1], 1u);
+            e = uni(e);
+            if (e >= a.max_events) { status = ST_EVENTS_FULL; break; }
+            if (lane == 0) a.events[e] = Event{(uint32_t)ji, o.n_events, (u64)opos, (u64)T};
+            ++o.n_events;
+            pos = pos_header((u64)(T + 8));
+            reader_on = false;
+        } else {
+            pos = pos_deflate((u64)bit);
+        }
+    }
+    // (on anything but a boundary exit o.end / o.out_syms still name the last boundary: what lies behind it is discarded)
+    o.status = status;
+    if (lane == 0) a.outs[ji] = o;
+}
+
+static __global__ __launch_bounds__(BLOCK) void k_gz_decode(Args a) {
+    __shared__ uint16_t s_ll[WAVES][288 + 32];
+    __shared__ uint8_t s_len[WAVES][320 + 64];
+    __shared__ __attribute__((aligned(4))) uint16_t s_lut[WAVES][1 << inf::LUT_BITS];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = (int)blockIdx.x * WAVES + wave;
+    if (k >= a.n_jobs) return;
+    run_job(a, a.job_base + k, s_ll[wave], s_ll[wave] + 288, s_len[wave], s_lut[wave]);
+}
+
+// ---- FIND: the first position in chunk c at which a block (or a member) can start ----------------------------------------------
+static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
+    __shared__ uint16_t s_ll[WAVES][288 + 32];
+    __shared__ uint8_t s_len[WAVES][320 + 64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int c = (int)blockIdx.x * WAVES + wave;
+    if (c >= a.n_cand || c == 0) return;   // (job 0 is the piece's exact start, written by the host)
+    uint16_t* sym_ll = s_ll[wave];
+    uint16_t* sym_d = s_ll[wave] + 288;
+    uint8_t* lens = s_len[wave];
+    const int64_t lo = (int64_t)c * a.chunk_bytes, hi = lo + a.chunk_bytes < a.n ? lo + a.chunk_bytes : a.n;
+    u64 found = POS_NONE;
+    for (int64_t P0 = 8 * lo; P0 < 8 * hi && found == POS_NONE; P0 += 64) {
+        const int64_t P = P0 + lane, byte = P >> 3;
+        const int sh = (int)(P & 7);
+        // 128 bits of the stream from this lane's byte on (the buffer has 64 bytes of slack behind the piece)
+        const uint32_t d0 = reinterpret_cast<const U32U*>(a.comp + byte)->v, d1 = reinterpret_cast<const U32U*>(a.comp + byte + 4)->v;
+        const uint32_t d2 = reinterpret_cast<const U32U*>(a.comp + byte + 8)->v, d3 = reinterpret_cast<const U32U*>(a.comp + byte + 12)->v;
+        const u64 lo64 = (u64)d0 | ((u64)d1 << 32), hi64 = (u64)d2 | ((u64)d3 << 32);
+        const u64 v = sh ? (lo64 >> sh) | (hi64 << (64 - sh)) : lo64, vh = hi64 >> sh;
+        // BFINAL = 0, BTYPE = 10, HLIT <= 29, HDIST <= 29, the code length code complete
+        const uint32_t hlit = (uint32_t)(v >> 3) & 31u, hdist = (uint32_t)(v >> 8) & 31u, hclen = ((uint32_t)(v >> 13) & 15u) + 4u;
+        bool dyn = ((uint32_t)v & 7u) == 4u && hlit <= 29u && hdist <= 29u && P + 17 + 3 * (int64_t)hclen <= 8 * a.n;
+        if (dyn) {
+            const u64 w = (v >> 17) | (vh << 47);
+            uint32_t kraft = 0;
+#pragma unroll
+            for (int i = 0; i < 19; ++i) {
+                const uint32_t l = (uint32_t)(w >> (3 * i)) & 7u;
+                kraft += ((uint32_t)i < hclen && l) ? (128u >> l) : 0u;
+            }
+            dyn = kraft == 128u;
+        }
+        const bool hdr = sh == 0 && (d0 & 0xFFFFFFu) == 0x088B1Fu && ((d0 >> 24) & 0xE0u) == 0 && byte + 18 <= a.n;
+        const bool in = P < 8 * hi;
+        const u64 m_dyn = __ballot(dyn && in), m_hdr = __ballot(hdr && in);
+        u64 m = m_dyn | m_hdr;
+        while (m && found == POS_NONE) {   // survivors in stream order, each judged by the whole wave
+            const int L = __builtin_ctzll(m);
+            m &= m - 1;
+            const int64_t Q = P0 + L;
+            GBits b;
+            Code ll, dd;
+            bool ok;
+            if ((m_hdr >> L) & 1ull) {
+                const int64_t dpos = parse_member_header(a.comp, a.n, Q >> 3);
+                ok = dpos > 0;
+                if (ok) {   // ... followed by a block header that can be one
+                    b.start(a.comp, a.n, 8 * dpos);
+                    b.refill();
+                    (void)b.take(1);
+                    const uint32_t type = b.take(2);
+                    if (type == 3) ok = false;
+                    else if (type == 0) { b.take(b.cnt & 7); b.refill(); const uint32_t len = b.take(16), nlen = b.take(16); ok = (len ^ nlen) == 0xFFFFu; }
+                    else if (type == 2) ok = read_dynamic(b, lens, sym_ll, sym_d, nullptr, ll, dd, false) && !b.beyond();
+                }
+                if (ok) found = pos_header((u64)(Q >> 3));
+            } else {
+                b.start(a.comp, a.n, Q + 3);
+                ok = read_dynamic(b, lens, sym_ll, sym_d, nullptr, ll, dd, false) && !b.beyond();
+                if (ok) found = pos_deflate((u64)Q);
+            }
+        }
+    }
+    if (lane == 0) a.jobs[c] = Job{found, c + 1, 0};
+}
+
+// ---- CHAIN: the window behind every chain chunk, sequentially; its tail (the last <= 32 KiB) goes out final ------------------------
+struct ChainItem { int64_t out_base, len; uint32_t page_a, page_b; };   // pages of positions len - t and len - 1, t = min(len, 32768)
+constexpr int CHAIN_THREADS = 1024;
+static __global__ __launch_bounds__(CHAIN_THREADS) void k_gz_chain(const ChainItem* items, int n_items, const uint16_t* pool, const uint8_t* w0,
+                                                                   uint8_t* out, uint8_t* w_next) {
+    __shared__ uint8_t win[2][32768];
+    const int tid = threadIdx.x;
+    for (int k = tid * 16; k < 32768; k += CHAIN_THREADS * 16) *reinterpret_cast<uint4*>(&win[0][k]) = *reinterpret_cast<const uint4*>(w0 + k);
+    __syncthreads();
+    int cur = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const ChainItem it = items[i];
+        const int t = (int)(it.len < 32768 ? it.len : 32768);
+        const int64_t first = it.len - t;
+        const uint8_t* ow = win[cur];
+        uint8_t* nw = win[cur ^ 1];
+        for (int k = tid; k < 32768 - t; k += CHAIN_THREADS) nw[k] = ow[k + t];
+        for (int k = tid; k < t; k += CHAIN_THREADS) {
+            const int64_t p = first + k;
+            const uint32_t pg = (p >> PAGE_SHIFT) == (first >> PAGE_SHIFT) ? it.page_a : it.page_b;
+            const uint32_t sym = pool[((size_t)pg << PAGE_SHIFT) + (p & (PAGE - 1))];
+            const uint8_t v = (sym & 0x8000u) ? ow[sym & 0x7FFFu] : (uint8_t)sym;
+            nw[32768 - t + k] = v;
+            out[it.out_base + p] = v;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    for (int k = tid * 16; k < 32768; k += CHAIN_THREADS * 16) *reinterpret_cast<uint4*>(w_next + k) = *reinterpret_cast<const uint4*>(&win[cur][k]);
+}
+
+// ---- RESOLVE: one page of symbols -> bytes at their final place -------------------------------------------------------------------
+struct ResItem { uint32_t page, n; int64_t dst, chunk_base; };   // symbols [0, n) of the page -> out[dst ..); the chunk's output starts at chunk_base
+struct __attribute__((packed, aligned(1))) U64U { u64 v; };
+static __global__ __launch_bounds__(BLOCK) void k_gz_resolve(const ResItem* items, const uint16_t* pool, const uint8_t* w0, uint8_t* out) {
+    const ResItem it = items[blockIdx.x];
+    const uint16_t* src = pool + ((size_t)it.page << PAGE_SHIFT);
+    auto window = [&](uint32_t w) -> uint32_t {   // byte w of the 32 KiB in front of the chunk: final output (the chain kernel wrote it) or the piece's entry window
+        const int64_t g = it.chunk_base - 32768 + (int64_t)w;
+        return g >= 0 ? out[g] : w0[32768 + g];
+    };
+    for (uint32_t k = threadIdx.x * 8u; k < it.n; k += BLOCK * 8u) {
+        if (k + 8u <= it.n) {
+            const uint4 s = *reinterpret_cast<const uint4*>(src + k);
+            const uint32_t wv[4] = {s.x, s.y, s.z, s.w};
+            u64 v = 0;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                uint32_t a0 = wv[h] & 0xFFFFu, a1 = wv[h] >> 16;
+                if (a0 & 0x8000u) a0 = window(a0 & 0x7FFFu);
+                if (a1 & 0x8000u) a1 = window(a1 & 0x7FFFu);
+                v |= (u64)(a0 | (a1 << 8)) << (16 * h);
+            }
+            reinterpret_cast<U64U*>(out + it.dst + k)->v = v;
+        } else {
+            for (uint32_t q = k; q < it.n; ++q) {
+                uint32_t a0 = src[q];
+                if (a0 & 0x8000u) a0 = window(a0 & 0x7FFFu);
+                out[it.dst + q] = (uint8_t)a0;
+            }
+        }
+    }
+}
+
+// ---- CRC-32 of out[off, off + n): one wave per segment (inf::block_crc32) -----------------------------------------------------------
+struct CrcSeg { int64_t off; int32_t n; uint32_t pad; };
+static __global__ __launch_bounds__(BLOCK) void k_gz_crc(const CrcSeg* segs, int n_segs, const uint8_t* out, uint32_t* crcs) {
+    __shared__ uint32_t s_crc_tab[256], s_x2n[32];
+    inf::crc_tables(s_crc_tab, s_x2n);
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int k = (int)blockIdx.x * WAVES + wave;
+    if (k >= n_segs) return;
+    const CrcSeg s = segs[k];
+    const uint32_t r = inf::block_crc32(out + s.off, s.n, s_crc_tab, s_x2n);
+    if ((threadIdx.x & 63) == 0) crcs[k] = r;
+}
+
+} // namespace gz
+} // namespace bzq
+
+// ================================================================================ host side
+#include <zlib.h>   // crc32_combine only: the CRCs themselves are computed on the device
+
+/* (declared in include/blazeseq_hip.h) */
+struct bzq_gzip {
+    int device = 0;
+    hipStream_t stream = nullptr;       // the stream the kernels and copies of a call run on
+    hipStream_t own_stream = nullptr;
+    std::string err;
+    int32_t chunk_bytes = 32768;        // CH: one decoder wave per this many compressed bytes
+    // device
+    struct Buf { void* p = nullptr; size_t cap = 0; };
+    Buf comp, jobs, outs, pool, page_next, counters, events, items, crcs, win[2];
+    Buf h_outs, h_events, h_pages, h_items, h_crcs;   // pinned host staging
+    uint32_t pool_pages = 0;
+    int wcur = 0;                       // win[wcur]: the 32 KiB of output in front of the next piece
+    // the stream
+    std::vector<uint8_t> carry;         // compressed bytes not consumed yet
+    unsigned long long start_pos = 1;   // where decoding resumes inside `carry`: pos_header(0), or pos_deflate(bit 0..7)
+    bool finished = false;
+    uint64_t members_done = 0;
+    uint32_t crc_run = 0;               // CRC-32 and length of the open member's output so far
+    uint64_t len_run = 0;
+    bzq_gzip_stats stats{};
+};
+
+namespace bzq {
+namespace gz {
+
+constexpr int MAX_FALLBACK = 64;   // explicit restarts per piece before the call gives up
+constexpr int32_t CRC_SEG = 256 << 10;
+
+inline int gz_fail(bzq_gzip* h, int code, const std::string& msg) { h->err = msg; return code; }
+#define GZCHK(h, call)                                                                                          \
+    do {                                                                                                        \
+        const hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess) return bzq::gz::gz_fail((h), BZQ_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+inline int gz_ensure(bzq_gzip* h, bzq_gzip::Buf& b, size_t bytes, bool pinned = false) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) { GZCHK(h, hipStreamSynchronize(h->stream)); GZCHK(h, pinned ? hipHostFree(b.p) : hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    const size_t want = bytes + bytes / 4 + 256;
+    const hipError_t e = pinned ? hipHostMalloc(&b.p, want, hipHostMallocDefault) : hipMalloc(&b.p, want);
+    if (e != hipSuccess) { b.p = nullptr; (void)hipGetLastError(); return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: cannot allocate " + std::to_string(want) + " bytes"); }
+    b.cap = want;
+    return 0;
+}
+
+inline void gz_free(bzq_gzip* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    for (bzq_gzip::Buf* b : {&h->comp, &h->jobs, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1]})
+        if (b->p) (void)hipFree(b->p);
+    for (bzq_gzip::Buf* b : {&h->h_outs, &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs})
+        if (b->p) (void)hipHostFree(b->p);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+}
+
+inline int gz_open(int device, bzq_gzip** out, std::string& err) {
+    *out = nullptr;
+    if (hipSetDevice(device) != hipSuccess) { err = "bzq_gzip_open: hipSetDevice failed"; return BZQ_ERR_HIP; }
+    bzq_gzip* h = new bzq_gzip();
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { err = "bzq_gzip_open: hipStreamCreate failed"; delete h; return BZQ_ERR_HIP; }
+    h->stream = h->own_stream;
+    int rc;
+    if ((rc = gz_ensure(h, h->win[0], 32768)) || (rc = gz_ensure(h, h->win[1], 32768)) || (rc = gz_ensure(h, h->counters, 64))) { err = h->err; gz_free(h); return rc; }
+    if (hipMemsetAsync(h->win[0].p, 0, 32768, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { err = "bzq_gzip_open: hipMemset failed"; gz_free(h); return BZQ_ERR_HIP; }
+    h->start_pos = pos_header(0);
+    *out = h;
+    return 0;
+}
+
+// The next piece of the compressed stream (host memory; pinned memory makes the copy a DMA) -> its bytes at d_out (device).
+// As many whole DEFLATE blocks as the piece holds and out_capacity takes are decoded; what is left of the piece is kept
+// inside the handle and decoded in front of the next piece.  *more = 1: the output was cut by out_capacity -- call again (n = 0
+// is fine) to get the rest.  Synchronous: on return the bytes are in d_out.
+inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_last, uint8_t* d_out, uint64_t out_cap, uint64_t* out_bytes, int32_t* more) {
+    *out_bytes = 0; *more = 0;
+    if (h->finished) return 0;   // (whatever follows the last member is ignored, like gzread does)
+    GZCHK(h, hipSetDevice(h->device));
+    const hipStream_t s = h->stream;
+    const uint64_t nc = h->carry.size(), n = nc + n_new;
+    auto byte_at = [&](uint64_t i) -> uint32_t { return i < nc ? h->carry[(size_t)i] : src[i - nc]; };
+    if (n == 0) {
+        if (is_last) {
+            if (h->members_done == 0) return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: empty input is not a gzip stream");
+            h->finished = true;
+        }
+        return 0;
+    }
+    if (n > (1ull << 33)) return gz_fail(h, BZQ_ERR_ARG, "bzq_gzip: more than 8 GiB of compressed bytes in one piece (a DEFLATE block that never ends?)");
+    int rc;
+    const int CH = h->chunk_bytes;
+    const int n_chunks = (int)((n + (uint64_t)CH - 1) / (uint64_t)CH);
+    const int n_jobs_cap = n_chunks + MAX_FALLBACK;
+    const uint32_t max_events = (uint32_t)std::min<uint64_t>(n / 18 + (uint64_t)n_chunks + 64, 1u << 28);
+    if ((rc = gz_ensure(h, h->comp, n + 64)) || (rc = gz_ensure(h, h->jobs, (size_t)n_jobs_cap * sizeof(Job))) ||
+        (rc = gz_ensure(h, h->outs, (size_t)n_jobs_cap * sizeof(JobOut))) || (rc = gz_ensure(h, h->events, (size_t)max_events * sizeof(Event))) ||
+        (rc = gz_ensure(h, h->h_outs, (size_t)n_jobs_cap * sizeof(JobOut) + 64, true)))
+        return rc;
+    uint8_t* d_comp = (uint8_t*)h->comp.p;
+    if (nc) GZCHK(h, hipMemcpyAsync(d_comp, h->carry.data(), nc, hipMemcpyHostToDevice, s));
+    if (n_new) GZCHK(h, hipMemcpyAsync(d_comp + nc, src, n_new, hipMemcpyHostToDevice, s));
+    GZCHK(h, hipMemsetAsync(d_comp + n, 0, 64, s));
+    if (nc) GZCHK(h, hipStreamSynchronize(s));   // (the carry is pageable memory: the copy is out of it before the vector changes)
+
+    JobOut* outs = (JobOut*)h->h_outs.p;
+    uint32_t* h_counters = (uint32_t*)((uint8_t*)h->h_outs.p + (size_t)n_jobs_cap * sizeof(JobOut));
+    {
+        const uint32_t want = (uint32_t)std::min<uint64_t>((n * 5) >> PAGE_SHIFT, 1u << 24) + 2u * (uint32_t)n_chunks + 64u;
+        if (h->pool_pages < want) h->pool_pages = want;
+    }
+    Args a{};
+    for (int attempt = 0;; ++attempt) {
+        if ((rc = gz_ensure(h, h->pool, ((size_t)h->pool_pages << PAGE_SHIFT) * 2)) || (rc = gz_ensure(h, h->page_next, (size_t)h->pool_pages * 4))) return rc;
+        const Job j0{h->start_pos, 1, 0};
+        GZCHK(h, hipMemsetAsync(h->counters.p, 0, 16, s));
+        GZCHK(h, hipMemcpyAsync(h->jobs.p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
+        a = Args{d_comp, (int64_t)n, (Job*)h->jobs.p, (JobOut*)h->outs.p, 0, n_chunks, n_chunks, CH, (uint16_t*)h->pool.p, h->pool_pages,
+                 (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events};
+        const unsigned grid = (unsigned)((n_chunks + WAVES - 1) / WAVES);
+        hipLaunchKernelGGL(k_gz_find, dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL(k_gz_decode, dim3(grid), dim3(BLOCK), 0, s, a);
+        GZCHK(h, hipGetLastError());
+        GZCHK(h, hipMemcpyAsync(outs, h->outs.p, (size_t)n_chunks * sizeof(JobOut), hipMemcpyDeviceToHost, s));
+        GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 16, hipMemcpyDeviceToHost, s));
+        GZCHK(h, hipStreamSynchronize(s));
+        if (h_counters[0] <= h->pool_pages) break;
+        if (attempt == 8) return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: the symbol pool keeps overflowing (" + std::to_string(h->pool_pages) + " pages)");
+        h->pool_pages = std::max<uint32_t>(2u * h->pool_pages, h_counters[0] + (uint32_t)n_chunks);   // (counts the refused requests too)
+        h->stats.pool_retries += 1;
+    }
+
+    // ---- the chain: from the piece's exact start, from every job to the job it ended on
+    std::vector<int> chain;
+    int fallbacks = 0;
+    unsigned long long final_pos = h->start_pos;
+    int32_t final_status = ST_ERROR;
+    for (int ji = 0;;) {
+        const JobOut& o = outs[ji];
+        chain.push_back(ji);
+        if (o.status == ST_TARGET) { ji = o.next_job; continue; }
+        if (o.status == ST_LOST) {   // it passed over too many (false) candidates: go on from where it stopped, with an explicit start
+            if (fallbacks == MAX_FALLBACK) return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: the stream defeats the block search (" + std::to_string(MAX_FALLBACK) + " restarts in one piece)");
+            const int k = n_chunks + fallbacks++;
+            const Job jb{o.end, (int32_t)std::min<uint64_t>((uint64_t)n_chunks, (o.end >> 4) / (uint64_t)CH), 0};
+            GZCHK(h, hipMemcpyAsync((Job*)h->jobs.p + k, &jb, sizeof jb, hipMemcpyHostToDevice, s));
+            a.job_base = k; a.n_jobs = 1;
+            hipLaunchKernelGGL(k_gz_decode, dim3(1), dim3(BLOCK), 0, s, a);
+            GZCHK(h, hipMemcpyAsync(outs + k, (JobOut*)h->outs.p + k, sizeof(JobOut), hipMemcpyDeviceToHost, s));
+            GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 16, hipMemcpyDeviceToHost, s));
+            GZCHK(h, hipStreamSynchronize(s));
+            if (outs[k].status == ST_POOL_FULL) return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: symbol pool exhausted in a restart");
+            h->stats.fallback_jobs += 1;
+            ji = k;
+            continue;
+        }
+        if (o.status == ST_ERROR)
+            return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: invalid DEFLATE data near byte " + std::to_string(h->stats.bytes_consumed + (o.err_bit >> 3)) + " of the compressed stream");
+        if (o.status == ST_POOL_FULL || o.status == ST_EMPTY) return gz_fail(h, BZQ_ERR_HIP, "bzq_gzip: internal: chain reached a job in state " + std::to_string(o.status));
+        final_status = o.status; final_pos = o.end;
+        break;
+    }
+    const int n_jobs_total = n_chunks + fallbacks;
+
+    // ---- what fits the caller's buffer
+    std::vector<int64_t> base(chain.size(), 0);
+    uint64_t total = 0;
+    size_t accepted = chain.size();
+    for (size_t i = 0; i < chain.size(); ++i) {
+        const uint64_t len = outs[chain[i]].out_syms;
+        if (total + len > out_cap) { accepted = i; break; }
+        base[i] = (int64_t)total; total += len;
+    }
+    if (accepted < chain.size()) {
+        if (accepted == 0)
+            return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: out_capacity (" + std::to_string(out_cap) + ") is below the output of one run of blocks (" + std::to_string(outs[chain[0]].out_syms) + ")");
+        final_pos = outs[chain[accepted]].start; final_status = ST_TARGET;
+        *more = 1;
+    }
+
+    // ---- members that ended inside the accepted part: (position in the output, trailer in the piece)
+    struct MemberEnd { int64_t out_pos; uint64_t trailer; size_t ci; uint32_t seq; };
+    std::vector<MemberEnd> ends;
+    const uint32_t n_events = std::min(h_counters[1], max_events);
+    if (n_events) {
+        if ((rc = gz_ensure(h, h->h_events, (size_t)n_events * sizeof(Event), true))) return rc;
+        GZCHK(h, hipMemcpyAsync(h->h_events.p, h->events.p, (size_t)n_events * sizeof(Event), hipMemcpyDeviceToHost, s));
+        GZCHK(h, hipStreamSynchronize(s));
+        std::vector<int> chain_idx((size_t)n_jobs_total, -1);
+        for (size_t i = 0; i < accepted; ++i) chain_idx[(size_t)chain[i]] = (int)i;
+        const Event* ev = (const Event*)h->h_events.p;
+        for (uint32_t e = 0; e < n_events; ++e) {
+            if ((int)ev[e].job >= n_jobs_total) continue;
+            const int ci = chain_idx[ev[e].job];
+            if (ci < 0 || ev[e].seq >= outs[ev[e].job].n_events || ev[e].out_syms > outs[ev[e].job].out_syms) continue;
+            ends.push_back(MemberEnd{base[(size_t)ci] + (int64_t)ev[e].out_syms, ev[e].trailer_byte, (size_t)ci, ev[e].seq});
+        }
+        std::sort(ends.begin(), ends.end(), [](const MemberEnd& x, const MemberEnd& y) { return x.ci != y.ci ? x.ci < y.ci : x.seq < y.seq; });
+    }
+
+    // ---- work lists: chain items, resolve items, CRC segments
+    const uint32_t pages_used = std::min(h_counters[0], h->pool_pages);
+    if ((rc = gz_ensure(h, h->h_pages, (size_t)pages_used * 4 + 16, true))) return rc;
+    if (pages_used) GZCHK(h, hipMemcpyAsync(h->h_pages.p, h->page_next.p, (size_t)pages_used * 4, hipMemcpyDeviceToHost, s));
+    GZCHK(h, hipStreamSynchronize(s));
+    const uint32_t* page_next = (const uint32_t*)h->h_pages.p;
+    std::vector<ChainItem> citems;
+    std::vector<ResItem> ritems;
+    std::vector<uint32_t> pages;
+    for (size_t i = 0; i < accepted; ++i) {
+        const JobOut& o = outs[chain[i]];
+        const int64_t len = (int64_t)o.out_syms;
+        if (len == 0) continue;
+        const int64_t np = (len + PAGE - 1) >> PAGE_SHIFT;
+        pages.clear();
+        for (uint32_t p = o.first_page; (int64_t)pages.size() < np; p = page_next[p]) {
+            if (p == NO_PAGE || p >= pages_used) return gz_fail(h, BZQ_ERR_HIP, "bzq_gzip: internal: broken page list");
+            pages.push_back(p);
+        }
+        const int64_t t = std::min<int64_t>(len, 32768);
+        citems.push_back(ChainItem{base[i], len, pages[(size_t)((len - t) >> PAGE_SHIFT)], pages[(size_t)((len - 1) >> PAGE_SHIFT)]});
+        for (int64_t pi = 0; pi * PAGE < len - t; ++pi)
+            ritems.push_back(ResItem{pages[(size_t)pi], (uint32_t)std::min<int64_t>(PAGE, len - t - pi * PAGE), base[i] + pi * PAGE, base[i]});
+    }
+    std::vector<CrcSeg> segs;
+    std::vector<int> seg_closes;   // per segment: index into `ends` of the member it closes, -1 = none
+    {
+        int64_t cur = 0;
+        auto cover = [&](int64_t to, int close) {   // [cur, to) in pieces; the last one (or an empty one) carries `close`
+            if (to == cur && close >= 0) { segs.push_back(CrcSeg{cur, 0, 0}); seg_closes.push_back(close); return; }
+            while (cur < to) {
+                const int32_t m = (int32_t)std::min<int64_t>(CRC_SEG, to - cur);
+                segs.push_back(CrcSeg{cur, m, 0});
+                cur += m;
+                seg_closes.push_back(cur == to ? close : -1);
+            }
+        };
+        for (size_t k = 0; k < ends.size(); ++k) cover(ends[k].out_pos, (int)k);
+        cover((int64_t)total, -1);
+    }
+    const size_t b_chain = citems.size() * sizeof(ChainItem), b_res = ritems.size() * sizeof(ResItem), b_seg = segs.size() * sizeof(CrcSeg);
+    const size_t o_res = (b_chain + 15) & ~(size_t)15, o_seg = (o_res + b_res + 15) & ~(size_t)15, b_all = o_seg + b_seg + 16;
+    if ((rc = gz_ensure(h, h->items, b_all)) || (rc = gz_ensure(h, h->h_items, b_all, true)) || (rc = gz_ensure(h, h->crcs, segs.size() * 4 + 16)) ||
+        (rc = gz_ensure(h, h->h_crcs, segs.size() * 4 + 16, true)))
+        return rc;
+    uint8_t* hi = (uint8_t*)h->h_items.p;
+    if (b_chain) memcpy(hi, citems.data(), b_chain);
+    if (b_res) memcpy(hi + o_res, ritems.data(), b_res);
+    if (b_seg) memcpy(hi + o_seg, segs.data(), b_seg);
+    GZCHK(h, hipMemcpyAsync(h->items.p, hi, b_all, hipMemcpyHostToDevice, s));
+    const uint8_t* w0 = (const uint8_t*)h->win[h->wcur].p;
+    uint8_t* w_next = (uint8_t*)h->win[h->wcur ^ 1].p;
+    hipLaunchKernelGGL(k_gz_chain, dim3(1), dim3(CHAIN_THREADS), 0, s, (const ChainItem*)h->items.p, (int)citems.size(), (const uint16_t*)h->pool.p, w0, d_out, w_next);
+    if (!ritems.empty())
+        hipLaunchKernelGGL(k_gz_resolve, dim3((unsigned)ritems.size()), dim3(BLOCK), 0, s, (const ResItem*)((uint8_t*)h->items.p + o_res), (const uint16_t*)h->pool.p, w0, d_out);
+    if (!segs.empty()) {
+        hipLaunchKernelGGL(k_gz_crc, dim3((unsigned)((segs.size() + WAVES - 1) / WAVES)), dim3(BLOCK), 0, s, (const CrcSeg*)((uint8_t*)h->items.p + o_seg), (int)segs.size(),
+                           (const uint8_t*)d_out, (uint32_t*)h->crcs.p);
+        GZCHK(h, hipMemcpyAsync(h->h_crcs.p, h->crcs.p, segs.size() * 4, hipMemcpyDeviceToHost, s));
+    }
+    GZCHK(h, hipGetLastError());
+    GZCHK(h, hipStreamSynchronize(s));
+    h->wcur ^= 1;
+
+    // ---- CRC-32 and ISIZE of every member that ended (RFC 1952 2.3.1)
+    const uint32_t* crcs = (const uint32_t*)h->h_crcs.p;
+    for (size_t k = 0; k < segs.size(); ++k) {
+        if (segs[k].n) {
+            h->crc_run = h->len_run ? (uint32_t)crc32_combine(h->crc_run, crcs[k], (z_off_t)segs[k].n) : crcs[k];
+            h->len_run += (uint64_t)segs[k].n;
+        }
+        if (seg_closes[k] >= 0) {
+            const uint64_t T = ends[(size_t)seg_closes[k]].trailer;
+            uint32_t crc_t = 0, isize_t = 0;
+            for (int q = 0; q < 4; ++q) { crc_t |= byte_at(T + q) << (8 * q); isize_t |= byte_at(T + 4 + q) << (8 * q); }
+            if ((h->len_run ? h->crc_run : 0u) != crc_t || (uint32_t)h->len_run != isize_t)
+                return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: member " + std::to_string(h->members_done) + " fails its " + ((uint32_t)h->len_run != isize_t ? "length" : "CRC-32") +
+                                                  " check (corrupt file)");
+            h->members_done += 1; h->crc_run = 0; h->len_run = 0;
+        }
+    }
+
+    // ---- what stays for the next call
+    const bool at_header = (final_pos & 1ull) != 0;
+    const uint64_t keep_from = at_header ? (uint64_t)(final_pos >> 4) : (uint64_t)(final_pos >> 4);   // byte of the position (bit >> 3)
+    const bool progressed = final_pos != h->start_pos || total > 0;
+    {
+        std::vector<uint8_t> nk;
+        if (keep_from < n) {
+            nk.resize((size_t)(n - keep_from));
+            size_t w = 0;
+            if (keep_from < nc) { memcpy(nk.data(), h->carry.data() + keep_from, (size_t)(nc - keep_from)); w = (size_t)(nc - keep_from); }
+            const uint64_t s0 = keep_from > nc ? keep_from - nc : 0;
+            if (n_new > s0) memcpy(nk.data() + w, src + s0, (size_t)(n_new - s0));
+        }
+        h->carry.swap(nk);
+        h->start_pos = at_header ? pos_header(0) : pos_deflate((final_pos >> 1) & 7ull);
+    }
+    h->stats.pieces += 1; h->stats.bytes_in += n_new; h->stats.bytes_consumed += keep_from; h->stats.bytes_out += total;
+    h->stats.chunks += (uint64_t)n_chunks; h->stats.chain_jobs += accepted; h->stats.members = h->members_done;
+    for (int c = 1; c < n_chunks; ++c) h->stats.chunks_with_start += outs[c].status != ST_EMPTY;
+    *out_bytes = total;
+
+    if (final_status == ST_EVENTS_FULL) *more = 1;   // (cannot happen with the event table sized as it is; call again)
+    if (*more) return 0;
+    const bool garbage = at_header && (final_status == ST_BAD_HEADER || (is_last && final_status == ST_NEED_MORE));
+    if (final_status == ST_BAD_HEADER && h->members_done == 0) return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: not a gzip stream (no member header at its start)");
+    if (garbage && h->members_done > 0) { h->finished = true; h->carry.clear(); return 0; }   // trailing bytes that are no member: ignored, like gzread
+    if (is_last) {
+        if (final_status == ST_END_INPUT) { h->finished = true; return 0; }
+        return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: unexpected end of the gzip stream (truncated file)");
+    }
+    if (!progressed && h->carry.size() > (1ull << 31)) return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: 2 GiB of compressed bytes hold no whole DEFLATE block");
+    return 0;
+}
+
+} // namespace gz
+} // namespace bzq

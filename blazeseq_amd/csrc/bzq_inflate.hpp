@@ -67,7 +67,16 @@ struct Bits {
 
 // One canonical Huffman code, spread over the lanes: lane L (1..15) holds, for the codes of length L, the left-aligned (15-bit)
 // upper bound `lim`, the first code `first` and the index of its first symbol in the sorted symbol table `offs`.
-struct Code { uint32_t lim, first, offs; int n_coded; };
+struct Code { uint32_t lim, first, offs; int n_coded; int kraft; };   // kraft: code space used, in units of 2^-15 (32768 = complete)
+
+// zlib's verdict on a set of code lengths (inflate_table, inftrees.c): over-subscribed sets are refused; an incomplete set only
+// passes as a single code of one bit (literal/length or distance code), or as no code at all (distance code of a block
+// without matches); the code length code must be complete.
+__device__ __forceinline__ bool code_valid(const Code& c, bool is_dist, bool is_precode) {
+    if (c.kraft == 32768) return true;
+    if (c.kraft > 32768 || is_precode) return false;
+    return (c.n_coded == 1 && c.kraft == 16384) || (is_dist && c.n_coded == 0);
+}
 
 // lens[0..n) (LDS, one byte per symbol, 0 = unused) -> Code + symtab (LDS).  Returns false when the lengths over-subscribe the
 // code space.  n <= 320.
@@ -93,7 +102,7 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint16_t*
         if (c + n_l > (1u << L)) over = true;
         c += n_l; o += n_l;
     }
-    code.first = first; code.offs = offs; code.lim = (lane >= 1 && lane <= 15) ? lim : 0u; code.n_coded = (int)o;
+    code.first = first; code.offs = offs; code.lim = (lane >= 1 && lane <= 15) ? lim : 0u; code.n_coded = (int)o; code.kraft = over ? 65536 : (int)c;
     // symbols sorted by (length, symbol): position = offs[length] + symbols of the same length before it
     uint32_t run = 0;        // lane L: symbols of length L placed so far
     for (int s0 = 0; s0 < n; s0 += 64) {
@@ -113,7 +122,8 @@ __device__ __forceinline__ bool build_code(const uint8_t* lens, int n, uint16_t*
 }
 
 // next symbol of `code` (uniform); -1 when the bits are no code.  Consumes its bits.
-__device__ __forceinline__ int decode_sym(Bits& b, const Code& code, const uint16_t* symtab) {
+template <class BitsT>   // (inf::Bits, or the absolute-position reader of bzq_gzip.hpp: only buf / cnt are touched)
+__device__ __forceinline__ int decode_sym(BitsT& b, const Code& code, const uint16_t* symtab) {
     const uint32_t c = __builtin_bitreverse32((uint32_t)b.buf) >> 17;
     const u64 m = __ballot(c < code.lim);
     if (!m) return -1;

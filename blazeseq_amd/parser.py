@@ -494,6 +494,50 @@ class FastqBatch:
         return [self.get_record(k) for k in range(self.num_records())]
 
 
+class GzipDecoder:
+    """bzq_gzip_*: any gzip stream inflated on the device in parallel (the reference's RapidgzipReader / GZFile,
+    blazeseq/io/readers.mojo:283-443).  A stream decoder: feed() the file piece by piece, in order."""
+
+    def __init__(self, ctx: Context, chunk_bytes: int = 0):
+        self._ctx = ctx
+        self._h = C.c_void_p()
+        _check(ctx.h, L.lib().bzq_gzip_open(ctx.h, C.byref(self._h)), "bzq_gzip_open")
+        if chunk_bytes:
+            self._gcheck(L.lib().bzq_gzip_set_option(self._h, b"chunk_bytes", chunk_bytes), "bzq_gzip_set_option")
+
+    def _gcheck(self, rc: int, what: str):
+        if rc < 0:
+            raise RuntimeError(f"{what} failed ({rc}): {(L.lib().bzq_gzip_last_error(self._h) or b'').decode('latin-1')}")
+
+    def feed(self, comp, is_last: bool, d_out: int, out_capacity: int):
+        """-> (bytes written at d_out, more): `more` = out_capacity cut the output short, call again (an empty piece is fine)."""
+        a = _as_u8(comp)
+        nb, more = C.c_uint64(), C.c_int32()
+        self._gcheck(L.lib().bzq_gzip_decode(self._h, a.ctypes.data if a.size else None, a.size, int(is_last), C.c_void_p(d_out), out_capacity,
+                                             C.byref(nb), C.byref(more)), "bzq_gzip_decode")
+        return int(nb.value), bool(more.value)
+
+    @property
+    def finished(self) -> bool:
+        return bool(L.lib().bzq_gzip_finished(self._h))
+
+    def stats(self) -> L.BzqGzipStats:
+        st = L.BzqGzipStats()
+        self._gcheck(L.lib().bzq_gzip_get_stats(self._h, C.byref(st)), "bzq_gzip_get_stats")
+        return st
+
+    def close(self):
+        if self._h:
+            L.lib().bzq_gzip_close(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Ingest:
     """bzq_ingest: file -> pinned double buffers -> device -> chunk parser (native reader threads, the H2D copy of
     chunk k+1 overlaps the consumption of chunk k).  ``next(records_taken)`` parses the next chunk; the records of

@@ -380,6 +380,47 @@ int32_t bzq_bgzf_scan(const uint8_t* comp, uint64_t n, uint64_t max_out, bzq_bgz
 int32_t bzq_bgzf_inflate(bzq_ctx* ctx, const uint8_t* d_comp, uint64_t comp_bytes, const bzq_bgzf_block* blocks, int64_t n_blocks,
                          uint8_t* d_out, uint64_t out_capacity);
 
+/* ---- any gzip stream inflated on the device, in parallel (second half) ---------------------------- */
+
+/* Replaces RapidgzipReader -- `RapidgzipFile.open(path, parallelism)` + read_to_buffer, blazeseq/io/readers.mojo:380-443 -- and
+ * GZFile (readers.mojo:283-377, libz gzopen / gzread) for gzip files that are not BGZF: single- or multi-member, any
+ * compressor, any level.  rapidgzip's two-stage speculation with both stages on the device (blazeseq_amd/csrc/bzq_gzip.hpp):
+ * the compressed piece is cut into chunks, one wave per chunk finds a block start and decodes to 16-bit symbols with window
+ * markers, the chain of chunks is followed from the piece's exact start, markers are resolved against the 32 KiB in front of
+ * every chunk, CRC-32 and ISIZE of every member are checked.  The bytes delivered are the sequential decode's (zlib's).
+ * A handle is a stream decoder like zlib's inflate: feed it the file piece by piece, in order. */
+typedef struct bzq_gzip bzq_gzip;
+
+typedef struct bzq_gzip_stats {
+    uint64_t pieces;             /* bzq_gzip_decode calls that decoded something */
+    uint64_t bytes_in;           /* compressed bytes handed in */
+    uint64_t bytes_consumed;     /* compressed bytes decoded (the rest waits inside the handle) */
+    uint64_t bytes_out;          /* bytes delivered */
+    uint64_t chunks;             /* chunks looked at by the block finder */
+    uint64_t chunks_with_start;  /* ... in which it found a start */
+    uint64_t chain_jobs;         /* decoder runs that ended up in the output (the others were speculation that did not hold) */
+    uint64_t fallback_jobs;      /* decoder runs restarted from an explicit position (the speculation had lost the thread) */
+    uint64_t members;            /* gzip members completed and verified */
+    uint64_t pool_retries;       /* pieces repeated with a larger symbol pool */
+} bzq_gzip_stats;
+
+/* A decoder on ctx's device, with a stream of its own. */
+int32_t bzq_gzip_open(bzq_ctx* ctx, bzq_gzip** out);
+/* "chunk_bytes": compressed bytes per decoder wave (default 32768; 4096 .. 1 MiB). */
+int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value);
+/* The next n compressed bytes (HOST memory; pinned memory makes the copy a DMA) -> their bytes at d_out (DEVICE memory,
+ * out_capacity bytes).  Whole DEFLATE blocks only: what is left of the piece stays inside the handle and is decoded in front of
+ * the next one.  *more = 1: out_capacity cut the output short -- call again (n = 0 is fine) for the rest.  is_last = 1 with the
+ * file's last bytes: a stream that does not end there is an error; bytes behind the last member are ignored (as gzread does).
+ * Synchronous: on return the *out_bytes bytes are in d_out.  BZQ_ERR_IO: not a valid gzip stream / CRC-32 or length mismatch
+ * (bzq_gzip_last_error says which); never wrong bytes. */
+int32_t bzq_gzip_decode(bzq_gzip* h, const uint8_t* comp, uint64_t n, int32_t is_last, uint8_t* d_out, uint64_t out_capacity,
+                        uint64_t* out_bytes, int32_t* more);
+int32_t bzq_gzip_finished(const bzq_gzip* h);   /* 1 once the stream's end has been seen */
+int32_t bzq_gzip_get_stats(const bzq_gzip* h, bzq_gzip_stats* out);
+const char* bzq_gzip_last_error(const bzq_gzip* h);
+void bzq_gzip_close(bzq_gzip* h);
+
 /* ---- host ingest pipeline ---------------------------------------------- */
 
 /* Replaces FileReader.read_to_buffer + BufferedReader._fill_buffer/_compact_from for plain files

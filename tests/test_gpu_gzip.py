@@ -1,0 +1,176 @@
+"""bzq_gzip_* (blazeseq_amd/csrc/bzq_gzip.hpp): ANY gzip stream inflated on the GPU in parallel == the bytes zlib gives.
+The checker is zlib itself -- the library behind the reference's GZFile (blazeseq/io/readers.mojo:226-377), and what
+rapidgzip's output (RapidgzipReader, readers.mojo:380-443) is defined to equal."""
+import gzip
+import zlib
+
+import numpy as np
+import pytest
+
+from blazeseq_amd.parser import Context
+from tests.fastq_fuzz import rand_stream
+from tests.gzip_util import DeviceGunzip, gzip_member
+
+pytestmark = pytest.mark.gpu
+
+
+def synthetic_fastq(n_records: int, seed: int = 5) -> bytes:
+    from oracle import oracle as O
+    return O.generate_synthetic(n_records, 150, 150, 33, 73, "generic").tobytes()
+
+
+def payloads():
+    rng = np.random.default_rng(21)
+    yield "fastq_small", rand_stream(rng, n_records=3000, max_len=150, dirty=0.0, tail=0)
+    yield "fastq_4mb", synthetic_fastq(13000)
+    yield "empty", b""
+    yield "one_byte", b"A"
+    yield "same_byte", b"G" * 700000
+    yield "period3", b"ACG" * 200000
+    yield "random", rng.integers(0, 256, 400000, dtype=np.uint8).tobytes()
+    yield "low_entropy", rng.integers(65, 69, 900000, dtype=np.uint8).tobytes()
+    yield "text", (b"the quick brown fox jumps over the lazy dog\n" * 20000)[:800001]
+    yield "far_matches", (bytes(rng.integers(0, 256, 31000, dtype=np.uint8)) * 20)
+
+
+@pytest.mark.parametrize("name,data", list(payloads()), ids=[n for n, _ in payloads()])
+def test_levels_and_strategies(name, data):
+    ctx = Context()
+    g = DeviceGunzip(ctx, len(data) + 4096, chunk_bytes=4096)
+    try:
+        for level, strategy in [(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (0, zlib.Z_DEFAULT_STRATEGY),
+                                (6, zlib.Z_FIXED), (6, zlib.Z_RLE), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_FILTERED)]:
+            comp = gzip_member(data, level, strategy)
+            g2 = DeviceGunzip(ctx, len(data) + 4096, chunk_bytes=4096)
+            got = g2.decode(comp)
+            st = g2.dec.stats()
+            g2.close()
+            assert got == data, (name, level, strategy, len(got), len(data))
+            assert st.members == 1 and st.bytes_out == len(data)
+    finally:
+        g.close()
+
+
+def test_the_speculation_is_what_runs():
+    """On an ordinary file the chunks find their own starts and the chain runs through them: many decoder waves end up in the
+    output, nothing is restarted."""
+    data = synthetic_fastq(40000)   # 12.7 MB
+    comp = gzip.compress(data, 6)
+    ctx = Context()
+    g = DeviceGunzip(ctx, len(data) + 4096)
+    assert g.decode(comp) == data
+    st = g.dec.stats()
+    g.close()
+    assert st.chain_jobs >= 20 and st.fallback_jobs == 0, (st.chain_jobs, st.fallback_jobs)
+    assert st.chunks_with_start >= st.chain_jobs - 1
+
+
+def test_header_fields_and_members():
+    rng = np.random.default_rng(3)
+    parts = [synthetic_fastq(2000), b"", rand_stream(rng, n_records=500, max_len=90, dirty=0.0, tail=0), b"x", synthetic_fastq(5000)]
+    comp = b"".join([
+        gzip_member(parts[0], 6, name=b"reads_1.fastq"),
+        gzip_member(parts[1], 6),
+        gzip_member(parts[2], 9, name=b"n" * 300, comment=b"a comment", extra=b"AB\x04\x00abcd", hcrc=True),
+        gzip_member(parts[3], 1),
+        gzip_member(parts[4], 6, flush_every=50000),
+    ])
+    want = b"".join(parts)
+    assert gzip.decompress(comp) == want
+    ctx = Context()
+    for piece in (0, 1 << 16, 70001, 999):
+        g = DeviceGunzip(ctx, len(want) + 4096, chunk_bytes=4096)
+        got = g.decode(comp, piece)
+        st = g.dec.stats()
+        g.close()
+        assert got == want, piece
+        assert st.members == 5 and g.dec.finished is not None
+
+
+def test_many_small_members_decode_in_parallel():
+    """A file of many small members that is not BGZF (no BC field): member headers are block starts like any other."""
+    data = synthetic_fastq(30000)
+    size = 60000
+    comp = b"".join(gzip_member(data[i:i + size], 6) for i in range(0, len(data), size))
+    ctx = Context()
+    g = DeviceGunzip(ctx, len(data) + 4096, chunk_bytes=8192)
+    assert g.decode(comp) == data
+    st = g.dec.stats()
+    g.close()
+    assert st.members == (len(data) + size - 1) // size
+    assert st.chain_jobs >= st.members // 4 and st.fallback_jobs == 0
+
+
+def test_pieces_and_small_output_buffers():
+    """The stream in pieces of every size (cuts inside headers, blocks, trailers), and an output buffer far smaller than the
+    output: the decoder hands over what fits and keeps the rest."""
+    data = synthetic_fastq(20000)
+    comp = gzip.compress(data, 6)
+    ctx = Context()
+    for piece, cap in [(1 << 20, 1 << 20), (100000, len(data)), (12345, 600000), (len(comp) - 3, len(data)), (len(comp) - 8, len(data))]:
+        g = DeviceGunzip(ctx, cap, chunk_bytes=4096)
+        assert g.decode(comp, piece) == data, (piece, cap)
+        g.close()
+
+
+def test_trailing_garbage_is_ignored_like_gzread_does():
+    data = synthetic_fastq(3000)
+    comp = gzip.compress(data, 6)
+    ctx = Context()
+    for junk in (b"\0" * 100, b"some text that is no gzip member", b"\x1f\x8b"):
+        g = DeviceGunzip(ctx, len(data) + 4096)
+        assert g.decode(comp + junk, 50000) == data
+        assert g.dec.finished
+        g.close()
+
+
+def test_corrupt_streams_fail_the_call():
+    data = synthetic_fastq(8000)
+    comp = bytearray(gzip.compress(data, 6))
+    ctx = Context()
+    # a flipped bit in the middle of the DEFLATE data, a wrong CRC, a wrong ISIZE, a truncated file
+    cases = {"bit_flip": bytearray(comp), "crc": bytearray(comp), "isize": bytearray(comp), "truncated": bytearray(comp[:len(comp) // 2])}
+    cases["bit_flip"][len(comp) // 2] ^= 0x10
+    cases["crc"][-6] ^= 0xFF
+    cases["isize"][-2] ^= 0x01
+    for name, bad in cases.items():
+        g = DeviceGunzip(ctx, len(data) + 4096, chunk_bytes=4096)
+        with pytest.raises(RuntimeError):
+            g.decode(bytes(bad), 200000)
+        g.close()
+    g = DeviceGunzip(ctx, 4096)
+    with pytest.raises(RuntimeError):
+        g.decode(b"this is not gzip at all, not even close" * 10)
+    g.close()
+
+
+def test_random_streams_against_zlib():
+    """300 random streams: content kinds x levels x strategies x memLevel x member splits x piece sizes x chunk sizes."""
+    rng = np.random.default_rng(77)
+    ctx = Context()
+    for it in range(300):
+        kind = it % 6
+        n = int(rng.integers(0, 400000))
+        if kind == 0:
+            data = rand_stream(rng, n_records=int(rng.integers(1, 3000)), max_len=int(rng.integers(10, 300)), dirty=0.0, tail=0)
+        elif kind == 1:
+            data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        elif kind == 2:
+            data = rng.integers(65, 65 + int(rng.integers(1, 20)), n, dtype=np.uint8).tobytes()
+        elif kind == 3:
+            unit = rng.integers(0, 256, int(rng.integers(1, 40000)), dtype=np.uint8).tobytes()
+            data = (unit * (n // max(1, len(unit)) + 1))[:n]
+        elif kind == 4:
+            data = bytes(rng.integers(0, 4, n, dtype=np.uint8) * 17 + 40)
+        else:
+            data = synthetic_fastq(int(rng.integers(1, 2500)))
+        n_members = int(rng.integers(1, 5))
+        cuts = sorted(int(x) for x in rng.integers(0, len(data) + 1, n_members - 1))
+        parts = [data[a:b] for a, b in zip([0] + cuts, cuts + [len(data)])]
+        comp = b"".join(gzip_member(p, int(rng.integers(0, 10)), int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED])),
+                                    mem_level=int(rng.integers(1, 10)), flush_every=int(rng.choice([0, 0, 30000]))) for p in parts)
+        piece = int(rng.choice([0, 1 << 16, int(rng.integers(1, len(comp) + 2))]))
+        g = DeviceGunzip(ctx, len(data) + 4096, chunk_bytes=int(rng.choice([4096, 8192, 32768])))
+        got = g.decode(comp, piece)
+        g.close()
+        assert got == data, (it, kind, len(data), n_members, piece)
