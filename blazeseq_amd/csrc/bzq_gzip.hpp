@@ -60,7 +60,8 @@ enum : int32_t {
     ST_ERROR = 5,        // invalid DEFLATE data behind `end`
     ST_POOL_FULL = 6,
     ST_LOST = 7,         // passed over more than MAX_PASSED candidates: stopped at the block boundary `end`
-    ST_EVENTS_FULL = 8
+    ST_EVENTS_FULL = 8,
+    ST_SPLIT = 9         // its output reached max_job_syms: stopped at the block boundary `end` (bounds what one job can ask of the caller's buffer)
 };
 
 struct Job { u64 start; int32_t cand_from; int32_t pad; };
@@ -82,6 +83,7 @@ struct Args {
     uint16_t* pool; uint32_t pool_pages; uint32_t* page_next;
     uint32_t* counters;                      // [0] pages taken, [1] events taken
     Event* events; uint32_t max_events;
+    int64_t max_job_syms;                    // a job stops at the first boundary at which it has stored this much
 };
 
 // ---- the bit reader of one wave (cf. inf::Bits), addressed by absolute bit offset in the piece -------------------------------
@@ -245,6 +247,7 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
             }
             if (hit) { status = ST_TARGET; o.next_job = j; break; }
             if (o.passed > (uint32_t)MAX_PASSED) { status = ST_LOST; break; }
+            if (opos >= a.max_job_syms) { status = ST_SPLIT; break; }
         }
         if (pos & 1ull) {   // a member header
             const int64_t B = (int64_t)(pos >> 4);
@@ -441,35 +444,160 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
     if (lane == 0) a.jobs[c] = Job{found, c + 1, 0};
 }
 
-// ---- CHAIN: the window behind every chain chunk, sequentially; its tail (the last <= 32 KiB) goes out final ------------------------
+// ---- CHAIN: the window behind every chain chunk; its tail (the last <= 32 KiB) goes out final ---------------------------------------
+// The window behind chunk i is a function of the window in front of it: new[k] = a byte the chunk wrote, or old[index] where it
+// wrote a marker.  Such functions compose (a table of 32768 symbols whose markers point into the OLDER window), so the chain
+// is not walked serially over all chunks: the chain is cut into groups of ~sqrt(n) chunks;
+//   pass 1 (k_gz_chain<true>, one workgroup per group, all groups at once): the composed table of the group, in LDS as 16-bit
+//          symbols, starting from the identity;
+//   pass 2 (k_gz_chain_groups, one workgroup): the window in front of every group, group table by group table;
+//   pass 3 (k_gz_chain<false>, one workgroup per group): the walk proper, from the group's true entry window, tails to the output.
 struct ChainItem { int64_t out_base, len; uint32_t page_a, page_b; };   // pages of positions len - t and len - 1, t = min(len, 32768)
 constexpr int CHAIN_THREADS = 1024;
-static __global__ __launch_bounds__(CHAIN_THREADS) void k_gz_chain(const ChainItem* items, int n_items, const uint16_t* pool, const uint8_t* w0,
-                                                                   uint8_t* out, uint8_t* w_next) {
-    __shared__ uint8_t win[2][32768];
+struct __attribute__((packed, aligned(2))) V16A2 { uint32_t w[4]; };   // 16 bytes at a 2-byte aligned address
+struct __attribute__((packed, aligned(1))) V16A1 { uint32_t w[4]; };   // 16 bytes anywhere
+template <bool SYM> struct ChainWin { typedef uint8_t T; };
+template <> struct ChainWin<true> { typedef uint16_t T; };
+
+// One step per chain chunk: thread i makes entries [32 i, 32 i + 32) of the new window -- the old window shifted by the chunk's
+// output, or (the usual case: the chunk wrote 32 KiB or more) 32 symbols of its tail, loaded as four 16-byte pieces, markers
+// looked up in the old window (LDS).  What a thread reads of an item depends on the item alone, not on the window: the symbols
+// of item i + 1 are fetched while item i is worked on.
+template <bool SYM>
+static __global__ __launch_bounds__(CHAIN_THREADS) void k_gz_chain(const ChainItem* items, int n_items, int per_group, const uint16_t* pool,
+                                                                   const uint8_t* entry_win, uint8_t* out, uint16_t* group_maps, uint8_t* w_next) {
+    typedef typename ChainWin<SYM>::T W;
+    __shared__ __attribute__((aligned(16))) W win[2][32768];
     const int tid = threadIdx.x;
-    for (int k = tid * 16; k < 32768; k += CHAIN_THREADS * 16) *reinterpret_cast<uint4*>(&win[0][k]) = *reinterpret_cast<const uint4*>(w0 + k);
+    const int k0 = tid * 32;
+    const int g = (int)blockIdx.x;
+    const int i_lo = g * per_group, i_hi = i_lo + per_group < n_items ? i_lo + per_group : n_items;
+    if (SYM) {
+        for (int k = tid; k < 32768; k += CHAIN_THREADS) win[0][k] = (W)(0x8000u | (uint32_t)k);
+    } else {
+        const uint8_t* w0 = entry_win + (size_t)g * 32768;
+        for (int k = tid * 16; k < 32768; k += CHAIN_THREADS * 16) *reinterpret_cast<uint4*>(&win[0][k]) = *reinterpret_cast<const uint4*>(w0 + k);
+    }
     __syncthreads();
     int cur = 0;
-    for (int i = 0; i < n_items; ++i) {
-        const ChainItem it = items[i];
+    struct Fetch { ChainItem it; int64_t p0; bool fast; uint32_t r[16]; };
+    auto fetch = [&](int i, Fetch& f) {
+        f.it = items[i];
+        const int t = (int)(f.it.len < 32768 ? f.it.len : 32768);
+        const int64_t first = f.it.len - t;
+        f.p0 = first + (k0 - (32768 - t));
+        f.fast = k0 >= 32768 - t && (f.p0 >> PAGE_SHIFT) == ((f.p0 + 31) >> PAGE_SHIFT);
+        if (f.fast) {
+            const uint32_t pg = (f.p0 >> PAGE_SHIFT) == (first >> PAGE_SHIFT) ? f.it.page_a : f.it.page_b;
+            const uint16_t* src = pool + ((size_t)pg << PAGE_SHIFT) + (f.p0 & (PAGE - 1));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const V16A2 v = *reinterpret_cast<const V16A2*>(src + 8 * q);
+                f.r[4 * q] = v.w[0]; f.r[4 * q + 1] = v.w[1]; f.r[4 * q + 2] = v.w[2]; f.r[4 * q + 3] = v.w[3];
+            }
+        }
+    };
+    Fetch fa, fb;
+    if (i_lo < i_hi) fetch(i_lo, fa);
+    for (int i = i_lo; i < i_hi; ++i) {
+        if (i + 1 < i_hi) fetch(i + 1, fb);
+        const ChainItem it = fa.it;
         const int t = (int)(it.len < 32768 ? it.len : 32768);
         const int64_t first = it.len - t;
-        const uint8_t* ow = win[cur];
-        uint8_t* nw = win[cur ^ 1];
-        for (int k = tid; k < 32768 - t; k += CHAIN_THREADS) nw[k] = ow[k + t];
-        for (int k = tid; k < t; k += CHAIN_THREADS) {
-            const int64_t p = first + k;
-            const uint32_t pg = (p >> PAGE_SHIFT) == (first >> PAGE_SHIFT) ? it.page_a : it.page_b;
-            const uint32_t sym = pool[((size_t)pg << PAGE_SHIFT) + (p & (PAGE - 1))];
-            const uint8_t v = (sym & 0x8000u) ? ow[sym & 0x7FFFu] : (uint8_t)sym;
-            nw[32768 - t + k] = v;
-            out[it.out_base + p] = v;
+        const int shift = 32768 - t;      // new[k] = old[k + t] for k < shift, the tail's symbol k - shift behind it
+        const W* ow = win[cur];
+        W* nw = win[cur ^ 1];
+        if (fa.fast) {
+            uint32_t a[32];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                uint32_t a0 = fa.r[q] & 0xFFFFu, a1 = fa.r[q] >> 16;
+                if (fa.r[q] & 0x80008000u) {
+                    if (a0 & 0x8000u) a0 = ow[a0 & 0x7FFFu];
+                    if (a1 & 0x8000u) a1 = ow[a1 & 0x7FFFu];
+                }
+                a[2 * q] = a0; a[2 * q + 1] = a1;
+            }
+            if (SYM) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<uint4*>(nw + k0 + 8 * q) = uint4{a[8 * q] | (a[8 * q + 1] << 16), a[8 * q + 2] | (a[8 * q + 3] << 16),
+                                                                       a[8 * q + 4] | (a[8 * q + 5] << 16), a[8 * q + 6] | (a[8 * q + 7] << 16)};
+            } else {
+                uint32_t o8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) o8[q] = a[4 * q] | (a[4 * q + 1] << 8) | (a[4 * q + 2] << 16) | (a[4 * q + 3] << 24);
+                *reinterpret_cast<uint4*>(nw + k0) = uint4{o8[0], o8[1], o8[2], o8[3]};
+                *reinterpret_cast<uint4*>(nw + k0 + 16) = uint4{o8[4], o8[5], o8[6], o8[7]};
+                uint8_t* dst = out + it.out_base + fa.p0;
+                *reinterpret_cast<V16A1*>(dst) = V16A1{{o8[0], o8[1], o8[2], o8[3]}};
+                *reinterpret_cast<V16A1*>(dst + 16) = V16A1{{o8[4], o8[5], o8[6], o8[7]}};
+            }
+        } else {
+            for (int k = k0; k < k0 + 32; ++k) {
+                if (k < shift) { nw[k] = ow[k + t]; continue; }
+                const int64_t p = first + (k - shift);
+                const uint32_t pg = (p >> PAGE_SHIFT) == (first >> PAGE_SHIFT) ? it.page_a : it.page_b;
+                const uint32_t sym = pool[((size_t)pg << PAGE_SHIFT) + (p & (PAGE - 1))];
+                const W v = (sym & 0x8000u) ? ow[sym & 0x7FFFu] : (W)sym;
+                nw[k] = v;
+                if (!SYM) out[it.out_base + p] = (uint8_t)v;
+            }
         }
         __syncthreads();
         cur ^= 1;
+        fa = fb;
     }
-    for (int k = tid * 16; k < 32768; k += CHAIN_THREADS * 16) *reinterpret_cast<uint4*>(w_next + k) = *reinterpret_cast<const uint4*>(&win[cur][k]);
+    if (SYM) {
+        uint16_t* dst = group_maps + (size_t)g * 32768;
+        for (int k = tid * 8; k < 32768; k += CHAIN_THREADS * 8) *reinterpret_cast<uint4*>(dst + k) = *reinterpret_cast<const uint4*>(&win[cur][k]);
+    } else if (i_hi == n_items) {   // the last group (or the only one): the window in front of the next piece
+        for (int k = tid * 16; k < 32768; k += CHAIN_THREADS * 16) *reinterpret_cast<uint4*>(w_next + k) = *reinterpret_cast<const uint4*>(&win[cur][k]);
+    }
+}
+
+// pass 2: entry_win[g] = the window in front of group g, from w0 through the groups' composed tables
+static __global__ __launch_bounds__(CHAIN_THREADS) void k_gz_chain_groups(const uint16_t* group_maps, int n_groups, const uint8_t* w0, uint8_t* entry_win) {
+    __shared__ __attribute__((aligned(16))) uint8_t win[2][32768];
+    const int tid = threadIdx.x;
+    const int k0 = tid * 32;
+    for (int k = tid * 16; k < 32768; k += CHAIN_THREADS * 16) *reinterpret_cast<uint4*>(&win[0][k]) = *reinterpret_cast<const uint4*>(w0 + k);
+    __syncthreads();
+    int cur = 0;
+    uint4 ra[4], rb[4];
+    auto fetch = [&](int g, uint4* r) {
+        const uint4* src = reinterpret_cast<const uint4*>(group_maps + (size_t)g * 32768 + k0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) r[q] = src[q];
+    };
+    if (n_groups > 0) fetch(0, ra);
+    for (int g = 0; g < n_groups; ++g) {
+        if (g + 1 < n_groups) fetch(g + 1, rb);
+        const uint8_t* ow = win[cur];
+        uint8_t* nw = win[cur ^ 1];
+        uint8_t* ew = entry_win + (size_t)g * 32768;
+        *reinterpret_cast<uint4*>(ew + k0) = *reinterpret_cast<const uint4*>(ow + k0);
+        *reinterpret_cast<uint4*>(ew + k0 + 16) = *reinterpret_cast<const uint4*>(ow + k0 + 16);
+        const uint32_t r[16] = {ra[0].x, ra[0].y, ra[0].z, ra[0].w, ra[1].x, ra[1].y, ra[1].z, ra[1].w, ra[2].x, ra[2].y, ra[2].z, ra[2].w, ra[3].x, ra[3].y, ra[3].z, ra[3].w};
+        uint32_t o8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            uint32_t a0 = r[2 * q] & 0xFFFFu, a1 = r[2 * q] >> 16, a2 = r[2 * q + 1] & 0xFFFFu, a3 = r[2 * q + 1] >> 16;
+            if ((r[2 * q] | r[2 * q + 1]) & 0x80008000u) {
+                if (a0 & 0x8000u) a0 = ow[a0 & 0x7FFFu];
+                if (a1 & 0x8000u) a1 = ow[a1 & 0x7FFFu];
+                if (a2 & 0x8000u) a2 = ow[a2 & 0x7FFFu];
+                if (a3 & 0x8000u) a3 = ow[a3 & 0x7FFFu];
+            }
+            o8[q] = a0 | (a1 << 8) | (a2 << 16) | (a3 << 24);
+        }
+        *reinterpret_cast<uint4*>(nw + k0) = uint4{o8[0], o8[1], o8[2], o8[3]};
+        *reinterpret_cast<uint4*>(nw + k0 + 16) = uint4{o8[4], o8[5], o8[6], o8[7]};
+        __syncthreads();
+        cur ^= 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ra[q] = rb[q];
+    }
 }
 
 // ---- RESOLVE: one page of symbols -> bytes at their final place -------------------------------------------------------------------
@@ -523,6 +651,10 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_crc(const CrcSeg* segs, int
 } // namespace bzq
 
 // ================================================================================ host side
+#include <algorithm>
+#include <chrono>
+#include <string>
+#include <vector>
 #include <zlib.h>   // crc32_combine only: the CRCs themselves are computed on the device
 
 /* (declared in include/blazeseq_hip.h) */
@@ -531,10 +663,10 @@ struct bzq_gzip {
     hipStream_t stream = nullptr;       // the stream the kernels and copies of a call run on
     hipStream_t own_stream = nullptr;
     std::string err;
-    int32_t chunk_bytes = 32768;        // CH: one decoder wave per this many compressed bytes
+    int32_t chunk_bytes = 16384;        // CH: one decoder wave per this many compressed bytes (zlib closes a block every ~20 KiB of FASTQ output stream)
     // device
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf comp, jobs, outs, pool, page_next, counters, events, items, crcs, win[2];
+    Buf comp, jobs, outs, pool, page_next, counters, events, items, crcs, win[2], chain_maps, chain_wins;
     Buf h_outs, h_events, h_pages, h_items, h_crcs;   // pinned host staging
     uint32_t pool_pages = 0;
     int wcur = 0;                       // win[wcur]: the 32 KiB of output in front of the next piece
@@ -552,7 +684,7 @@ namespace bzq {
 namespace gz {
 
 constexpr int MAX_FALLBACK = 64;   // explicit restarts per piece before the call gives up
-constexpr int32_t CRC_SEG = 256 << 10;
+constexpr int32_t CRC_SEG = 1 << 20;
 
 inline int gz_fail(bzq_gzip* h, int code, const std::string& msg) { h->err = msg; return code; }
 #define GZCHK(h, call)                                                                                          \
@@ -575,7 +707,7 @@ inline void gz_free(bzq_gzip* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    for (bzq_gzip::Buf* b : {&h->comp, &h->jobs, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1]})
+    for (bzq_gzip::Buf* b : {&h->comp, &h->jobs, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
         if (b->p) (void)hipFree(b->p);
     for (bzq_gzip::Buf* b : {&h->h_outs, &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs})
         if (b->p) (void)hipHostFree(b->p);
@@ -618,6 +750,10 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     }
     if (n > (1ull << 33)) return gz_fail(h, BZQ_ERR_ARG, "bzq_gzip: more than 8 GiB of compressed bytes in one piece (a DEFLATE block that never ends?)");
     int rc;
+    static const bool timing = getenv("BZQ_GZ_TIMING") != nullptr;   // debug: phase times of every call on stderr
+    auto t_prev = std::chrono::steady_clock::now();
+    double t_ph[8] = {0};
+    auto lap = [&](int k) { if (timing) { const auto t = std::chrono::steady_clock::now(); t_ph[k] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; } };
     const int CH = h->chunk_bytes;
     const int n_chunks = (int)((n + (uint64_t)CH - 1) / (uint64_t)CH);
     const int n_jobs_cap = n_chunks + MAX_FALLBACK;
@@ -630,7 +766,8 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     if (nc) GZCHK(h, hipMemcpyAsync(d_comp, h->carry.data(), nc, hipMemcpyHostToDevice, s));
     if (n_new) GZCHK(h, hipMemcpyAsync(d_comp + nc, src, n_new, hipMemcpyHostToDevice, s));
     GZCHK(h, hipMemsetAsync(d_comp + n, 0, 64, s));
-    if (nc) GZCHK(h, hipStreamSynchronize(s));   // (the carry is pageable memory: the copy is out of it before the vector changes)
+    if (nc || timing) GZCHK(h, hipStreamSynchronize(s));   // (the carry is pageable memory: the copy is out of it before the vector changes)
+    lap(0);
 
     JobOut* outs = (JobOut*)h->h_outs.p;
     uint32_t* h_counters = (uint32_t*)((uint8_t*)h->h_outs.p + (size_t)n_jobs_cap * sizeof(JobOut));
@@ -638,6 +775,8 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         const uint32_t want = (uint32_t)std::min<uint64_t>((n * 5) >> PAGE_SHIFT, 1u << 24) + 2u * (uint32_t)n_chunks + 64u;
         if (h->pool_pages < want) h->pool_pages = want;
     }
+    // one job's output is bounded (it must fit the caller's buffer whole): a quarter of the buffer, 64 KiB .. 16 MiB
+    const int64_t max_job = (int64_t)std::min<uint64_t>(16ull << 20, std::max<uint64_t>(64ull << 10, out_cap / 4));
     Args a{};
     for (int attempt = 0;; ++attempt) {
         if ((rc = gz_ensure(h, h->pool, ((size_t)h->pool_pages << PAGE_SHIFT) * 2)) || (rc = gz_ensure(h, h->page_next, (size_t)h->pool_pages * 4))) return rc;
@@ -645,14 +784,16 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         GZCHK(h, hipMemsetAsync(h->counters.p, 0, 16, s));
         GZCHK(h, hipMemcpyAsync(h->jobs.p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
         a = Args{d_comp, (int64_t)n, (Job*)h->jobs.p, (JobOut*)h->outs.p, 0, n_chunks, n_chunks, CH, (uint16_t*)h->pool.p, h->pool_pages,
-                 (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events};
+                 (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events, max_job};
         const unsigned grid = (unsigned)((n_chunks + WAVES - 1) / WAVES);
         hipLaunchKernelGGL(k_gz_find, dim3(grid), dim3(BLOCK), 0, s, a);
+        if (timing) { GZCHK(h, hipStreamSynchronize(s)); lap(1); }
         hipLaunchKernelGGL(k_gz_decode, dim3(grid), dim3(BLOCK), 0, s, a);
         GZCHK(h, hipGetLastError());
         GZCHK(h, hipMemcpyAsync(outs, h->outs.p, (size_t)n_chunks * sizeof(JobOut), hipMemcpyDeviceToHost, s));
         GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 16, hipMemcpyDeviceToHost, s));
         GZCHK(h, hipStreamSynchronize(s));
+        lap(2);
         if (h_counters[0] <= h->pool_pages) break;
         if (attempt == 8) return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: the symbol pool keeps overflowing (" + std::to_string(h->pool_pages) + " pages)");
         h->pool_pages = std::max<uint32_t>(2u * h->pool_pages, h_counters[0] + (uint32_t)n_chunks);   // (counts the refused requests too)
@@ -668,8 +809,11 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         const JobOut& o = outs[ji];
         chain.push_back(ji);
         if (o.status == ST_TARGET) { ji = o.next_job; continue; }
-        if (o.status == ST_LOST) {   // it passed over too many (false) candidates: go on from where it stopped, with an explicit start
-            if (fallbacks == MAX_FALLBACK) return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: the stream defeats the block search (" + std::to_string(MAX_FALLBACK) + " restarts in one piece)");
+        if (o.status == ST_LOST || o.status == ST_SPLIT) {
+            // it passed over too many (false) candidates, or its output reached the bound: go on from where it stopped, with an
+            // explicit start.  A stream without findable block starts (fixed-Huffman or stored blocks only) proceeds like this,
+            // serially; after MAX_FALLBACK restarts the call hands over what it has (*more).
+            if (fallbacks == MAX_FALLBACK) { final_status = ST_SPLIT; final_pos = o.end; break; }
             const int k = n_chunks + fallbacks++;
             const Job jb{o.end, (int32_t)std::min<uint64_t>((uint64_t)n_chunks, (o.end >> 4) / (uint64_t)CH), 0};
             GZCHK(h, hipMemcpyAsync((Job*)h->jobs.p + k, &jb, sizeof jb, hipMemcpyHostToDevice, s));
@@ -776,12 +920,31 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     if (b_chain) memcpy(hi, citems.data(), b_chain);
     if (b_res) memcpy(hi + o_res, ritems.data(), b_res);
     if (b_seg) memcpy(hi + o_seg, segs.data(), b_seg);
+    lap(3);
     GZCHK(h, hipMemcpyAsync(h->items.p, hi, b_all, hipMemcpyHostToDevice, s));
     const uint8_t* w0 = (const uint8_t*)h->win[h->wcur].p;
     uint8_t* w_next = (uint8_t*)h->win[h->wcur ^ 1].p;
-    hipLaunchKernelGGL(k_gz_chain, dim3(1), dim3(CHAIN_THREADS), 0, s, (const ChainItem*)h->items.p, (int)citems.size(), (const uint16_t*)h->pool.p, w0, d_out, w_next);
+    {
+        const int n_it = (int)citems.size();
+        int per_group = 16;
+        while (per_group * per_group < n_it) per_group += 8;
+        const int n_groups = n_it ? (n_it + per_group - 1) / per_group : 1;
+        const ChainItem* d_items = (const ChainItem*)h->items.p;
+        if (n_groups <= 1) {
+            hipLaunchKernelGGL(k_gz_chain<false>, dim3(1), dim3(CHAIN_THREADS), 0, s, d_items, n_it, std::max(1, n_it), (const uint16_t*)h->pool.p, w0, d_out, (uint16_t*)nullptr, w_next);
+        } else {
+            if ((rc = gz_ensure(h, h->chain_maps, (size_t)n_groups * 65536)) || (rc = gz_ensure(h, h->chain_wins, (size_t)n_groups * 32768))) return rc;
+            hipLaunchKernelGGL(k_gz_chain<true>, dim3((unsigned)n_groups), dim3(CHAIN_THREADS), 0, s, d_items, n_it, per_group, (const uint16_t*)h->pool.p, (const uint8_t*)nullptr, (uint8_t*)nullptr,
+                               (uint16_t*)h->chain_maps.p, (uint8_t*)nullptr);
+            hipLaunchKernelGGL(k_gz_chain_groups, dim3(1), dim3(CHAIN_THREADS), 0, s, (const uint16_t*)h->chain_maps.p, n_groups, w0, (uint8_t*)h->chain_wins.p);
+            hipLaunchKernelGGL(k_gz_chain<false>, dim3((unsigned)n_groups), dim3(CHAIN_THREADS), 0, s, d_items, n_it, per_group, (const uint16_t*)h->pool.p, (const uint8_t*)h->chain_wins.p, d_out,
+                               (uint16_t*)nullptr, w_next);
+        }
+    }
+    if (timing) { GZCHK(h, hipStreamSynchronize(s)); lap(4); }
     if (!ritems.empty())
         hipLaunchKernelGGL(k_gz_resolve, dim3((unsigned)ritems.size()), dim3(BLOCK), 0, s, (const ResItem*)((uint8_t*)h->items.p + o_res), (const uint16_t*)h->pool.p, w0, d_out);
+    if (timing) { GZCHK(h, hipStreamSynchronize(s)); lap(5); }
     if (!segs.empty()) {
         hipLaunchKernelGGL(k_gz_crc, dim3((unsigned)((segs.size() + WAVES - 1) / WAVES)), dim3(BLOCK), 0, s, (const CrcSeg*)((uint8_t*)h->items.p + o_seg), (int)segs.size(),
                            (const uint8_t*)d_out, (uint32_t*)h->crcs.p);
@@ -789,6 +952,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     }
     GZCHK(h, hipGetLastError());
     GZCHK(h, hipStreamSynchronize(s));
+    lap(6);
     h->wcur ^= 1;
 
     // ---- CRC-32 and ISIZE of every member that ended (RFC 1952 2.3.1)
@@ -829,8 +993,12 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     h->stats.chunks += (uint64_t)n_chunks; h->stats.chain_jobs += accepted; h->stats.members = h->members_done;
     for (int c = 1; c < n_chunks; ++c) h->stats.chunks_with_start += outs[c].status != ST_EMPTY;
     *out_bytes = total;
+    lap(7);
+    if (timing)
+        fprintf(stderr, "bzq_gzip piece: %.1f MiB in -> %.1f MiB out, %d chunks, %zu chain jobs | ms: h2d %.2f find %.2f decode %.2f host-plan %.2f chain %.2f resolve %.2f crc %.2f host-verify+carry %.2f\n",
+                n / 1048576.0, total / 1048576.0, n_chunks, accepted, t_ph[0], t_ph[1], t_ph[2], t_ph[3], t_ph[4], t_ph[5], t_ph[6], t_ph[7]);
 
-    if (final_status == ST_EVENTS_FULL) *more = 1;   // (cannot happen with the event table sized as it is; call again)
+    if (final_status == ST_EVENTS_FULL || final_status == ST_SPLIT) *more = 1;   // (cannot happen with the event table sized as it is; call again)
     if (*more) return 0;
     const bool garbage = at_header && (final_status == ST_BAD_HEADER || (is_last && final_status == ST_NEED_MORE));
     if (final_status == ST_BAD_HEADER && h->members_done == 0) return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: not a gzip stream (no member header at its start)");

@@ -64,6 +64,13 @@ struct bzq_ingest {
     unsigned long long* bad_dev = nullptr;      // [INGEST_SLOTS]
     unsigned long long* bad_pinned = nullptr;   // [INGEST_SLOTS]
     double ratio_est = 0.30;       // compressed / inflated bytes of the last chunk: how much to read for the next one
+    // any other gzip file inflated on the device (bzq_gzip.hpp): the compressed pieces travel through the slot's pinned buffer,
+    // the decoder's output collects in a device FIFO (its size per piece is not known beforehand) and leaves chunk by chunk
+    bzq_gzip* gz_dev = nullptr;
+    uint8_t* gz_fifo[2] = {};      // the FIFO and the buffer its remainder moves to
+    int gz_cur = 0;
+    uint64_t gz_cap = 0, gz_have = 0, gz_off = 0;   // capacity, bytes waiting, file offset of the next compressed byte
+    bool gz_more = false, gz_done = false;
     bzq::IngestSlot slot[bzq::INGEST_SLOTS];
     hipStream_t copy_stream = nullptr;   // H2D of the chunks
     hipStream_t inflate_stream[bzq::INGEST_SLOTS] = {};   // device inflate: one stream per slot, so that the chunks' kernels overlap
@@ -211,6 +218,7 @@ inline bool read_compressed_chunk(bzq_ingest* g, uint8_t* dst, uint64_t cap, uin
         return true;
     }
     // BGZF: collect whole blocks until the chunk is full
+    if (g->compression != 2) { err = "internal: read_compressed_chunk on a file that is neither gzip nor BGZF"; return false; }
     std::vector<BgzfBlock> blocks;
     uint64_t usum = 0, coff = g->bgzf_off;
     uint8_t hdr[18], tail[8];
@@ -286,6 +294,32 @@ inline bool read_bgzf_window(bzq_ingest* g, uint8_t* pinned, uint64_t cap, bzq::
     return true;
 }
 
+// Device gzip: decode pieces of the file into the FIFO until it holds a chunk (or the stream ends).  A piece is sized from the
+// last pieces' compression ratio so that its output fits the free half of the FIFO; the decoder keeps what does not.
+inline bool gz_fill_fifo(bzq_ingest* g, uint8_t* pinned, std::string& err) {
+    while (g->gz_have < g->chunk_bytes && !g->gz_done) {
+        const uint64_t free_bytes = g->gz_cap - g->gz_have, remaining = g->file_size - g->gz_off;
+        uint64_t want = 0;
+        if (!g->gz_more) {
+            want = (uint64_t)((double)free_bytes * g->ratio_est * 0.8);
+            want = std::min<uint64_t>({std::max<uint64_t>(want, 64u << 10), g->chunk_bytes, remaining});
+            if (want && !parallel_pread(g->fd, pinned, g->gz_off, want, g->n_threads, err, g->fd_direct, &g->numa_cpus)) return false;
+            g->gz_off += want;
+        }
+        const bool file_done = g->gz_off >= g->file_size;
+        uint64_t got = 0;
+        int32_t more = 0;
+        const uint64_t consumed0 = g->gz_dev->stats.bytes_consumed;
+        if (bzq::gz::gz_decode(g->gz_dev, pinned, want, file_done, g->gz_fifo[g->gz_cur] + g->gz_have, free_bytes, &got, &more) < 0) { err = g->gz_dev->err; return false; }
+        if (got) g->ratio_est = std::min(1.0, std::max(0.01, 0.5 * g->ratio_est + 0.5 * (double)(g->gz_dev->stats.bytes_consumed - consumed0) / (double)got));
+        g->gz_have += got;
+        g->gz_more = more != 0;
+        g->gz_done = (file_done && !more) || g->gz_dev->finished;
+        if (!got && !want && !more && !g->gz_done) { err = "gzip: the decoder made no progress"; return false; }
+    }
+    return true;
+}
+
 inline void ingest_producer(bzq_ingest* g) {
     // a failed HIP call stops the pipeline with an error the consumer reports: a chunk is never published unless its copy
     // was enqueued successfully
@@ -312,11 +346,15 @@ inline void ingest_producer(bzq_ingest* g) {
         int64_t n_blocks = 0;
         // one block is decoded by one wave at its own pace (~20 ms for 64 KiB): a chunk is too few blocks to fill the device,
         // so the inflate kernels of consecutive chunks run side by side on two streams
-        const hipStream_t cs = g->gpu_inflate ? g->inflate_stream[b] : g->copy_stream;
+        const hipStream_t cs = g->gz_dev ? g->gz_dev->stream : (g->gpu_inflate ? g->inflate_stream[b] : g->copy_stream);
         bool eof = false, ok;
         const auto t0 = std::chrono::steady_clock::now();
         std::string err;
-        if (g->gpu_inflate) {
+        if (g->gz_dev) {
+            ok = gz_fill_fifo(g, s.pinned + g->reserve, err);
+            len = std::min<uint64_t>(g->gz_have, g->chunk_bytes);
+            eof = g->gz_done && g->gz_have <= g->chunk_bytes;
+        } else if (g->gpu_inflate) {
             ok = read_bgzf_window(g, s.pinned + g->reserve, g->chunk_bytes, g->tab_pinned[b], &n_blocks, &comp_len, &len, &eof, err);
         } else if (g->compression == 0) {
             len = std::min<uint64_t>(g->chunk_bytes, g->file_size - off);
@@ -341,7 +379,13 @@ inline void ingest_producer(bzq_ingest* g) {
             he = g->dev_free_valid[b] ? hipStreamWaitEvent(cs, g->dev_free[b], 0) : hipSuccess;
         }
         if (he != hipSuccess) return fail("reader: hipStreamWaitEvent", he);
-        if (g->gpu_inflate) {
+        if (g->gz_dev) {   // the chunk leaves the FIFO, what is left moves to the front of the other buffer
+            uint8_t* from = g->gz_fifo[g->gz_cur];
+            if (len && (he = hipMemcpyAsync(s.dev + g->reserve, from, len, hipMemcpyDeviceToDevice, cs)) != hipSuccess) return fail("reader: FIFO to chunk", he);
+            const uint64_t left = g->gz_have - len;
+            if (left && (he = hipMemcpyAsync(g->gz_fifo[g->gz_cur ^ 1], from + len, left, hipMemcpyDeviceToDevice, cs)) != hipSuccess) return fail("reader: FIFO remainder", he);
+            g->gz_cur ^= 1; g->gz_have = left;
+        } else if (g->gpu_inflate) {
             g->bad_pinned[b] = ~0ull;   // (the consumer read the previous verdict of this slot two chunks ago)
             if (n_blocks) {
                 if ((he = hipMemcpyAsync(g->comp_dev[b], s.pinned + g->reserve, comp_len, hipMemcpyHostToDevice, cs)) != hipSuccess ||
@@ -392,6 +436,8 @@ inline void ingest_free(bzq_ingest* g) {
     if (g->bad_dev) (void)hipFree(g->bad_dev);
     if (g->bad_pinned) (void)hipHostFree(g->bad_pinned);
     if (g->gz) gzclose(g->gz);
+    if (g->gz_dev) bzq::gz::gz_free(g->gz_dev);
+    for (int i = 0; i < 2; ++i) if (g->gz_fifo[i]) (void)hipFree(g->gz_fifo[i]);
     if (g->fd >= 0) close(g->fd);
     if (g->fd_direct >= 0) close(g->fd_direct);
     delete g;

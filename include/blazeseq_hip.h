@@ -406,7 +406,7 @@ typedef struct bzq_gzip_stats {
 
 /* A decoder on ctx's device, with a stream of its own. */
 int32_t bzq_gzip_open(bzq_ctx* ctx, bzq_gzip** out);
-/* "chunk_bytes": compressed bytes per decoder wave (default 32768; 4096 .. 1 MiB). */
+/* "chunk_bytes": compressed bytes per decoder wave (default 16384; 4096 .. 1 MiB). */
 int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value);
 /* The next n compressed bytes (HOST memory; pinned memory makes the copy a DMA) -> their bytes at d_out (DEVICE memory,
  * out_capacity bytes).  Whole DEFLATE blocks only: what is left of the piece stays inside the handle and is decoded in front of
