@@ -36,7 +36,8 @@ def test_struct_sizes_match_header(tmp_path):
                "bzq_shard_result": _lib.BzqShardResult, "bzq_nccl_id": _lib.BzqNcclId,
                "bzq_fasta_config": _lib.BzqFastaConfig, "bzq_fasta_chunk": _lib.BzqFastaChunk,
                "bzq_fasta_shard_summary": _lib.BzqFastaShardSummary, "bzq_fasta_shard_plan": _lib.BzqFastaShardPlan,
-               "bzq_fasta_shard_result": _lib.BzqFastaShardResult, "bzq_bgzf_block": _lib.BzqBgzfBlock}
+               "bzq_fasta_shard_result": _lib.BzqFastaShardResult, "bzq_bgzf_block": _lib.BzqBgzfBlock,
+               "bzq_device_views": _lib.BzqDeviceViews, "bzq_gzip_stats": _lib.BzqGzipStats}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "blazeseq_hip.h"', "int main(void) {"]
     for cname, ct in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
@@ -113,3 +114,64 @@ def test_integration_md_config_struct_matches_the_header():
     block = md[md.index("struct BzqConfig"):md.index("struct HipFastq")]
     mojo_fields = re.findall(r"^\s+var (\w+):", block, re.M)
     assert mojo_fields == [f[0] for f in _lib.BzqConfig._fields_]
+
+
+# ---- mojo/blazeseq_hip.mojo: the binding a BlazeSeq maintainer adds (it cannot be compiled here: no Mojo toolchain) -------------
+
+MOJO_SIZES = {"UInt64": 8, "Int64": 8, "Int32": 4, "UInt32": 4, "UInt8": 1, "Int8": 1, "Float32": 4, "Float64": 8, "c_void_ptr": 8}
+
+
+def _mojo_structs():
+    import re
+    src = open(os.path.join(ROOT, "mojo", "blazeseq_hip.mojo")).read()
+    out = {}
+    for m in re.finditer(r"^@fieldwise_init\nstruct (Bzq\w+)\(Copyable, Movable\):[^\n]*\n((?:    var \w+: [^\n]+\n)+)", src, re.M):
+        out[m.group(1)] = re.findall(r"^    var (\w+): (.+)$", m.group(2), re.M)
+    return src, out
+
+
+def test_every_struct_of_the_mojo_shim_matches_the_header_field_for_field():
+    """field order, field sizes and total size of EVERY struct in mojo/blazeseq_hip.mojo against the ctypes
+    mirror (itself pinned against the compiled C header by test_struct_sizes_match_header)."""
+    import ctypes as C
+    import re
+    from blazeseq_amd import _lib
+    _, structs = _mojo_structs()
+    mirror = {n: getattr(_lib, n) for n in dir(_lib) if isinstance(getattr(_lib, n), type) and issubclass(getattr(_lib, n), C.Structure)
+              and n.startswith("Bzq")}
+    assert set(structs) == set(mirror), (sorted(set(mirror) - set(structs)), sorted(set(structs) - set(mirror)))
+
+    def size_of(t):
+        t = t.strip()
+        m = re.fullmatch(r"InlineArray\[(\w+), (\d+)\]", t)
+        if m:
+            return MOJO_SIZES[m.group(1)] * int(m.group(2))
+        if t in MOJO_SIZES:
+            return MOJO_SIZES[t]
+        return C.sizeof(mirror[t])   # a nested struct
+    for name, fields in structs.items():
+        st = mirror[name]
+        assert [f for f, _ in fields] == [f[0] for f in st._fields_], name
+        off = 0
+        for (fname, ftype), (_, ctype) in zip(fields, st._fields_):
+            assert size_of(ftype) == C.sizeof(ctype), (name, fname, ftype)
+            assert getattr(st, fname).offset >= off, (name, fname)   # (natural alignment on both sides: no field overlaps its predecessor)
+            off = getattr(st, fname).offset + C.sizeof(ctype)
+        m = re.search(r"struct " + name + r"\(Copyable, Movable\):\s+# include/blazeseq_hip.h: (\w+) \((\d+) bytes", open(os.path.join(ROOT, "mojo", "blazeseq_hip.mojo")).read())
+        assert m and int(m.group(2)) == C.sizeof(st), name
+        assert "} " + m.group(1) + ";" in open(os.path.join(ROOT, "include", "blazeseq_hip.h")).read(), m.group(1)
+
+
+def test_every_function_type_of_the_mojo_shim_names_an_export_with_the_right_arity():
+    import re
+    from blazeseq_amd import _lib
+    src, _ = _mojo_structs()
+    aliases = re.findall(r"^comptime (bzq_\w+)_fn = fn\((.*)\) -> (\w+)$", src, re.M)
+    assert len(aliases) >= 30
+    for name, args, _ret in aliases:
+        assert name in _lib.SYMBOLS, name
+        n_args = 0 if not args.strip() else len(re.findall(r"\w+: ", args))
+        assert n_args == len(_lib.SYMBOLS[name][1]), (name, n_args, len(_lib.SYMBOLS[name][1]))
+    used = set(re.findall(r'get_function\[(bzq_\w+)_fn\]\("(bzq_\w+)"\)', src))
+    assert used and all(a == b for a, b in used)   # every call binds the symbol its type alias is named after
+    assert {a for a, _ in used} <= {n for n, _, _ in aliases}
