@@ -19,6 +19,7 @@ CAMPAIGNS = {
     "shards": (["tests/fuzz_campaign_shards.py", "--seconds", BUDGET], "identical to the one-shot parse"),
     "fasta": (["tests/fuzz_campaign_fasta.py", BUDGET, "1"], "identical"),
     "inflate": (["tests/fuzz_campaign_inflate.py", "--seconds", BUDGET], "identical to the bytes zlib compressed"),
+    "gzip": (["tests/fuzz_campaign_gzip.py", "--seconds", BUDGET], "identical to the bytes zlib compressed"),
     "fasta_shards": (["tests/fuzz_campaign_fasta_shards.py", "--seconds", BUDGET], "identical to the sequential parse"),
 }
 
