@@ -124,7 +124,7 @@ struct GBits {
 
 // ---- the dynamic block header (RFC 1951 3.2.7), with zlib's validity rules ----------------------------------------------------
 // On entry the 3 header bits are consumed.  Builds both codes (and the literal/length direct table when `tables`).
-__device__ __forceinline__ bool read_dynamic(GBits& b, uint8_t* lens, uint16_t* sym_ll, uint16_t* sym_d, uint16_t* lut, Code& ll, Code& dd, bool tables) {
+__device__ __forceinline__ bool read_dynamic(GBits& b, uint8_t* lens, uint16_t* sym_ll, uint16_t* sym_d, uint32_t* lut2, uint32_t* dlut, Code& ll, Code& dd, bool tables) {
     const int lane = threadIdx.x & 63;
     b.refill();
     const int hlit = (int)b.take(5) + 257, hdist = (int)b.take(5) + 1, hclen = (int)b.take(4) + 4;
@@ -159,7 +159,7 @@ __device__ __forceinline__ bool read_dynamic(GBits& b, uint8_t* lens, uint16_t* 
     if (lens[32 + 256] == 0) return false;   // no end-of-block code
     if (!inf::build_code(lens + 32, hlit, sym_ll, ll) || !inf::code_valid(ll, false, false)) return false;
     if (!inf::build_code(lens + 32 + hlit, hdist, sym_d, dd) || !inf::code_valid(dd, true, false)) return false;
-    if (tables) inf::build_lut(ll, sym_ll, lens + 32, lut);
+    if (tables) { inf::build_lut2(ll, sym_ll, lens + 32, lut2); inf::build_dlut(dd, sym_d, lens + 32 + hlit, dlut); }
     return true;
 }
 
@@ -187,8 +187,217 @@ __device__ __forceinline__ int64_t parse_member_header(const uint8_t* comp, int6
     return p < n ? p : 0;   // (at least the first byte of the DEFLATE data must be there)
 }
 
+// ---- the symbol loop, by hand (cf. inf::sym_run) ----------------------------------------------------------------------------------
+// The same loop for this decoder's output: 16-bit symbols into the CURRENT page (`page` = its first symbol, st.pos = the offset
+// of the next symbol in it, 0..65536), a match source in front of the job's output becomes a marker -- which is simply the low
+// 16 bits of its (negative) position: 0x8000 | (32768 + q) == q & 0xFFFF for -32768 <= q < 0.  A distance never needs a check
+// here (the format ends at 32768, and 32 KiB in front of the job are addressable as markers).  What the asm block does not take
+// it hands back untouched: anything that would cross the page's end (6: pending literals, 4: a match), a match whose source
+// lies in the page before (4), matches longer than 64 symbols or overlapping themselves (4), long or missing codes (0, 3), the
+// window register running out (2).  `first` = the page is the job's first (sources may be markers).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const uint32_t* dlut, uint16_t* page, bool first, inf::SymState& st, uint32_t& mylit) {
+    uint32_t reason, vt, vt2, vq, ee;
+    u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
+    int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), n = (int)uni((uint32_t)st.ns), pos = (int)uni((uint32_t)st.pos);
+    int len = (int)uni((uint32_t)st.len), dist = 0;
+    const int wb = (int)uni((uint32_t)b.win_base), fp = (int)uni(first ? 1u : 0u);
+    const uint32_t lds = uni((uint32_t)(uintptr_t)lut2), ldd = uni((uint32_t)(uintptr_t)dlut);
+    const u64 ob = ((u64)uni((uint32_t)((uintptr_t)page >> 32)) << 32) | uni((uint32_t)(uintptr_t)page);
+    const uint32_t lane = threadIdx.x & 63;
+    asm volatile(
+        "s_mov_b64 s[40:41], %[buf]\n\t"
+        "s_mov_b32 s42, %[cnt]\n\t"
+        "s_mov_b32 s43, %[next]\n\t"
+        "s_mov_b32 s44, %[pos]\n\t"
+        "s_mov_b32 s45, %[ns]\n\t"
+        "s_mov_b32 s51, %[len]\n\t"
+        "s_mov_b32 s53, %[fp]\n\t"
+        "s_mov_b32 s54, %[wb]\n\t"
+        "s_mov_b32 s55, %[lds]\n\t"
+        "s_mov_b32 s56, %[ldd]\n\t"
+        "s_mov_b64 s[60:61], %[ob]\n\t"
+        "s_mov_b32 s52, 0\n\t"
+        "s_cmp_lg_u32 s51, 0\n\t"
+        "s_cbranch_scc1 4f\n"
+        // ---- top: refill, look up
+        "1:\n\t"
+        "s_cmp_gt_i32 s42, 32\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sub_i32 s47, s43, s54\n\t"
+        "s_cmp_gt_i32 s47, 63\n\t"
+        "s_cbranch_scc1 80f\n\t"
+        "v_readlane_b32 s48, %[win], s47\n\t"
+        "s_mov_b32 s49, 0\n\t"
+        "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
+        "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
+        "s_add_i32 s42, s42, 32\n\t"
+        "s_add_i32 s43, s43, 1\n\t"
+        "s_branch 1b\n"
+        "2:\n\t"
+        "s_and_b32 s47, s40, 0x3ff\n\t"
+        "s_lshl2_add_u32 s47, s47, s55\n\t"
+        "v_mov_b32 %[vt], s47\n\t"
+        "ds_read_b32 %[vt], %[vt]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 s46, %[vt]\n\t"
+        "s_cmp_lt_i32 s46, 0\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        // ---- one or two literals
+        "s_mov_b32 m0, s45\n\t"
+        "v_writelane_b32 %[lit], s46, m0\n\t"
+        "s_lshr_b32 s47, s46, 8\n\t"
+        "s_add_i32 m0, s45, 1\n\t"
+        "v_writelane_b32 %[lit], s47, m0\n\t"
+        "s_bfe_u32 s47, s46, 0x20018\n\t"
+        "s_add_i32 s45, s45, s47\n\t"
+        "s_bfe_u32 s47, s46, 0x50010\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+        "s_sub_i32 s42, s42, s47\n\t"
+        "s_cmp_lt_i32 s45, 63\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        // 63 or 64 pending: store them, if the page takes them
+        "s_add_i32 s47, s44, s45\n\t"
+        "s_cmp_gt_u32 s47, 0x10000\n\t"
+        "s_cbranch_scc1 86f\n\t"
+        "v_cmp_gt_u32 vcc, s45, %[lane]\n\t"
+        "s_and_saveexec_b64 s[58:59], vcc\n\t"
+        "v_add_u32 %[vt], s44, %[lane]\n\t"
+        "v_lshlrev_b32 %[vt], 1, %[vt]\n\t"
+        "v_and_b32 %[vt2], 0xff, %[lit]\n\t"
+        "global_store_short %[vt], %[vt2], s[60:61]\n\t"
+        "s_mov_b64 exec, s[58:59]\n\t"
+        "s_mov_b32 s44, s47\n\t"
+        "s_mov_b32 s45, 0\n\t"
+        "s_branch 1b\n"
+        // ---- not a literal
+        "3:\n\t"
+        "s_bitcmp1_b32 s46, 30\n\t"
+        "s_cbranch_scc0 70f\n\t"
+        "s_bfe_u32 s47, s46, 0x50010\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+        "s_sub_i32 s42, s42, s47\n\t"
+        "s_bfe_u32 s47, s46, 0x30009\n\t"
+        "s_bfm_b32 s48, s47, 0\n\t"
+        "s_and_b32 s48, s48, s40\n\t"
+        "s_and_b32 s51, s46, 0x1ff\n\t"
+        "s_add_i32 s51, s51, s48\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+        "s_sub_i32 s42, s42, s47\n"
+        // ---- the distance: refill, look up
+        "4:\n\t"
+        "s_cmp_gt_i32 s42, 32\n\t"
+        "s_cbranch_scc1 5f\n\t"
+        "s_sub_i32 s47, s43, s54\n\t"
+        "s_cmp_gt_i32 s47, 63\n\t"
+        "s_cbranch_scc1 80f\n\t"
+        "v_readlane_b32 s48, %[win], s47\n\t"
+        "s_mov_b32 s49, 0\n\t"
+        "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
+        "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
+        "s_add_i32 s42, s42, 32\n\t"
+        "s_add_i32 s43, s43, 1\n\t"
+        "s_branch 4b\n"
+        "5:\n\t"
+        "s_and_b32 s47, s40, 0xff\n\t"
+        "s_lshl2_add_u32 s47, s47, s56\n\t"
+        "v_mov_b32 %[vt], s47\n\t"
+        "ds_read_b32 %[vt], %[vt]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 s46, %[vt]\n\t"
+        "s_cmp_lt_i32 s46, 0\n\t"
+        "s_cbranch_scc1 83f\n\t"
+        "s_bfe_u32 s47, s46, 0x50014\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+        "s_sub_i32 s42, s42, s47\n\t"
+        "s_bfe_u32 s47, s46, 0x40010\n\t"
+        "s_bfm_b32 s48, s47, 0\n\t"
+        "s_and_b32 s48, s48, s40\n\t"
+        "s_and_b32 s52, s46, 0x7fff\n\t"
+        "s_add_i32 s52, s52, s48\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+        "s_sub_i32 s42, s42, s47\n\t"
+        // ---- what the fast copy takes: up to 64 symbols, not overlapping itself, inside this page, source in this page (or markers)
+        "s_cmp_lt_u32 s52, s51\n\t"
+        "s_cbranch_scc1 84f\n\t"
+        "s_cmp_gt_u32 s51, 64\n\t"
+        "s_cbranch_scc1 84f\n\t"
+        "s_add_i32 s47, s44, s45\n\t"
+        "s_add_i32 s48, s47, s51\n\t"
+        "s_cmp_gt_u32 s48, 0x10000\n\t"
+        "s_cbranch_scc1 84f\n\t"
+        "s_cmp_lg_u32 s53, 0\n\t"
+        "s_cbranch_scc1 6f\n\t"
+        "s_cmp_gt_u32 s52, s47\n\t"
+        "s_cbranch_scc1 84f\n"
+        "6:\n\t"
+        // pending literals out
+        "v_cmp_gt_u32 vcc, s45, %[lane]\n\t"
+        "s_and_saveexec_b64 s[58:59], vcc\n\t"
+        "v_add_u32 %[vt], s44, %[lane]\n\t"
+        "v_lshlrev_b32 %[vt], 1, %[vt]\n\t"
+        "v_and_b32 %[vt2], 0xff, %[lit]\n\t"
+        "global_store_short %[vt], %[vt2], s[60:61]\n\t"
+        "s_mov_b64 exec, s[58:59]\n\t"
+        "s_mov_b32 s44, s47\n\t"
+        "s_mov_b32 s45, 0\n\t"
+        // the copy: lane i < len takes the symbol at q = pos - dist + i, or the marker q & 0xFFFF when q < 0
+        "v_cmp_gt_u32 vcc, s51, %[lane]\n\t"
+        "s_and_saveexec_b64 s[58:59], vcc\n\t"
+        "s_sub_i32 s47, s44, s52\n\t"
+        "v_add_u32 %[vq], s47, %[lane]\n\t"
+        "v_and_b32 %[vt2], 0xffff, %[vq]\n\t"
+        "v_cmp_le_i32 vcc, 0, %[vq]\n\t"
+        "s_and_saveexec_b64 s[62:63], vcc\n\t"
+        "v_lshlrev_b32 %[vt], 1, %[vq]\n\t"
+        "global_load_ushort %[vt2], %[vt], s[60:61]\n\t"
+        "s_mov_b64 exec, s[62:63]\n\t"
+        "v_add_u32 %[vt], s44, %[lane]\n\t"
+        "v_lshlrev_b32 %[vt], 1, %[vt]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "global_store_short %[vt], %[vt2], s[60:61]\n\t"
+        "s_mov_b64 exec, s[58:59]\n\t"
+        "s_add_i32 s44, s44, s51\n\t"
+        "s_mov_b32 s51, 0\n\t"
+        "s_branch 1b\n"
+        // ---- ways out
+        "70:\n\t"
+        "s_mov_b32 s50, 0\n\t"
+        "s_branch 9f\n"
+        "80:\n\t"
+        "s_mov_b32 s50, 2\n\t"
+        "s_branch 9f\n"
+        "83:\n\t"
+        "s_mov_b32 s50, 3\n\t"
+        "s_branch 9f\n"
+        "84:\n\t"
+        "s_mov_b32 s50, 4\n\t"
+        "s_branch 9f\n"
+        "86:\n\t"
+        "s_mov_b32 s50, 6\n"
+        "9:\n\t"
+        "s_mov_b64 %[buf], s[40:41]\n\t"
+        "s_mov_b32 %[cnt], s42\n\t"
+        "s_mov_b32 %[next], s43\n\t"
+        "s_mov_b32 %[pos], s44\n\t"
+        "s_mov_b32 %[ns], s45\n\t"
+        "s_mov_b32 %[e], s46\n\t"
+        "s_mov_b32 %[len], s51\n\t"
+        "s_mov_b32 %[dist], s52\n\t"
+        "s_mov_b32 %[reason], s50"
+        : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [ns] "+s"(n), [len] "+s"(len), [dist] "+s"(dist), [lit] "+v"(mylit),
+          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [e] "=s"(ee), [reason] "=s"(reason)
+        : [wb] "s"(wb), [fp] "s"(fp), [win] "v"(b.win), [lane] "v"(lane), [lds] "s"(lds), [ldd] "s"(ldd), [ob] "s"(ob)
+        : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s58", "s59", "s60", "s61",
+          "s62", "s63", "m0", "scc", "vcc", "memory");
+    b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.ns = n; st.len = len; st.dist = dist; st.e = ee;
+    return (int)reason;
+}
+#pragma clang diagnostic pop
+
 // ---- the decoder of one job ----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens, uint16_t* lut) {
+__device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens, uint32_t* lut2, uint32_t* dlut) {
     const int lane = threadIdx.x & 63;
     const Job job = a.jobs[ji];
     JobOut o;
@@ -222,7 +431,7 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
     auto flush = [&]() -> bool {
         if (ns == 0) return true;
         if (!ensure(opos + ns)) return false;
-        if (lane < ns) *at(opos + lane) = (uint16_t)mylit;
+        if (lane < ns) *at(opos + lane) = (uint16_t)(mylit & 0xFFu);   // (the literal loop leaves whatever sat above bit 7 of its table entry)
         opos += ns; ns = 0;
         return true;
     };
@@ -295,47 +504,50 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
                 if (lane < 32) lens[288 + lane] = 5;
                 __builtin_amdgcn_wave_barrier();
                 if (!inf::build_code(lens, 288, sym_ll, ll) || !inf::build_code(lens + 288, 30, sym_d, dd)) ok = false;
-                else inf::build_lut(ll, sym_ll, lens, lut);
-            } else if (!read_dynamic(b, lens, sym_ll, sym_d, lut, ll, dd, true)) ok = false;
-            while (ok) {
-                // a run of literals through the direct table (cf. inf::inflate_block)
-                uint32_t e;
-                for (;;) {
-                    b.refill();
-                    e = uni(lut[(uint32_t)b.buf & ((1u << inf::LUT_BITS) - 1u)]);
-                    if (e & 0x100u) break;
-                    const int l = (int)(e >> 12);
-                    b.buf >>= l; b.cnt -= l;
-                    if (lane == ns) mylit = e & 0xFFu;
-                    if (++ns == 64) {
-                        if (!flush() || b.ran_out) { ok = false; break; }
-                    }
-                }
-                if (!ok) break;
-                int s;
-                if (e != inf::LUT_LONG) { s = (int)(e & 0xFFFu); const int l = (int)(e >> 12); b.buf >>= l; b.cnt -= l; }
-                else { s = inf::decode_sym(b, ll, sym_ll); if (s < 0) { ok = false; break; } }
-                if (s < 256) {   // a literal with a long code
-                    if (lane == ns) mylit = (uint32_t)s;
-                    if (++ns == 64 && (!flush() || b.ran_out)) { ok = false; break; }
-                    continue;
-                }
-                if (s == 256) break;
-                if (s > 285 || b.ran_out) { ok = false; break; }
-                const int len = (int)(rdlane(lbase, s - 257) + b.take((int)rdlane(lext, s - 257)));
-                b.refill();
-                const int ds = inf::decode_sym(b, dd, sym_d);
-                if (ds < 0 || ds > 29) { ok = false; break; }
-                const int dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));
-                if (!flush() || !ensure(opos + len)) { ok = false; break; }
-                if ((int64_t)dist > opos + 32768) { ok = false; break; }   // further back than any window
+                else { inf::build_lut2(ll, sym_ll, lens, lut2); inf::build_dlut(dd, sym_d, lens + 288, dlut); }
+            } else if (!read_dynamic(b, lens, sym_ll, sym_d, lut2, dlut, ll, dd, true)) ok = false;
+            // the symbols: sym_run_gz does the common cases inside one asm block; what it hands back is rare
+            inf::SymState st{0, 0, 0, 0, 0u};
+            auto general_copy = [&](int len, int dist) -> bool {
                 // out[opos + i] = out[opos - dist + i]; with dist < len the source repeats with period dist.  A source in front of
-                // this job's output is not known yet: a marker for index 32768 + (source position) of the window in front of it.
+                // this job's output is not known yet: a marker, the low 16 bits of its (negative) position.
+                if (!flush() || !ensure(opos + len)) return false;
                 for (int i = lane; i < len; i += 64) {
                     const int64_t q = opos - dist + (dist >= len ? i : i % dist);
                     *at(opos + i) = q >= 0 ? *at(q) : (uint16_t)(0x8000u | (uint32_t)(32768 + q));
                 }
                 opos += len;
+                return true;
+            };
+            while (ok) {
+                if (!ensure(opos + 1)) { ok = false; break; }   // `cur` is the page of position opos
+                st.pos = (int)(opos & (PAGE - 1)); st.ns = ns;
+                const int why = sym_run_gz(b, lut2, dlut, cur, cur_idx == 0, st, mylit);
+                opos = (opos & ~(int64_t)(PAGE - 1)) + st.pos; ns = st.ns;
+                if (why == 2) { b.refill(); if (b.ran_out) { ok = false; break; } continue; }   // (with st.len set it resumes in the distance half)
+                if (why == 6) { if (!flush() || b.ran_out) { ok = false; break; } continue; }    // pending literals across the page's end
+                if (why == 4) { if (!general_copy(st.len, st.dist)) { ok = false; break; } st.len = 0; continue; }
+                if (why == 3) {   // a distance code the direct table does not hold
+                    const int ds = inf::decode_sym(b, dd, sym_d);
+                    if (ds < 0 || ds > 29) { ok = false; break; }
+                    const int dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));
+                    if (!general_copy(st.len, dist)) { ok = false; break; }
+                    st.len = 0;
+                    continue;
+                }
+                // why == 0: end of block, a literal / length code longer than the table's index, or no code at all
+                const uint32_t e = st.e & 0xFFFFu;
+                int s;
+                if (e != inf::LUT_LONG) { s = (int)(e & 0xFFFu); const int l = (int)(e >> 12); b.buf >>= l; b.cnt -= l; }
+                else { s = inf::decode_sym(b, ll, sym_ll); if (s < 0) { ok = false; break; } }
+                if (s < 256) {   // a literal with a long code
+                    mylit = inf::wrlane((uint32_t)s, ns, mylit);
+                    if (++ns >= 63 && (!flush() || b.ran_out)) { ok = false; break; }
+                    continue;
+                }
+                if (s == 256) break;
+                if (s > 285 || b.ran_out) { ok = false; break; }
+                st.len = (int)(rdlane(lbase, s - 257) + b.take((int)rdlane(lext, s - 257)));   // sym_run_gz goes on with its distance
             }
         }
         if (pool_full) { status = ST_POOL_FULL; break; }
@@ -369,11 +581,12 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
 static __global__ __launch_bounds__(BLOCK) void k_gz_decode(Args a) {
     __shared__ uint16_t s_ll[WAVES][288 + 32];
     __shared__ uint8_t s_len[WAVES][320 + 64];
-    __shared__ __attribute__((aligned(4))) uint16_t s_lut[WAVES][1 << inf::LUT_BITS];
+    __shared__ uint32_t s_lut[WAVES][1 << inf::LUT_BITS];
+    __shared__ uint32_t s_dlut[WAVES][1 << inf::DLUT_BITS];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int k = (int)blockIdx.x * WAVES + wave;
     if (k >= a.n_jobs) return;
-    run_job(a, a.job_base + k, s_ll[wave], s_ll[wave] + 288, s_len[wave], s_lut[wave]);
+    run_job(a, a.job_base + k, s_ll[wave], s_ll[wave] + 288, s_len[wave], s_lut[wave], s_dlut[wave]);
 }
 
 // ---- FIND: the first position in chunk c at which a block (or a member) can start ----------------------------------------------
@@ -431,12 +644,12 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
                     const uint32_t type = b.take(2);
                     if (type == 3) ok = false;
                     else if (type == 0) { b.take(b.cnt & 7); b.refill(); const uint32_t len = b.take(16), nlen = b.take(16); ok = (len ^ nlen) == 0xFFFFu; }
-                    else if (type == 2) ok = read_dynamic(b, lens, sym_ll, sym_d, nullptr, ll, dd, false) && !b.beyond();
+                    else if (type == 2) ok = read_dynamic(b, lens, sym_ll, sym_d, nullptr, nullptr, ll, dd, false) && !b.beyond();
                 }
                 if (ok) found = pos_header((u64)(Q >> 3));
             } else {
                 b.start(a.comp, a.n, Q + 3);
-                ok = read_dynamic(b, lens, sym_ll, sym_d, nullptr, ll, dd, false) && !b.beyond();
+                ok = read_dynamic(b, lens, sym_ll, sym_d, nullptr, nullptr, ll, dd, false) && !b.beyond();
                 if (ok) found = pos_deflate((u64)Q);
             }
         }

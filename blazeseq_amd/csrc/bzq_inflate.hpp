@@ -139,11 +139,12 @@ __device__ __forceinline__ int decode_sym(BitsT& b, const Code& code, const uint
 // first[l] + (p - offs[l]), its bit-reversed value r selects the entries r + k * 2^l.
 constexpr int LUT_BITS = 10;
 constexpr uint32_t LUT_LONG = 0x100u;   // entry of a code longer than LUT_BITS (bit 8 set like every non-literal, length 0)
+template <int BITS = LUT_BITS>
 __device__ __forceinline__ void build_lut(const Code& code, const uint16_t* symtab, const uint8_t* lens, uint16_t* lut) {
     const int lane = threadIdx.x & 63;
     uint32_t* lut32 = reinterpret_cast<uint32_t*>(lut);
 #pragma unroll
-    for (int i = 0; i < (1 << LUT_BITS) / 2 / 64; ++i) lut32[i * 64 + lane] = LUT_LONG * 0x10001u;
+    for (int i = 0; i < (1 << BITS) / 2 / 64; ++i) lut32[i * 64 + lane] = LUT_LONG * 0x10001u;
     __builtin_amdgcn_wave_barrier();
     for (int p0 = 0; p0 < code.n_coded; p0 += 64) {
         const int p = p0 + lane;
@@ -151,14 +152,358 @@ __device__ __forceinline__ void build_lut(const Code& code, const uint16_t* symt
         const int l = p < code.n_coded ? lens[sym] : 0;
         // (every lane takes part in the gathers: ds_bpermute reads nothing from a lane that is switched off)
         const uint32_t f = (uint32_t)__builtin_amdgcn_ds_bpermute(l * 4, (int)code.first), o = (uint32_t)__builtin_amdgcn_ds_bpermute(l * 4, (int)code.offs);
-        if (l >= 1 && l <= LUT_BITS) {
+        if (l >= 1 && l <= BITS) {
             const uint32_t r = __builtin_bitreverse32(f + ((uint32_t)p - o)) >> (32 - l);
             const uint16_t e = (uint16_t)(sym | ((uint32_t)l << 12));
-            for (uint32_t k = r; k < (1u << LUT_BITS); k += 1u << l) lut[k] = e;
+            for (uint32_t k = r; k < (1u << BITS); k += 1u << l) lut[k] = e;
         }
     }
     __builtin_amdgcn_wave_barrier();
 }
+
+// The table the literal loop reads: 32-bit entries, up to TWO literals per lookup.  The decoder is bound by instruction issue, not by
+// latency, and in FASTQ most symbols are literals with short codes (bases: 2-3 bits, qualities: 4-6), so two of
+// them usually fit the 10 index bits -- one trip through the loop then delivers two bytes.
+//   bit 31      the first symbol is not a literal with a code of <= LUT_BITS bits.  Bit 30 set: a LENGTH symbol (257..285) with
+//               such a code, base and extra bits folded in: bits 0..8 = base length, 9..11 = number of extra bits, 16..20 = code
+//               bits.  Bit 30 clear: bits 0..15 = the one-symbol entry of build_lut (end of block, a longer code, no code)
+//   bits 0..7   first literal, bits 8..15 second literal, bits 24..25 = how many (1 or 2), bits 16..20 = code bits consumed by both
+// lut2 = LUT_BITS-indexed, 4 KiB; its upper half serves as the one-symbol table while it is built.
+__device__ __forceinline__ void build_lut2(const Code& code, const uint16_t* symtab, const uint8_t* lens, uint32_t* lut2) {
+    const int lane = threadIdx.x & 63;
+    uint16_t* lut1 = reinterpret_cast<uint16_t*>(lut2) + (1 << LUT_BITS);
+    build_lut(code, symtab, lens, lut1);
+    uint32_t ent[(1 << LUT_BITS) / 64];
+#pragma unroll
+    for (int k = 0; k < (1 << LUT_BITS) / 64; ++k) {
+        const uint32_t i = (uint32_t)(k * 64 + lane);
+        const uint32_t e1 = lut1[i];
+        if (e1 & 0x100u) {
+            const uint32_t sym = e1 & 0xFFFu;
+            if (e1 != LUT_LONG && sym >= 257u && sym <= 285u) {   // RFC 1951 3.2.5
+                const uint32_t c = sym - 257u, ext = (c < 8u || c >= 28u) ? 0u : (c - 4u) >> 2;
+                const uint32_t base = c < 8u ? 3u + c : (c >= 28u ? 258u : 3u + ((4u + (c & 3u)) << ext));
+                ent[k] = 0xC0000000u | base | (ext << 9) | ((e1 >> 12) << 16);
+            } else ent[k] = 0x80000000u | e1;
+            continue;
+        }
+        const uint32_t l1 = e1 >> 12;
+        const uint32_t e2 = lut1[i >> l1];   // (the bits above the 10 - l1 valid ones are zero: a code of <= 10 - l1 bits does not look at them)
+        const uint32_t l2 = e2 >> 12;
+        const bool two = !(e2 & 0x100u) && l1 + l2 <= (uint32_t)LUT_BITS;
+        ent[k] = (e1 & 0xFFu) | (two ? ((e2 & 0xFFu) << 8) | (2u << 24) | ((l1 + l2) << 16) : (1u << 24) | (l1 << 16));
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < (1 << LUT_BITS) / 64; ++k) lut2[k * 64 + lane] = ent[k];
+    __builtin_amdgcn_wave_barrier();
+}
+// lane `lane` of `old` := v (both uniform): v_writelane_b32 with the lane select in M0 (a VALU instruction takes one SGPR; M0 is
+// extra) -- two instructions where "if (lane_id == lane) old = v" costs three.  This compiler has no builtin for it; nothing in
+// these kernels uses M0 otherwise (no LDS-DMA, no movrel).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ uint32_t wrlane(uint32_t v, int lane, uint32_t old) {
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(uni(v)), "s"((int)uni((uint32_t)lane)) : "m0");
+    return old;
+}
+
+// The literal run, by hand.  The decoder is bound by the CU's scalar unit (PMC: 1.03 scalar instructions per CU cycle, 21.6 per
+// output byte), and what the compiler makes of the C++ loop is ~41 instructions per trip (SGPR spills reloaded inside it, the
+// reader's counters kept in vector registers, selects and copies around every exit).  This is the same loop in 21: refill
+// from the window register (v_readlane), table lookup (one ds_read_b32), one or two literals into the pending register
+// (v_writelane, lane select in M0), shift.  It leaves with
+//   0  the entry is not a plain literal: *e = the entry (bit 31 set); its bits are NOT consumed
+//   1  63 or 64 literals are pending: the caller stores them
+//   2  the window register is used up: the caller reloads it (refill())
+// Fixed scalar registers (named in the clobber list) because inline asm cannot name the halves of a 64-bit operand.
+template <class BitsT>
+__device__ __forceinline__ int lit_run(BitsT& b, const uint32_t* lut2, int& ns, uint32_t& mylit, uint32_t& e) {
+    uint32_t reason, vt, ee;
+    // (all of it is uniform; the compiler cannot always prove it and refuses a vector register for an "s" operand)
+    u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
+    int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), n = (int)uni((uint32_t)ns);
+    const int wb = (int)uni((uint32_t)b.win_base);
+    const uint32_t lds = uni((uint32_t)(uintptr_t)lut2);   // (a generic pointer into LDS: its low half is the LDS address)
+    asm volatile(
+        "s_mov_b64 s[40:41], %[buf]\n\t"
+        "s_mov_b32 s42, %[cnt]\n\t"
+        "s_mov_b32 s43, %[next]\n\t"
+        "s_mov_b32 s45, %[ns]\n"
+        "1:\n\t"
+        "s_cmp_gt_i32 s42, 32\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sub_i32 s47, s43, %[wb]\n\t"
+        "s_cmp_gt_i32 s47, 63\n\t"
+        "s_cbranch_scc1 8f\n\t"
+        "v_readlane_b32 s48, %[win], s47\n\t"
+        "s_mov_b32 s49, 0\n\t"
+        "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
+        "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
+        "s_add_i32 s42, s42, 32\n\t"
+        "s_add_i32 s43, s43, 1\n\t"
+        "s_branch 1b\n"
+        "2:\n\t"
+        "s_and_b32 s47, s40, 0x3ff\n\t"
+        "s_lshl2_add_u32 s47, s47, %[lds]\n\t"
+        "v_mov_b32 %[vt], s47\n\t"
+        "ds_read_b32 %[vt], %[vt]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 s46, %[vt]\n\t"
+        "s_cmp_lt_i32 s46, 0\n\t"
+        "s_cbranch_scc1 7f\n\t"
+        "s_mov_b32 m0, s45\n\t"
+        "v_writelane_b32 %[lit], s46, m0\n\t"
+        "s_lshr_b32 s47, s46, 8\n\t"
+        "s_add_i32 m0, s45, 1\n\t"
+        "v_writelane_b32 %[lit], s47, m0\n\t"
+        "s_bfe_u32 s47, s46, 0x20018\n\t"
+        "s_add_i32 s45, s45, s47\n\t"
+        "s_bfe_u32 s47, s46, 0x50010\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+        "s_sub_i32 s42, s42, s47\n\t"
+        "s_cmp_lt_i32 s45, 63\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_mov_b32 s50, 1\n\t"
+        "s_branch 9f\n"
+        "7:\n\t"
+        "s_mov_b32 s50, 0\n\t"
+        "s_branch 9f\n"
+        "8:\n\t"
+        "s_mov_b32 s50, 2\n"
+        "9:\n\t"
+        "s_mov_b64 %[buf], s[40:41]\n\t"
+        "s_mov_b32 %[cnt], s42\n\t"
+        "s_mov_b32 %[next], s43\n\t"
+        "s_mov_b32 %[ns], s45\n\t"
+        "s_mov_b32 %[e], s46\n\t"
+        "s_mov_b32 %[reason], s50"
+        : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [ns] "+s"(n), [lit] "+v"(mylit), [vt] "=&v"(vt), [e] "=s"(ee), [reason] "=s"(reason)
+        : [wb] "s"(wb), [win] "v"(b.win), [lds] "s"(lds)
+        : "s40", "s41", "s42", "s43", "s45", "s46", "s47", "s48", "s49", "s50", "m0", "scc", "memory");
+    b.buf = buf; b.cnt = cnt; b.next = next; ns = n; e = ee;
+    return (int)reason;
+}
+
+// The distance code's direct table: DLUT_BITS index bits, 32-bit entries with base and extra bits folded in (RFC 1951 3.2.5):
+// bits 0..14 = base distance, 16..19 = number of extra bits, 20..24 = code bits; bit 31 = a longer code, no code, or one of
+// the two symbols that must not occur (30, 31): the slow path judges those.  Its upper half serves as the 16-bit table while it
+// is built.
+constexpr int DLUT_BITS = 8;
+__device__ __forceinline__ void build_dlut(const Code& code, const uint16_t* symtab, const uint8_t* lens, uint32_t* dlut) {
+    const int lane = threadIdx.x & 63;
+    uint16_t* t16 = reinterpret_cast<uint16_t*>(dlut) + (1 << DLUT_BITS);
+    build_lut<DLUT_BITS>(code, symtab, lens, t16);
+    uint32_t ent[(1 << DLUT_BITS) / 64];
+#pragma unroll
+    for (int k = 0; k < (1 << DLUT_BITS) / 64; ++k) {
+        const uint32_t e1 = t16[k * 64 + lane], sym = e1 & 0xFFFu;
+        if (e1 == LUT_LONG || sym > 29u) { ent[k] = 0x80000000u; continue; }
+        const uint32_t ext = sym < 4u ? 0u : (sym - 2u) >> 1;
+        const uint32_t base = sym < 4u ? 1u + sym : 1u + ((2u + (sym & 1u)) << ext);
+        ent[k] = base | (ext << 16) | ((e1 >> 12) << 20);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < (1 << DLUT_BITS) / 64; ++k) dlut[k * 64 + lane] = ent[k];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The symbol loop of a BGZF block, by hand: literals as in lit_run, and the whole match path -- length from the folded table
+// entry, distance through its own direct table, the checks, the store of the pending literals and the copy of a match of up to
+// 64 bytes that does not overlap itself -- without leaving the asm block (in the benchmark's FASTQ 71 % of the bytes come out of
+// matches of 5.5 bytes on average: what the match path costs decides the rate).  ~21 instructions per literal pair, ~70 per
+// match (the C++ loop: ~41 and ~120).  It leaves with
+//   0  an entry that is neither literal nor a folded length symbol (end of block, long code, no code): e, bits not consumed
+//   2  the window register is used up (refill() and come back; with `len` > 0: come back into the distance half)
+//   3  a distance code the table does not hold: len is decoded, the distance bits are not consumed
+//   4  a match the fast copy does not take (longer than 64 bytes, or overlapping itself): len, dist; pending literals stored
+//   5  invalid: distance beyond the start of the output, or output beyond usize
+struct SymState { int pos, ns, len, dist; uint32_t e; };
+template <class BitsT>
+__device__ __forceinline__ int sym_run(BitsT& b, const uint32_t* lut2, const uint32_t* dlut, uint8_t* out, int usize, SymState& st, uint32_t& mylit) {
+    uint32_t reason, vt, vt2, ee;
+    u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
+    int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), n = (int)uni((uint32_t)st.ns), pos = (int)uni((uint32_t)st.pos);
+    int len = (int)uni((uint32_t)st.len), dist = 0;
+    const int wb = (int)uni((uint32_t)b.win_base), us = (int)uni((uint32_t)usize);
+    const uint32_t lds = uni((uint32_t)(uintptr_t)lut2), ldd = uni((uint32_t)(uintptr_t)dlut);
+    const u64 ob = ((u64)uni((uint32_t)((uintptr_t)out >> 32)) << 32) | uni((uint32_t)(uintptr_t)out);
+    const uint32_t lane = threadIdx.x & 63;
+    asm volatile(
+        "s_mov_b64 s[40:41], %[buf]\n\t"
+        "s_mov_b32 s42, %[cnt]\n\t"
+        "s_mov_b32 s43, %[next]\n\t"
+        "s_mov_b32 s44, %[pos]\n\t"
+        "s_mov_b32 s45, %[ns]\n\t"
+        "s_mov_b32 s51, %[len]\n\t"
+        "s_mov_b32 s53, %[us]\n\t"
+        "s_mov_b32 s54, %[wb]\n\t"
+        "s_mov_b32 s55, %[lds]\n\t"
+        "s_mov_b32 s56, %[ldd]\n\t"
+        "s_mov_b64 s[60:61], %[ob]\n\t"
+        "s_mov_b32 s52, 0\n\t"
+        "s_cmp_lg_u32 s51, 0\n\t"
+        "s_cbranch_scc1 4f\n"
+        // ---- top: refill, look up
+        "1:\n\t"
+        "s_cmp_gt_i32 s42, 32\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_sub_i32 s47, s43, s54\n\t"
+        "s_cmp_gt_i32 s47, 63\n\t"
+        "s_cbranch_scc1 80f\n\t"
+        "v_readlane_b32 s48, %[win], s47\n\t"
+        "s_mov_b32 s49, 0\n\t"
+        "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
+        "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
+        "s_add_i32 s42, s42, 32\n\t"
+        "s_add_i32 s43, s43, 1\n\t"
+        "s_branch 1b\n"
+        "2:\n\t"
+        "s_and_b32 s47, s40, 0x3ff\n\t"
+        "s_lshl2_add_u32 s47, s47, s55\n\t"
+        "v_mov_b32 %[vt], s47\n\t"
+        "ds_read_b32 %[vt], %[vt]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 s46, %[vt]\n\t"
+        "s_cmp_lt_i32 s46, 0\n\t"
+        "s_cbranch_scc1 3f\n\t"
+        // ---- one or two literals
+        "s_mov_b32 m0, s45\n\t"
+        "v_writelane_b32 %[lit], s46, m0\n\t"
+        "s_lshr_b32 s47, s46, 8\n\t"
+        "s_add_i32 m0, s45, 1\n\t"
+        "v_writelane_b32 %[lit], s47, m0\n\t"
+        "s_bfe_u32 s47, s46, 0x20018\n\t"
+        "s_add_i32 s45, s45, s47\n\t"
+        "s_bfe_u32 s47, s46, 0x50010\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+        "s_sub_i32 s42, s42, s47\n\t"
+        "s_cmp_lt_i32 s45, 63\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        // 63 or 64 pending: store them
+        "s_add_i32 s47, s44, s45\n\t"
+        "s_cmp_gt_u32 s47, s53\n\t"
+        "s_cbranch_scc1 85f\n\t"
+        "v_cmp_gt_u32 vcc, s45, %[lane]\n\t"
+        "s_and_saveexec_b64 s[58:59], vcc\n\t"
+        "v_add_u32 %[vt], s44, %[lane]\n\t"
+        "global_store_byte %[vt], %[lit], s[60:61]\n\t"
+        "s_mov_b64 exec, s[58:59]\n\t"
+        "s_mov_b32 s44, s47\n\t"
+        "s_mov_b32 s45, 0\n\t"
+        "s_branch 1b\n"
+        // ---- not a literal
+        "3:\n\t"
+        "s_bitcmp1_b32 s46, 30\n\t"
+        "s_cbranch_scc0 70f\n\t"
+        "s_bfe_u32 s47, s46, 0x50010\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+        "s_sub_i32 s42, s42, s47\n\t"
+        "s_bfe_u32 s47, s46, 0x30009\n\t"
+        "s_bfm_b32 s48, s47, 0\n\t"
+        "s_and_b32 s48, s48, s40\n\t"
+        "s_and_b32 s51, s46, 0x1ff\n\t"
+        "s_add_i32 s51, s51, s48\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+        "s_sub_i32 s42, s42, s47\n"
+        // ---- the distance: refill, look up
+        "4:\n\t"
+        "s_cmp_gt_i32 s42, 32\n\t"
+        "s_cbranch_scc1 5f\n\t"
+        "s_sub_i32 s47, s43, s54\n\t"
+        "s_cmp_gt_i32 s47, 63\n\t"
+        "s_cbranch_scc1 80f\n\t"
+        "v_readlane_b32 s48, %[win], s47\n\t"
+        "s_mov_b32 s49, 0\n\t"
+        "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
+        "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
+        "s_add_i32 s42, s42, 32\n\t"
+        "s_add_i32 s43, s43, 1\n\t"
+        "s_branch 4b\n"
+        "5:\n\t"
+        "s_and_b32 s47, s40, 0xff\n\t"
+        "s_lshl2_add_u32 s47, s47, s56\n\t"
+        "v_mov_b32 %[vt], s47\n\t"
+        "ds_read_b32 %[vt], %[vt]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 s46, %[vt]\n\t"
+        "s_cmp_lt_i32 s46, 0\n\t"
+        "s_cbranch_scc1 83f\n\t"
+        "s_bfe_u32 s47, s46, 0x50014\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+        "s_sub_i32 s42, s42, s47\n\t"
+        "s_bfe_u32 s47, s46, 0x40010\n\t"
+        "s_bfm_b32 s48, s47, 0\n\t"
+        "s_and_b32 s48, s48, s40\n\t"
+        "s_and_b32 s52, s46, 0x7fff\n\t"
+        "s_add_i32 s52, s52, s48\n\t"
+        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
+        "s_sub_i32 s42, s42, s47\n\t"
+        // ---- checks, pending literals out, copy
+        "s_add_i32 s47, s44, s45\n\t"
+        "s_cmp_gt_u32 s52, s47\n\t"
+        "s_cbranch_scc1 85f\n\t"
+        "s_add_i32 s48, s47, s51\n\t"
+        "s_cmp_gt_u32 s48, s53\n\t"
+        "s_cbranch_scc1 85f\n\t"
+        "v_cmp_gt_u32 vcc, s45, %[lane]\n\t"
+        "s_and_saveexec_b64 s[58:59], vcc\n\t"
+        "v_add_u32 %[vt], s44, %[lane]\n\t"
+        "global_store_byte %[vt], %[lit], s[60:61]\n\t"
+        "s_mov_b64 exec, s[58:59]\n\t"
+        "s_mov_b32 s44, s47\n\t"
+        "s_mov_b32 s45, 0\n\t"
+        "s_cmp_lt_u32 s52, s51\n\t"
+        "s_cbranch_scc1 84f\n\t"
+        "s_cmp_gt_u32 s51, 64\n\t"
+        "s_cbranch_scc1 84f\n\t"
+        "v_cmp_gt_u32 vcc, s51, %[lane]\n\t"
+        "s_and_saveexec_b64 s[58:59], vcc\n\t"
+        "s_sub_i32 s47, s44, s52\n\t"
+        "v_add_u32 %[vt], s47, %[lane]\n\t"
+        "global_load_ubyte %[vt2], %[vt], s[60:61]\n\t"
+        "v_add_u32 %[vt], s44, %[lane]\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "global_store_byte %[vt], %[vt2], s[60:61]\n\t"
+        "s_mov_b64 exec, s[58:59]\n\t"
+        "s_add_i32 s44, s44, s51\n\t"
+        "s_mov_b32 s51, 0\n\t"
+        "s_branch 1b\n"
+        // ---- ways out
+        "70:\n\t"
+        "s_mov_b32 s50, 0\n\t"
+        "s_branch 9f\n"
+        "80:\n\t"
+        "s_mov_b32 s50, 2\n\t"
+        "s_branch 9f\n"
+        "83:\n\t"
+        "s_mov_b32 s50, 3\n\t"
+        "s_branch 9f\n"
+        "84:\n\t"
+        "s_mov_b32 s50, 4\n\t"
+        "s_branch 9f\n"
+        "85:\n\t"
+        "s_mov_b32 s50, 5\n"
+        "9:\n\t"
+        "s_mov_b64 %[buf], s[40:41]\n\t"
+        "s_mov_b32 %[cnt], s42\n\t"
+        "s_mov_b32 %[next], s43\n\t"
+        "s_mov_b32 %[pos], s44\n\t"
+        "s_mov_b32 %[ns], s45\n\t"
+        "s_mov_b32 %[e], s46\n\t"
+        "s_mov_b32 %[len], s51\n\t"
+        "s_mov_b32 %[dist], s52\n\t"
+        "s_mov_b32 %[reason], s50"
+        : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [ns] "+s"(n), [len] "+s"(len), [dist] "+s"(dist), [lit] "+v"(mylit),
+          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [e] "=s"(ee), [reason] "=s"(reason)
+        : [wb] "s"(wb), [us] "s"(us), [win] "v"(b.win), [lane] "v"(lane), [lds] "s"(lds), [ldd] "s"(ldd), [ob] "s"(ob)
+        : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s58", "s59", "s60", "s61",
+          "m0", "scc", "vcc", "memory");
+    b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.ns = n; st.len = len; st.dist = dist; st.e = ee;
+    return (int)reason;
+}
+#pragma clang diagnostic pop
 
 // RFC 1951 3.2.5: base and extra bits of the length codes 257..285 and the distance codes 0..29, lane i = code i
 __device__ __forceinline__ void length_dist_tables(uint32_t& lbase, uint32_t& lext, uint32_t& dbase, uint32_t& dext) {
@@ -227,7 +572,7 @@ __device__ __forceinline__ uint32_t block_crc32(const uint8_t* out, int n, const
 
 // One BGZF block by one wave.  Every branch in here is uniform; false = the stream is not a valid DEFLATE stream of usize bytes.
 __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_left, int csize, uint8_t* out, int usize,
-                                              uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens, uint16_t* lut) {
+                                              uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens, uint32_t* lut2, uint32_t* dlut) {
     const int lane = threadIdx.x & 63;
     uint32_t lbase, lext, dbase, dext;
     length_dist_tables(lbase, lext, dbase, dext);
@@ -238,12 +583,16 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
     if (comp_left > (int64_t)csize + 8) comp_left = (int64_t)csize + 8;
     b.start(comp, comp_left);
     int64_t payload_off = 0;   // bytes of the payload in front of b.base (the reader is re-based behind every stored block)
-    int pos = 0;             // bytes stored so far
-    int ns = 0;              // literals decoded and not yet stored: lane k holds the k-th (pos + ns = bytes decoded)
+    // st.pos bytes are stored, st.ns literals are decoded and not yet stored: lane k of mylit holds the k-th
+    SymState st{0, 0, 0, 0, 0u};
     uint32_t mylit = 0;
     auto flush = [&]() {     // (callers have checked pos + ns <= usize)
-        if (lane < ns) out[pos + lane] = (uint8_t)mylit;
-        pos += ns; ns = 0;
+        if (lane < st.ns) out[st.pos + lane] = (uint8_t)mylit;
+        st.pos += st.ns; st.ns = 0;
+    };
+    auto copy = [&](int len, int dist) {   // out[pos + i] = out[pos - dist + i]; with dist < len the source repeats with period dist: only bytes in front of pos are read
+        for (int i = lane; i < len; i += 64) out[st.pos + i] = out[st.pos - dist + (dist >= len ? i : i % dist)];
+        st.pos += len;
     };
     for (bool last = false; !last;) {
         b.refill();
@@ -254,12 +603,12 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             b.take(b.cnt & 7);
             b.refill();
             const uint32_t len = b.take(16), nlen = b.take(16);
-            if ((len ^ nlen) != 0xFFFFu || pos + ns + (int)len > usize) return false;
+            if ((len ^ nlen) != 0xFFFFu || st.pos + st.ns + (int)len > usize) return false;
             flush();
             const int64_t src = b.byte_pos();
             if (payload_off + src + (int64_t)len > (int64_t)csize) return false;   // the bytes must lie inside this block's payload
-            for (int i = lane; i < (int)len; i += 64) out[pos + i] = b.base[src + i];
-            pos += (int)len;
+            for (int i = lane; i < (int)len; i += 64) out[st.pos + i] = b.base[src + i];
+            st.pos += (int)len;
             payload_off += src + len;
             b.start(b.base + src + len, b.limit - (src + len));
             continue;
@@ -270,7 +619,8 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             if (lane < 32) lens[288 + lane] = 5;
             __builtin_amdgcn_wave_barrier();
             if (!build_code(lens, 288, sym_ll, ll) || !build_code(lens + 288, 30, sym_d, dd)) return false;
-            build_lut(ll, sym_ll, lens, lut);
+            build_lut2(ll, sym_ll, lens, lut2);
+            build_dlut(dd, sym_d, lens + 288, dlut);
         } else {           // dynamic code (3.2.7)
             const int hlit = (int)b.take(5) + 257, hdist = (int)b.take(5) + 1, hclen = (int)b.take(4) + 4;
             if (hlit > 286 || hdist > 30) return false;
@@ -303,62 +653,53 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             __builtin_amdgcn_wave_barrier();
             if (lens[32 + 256] == 0) return false;   // no end-of-block code
             if (!build_code(lens + 32, hlit, sym_ll, ll) || !build_code(lens + 32 + hlit, hdist, sym_d, dd)) return false;
-            build_lut(ll, sym_ll, lens + 32, lut);
+            build_lut2(ll, sym_ll, lens + 32, lut2);
+            build_dlut(dd, sym_d, lens + 32 + hlit, dlut);
         }
+        // the symbols: sym_run does the common cases without leaving its asm block; what it hands back is rare
         for (;;) {
-            // the common case first, as tight as it gets (the decoder is bound by the CU's one scalar unit): a run of
-            // literals through the direct table.  Bit 8 of an entry says "not a literal" (a length code, the end of the
-            // block, or the marker of a code longer than the table).
-            uint32_t e;
-            for (;;) {
-                b.refill();
-                e = uni(lut[(uint32_t)b.buf & ((1u << LUT_BITS) - 1u)]);
-                if (e & 0x100u) break;
-                const int l = (int)(e >> 12);
-                b.buf >>= l; b.cnt -= l;
-                if (lane == ns) mylit = e;
-                if (++ns == 64) {
-                    if (pos + 64 > usize) return false;
-                    out[pos + lane] = (uint8_t)mylit;
-                    pos += 64; ns = 0;
-                }
+            const int why = sym_run(b, lut2, dlut, out, usize, st, mylit);
+            if (why == 2) { b.refill(); continue; }              // (with st.len set it resumes in the distance half)
+            if (why == 5) return false;
+            if (why == 4) { copy(st.len, st.dist); st.len = 0; continue; }
+            if (why == 3) {   // a distance code the direct table does not hold (longer than 8 bits, or none): the lane method judges it
+                const int ds = decode_sym(b, dd, sym_d);
+                if (ds < 0 || ds > 29) return false;
+                const int dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));
+                if (dist > st.pos + st.ns || st.pos + st.ns + st.len > usize) return false;
+                flush();
+                copy(st.len, dist);
+                st.len = 0;
+                continue;
             }
+            // why == 0: end of block, a literal / length code longer than the table's index, or no code at all
+            const uint32_t e = st.e & 0xFFFFu;
             int s;
             if (e != LUT_LONG) { s = (int)(e & 0xFFFu); const int l = (int)(e >> 12); b.buf >>= l; b.cnt -= l; }
             else { s = decode_sym(b, ll, sym_ll); if (s < 0) return false; }
             if (s < 256) {   // a literal with a long code
-                if (lane == ns) mylit = (uint32_t)s;
-                if (++ns == 64) {
-                    if (pos + 64 > usize) return false;
-                    out[pos + lane] = (uint8_t)mylit;
-                    pos += 64; ns = 0;
+                mylit = wrlane((uint32_t)s, st.ns, mylit);
+                if (++st.ns >= 63) {
+                    if (st.pos + st.ns > usize) return false;
+                    flush();
                 }
                 continue;
             }
             if (s == 256) break;
             if (s > 285) return false;
-            const int len = (int)(rdlane(lbase, s - 257) + b.take((int)rdlane(lext, s - 257)));
-            b.refill();
-            const int ds = decode_sym(b, dd, sym_d);
-            if (ds < 0 || ds > 29) return false;
-            const int dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));
-            if (dist > pos + ns || pos + ns + len > usize) return false;
-            flush();
-            // out[pos + i] = out[pos - dist + i]; with dist < len the source repeats with period dist: only bytes in front of
-            // pos are read
-            for (int i = lane; i < len; i += 64) out[pos + i] = out[pos - dist + (dist >= len ? i : i % dist)];
-            pos += len;
+            st.len = (int)(rdlane(lbase, s - 257) + b.take((int)rdlane(lext, s - 257)));   // sym_run goes on with its distance
         }
     }
-    if (pos + ns > usize) return false;
+    if (st.pos + st.ns > usize) return false;
     flush();
-    return pos == usize;
+    return st.pos == usize;
 }
 
 static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
     __shared__ uint16_t s_ll[WAVES][288 + 32];   // sorted literal/length symbols, then the distance symbols
     __shared__ uint8_t s_len[WAVES][320 + 64];
-    __shared__ __attribute__((aligned(4))) uint16_t s_lut[WAVES][1 << LUT_BITS];
+    __shared__ uint32_t s_lut[WAVES][1 << LUT_BITS];
+    __shared__ uint32_t s_dlut[WAVES][1 << DLUT_BITS];
     __shared__ uint32_t s_crc_tab[256], s_x2n[32];
     crc_tables(s_crc_tab, s_x2n);
     __syncthreads();
@@ -367,7 +708,7 @@ static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
     if (bi >= a.n_blocks) return;
     const DevBlock blk = a.blocks[bi];
     bool ok = inflate_block(a.comp + blk.coff, (int64_t)(a.comp_bytes - blk.coff), (int)blk.csize, a.out + blk.uoff, (int)blk.usize,
-                            s_ll[wave], s_ll[wave] + 288, s_len[wave], s_lut[wave]);
+                            s_ll[wave], s_ll[wave] + 288, s_len[wave], s_lut[wave], s_dlut[wave]);
     // (the wave reads back what it stored itself: same L1, program order)
     if (ok) ok = block_crc32(a.out + blk.uoff, (int)blk.usize, s_crc_tab, s_x2n) == blk.crc;
     if (!ok && (threadIdx.x & 63) == 0) atomicMin(a.first_bad, (unsigned long long)bi);
