@@ -13,6 +13,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <future>
 
 #include <errno.h>
 #include <fcntl.h>
@@ -71,6 +72,13 @@ struct bzq_ingest {
     int gz_cur = 0;
     uint64_t gz_cap = 0, gz_have = 0, gz_off = 0;   // capacity, bytes waiting, file offset of the next compressed byte
     bool gz_more = false, gz_done = false;
+    // read-ahead: while piece k is decoded, helper threads read piece k + 1 into the other slot's pinned buffer
+    uint64_t gz_piece = 0;             // compressed bytes per piece
+    std::thread gz_reader;
+    bool gz_read_pending = false, gz_read_ok = true;
+    int gz_read_buf = 0;               // which pinned buffer the pending / last read went to
+    uint64_t gz_read_len = 0;
+    std::string gz_read_err;
     bzq::IngestSlot slot[bzq::INGEST_SLOTS];
     hipStream_t copy_stream = nullptr;   // H2D of the chunks
     hipStream_t inflate_stream[bzq::INGEST_SLOTS] = {};   // device inflate: one stream per slot, so that the chunks' kernels overlap
@@ -294,24 +302,39 @@ inline bool read_bgzf_window(bzq_ingest* g, uint8_t* pinned, uint64_t cap, bzq::
     return true;
 }
 
-// Device gzip: decode pieces of the file into the FIFO until it holds a chunk (or the stream ends).  A piece is sized from the
-// last pieces' compression ratio so that its output fits the free half of the FIFO; the decoder keeps what does not.
-inline bool gz_fill_fifo(bzq_ingest* g, uint8_t* pinned, std::string& err) {
+// Device gzip: decode pieces of the file into the FIFO until it holds a chunk (or the stream ends).  Pieces have a fixed size
+// (half a chunk of compressed bytes: enough block starts to fill the device) and are read AHEAD: while piece k is decoded,
+// helper threads read piece k + 1 into the other slot's pinned buffer.  The FIFO is sized so that a piece's output always fits
+// behind a chunk that is still waiting in it (6 chunks; beyond a ratio of 10 the decoder keeps the rest and is asked again).
+inline void gz_start_read(bzq_ingest* g, int buf) {
+    const uint64_t len = std::min<uint64_t>(g->gz_piece, g->file_size - g->gz_off), off = g->gz_off;
+    g->gz_off += len;
+    g->gz_read_buf = buf; g->gz_read_len = len; g->gz_read_pending = true;
+    uint8_t* dst = g->slot[buf].pinned + g->reserve;
+    g->gz_reader = std::thread([g, dst, off, len]() {
+        g->gz_read_ok = parallel_pread(g->fd, dst, off, len, g->n_threads, g->gz_read_err, g->fd_direct, &g->numa_cpus);
+    });
+}
+inline bool gz_fill_fifo(bzq_ingest* g, std::string& err) {
     while (g->gz_have < g->chunk_bytes && !g->gz_done) {
-        const uint64_t free_bytes = g->gz_cap - g->gz_have, remaining = g->file_size - g->gz_off;
+        const uint64_t free_bytes = g->gz_cap - g->gz_have;
+        const uint8_t* src = nullptr;
         uint64_t want = 0;
-        if (!g->gz_more) {
-            want = (uint64_t)((double)free_bytes * g->ratio_est * 0.8);
-            want = std::min<uint64_t>({std::max<uint64_t>(want, 64u << 10), g->chunk_bytes, remaining});
-            if (want && !parallel_pread(g->fd, pinned, g->gz_off, want, g->n_threads, err, g->fd_direct, &g->numa_cpus)) return false;
-            g->gz_off += want;
+        bool file_done = g->gz_off >= g->file_size && !g->gz_read_pending;
+        if (!g->gz_more && !file_done) {
+            if (!g->gz_read_pending) gz_start_read(g, 0);
+            g->gz_reader.join();
+            g->gz_read_pending = false;
+            if (!g->gz_read_ok) { err = g->gz_read_err; return false; }
+            src = g->slot[g->gz_read_buf].pinned + g->reserve;
+            want = g->gz_read_len;
+            file_done = g->gz_off >= g->file_size;
+            if (!file_done) gz_start_read(g, g->gz_read_buf ^ 1);   // the next piece travels from the disk while this one is decoded
+            // (gz_read_buf now names the NEXT buffer; `src` keeps this one)
         }
-        const bool file_done = g->gz_off >= g->file_size;
         uint64_t got = 0;
         int32_t more = 0;
-        const uint64_t consumed0 = g->gz_dev->stats.bytes_consumed;
-        if (bzq::gz::gz_decode(g->gz_dev, pinned, want, file_done, g->gz_fifo[g->gz_cur] + g->gz_have, free_bytes, &got, &more) < 0) { err = g->gz_dev->err; return false; }
-        if (got) g->ratio_est = std::min(1.0, std::max(0.01, 0.5 * g->ratio_est + 0.5 * (double)(g->gz_dev->stats.bytes_consumed - consumed0) / (double)got));
+        if (bzq::gz::gz_decode(g->gz_dev, src, want, file_done, g->gz_fifo[g->gz_cur] + g->gz_have, free_bytes, &got, &more) < 0) { err = g->gz_dev->err; return false; }
         g->gz_have += got;
         g->gz_more = more != 0;
         g->gz_done = (file_done && !more) || g->gz_dev->finished;
@@ -351,7 +374,7 @@ inline void ingest_producer(bzq_ingest* g) {
         const auto t0 = std::chrono::steady_clock::now();
         std::string err;
         if (g->gz_dev) {
-            ok = gz_fill_fifo(g, s.pinned + g->reserve, err);
+            ok = gz_fill_fifo(g, err);
             len = std::min<uint64_t>(g->gz_have, g->chunk_bytes);
             eof = g->gz_done && g->gz_have <= g->chunk_bytes;
         } else if (g->gpu_inflate) {
@@ -420,6 +443,7 @@ inline void ingest_free(bzq_ingest* g) {
         g->cv.notify_all();
     }
     if (g->producer.joinable()) g->producer.join();
+    if (g->gz_reader.joinable()) g->gz_reader.join();   // (a read-ahead still writing into a slot's pinned buffer)
     (void)hipSetDevice(g->device);
     if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
     for (int i = 0; i < INGEST_SLOTS; ++i) {
