@@ -28,7 +28,7 @@ namespace bzq {
 // Two: a third slot was measured (BGZF 15.8 -> 16.0 GB/s end to end: the device inflate is already at 3/4 of its kernel rate
 // with two chunks' blocks in flight) and costs another 288 MiB of pinning in front of a mid-sized file (plain 3 GB file: 50 ->
 // 37 GB/s including the open).
-constexpr int INGEST_SLOTS = 2;
+constexpr int INGEST_SLOTS = 3;
 
 struct IngestSlot {
     uint8_t* pinned = nullptr;     // reserve + chunk_bytes
