@@ -157,11 +157,22 @@ struct bzq_ctx {
     uint64_t shard_totals[3] = {0, 0, 0};   // records, bases, bytes over all ranks after the last bzq_shard_stitch
     bool have_shard_totals = false;
     float ms_scan_shard = 0.f;         // kernels of the bzq_shard_scan that preceded this submit (pass A + scan)
-    // stream parsed in several chunks: absolute record ends of everything delivered so far (8 B per record), so that the
-    // reference's window can be replayed from the stream's first byte when the stream ends in bytes that are not a record
-    // Kept in fixed-size blocks that are never moved (no reallocation, no copy, no stall on the hot path).
-    std::vector<DevBuf> tail_log;
-    int64_t records_before = -1;   // option "records_before": records delivered by earlier chunks; < 0 = no log
+    // A stream parsed in several chunks: where the reference's BufferedReader window stands behind every record handed out so
+    // far (option "records_before").  Which outcome the reference gives for a stream that ends in bytes that are not a record
+    // depends on that window, and the window on every record since the stream's first byte -- but only through
+    // a state of three integers.  The record ends of chunk k come back to the host behind its parse (8 B per record, pinned,
+    // asynchronous) and are walked while chunk k + 1 is being parsed, as soon as the caller has said how many of them it took
+    // (records_before of the next submit).  (Rounds 1-2 kept every record end of the whole stream on the device for this:
+    // 5 GB for a 625 M-read stream.)
+    int64_t records_before = -1;   // option "records_before": records delivered by earlier chunks; < 0 = every chunk a stream of its own
+    Window follow;                 // the window behind the last record walked (N = "unbounded" until the stream's end is known)
+    int64_t follow_head = 0, follow_records = 0;   // stream offset behind that record; records walked
+    bool follow_on = false;
+    int64_t* stage_pin = nullptr;  // record ends of the last parsed chunk, chunk relative (pinned)
+    size_t stage_cap = 0;
+    int64_t stage_n = 0, stage_rb = 0, stage_pos = 0, stage_head = 0;
+    bool stage_valid = false;
+    hipEvent_t stage_ev = nullptr;
 };
 
 namespace {
@@ -189,39 +200,8 @@ int ensure(bzq_ctx* c, DevBuf& b, size_t bytes) {
     return 0;
 }
 
-static __global__ void k_log_ends(const int64_t* __restrict__ rec_end, int64_t n, int64_t stream_pos, int64_t* __restrict__ log) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n) log[r] = stream_pos + rec_end[r];
-}
-
-// The stream's record-end log (option records_before): fixed blocks of LOG_BLOCK records, allocated as the stream grows
-// and never moved, so logging a chunk costs one small kernel per block it touches and nothing else.
-constexpr int64_t LOG_BLOCK = 1ll << 20;   // records per block (8 MiB)
 constexpr int64_t BB_MAX_BATCHES = 1ll << 20;   // batch-boundary table kept for chunks of at most this many batches (16 MiB)
-int log_record_ends(bzq_ctx* c, int64_t first, int64_t n, const int64_t* d_rec_end, int64_t stream_pos) {
-    int64_t done = 0;
-    while (done < n) {
-        const int64_t idx = first + done, blk = idx / LOG_BLOCK, in = idx - blk * LOG_BLOCK;
-        while ((int64_t)c->tail_log.size() <= blk) {
-            DevBuf b;
-            int rc;
-            if ((rc = ensure(c, b, (size_t)LOG_BLOCK * 8))) return rc;
-            c->tail_log.push_back(b);
-        }
-        const int64_t m = std::min(n - done, LOG_BLOCK - in);
-        hipLaunchKernelGGL(k_log_ends, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream, d_rec_end + done, m, stream_pos,
-                           (int64_t*)c->tail_log[(size_t)blk].p + in);
-        done += m;
-    }
-    return 0;
-}
-int fetch_record_ends(bzq_ctx* c, int64_t n, int64_t* dst) {   // cold path: the first n logged record ends to the host
-    for (int64_t done = 0; done < n; done += LOG_BLOCK) {
-        const int64_t m = std::min(n - done, LOG_BLOCK);
-        HIPCHK(c, hipMemcpy(dst + done, c->tail_log[(size_t)(done / LOG_BLOCK)].p, (size_t)m * 8, hipMemcpyDeviceToHost));
-    }
-    return 0;
-}
+int follow_consume(bzq_ctx* c);   // (defined behind the window arithmetic)
 
 int64_t tiles_for(uint64_t n) { return (int64_t)((n + TILE - 1) / TILE); }
 
@@ -684,7 +664,7 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
     c->pending = true; c->have_result = false;
-    return 0;
+    return follow_consume(c);   // (host work: it overlaps the parse that was just enqueued)
 }
 
 // Replays the reference's BufferedReader over the delivered records to learn the window state at
@@ -751,6 +731,49 @@ int classify_tail(bzq_ctx* c, const std::vector<int64_t>& rec_end, int64_t N, in
     int64_t head = first_header;
     window_walk(s, head, rec_end.data(), rec_end.size(), 0, c->cfg);
     return window_classify(s, consumed, c->cfg, tail_phase, tail_nonblank, accept_last, phase_out, cap_out);
+}
+
+constexpr int64_t FOLLOW_UNBOUNDED = 1ll << 60;
+// The caller has told (records_before of the chunk being submitted) how many records of the previous chunk it took: walk the
+// window over exactly those.  Comparisons of the walk only involve records that exist, so the stream's still unknown length
+// does not enter (Window::N = unbounded; window_classify gets the true length, and `end` clipped to it, at the stream's end).
+int follow_consume(bzq_ctx* c) {
+    if (c->records_before < 0 || c->shard_mode) { c->stage_valid = false; c->follow_on = false; return 0; }
+    if (c->records_before == 0) { c->stage_valid = false; c->follow_on = false; return 0; }   // a new stream starts with this chunk
+    if (!c->stage_valid) return 0;   // (nothing staged: the follower stays where it is, or off)
+    const int64_t taken = std::max<int64_t>(0, std::min<int64_t>(c->stage_n, c->records_before - c->stage_rb));
+    HIPCHK(c, hipEventSynchronize(c->stage_ev));
+    if (c->stage_rb == 0 || !c->follow_on) {   // the stream's first chunk: BufferedReader.__init__
+        if (c->stage_rb != 0) { c->stage_valid = false; return 0; }   // (a stream picked up in the middle: no window to follow)
+        window_start(c->follow, c->cfg, FOLLOW_UNBOUNDED);
+        c->follow_head = c->stage_head;
+        c->follow_records = 0;
+        c->follow_on = true;
+    }
+    if (c->follow_records != c->stage_rb) { c->follow_on = false; c->stage_valid = false; return 0; }   // records_before jumped: not one stream
+    window_walk(c->follow, c->follow_head, c->stage_pin, (size_t)taken, c->stage_pos, c->cfg);
+    c->follow_records += taken;
+    c->stage_valid = false;
+    return 0;
+}
+// Behind a parsed chunk of a multi-chunk stream: its record ends to the host, asynchronously
+int follow_stage(bzq_ctx* c, int64_t n_complete) {
+    c->stage_valid = false;
+    if (c->records_before < 0 || c->shard_mode) return 0;
+    if ((size_t)n_complete > c->stage_cap) {
+        if (c->stage_pin) { HIPCHK(c, hipStreamSynchronize(c->stream)); HIPCHK(c, hipHostFree(c->stage_pin)); c->stage_pin = nullptr; c->stage_cap = 0; }
+        const size_t want = (size_t)n_complete + (size_t)n_complete / 4 + 1024;
+        if (hipHostMalloc((void**)&c->stage_pin, want * 8, hipHostMallocDefault) != hipSuccess) { c->err = "pinned staging for the record ends"; return BZQ_ERR_NOMEM; }
+        c->stage_cap = want;
+    }
+    if (!c->stage_ev) HIPCHK(c, hipEventCreateWithFlags(&c->stage_ev, hipEventDisableTiming));
+    if (n_complete > 0) HIPCHK(c, hipMemcpyAsync(c->stage_pin, c->o().rec_end.p, (size_t)n_complete * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->stage_ev, c->stream));
+    c->stage_n = n_complete; c->stage_rb = c->records_before;
+    c->stage_pos = (int64_t)c->cur_stream_pos;
+    c->stage_head = (int64_t)c->cur_stream_pos + c->cur_first_header;
+    c->stage_valid = true;
+    return 0;
 }
 
 void sb_put(std::string& s, const char* label, long long v) {
@@ -872,10 +895,11 @@ void bzq_destroy(bzq_ctx* c) {
         for (DevBuf& b : o.view_blocks) bufs.push_back(&b);
         if (o.h_bb) (void)hipHostFree(o.h_bb);
     }
-    for (DevBuf& b : c->tail_log) bufs.push_back(&b);
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
+    if (c->stage_pin) (void)hipHostFree(c->stage_pin);
+    if (c->stage_ev) (void)hipEventDestroy(c->stage_ev);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
     for (hipEvent_t e : c->ev_detail) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -1170,9 +1194,9 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     r.status = BZQ_OK;
     c->term_phase = 0; c->term_cap = c->cfg.buffer_capacity;
 
-    if (c->records_before >= 0 && !c->shard_mode && n_complete > 0) {
+    if (c->records_before >= 0 && !c->shard_mode && !c->cur_is_eof) {   // (a stream's last chunk walks its own records below, if it has to)
         int rc2;
-        if ((rc2 = log_record_ends(c, c->records_before, n_complete, (const int64_t*)c->o().rec_end.p, (int64_t)c->cur_stream_pos))) return rc2;
+        if ((rc2 = follow_stage(c, n_complete))) return rc2;
     }
     auto key_rec = [](u64 k) { return (int64_t)(k >> 3); };
     // first failing record among the complete ones; same record: buffer < structure < validation
@@ -1192,21 +1216,23 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         if (consumed >= n) {
             r.status = BZQ_EOF;
         } else {
-            // the records the window has passed over: this chunk's, or -- for a stream that came in several chunks and
-            // was logged -- every record since the stream's first byte, in stream offsets
-            const int64_t rb = c->records_before > 0 ? c->records_before : 0;
-            std::vector<int64_t> re((size_t)(rb + n_complete));
-            int64_t N = (int64_t)n, cons = consumed, fh = c->cur_first_header;
-            if (rb > 0) {
-                HIPCHK(c, hipStreamSynchronize(c->stream));
-                int rc3;
-                if ((rc3 = fetch_record_ends(c, (int64_t)re.size(), re.data()))) return rc3;
-                N += (int64_t)c->cur_stream_pos; cons += (int64_t)c->cur_stream_pos; fh = 0;
-            } else if (n_complete) {
-                HIPCHK(c, hipMemcpy(re.data(), c->o().rec_end.p, (size_t)n_complete * 8, hipMemcpyDeviceToHost));
-            }
+            // the records the window has passed over: this chunk's -- behind, for a stream that came in several chunks, the window
+            // state the follower carried over every record handed out before it (stream offsets)
+            std::vector<int64_t> re((size_t)n_complete);
+            if (n_complete) HIPCHK(c, hipMemcpy(re.data(), c->o().rec_end.p, (size_t)n_complete * 8, hipMemcpyDeviceToHost));
             int ph = 0; int64_t cap = c->cfg.buffer_capacity;
-            int code = classify_tail(c, re, N, fh, cons, tail_phase, h->tail_nonblank != 0, &accept_last, &ph, &cap);
+            int code;
+            if (c->records_before > 0 && c->follow_on && c->follow_records == c->records_before) {
+                Window sw = c->follow;
+                int64_t head = c->follow_head;
+                const int64_t N = (int64_t)c->cur_stream_pos + (int64_t)n;
+                window_walk(sw, head, re.data(), re.size(), (int64_t)c->cur_stream_pos, c->cfg);
+                sw.N = N;
+                if (sw.end > N) sw.end = N;
+                code = window_classify(sw, (int64_t)c->cur_stream_pos + consumed, c->cfg, tail_phase, h->tail_nonblank != 0, &accept_last, &ph, &cap);
+            } else {
+                code = classify_tail(c, re, (int64_t)n, c->cur_first_header, consumed, tail_phase, h->tail_nonblank != 0, &accept_last, &ph, &cap);
+            }
             c->term_phase = ph; c->term_cap = cap;
             if (accept_last) {
                 // last record without trailing newline (Q4): structure check skipped, validation still applies

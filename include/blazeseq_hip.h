@@ -214,10 +214,12 @@ int32_t bzq_get_config(const bzq_ctx* ctx, bzq_config* out);
 /* Run-time knobs that are not part of ParserConfig: "pass_bytes" (bytes per kernel round),
  * "timing_detail" (per-kernel hipEvent timing in bzq_chunk), "force_dense" (tests: route every
  * tile through the serial in-kernel path), "records_before" (a stream submitted in SEVERAL chunks: the
- * number of records delivered from earlier chunks, set before each bzq_submit_chunk_*; the ctx then keeps
- * the stream's record ends -- 8 bytes per record on the device -- so that trailing bytes that are not a
- * record are judged with the reference's BufferedReader window where it really sits, io/buffered.mojo:
- * 239-290; -1 (default) = each chunk is judged as a stream of its own; bzq_ingest_next sets it itself);
+ * number of records delivered from earlier chunks, set before each bzq_submit_chunk_*, 0 for the stream's first
+ * chunk; the ctx then follows the reference's BufferedReader window over the records handed out -- each chunk's
+ * record ends come back to the host behind its parse, 8 bytes per record, and are walked while the next
+ * chunk is parsed -- so that trailing bytes that are not a record are judged with that window where it
+ * really sits, io/buffered.mojo:239-290; -1 (default) = each chunk is judged as a stream of its own;
+ * bzq_ingest_next sets it itself);
  * "double_buffer" (1 default / 0: number of output sets, see the lifetime rule at the top). */
 int32_t bzq_set_option(bzq_ctx* ctx, const char* key, int64_t value);
 
