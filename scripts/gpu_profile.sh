@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $R
-BENCH="python bench.py --no-cpu-baseline $*"
+BENCH="python bench.py --no-cpu-baseline --no-extra-modes $*"   # (the extra figures of the default line run other inputs through the same kernels: they would blur the per-kernel averages)
 LONG="--steps 10 --warmup 3"; SHORT="--steps 2 --warmup 1 --min-seconds 0"   # PMC passes: no time-based warm-up (the counter databases grow with every dispatch)
 # another command under the same passes (e.g. scripts/bench_fasta.py): BZQ_PROFILE_CMD="python scripts/bench_fasta.py 0"
 if [ -n "${BZQ_PROFILE_CMD:-}" ]; then BENCH="$BZQ_PROFILE_CMD"; LONG=""; SHORT=""; fi

@@ -260,3 +260,31 @@ def test_shm_init_ignores_the_stale_segment_of_a_crashed_run(tmp_path):
     o1, e1 = p1.communicate(timeout=120)
     assert p0.returncode == 0 and p1.returncode == 0, (e0, e1)
     _check_sharded_outputs([o0, o1], data, False, 0)
+
+
+@pytest.mark.gpu
+def test_gunzip_from_plain_c(tmp_path):
+    """tests/c_driver/bzq_gunzip.c: a gzip file (three members, one of them flushed, header fields) through bzq_gzip_* with no
+    Python in the process == the bytes zlib gives; a damaged copy fails with exit code 3."""
+    import gzip
+    import zlib
+    from tests.gzip_util import gzip_member
+    from oracle import oracle as O
+    _build()
+    exe = os.path.join(DRV, "bzq_gunzip")
+    data = bytes(O.generate_synthetic(30_000, 150, 150, 33, 73, "generic"))
+    cut = len(data) // 3
+    comp = gzip_member(data[:cut], 6, name=b"reads.fastq") + gzip_member(data[cut:2 * cut], 1, flush_every=200000) + gzip_member(data[2 * cut:], 9, zlib.Z_DEFAULT_STRATEGY, hcrc=True)
+    assert gzip.decompress(comp) == data
+    path = tmp_path / "reads.fastq.gz"
+    path.write_bytes(comp)
+    for piece, cap in ((8 << 20, 64 << 20), (300_000, 12 << 20), (65_536, 9 << 20)):
+        r = subprocess.run([exe, str(path), str(piece), str(cap), "8192"], capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert r.stdout == data, (piece, cap, len(r.stdout), len(data))
+        assert b"members=3" in r.stderr and b"finished=1" in r.stderr
+    bad = bytearray(comp)
+    bad[len(bad) // 2] ^= 0x20
+    path.write_bytes(bytes(bad))
+    r = subprocess.run([exe, str(path)], capture_output=True, timeout=300)
+    assert r.returncode == 3 and b"bzq_gzip" in r.stderr
