@@ -61,6 +61,7 @@ enum : int32_t {
     ST_POOL_FULL = 6,
     ST_LOST = 7,         // passed over more than MAX_PASSED candidates: stopped at the block boundary `end`
     ST_EVENTS_FULL = 8,
+    ST_TOO_BIG = 10,     // one block's output went beyond what the caller's buffer can take at all (a decoder fed garbage, or a block larger than out_capacity)
     ST_SPLIT = 9         // its output reached max_job_syms: stopped at the block boundary `end` (bounds what one job can ask of the caller's buffer)
 };
 
@@ -84,6 +85,7 @@ struct Args {
     uint32_t* counters;                      // [0] pages taken, [1] events taken
     Event* events; uint32_t max_events;
     int64_t max_job_syms;                    // a job stops at the first boundary at which it has stored this much
+    int64_t hard_cap_syms;                   // ... and gives up in the middle of a block beyond this much (bounds what a wrong guess can take from the pool)
 };
 
 // ---- the bit reader of one wave (cf. inf::Bits), addressed by absolute bit offset in the piece -------------------------------
@@ -414,8 +416,9 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
     uint16_t *cur = nullptr, *prev = nullptr;
     int64_t cur_idx = -1;
     uint32_t cur_page = NO_PAGE;
-    bool pool_full = false;
+    bool pool_full = false, too_big = false;
     auto ensure = [&](int64_t p_end) -> bool {   // pages for positions < p_end
+        if (p_end > a.hard_cap_syms) { too_big = true; return false; }
         while (((p_end - 1) >> PAGE_SHIFT) > cur_idx) {
             uint32_t np = 0;
             if (lane == 0) np = atomicAdd(&a.counters[0], 1u);
@@ -444,7 +447,7 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
     Code ll, dd;
     for (;;) {
         // ---- a boundary: everything in front of `pos` is decoded
-        if (!flush()) { status = ST_POOL_FULL; break; }
+        if (!flush()) { status = too_big ? ST_TOO_BIG : ST_POOL_FULL; break; }
         o.end = pos; o.out_syms = (u64)opos;
         if (pos != job.start) {
             bool hit = false;
@@ -484,8 +487,8 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
             if ((len ^ nlen) != 0xFFFFu) ok = false;
             else if (src + (int64_t)len > a.n) { ok = false; b.ran_out = 1; }
             else {
-                if (!flush()) { status = ST_POOL_FULL; break; }
-                for (int64_t done = 0; done < (int64_t)len && !pool_full;) {
+                if (!flush()) { status = too_big ? ST_TOO_BIG : ST_POOL_FULL; break; }
+                for (int64_t done = 0; done < (int64_t)len && !pool_full && !too_big;) {
                     const int64_t p = opos + done;
                     const int room = PAGE - (int)(p & (PAGE - 1));
                     const int m = (int)((int64_t)len - done < room ? (int64_t)len - done : room);
@@ -494,7 +497,7 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
                     for (int i = lane; i < m; i += 64) dst[i] = a.comp[src + done + i];
                     done += m;
                 }
-                if (pool_full) { status = ST_POOL_FULL; break; }
+                if (pool_full || too_big) { status = too_big ? ST_TOO_BIG : ST_POOL_FULL; break; }
                 opos += len;
                 b.start(a.comp, a.n, 8 * (src + (int64_t)len));
             }
@@ -550,13 +553,14 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
                 st.len = (int)(rdlane(lbase, s - 257) + b.take((int)rdlane(lext, s - 257)));   // sym_run_gz goes on with its distance
             }
         }
+        if (too_big) { status = ST_TOO_BIG; break; }
         if (pool_full) { status = ST_POOL_FULL; break; }
         if (!ok || b.beyond()) {   // invalid data -- unless the reader had run out of input: then the block is just not whole yet
             status = b.beyond() ? ST_NEED_MORE : ST_ERROR;
             o.err_bit = (u64)b.bitpos();
             break;
         }
-        if (!flush()) { status = ST_POOL_FULL; break; }
+        if (!flush()) { status = too_big ? ST_TOO_BIG : ST_POOL_FULL; break; }
         const int64_t bit = b.bitpos();
         if (last) {   // member trailer: CRC-32 and ISIZE behind the next byte edge (checked by the host from the event)
             const int64_t T = (bit + 7) >> 3;
@@ -590,6 +594,11 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_decode(Args a) {
 }
 
 // ---- FIND: the first position in chunk c at which a block (or a member) can start ----------------------------------------------
+// 512 bit positions per round, in two stages.  Stage 1, every lane 8 positions: the 13 header bits that need no arithmetic
+// (BFINAL = 0, BTYPE = 10, HLIT <= 29, HDIST <= 29: 11 % of random positions pass) and, at byte positions, the member magic.
+// Stage 2, the survivors COMPACTED onto the lanes in stream order: 128 bits of the stream each, the code length code must be
+// complete (a 19-step Kraft sum) -- run once per 64 survivors instead of once per 64 positions.  Whoever passes that is judged
+// by the whole wave, in stream order: all three Huffman codes of the header must be ones zlib accepts.
 static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
     __shared__ uint16_t s_ll[WAVES][288 + 32];
     __shared__ uint8_t s_len[WAVES][320 + 64];
@@ -601,19 +610,73 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
     uint16_t* sym_d = s_ll[wave] + 288;
     uint8_t* lens = s_len[wave];
     const int64_t lo = (int64_t)c * a.chunk_bytes, hi = lo + a.chunk_bytes < a.n ? lo + a.chunk_bytes : a.n;
+    const u64 below = (1ull << lane) - 1ull;
     u64 found = POS_NONE;
-    for (int64_t P0 = 8 * lo; P0 < 8 * hi && found == POS_NONE; P0 += 64) {
-        const int64_t P = P0 + lane, byte = P >> 3;
-        const int sh = (int)(P & 7);
-        // 128 bits of the stream from this lane's byte on (the buffer has 64 bytes of slack behind the piece)
-        const uint32_t d0 = reinterpret_cast<const U32U*>(a.comp + byte)->v, d1 = reinterpret_cast<const U32U*>(a.comp + byte + 4)->v;
-        const uint32_t d2 = reinterpret_cast<const U32U*>(a.comp + byte + 8)->v, d3 = reinterpret_cast<const U32U*>(a.comp + byte + 12)->v;
-        const u64 lo64 = (u64)d0 | ((u64)d1 << 32), hi64 = (u64)d2 | ((u64)d3 << 32);
-        const u64 v = sh ? (lo64 >> sh) | (hi64 << (64 - sh)) : lo64, vh = hi64 >> sh;
-        // BFINAL = 0, BTYPE = 10, HLIT <= 29, HDIST <= 29, the code length code complete
-        const uint32_t hlit = (uint32_t)(v >> 3) & 31u, hdist = (uint32_t)(v >> 8) & 31u, hclen = ((uint32_t)(v >> 13) & 15u) + 4u;
-        bool dyn = ((uint32_t)v & 7u) == 4u && hlit <= 29u && hdist <= 29u && P + 17 + 3 * (int64_t)hclen <= 8 * a.n;
-        if (dyn) {
+    auto judge_dynamic = [&](int64_t Q) -> bool {
+        GBits b;
+        Code ll, dd;
+        b.start(a.comp, a.n, Q + 3);
+        return read_dynamic(b, lens, sym_ll, sym_d, nullptr, nullptr, ll, dd, false) && !b.beyond();
+    };
+    auto judge_header = [&](int64_t B) -> bool {   // a member header ... followed by a block header that can be one
+        const int64_t dpos = parse_member_header(a.comp, a.n, B);
+        if (dpos <= 0) return false;
+        GBits b;
+        Code ll, dd;
+        b.start(a.comp, a.n, 8 * dpos);
+        b.refill();
+        (void)b.take(1);
+        const uint32_t type = b.take(2);
+        if (type == 3) return false;
+        if (type == 0) { b.take(b.cnt & 7); b.refill(); const uint32_t len = b.take(16), nlen = b.take(16); return (len ^ nlen) == 0xFFFFu; }
+        if (type == 2) return read_dynamic(b, lens, sym_ll, sym_d, nullptr, nullptr, ll, dd, false) && !b.beyond();
+        return true;
+    };
+    for (int64_t P0 = 8 * lo; P0 < 8 * hi && found == POS_NONE; P0 += 512) {
+        // stage 1
+        u64 pass[8], hdrm[8];
+        int total = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int64_t P = P0 + 64 * j + lane, byte = P >> 3;
+            const int sh = (int)(P & 7);
+            const uint32_t d0 = reinterpret_cast<const U32U*>(a.comp + byte)->v;   // (64 bytes of slack behind the piece)
+            const uint32_t v = d0 >> sh;
+            const bool in = P < 8 * hi;
+            const bool dyn = in && (v & 7u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u && P + 17 + 3 * (int64_t)(((v >> 13) & 15u) + 4u) <= 8 * a.n;
+            const bool hdr = in && sh == 0 && (d0 & 0xFFFFFFu) == 0x088B1Fu && ((d0 >> 24) & 0xE0u) == 0 && byte + 18 <= a.n;
+            pass[j] = __ballot(dyn);
+            hdrm[j] = __ballot(hdr);
+            total += __builtin_popcountll(pass[j]);
+        }
+        // stage 2: survivor k of the round (stream order: j-major, lane-minor) goes to lane k & 63
+        u64 first_dyn = POS_NONE;
+        for (int k0 = 0; k0 < total && first_dyn == POS_NONE; k0 += 64) {
+            const int k = k0 + lane;
+            int j = 0, rem = k;
+            u64 mj = pass[0];
+#pragma unroll
+            for (int jj = 0; jj < 7; ++jj) {
+                const int cj = __builtin_popcountll(pass[jj]);
+                if (j == jj && rem >= cj) { j = jj + 1; rem -= cj; mj = pass[jj + 1]; }
+            }
+            const bool have = k < total;
+            int lp = 0;   // select(mj, rem): six halving steps
+            {
+                u64 x = mj; int kk = have ? rem : 0;
+#pragma unroll
+                for (int h = 32; h >= 1; h >>= 1) {
+                    const int cc = __builtin_popcountll(x & ((1ull << h) - 1ull));
+                    if (kk >= cc) { lp += h; kk -= cc; x >>= h; }
+                }
+            }
+            const int64_t P = have ? P0 + 64 * j + lp : 8 * lo, byte = P >> 3;
+            const int sh = (int)(P & 7);
+            const uint32_t d0 = reinterpret_cast<const U32U*>(a.comp + byte)->v, d1 = reinterpret_cast<const U32U*>(a.comp + byte + 4)->v;
+            const uint32_t d2 = reinterpret_cast<const U32U*>(a.comp + byte + 8)->v, d3 = reinterpret_cast<const U32U*>(a.comp + byte + 12)->v;
+            const u64 lo64 = (u64)d0 | ((u64)d1 << 32), hi64 = (u64)d2 | ((u64)d3 << 32);
+            const u64 v = sh ? (lo64 >> sh) | (hi64 << (64 - sh)) : lo64, vh = hi64 >> sh;
+            const uint32_t hclen = ((uint32_t)(v >> 13) & 15u) + 4u;
             const u64 w = (v >> 17) | (vh << 47);
             uint32_t kraft = 0;
 #pragma unroll
@@ -621,39 +684,30 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
                 const uint32_t l = (uint32_t)(w >> (3 * i)) & 7u;
                 kraft += ((uint32_t)i < hclen && l) ? (128u >> l) : 0u;
             }
-            dyn = kraft == 128u;
-        }
-        const bool hdr = sh == 0 && (d0 & 0xFFFFFFu) == 0x088B1Fu && ((d0 >> 24) & 0xE0u) == 0 && byte + 18 <= a.n;
-        const bool in = P < 8 * hi;
-        const u64 m_dyn = __ballot(dyn && in), m_hdr = __ballot(hdr && in);
-        u64 m = m_dyn | m_hdr;
-        while (m && found == POS_NONE) {   // survivors in stream order, each judged by the whole wave
-            const int L = __builtin_ctzll(m);
-            m &= m - 1;
-            const int64_t Q = P0 + L;
-            GBits b;
-            Code ll, dd;
-            bool ok;
-            if ((m_hdr >> L) & 1ull) {
-                const int64_t dpos = parse_member_header(a.comp, a.n, Q >> 3);
-                ok = dpos > 0;
-                if (ok) {   // ... followed by a block header that can be one
-                    b.start(a.comp, a.n, 8 * dpos);
-                    b.refill();
-                    (void)b.take(1);
-                    const uint32_t type = b.take(2);
-                    if (type == 3) ok = false;
-                    else if (type == 0) { b.take(b.cnt & 7); b.refill(); const uint32_t len = b.take(16), nlen = b.take(16); ok = (len ^ nlen) == 0xFFFFu; }
-                    else if (type == 2) ok = read_dynamic(b, lens, sym_ll, sym_d, nullptr, nullptr, ll, dd, false) && !b.beyond();
-                }
-                if (ok) found = pos_header((u64)(Q >> 3));
-            } else {
-                b.start(a.comp, a.n, Q + 3);
-                ok = read_dynamic(b, lens, sym_ll, sym_d, nullptr, nullptr, ll, dd, false) && !b.beyond();
-                if (ok) found = pos_deflate((u64)Q);
+            u64 m2 = __ballot(have && kraft == 128u);
+            while (m2 && first_dyn == POS_NONE) {
+                const int L = __builtin_ctzll(m2);
+                m2 &= m2 - 1;
+                const int64_t Q = ((int64_t)rdlane((uint32_t)((u64)P >> 32), L) << 32) | (int64_t)rdlane((uint32_t)P, L);
+                if (judge_dynamic(Q)) first_dyn = pos_deflate((u64)Q);
             }
         }
+        // member headers of the round, up to the dynamic block that was found
+        u64 first_hdr = POS_NONE;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            u64 mh = hdrm[j];
+            while (mh && first_hdr == POS_NONE) {
+                const int L = __builtin_ctzll(mh);
+                mh &= mh - 1;
+                const int64_t Q = P0 + 64 * j + L;
+                if (pos_header((u64)(Q >> 3)) > first_dyn) { mh = 0; break; }
+                if (judge_header(Q >> 3)) first_hdr = pos_header((u64)(Q >> 3));
+            }
+        }
+        found = first_hdr < first_dyn ? first_hdr : first_dyn;
     }
+    (void)below;
     if (lane == 0) a.jobs[c] = Job{found, c + 1, 0};
 }
 
@@ -997,7 +1051,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         GZCHK(h, hipMemsetAsync(h->counters.p, 0, 16, s));
         GZCHK(h, hipMemcpyAsync(h->jobs.p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
         a = Args{d_comp, (int64_t)n, (Job*)h->jobs.p, (JobOut*)h->outs.p, 0, n_chunks, n_chunks, CH, (uint16_t*)h->pool.p, h->pool_pages,
-                 (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events, max_job};
+                 (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events, max_job, (int64_t)std::max<uint64_t>(out_cap, 1ull << 20)};
         const unsigned grid = (unsigned)((n_chunks + WAVES - 1) / WAVES);
         hipLaunchKernelGGL(k_gz_find, dim3(grid), dim3(BLOCK), 0, s, a);
         if (timing) { GZCHK(h, hipStreamSynchronize(s)); lap(1); }
@@ -1042,6 +1096,9 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         }
         if (o.status == ST_ERROR)
             return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: invalid DEFLATE data near byte " + std::to_string(h->stats.bytes_consumed + (o.err_bit >> 3)) + " of the compressed stream");
+        if (o.status == ST_TOO_BIG)
+            return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: out_capacity (" + std::to_string(out_cap) + ") is below the output of one DEFLATE block near byte " +
+                                                 std::to_string(h->stats.bytes_consumed + (o.end >> 4)) + " of the compressed stream");
         if (o.status == ST_POOL_FULL || o.status == ST_EMPTY) return gz_fail(h, BZQ_ERR_HIP, "bzq_gzip: internal: chain reached a job in state " + std::to_string(o.status));
         final_status = o.status; final_pos = o.end;
         break;
