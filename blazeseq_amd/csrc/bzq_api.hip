@@ -1758,7 +1758,7 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
             }
         } else if (gpu_inflate) {   // any other gzip file: rapidgzip's two-stage decode on the device (bzq_gzip.hpp)
             g->compression = 1;
-            g->gz_piece = std::max<uint64_t>(g->chunk_bytes / 2, 64ull << 10);
+            g->gz_piece = std::max<uint64_t>(g->chunk_bytes / 2, std::min<uint64_t>(g->chunk_bytes, 64ull << 10));   // (a piece is read into a slot's pinned buffer: never more than a chunk)
             g->gz_cap = std::max<uint64_t>(6 * g->chunk_bytes, 64ull << 20);
             int grc = bzq::gz::gz_open(device, &g->gz_dev, err);
             if (!grc && (hipMalloc((void**)&g->gz_fifo[0], g->gz_cap + 64) != hipSuccess || hipMalloc((void**)&g->gz_fifo[1], g->gz_cap + 64) != hipSuccess)) {

@@ -8,10 +8,11 @@
 // here, stage one and two on the device:
 //
 //   0. the compressed piece is cut into chunks of CH bytes.  FIND (k_gz_find, one wave per chunk): the first position in the
-//      chunk at which a DEFLATE block can start -- 64 lanes test 64 consecutive BIT offsets at once for a non-final dynamic
-//      block header whose code length code is complete (3 + 14 + up to 57 bits), survivors are validated by the whole wave
-//      (all three Huffman codes must be ones zlib accepts); byte positions are also tested for a gzip member header followed by
-//      a valid block header.  A false positive costs time, never correctness (below).
+//      chunk at which a DEFLATE block can start -- the lanes test 512 consecutive BIT offsets per round for a non-final dynamic
+//      block header (13 bits that need no arithmetic; the survivors, compacted onto the lanes, for a complete code length code:
+//      up to 57 more bits), what is left is validated by the whole wave (all three Huffman codes must be ones zlib accepts);
+//      byte positions are also tested for a gzip member header followed by a valid block header.  A false positive costs
+//      time, never correctness (below).
 //   1. DECODE (k_gz_decode, one wave per chunk that has a start): blocks are decoded from the chunk's start until the decoder
 //      arrives EXACTLY at a later chunk's start (a candidate it passes over without meeting it was a false positive and is
 //      dropped), through member trailers and member headers where they come.  What lies more than `pos` bytes back is not
@@ -21,8 +22,8 @@
 //   2. the host walks the chain (chunk 0 starts at a known position; every chunk names the chunk it ended on), and the device
 //      finishes: CHAIN (k_gz_chain, one workgroup, sequential over the chain, ~2 us per chunk): the 32 KiB window behind every
 //      chunk from the window in front of it -- the only serial step; RESOLVE (k_gz_resolve, one workgroup per page): every
-//      symbol to its byte, contiguous in the caller's buffer; CRC (k_gz_crc): CRC-32 of every 256 KiB piece of every member,
-//      combined on the host (crc32_combine) and checked against the member trailers together with ISIZE.
+//      symbol to its byte, contiguous in the caller's buffer; CRC (k_gz_crc): CRC-32 of every MiB of every member, combined on
+//      the host (crc32_combine) and checked against the member trailers together with ISIZE.
 //
 // Correctness does not rest on the speculation: the chain starts at an exact position and only ever follows exact ends, so
 // what is delivered is the sequential decode; a chunk the chain never lands on is ignored.  Streams that defeat the
@@ -593,6 +594,87 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_decode(Args a) {
     run_job(a, a.job_base + k, s_ll[wave], s_ll[wave] + 288, s_len[wave], s_lut[wave], s_dlut[wave]);
 }
 
+// ---- one lane's look at a dynamic block header: a NECESSARY condition, cheap ---------------------------------------------------
+// The whole-wave judgement (read_dynamic) costs ~30 us per candidate, and about one bit position in 2 000 passes the code length
+// code test: at 131 072 positions per chunk that was most of the finder's time.  Here every lane decodes the code lengths of ITS
+// candidate by itself -- a 7-bit direct table of the code length code in LDS (128 bytes per lane, lanes 33 dwords apart: no
+// bank conflicts), the repeat codes, the Kraft sums of the two codes it describes, the end-of-block code -- with zlib's rules
+// (inflate_table): 64 candidates at once.  It must never refuse what read_dynamic accepts (a wrong refusal would cost a chunk
+// its start, i.e. parallelism -- tests/test_gpu_gzip.py::test_the_speculation_is_what_runs watches that); what it lets through is
+// still judged by the wave.
+constexpr int LANE_LUT_STRIDE = 132;
+__device__ __forceinline__ bool lane_check_dynamic(const uint8_t* comp, int64_t n, int64_t P, u64 w, uint32_t hclen, uint32_t hlit, uint32_t hdist, uint8_t* lut) {
+    // code length code: lengths by symbol (RFC 1951 3.2.7 stores them in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15)
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto len_at = [&](uint32_t i) -> uint32_t { return i < hclen ? (uint32_t)(w >> (3 * i)) & 7u : 0u; };
+#pragma unroll
+    for (int i = 0; i < 19; ++i) {
+        const uint32_t l = len_at((uint32_t)i);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) cnt[q] += l == (uint32_t)q;
+    }
+    uint32_t next[8];
+    next[0] = 0; next[1] = 0;
+#pragma unroll
+    for (int q = 2; q < 8; ++q) next[q] = (next[q - 1] + cnt[q - 1]) << 1;
+    // the direct table: entry = symbol << 3 | length, for all 7-bit patterns (the code is complete: every pattern is covered)
+    constexpr uint8_t INV[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};   // position of symbol s in that order
+#pragma unroll
+    for (int sym = 0; sym < 19; ++sym) {
+        const uint32_t l = len_at(INV[sym]);
+        if (l) {
+            uint32_t code = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q) if (l == (uint32_t)q) { code = next[q]; next[q] += 1; }
+            const uint32_t r = __builtin_bitreverse32(code) >> (32 - l);
+            for (uint32_t k = r; k < 128u; k += 1u << l) lut[k] = (uint8_t)((sym << 3) | l);
+        }
+    }
+    // the code lengths
+    const int64_t start = P + 17 + 3 * (int64_t)hclen;
+    int64_t nb = start >> 3;
+    u64 buf = 0;
+    int bc = 0;
+    auto refill = [&]() {
+        if (bc <= 32) {
+            const uint32_t d = nb + 4 <= n + 60 ? reinterpret_cast<const U32U*>(comp + nb)->v : 0u;   // (64 bytes of slack behind the piece)
+            buf |= (u64)d << bc; bc += 32; nb += 4;
+        }
+    };
+    refill();
+    { const int sk = (int)(start & 7); buf >>= sk; bc -= sk; }
+    const int total = (int)(hlit + 257 + hdist + 1), n_ll = (int)hlit + 257;
+    int i = 0;
+    uint32_t prev = 0, kr_ll = 0, kr_d = 0, c_ll = 0, c_d = 0, eob = 0;
+    bool ok = true;
+    while (i < total && ok) {
+        refill();
+        const uint32_t e = lut[(uint32_t)buf & 127u];
+        const uint32_t l = e & 7u, sym = e >> 3;
+        buf >>= l; bc -= (int)l;
+        uint32_t val = 0;
+        int rep = 1;
+        if (sym < 16u) { val = sym; prev = sym; }
+        else if (sym == 16u) { if (i == 0) { ok = false; break; } val = prev; rep = 3 + (int)((uint32_t)buf & 3u); buf >>= 2; bc -= 2; }
+        else if (sym == 17u) { rep = 3 + (int)((uint32_t)buf & 7u); buf >>= 3; bc -= 3; prev = 0; }
+        else { rep = 11 + (int)((uint32_t)buf & 127u); buf >>= 7; bc -= 7; prev = 0; }
+        if (i + rep > total) { ok = false; break; }
+        if (val) {
+            const int a = i >= n_ll ? 0 : (i + rep <= n_ll ? rep : n_ll - i);
+            const uint32_t unit = 32768u >> val;
+            kr_ll += (uint32_t)a * unit; c_ll += (uint32_t)a;
+            kr_d += (uint32_t)(rep - a) * unit; c_d += (uint32_t)(rep - a);
+        }
+        if (i <= 256 && 256 < i + rep) eob = val;
+        i += rep;
+    }
+    if (!ok || eob == 0u) return false;
+    if (8 * (nb - 4) + (32 - bc) > 8 * n + 64) return false;   // (ran past the input: generous, the wave's judgement is exact)
+    const bool ll_ok = kr_ll == 32768u || (c_ll == 1u && kr_ll == 16384u);
+    const bool d_ok = kr_d == 32768u || (c_d == 1u && kr_d == 16384u) || c_d == 0u;
+    return ll_ok && d_ok;
+}
+
 // ---- FIND: the first position in chunk c at which a block (or a member) can start ----------------------------------------------
 // 512 bit positions per round, in two stages.  Stage 1, every lane 8 positions: the 13 header bits that need no arithmetic
 // (BFINAL = 0, BTYPE = 10, HLIT <= 29, HDIST <= 29: 11 % of random positions pass) and, at byte positions, the member magic.
@@ -602,6 +684,7 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_decode(Args a) {
 static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
     __shared__ uint16_t s_ll[WAVES][288 + 32];
     __shared__ uint8_t s_len[WAVES][320 + 64];
+    __shared__ __attribute__((aligned(4))) uint8_t s_lane_lut[WAVES][64 * LANE_LUT_STRIDE];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int c = (int)blockIdx.x * WAVES + wave;
@@ -684,7 +767,9 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
                 const uint32_t l = (uint32_t)(w >> (3 * i)) & 7u;
                 kraft += ((uint32_t)i < hclen && l) ? (128u >> l) : 0u;
             }
-            u64 m2 = __ballot(have && kraft == 128u);
+            bool cand = have && kraft == 128u;
+            if (cand) cand = lane_check_dynamic(a.comp, a.n, P, w, hclen, (uint32_t)(v >> 3) & 31u, (uint32_t)(v >> 8) & 31u, s_lane_lut[wave] + lane * LANE_LUT_STRIDE);
+            u64 m2 = __ballot(cand);
             while (m2 && first_dyn == POS_NONE) {
                 const int L = __builtin_ctzll(m2);
                 m2 &= m2 - 1;
@@ -1075,7 +1160,12 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     for (int ji = 0;;) {
         const JobOut& o = outs[ji];
         chain.push_back(ji);
-        if (o.status == ST_TARGET) { ji = o.next_job; continue; }
+        if (o.status == ST_TARGET) {   // (positions only grow along the chain: the index does too)
+            if (o.next_job <= ji && ji < n_chunks) return gz_fail(h, BZQ_ERR_HIP, "bzq_gzip: internal: the chain does not advance");
+            if (o.next_job < 0 || o.next_job >= n_chunks) return gz_fail(h, BZQ_ERR_HIP, "bzq_gzip: internal: the chain leaves the job table");
+            ji = o.next_job;
+            continue;
+        }
         if (o.status == ST_LOST || o.status == ST_SPLIT) {
             // it passed over too many (false) candidates, or its output reached the bound: go on from where it stopped, with an
             // explicit start.  A stream without findable block starts (fixed-Huffman or stored blocks only) proceeds like this,

@@ -86,3 +86,59 @@ def test_synthetic_generator_by_hand():
     # compute_num_reads_for_size, utils.mojo:640-678: 3 GiB of 100 bp reads -> 14.7 M
     n = O.compute_num_reads_for_size(3 * 1024 ** 3, 100, 100)
     assert n == 3 * 1024 ** 3 // (6 + 8 + 1 + 204)
+
+
+def _spec_record(i, nd, min_len, max_len, min_phred, max_phred, schema):
+    """Record i of SURVEY.md Appendix B (utils.mojo:707-917) written out a second time, in plain Python, independent of oracle/:
+    the byte-exact definition every BASELINE input flows from (nd = digits of the header number)."""
+    M = (1 << 63) - 1
+    lower, upper, offset = {"generic": (33, 126, 33), "sanger": (33, 126, 33), "solexa": (59, 126, 64), "illumina_1.3": (64, 126, 64),
+                            "illumina_1.5": (66, 126, 64), "illumina_1.8": (33, 126, 33)}[schema]
+    lut = b"GCGCATAT"      # gc_bias 0.5 -> 4 of the 8 slots alternate G, C, the rest A, T
+    q_range = max_phred - min_phred
+    noise_amp = q_range // 6 + 1
+    out = bytearray()
+    L = min_len if min_len == max_len else min_len + ((i * 31 + 7) % (max_len - min_len + 1))
+    out += b"@read_" + str(i).zfill(nd).encode() + b"\n"
+    st = (i * 6364136223846793005 + 1442695040888963407) & M
+    for _ in range(L):
+        st = (st * 6364136223846793005 + 1442695040888963407) & M
+        out.append(lut[(st >> 33) % 8])
+    out += b"\n+\n"
+    r = (i * 2654435761 + 1013904223) & M
+    for p in range(L):
+        mean = max_phred if L == 1 else max_phred - (q_range * p + (L - 1) // 2) // (L - 1)
+        r = (r * 1664525 + 1013904223) & M
+        phred = mean + ((r >> 17) % (2 * noise_amp + 1)) - noise_amp
+        phred = min(max(phred, min_phred), max_phred)
+        out.append(min(max(offset + phred, lower), upper))
+    out += b"\n"
+    return bytes(out)
+
+
+def _generator_spec(num_reads, min_len, max_len, min_phred, max_phred, schema):
+    """the pin has to look at more than record 0 of a 3-base read -- variable lengths, the quality ramp,
+    noise_amp, the clamp to the schema, 7- and 9-digit headers."""
+    nd = 1 if num_reads <= 1 else len(str(num_reads - 1))
+    return b"".join(_spec_record(i, nd, min_len, max_len, min_phred, max_phred, schema) for i in range(num_reads))
+
+
+@pytest.mark.parametrize("args", [
+    (1200, 150, 150, 33, 73, "generic"),          # the bench's records: 4-digit headers here
+    (3, 150, 150, 33, 73, "generic"),
+    (700, 5, 12, 0, 40, "sanger"),                # variable lengths (test_parser.mojo:228-288's shape), ramp + noise + clamp
+    (300, 200, 19_800, 5, 30, "sanger"),          # config 4's long reads
+    (40, 1, 1, 10, 10, "illumina_1.3"),           # L = 1: the ramp's special case; another offset
+    (25, 30, 60, 0, 62, "solexa"),                # clamp to the schema's LOWER
+])
+def test_synthetic_generator_against_an_independent_restatement(args):
+    assert O.generate_synthetic(*args).tobytes() == _generator_spec(*args)
+
+
+def test_synthetic_generator_header_width_follows_the_read_count():
+    """7-digit headers for the 10 M-read input (config 2), 9 digits for the 625 M-read one (config 5): record i depends only on i
+    and on the digit count, so single records of those files are checked without generating the files."""
+    for total, digits in ((10_000_000, 7), (625_000_000, 9)):
+        for i in (0, 4095, 4096, total - 1):
+            one = O.generate_synthetic(total, 150, 150, 33, 73, "generic", first=i, count=1).tobytes()
+            assert one == _spec_record(i, digits, 150, 150, 33, 73, "generic")
