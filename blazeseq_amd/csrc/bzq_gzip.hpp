@@ -594,87 +594,6 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_decode(Args a) {
     run_job(a, a.job_base + k, s_ll[wave], s_ll[wave] + 288, s_len[wave], s_lut[wave], s_dlut[wave]);
 }
 
-// ---- one lane's look at a dynamic block header: a NECESSARY condition, cheap ---------------------------------------------------
-// The whole-wave judgement (read_dynamic) costs ~30 us per candidate, and about one bit position in 2 000 passes the code length
-// code test: at 131 072 positions per chunk that was most of the finder's time.  Here every lane decodes the code lengths of ITS
-// candidate by itself -- a 7-bit direct table of the code length code in LDS (128 bytes per lane, lanes 33 dwords apart: no
-// bank conflicts), the repeat codes, the Kraft sums of the two codes it describes, the end-of-block code -- with zlib's rules
-// (inflate_table): 64 candidates at once.  It must never refuse what read_dynamic accepts (a wrong refusal would cost a chunk
-// its start, i.e. parallelism -- tests/test_gpu_gzip.py::test_the_speculation_is_what_runs watches that); what it lets through is
-// still judged by the wave.
-constexpr int LANE_LUT_STRIDE = 132;
-__device__ __forceinline__ bool lane_check_dynamic(const uint8_t* comp, int64_t n, int64_t P, u64 w, uint32_t hclen, uint32_t hlit, uint32_t hdist, uint8_t* lut) {
-    // code length code: lengths by symbol (RFC 1951 3.2.7 stores them in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15)
-    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto len_at = [&](uint32_t i) -> uint32_t { return i < hclen ? (uint32_t)(w >> (3 * i)) & 7u : 0u; };
-#pragma unroll
-    for (int i = 0; i < 19; ++i) {
-        const uint32_t l = len_at((uint32_t)i);
-#pragma unroll
-        for (int q = 1; q < 8; ++q) cnt[q] += l == (uint32_t)q;
-    }
-    uint32_t next[8];
-    next[0] = 0; next[1] = 0;
-#pragma unroll
-    for (int q = 2; q < 8; ++q) next[q] = (next[q - 1] + cnt[q - 1]) << 1;
-    // the direct table: entry = symbol << 3 | length, for all 7-bit patterns (the code is complete: every pattern is covered)
-    constexpr uint8_t INV[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};   // position of symbol s in that order
-#pragma unroll
-    for (int sym = 0; sym < 19; ++sym) {
-        const uint32_t l = len_at(INV[sym]);
-        if (l) {
-            uint32_t code = 0;
-#pragma unroll
-            for (int q = 1; q < 8; ++q) if (l == (uint32_t)q) { code = next[q]; next[q] += 1; }
-            const uint32_t r = __builtin_bitreverse32(code) >> (32 - l);
-            for (uint32_t k = r; k < 128u; k += 1u << l) lut[k] = (uint8_t)((sym << 3) | l);
-        }
-    }
-    // the code lengths
-    const int64_t start = P + 17 + 3 * (int64_t)hclen;
-    int64_t nb = start >> 3;
-    u64 buf = 0;
-    int bc = 0;
-    auto refill = [&]() {
-        if (bc <= 32) {
-            const uint32_t d = nb + 4 <= n + 60 ? reinterpret_cast<const U32U*>(comp + nb)->v : 0u;   // (64 bytes of slack behind the piece)
-            buf |= (u64)d << bc; bc += 32; nb += 4;
-        }
-    };
-    refill();
-    { const int sk = (int)(start & 7); buf >>= sk; bc -= sk; }
-    const int total = (int)(hlit + 257 + hdist + 1), n_ll = (int)hlit + 257;
-    int i = 0;
-    uint32_t prev = 0, kr_ll = 0, kr_d = 0, c_ll = 0, c_d = 0, eob = 0;
-    bool ok = true;
-    while (i < total && ok) {
-        refill();
-        const uint32_t e = lut[(uint32_t)buf & 127u];
-        const uint32_t l = e & 7u, sym = e >> 3;
-        buf >>= l; bc -= (int)l;
-        uint32_t val = 0;
-        int rep = 1;
-        if (sym < 16u) { val = sym; prev = sym; }
-        else if (sym == 16u) { if (i == 0) { ok = false; break; } val = prev; rep = 3 + (int)((uint32_t)buf & 3u); buf >>= 2; bc -= 2; }
-        else if (sym == 17u) { rep = 3 + (int)((uint32_t)buf & 7u); buf >>= 3; bc -= 3; prev = 0; }
-        else { rep = 11 + (int)((uint32_t)buf & 127u); buf >>= 7; bc -= 7; prev = 0; }
-        if (i + rep > total) { ok = false; break; }
-        if (val) {
-            const int a = i >= n_ll ? 0 : (i + rep <= n_ll ? rep : n_ll - i);
-            const uint32_t unit = 32768u >> val;
-            kr_ll += (uint32_t)a * unit; c_ll += (uint32_t)a;
-            kr_d += (uint32_t)(rep - a) * unit; c_d += (uint32_t)(rep - a);
-        }
-        if (i <= 256 && 256 < i + rep) eob = val;
-        i += rep;
-    }
-    if (!ok || eob == 0u) return false;
-    if (8 * (nb - 4) + (32 - bc) > 8 * n + 64) return false;   // (ran past the input: generous, the wave's judgement is exact)
-    const bool ll_ok = kr_ll == 32768u || (c_ll == 1u && kr_ll == 16384u);
-    const bool d_ok = kr_d == 32768u || (c_d == 1u && kr_d == 16384u) || c_d == 0u;
-    return ll_ok && d_ok;
-}
-
 // ---- FIND: the first position in chunk c at which a block (or a member) can start ----------------------------------------------
 // 512 bit positions per round, in two stages.  Stage 1, every lane 8 positions: the 13 header bits that need no arithmetic
 // (BFINAL = 0, BTYPE = 10, HLIT <= 29, HDIST <= 29: 11 % of random positions pass) and, at byte positions, the member magic.
@@ -684,7 +603,6 @@ __device__ __forceinline__ bool lane_check_dynamic(const uint8_t* comp, int64_t 
 static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
     __shared__ uint16_t s_ll[WAVES][288 + 32];
     __shared__ uint8_t s_len[WAVES][320 + 64];
-    __shared__ __attribute__((aligned(4))) uint8_t s_lane_lut[WAVES][64 * LANE_LUT_STRIDE];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int c = (int)blockIdx.x * WAVES + wave;
@@ -732,6 +650,7 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
             hdrm[j] = __ballot(hdr);
             total += __builtin_popcountll(pass[j]);
         }
+        if (lane == 0 && a.counters[7]) atomicAdd(&a.counters[3], (uint32_t)total);
         // stage 2: survivor k of the round (stream order: j-major, lane-minor) goes to lane k & 63
         u64 first_dyn = POS_NONE;
         for (int k0 = 0; k0 < total && first_dyn == POS_NONE; k0 += 64) {
@@ -767,9 +686,8 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
                 const uint32_t l = (uint32_t)(w >> (3 * i)) & 7u;
                 kraft += ((uint32_t)i < hclen && l) ? (128u >> l) : 0u;
             }
-            bool cand = have && kraft == 128u;
-            if (cand) cand = lane_check_dynamic(a.comp, a.n, P, w, hclen, (uint32_t)(v >> 3) & 31u, (uint32_t)(v >> 8) & 31u, s_lane_lut[wave] + lane * LANE_LUT_STRIDE);
-            u64 m2 = __ballot(cand);
+            u64 m2 = __ballot(have && kraft == 128u);
+            if (lane == 0 && a.counters[7]) atomicAdd(&a.counters[4], (uint32_t)__builtin_popcountll(m2));
             while (m2 && first_dyn == POS_NONE) {
                 const int L = __builtin_ctzll(m2);
                 m2 &= m2 - 1;
@@ -1133,7 +1051,8 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     for (int attempt = 0;; ++attempt) {
         if ((rc = gz_ensure(h, h->pool, ((size_t)h->pool_pages << PAGE_SHIFT) * 2)) || (rc = gz_ensure(h, h->page_next, (size_t)h->pool_pages * 4))) return rc;
         const Job j0{h->start_pos, 1, 0};
-        GZCHK(h, hipMemsetAsync(h->counters.p, 0, 16, s));
+        GZCHK(h, hipMemsetAsync(h->counters.p, 0, 32, s));
+        if (timing) { const uint32_t one = 1; GZCHK(h, hipMemcpyAsync((uint32_t*)h->counters.p + 7, &one, 4, hipMemcpyHostToDevice, s)); }
         GZCHK(h, hipMemcpyAsync(h->jobs.p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
         a = Args{d_comp, (int64_t)n, (Job*)h->jobs.p, (JobOut*)h->outs.p, 0, n_chunks, n_chunks, CH, (uint16_t*)h->pool.p, h->pool_pages,
                  (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events, max_job, (int64_t)std::max<uint64_t>(out_cap, 1ull << 20)};
@@ -1143,9 +1062,10 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         hipLaunchKernelGGL(k_gz_decode, dim3(grid), dim3(BLOCK), 0, s, a);
         GZCHK(h, hipGetLastError());
         GZCHK(h, hipMemcpyAsync(outs, h->outs.p, (size_t)n_chunks * sizeof(JobOut), hipMemcpyDeviceToHost, s));
-        GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 16, hipMemcpyDeviceToHost, s));
+        GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 32, hipMemcpyDeviceToHost, s));
         GZCHK(h, hipStreamSynchronize(s));
         lap(2);
+        if (timing) fprintf(stderr, "bzq_gzip finder: %u positions passed the 13-bit filter, %u of them the code length code test (judged by the whole wave)\n", h_counters[3], h_counters[4]);
         if (h_counters[0] <= h->pool_pages) break;
         if (attempt == 8) return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: the symbol pool keeps overflowing (" + std::to_string(h->pool_pages) + " pages)");
         h->pool_pages = std::max<uint32_t>(2u * h->pool_pages, h_counters[0] + (uint32_t)n_chunks);   // (counts the refused requests too)
