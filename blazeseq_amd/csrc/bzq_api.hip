@@ -216,7 +216,7 @@ int ensure_tile_arenas(bzq_ctx* c, uint64_t n) {
             (rc = ensure(c, c->tileI, nt * 8)) || (rc = ensure(c, c->grp, (nt / SG_TILES + 2) * 80)))
             return rc;
 #if BZQ_EXPERIMENTS
-        if ((rc = ensure(c, c->desc, (nt * 6 + (nt / 64 + 2) * 4 + 16) * 8))) return rc;   // single-launch variants only
+        if ((rc = ensure(c, c->desc, (nt * 6 + (nt / 64 + 2) * 4 + 64) * 8))) return rc;   // single-launch variants only
 #endif
         c->tile_cap = nt;
     }
@@ -362,13 +362,25 @@ FusedArgs make_fused_args(bzq_ctx* c) {
 
 #if BZQ_EXPERIMENTS
 // One launch for the whole chunk (single-pass kernel, bzq_fused.hpp).
+static __global__ void k_pick_run_bases(const int64_t* P, const int64_t* S, const int64_t* Q, const int64_t* I, int64_t run, int64_t nt, int64_t* out) {
+    const int e = threadIdx.x;
+    const int64_t t = (int64_t)e * run;
+    if (t < nt) { out[4 * e] = P[t]; out[4 * e + 1] = S[t]; out[4 * e + 2] = Q[t]; out[4 * e + 3] = I[t]; }
+}
 int enqueue_fused(bzq_ctx* c) {
     const int64_t nt = tiles_for(c->cur_n);
     u64* d = (u64*)c->desc.p;
-    hipError_t e = hipMemsetAsync(d, 0, (size_t)(nt * 5 + 8) * 8, c->stream);
+    hipError_t e = hipMemsetAsync(d, 0, (size_t)(nt * 5 + 8 + 32) * 8, c->stream);
     if (e != hipSuccess) { c->err = std::string("hipMemsetAsync(desc): ") + hipGetErrorString(e); return BZQ_ERR_HIP; }
     FusedArgs f = make_fused_args(c);
     f.ticket = d; f.desc_c = d + 8; f.desc_agg = d + 8 + nt; f.desc_pre = d + 8 + 2 * nt;
+    if (c->single_pass == 4) {   // round-3 experiment: one look-back chain per XCD, the chain starts given (tile prefixes of the two-pass run before)
+        f.xcd_tiles = (nt + 7) / 8;
+        int64_t* xb = (int64_t*)(d + 8 + 5 * nt);
+        hipLaunchKernelGGL(k_pick_run_bases, dim3(1), dim3(8), 0, c->stream, (const int64_t*)c->tileP.p, (const int64_t*)c->tileS.p, (const int64_t*)c->tileQ.p,
+                           (const int64_t*)c->tileI.p, f.xcd_tiles, nt, xb);
+        f.xcd_base = xb;
+    }
     if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
     launch_fused<true>(c, dim3((unsigned)nt), f);
     if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
@@ -455,7 +467,7 @@ int enqueue_stream(bzq_ctx* c) { c->err = "k_stream exists only in an EXPERIMENT
 
 int enqueue_single_launch(bzq_ctx* c) {
 #if BZQ_EXPERIMENTS
-    return c->single_pass >= 2 ? enqueue_single(c) : enqueue_fused(c);
+    return (c->single_pass == 2 || c->single_pass == 3) ? enqueue_single(c) : enqueue_fused(c);   // 1: one look-back chain, 4: one per XCD (experiment), 2 / 3: service / hierarchical
 #else
     c->err = "single-launch variants exist only in an EXPERIMENTS build";
     return BZQ_ERR_ARG;

@@ -71,6 +71,12 @@ struct FusedArgs {
     int64_t walk_limit;   // ByteSrc::walk_limit (0 = none)
     int32_t check_h;      // pass A was k_tile_aggregate_h: flag every header line whose kept range is not "all but the '@'"
     int32_t ablate;   // timing experiments, compiled in only with -DBZQ_EXPERIMENTS=1 (make EXPERIMENTS=1): see BZQ_ABLATE uses
+    // LB only, round-3 experiment (profiles/r3_single_read_xcd.md): > 0 = every XCD walks its own contiguous run of this many
+    // tiles with look-backs that never leave the XCD; xcd_base[4 e + {0,1,2,3}] = line index and the three column offsets at the
+    // start of run e -- handed in by the host (taken from a two-pass run of the same input: what a per-run column layout would make
+    // unnecessary is simply given here, so that the kernel's time can be measured and its output compared)
+    int64_t xcd_tiles;
+    const int64_t* xcd_base;
 };
 
 // Exclusive line prefix of tile t (wave 0, all 64 lanes).  Lane i inspects predecessor t-1-i.
@@ -259,11 +265,23 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     const int tid0 = threadIdx.x;
 
     if (LB) {
-        if (tid0 == 0) s_bcast[0] = (int64_t)atomicAdd(a.ticket, 1ull);
+        if (tid0 == 0) {
+            if (a.xcd_tiles > 0) {   // a ticket of THIS XCD's run (HW_REG_XCC_ID, bits 3:0); a run that is used up: help the next one
+                uint32_t x = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;
+                int64_t tt = -1;
+                for (int tries = 0; tries < 8 && tt < 0; ++tries, x = (x + 1) & 7u) {
+                    const int64_t lo = (int64_t)x * a.xcd_tiles, hi = lo + a.xcd_tiles < a.n_tiles ? lo + a.xcd_tiles : a.n_tiles;
+                    if (lo >= hi) continue;
+                    const int64_t k = (int64_t)atomicAdd(&a.ticket[x], 1ull);
+                    if (lo + k < hi) tt = lo + k;
+                }
+                s_bcast[0] = tt;
+            } else s_bcast[0] = (int64_t)atomicAdd(a.ticket, 1ull);
+        }
         __syncthreads();
     }
     int64_t t;
-    if (LB) t = s_bcast[0];
+    if (LB) { t = s_bcast[0]; if (t < 0) return; }
     else {
         t = a.tile_begin + xcd_tile();   // (neighbouring tiles on one XCD: bzq_device.hpp)
         if (t >= a.tile_end) return;
@@ -315,8 +333,9 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
 
     // ---- look-back 1: line index of the tile's first line --------------------------------------
     if (LB && wave == 0) {
-        if (lane == 0 && t > 0) st_agent(&a.desc_c[t], DESC_A | (u64)c);
-        const int64_t Pex = lookback_lines(a.desc_c, t, a.st->P0, lane, a.st);
+        if (lane == 0 && t > 0) st_agent(&a.desc_c[t], DESC_A | (u64)c);   // (the first tile of a chain publishes its prefix directly below)
+        const int64_t run0 = a.xcd_tiles > 0 ? (t / a.xcd_tiles) * a.xcd_tiles : 0;   // first tile of the look-back chain
+        const int64_t Pex = lookback_lines(a.desc_c + run0, t - run0, a.xcd_tiles > 0 ? a.xcd_base[4 * (run0 / a.xcd_tiles)] : a.st->P0, lane, a.st);
         if (lane == 0) {
             st_agent(&a.desc_c[t], DESC_P | (u64)(Pex + (int64_t)c + DESC_BIAS));
             s_bcast[1] = Pex;
@@ -481,7 +500,9 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     if (LB && wave == 0) {
         if (lane == 0 && t > 0)
             st_agent(&a.desc_agg[t], DESC_A | (u64)n_seq | ((u64)n_qual << 20) | ((u64)n_id << 40));
-        const Cols ex = lookback_cols(a.desc_agg, a.desc_pre, t, a.st->S0, a.st->Q0, a.st->I0, lane, a.st);
+        const int64_t run0 = a.xcd_tiles > 0 ? (t / a.xcd_tiles) * a.xcd_tiles : 0;
+        const int64_t* xb = a.xcd_tiles > 0 ? a.xcd_base + 4 * (run0 / a.xcd_tiles) : nullptr;
+        const Cols ex = lookback_cols(a.desc_agg + run0, a.desc_pre + 3 * run0, t - run0, xb ? xb[1] : a.st->S0, xb ? xb[2] : a.st->Q0, xb ? xb[3] : a.st->I0, lane, a.st);
         if (lane == 0) {
             st_agent(&a.desc_pre[3 * t], DESC_P | (u64)(ex.s + n_seq + DESC_BIAS));
             st_agent(&a.desc_pre[3 * t + 1], DESC_P | (u64)(ex.q + n_qual + DESC_BIAS));
