@@ -611,7 +611,6 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
     uint16_t* sym_d = s_ll[wave] + 288;
     uint8_t* lens = s_len[wave];
     const int64_t lo = (int64_t)c * a.chunk_bytes, hi = lo + a.chunk_bytes < a.n ? lo + a.chunk_bytes : a.n;
-    const u64 below = (1ull << lane) - 1ull;
     u64 found = POS_NONE;
     auto judge_dynamic = [&](int64_t Q) -> bool {
         GBits b;
@@ -710,7 +709,6 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
         }
         found = first_hdr < first_dyn ? first_hdr : first_dyn;
     }
-    (void)below;
     if (lane == 0) a.jobs[c] = Job{found, c + 1, 0};
 }
 

@@ -208,83 +208,6 @@ __device__ __forceinline__ uint32_t wrlane(uint32_t v, int lane, uint32_t old) {
     return old;
 }
 
-// The literal run, by hand.  The decoder is bound by the CU's scalar unit (PMC: 1.03 scalar instructions per CU cycle, 21.6 per
-// output byte), and what the compiler makes of the C++ loop is ~41 instructions per trip (SGPR spills reloaded inside it, the
-// reader's counters kept in vector registers, selects and copies around every exit).  This is the same loop in 21: refill
-// from the window register (v_readlane), table lookup (one ds_read_b32), one or two literals into the pending register
-// (v_writelane, lane select in M0), shift.  It leaves with
-//   0  the entry is not a plain literal: *e = the entry (bit 31 set); its bits are NOT consumed
-//   1  63 or 64 literals are pending: the caller stores them
-//   2  the window register is used up: the caller reloads it (refill())
-// Fixed scalar registers (named in the clobber list) because inline asm cannot name the halves of a 64-bit operand.
-template <class BitsT>
-__device__ __forceinline__ int lit_run(BitsT& b, const uint32_t* lut2, int& ns, uint32_t& mylit, uint32_t& e) {
-    uint32_t reason, vt, ee;
-    // (all of it is uniform; the compiler cannot always prove it and refuses a vector register for an "s" operand)
-    u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
-    int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), n = (int)uni((uint32_t)ns);
-    const int wb = (int)uni((uint32_t)b.win_base);
-    const uint32_t lds = uni((uint32_t)(uintptr_t)lut2);   // (a generic pointer into LDS: its low half is the LDS address)
-    asm volatile(
-        "s_mov_b64 s[40:41], %[buf]\n\t"
-        "s_mov_b32 s42, %[cnt]\n\t"
-        "s_mov_b32 s43, %[next]\n\t"
-        "s_mov_b32 s45, %[ns]\n"
-        "1:\n\t"
-        "s_cmp_gt_i32 s42, 32\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "s_sub_i32 s47, s43, %[wb]\n\t"
-        "s_cmp_gt_i32 s47, 63\n\t"
-        "s_cbranch_scc1 8f\n\t"
-        "v_readlane_b32 s48, %[win], s47\n\t"
-        "s_mov_b32 s49, 0\n\t"
-        "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
-        "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
-        "s_add_i32 s42, s42, 32\n\t"
-        "s_add_i32 s43, s43, 1\n\t"
-        "s_branch 1b\n"
-        "2:\n\t"
-        "s_and_b32 s47, s40, 0x3ff\n\t"
-        "s_lshl2_add_u32 s47, s47, %[lds]\n\t"
-        "v_mov_b32 %[vt], s47\n\t"
-        "ds_read_b32 %[vt], %[vt]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_readfirstlane_b32 s46, %[vt]\n\t"
-        "s_cmp_lt_i32 s46, 0\n\t"
-        "s_cbranch_scc1 7f\n\t"
-        "s_mov_b32 m0, s45\n\t"
-        "v_writelane_b32 %[lit], s46, m0\n\t"
-        "s_lshr_b32 s47, s46, 8\n\t"
-        "s_add_i32 m0, s45, 1\n\t"
-        "v_writelane_b32 %[lit], s47, m0\n\t"
-        "s_bfe_u32 s47, s46, 0x20018\n\t"
-        "s_add_i32 s45, s45, s47\n\t"
-        "s_bfe_u32 s47, s46, 0x50010\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
-        "s_sub_i32 s42, s42, s47\n\t"
-        "s_cmp_lt_i32 s45, 63\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        "s_mov_b32 s50, 1\n\t"
-        "s_branch 9f\n"
-        "7:\n\t"
-        "s_mov_b32 s50, 0\n\t"
-        "s_branch 9f\n"
-        "8:\n\t"
-        "s_mov_b32 s50, 2\n"
-        "9:\n\t"
-        "s_mov_b64 %[buf], s[40:41]\n\t"
-        "s_mov_b32 %[cnt], s42\n\t"
-        "s_mov_b32 %[next], s43\n\t"
-        "s_mov_b32 %[ns], s45\n\t"
-        "s_mov_b32 %[e], s46\n\t"
-        "s_mov_b32 %[reason], s50"
-        : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [ns] "+s"(n), [lit] "+v"(mylit), [vt] "=&v"(vt), [e] "=s"(ee), [reason] "=s"(reason)
-        : [wb] "s"(wb), [win] "v"(b.win), [lds] "s"(lds)
-        : "s40", "s41", "s42", "s43", "s45", "s46", "s47", "s48", "s49", "s50", "m0", "scc", "memory");
-    b.buf = buf; b.cnt = cnt; b.next = next; ns = n; e = ee;
-    return (int)reason;
-}
-
 // The distance code's direct table: DLUT_BITS index bits, 32-bit entries with base and extra bits folded in (RFC 1951 3.2.5):
 // bits 0..14 = base distance, 16..19 = number of extra bits, 20..24 = code bits; bit 31 = a longer code, no code, or one of
 // the two symbols that must not occur (30, 31): the slow path judges those.  Its upper half serves as the 16-bit table while it
@@ -309,7 +232,11 @@ __device__ __forceinline__ void build_dlut(const Code& code, const uint16_t* sym
     __builtin_amdgcn_wave_barrier();
 }
 
-// The symbol loop of a BGZF block, by hand: literals as in lit_run, and the whole match path -- length from the folded table
+// The symbol loop of a BGZF block, by hand.  The decoder is bound by the CU's scalar unit (PMC on the C++ loop: 1.03 scalar
+// instructions per CU cycle, 21.6 per output byte), and what the compiler makes of that loop is ~41 instructions per literal and
+// ~120 per match (SGPR spills reloaded inside it, the reader's counters kept in vector registers, selects and copies around
+// every exit).  Here: refill from the window register (v_readlane), table lookup (one ds_read_b32), one or two literals into
+// the pending register (v_writelane, lane select in M0), shift -- and the whole match path: length from the folded table
 // entry, distance through its own direct table, the checks, the store of the pending literals and the copy of a match of up to
 // 64 bytes that does not overlap itself -- without leaving the asm block (in the benchmark's FASTQ 71 % of the bytes come out of
 // matches of 5.5 bytes on average: what the match path costs decides the rate).  ~21 instructions per literal pair, ~70 per
@@ -319,6 +246,8 @@ __device__ __forceinline__ void build_dlut(const Code& code, const uint16_t* sym
 //   3  a distance code the table does not hold: len is decoded, the distance bits are not consumed
 //   4  a match the fast copy does not take (longer than 64 bytes, or overlapping itself): len, dist; pending literals stored
 //   5  invalid: distance beyond the start of the output, or output beyond usize
+// Fixed scalar registers (named in the clobber list) because inline asm cannot name the halves of a 64-bit operand.  (A first
+// version had only the literal run in asm: on a stream of 71 % match bytes, leaving the block at every match ate the gain.)
 struct SymState { int pos, ns, len, dist; uint32_t e; };
 template <class BitsT>
 __device__ __forceinline__ int sym_run(BitsT& b, const uint32_t* lut2, const uint32_t* dlut, uint8_t* out, int usize, SymState& st, uint32_t& mylit) {
