@@ -594,6 +594,152 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_decode(Args a) {
     run_job(a, a.job_base + k, s_ll[wave], s_ll[wave] + 288, s_len[wave], s_lut[wave], s_dlut[wave]);
 }
 
+// ---- one lane's look at a dynamic block header: a NECESSARY condition, cheap ---------------------------------------------------
+// The whole-wave judgement (read_dynamic) costs ~50 us per candidate (up to 316 code lengths decoded one after the other), and
+// about one bit position in 2 000 passes the code length code test: ~60 candidates per 16 KiB chunk, which was the finder's
+// time.  Here every lane decodes the code lengths of ITS candidate by itself -- a 7-bit direct table of the code length code in
+// LDS (128 bytes per lane, lanes 33 dwords apart: no bank conflicts), the repeat codes, the Kraft sums of the two codes it
+// describes, the end-of-block code -- with zlib's rules (inflate_table).  ~5 000 instructions, so it only pays with the lanes
+// FULL: the finder queues its candidates and looks at 64 at once (run by the lane that met a candidate, with 63 idle, it was
+// slower than the whole-wave judgement: measured).  It must never refuse what read_dynamic accepts (a wrong refusal would cost
+// a chunk its start, i.e. parallelism -- tests/test_gpu_gzip.py::test_the_speculation_is_what_runs watches that); what it
+// lets through is still judged by the wave.
+constexpr int LANE_LUT_STRIDE = 132;
+constexpr int FIND_STAGE = 2048;   // bytes of a chunk in LDS at a time (32 rounds)
+__device__ __forceinline__ bool lane_check_dynamic(const uint8_t* comp, int64_t n, int64_t P, u64 w, uint32_t hclen, uint32_t hlit, uint32_t hdist, uint8_t* lut) {
+    // code length code: lengths by symbol (RFC 1951 3.2.7 stores them in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15)
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto len_at = [&](uint32_t i) -> uint32_t { return i < hclen ? (uint32_t)(w >> (3 * i)) & 7u : 0u; };
+#pragma unroll
+    for (int i = 0; i < 19; ++i) {
+        const uint32_t l = len_at((uint32_t)i);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) cnt[q] += l == (uint32_t)q;
+    }
+    uint32_t next[8];
+    next[0] = 0; next[1] = 0;
+#pragma unroll
+    for (int q = 2; q < 8; ++q) next[q] = (next[q - 1] + cnt[q - 1]) << 1;
+    // the direct table: entry = symbol << 3 | length, for all 7-bit patterns (the code is complete: every pattern is covered)
+    constexpr uint8_t INV[19] = {3, 17, 15, 13, 11, 9, 7, 5, 4, 6, 8, 10, 12, 14, 16, 18, 0, 1, 2};   // position of symbol s in that order
+#pragma unroll
+    for (int sym = 0; sym < 19; ++sym) {
+        const uint32_t l = len_at(INV[sym]);
+        if (l) {
+            uint32_t code = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q) if (l == (uint32_t)q) { code = next[q]; next[q] += 1; }
+            const uint32_t r = __builtin_bitreverse32(code) >> (32 - l);
+            for (uint32_t k = r; k < 128u; k += 1u << l) lut[k] = (uint8_t)((sym << 3) | l);
+        }
+    }
+    // the code lengths
+    const int64_t start = P + 17 + 3 * (int64_t)hclen;
+    int64_t nb = start >> 3;
+    u64 buf = 0;
+    int bc = 0;
+    // (two dwords ahead of the one being shifted in: the loads' latency is behind ~16 symbols of work instead of in front of every 8)
+    auto load = [&](int64_t at) -> uint32_t { return at + 4 <= n + 60 ? reinterpret_cast<const U32U*>(comp + at)->v : 0u; };   // (64 bytes of slack behind the piece)
+    uint32_t n0 = load(nb), n1 = load(nb + 4);
+    auto refill = [&]() {
+        if (bc <= 32) {
+            buf |= (u64)n0 << bc; bc += 32; nb += 4;
+            n0 = n1; n1 = load(nb + 4);
+        }
+    };
+    refill();
+    { const int sk = (int)(start & 7); buf >>= sk; bc -= sk; }
+    const int total = (int)(hlit + 257 + hdist + 1), n_ll = (int)hlit + 257;
+    int i = 0;
+    uint32_t prev = 0, kr_ll = 0, kr_d = 0, c_ll = 0, c_d = 0, eob = 0;
+    bool ok = true;
+    while (i < total && ok) {
+        refill();
+        const uint32_t e = lut[(uint32_t)buf & 127u];
+        const uint32_t l = e & 7u, sym = e >> 3;
+        buf >>= l; bc -= (int)l;
+        uint32_t val = 0;
+        int rep = 1;
+        if (sym < 16u) { val = sym; prev = sym; }
+        else if (sym == 16u) { if (i == 0) { ok = false; break; } val = prev; rep = 3 + (int)((uint32_t)buf & 3u); buf >>= 2; bc -= 2; }
+        else if (sym == 17u) { rep = 3 + (int)((uint32_t)buf & 7u); buf >>= 3; bc -= 3; prev = 0; }
+        else { rep = 11 + (int)((uint32_t)buf & 127u); buf >>= 7; bc -= 7; prev = 0; }
+        if (i + rep > total) { ok = false; break; }
+        if (val) {
+            const int a = i >= n_ll ? 0 : (i + rep <= n_ll ? rep : n_ll - i);
+            const uint32_t unit = 32768u >> val;
+            kr_ll += (uint32_t)a * unit; c_ll += (uint32_t)a;
+            kr_d += (uint32_t)(rep - a) * unit; c_d += (uint32_t)(rep - a);
+        }
+        if (i <= 256 && 256 < i + rep) eob = val;
+        i += rep;
+    }
+    if (!ok || eob == 0u) return false;
+    if (8 * (nb - 4) + (32 - bc) > 8 * n + 64) return false;   // (ran past the input: generous, the wave's judgement is exact)
+    const bool ll_ok = kr_ll == 32768u || (c_ll == 1u && kr_ll == 16384u);
+    const bool d_ok = kr_d == 32768u || (c_d == 1u && kr_d == 16384u) || c_d == 0u;
+    return ll_ok && d_ok;
+}
+
+// ---- the finder's rare, long paths, OUT OF LINE ----------------------------------------------------------------------------------
+// Inlined, the judgement's registers pushed the scan loop's scalars into spill lanes (a third of the loop's instructions were
+// v_readlane / v_writelane).  A call keeps the two allocations apart; LDS addresses travel as 32-bit offsets so that the
+// callee's accesses stay ds_ instructions (a generic pointer parameter would make them flat_).
+template <class T> __device__ __forceinline__ uint32_t lds_off(T* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)p; }
+template <class T> __device__ __forceinline__ T* lds_ptr(uint32_t off) { return (T*)(__attribute__((address_space(3))) T*)(uintptr_t)off; }
+
+// a dynamic block header at bit Q, judged by the whole wave: all three Huffman codes must be ones zlib accepts
+static __device__ __forceinline__ bool judge_dynamic_at(const uint8_t* comp, int64_t n, int64_t Q, uint8_t* lens, uint16_t* sym_ll, uint16_t* sym_d) {
+    GBits b;
+    Code ll, dd;
+    b.start(comp, n, Q + 3);
+    return read_dynamic(b, lens, sym_ll, sym_d, nullptr, nullptr, ll, dd, false) && !b.beyond();
+}
+
+// the first QN queued candidates (QN <= 64), one per lane: the per-lane look, then the whole wave's judgement of whoever is
+// left, in stream order.  Returns the first position that holds, or POS_NONE.
+static __device__ __attribute__((noinline)) u64 find_flush(const uint8_t* comp, int64_t n, int64_t lo, uint32_t queue_o, int QN, uint32_t lane_lut_o,
+                                                           uint32_t lens_o, uint32_t sym_ll_o, uint32_t sym_d_o, uint32_t* counter) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t* queue = lds_ptr<uint32_t>(queue_o);
+    const bool have = lane < QN;
+    const int64_t P = 8 * lo + (have ? (int64_t)queue[lane] : 0), byte = P >> 3;
+    const int sh = (int)(P & 7);
+    const uint32_t d0 = reinterpret_cast<const U32U*>(comp + byte)->v, d1 = reinterpret_cast<const U32U*>(comp + byte + 4)->v;
+    const uint32_t d2 = reinterpret_cast<const U32U*>(comp + byte + 8)->v, d3 = reinterpret_cast<const U32U*>(comp + byte + 12)->v;
+    const u64 lo64 = (u64)d0 | ((u64)d1 << 32), hi64 = (u64)d2 | ((u64)d3 << 32);
+    const u64 v = sh ? (lo64 >> sh) | (hi64 << (64 - sh)) : lo64, vh = hi64 >> sh;
+    const u64 w = (v >> 17) | (vh << 47);
+    bool ok = have;
+    if (ok) ok = lane_check_dynamic(comp, n, P, w, ((uint32_t)(v >> 13) & 15u) + 4u, (uint32_t)(v >> 3) & 31u, (uint32_t)(v >> 8) & 31u, lds_ptr<uint8_t>(lane_lut_o) + lane * LANE_LUT_STRIDE);
+    u64 m = __ballot(ok);
+    if (counter && lane == 0) atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+    u64 got = POS_NONE;
+    while (m && got == POS_NONE) {
+        const int L = __builtin_ctzll(m);
+        m &= m - 1;
+        const int64_t Q = 8 * lo + (int64_t)queue[L];
+        if (judge_dynamic_at(comp, n, Q, lds_ptr<uint8_t>(lens_o), lds_ptr<uint16_t>(sym_ll_o), lds_ptr<uint16_t>(sym_d_o))) got = pos_deflate((u64)Q);
+    }
+    return got;
+}
+
+// a member header at byte B ... followed by a block header that can be one
+static __device__ __attribute__((noinline)) bool find_header(const uint8_t* comp, int64_t n, int64_t B, uint32_t lens_o, uint32_t sym_ll_o, uint32_t sym_d_o) {
+    const int64_t dpos = parse_member_header(comp, n, B);
+    if (dpos <= 0) return false;
+    GBits b;
+    Code ll, dd;
+    b.start(comp, n, 8 * dpos);
+    b.refill();
+    (void)b.take(1);
+    const uint32_t type = b.take(2);
+    if (type == 3) return false;
+    if (type == 0) { b.take(b.cnt & 7); b.refill(); const uint32_t len = b.take(16), nlen = b.take(16); return (len ^ nlen) == 0xFFFFu; }
+    if (type == 2) return read_dynamic(b, lds_ptr<uint8_t>(lens_o), lds_ptr<uint16_t>(sym_ll_o), lds_ptr<uint16_t>(sym_d_o), nullptr, nullptr, ll, dd, false) && !b.beyond();
+    return true;
+}
+
 // ---- FIND: the first position in chunk c at which a block (or a member) can start ----------------------------------------------
 // 512 bit positions per round, in two stages.  Stage 1, every lane 8 positions: the 13 header bits that need no arithmetic
 // (BFINAL = 0, BTYPE = 10, HLIT <= 29, HDIST <= 29: 11 % of random positions pass) and, at byte positions, the member magic.
@@ -603,111 +749,147 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_decode(Args a) {
 static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
     __shared__ uint16_t s_ll[WAVES][288 + 32];
     __shared__ uint8_t s_len[WAVES][320 + 64];
+    __shared__ uint16_t s_surv[WAVES][1024 + 64];
+    __shared__ uint8_t kraft4[4096];   // four 3-bit code lengths -> their Kraft sum in 1/128 (saturated: anything > 128 is refused anyway)
+    __shared__ uint32_t s_queue[WAVES][64 + 64 + 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[WAVES][(FIND_STAGE + 64) / 4];
+    __shared__ __attribute__((aligned(4))) uint8_t s_lane_lut[WAVES][64 * LANE_LUT_STRIDE];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int c = (int)blockIdx.x * WAVES + wave;
+    for (uint32_t e = threadIdx.x; e < 4096u; e += BLOCK) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { const uint32_t l = (e >> (3 * f)) & 7u; sum += l ? 128u >> l : 0u; }
+        kraft4[e] = (uint8_t)(sum > 200u ? 200u : sum);
+    }
+    __syncthreads();
     if (c >= a.n_cand || c == 0) return;   // (job 0 is the piece's exact start, written by the host)
+    uint16_t* surv = s_surv[wave];
+    uint32_t* queue = s_queue[wave];
+    uint32_t* stg = s_stage[wave];
+    uint8_t* lane_lut = s_lane_lut[wave];
     uint16_t* sym_ll = s_ll[wave];
     uint16_t* sym_d = s_ll[wave] + 288;
     uint8_t* lens = s_len[wave];
     const int64_t lo = (int64_t)c * a.chunk_bytes, hi = lo + a.chunk_bytes < a.n ? lo + a.chunk_bytes : a.n;
+    const bool count_them = a.counters[7] != 0;   // (BZQ_GZ_TIMING: how many positions survive each stage)
     u64 found = POS_NONE;
-    auto judge_dynamic = [&](int64_t Q) -> bool {
-        GBits b;
-        Code ll, dd;
-        b.start(a.comp, a.n, Q + 3);
-        return read_dynamic(b, lens, sym_ll, sym_d, nullptr, nullptr, ll, dd, false) && !b.beyond();
+    // candidates that passed the code length code test, waiting for the per-lane look: positions relative to the chunk's first bit
+    int qn = 0, qh = 0;   // (entries queue[qh .. qh + qn))
+    const uint32_t judge_lds[3] = {lds_off(lens), lds_off(sym_ll), lds_off(sym_d)};
+    auto flush_queue = [&](int QN) -> u64 {
+        const u64 got = find_flush(a.comp, a.n, lo, lds_off(queue + qh), QN, lds_off(lane_lut), judge_lds[0], judge_lds[1], judge_lds[2], count_them ? a.counters + 5 : nullptr);
+        qh += QN; qn -= QN;
+        return got;
     };
-    auto judge_header = [&](int64_t B) -> bool {   // a member header ... followed by a block header that can be one
-        const int64_t dpos = parse_member_header(a.comp, a.n, B);
-        if (dpos <= 0) return false;
-        GBits b;
-        Code ll, dd;
-        b.start(a.comp, a.n, 8 * dpos);
-        b.refill();
-        (void)b.take(1);
-        const uint32_t type = b.take(2);
-        if (type == 3) return false;
-        if (type == 0) { b.take(b.cnt & 7); b.refill(); const uint32_t len = b.take(16), nlen = b.take(16); return (len ^ nlen) == 0xFFFFu; }
-        if (type == 2) return read_dynamic(b, lens, sym_ll, sym_d, nullptr, nullptr, ll, dd, false) && !b.beyond();
-        return true;
+    auto judge_header = [&](int64_t B) -> bool { return find_header(a.comp, a.n, B, judge_lds[0], judge_lds[1], judge_lds[2]); };
+    // The chunk goes through LDS FIND_STAGE bytes at a time, the next stage's loads in flight while this one is looked at (read
+    // from global memory round by round, every round waited ~2 us for 64 bytes: that, not arithmetic, was the finder's time).
+    struct Q4 { uint32_t x, y, z, w; };
+    struct __attribute__((packed, aligned(1))) Q4U { Q4 v; };
+    Q4 r0, r1, r2;
+    auto fetch = [&](int64_t s0) {
+        const int64_t lim = a.n + 64;   // (64 bytes of slack behind the piece; every byte of the piece lies >= 64 in front of lim)
+        const int64_t p0 = s0 + 16 * lane, p1 = p0 + FIND_STAGE / 2, p2 = s0 + FIND_STAGE + 16 * lane;
+        r0 = p0 + 16 <= lim ? reinterpret_cast<const Q4U*>(a.comp + p0)->v : Q4{0, 0, 0, 0};
+        r1 = p1 + 16 <= lim ? reinterpret_cast<const Q4U*>(a.comp + p1)->v : Q4{0, 0, 0, 0};
+        r2 = (lane < 4 && p2 + 16 <= lim) ? reinterpret_cast<const Q4U*>(a.comp + p2)->v : Q4{0, 0, 0, 0};
     };
-    for (int64_t P0 = 8 * lo; P0 < 8 * hi && found == POS_NONE; P0 += 512) {
-        // stage 1
-        u64 pass[8], hdrm[8];
+    fetch(lo);
+    for (int64_t s0 = lo; s0 < hi && found == POS_NONE; s0 += FIND_STAGE) {
+    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<Q4*>(stg + 4 * lane) = r0;
+    *reinterpret_cast<Q4*>(stg + FIND_STAGE / 8 + 4 * lane) = r1;
+    if (lane < 4) *reinterpret_cast<Q4*>(stg + FIND_STAGE / 4 + 4 * lane) = r2;
+    __builtin_amdgcn_wave_barrier();
+    if (s0 + FIND_STAGE < hi) fetch(s0 + FIND_STAGE);
+    const int64_t s1 = s0 + FIND_STAGE < hi ? s0 + FIND_STAGE : hi;
+    // limits relative to the stage's first bit (32-bit arithmetic in the loops)
+    const int lim_in = (int)(8 * (s1 - s0));                                              // positions of this chunk
+    const int lim_n = (int)(8 * a.n - 8 * s0 < (1 << 20) ? 8 * a.n - 8 * s0 : (1 << 20));   // bits of the piece
+    for (int gb = 0; 8 * gb < lim_in && found == POS_NONE; gb += 128) {
+        // stage 1, sixteen positions per lane AT ONCE: bit p of x is the first bit of candidate p, and the thirteen header bits
+        // that need no arithmetic are tested for all sixteen with word operations --
+        //   BFINAL = 0, BTYPE = 10:  x[p] = 0, x[p+1] = 0, x[p+2] = 1
+        //   HLIT <= 29:  not all of x[p+4 .. p+7];   HDIST <= 29:  not all of x[p+9 .. p+12]
+        const int bo = gb + 2 * lane;   // (the lane's 32-bit window: bytes bo .. bo + 3 of the stage)
+        const uint32_t x = __builtin_amdgcn_alignbyte(stg[(bo >> 2) + 1], stg[bo >> 2], (uint32_t)bo & 3u);
+        const uint32_t p2 = x & (x >> 1), ones4 = p2 & (p2 >> 2);   // ones4[i]: x[i .. i+3] all set
+        const int rem = lim_in - 8 * bo;   // how many of the lane's positions belong to the chunk
+        uint32_t m = (x >> 2) & ~(x | (x >> 1)) & ~(ones4 >> 4) & ~(ones4 >> 9) & (rem >= 16 ? 0xFFFFu : rem <= 0 ? 0u : (1u << rem) - 1u);
+        // member magic (1F 8B 08) at the lane's two bytes; the flag byte is judge_header's business
+        const bool hdr0 = (x & 0xFFFFFFu) == 0x088B1Fu && rem > 0, hdr1 = (x >> 8) == 0x088B1Fu && rem > 8;
+        const u64 h0 = __ballot(hdr0), h1 = __ballot(hdr1);
+        // every lane's survivors go to the wave's list in stream order: exclusive prefix of the counts (<= 16: five ballots)
+        const uint32_t cnt = (uint32_t)__builtin_popcount(m);
+        uint32_t off = 0;
         int total = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int64_t P = P0 + 64 * j + lane, byte = P >> 3;
-            const int sh = (int)(P & 7);
-            const uint32_t d0 = reinterpret_cast<const U32U*>(a.comp + byte)->v;   // (64 bytes of slack behind the piece)
-            const uint32_t v = d0 >> sh;
-            const bool in = P < 8 * hi;
-            const bool dyn = in && (v & 7u) == 4u && ((v >> 3) & 31u) <= 29u && ((v >> 8) & 31u) <= 29u && P + 17 + 3 * (int64_t)(((v >> 13) & 15u) + 4u) <= 8 * a.n;
-            const bool hdr = in && sh == 0 && (d0 & 0xFFFFFFu) == 0x088B1Fu && ((d0 >> 24) & 0xE0u) == 0 && byte + 18 <= a.n;
-            pass[j] = __ballot(dyn);
-            hdrm[j] = __ballot(hdr);
-            total += __builtin_popcountll(pass[j]);
+        for (int bit = 0; bit < 5; ++bit) {
+            const u64 bm = __ballot((cnt >> bit) & 1u);
+            off += __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u)) << bit;
+            total += __builtin_popcountll(bm) << bit;
         }
-        if (lane == 0 && a.counters[7]) atomicAdd(&a.counters[3], (uint32_t)total);
-        // stage 2: survivor k of the round (stream order: j-major, lane-minor) goes to lane k & 63
-        u64 first_dyn = POS_NONE;
-        for (int k0 = 0; k0 < total && first_dyn == POS_NONE; k0 += 64) {
-            const int k = k0 + lane;
-            int j = 0, rem = k;
-            u64 mj = pass[0];
-#pragma unroll
-            for (int jj = 0; jj < 7; ++jj) {
-                const int cj = __builtin_popcountll(pass[jj]);
-                if (j == jj && rem >= cj) { j = jj + 1; rem -= cj; mj = pass[jj + 1]; }
-            }
-            const bool have = k < total;
-            int lp = 0;   // select(mj, rem): six halving steps
-            {
-                u64 x = mj; int kk = have ? rem : 0;
-#pragma unroll
-                for (int h = 32; h >= 1; h >>= 1) {
-                    const int cc = __builtin_popcountll(x & ((1ull << h) - 1ull));
-                    if (kk >= cc) { lp += h; kk -= cc; x >>= h; }
-                }
-            }
-            const int64_t P = have ? P0 + 64 * j + lp : 8 * lo, byte = P >> 3;
-            const int sh = (int)(P & 7);
-            const uint32_t d0 = reinterpret_cast<const U32U*>(a.comp + byte)->v, d1 = reinterpret_cast<const U32U*>(a.comp + byte + 4)->v;
-            const uint32_t d2 = reinterpret_cast<const U32U*>(a.comp + byte + 8)->v, d3 = reinterpret_cast<const U32U*>(a.comp + byte + 12)->v;
-            const u64 lo64 = (u64)d0 | ((u64)d1 << 32), hi64 = (u64)d2 | ((u64)d3 << 32);
-            const u64 v = sh ? (lo64 >> sh) | (hi64 << (64 - sh)) : lo64, vh = hi64 >> sh;
-            const uint32_t hclen = ((uint32_t)(v >> 13) & 15u) + 4u;
-            const u64 w = (v >> 17) | (vh << 47);
-            uint32_t kraft = 0;
-#pragma unroll
-            for (int i = 0; i < 19; ++i) {
-                const uint32_t l = (uint32_t)(w >> (3 * i)) & 7u;
-                kraft += ((uint32_t)i < hclen && l) ? (128u >> l) : 0u;
-            }
-            u64 m2 = __ballot(have && kraft == 128u);
-            if (lane == 0 && a.counters[7]) atomicAdd(&a.counters[4], (uint32_t)__builtin_popcountll(m2));
-            while (m2 && first_dyn == POS_NONE) {
-                const int L = __builtin_ctzll(m2);
-                m2 &= m2 - 1;
-                const int64_t Q = ((int64_t)rdlane((uint32_t)((u64)P >> 32), L) << 32) | (int64_t)rdlane((uint32_t)P, L);
-                if (judge_dynamic(Q)) first_dyn = pos_deflate((u64)Q);
-            }
+        while (m) {   // (as many trips as the fullest lane has survivors: ~5 of 16)
+            surv[off++] = (uint16_t)(16 * lane + __builtin_ctz(m));
+            m &= m - 1;
         }
-        // member headers of the round, up to the dynamic block that was found
-        u64 first_hdr = POS_NONE;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            u64 mh = hdrm[j];
-            while (mh && first_hdr == POS_NONE) {
-                const int L = __builtin_ctzll(mh);
-                mh &= mh - 1;
-                const int64_t Q = P0 + 64 * j + L;
-                if (pos_header((u64)(Q >> 3)) > first_dyn) { mh = 0; break; }
-                if (judge_header(Q >> 3)) first_hdr = pos_header((u64)(Q >> 3));
+        __builtin_amdgcn_wave_barrier();
+        if (count_them && lane == 0) atomicAdd(&a.counters[3], (uint32_t)total);
+        const bool any_hdr = (h0 | h1) != 0, last_group = 8 * (gb + 128) >= lim_in && s1 == hi;
+        // stage 2: survivor k of the group (stream order) goes to lane k & 63; who passes is queued
+        for (int k0 = 0;; k0 += 64) {
+            if (k0 < total) {
+                const int k = k0 + lane;
+                const bool have = k < total;
+                const int sp = have ? (int)surv[k] : 0;
+                const int sh = sp & 7, sb = gb + (sp >> 3);
+                const uint32_t* e = stg + (sb >> 2);
+                const uint32_t e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4], by = (uint32_t)sb & 3u;
+                const uint32_t d0 = __builtin_amdgcn_alignbyte(e1, e0, by), d1 = __builtin_amdgcn_alignbyte(e2, e1, by);
+                const uint32_t d2 = __builtin_amdgcn_alignbyte(e3, e2, by), d3 = __builtin_amdgcn_alignbyte(e4, e3, by);
+                const u64 lo64 = (u64)d0 | ((u64)d1 << 32), hi64 = (u64)d2 | ((u64)d3 << 32);
+                const u64 v = sh ? (lo64 >> sh) | (hi64 << (64 - sh)) : lo64, vh = hi64 >> sh;
+                const uint32_t hclen = ((uint32_t)(v >> 13) & 15u) + 4u;
+                // the code length code must be complete: its 19 (hclen stored) 3-bit lengths, four at a time through the table
+                const u64 w = ((v >> 17) | (vh << 47)) & ((1ull << (3 * hclen)) - 1ull);
+                const uint32_t kraft = (uint32_t)kraft4[(uint32_t)w & 4095u] + kraft4[(uint32_t)(w >> 12) & 4095u] + kraft4[(uint32_t)(w >> 24) & 4095u] +
+                                       kraft4[(uint32_t)(w >> 36) & 4095u] + kraft4[(uint32_t)(w >> 48) & 4095u];
+                const int rel = 8 * gb + sp;   // (relative to the stage)
+                const bool pass2 = have && kraft == 128u && rel + 17 + 3 * (int)hclen <= lim_n;
+                const u64 m2 = __ballot(pass2);
+                if (count_them && lane == 0) atomicAdd(&a.counters[4], (uint32_t)__builtin_popcountll(m2));
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m2, 0u));
+                if (pass2) queue[qh + qn + (int)rank] = (uint32_t)(8 * (s0 - lo) + rel);
+                qn += __builtin_popcountll(m2);
+                __builtin_amdgcn_wave_barrier();
             }
+            // the ONE place the queue is looked at (the judgement is long code: one copy of it): full lanes; or, behind the
+            // group's last survivors, a member header in the group or the end of the chunk -- then whatever there is
+            const bool last = k0 + 64 >= total;
+            const bool drain = last && (any_hdr || last_group);
+            while (found == POS_NONE && (qn >= 64 || (drain && qn > 0))) found = flush_queue(qn < 64 ? qn : 64);
+            if (qh) {   // what is left (< 64) moves to the front
+                const uint32_t t = lane < qn ? queue[qh + lane] : 0u;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < qn) queue[lane] = t;
+                qh = 0;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (last || found != POS_NONE) break;
         }
-        found = first_hdr < first_dyn ? first_hdr : first_dyn;
+        // member headers of the group (rare), in stream order; everything queued in front of them has been looked at
+        u64 ha = h0, hb = h1;
+        while ((ha | hb) && found == POS_NONE) {
+            const int ia = ha ? 2 * __builtin_ctzll(ha) : 1 << 20, ib = hb ? 2 * __builtin_ctzll(hb) + 1 : 1 << 20;
+            const int ib_ = ia < ib ? ia : ib;
+            if (ia < ib) ha &= ha - 1; else hb &= hb - 1;
+            const int64_t B = s0 + gb + ib_;
+            if (B + 18 <= a.n && judge_header(B)) found = pos_header((u64)B);
+        }
+        __builtin_amdgcn_wave_barrier();   // (the next group rewrites the list)
+    }
     }
     if (lane == 0) a.jobs[c] = Job{found, c + 1, 0};
 }
@@ -1050,7 +1232,8 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         if ((rc = gz_ensure(h, h->pool, ((size_t)h->pool_pages << PAGE_SHIFT) * 2)) || (rc = gz_ensure(h, h->page_next, (size_t)h->pool_pages * 4))) return rc;
         const Job j0{h->start_pos, 1, 0};
         GZCHK(h, hipMemsetAsync(h->counters.p, 0, 32, s));
-        if (timing) { const uint32_t one = 1; GZCHK(h, hipMemcpyAsync((uint32_t*)h->counters.p + 7, &one, 4, hipMemcpyHostToDevice, s)); }
+        static const bool counting = getenv("BZQ_GZ_COUNT") != nullptr;   // debug: the finder's survivor counts (atomics in its loop: not for timing)
+        if (counting) { const uint32_t one = 1; GZCHK(h, hipMemcpyAsync((uint32_t*)h->counters.p + 7, &one, 4, hipMemcpyHostToDevice, s)); }
         GZCHK(h, hipMemcpyAsync(h->jobs.p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
         a = Args{d_comp, (int64_t)n, (Job*)h->jobs.p, (JobOut*)h->outs.p, 0, n_chunks, n_chunks, CH, (uint16_t*)h->pool.p, h->pool_pages,
                  (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events, max_job, (int64_t)std::max<uint64_t>(out_cap, 1ull << 20)};
@@ -1063,7 +1246,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 32, hipMemcpyDeviceToHost, s));
         GZCHK(h, hipStreamSynchronize(s));
         lap(2);
-        if (timing) fprintf(stderr, "bzq_gzip finder: %u positions passed the 13-bit filter, %u of them the code length code test (judged by the whole wave)\n", h_counters[3], h_counters[4]);
+        if (counting) fprintf(stderr, "bzq_gzip finder: %u positions passed the 13-bit filter, %u of them the code length code test, %u of those one lane's look at the code lengths (judged by the whole wave)\n", h_counters[3], h_counters[4], h_counters[5]);
         if (h_counters[0] <= h->pool_pages) break;
         if (attempt == 8) return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: the symbol pool keeps overflowing (" + std::to_string(h->pool_pages) + " pages)");
         h->pool_pages = std::max<uint32_t>(2u * h->pool_pages, h_counters[0] + (uint32_t)n_chunks);   // (counts the refused requests too)
