@@ -236,6 +236,7 @@ SYMBOLS = {
     "bzq_gzip_open": (C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "bzq_gzip_set_option": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_int64]),
     "bzq_gzip_decode": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]),
+    "bzq_gzip_stage": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64]),
     "bzq_gzip_finished": (C.c_int32, [C.c_void_p]),
     "bzq_gzip_get_stats": (C.c_int32, [C.c_void_p, C.POINTER(BzqGzipStats)]),
     "bzq_gzip_last_error": (C.c_char_p, [C.c_void_p]),

@@ -1066,6 +1066,11 @@ int32_t bzq_gzip_decode(bzq_gzip* h, const uint8_t* comp, uint64_t n, int32_t is
     if (!h || !out_bytes || !more || (n && !comp) || (out_capacity && !d_out)) return BZQ_ERR_ARG;
     return bzq::gz::gz_decode(h, comp, n, is_last != 0, d_out, out_capacity, out_bytes, more);
 }
+int32_t bzq_gzip_stage(bzq_gzip* h, const uint8_t* comp, uint64_t n) {
+    if (!h) return BZQ_ERR_ARG;
+    if (n && !comp) { h->err = "bzq_gzip_stage: NULL input"; return BZQ_ERR_ARG; }
+    return bzq::gz::gz_stage(h, comp, n);
+}
 int32_t bzq_gzip_finished(const bzq_gzip* h) { return h && h->finished ? 1 : 0; }
 int32_t bzq_gzip_get_stats(const bzq_gzip* h, bzq_gzip_stats* out) {
     if (!h || !out) return BZQ_ERR_ARG;

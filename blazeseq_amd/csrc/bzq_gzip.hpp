@@ -583,7 +583,7 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
     if (lane == 0) a.outs[ji] = o;
 }
 
-static __global__ __launch_bounds__(BLOCK) void k_gz_decode(Args a) {
+static __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_gz_decode(Args a) {
     __shared__ uint16_t s_ll[WAVES][288 + 32];
     __shared__ uint8_t s_len[WAVES][320 + 64];
     __shared__ uint32_t s_lut[WAVES][1 << inf::LUT_BITS];
@@ -1102,7 +1102,10 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_crc(const CrcSeg* segs, int
 
 // ================================================================================ host side
 #include <algorithm>
+#include <array>
 #include <chrono>
+#include <deque>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <zlib.h>   // crc32_combine only: the CRCs themselves are computed on the device
@@ -1116,10 +1119,18 @@ struct bzq_gzip {
     int32_t chunk_bytes = 16384;        // CH: one decoder wave per this many compressed bytes (zlib closes a block every ~20 KiB of FASTQ output stream)
     // device
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf comp, jobs, outs, pool, page_next, counters, events, items, crcs, win[2], chain_maps, chain_wins;
+    Buf comp[2], jobs, outs, pool, page_next, counters, events, items, crcs, win[2], chain_maps, chain_wins;
     Buf h_outs, h_events, h_pages, h_items, h_crcs;   // pinned host staging
     uint32_t pool_pages = 0;
     int wcur = 0;                       // win[wcur]: the 32 KiB of output in front of the next piece
+    // pieces on their way to the device while the one in front of them is decoded (bzq_gzip_stage): comp[b] holds one
+    // STAGE_RESERVE bytes in, so that the bytes carried over from the piece in front can be put before it
+    struct StagedPiece { const uint8_t* src; uint64_t n; int buf; };
+    std::mutex stage_mu;                // (bzq_gzip_stage may come from a second thread)
+    std::deque<StagedPiece> staged;     // oldest first, at most two
+    bool comp_busy[2] = {false, false}; // holds a staged piece, or the piece being decoded
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t staged_ev[2] = {nullptr, nullptr};
     // the stream
     std::vector<uint8_t> carry;         // compressed bytes not consumed yet
     unsigned long long start_pos = 1;   // where decoding resumes inside `carry`: pos_header(0), or pos_deflate(bit 0..7)
@@ -1137,6 +1148,26 @@ constexpr int MAX_FALLBACK = 64;   // explicit restarts per piece before the cal
 constexpr int32_t CRC_SEG = 1 << 20;
 
 inline int gz_fail(bzq_gzip* h, int code, const std::string& msg) { h->err = msg; return code; }
+
+// CRC-32 of a concatenation: crc(A B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] mod the CRC polynomial (reflected bit order).
+// zlib 1.2.11's crc32_combine squares a 32x32 matrix ~20 times per call (~10 us): with a segment per MiB that was 3..6 ms of
+// host time per piece.  Here the power of x is computed once per distinct length (all full segments share one) and applied
+// with 32 shift-and-xor steps.
+inline uint32_t crc_mul(uint32_t a, uint32_t b) {   // a * b mod P
+    uint32_t m = 1u << 31, p = 0;
+    for (;;) {
+        if (a & m) { p ^= b; if ((a & (m - 1)) == 0) break; }
+        m >>= 1;
+        b = (b & 1u) ? (b >> 1) ^ 0xEDB88320u : b >> 1;
+    }
+    return p;
+}
+inline uint32_t crc_xpow8(uint64_t n) {   // x^(8 n) mod P
+    static const std::array<uint32_t, 64> sq = [] { std::array<uint32_t, 64> t{}; t[0] = 1u << 30; for (int i = 1; i < 64; ++i) t[(size_t)i] = crc_mul(t[(size_t)i - 1], t[(size_t)i - 1]); return t; }();   // x^(2^i)
+    uint32_t p = 1u << 31;
+    for (int k = 3; n; n >>= 1, ++k) if (n & 1u) p = crc_mul(sq[(size_t)(k & 63)], p);
+    return p;
+}
 #define GZCHK(h, call)                                                                                          \
     do {                                                                                                        \
         const hipError_t e_ = (call);                                                                           \
@@ -1157,7 +1188,9 @@ inline void gz_free(bzq_gzip* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    for (bzq_gzip::Buf* b : {&h->comp, &h->jobs, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    for (hipEvent_t e : h->staged_ev) if (e) (void)hipEventDestroy(e);
+    for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->jobs, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
         if (b->p) (void)hipFree(b->p);
     for (bzq_gzip::Buf* b : {&h->h_outs, &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs})
         if (b->p) (void)hipHostFree(b->p);
@@ -1172,11 +1205,52 @@ inline int gz_open(int device, bzq_gzip** out, std::string& err) {
     h->device = device;
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { err = "bzq_gzip_open: hipStreamCreate failed"; delete h; return BZQ_ERR_HIP; }
     h->stream = h->own_stream;
+    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->staged_ev[1], hipEventDisableTiming) != hipSuccess) {
+        err = "bzq_gzip_open: hipStreamCreate failed"; gz_free(h); return BZQ_ERR_HIP;
+    }
     int rc;
     if ((rc = gz_ensure(h, h->win[0], 32768)) || (rc = gz_ensure(h, h->win[1], 32768)) || (rc = gz_ensure(h, h->counters, 64))) { err = h->err; gz_free(h); return rc; }
     if (hipMemsetAsync(h->win[0].p, 0, 32768, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { err = "bzq_gzip_open: hipMemset failed"; gz_free(h); return BZQ_ERR_HIP; }
     h->start_pos = pos_header(0);
+    for (uint64_t len : {1ull, 4097ull, (unsigned long long)CRC_SEG})   // (the combine above against zlib's, once)
+        if ((crc_mul(crc_xpow8(len), 0x12345678u) ^ 0x9ABCDEF0u) != (uint32_t)crc32_combine(0x12345678u, 0x9ABCDEF0u, (z_off_t)len)) { err = "bzq_gzip_open: internal: CRC combine self-check failed"; gz_free(h); return BZQ_ERR_HIP; }
     *out = h;
+    return 0;
+}
+
+// A piece that a LATER gz_decode will be given starts its way to the device now (pinned host memory, or the call is
+// pointless): the gz_decode that gets the same (src, n) finds it there instead of copying -- 5 ms of a 256 MiB piece's ~35,
+// hidden behind the decoding of the piece in front.  Two pieces can be outstanding (two buffers: one may be the piece being
+// decoded); with both taken the call does nothing, and that piece is copied by its gz_decode as if never staged.  Pieces are
+// taken in the order staged.  May be called from another thread than gz_decode's while that runs (the ingest's read-ahead
+// thread does), not concurrently with itself; src must stay untouched until its gz_decode has returned.
+constexpr uint64_t STAGE_RESERVE = 4ull << 20;
+inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
+    if (h->finished || !n_new) return 0;
+    GZCHK(h, hipSetDevice(h->device));
+    int bi;
+    {
+        std::lock_guard<std::mutex> lk(h->stage_mu);
+        bi = !h->comp_busy[0] ? 0 : !h->comp_busy[1] ? 1 : -1;
+        if (bi < 0) return 0;
+        h->comp_busy[bi] = true;
+    }
+    auto give_back = [&]() { std::lock_guard<std::mutex> lk(h->stage_mu); h->comp_busy[bi] = false; };
+    bzq_gzip::Buf& b = h->comp[bi];
+    if (b.cap < STAGE_RESERVE + n_new + 64) {   // (not gz_ensure: that waits for the decode stream, which the other thread may be feeding)
+        if (b.p) { const hipError_t e = hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) { give_back(); return gz_fail(h, BZQ_ERR_HIP, std::string("hipFree: ") + hipGetErrorString(e)); } }
+        const size_t want = (size_t)(STAGE_RESERVE + n_new + n_new / 4 + 256);
+        if (hipMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; (void)hipGetLastError(); give_back(); return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: cannot allocate " + std::to_string(want) + " bytes"); }
+        b.cap = want;
+    }
+    uint8_t* d = (uint8_t*)b.p + STAGE_RESERVE;
+    hipError_t e = hipMemcpyAsync(d, src, n_new, hipMemcpyHostToDevice, h->copy_stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d + n_new, 0, 64, h->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(h->staged_ev[bi], h->copy_stream);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(h->copy_stream); give_back(); return gz_fail(h, BZQ_ERR_HIP, std::string("bzq_gzip_stage: ") + hipGetErrorString(e)); }
+    std::lock_guard<std::mutex> lk(h->stage_mu);
+    h->staged.push_back(bzq_gzip::StagedPiece{src, n_new, bi});
     return 0;
 }
 
@@ -1208,15 +1282,37 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     const int n_chunks = (int)((n + (uint64_t)CH - 1) / (uint64_t)CH);
     const int n_jobs_cap = n_chunks + MAX_FALLBACK;
     const uint32_t max_events = (uint32_t)std::min<uint64_t>(n / 18 + (uint64_t)n_chunks + 64, 1u << 28);
-    if ((rc = gz_ensure(h, h->comp, n + 64)) || (rc = gz_ensure(h, h->jobs, (size_t)n_jobs_cap * sizeof(Job))) ||
+    // the buffer of the compressed bytes: the one this piece was staged into, or a free one (a staged piece that is not
+    // this one stays where it is, unless both buffers hold such: then the younger is dropped)
+    bool use_staged = false;
+    int cb = -1;
+    {
+        std::unique_lock<std::mutex> lk(h->stage_mu);
+        if (n_new && !h->staged.empty() && h->staged.front().src == src && h->staged.front().n == n_new) {
+            cb = h->staged.front().buf;
+            h->staged.pop_front();
+            use_staged = nc <= STAGE_RESERVE;   // (else the copy is wasted: the carry does not fit in front of it)
+        } else {
+            cb = !h->comp_busy[0] ? 0 : !h->comp_busy[1] ? 1 : -1;
+            if (cb < 0) { cb = h->staged.back().buf; h->staged.pop_back(); }
+            else h->comp_busy[cb] = true;
+        }
+    }
+    struct Release { bzq_gzip* h; int b; ~Release() { std::lock_guard<std::mutex> lk(h->stage_mu); h->comp_busy[b] = false; } } release{h, cb};
+    if (!use_staged) GZCHK(h, hipEventSynchronize(h->staged_ev[cb]));   // (whatever was last staged into it has arrived)
+    if ((!use_staged && (rc = gz_ensure(h, h->comp[cb], n + 64))) || (rc = gz_ensure(h, h->jobs, (size_t)n_jobs_cap * sizeof(Job))) ||
         (rc = gz_ensure(h, h->outs, (size_t)n_jobs_cap * sizeof(JobOut))) || (rc = gz_ensure(h, h->events, (size_t)max_events * sizeof(Event))) ||
         (rc = gz_ensure(h, h->h_outs, (size_t)n_jobs_cap * sizeof(JobOut) + 64, true)))
         return rc;
-    uint8_t* d_comp = (uint8_t*)h->comp.p;
+    uint8_t* d_comp = (uint8_t*)h->comp[cb].p + (use_staged ? STAGE_RESERVE - nc : 0);
+    // (the carry is pageable memory; the vector is not touched before the stream has been waited for, further down)
     if (nc) GZCHK(h, hipMemcpyAsync(d_comp, h->carry.data(), nc, hipMemcpyHostToDevice, s));
-    if (n_new) GZCHK(h, hipMemcpyAsync(d_comp + nc, src, n_new, hipMemcpyHostToDevice, s));
-    GZCHK(h, hipMemsetAsync(d_comp + n, 0, 64, s));
-    if (nc || timing) GZCHK(h, hipStreamSynchronize(s));   // (the carry is pageable memory: the copy is out of it before the vector changes)
+    if (use_staged) GZCHK(h, hipStreamWaitEvent(s, h->staged_ev[cb], 0));
+    else {
+        if (n_new) GZCHK(h, hipMemcpyAsync(d_comp + nc, src, n_new, hipMemcpyHostToDevice, s));
+        GZCHK(h, hipMemsetAsync(d_comp + n, 0, 64, s));
+    }
+    if (timing) GZCHK(h, hipStreamSynchronize(s));
     lap(0);
 
     JobOut* outs = (JobOut*)h->h_outs.p;
@@ -1418,9 +1514,10 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
 
     // ---- CRC-32 and ISIZE of every member that ended (RFC 1952 2.3.1)
     const uint32_t* crcs = (const uint32_t*)h->h_crcs.p;
+    const uint32_t xp_full = crc_xpow8((uint64_t)CRC_SEG);
     for (size_t k = 0; k < segs.size(); ++k) {
         if (segs[k].n) {
-            h->crc_run = h->len_run ? (uint32_t)crc32_combine(h->crc_run, crcs[k], (z_off_t)segs[k].n) : crcs[k];
+            h->crc_run = h->len_run ? crc_mul(segs[k].n == CRC_SEG ? xp_full : crc_xpow8((uint64_t)segs[k].n), h->crc_run) ^ crcs[k] : crcs[k];
             h->len_run += (uint64_t)segs[k].n;
         }
         if (seg_closes[k] >= 0) {

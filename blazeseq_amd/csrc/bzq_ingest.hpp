@@ -313,6 +313,9 @@ inline void gz_start_read(bzq_ingest* g, int buf) {
     uint8_t* dst = g->slot[buf].pinned + g->reserve;
     g->gz_reader = std::thread([g, dst, off, len]() {
         g->gz_read_ok = parallel_pread(g->fd, dst, off, len, g->n_threads, g->gz_read_err, g->fd_direct, &g->numa_cpus);
+        // on to the device at once: the copy runs behind the decoding of the piece in front (a failure here only means that
+        // the piece is copied by its gz_decode)
+        if (g->gz_read_ok && g->gz_dev) (void)bzq::gz::gz_stage(g->gz_dev, dst, len);
     });
 }
 inline bool gz_fill_fifo(bzq_ingest* g, std::string& err) {

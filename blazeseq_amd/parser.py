@@ -517,6 +517,13 @@ class GzipDecoder:
                                              C.byref(nb), C.byref(more)), "bzq_gzip_decode")
         return int(nb.value), bool(more.value)
 
+    def stage(self, comp):
+        """Read-ahead (bzq_gzip_stage): the piece AFTER the one about to be fed starts its way to the device; feed() of the
+        same array later finds it there.  `comp`: pinned memory (Context.pinned_array), untouched until that feed() returns."""
+        a = _as_u8(comp)
+        if a.size:
+            self._gcheck(L.lib().bzq_gzip_stage(self._h, a.ctypes.data, a.size), "bzq_gzip_stage")
+
     @property
     def finished(self) -> bool:
         return bool(L.lib().bzq_gzip_finished(self._h))

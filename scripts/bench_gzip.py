@@ -24,6 +24,7 @@ ap.add_argument("--piece-mib", type=int, default=256, help="compressed bytes han
 ap.add_argument("--chunk-kib", type=int, default=16, help="compressed bytes per decoder wave")
 ap.add_argument("--chunk-mib", type=int, default=256, help="ingest chunk (decompressed bytes)")
 ap.add_argument("--dir", default="/dev/shm")
+ap.add_argument("--no-stage", action="store_true", help="no bzq_gzip_stage read-ahead of the next piece")
 ap.add_argument("--no-ingest", action="store_true")
 args = ap.parse_args()
 
@@ -92,9 +93,13 @@ for kind in args.kinds.split(","):
             t1 = time.perf_counter()
             off, got = 0, 0
             piece = args.piece_mib << 20
+            if not args.no_stage:
+                dec.stage(pin[0:piece].numpy())
             while off < pin.numel() or not dec.finished:
                 part = pin[off:off + piece].numpy()
                 off += part.size
+                if not args.no_stage and off < pin.numel():
+                    dec.stage(pin[off:off + piece].numpy())   # the next piece travels while this one is decoded
                 while True:
                     nb, more = dec.feed(part, off >= pin.numel(), out.data_ptr() + got, out.numel() - got)
                     got += nb

@@ -41,12 +41,19 @@ class DeviceGunzip:
         assert L.lib().bzq_device_alloc(ctx.h, out_capacity + 64, C.byref(self.d_out)) == 0
         self.dec = GzipDecoder(ctx, chunk_bytes)
 
-    def decode(self, comp: bytes, piece: int = 0) -> bytes:
+    def decode(self, comp: bytes, piece: int = 0, ahead: int = 0) -> bytes:
+        """ahead > 0: that many pieces are kept staged (bzq_gzip_stage) in front of the one being fed."""
         a = np.frombuffer(comp, dtype=np.uint8)
         piece = piece or max(1, a.size)
         out = []
         off = 0
+        staged_to = 0   # pieces [0, staged_to) have been staged
         while True:
+            k = off // piece
+            while ahead and staged_to < k + 1 + ahead and staged_to * piece < a.size:
+                if staged_to >= k:
+                    self.dec.stage(a[staged_to * piece:(staged_to + 1) * piece])
+                staged_to += 1
             part = a[off:off + piece]
             off += part.size
             last = off >= a.size

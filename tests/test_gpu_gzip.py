@@ -113,6 +113,25 @@ def test_pieces_and_small_output_buffers():
         g.close()
 
 
+def test_staged_pieces_are_the_pieces():
+    """bzq_gzip_stage: pieces sent to the device ahead of their decode call (one or two in front, the second refused when both
+    buffers are taken), with an output buffer that cuts pieces (decode calls without input in between), and a staged piece
+    that is never fed (dropped): the bytes are the same."""
+    data = synthetic_fastq(30000)
+    comp = gzip.compress(data, 6)
+    ctx = Context()
+    for piece, cap, ahead in [(1 << 20, len(data), 1), (300000, len(data), 2), (99991, 700000, 1), (50000, 400000, 3), (len(comp), len(data), 1)]:
+        g = DeviceGunzip(ctx, cap, chunk_bytes=4096)
+        assert g.decode(comp, piece, ahead=ahead) == data, (piece, cap, ahead)
+        g.close()
+    g = DeviceGunzip(ctx, len(data), chunk_bytes=4096)
+    stray = np.frombuffer(comp, dtype=np.uint8)[1000:50000].copy()
+    g.dec.stage(stray)
+    g.dec.stage(stray[:100])
+    assert g.decode(comp, 200000, ahead=1) == data
+    g.close()
+
+
 def test_trailing_garbage_is_ignored_like_gzread_does():
     data = synthetic_fastq(3000)
     comp = gzip.compress(data, 6)
