@@ -87,6 +87,7 @@ struct Args {
     Event* events; uint32_t max_events;
     int64_t max_job_syms;                    // a job stops at the first boundary at which it has stored this much
     int64_t hard_cap_syms;                   // ... and gives up in the middle of a block beyond this much (bounds what a wrong guess can take from the pool)
+    const uint32_t* order;                   // workgroup k of the decode launch runs job order[k] (nullptr: job_base + k)
 };
 
 // ---- the bit reader of one wave (cf. inf::Bits), addressed by absolute bit offset in the piece -------------------------------
@@ -195,212 +196,283 @@ __device__ __forceinline__ int64_t parse_member_header(const uint8_t* comp, int6
 // of the next symbol in it, 0..65536), a match source in front of the job's output becomes a marker -- which is simply the low
 // 16 bits of its (negative) position: 0x8000 | (32768 + q) == q & 0xFFFF for -32768 <= q < 0.  A distance never needs a check
 // here (the format ends at 32768, and 32 KiB in front of the job are addressable as markers).  What the asm block does not take
-// it hands back untouched: anything that would cross the page's end (6: pending literals, 4: a match), a match whose source
-// lies in the page before (4), matches longer than 64 symbols or overlapping themselves (4), long or missing codes (0, 3), the
-// window register running out (2).  `first` = the page is the job's first (sources may be markers).
+// it hands back untouched: a match that would cross the page's end or whose source lies in the page before, is longer than 63
+// symbols or overlaps itself (4), long or missing codes (0, 3), the window register running out (2), a page with fewer than
+// two free slots (6: the caller decodes one symbol itself).  `first` = the page is the job's first (sources may be markers).
+//
+// What bounds this kernel is the CU's ONE scalar unit (the microbenchmark experiments/micro/salu_loop.hip and PMC: 24 waves
+// of a CU want ~6 scalar instructions per cycle, it issues 1), so the loop is written to need few of them and to put what it
+// can on the vector unit: the table index is computed there (v_bfe, v_lshl_add), literals go from the entry register to the
+// buffer without passing a scalar register (lanes 0 and 1 are the only active ones between matches: lane 0 writes the
+// first literal of the entry, lane 1 the second), a length entry is its own s_bfe operand.  11 scalar instructions per
+// lookup of one or two literals, 51 per match (the version before: 15 and 71).
+//
+// The symbols do not go to the page one match at a time: they collect in an LDS buffer (`obuf`, OB_SLOTS dwords, one symbol
+// each) that is written out 64 lanes wide when it holds more than OB_FLUSH.  That is what lets a match NOT wait for its
+// source: global_load_lds_ushort puts lane i's symbol straight into buffer slot i of the match (the instruction writes a
+// zero-extended DWORD per lane at M0 + 4 * lane, M0 rounded down to a dword: experiments/micro/glds_u16.hip), and the loop
+// goes on decoding while it travels.  A source that is still in the buffer is copied inside it (after a wait, if a load into
+// those very slots may be in flight: s57 = the lowest slot written by a load since the last vmcnt(0)); one that straddles
+// buffer and page is handed back (4).  Every way out writes the buffer out: outside this block the page holds everything in
+// front of st.pos.
+constexpr int OB_SLOTS = 192, OB_FLUSH = 128;   // (at most OB_FLUSH + 2 literals, or OB_FLUSH + a match of 63 symbols; the asm has the 128)
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const uint32_t* dlut, uint16_t* page, bool first, inf::SymState& st, uint32_t& mylit) {
-    uint32_t reason, vt, vt2, vq, ee;
+__device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const uint32_t* dlut, uint32_t* obuf, uint16_t* page, bool first, inf::SymState& st) {
+    uint32_t reason, vt, vt2, vq, ve, vslot, ee;
     u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
-    int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), n = (int)uni((uint32_t)st.ns), pos = (int)uni((uint32_t)st.pos);
+    int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), pos = (int)uni((uint32_t)st.pos);
     int len = (int)uni((uint32_t)st.len), dist = 0;
-    const int wb = (int)uni((uint32_t)b.win_base), fp = (int)uni(first ? 1u : 0u);
-    const uint32_t lds = uni((uint32_t)(uintptr_t)lut2), ldd = uni((uint32_t)(uintptr_t)dlut);
+    const int wb = (int)uni((uint32_t)b.win_base), fp = (int)uni(first ? 0x40000000u : 0u);   // how far in front of the page a source may lie
+    const uint32_t lds = uni((uint32_t)(uintptr_t)lut2), ldd = uni((uint32_t)(uintptr_t)dlut), ldo = uni((uint32_t)(uintptr_t)obuf);
     const u64 ob = ((u64)uni((uint32_t)((uintptr_t)page >> 32)) << 32) | uni((uint32_t)(uintptr_t)page);
-    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t lane = threadIdx.x & 63, lane4 = lane << 2, sh8 = lane << 3;
     asm volatile(
-        "s_mov_b64 s[40:41], %[buf]\n\t"
-        "s_mov_b32 s42, %[cnt]\n\t"
-        "s_mov_b32 s43, %[next]\n\t"
-        "s_mov_b32 s44, %[pos]\n\t"
-        "s_mov_b32 s45, %[ns]\n\t"
-        "s_mov_b32 s51, %[len]\n\t"
-        "s_mov_b32 s53, %[fp]\n\t"
-        "s_mov_b32 s54, %[wb]\n\t"
-        "s_mov_b32 s55, %[lds]\n\t"
-        "s_mov_b32 s56, %[ldd]\n\t"
-        "s_mov_b64 s[60:61], %[ob]\n\t"
-        "s_mov_b32 s52, 0\n\t"
-        "s_cmp_lg_u32 s51, 0\n\t"
-        "s_cbranch_scc1 4f\n"
-        // ---- top: refill, look up
-        "1:\n\t"
-        "s_cmp_gt_i32 s42, 32\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "s_sub_i32 s47, s43, s54\n\t"
-        "s_cmp_gt_i32 s47, 63\n\t"
-        "s_cbranch_scc1 80f\n\t"
-        "v_readlane_b32 s48, %[win], s47\n\t"
-        "s_mov_b32 s49, 0\n\t"
-        "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
-        "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
-        "s_add_i32 s42, s42, 32\n\t"
-        "s_add_i32 s43, s43, 1\n\t"
-        "s_branch 1b\n"
-        "2:\n\t"
-        "s_and_b32 s47, s40, 0x3ff\n\t"
-        "s_lshl2_add_u32 s47, s47, s55\n\t"
-        "v_mov_b32 %[vt], s47\n\t"
-        "ds_read_b32 %[vt], %[vt]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_readfirstlane_b32 s46, %[vt]\n\t"
-        "s_cmp_lt_i32 s46, 0\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        // ---- one or two literals
-        "s_mov_b32 m0, s45\n\t"
-        "v_writelane_b32 %[lit], s46, m0\n\t"
-        "s_lshr_b32 s47, s46, 8\n\t"
-        "s_add_i32 m0, s45, 1\n\t"
-        "v_writelane_b32 %[lit], s47, m0\n\t"
-        "s_bfe_u32 s47, s46, 0x20018\n\t"
-        "s_add_i32 s45, s45, s47\n\t"
-        "s_bfe_u32 s47, s46, 0x50010\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
-        "s_sub_i32 s42, s42, s47\n\t"
-        "s_cmp_lt_i32 s45, 63\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        // 63 or 64 pending: store them, if the page takes them
-        "s_add_i32 s47, s44, s45\n\t"
-        "s_cmp_gt_u32 s47, 0x10000\n\t"
-        "s_cbranch_scc1 86f\n\t"
-        "v_cmp_gt_u32 vcc, s45, %[lane]\n\t"
-        "s_and_saveexec_b64 s[58:59], vcc\n\t"
-        "v_add_u32 %[vt], s44, %[lane]\n\t"
-        "v_lshlrev_b32 %[vt], 1, %[vt]\n\t"
-        "v_and_b32 %[vt2], 0xff, %[lit]\n\t"
-        "global_store_short %[vt], %[vt2], s[60:61]\n\t"
-        "s_mov_b64 exec, s[58:59]\n\t"
-        "s_mov_b32 s44, s47\n\t"
-        "s_mov_b32 s45, 0\n\t"
-        "s_branch 1b\n"
-        // ---- not a literal
-        "3:\n\t"
-        "s_bitcmp1_b32 s46, 30\n\t"
-        "s_cbranch_scc0 70f\n\t"
-        "s_bfe_u32 s47, s46, 0x50010\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
-        "s_sub_i32 s42, s42, s47\n\t"
-        "s_bfe_u32 s47, s46, 0x30009\n\t"
-        "s_bfm_b32 s48, s47, 0\n\t"
-        "s_and_b32 s48, s48, s40\n\t"
-        "s_and_b32 s51, s46, 0x1ff\n\t"
-        "s_add_i32 s51, s51, s48\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
-        "s_sub_i32 s42, s42, s47\n"
-        // ---- the distance: refill, look up
-        "4:\n\t"
-        "s_cmp_gt_i32 s42, 32\n\t"
-        "s_cbranch_scc1 5f\n\t"
-        "s_sub_i32 s47, s43, s54\n\t"
-        "s_cmp_gt_i32 s47, 63\n\t"
-        "s_cbranch_scc1 80f\n\t"
-        "v_readlane_b32 s48, %[win], s47\n\t"
-        "s_mov_b32 s49, 0\n\t"
-        "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
-        "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
-        "s_add_i32 s42, s42, 32\n\t"
-        "s_add_i32 s43, s43, 1\n\t"
-        "s_branch 4b\n"
-        "5:\n\t"
-        "s_and_b32 s47, s40, 0xff\n\t"
-        "s_lshl2_add_u32 s47, s47, s56\n\t"
-        "v_mov_b32 %[vt], s47\n\t"
-        "ds_read_b32 %[vt], %[vt]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_readfirstlane_b32 s46, %[vt]\n\t"
-        "s_cmp_lt_i32 s46, 0\n\t"
-        "s_cbranch_scc1 83f\n\t"
-        "s_bfe_u32 s47, s46, 0x50014\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
-        "s_sub_i32 s42, s42, s47\n\t"
-        "s_bfe_u32 s47, s46, 0x40010\n\t"
-        "s_bfm_b32 s48, s47, 0\n\t"
-        "s_and_b32 s48, s48, s40\n\t"
-        "s_and_b32 s52, s46, 0x7fff\n\t"
-        "s_add_i32 s52, s52, s48\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
-        "s_sub_i32 s42, s42, s47\n\t"
-        // ---- what the fast copy takes: up to 64 symbols, not overlapping itself, inside this page, source in this page (or markers)
-        "s_cmp_lt_u32 s52, s51\n\t"
-        "s_cbranch_scc1 84f\n\t"
-        "s_cmp_gt_u32 s51, 64\n\t"
-        "s_cbranch_scc1 84f\n\t"
-        "s_add_i32 s47, s44, s45\n\t"
-        "s_add_i32 s48, s47, s51\n\t"
-        "s_cmp_gt_u32 s48, 0x10000\n\t"
-        "s_cbranch_scc1 84f\n\t"
-        "s_cmp_lg_u32 s53, 0\n\t"
-        "s_cbranch_scc1 6f\n\t"
-        "s_cmp_gt_u32 s52, s47\n\t"
-        "s_cbranch_scc1 84f\n"
-        "6:\n\t"
-        // pending literals out
-        "v_cmp_gt_u32 vcc, s45, %[lane]\n\t"
-        "s_and_saveexec_b64 s[58:59], vcc\n\t"
-        "v_add_u32 %[vt], s44, %[lane]\n\t"
-        "v_lshlrev_b32 %[vt], 1, %[vt]\n\t"
-        "v_and_b32 %[vt2], 0xff, %[lit]\n\t"
-        "global_store_short %[vt], %[vt2], s[60:61]\n\t"
-        "s_mov_b64 exec, s[58:59]\n\t"
-        "s_mov_b32 s44, s47\n\t"
-        "s_mov_b32 s45, 0\n\t"
-        // the copy: lane i < len takes the symbol at q = pos - dist + i, or the marker q & 0xFFFF when q < 0
-        "v_cmp_gt_u32 vcc, s51, %[lane]\n\t"
-        "s_and_saveexec_b64 s[58:59], vcc\n\t"
-        "s_sub_i32 s47, s44, s52\n\t"
-        "v_add_u32 %[vq], s47, %[lane]\n\t"
-        "v_and_b32 %[vt2], 0xffff, %[vq]\n\t"
-        "v_cmp_le_i32 vcc, 0, %[vq]\n\t"
-        "s_and_saveexec_b64 s[62:63], vcc\n\t"
-        "v_lshlrev_b32 %[vt], 1, %[vq]\n\t"
-        "global_load_ushort %[vt2], %[vt], s[60:61]\n\t"
-        "s_mov_b64 exec, s[62:63]\n\t"
-        "v_add_u32 %[vt], s44, %[lane]\n\t"
-        "v_lshlrev_b32 %[vt], 1, %[vt]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "global_store_short %[vt], %[vt2], s[60:61]\n\t"
-        "s_mov_b64 exec, s[58:59]\n\t"
-        "s_add_i32 s44, s44, s51\n\t"
-        "s_mov_b32 s51, 0\n\t"
-        "s_branch 1b\n"
+        "\ts_mov_b64 s[68:69], exec\n"
+        "\ts_mov_b64 s[40:41], %[buf]\n"
+        "\ts_mov_b32 s42, %[cnt]\n"
+        "\ts_mov_b32 s43, %[next]\n"
+        "\ts_mov_b32 s44, %[pos]\n"
+        "\ts_mov_b32 s51, %[len]\n"
+        "\ts_mov_b32 s53, %[fp]\n"
+        "\ts_mov_b32 s54, %[wb]\n"
+        "\ts_mov_b32 s55, %[lds]\n"
+        "\ts_mov_b32 s56, %[ldd]\n"
+        "\ts_mov_b64 s[60:61], %[ob]\n"
+        "\ts_mov_b32 s65, %[obuf]\n"
+        "\ts_mov_b32 s52, 0\n"
+        "\ts_mov_b32 s64, 0\n"
+        "\ts_mov_b32 s57, 0x7fffffff\n"
+        "\ts_sub_i32 s67, 0xfffe, s44\n"
+        "\ts_min_i32 s67, s67, 128\n"
+        "\tv_add_u32 %[vslot], s65, %[lane4]\n"
+        "\ts_mov_b64 exec, 3\n"
+        "\ts_cmp_lg_u32 s51, 0\n"
+        "\ts_cbranch_scc1 4f\n"
+        // ---- between symbols: room for two more literals in buffer and page?
+        "8:\n"
+        "\ts_cmp_le_i32 s64, s67\n"
+        "\ts_cbranch_scc1 1f\n"
+        "\ts_cmp_eq_u32 s64, 0\n"
+        "\ts_cbranch_scc1 86f\n"
+        "\ts_mov_b32 s66, 0\n"
+        "\ts_branch 30f\n"
+        // ---- a symbol: look up (lanes 0 and 1 are the active ones here)
+        "1:\n"
+        "\ts_cmp_gt_i32 s42, 32\n"
+        "\ts_cbranch_scc0 10f\n"
+        "\tv_bfe_u32 %[vt], s40, 0, 10\n"
+        "\tv_lshl_add_u32 %[vt], %[vt], 2, s55\n"
+        "\tds_read_b32 %[ve], %[vt]\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tv_readfirstlane_b32 s46, %[ve]\n"
+        "\ts_cmp_lt_i32 s46, 0\n"
+        "\ts_cbranch_scc1 3f\n"
+        // one or two literals: lane 0 writes the first into the next buffer slot, lane 1 the second into the one after (junk, and
+        // overwritten by the next symbol, when the entry holds one)
+        "\tv_bfe_u32 %[vt2], %[ve], %[sh8], 8\n"
+        "\tds_write_b32 %[vslot], %[vt2]\n"
+        "\ts_bfe_u32 s47, s46, 0x20018\n"
+        "\ts_add_i32 s64, s64, s47\n"
+        "\tv_lshl_add_u32 %[vslot], s47, 2, %[vslot]\n"
+        "\ts_bfe_u32 s47, s46, 0x50010\n"
+        "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
+        "\ts_sub_i32 s42, s42, s47\n"
+        "\ts_branch 8b\n"
+        // ---- not a literal: a length symbol with its base and extra bits folded into the entry (the entry is the s_bfe operand)
+        "3:\n"
+        "\ts_bitcmp1_b32 s46, 30\n"
+        "\ts_cbranch_scc0 70f\n"
+        "\ts_bfe_u32 s48, s40, s46\n"
+        "\ts_bfe_u32 s51, s46, 0x90005\n"
+        "\ts_add_i32 s51, s51, s48\n"
+        "\ts_bfe_u32 s47, s46, 0x50017\n"
+        "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
+        "\ts_sub_i32 s42, s42, s47\n"
+        // ---- the distance
+        "4:\n"
+        "\ts_cmp_gt_i32 s42, 32\n"
+        "\ts_cbranch_scc0 11f\n"
+        "\tv_bfe_u32 %[vt], s40, 0, 8\n"
+        "\tv_lshl_add_u32 %[vt], %[vt], 2, s56\n"
+        "\tds_read_b32 %[ve], %[vt]\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tv_readfirstlane_b32 s46, %[ve]\n"
+        "\ts_cmp_lt_i32 s46, 0\n"
+        "\ts_cbranch_scc1 83f\n"
+        "\ts_bfe_u32 s47, s46, 0x50014\n"
+        "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
+        "\ts_sub_i32 s42, s42, s47\n"
+        "\ts_bfe_u32 s47, s46, 0x40010\n"
+        "\ts_bfm_b32 s48, s47, 0\n"
+        "\ts_and_b32 s48, s48, s40\n"
+        "\ts_and_b32 s52, s46, 0x7fff\n"
+        "\ts_add_i32 s52, s52, s48\n"
+        "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
+        "\ts_sub_i32 s42, s42, s47\n"
+        // ---- what the fast copy takes: up to 63 symbols, not overlapping itself, inside this page, source in this page (or markers)
+        "\ts_min_u32 s47, s52, 63\n"
+        "\ts_cmp_gt_u32 s51, s47\n"
+        "\ts_cbranch_scc1 84f\n"
+        "\ts_add_i32 s47, s44, s64\n"
+        "\ts_add_i32 s48, s47, s51\n"
+        "\ts_cmp_gt_u32 s48, 0x10000\n"
+        "\ts_cbranch_scc1 84f\n"
+        "\ts_add_i32 s48, s47, s53\n"
+        "\ts_cmp_gt_u32 s52, s48\n"
+        "\ts_cbranch_scc1 84f\n"
+        // where the source lies: dist - len >= what the buffer holds -> all of it is in memory (or in front of the page: markers)
+        "\ts_sub_i32 s48, s52, s51\n"
+        "\ts_cmp_ge_u32 s48, s64\n"
+        "\ts_cbranch_scc0 65f\n"
+        // far: lane i < len fetches the symbol at q = pos - dist + i STRAIGHT INTO its buffer slot (LDS-direct load: nothing to wait
+        // for, nothing held in registers; the decoding goes on while the symbols travel)
+        "\ts_bfm_b64 exec, s51, 0\n"
+        "\ts_sub_i32 s47, s47, s52\n"
+        "\tv_add_u32 %[vq], s47, %[lane]\n"
+        "\ts_lshl2_add_u32 m0, s64, s65\n"
+        "\ts_cmp_ge_i32 s47, 0\n"
+        "\ts_cbranch_scc0 64f\n"
+        "62:\n"
+        "\tv_lshlrev_b32 %[vt], 1, %[vq]\n"
+        "\ts_min_u32 s57, s57, s64\n"
+        "\tglobal_load_lds_ushort %[vt], s[60:61]\n"
+        "63:\n"
+        "\ts_mov_b64 exec, 3\n"
+        "\ts_add_i32 s64, s64, s51\n"
+        "\tv_lshl_add_u32 %[vslot], s51, 2, %[vslot]\n"
+        "\ts_mov_b32 s51, 0\n"
+        "\ts_branch 8b\n"
+        // (first page) lanes with q < 0 write the marker q & 0xFFFF themselves
+        "64:\n"
+        "\tv_cmp_gt_i32 vcc, 0, %[vq]\n"
+        "\ts_and_saveexec_b64 s[62:63], vcc\n"
+        "\tv_and_b32 %[vt2], 0xffff, %[vq]\n"
+        "\ts_lshl2_add_u32 s48, s64, s65\n"
+        "\tv_add_u32 %[vt], s48, %[lane4]\n"
+        "\tds_write_b32 %[vt], %[vt2]\n"
+        "\ts_andn2_b64 exec, s[62:63], vcc\n"
+        "\ts_cbranch_execz 63b\n"
+        "\ts_branch 62b\n"
+        // near: dist <= what the buffer holds -> all of it is in the buffer (slots ob_n - dist ..); anything else straddles: handed back
+        "65:\n"
+        "\ts_cmp_le_u32 s52, s64\n"
+        "\ts_cbranch_scc0 84f\n"
+        "\ts_sub_i32 s47, s64, s52\n"
+        "\ts_add_i32 s48, s47, s51\n"
+        "\ts_cmp_le_u32 s48, s57\n"
+        "\ts_cbranch_scc1 66f\n"
+        "\ts_waitcnt vmcnt(0)\n"
+        "\ts_mov_b32 s57, 0x7fffffff\n"
+        "66:\n"
+        "\ts_bfm_b64 exec, s51, 0\n"
+        "\ts_lshl2_add_u32 s47, s47, s65\n"
+        "\tv_add_u32 %[vt], s47, %[lane4]\n"
+        "\tds_read_b32 %[vt2], %[vt]\n"
+        "\ts_lshl2_add_u32 s48, s64, s65\n"
+        "\tv_add_u32 %[vt], s48, %[lane4]\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tds_write_b32 %[vt], %[vt2]\n"
+        "\ts_branch 63b\n"
+        // ---- the bit buffer's refills (every ~5 symbols: out of the way)
+        "10:\n"
+        "\ts_sub_i32 s47, s43, s54\n"
+        "\ts_cmp_gt_i32 s47, 63\n"
+        "\ts_cbranch_scc1 80f\n"
+        "\tv_readlane_b32 s48, %[win], s47\n"
+        "\ts_mov_b32 s49, 0\n"
+        "\ts_lshl_b64 s[48:49], s[48:49], s42\n"
+        "\ts_or_b64 s[40:41], s[40:41], s[48:49]\n"
+        "\ts_add_i32 s42, s42, 32\n"
+        "\ts_add_i32 s43, s43, 1\n"
+        "\ts_branch 1b\n"
+        "11:\n"
+        "\ts_sub_i32 s47, s43, s54\n"
+        "\ts_cmp_gt_i32 s47, 63\n"
+        "\ts_cbranch_scc1 80f\n"
+        "\tv_readlane_b32 s48, %[win], s47\n"
+        "\ts_mov_b32 s49, 0\n"
+        "\ts_lshl_b64 s[48:49], s[48:49], s42\n"
+        "\ts_or_b64 s[40:41], s[40:41], s[48:49]\n"
+        "\ts_add_i32 s42, s42, 32\n"
+        "\ts_add_i32 s43, s43, 1\n"
+        "\ts_branch 4b\n"
+        // ---- the buffer (s64 symbols, a dword each) to the page: everything in flight has landed first
+        "30:\n"
+        "\ts_mov_b64 exec, s[68:69]\n"
+        "\ts_waitcnt vmcnt(0)\n"
+        "\tv_add_u32 %[vq], s44, %[lane]\n"
+        "\tv_lshlrev_b32 %[vq], 1, %[vq]\n"
+        "\tv_add_u32 %[vt], s65, %[lane4]\n"
+        "\tv_cmp_gt_i32 vcc, s64, %[lane]\n"
+        "\ts_and_saveexec_b64 s[58:59], vcc\n"
+        "\tds_read_b32 %[vt2], %[vt]\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tglobal_store_short %[vq], %[vt2], s[60:61]\n"
+        "\ts_mov_b64 exec, s[58:59]\n"
+        "\ts_sub_i32 s48, s64, 64\n"
+        "\tv_cmp_gt_i32 vcc, s48, %[lane]\n"
+        "\ts_and_saveexec_b64 s[58:59], vcc\n"
+        "\tds_read_b32 %[vt2], %[vt] offset:256\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tglobal_store_short %[vq], %[vt2], s[60:61] offset:128\n"
+        "\ts_mov_b64 exec, s[58:59]\n"
+        "\ts_sub_i32 s48, s64, 128\n"
+        "\tv_cmp_gt_i32 vcc, s48, %[lane]\n"
+        "\ts_and_saveexec_b64 s[58:59], vcc\n"
+        "\tds_read_b32 %[vt2], %[vt] offset:512\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tglobal_store_short %[vq], %[vt2], s[60:61] offset:256\n"
+        "\ts_mov_b64 exec, s[58:59]\n"
+        "\ts_add_i32 s44, s44, s64\n"
+        "\ts_mov_b32 s64, 0\n"
+        "\ts_mov_b32 s57, 0x7fffffff\n"
+        "\ts_sub_i32 s67, 0xfffe, s44\n"
+        "\ts_min_i32 s67, s67, 128\n"
+        "\tv_add_u32 %[vslot], s65, %[lane4]\n"
+        "\ts_cmp_eq_u32 s66, 0\n"
+        "\ts_cbranch_scc0 91f\n"
+        "\ts_mov_b64 exec, 3\n"
+        "\ts_branch 8b\n"
         // ---- ways out
-        "70:\n\t"
-        "s_mov_b32 s50, 0\n\t"
-        "s_branch 9f\n"
-        "80:\n\t"
-        "s_mov_b32 s50, 2\n\t"
-        "s_branch 9f\n"
-        "83:\n\t"
-        "s_mov_b32 s50, 3\n\t"
-        "s_branch 9f\n"
-        "84:\n\t"
-        "s_mov_b32 s50, 4\n\t"
-        "s_branch 9f\n"
-        "86:\n\t"
-        "s_mov_b32 s50, 6\n"
-        "9:\n\t"
-        "s_mov_b64 %[buf], s[40:41]\n\t"
-        "s_mov_b32 %[cnt], s42\n\t"
-        "s_mov_b32 %[next], s43\n\t"
-        "s_mov_b32 %[pos], s44\n\t"
-        "s_mov_b32 %[ns], s45\n\t"
-        "s_mov_b32 %[e], s46\n\t"
-        "s_mov_b32 %[len], s51\n\t"
-        "s_mov_b32 %[dist], s52\n\t"
-        "s_mov_b32 %[reason], s50"
-        : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [ns] "+s"(n), [len] "+s"(len), [dist] "+s"(dist), [lit] "+v"(mylit),
-          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [e] "=s"(ee), [reason] "=s"(reason)
-        : [wb] "s"(wb), [fp] "s"(fp), [win] "v"(b.win), [lane] "v"(lane), [lds] "s"(lds), [ldd] "s"(ldd), [ob] "s"(ob)
-        : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s58", "s59", "s60", "s61",
-          "s62", "s63", "m0", "scc", "vcc", "memory");
-    b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.ns = n; st.len = len; st.dist = dist; st.e = ee;
+        "70:\n"
+        "\ts_mov_b32 s50, 0\n"
+        "\ts_branch 9f\n"
+        "80:\n"
+        "\ts_mov_b32 s50, 2\n"
+        "\ts_branch 9f\n"
+        "83:\n"
+        "\ts_mov_b32 s50, 3\n"
+        "\ts_branch 9f\n"
+        "84:\n"
+        "\ts_mov_b32 s50, 4\n"
+        "\ts_branch 9f\n"
+        "86:\n"
+        "\ts_mov_b32 s50, 6\n"
+        "9:\n"
+        "\ts_mov_b32 s66, 1\n"
+        "\ts_branch 30b\n"
+        "91:\n"
+        "\ts_mov_b64 %[buf], s[40:41]\n"
+        "\ts_mov_b32 %[cnt], s42\n"
+        "\ts_mov_b32 %[next], s43\n"
+        "\ts_mov_b32 %[pos], s44\n"
+        "\ts_mov_b32 %[e], s46\n"
+        "\ts_mov_b32 %[len], s51\n"
+        "\ts_mov_b32 %[dist], s52\n"
+        "\ts_mov_b32 %[reason], s50"
+        : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [len] "+s"(len), [dist] "+s"(dist),
+          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [ve] "=&v"(ve), [vslot] "=&v"(vslot), [e] "=s"(ee), [reason] "=s"(reason)
+        : [wb] "s"(wb), [fp] "s"(fp), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
+        : "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",
+          "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "m0", "scc", "vcc", "memory");
+    b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.len = len; st.dist = dist; st.e = ee;
     return (int)reason;
 }
 #pragma clang diagnostic pop
 
 // ---- the decoder of one job ----------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens, uint32_t* lut2, uint32_t* dlut) {
+__device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens, uint32_t* lut2, uint32_t* dlut, uint32_t* obuf) {
     const int lane = threadIdx.x & 63;
     const Job job = a.jobs[ji];
     JobOut o;
@@ -408,6 +480,7 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
     o.n_events = 0; o.passed = 0;
     if (job.start == POS_NONE) { if (lane == 0) a.outs[ji] = o; return; }
 
+    const bool count_them = a.counters[7] != 0;   // (BZQ_GZ_COUNT: why sym_run_gz hands back, counted)
     uint32_t lbase, lext, dbase, dext;
     inf::length_dist_tables(lbase, lext, dbase, dext);
     // output: stored symbols [0, opos) + ns pending literals (lane k holds the k-th)
@@ -524,12 +597,13 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
                 return true;
             };
             while (ok) {
+                if (!flush()) { ok = false; break; }            // (the block below knows no pending literals)
                 if (!ensure(opos + 1)) { ok = false; break; }   // `cur` is the page of position opos
-                st.pos = (int)(opos & (PAGE - 1)); st.ns = ns;
-                const int why = sym_run_gz(b, lut2, dlut, cur, cur_idx == 0, st, mylit);
-                opos = (opos & ~(int64_t)(PAGE - 1)) + st.pos; ns = st.ns;
+                st.pos = (int)(opos & (PAGE - 1));
+                const int why = sym_run_gz(b, lut2, dlut, obuf, cur, cur_idx == 0, st);
+                if (count_them && lane == 0) atomicAdd(&a.counters[8 + why], 1u);
+                opos = (opos & ~(int64_t)(PAGE - 1)) + st.pos;
                 if (why == 2) { b.refill(); if (b.ran_out) { ok = false; break; } continue; }   // (with st.len set it resumes in the distance half)
-                if (why == 6) { if (!flush() || b.ran_out) { ok = false; break; } continue; }    // pending literals across the page's end
                 if (why == 4) { if (!general_copy(st.len, st.dist)) { ok = false; break; } st.len = 0; continue; }
                 if (why == 3) {   // a distance code the direct table does not hold
                     const int ds = inf::decode_sym(b, dd, sym_d);
@@ -539,8 +613,9 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
                     st.len = 0;
                     continue;
                 }
-                // why == 0: end of block, a literal / length code longer than the table's index, or no code at all
-                const uint32_t e = st.e & 0xFFFFu;
+                // why == 0: end of block, a literal / length code longer than the table's index, or no code at all;
+                // why == 6: the page has fewer than two slots left -- one symbol the long way (a literal then crosses into the next page here)
+                const uint32_t e = why == 6 ? inf::LUT_LONG : st.e & 0xFFFFu;
                 int s;
                 if (e != inf::LUT_LONG) { s = (int)(e & 0xFFFu); const int l = (int)(e >> 12); b.buf >>= l; b.cnt -= l; }
                 else { s = inf::decode_sym(b, ll, sym_ll); if (s < 0) { ok = false; break; } }
@@ -583,15 +658,18 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
     if (lane == 0) a.outs[ji] = o;
 }
 
-static __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_gz_decode(Args a) {
-    __shared__ uint16_t s_ll[WAVES][288 + 32];
-    __shared__ uint8_t s_len[WAVES][320 + 64];
-    __shared__ uint32_t s_lut[WAVES][1 << inf::LUT_BITS];
-    __shared__ uint32_t s_dlut[WAVES][1 << inf::DLUT_BITS];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int k = (int)blockIdx.x * WAVES + wave;
-    if (k >= a.n_jobs) return;
-    run_job(a, a.job_base + k, s_ll[wave], s_ll[wave] + 288, s_len[wave], s_lut[wave], s_dlut[wave]);
+// One wave per workgroup: a workgroup's LDS and wave slots are held until its LAST wave is done, and the jobs' lengths differ by
+// a factor of three and more -- with four jobs to a workgroup the slots sat behind the longest of four.
+constexpr int DEC_BLOCK = 64;
+static __global__ __launch_bounds__(DEC_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_gz_decode(Args a) {
+    __shared__ uint16_t s_ll[288 + 32];
+    __shared__ uint32_t s_lut[1 << inf::LUT_BITS];
+    __shared__ uint32_t s_dlut[1 << inf::DLUT_BITS];
+    __shared__ uint32_t s_ob[OB_SLOTS];   // sym_run_gz's output buffer; between its calls (it leaves it empty) the code lengths of a block header
+    static_assert(OB_FLUSH == 128 && OB_SLOTS >= OB_FLUSH + 64 && OB_SLOTS * 4 >= 320 + 64, "the code lengths share the output buffer");
+    if ((int)blockIdx.x >= a.n_jobs) return;
+    const int k = a.order ? (int)a.order[blockIdx.x] : (int)blockIdx.x;
+    run_job(a, a.job_base + k, s_ll, s_ll + 288, reinterpret_cast<uint8_t*>(s_ob), s_lut, s_dlut, s_ob);
 }
 
 // ---- one lane's look at a dynamic block header: a NECESSARY condition, cheap ---------------------------------------------------
@@ -894,6 +972,38 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
     if (lane == 0) a.jobs[c] = Job{found, c + 1, 0};
 }
 
+// ---- ORDER: the longest jobs first ---------------------------------------------------------------------------------------------
+// A job runs from its chunk's start to the next chunk that has one: mostly one or two chunks, sometimes many (a chunk inside a
+// long block has no start).  Workgroups are dispatched in index order, so with the jobs in chunk order the launch ended with
+// a few long jobs running alone (the decode kernel took twice the time its work divided by the machine's wave slots).  Two tiny
+// launches sort the chunks by the distance to the next start, descending (a counting sort over 64 bins; chunks without a start
+// last): longest processing time first.
+constexpr int ORDER_BINS = 64;
+static __global__ __launch_bounds__(BLOCK) void k_gz_span(const Job* jobs, int n, uint8_t* keys, uint32_t* bins) {
+    const int c = (int)(blockIdx.x * BLOCK + threadIdx.x);
+    if (c >= n) return;
+    int key = 0;
+    if (jobs[c].start != POS_NONE) {
+        key = 1;
+        while (key < ORDER_BINS - 1 && c + key < n && jobs[c + key].start == POS_NONE) ++key;
+    }
+    keys[c] = (uint8_t)key;
+    atomicAdd(&bins[key], 1u);
+}
+static __global__ __launch_bounds__(BLOCK) void k_gz_order(int n, const uint8_t* keys, const uint32_t* bins, uint32_t* cursor, uint32_t* order) {
+    __shared__ uint32_t base[ORDER_BINS];
+    if (threadIdx.x < ORDER_BINS) {
+        uint32_t b = 0;
+        for (int k = ORDER_BINS - 1; k > (int)threadIdx.x; --k) b += bins[k];
+        base[threadIdx.x] = b;
+    }
+    __syncthreads();
+    const int c = (int)(blockIdx.x * BLOCK + threadIdx.x);
+    if (c >= n) return;
+    const int key = keys[c];
+    order[base[key] + atomicAdd(&cursor[key], 1u)] = (uint32_t)c;
+}
+
 // ---- CHAIN: the window behind every chain chunk; its tail (the last <= 32 KiB) goes out final ---------------------------------------
 // The window behind chunk i is a function of the window in front of it: new[k] = a byte the chunk wrote, or old[index] where it
 // wrote a marker.  Such functions compose (a table of 32768 symbols whose markers point into the OLDER window), so the chain
@@ -1119,7 +1229,7 @@ struct bzq_gzip {
     int32_t chunk_bytes = 16384;        // CH: one decoder wave per this many compressed bytes (zlib closes a block every ~20 KiB of FASTQ output stream)
     // device
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf comp[2], jobs, outs, pool, page_next, counters, events, items, crcs, win[2], chain_maps, chain_wins;
+    Buf comp[2], jobs, outs, order, pool, page_next, counters, events, items, crcs, win[2], chain_maps, chain_wins;
     Buf h_outs, h_events, h_pages, h_items, h_crcs;   // pinned host staging
     uint32_t pool_pages = 0;
     int wcur = 0;                       // win[wcur]: the 32 KiB of output in front of the next piece
@@ -1190,7 +1300,7 @@ inline void gz_free(bzq_gzip* h) {
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     for (hipEvent_t e : h->staged_ev) if (e) (void)hipEventDestroy(e);
-    for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->jobs, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
+    for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->order, &h->jobs, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
         if (b->p) (void)hipFree(b->p);
     for (bzq_gzip::Buf* b : {&h->h_outs, &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs})
         if (b->p) (void)hipHostFree(b->p);
@@ -1300,7 +1410,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     }
     struct Release { bzq_gzip* h; int b; ~Release() { std::lock_guard<std::mutex> lk(h->stage_mu); h->comp_busy[b] = false; } } release{h, cb};
     if (!use_staged) GZCHK(h, hipEventSynchronize(h->staged_ev[cb]));   // (whatever was last staged into it has arrived)
-    if ((!use_staged && (rc = gz_ensure(h, h->comp[cb], n + 64))) || (rc = gz_ensure(h, h->jobs, (size_t)n_jobs_cap * sizeof(Job))) ||
+    if ((rc = gz_ensure(h, h->order, (size_t)2 * ORDER_BINS * 4 + (size_t)n_chunks * 5 + 64)) || (!use_staged && (rc = gz_ensure(h, h->comp[cb], n + 64))) || (rc = gz_ensure(h, h->jobs, (size_t)n_jobs_cap * sizeof(Job))) ||
         (rc = gz_ensure(h, h->outs, (size_t)n_jobs_cap * sizeof(JobOut))) || (rc = gz_ensure(h, h->events, (size_t)max_events * sizeof(Event))) ||
         (rc = gz_ensure(h, h->h_outs, (size_t)n_jobs_cap * sizeof(JobOut) + 64, true)))
         return rc;
@@ -1327,7 +1437,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     for (int attempt = 0;; ++attempt) {
         if ((rc = gz_ensure(h, h->pool, ((size_t)h->pool_pages << PAGE_SHIFT) * 2)) || (rc = gz_ensure(h, h->page_next, (size_t)h->pool_pages * 4))) return rc;
         const Job j0{h->start_pos, 1, 0};
-        GZCHK(h, hipMemsetAsync(h->counters.p, 0, 32, s));
+        GZCHK(h, hipMemsetAsync(h->counters.p, 0, 64, s));
         static const bool counting = getenv("BZQ_GZ_COUNT") != nullptr;   // debug: the finder's survivor counts (atomics in its loop: not for timing)
         if (counting) { const uint32_t one = 1; GZCHK(h, hipMemcpyAsync((uint32_t*)h->counters.p + 7, &one, 4, hipMemcpyHostToDevice, s)); }
         GZCHK(h, hipMemcpyAsync(h->jobs.p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
@@ -1335,13 +1445,26 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
                  (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events, max_job, (int64_t)std::max<uint64_t>(out_cap, 1ull << 20)};
         const unsigned grid = (unsigned)((n_chunks + WAVES - 1) / WAVES);
         hipLaunchKernelGGL(k_gz_find, dim3(grid), dim3(BLOCK), 0, s, a);
+        {   // [bins][cursor][order n_chunks][keys n_chunks]
+            uint32_t* bins = (uint32_t*)h->order.p;
+            uint32_t* order = bins + 2 * ORDER_BINS;
+            uint8_t* keys = (uint8_t*)(order + n_chunks);
+            GZCHK(h, hipMemsetAsync(bins, 0, 2 * ORDER_BINS * 4, s));
+            const unsigned g1 = (unsigned)((n_chunks + BLOCK - 1) / BLOCK);
+            hipLaunchKernelGGL(k_gz_span, dim3(g1), dim3(BLOCK), 0, s, (const Job*)h->jobs.p, n_chunks, keys, bins);
+            hipLaunchKernelGGL(k_gz_order, dim3(g1), dim3(BLOCK), 0, s, n_chunks, (const uint8_t*)keys, (const uint32_t*)bins, bins + ORDER_BINS, order);
+            a.order = order;
+        }
         if (timing) { GZCHK(h, hipStreamSynchronize(s)); lap(1); }
-        hipLaunchKernelGGL(k_gz_decode, dim3(grid), dim3(BLOCK), 0, s, a);
+        hipLaunchKernelGGL(k_gz_decode, dim3((unsigned)n_chunks), dim3(DEC_BLOCK), 0, s, a);
         GZCHK(h, hipGetLastError());
         GZCHK(h, hipMemcpyAsync(outs, h->outs.p, (size_t)n_chunks * sizeof(JobOut), hipMemcpyDeviceToHost, s));
-        GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 32, hipMemcpyDeviceToHost, s));
+        GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 64, hipMemcpyDeviceToHost, s));
         GZCHK(h, hipStreamSynchronize(s));
         lap(2);
+        if (getenv("BZQ_GZ_EARLY")) fprintf(stderr, "early: find %.2f decode %.2f (%d chunks)\n", t_ph[1], t_ph[2], n_chunks);
+        if (counting) fprintf(stderr, "bzq_gzip decoder: the symbol loop handed back %u times for a code it does not take / the end of a block, %u for its window, %u for a long distance code, %u for a copy it does not take, %u at a page's end\n",
+                              h_counters[8], h_counters[10], h_counters[11], h_counters[12], h_counters[14]);
         if (counting) fprintf(stderr, "bzq_gzip finder: %u positions passed the 13-bit filter, %u of them the code length code test, %u of those one lane's look at the code lengths (judged by the whole wave)\n", h_counters[3], h_counters[4], h_counters[5]);
         if (h_counters[0] <= h->pool_pages) break;
         if (attempt == 8) return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: the symbol pool keeps overflowing (" + std::to_string(h->pool_pages) + " pages)");
@@ -1371,8 +1494,8 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
             const int k = n_chunks + fallbacks++;
             const Job jb{o.end, (int32_t)std::min<uint64_t>((uint64_t)n_chunks, (o.end >> 4) / (uint64_t)CH), 0};
             GZCHK(h, hipMemcpyAsync((Job*)h->jobs.p + k, &jb, sizeof jb, hipMemcpyHostToDevice, s));
-            a.job_base = k; a.n_jobs = 1;
-            hipLaunchKernelGGL(k_gz_decode, dim3(1), dim3(BLOCK), 0, s, a);
+            a.job_base = k; a.n_jobs = 1; a.order = nullptr;
+            hipLaunchKernelGGL(k_gz_decode, dim3(1), dim3(DEC_BLOCK), 0, s, a);
             GZCHK(h, hipMemcpyAsync(outs + k, (JobOut*)h->outs.p + k, sizeof(JobOut), hipMemcpyDeviceToHost, s));
             GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 16, hipMemcpyDeviceToHost, s));
             GZCHK(h, hipStreamSynchronize(s));

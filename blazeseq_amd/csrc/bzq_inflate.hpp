@@ -165,8 +165,10 @@ __device__ __forceinline__ void build_lut(const Code& code, const uint16_t* symt
 // latency, and in FASTQ most symbols are literals with short codes (bases: 2-3 bits, qualities: 4-6), so two of
 // them usually fit the 10 index bits -- one trip through the loop then delivers two bytes.
 //   bit 31      the first symbol is not a literal with a code of <= LUT_BITS bits.  Bit 30 set: a LENGTH symbol (257..285) with
-//               such a code, base and extra bits folded in: bits 0..8 = base length, 9..11 = number of extra bits, 16..20 = code
-//               bits.  Bit 30 clear: bits 0..15 = the one-symbol entry of build_lut (end of block, a longer code, no code)
+//               such a code, base and extra bits folded in, laid out so that the entry itself is the operand of the s_bfe_u32
+//               that pulls the extra bits out of the bit buffer (offset = S1[4:0], width = S1[22:16], the rest is ignored):
+//               bits 0..4 = code bits, 16..18 = number of extra bits; bits 5..13 = base length, 23..27 = code + extra bits.
+//               Bit 30 clear: bits 0..15 = the one-symbol entry of build_lut (end of block, a longer code, no code)
 //   bits 0..7   first literal, bits 8..15 second literal, bits 24..25 = how many (1 or 2), bits 16..20 = code bits consumed by both
 // lut2 = LUT_BITS-indexed, 4 KiB; its upper half serves as the one-symbol table while it is built.
 __device__ __forceinline__ void build_lut2(const Code& code, const uint16_t* symtab, const uint8_t* lens, uint32_t* lut2) {
@@ -183,7 +185,7 @@ __device__ __forceinline__ void build_lut2(const Code& code, const uint16_t* sym
             if (e1 != LUT_LONG && sym >= 257u && sym <= 285u) {   // RFC 1951 3.2.5
                 const uint32_t c = sym - 257u, ext = (c < 8u || c >= 28u) ? 0u : (c - 4u) >> 2;
                 const uint32_t base = c < 8u ? 3u + c : (c >= 28u ? 258u : 3u + ((4u + (c & 3u)) << ext));
-                ent[k] = 0xC0000000u | base | (ext << 9) | ((e1 >> 12) << 16);
+                ent[k] = 0xC0000000u | (e1 >> 12) | (base << 5) | (ext << 16) | (((e1 >> 12) + ext) << 23);
             } else ent[k] = 0x80000000u | e1;
             continue;
         }
@@ -326,14 +328,10 @@ __device__ __forceinline__ int sym_run(BitsT& b, const uint32_t* lut2, const uin
         "3:\n\t"
         "s_bitcmp1_b32 s46, 30\n\t"
         "s_cbranch_scc0 70f\n\t"
-        "s_bfe_u32 s47, s46, 0x50010\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
-        "s_sub_i32 s42, s42, s47\n\t"
-        "s_bfe_u32 s47, s46, 0x30009\n\t"
-        "s_bfm_b32 s48, s47, 0\n\t"
-        "s_and_b32 s48, s48, s40\n\t"
-        "s_and_b32 s51, s46, 0x1ff\n\t"
+        "s_bfe_u32 s48, s40, s46\n\t"
+        "s_bfe_u32 s51, s46, 0x90005\n\t"
         "s_add_i32 s51, s51, s48\n\t"
+        "s_bfe_u32 s47, s46, 0x50017\n\t"
         "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
         "s_sub_i32 s42, s42, s47\n"
         // ---- the distance: refill, look up
