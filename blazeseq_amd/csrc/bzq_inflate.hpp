@@ -484,6 +484,21 @@ __device__ __forceinline__ uint32_t block_crc32(const uint8_t* out, int n, const
     const int lo = lane * seg < n ? lane * seg : n, hi = lo + seg < n ? lo + seg : n;
     uint32_t r = 0;
     int i = lo;
+    // (64 bytes per trip, the four loads of a cache line back to back: the lanes' pieces lie seg bytes apart, and a dword per
+    // load fetched every line from L2 sixteen times)
+    struct W4 { uint32_t w[4]; };
+    struct __attribute__((packed, aligned(1))) W4U { W4 v; };
+    for (; i + 64 <= hi; i += 64) {
+        W4 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = reinterpret_cast<const W4U*>(out + i + 16 * j)->v;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            uint32_t w = q[j >> 2].w[j & 3];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { r = s_tab[(r ^ w) & 0xFFu] ^ (r >> 8); w >>= 8; }
+        }
+    }
     for (; i + 4 <= hi; i += 4) {
         uint32_t w = reinterpret_cast<const U32U*>(out + i)->v;
 #pragma unroll
