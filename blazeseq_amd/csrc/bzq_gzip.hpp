@@ -215,7 +215,8 @@ __device__ __forceinline__ int64_t parse_member_header(const uint8_t* comp, int6
 // those very slots may be in flight: s57 = the lowest slot written by a load since the last vmcnt(0)); one that straddles
 // buffer and page is handed back (4).  Every way out writes the buffer out: outside this block the page holds everything in
 // front of st.pos.
-constexpr int OB_SLOTS = 192, OB_FLUSH = 128;   // (at most OB_FLUSH + 2 literals, or OB_FLUSH + a match of 63 symbols; the asm has the 128)
+using inf::OB_SLOTS;
+using inf::OB_FLUSH;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const uint32_t* dlut, uint32_t* obuf, uint16_t* page, bool first, inf::SymState& st) {
@@ -254,7 +255,7 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_cmp_le_i32 s64, s67\n"
         "\ts_cbranch_scc1 1f\n"
         "\ts_cmp_eq_u32 s64, 0\n"
-        "\ts_cbranch_scc1 86f\n"
+        "\ts_cbranch_scc1 12f\n"
         "\ts_mov_b32 s66, 0\n"
         "\ts_branch 30f\n"
         // ---- a symbol: look up (lanes 0 and 1 are the active ones here)
@@ -397,6 +398,20 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_add_i32 s42, s42, 32\n"
         "\ts_add_i32 s43, s43, 1\n"
         "\ts_branch 4b\n"
+        // (on the way out through 6 the bit buffer is as full as on every other way out: the caller decodes a symbol from it)
+        "12:\n"
+        "\ts_cmp_gt_i32 s42, 32\n"
+        "\ts_cbranch_scc1 86f\n"
+        "\ts_sub_i32 s47, s43, s54\n"
+        "\ts_cmp_gt_i32 s47, 63\n"
+        "\ts_cbranch_scc1 80f\n"
+        "\tv_readlane_b32 s48, %[win], s47\n"
+        "\ts_mov_b32 s49, 0\n"
+        "\ts_lshl_b64 s[48:49], s[48:49], s42\n"
+        "\ts_or_b64 s[40:41], s[40:41], s[48:49]\n"
+        "\ts_add_i32 s42, s42, 32\n"
+        "\ts_add_i32 s43, s43, 1\n"
+        "\ts_branch 12b\n"
         // ---- the buffer (s64 symbols, a dword each) to the page: everything in flight has landed first
         "30:\n"
         "\ts_mov_b64 exec, s[68:69]\n"

@@ -430,6 +430,283 @@ __device__ __forceinline__ int sym_run(BitsT& b, const uint32_t* lut2, const uin
     b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.ns = n; st.len = len; st.dist = dist; st.e = ee;
     return (int)reason;
 }
+// ---- the symbol loop, second generation -------------------------------------------------------------------------------------------
+// What bounds these kernels is the CU's ONE scalar unit (experiments/micro/salu_loop.hip and PMC: the waves of a CU want
+// several scalar instructions per cycle, it issues one), so this loop needs few of them and puts what it can on the vector
+// unit: the table index is computed there (v_bfe, v_lshl_add), literals go from the entry register to the output buffer
+// without passing a scalar register (lanes 0 and 1 are the only active ones between matches: lane 0 writes the first literal
+// of the entry, lane 1 the second), a length entry is its own s_bfe operand.  11 scalar instructions per lookup of one or
+// two literals, ~50 per match (sym_run: 15 and ~70).
+// The bytes do not go to memory one match at a time: they collect in an LDS buffer (`obuf`, OB_SLOTS dwords, one byte each)
+// that is written out 64 lanes wide when it holds more than OB_FLUSH.  That lets a match NOT wait for its source:
+// global_load_lds_ubyte puts lane i's byte straight into buffer slot i of the match (a zero-extended DWORD per lane at
+// M0 + 4 * lane: experiments/micro/glds_u16.hip), and the loop goes on decoding while it travels.  A source still in the buffer
+// is copied inside it (after a wait, if a load into those very slots may be in flight: s57 = the lowest slot written by a
+// load since the last vmcnt(0)); one that straddles buffer and memory is handed back (4).  Every way out writes the buffer
+// out: outside this block `out` holds everything in front of st.pos.  No pending literals in here (st.ns must be 0).
+// It leaves with sym_run's reasons, and
+//   6  fewer than two bytes of the block's size are left (the caller decodes one symbol itself)
+constexpr int OB_SLOTS = 192, OB_FLUSH = 128;   // (at most OB_FLUSH + 2 literals, or OB_FLUSH + a match of 63 bytes; the asm has the 128)
+template <class BitsT>
+__device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const uint32_t* dlut, uint32_t* obuf, uint8_t* out, int usize, SymState& st) {
+    uint32_t reason, vt, vt2, vq, ve, vslot, ee;
+    u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
+    int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), pos = (int)uni((uint32_t)st.pos);
+    int len = (int)uni((uint32_t)st.len), dist = 0;
+    const int wb = (int)uni((uint32_t)b.win_base), us2 = (int)uni((uint32_t)(usize - 2));
+    const uint32_t lds = uni((uint32_t)(uintptr_t)lut2), ldd = uni((uint32_t)(uintptr_t)dlut), ldo = uni((uint32_t)(uintptr_t)obuf);
+    const u64 ob = ((u64)uni((uint32_t)((uintptr_t)out >> 32)) << 32) | uni((uint32_t)(uintptr_t)out);
+    const uint32_t lane = threadIdx.x & 63, lane4 = lane << 2, sh8 = lane << 3;
+    asm volatile(
+        "\ts_mov_b64 s[68:69], exec\n"
+        "\ts_mov_b64 s[40:41], %[buf]\n"
+        "\ts_mov_b32 s42, %[cnt]\n"
+        "\ts_mov_b32 s43, %[next]\n"
+        "\ts_mov_b32 s44, %[pos]\n"
+        "\ts_mov_b32 s51, %[len]\n"
+        "\ts_mov_b32 s53, %[us2]\n"
+        "\ts_mov_b32 s54, %[wb]\n"
+        "\ts_mov_b32 s55, %[lds]\n"
+        "\ts_mov_b32 s56, %[ldd]\n"
+        "\ts_mov_b64 s[60:61], %[ob]\n"
+        "\ts_mov_b32 s65, %[obuf]\n"
+        "\ts_mov_b32 s52, 0\n"
+        "\ts_mov_b32 s64, 0\n"
+        "\ts_mov_b32 s57, 0x7fffffff\n"
+        "\ts_sub_i32 s67, s53, s44\n"
+        "\ts_min_i32 s67, s67, 128\n"
+        "\tv_add_u32 %[vslot], s65, %[lane4]\n"
+        "\ts_mov_b64 exec, 3\n"
+        "\ts_cmp_lg_u32 s51, 0\n"
+        "\ts_cbranch_scc1 4f\n"
+        // ---- between symbols: room for two more literals in buffer and block?
+        "8:\n"
+        "\ts_cmp_le_i32 s64, s67\n"
+        "\ts_cbranch_scc1 1f\n"
+        "\ts_cmp_eq_u32 s64, 0\n"
+        "\ts_cbranch_scc1 12f\n"
+        "\ts_mov_b32 s66, 0\n"
+        "\ts_branch 30f\n"
+        // ---- a symbol: look up (lanes 0 and 1 are the active ones here)
+        "1:\n"
+        "\ts_cmp_gt_i32 s42, 32\n"
+        "\ts_cbranch_scc0 10f\n"
+        "\tv_bfe_u32 %[vt], s40, 0, 10\n"
+        "\tv_lshl_add_u32 %[vt], %[vt], 2, s55\n"
+        "\tds_read_b32 %[ve], %[vt]\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tv_readfirstlane_b32 s46, %[ve]\n"
+        "\ts_cmp_lt_i32 s46, 0\n"
+        "\ts_cbranch_scc1 3f\n"
+        // one or two literals: lane 0 writes the first into the next buffer slot, lane 1 the second into the one after (junk, and
+        // overwritten by the next symbol, when the entry holds one)
+        "\tv_bfe_u32 %[vt2], %[ve], %[sh8], 8\n"
+        "\tds_write_b32 %[vslot], %[vt2]\n"
+        "\ts_bfe_u32 s47, s46, 0x20018\n"
+        "\ts_add_i32 s64, s64, s47\n"
+        "\tv_lshl_add_u32 %[vslot], s47, 2, %[vslot]\n"
+        "\ts_bfe_u32 s47, s46, 0x50010\n"
+        "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
+        "\ts_sub_i32 s42, s42, s47\n"
+        "\ts_branch 8b\n"
+        // ---- not a literal: a length symbol with its base and extra bits folded into the entry (the entry is the s_bfe operand)
+        "3:\n"
+        "\ts_bitcmp1_b32 s46, 30\n"
+        "\ts_cbranch_scc0 70f\n"
+        "\ts_bfe_u32 s48, s40, s46\n"
+        "\ts_bfe_u32 s51, s46, 0x90005\n"
+        "\ts_add_i32 s51, s51, s48\n"
+        "\ts_bfe_u32 s47, s46, 0x50017\n"
+        "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
+        "\ts_sub_i32 s42, s42, s47\n"
+        // ---- the distance
+        "4:\n"
+        "\ts_cmp_gt_i32 s42, 32\n"
+        "\ts_cbranch_scc0 11f\n"
+        "\tv_bfe_u32 %[vt], s40, 0, 8\n"
+        "\tv_lshl_add_u32 %[vt], %[vt], 2, s56\n"
+        "\tds_read_b32 %[ve], %[vt]\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tv_readfirstlane_b32 s46, %[ve]\n"
+        "\ts_cmp_lt_i32 s46, 0\n"
+        "\ts_cbranch_scc1 83f\n"
+        "\ts_bfe_u32 s47, s46, 0x50014\n"
+        "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
+        "\ts_sub_i32 s42, s42, s47\n"
+        "\ts_bfe_u32 s47, s46, 0x40010\n"
+        "\ts_bfm_b32 s48, s47, 0\n"
+        "\ts_and_b32 s48, s48, s40\n"
+        "\ts_and_b32 s52, s46, 0x7fff\n"
+        "\ts_add_i32 s52, s52, s48\n"
+        "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
+        "\ts_sub_i32 s42, s42, s47\n"
+        // ---- invalid: a source in front of the block's output, output beyond the block's size
+        "\ts_add_i32 s47, s44, s64\n"
+        "\ts_cmp_gt_u32 s52, s47\n"
+        "\ts_cbranch_scc1 85f\n"
+        "\ts_add_i32 s48, s47, s51\n"
+        "\ts_sub_i32 s48, s48, 2\n"
+        "\ts_cmp_gt_i32 s48, s53\n"
+        "\ts_cbranch_scc1 85f\n"
+        // ---- what the fast copy takes: up to 63 bytes, not overlapping itself
+        "\ts_min_u32 s48, s52, 63\n"
+        "\ts_cmp_gt_u32 s51, s48\n"
+        "\ts_cbranch_scc1 84f\n"
+        // where the source lies: dist - len >= what the buffer holds -> all of it is in memory
+        "\ts_sub_i32 s48, s52, s51\n"
+        "\ts_cmp_ge_u32 s48, s64\n"
+        "\ts_cbranch_scc0 65f\n"
+        // far: lane i < len fetches the byte at pos - dist + i STRAIGHT INTO its buffer slot (LDS-direct load: nothing to wait for)
+#ifdef BZQ_OB_NO_FAR
+        "\ts_branch 84f\n"
+#endif
+        "\ts_bfm_b64 exec, s51, 0\n"
+        "\ts_sub_i32 s47, s47, s52\n"
+        "\tv_add_u32 %[vq], s47, %[lane]\n"
+        "\ts_lshl2_add_u32 m0, s64, s65\n"
+        "\ts_min_u32 s57, s57, s64\n"
+        "\ts_nop 0\n"
+        "\tglobal_load_lds_ubyte %[vq], s[60:61]\n"
+        "63:\n"
+        "\ts_mov_b64 exec, 3\n"
+        "\ts_add_i32 s64, s64, s51\n"
+        "\tv_lshl_add_u32 %[vslot], s51, 2, %[vslot]\n"
+        "\ts_mov_b32 s51, 0\n"
+        "\ts_branch 8b\n"
+        // near: dist <= what the buffer holds -> all of it is in the buffer (slots ob_n - dist ..); anything else straddles: handed back
+        "65:\n"
+#ifdef BZQ_OB_NO_NEAR
+        "\ts_branch 84f\n"
+#endif
+        "\ts_cmp_le_u32 s52, s64\n"
+        "\ts_cbranch_scc0 84f\n"
+        "\ts_sub_i32 s47, s64, s52\n"
+        "\ts_add_i32 s48, s47, s51\n"
+        "\ts_cmp_le_u32 s48, s57\n"
+        "\ts_cbranch_scc1 66f\n"
+        "\ts_waitcnt vmcnt(0)\n"
+        "\ts_mov_b32 s57, 0x7fffffff\n"
+        "66:\n"
+        "\ts_bfm_b64 exec, s51, 0\n"
+        "\ts_lshl2_add_u32 s47, s47, s65\n"
+        "\tv_add_u32 %[vt], s47, %[lane4]\n"
+        "\tds_read_b32 %[vt2], %[vt]\n"
+        "\ts_lshl2_add_u32 s48, s64, s65\n"
+        "\tv_add_u32 %[vt], s48, %[lane4]\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tds_write_b32 %[vt], %[vt2]\n"
+        "\ts_branch 63b\n"
+        // ---- the bit buffer's refills (every ~5 symbols: out of the way)
+        "10:\n"
+        "\ts_sub_i32 s47, s43, s54\n"
+        "\ts_cmp_gt_i32 s47, 63\n"
+        "\ts_cbranch_scc1 80f\n"
+        "\tv_readlane_b32 s48, %[win], s47\n"
+        "\ts_mov_b32 s49, 0\n"
+        "\ts_lshl_b64 s[48:49], s[48:49], s42\n"
+        "\ts_or_b64 s[40:41], s[40:41], s[48:49]\n"
+        "\ts_add_i32 s42, s42, 32\n"
+        "\ts_add_i32 s43, s43, 1\n"
+        "\ts_branch 1b\n"
+        "11:\n"
+        "\ts_sub_i32 s47, s43, s54\n"
+        "\ts_cmp_gt_i32 s47, 63\n"
+        "\ts_cbranch_scc1 80f\n"
+        "\tv_readlane_b32 s48, %[win], s47\n"
+        "\ts_mov_b32 s49, 0\n"
+        "\ts_lshl_b64 s[48:49], s[48:49], s42\n"
+        "\ts_or_b64 s[40:41], s[40:41], s[48:49]\n"
+        "\ts_add_i32 s42, s42, 32\n"
+        "\ts_add_i32 s43, s43, 1\n"
+        "\ts_branch 4b\n"
+        // (on the way out through 6 the bit buffer is as full as on every other way out: the caller decodes a symbol from it)
+        "12:\n"
+        "\ts_cmp_gt_i32 s42, 32\n"
+        "\ts_cbranch_scc1 86f\n"
+        "\ts_sub_i32 s47, s43, s54\n"
+        "\ts_cmp_gt_i32 s47, 63\n"
+        "\ts_cbranch_scc1 80f\n"
+        "\tv_readlane_b32 s48, %[win], s47\n"
+        "\ts_mov_b32 s49, 0\n"
+        "\ts_lshl_b64 s[48:49], s[48:49], s42\n"
+        "\ts_or_b64 s[40:41], s[40:41], s[48:49]\n"
+        "\ts_add_i32 s42, s42, 32\n"
+        "\ts_add_i32 s43, s43, 1\n"
+        "\ts_branch 12b\n"
+        // ---- the buffer (s64 bytes, a dword each) to the output: everything in flight has landed first
+        "30:\n"
+        "\ts_mov_b64 exec, s[68:69]\n"
+        "\ts_waitcnt vmcnt(0)\n"
+        "\tv_add_u32 %[vq], s44, %[lane]\n"
+        "\tv_add_u32 %[vt], s65, %[lane4]\n"
+        "\tv_cmp_gt_i32 vcc, s64, %[lane]\n"
+        "\ts_and_saveexec_b64 s[58:59], vcc\n"
+        "\tds_read_b32 %[vt2], %[vt]\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tglobal_store_byte %[vq], %[vt2], s[60:61]\n"
+        "\ts_mov_b64 exec, s[58:59]\n"
+        "\ts_sub_i32 s48, s64, 64\n"
+        "\tv_cmp_gt_i32 vcc, s48, %[lane]\n"
+        "\ts_and_saveexec_b64 s[58:59], vcc\n"
+        "\tds_read_b32 %[vt2], %[vt] offset:256\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tglobal_store_byte %[vq], %[vt2], s[60:61] offset:64\n"
+        "\ts_mov_b64 exec, s[58:59]\n"
+        "\ts_sub_i32 s48, s64, 128\n"
+        "\tv_cmp_gt_i32 vcc, s48, %[lane]\n"
+        "\ts_and_saveexec_b64 s[58:59], vcc\n"
+        "\tds_read_b32 %[vt2], %[vt] offset:512\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tglobal_store_byte %[vq], %[vt2], s[60:61] offset:128\n"
+        "\ts_mov_b64 exec, s[58:59]\n"
+        "\ts_add_i32 s44, s44, s64\n"
+        "\ts_mov_b32 s64, 0\n"
+        "\ts_mov_b32 s57, 0x7fffffff\n"
+        "\ts_sub_i32 s67, s53, s44\n"
+        "\ts_min_i32 s67, s67, 128\n"
+        "\tv_add_u32 %[vslot], s65, %[lane4]\n"
+        "\ts_cmp_eq_u32 s66, 0\n"
+        "\ts_cbranch_scc0 91f\n"
+        "\ts_mov_b64 exec, 3\n"
+        "\ts_branch 8b\n"
+        // ---- ways out
+        "70:\n"
+        "\ts_mov_b32 s50, 0\n"
+        "\ts_branch 9f\n"
+        "80:\n"
+        "\ts_mov_b32 s50, 2\n"
+        "\ts_branch 9f\n"
+        "83:\n"
+        "\ts_mov_b32 s50, 3\n"
+        "\ts_branch 9f\n"
+        "84:\n"
+        "\ts_mov_b32 s50, 4\n"
+        "\ts_branch 9f\n"
+        "85:\n"
+        "\ts_mov_b32 s50, 5\n"
+        "\ts_branch 9f\n"
+        "86:\n"
+        "\ts_mov_b32 s50, 6\n"
+        "9:\n"
+        "\ts_mov_b32 s66, 1\n"
+        "\ts_branch 30b\n"
+        "91:\n"
+        "\ts_mov_b64 %[buf], s[40:41]\n"
+        "\ts_mov_b32 %[cnt], s42\n"
+        "\ts_mov_b32 %[next], s43\n"
+        "\ts_mov_b32 %[pos], s44\n"
+        "\ts_mov_b32 %[e], s46\n"
+        "\ts_mov_b32 %[len], s51\n"
+        "\ts_mov_b32 %[dist], s52\n"
+        "\ts_mov_b32 %[reason], s50"
+        : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [len] "+s"(len), [dist] "+s"(dist),
+          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [ve] "=&v"(ve), [vslot] "=&v"(vslot), [e] "=s"(ee), [reason] "=s"(reason)
+        : [wb] "s"(wb), [us2] "s"(us2), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
+        : "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",
+          "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "m0", "scc", "vcc", "memory");
+    b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.len = len; st.dist = dist; st.e = ee;
+    return (int)reason;
+}
 #pragma clang diagnostic pop
 
 // RFC 1951 3.2.5: base and extra bits of the length codes 257..285 and the distance codes 0..29, lane i = code i
@@ -514,7 +791,7 @@ __device__ __forceinline__ uint32_t block_crc32(const uint8_t* out, int n, const
 
 // One BGZF block by one wave.  Every branch in here is uniform; false = the stream is not a valid DEFLATE stream of usize bytes.
 __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_left, int csize, uint8_t* out, int usize,
-                                              uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens, uint32_t* lut2, uint32_t* dlut) {
+                                              uint16_t* sym_ll, uint16_t* sym_d, uint8_t* lens, uint32_t* lut2, uint32_t* dlut, uint32_t* obuf) {
     const int lane = threadIdx.x & 63;
     uint32_t lbase, lext, dbase, dext;
     length_dist_tables(lbase, lext, dbase, dext);
@@ -600,7 +877,9 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
         }
         // the symbols: sym_run does the common cases without leaving its asm block; what it hands back is rare
         for (;;) {
-            const int why = sym_run(b, lut2, dlut, out, usize, st, mylit);
+            if (st.pos + st.ns > usize) return false;
+            flush();   // (sym_run_ob knows no pending literals)
+            const int why = sym_run_ob(b, lut2, dlut, obuf, out, usize, st);
             if (why == 2) { b.refill(); continue; }              // (with st.len set it resumes in the distance half)
             if (why == 5) return false;
             if (why == 4) { copy(st.len, st.dist); st.len = 0; continue; }
@@ -614,8 +893,9 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
                 st.len = 0;
                 continue;
             }
-            // why == 0: end of block, a literal / length code longer than the table's index, or no code at all
-            const uint32_t e = st.e & 0xFFFFu;
+            // why == 0: end of block, a literal / length code longer than the table's index, or no code at all;
+            // why == 6: fewer than two bytes of the block are left -- one symbol the long way
+            const uint32_t e = why == 6 ? LUT_LONG : st.e & 0xFFFFu;
             int s;
             if (e != LUT_LONG) { s = (int)(e & 0xFFFu); const int l = (int)(e >> 12); b.buf >>= l; b.cnt -= l; }
             else { s = decode_sym(b, ll, sym_ll); if (s < 0) return false; }
@@ -639,7 +919,8 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
 
 static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
     __shared__ uint16_t s_ll[WAVES][288 + 32];   // sorted literal/length symbols, then the distance symbols
-    __shared__ uint8_t s_len[WAVES][320 + 64];
+    __shared__ uint32_t s_ob[WAVES][OB_SLOTS];   // sym_run_ob's output buffer; between its calls (it leaves it empty) the code lengths of a block header
+    static_assert(OB_FLUSH == 128 && OB_SLOTS >= OB_FLUSH + 64 && OB_SLOTS * 4 >= 320 + 64, "the code lengths share the output buffer");
     __shared__ uint32_t s_lut[WAVES][1 << LUT_BITS];
     __shared__ uint32_t s_dlut[WAVES][1 << DLUT_BITS];
     __shared__ uint32_t s_crc_tab[256], s_x2n[32];
@@ -650,7 +931,7 @@ static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
     if (bi >= a.n_blocks) return;
     const DevBlock blk = a.blocks[bi];
     bool ok = inflate_block(a.comp + blk.coff, (int64_t)(a.comp_bytes - blk.coff), (int)blk.csize, a.out + blk.uoff, (int)blk.usize,
-                            s_ll[wave], s_ll[wave] + 288, s_len[wave], s_lut[wave], s_dlut[wave]);
+                            s_ll[wave], s_ll[wave] + 288, reinterpret_cast<uint8_t*>(s_ob[wave]), s_lut[wave], s_dlut[wave], s_ob[wave]);
     // (the wave reads back what it stored itself: same L1, program order)
     if (ok) ok = block_crc32(a.out + blk.uoff, (int)blk.usize, s_crc_tab, s_x2n) == blk.crc;
     if (!ok && (threadIdx.x & 63) == 0) atomicMin(a.first_bad, (unsigned long long)bi);

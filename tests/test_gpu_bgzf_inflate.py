@@ -72,6 +72,18 @@ def test_block_sizes_around_the_edges():
     assert inflate_on_device(ctx, b"".join(parts)) == b"".join(want)
 
 
+def test_the_last_symbols_of_many_blocks():
+    """Every block's last two bytes are decoded outside the hand-written loop (it leaves with 'fewer than two bytes left'),
+    from whatever the bit buffer holds at that moment: hundreds of blocks of ordinary FASTQ at the levels whose codes are
+    longest (a level-1 block of the benchmark's data once failed exactly there -- the loop had left in front of its refill)."""
+    from oracle import oracle as O
+    ctx = Context()
+    data = O.generate_synthetic(60000, 150, 150, 33, 73, "generic").tobytes()   # ~19 MB: ~290 blocks
+    for level in (1, 2, 9):
+        comp = bgzf_compress(data, block=65280, level=level)
+        assert inflate_on_device(ctx, comp) == data, level
+
+
 def test_many_blocks_random_mix():
     ctx = Context()
     rng = np.random.default_rng(8)
