@@ -495,7 +495,7 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
     o.n_events = 0; o.passed = 0;
     if (job.start == POS_NONE) { if (lane == 0) a.outs[ji] = o; return; }
 
-    const bool count_them = a.counters[7] != 0;   // (BZQ_GZ_COUNT: why sym_run_gz hands back, counted)
+    const bool count_them = (a.counters[7] & 1u) != 0;   // (BZQ_GZ_COUNT=1: why sym_run_gz hands back, counted)
     uint32_t lbase, lext, dbase, dext;
     inf::length_dist_tables(lbase, lext, dbase, dext);
     // output: stored symbols [0, opos) + ns pending literals (lane k holds the k-th)
@@ -616,7 +616,7 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
                 if (!ensure(opos + 1)) { ok = false; break; }   // `cur` is the page of position opos
                 st.pos = (int)(opos & (PAGE - 1));
                 const int why = sym_run_gz(b, lut2, dlut, obuf, cur, cur_idx == 0, st);
-                if (count_them && lane == 0) atomicAdd(&a.counters[8 + why], 1u);
+                if (count_them && lane == 0) atomicAdd(&a.counters[16 + why], 1u);
                 opos = (opos & ~(int64_t)(PAGE - 1)) + st.pos;
                 if (why == 2) { b.refill(); if (b.ran_out) { ok = false; break; } continue; }   // (with st.len set it resumes in the distance half)
                 if (why == 4) { if (!general_copy(st.len, st.dist)) { ok = false; break; } st.len = 0; continue; }
@@ -698,6 +698,7 @@ static __global__ __launch_bounds__(DEC_BLOCK) __attribute__((amdgpu_waves_per_e
 // a chunk its start, i.e. parallelism -- tests/test_gpu_gzip.py::test_the_speculation_is_what_runs watches that); what it
 // lets through is still judged by the wave.
 constexpr int LANE_LUT_STRIDE = 132;
+
 constexpr int FIND_STAGE = 2048;   // bytes of a chunk in LDS at a time (32 rounds)
 __device__ __forceinline__ bool lane_check_dynamic(const uint8_t* comp, int64_t n, int64_t P, u64 w, uint32_t hclen, uint32_t hlit, uint32_t hdist, uint8_t* lut) {
     // code length code: lengths by symbol (RFC 1951 3.2.7 stores them in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15)
@@ -731,7 +732,7 @@ __device__ __forceinline__ bool lane_check_dynamic(const uint8_t* comp, int64_t 
     int64_t nb = start >> 3;
     u64 buf = 0;
     int bc = 0;
-    // (two dwords ahead of the one being shifted in: the loads' latency is behind ~16 symbols of work instead of in front of every 8)
+    // (two dwords ahead of the one being shifted in; 16 bytes per load and one load ahead was tried: slower)
     auto load = [&](int64_t at) -> uint32_t { return at + 4 <= n + 60 ? reinterpret_cast<const U32U*>(comp + at)->v : 0u; };   // (64 bytes of slack behind the piece)
     uint32_t n0 = load(nb), n1 = load(nb + 4);
     auto refill = [&]() {
@@ -746,7 +747,7 @@ __device__ __forceinline__ bool lane_check_dynamic(const uint8_t* comp, int64_t 
     int i = 0;
     uint32_t prev = 0, kr_ll = 0, kr_d = 0, c_ll = 0, c_d = 0, eob = 0;
     bool ok = true;
-    while (i < total && ok) {
+    while (i < total && ok) {   // (a look that stopped after 64 code lengths and left the rest to the wave was tried: 19 times as many candidates reach the wave -- what random bits describe is rarely refused early -- and the kernel took twice the time)
         refill();
         const uint32_t e = lut[(uint32_t)buf & 127u];
         const uint32_t l = e & 7u, sym = e >> 3;
@@ -766,6 +767,10 @@ __device__ __forceinline__ bool lane_check_dynamic(const uint8_t* comp, int64_t 
         }
         if (i <= 256 && 256 < i + rep) eob = val;
         i += rep;
+        // an over-subscribed code is refused the moment it is one (zlib: inflate_table returns -1), not after the last length:
+        // what random bits describe is over-subscribed within ~20 lengths, and without this every lane of a look walked all
+        // ~300 -- the wave was done when its slowest lane was, ~100 us a look, a quarter of the kernel's time
+        if (kr_ll > 32768u || kr_d > 32768u) { ok = false; break; }
     }
     if (!ok || eob == 0u) return false;
     if (8 * (nb - 4) + (32 - bc) > 8 * n + 64) return false;   // (ran past the input: generous, the wave's judgement is exact)
@@ -791,8 +796,8 @@ static __device__ __forceinline__ bool judge_dynamic_at(const uint8_t* comp, int
 
 // the first QN queued candidates (QN <= 64), one per lane: the per-lane look, then the whole wave's judgement of whoever is
 // left, in stream order.  Returns the first position that holds, or POS_NONE.
-static __device__ __attribute__((noinline)) u64 find_flush(const uint8_t* comp, int64_t n, int64_t lo, uint32_t queue_o, int QN, uint32_t lane_lut_o,
-                                                           uint32_t lens_o, uint32_t sym_ll_o, uint32_t sym_d_o, uint32_t* counter) {
+static __device__ __attribute__((noinline)) u64 find_flush(const uint8_t* comp, int64_t n, int64_t lo, uint32_t queue_o, int QN, uint32_t lane_lut_o, uint32_t lock_o,
+                                                           uint32_t lens_o, uint32_t sym_ll_o, uint32_t sym_d_o, uint32_t* counter, uint32_t* clocks) {
     const int lane = threadIdx.x & 63;
     const uint32_t* queue = lds_ptr<uint32_t>(queue_o);
     const bool have = lane < QN;
@@ -804,7 +809,20 @@ static __device__ __attribute__((noinline)) u64 find_flush(const uint8_t* comp, 
     const u64 v = sh ? (lo64 >> sh) | (hi64 << (64 - sh)) : lo64, vh = hi64 >> sh;
     const u64 w = (v >> 17) | (vh << 47);
     bool ok = have;
+    // (the per-lane tables are the workgroup's, not the wave's: 8 KiB each, and with one set per wave the LDS allowed two
+    // workgroups per CU -- the scan loop, which is most of the kernel, ran at half the vector unit's rate for want of waves.
+    // A look takes ~20 us once or twice per chunk: the waves take turns.)
+    uint32_t* lock = lds_ptr<uint32_t>(lock_o);
+    const long long t0 = clocks ? clock64() : 0;
+    if (lane == 0) while (atomicCAS(lock, 0u, 1u) != 0u) __builtin_amdgcn_s_sleep(8);
+    const long long t0b = clocks ? clock64() : 0;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (ok) ok = lane_check_dynamic(comp, n, P, w, ((uint32_t)(v >> 13) & 15u) + 4u, (uint32_t)(v >> 3) & 31u, (uint32_t)(v >> 8) & 31u, lds_ptr<uint8_t>(lane_lut_o) + lane * LANE_LUT_STRIDE);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) atomicExch(lock, 0u);
+    const long long t1 = clocks ? clock64() : 0;
     u64 m = __ballot(ok);
     if (counter && lane == 0) atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
     u64 got = POS_NONE;
@@ -813,6 +831,9 @@ static __device__ __attribute__((noinline)) u64 find_flush(const uint8_t* comp, 
         m &= m - 1;
         const int64_t Q = 8 * lo + (int64_t)queue[L];
         if (judge_dynamic_at(comp, n, Q, lds_ptr<uint8_t>(lens_o), lds_ptr<uint16_t>(sym_ll_o), lds_ptr<uint16_t>(sym_d_o))) got = pos_deflate((u64)Q);
+    }
+    if (clocks && lane == 0) {   // (debug: where a flush's time goes, in units of 256 clocks: lock wait, the lanes' look, the wave's judgement)
+        atomicAdd(clocks, (uint32_t)((t0b - t0) >> 8)); atomicAdd(clocks + 1, (uint32_t)((t1 - t0b) >> 8)); atomicAdd(clocks + 2, (uint32_t)((clock64() - t1) >> 8));
     }
     return got;
 }
@@ -846,10 +867,12 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
     __shared__ uint8_t kraft4[4096];   // four 3-bit code lengths -> their Kraft sum in 1/128 (saturated: anything > 128 is refused anyway)
     __shared__ uint32_t s_queue[WAVES][64 + 64 + 64];
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[WAVES][(FIND_STAGE + 64) / 4];
-    __shared__ __attribute__((aligned(4))) uint8_t s_lane_lut[WAVES][64 * LANE_LUT_STRIDE];
+    __shared__ __attribute__((aligned(4))) uint8_t s_lane_lut[64 * LANE_LUT_STRIDE];   // one set for the workgroup's waves (find_flush)
+    __shared__ uint32_t s_lane_lock;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int c = (int)blockIdx.x * WAVES + wave;
+    if (threadIdx.x == 0) s_lane_lock = 0;
     for (uint32_t e = threadIdx.x; e < 4096u; e += BLOCK) {
         uint32_t sum = 0;
 #pragma unroll
@@ -861,18 +884,19 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
     uint16_t* surv = s_surv[wave];
     uint32_t* queue = s_queue[wave];
     uint32_t* stg = s_stage[wave];
-    uint8_t* lane_lut = s_lane_lut[wave];
+    uint8_t* lane_lut = s_lane_lut;
     uint16_t* sym_ll = s_ll[wave];
     uint16_t* sym_d = s_ll[wave] + 288;
     uint8_t* lens = s_len[wave];
     const int64_t lo = (int64_t)c * a.chunk_bytes, hi = lo + a.chunk_bytes < a.n ? lo + a.chunk_bytes : a.n;
-    const bool count_them = a.counters[7] != 0;   // (BZQ_GZ_TIMING: how many positions survive each stage)
+    const bool count_them = (a.counters[7] & 1u) != 0, time_them = (a.counters[7] & 2u) != 0;   // (BZQ_GZ_COUNT=1: how many positions survive each stage; =2: where the time goes)
+    const long long t_begin = time_them ? clock64() : 0;
     u64 found = POS_NONE;
     // candidates that passed the code length code test, waiting for the per-lane look: positions relative to the chunk's first bit
     int qn = 0, qh = 0;   // (entries queue[qh .. qh + qn))
     const uint32_t judge_lds[3] = {lds_off(lens), lds_off(sym_ll), lds_off(sym_d)};
     auto flush_queue = [&](int QN) -> u64 {
-        const u64 got = find_flush(a.comp, a.n, lo, lds_off(queue + qh), QN, lds_off(lane_lut), judge_lds[0], judge_lds[1], judge_lds[2], count_them ? a.counters + 5 : nullptr);
+        const u64 got = find_flush(a.comp, a.n, lo, lds_off(queue + qh), QN, lds_off(lane_lut), lds_off(&s_lane_lock), judge_lds[0], judge_lds[1], judge_lds[2], count_them ? a.counters + 5 : nullptr, time_them ? a.counters + 9 : nullptr);
         qh += QN; qn -= QN;
         return got;
     };
@@ -984,6 +1008,7 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
         __builtin_amdgcn_wave_barrier();   // (the next group rewrites the list)
     }
     }
+    if (time_them && lane == 0) atomicAdd(&a.counters[12], (uint32_t)((clock64() - t_begin) >> 8));
     if (lane == 0) a.jobs[c] = Job{found, c + 1, 0};
 }
 
@@ -995,28 +1020,39 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_find(Args a) {
 // last): longest processing time first.
 constexpr int ORDER_BINS = 64;
 static __global__ __launch_bounds__(BLOCK) void k_gz_span(const Job* jobs, int n, uint8_t* keys, uint32_t* bins) {
+    __shared__ uint32_t s_bins[ORDER_BINS];   // (one global atomic per bin and workgroup: 16 384 threads adding to the same few words took 0.15 ms)
+    if (threadIdx.x < ORDER_BINS) s_bins[threadIdx.x] = 0;
+    __syncthreads();
     const int c = (int)(blockIdx.x * BLOCK + threadIdx.x);
-    if (c >= n) return;
-    int key = 0;
-    if (jobs[c].start != POS_NONE) {
-        key = 1;
-        while (key < ORDER_BINS - 1 && c + key < n && jobs[c + key].start == POS_NONE) ++key;
+    if (c < n) {
+        int key = 0;
+        if (jobs[c].start != POS_NONE) {
+            key = 1;
+            while (key < ORDER_BINS - 1 && c + key < n && jobs[c + key].start == POS_NONE) ++key;
+        }
+        keys[c] = (uint8_t)key;
+        atomicAdd(&s_bins[key], 1u);
     }
-    keys[c] = (uint8_t)key;
-    atomicAdd(&bins[key], 1u);
+    __syncthreads();
+    if (threadIdx.x < ORDER_BINS && s_bins[threadIdx.x]) atomicAdd(&bins[threadIdx.x], s_bins[threadIdx.x]);
 }
 static __global__ __launch_bounds__(BLOCK) void k_gz_order(int n, const uint8_t* keys, const uint32_t* bins, uint32_t* cursor, uint32_t* order) {
-    __shared__ uint32_t base[ORDER_BINS];
+    __shared__ uint32_t base[ORDER_BINS], s_cnt[ORDER_BINS], s_at[ORDER_BINS];
     if (threadIdx.x < ORDER_BINS) {
         uint32_t b = 0;
         for (int k = ORDER_BINS - 1; k > (int)threadIdx.x; --k) b += bins[k];
         base[threadIdx.x] = b;
+        s_cnt[threadIdx.x] = 0;
     }
     __syncthreads();
     const int c = (int)(blockIdx.x * BLOCK + threadIdx.x);
-    if (c >= n) return;
-    const int key = keys[c];
-    order[base[key] + atomicAdd(&cursor[key], 1u)] = (uint32_t)c;
+    const int key = c < n ? keys[c] : 0;
+    uint32_t mine = 0;
+    if (c < n) mine = atomicAdd(&s_cnt[key], 1u);                    // rank among the workgroup's chunks of this key
+    __syncthreads();
+    if (threadIdx.x < ORDER_BINS && s_cnt[threadIdx.x]) s_at[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], s_cnt[threadIdx.x]);   // the workgroup's range in the bin
+    __syncthreads();
+    if (c < n) order[base[key] + s_at[key] + mine] = (uint32_t)c;
 }
 
 // ---- CHAIN: the window behind every chain chunk; its tail (the last <= 32 KiB) goes out final ---------------------------------------
@@ -1371,7 +1407,7 @@ inline int gz_open(int device, bzq_gzip** out, std::string& err) {
         err = "bzq_gzip_open: hipStreamCreate failed"; gz_free(h); return BZQ_ERR_HIP;
     }
     int rc;
-    if ((rc = gz_ensure(h, h->win[0], 32768)) || (rc = gz_ensure(h, h->win[1], 32768)) || (rc = gz_ensure(h, h->counters, 64))) { err = h->err; gz_free(h); return rc; }
+    if ((rc = gz_ensure(h, h->win[0], 32768)) || (rc = gz_ensure(h, h->win[1], 32768)) || (rc = gz_ensure(h, h->counters, 128))) { err = h->err; gz_free(h); return rc; }
     if (hipMemsetAsync(h->win[0].p, 0, 32768, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { err = "bzq_gzip_open: hipMemset failed"; gz_free(h); return BZQ_ERR_HIP; }
     h->start_pos = pos_header(0);
     for (uint64_t len : {1ull, 4097ull, (unsigned long long)CRC_SEG})   // (the combine above against zlib's, once)
@@ -1463,7 +1499,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     if (!use_staged) GZCHK(h, hipEventSynchronize(h->staged_ev[cb]));   // (whatever was last staged into it has arrived)
     if ((rc = gz_ensure(h, h->order, (size_t)2 * ORDER_BINS * 4 + (size_t)n_chunks * 5 + 64)) || (!use_staged && (rc = gz_ensure(h, h->comp[cb], n + 64))) || (rc = gz_ensure(h, h->jobs, (size_t)n_jobs_cap * sizeof(Job))) ||
         (rc = gz_ensure(h, h->outs, (size_t)n_jobs_cap * sizeof(JobOut))) || (rc = gz_ensure(h, h->events, (size_t)max_events * sizeof(Event))) ||
-        (rc = gz_ensure(h, h->h_outs, (size_t)n_jobs_cap * sizeof(JobOut) + 64, true)))
+        (rc = gz_ensure(h, h->h_outs, (size_t)n_jobs_cap * sizeof(JobOut) + 128, true)))
         return rc;
     uint8_t* d_comp = (uint8_t*)h->comp[cb].p + (use_staged ? STAGE_RESERVE - nc : 0);
     // (the carry is pageable memory; the vector is not touched before the stream has been waited for, further down)
@@ -1488,9 +1524,9 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     for (int attempt = 0;; ++attempt) {
         if ((rc = gz_ensure(h, h->pool, ((size_t)h->pool_pages << PAGE_SHIFT) * 2)) || (rc = gz_ensure(h, h->page_next, (size_t)h->pool_pages * 4))) return rc;
         const Job j0{h->start_pos, 1, 0};
-        GZCHK(h, hipMemsetAsync(h->counters.p, 0, 64, s));
-        static const bool counting = getenv("BZQ_GZ_COUNT") != nullptr;   // debug: the finder's survivor counts (atomics in its loop: not for timing)
-        if (counting) { const uint32_t one = 1; GZCHK(h, hipMemcpyAsync((uint32_t*)h->counters.p + 7, &one, 4, hipMemcpyHostToDevice, s)); }
+        GZCHK(h, hipMemsetAsync(h->counters.p, 0, 128, s));
+        static const uint32_t counting = getenv("BZQ_GZ_COUNT") ? (uint32_t)atoi(getenv("BZQ_GZ_COUNT")) : 0u;   // debug: 1 = survivor / hand-back counts (atomics in the loops: not for timing), 2 = the finder's clocks
+        if (counting) GZCHK(h, hipMemcpyAsync((uint32_t*)h->counters.p + 7, &counting, 4, hipMemcpyHostToDevice, s));
         GZCHK(h, hipMemcpyAsync(h->jobs.p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
         a = Args{d_comp, (int64_t)n, (Job*)h->jobs.p, (JobOut*)h->outs.p, 0, n_chunks, n_chunks, CH, (uint16_t*)h->pool.p, h->pool_pages,
                  (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events, max_job, (int64_t)std::max<uint64_t>(out_cap, 1ull << 20)};
@@ -1510,12 +1546,13 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         hipLaunchKernelGGL(k_gz_decode, dim3((unsigned)n_chunks), dim3(DEC_BLOCK), 0, s, a);
         GZCHK(h, hipGetLastError());
         GZCHK(h, hipMemcpyAsync(outs, h->outs.p, (size_t)n_chunks * sizeof(JobOut), hipMemcpyDeviceToHost, s));
-        GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 64, hipMemcpyDeviceToHost, s));
+        GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 128, hipMemcpyDeviceToHost, s));
         GZCHK(h, hipStreamSynchronize(s));
         lap(2);
         if (getenv("BZQ_GZ_EARLY")) fprintf(stderr, "early: find %.2f decode %.2f (%d chunks)\n", t_ph[1], t_ph[2], n_chunks);
         if (counting) fprintf(stderr, "bzq_gzip decoder: the symbol loop handed back %u times for a code it does not take / the end of a block, %u for its window, %u for a long distance code, %u for a copy it does not take, %u at a page's end\n",
-                              h_counters[8], h_counters[10], h_counters[11], h_counters[12], h_counters[14]);
+                              h_counters[16], h_counters[18], h_counters[19], h_counters[20], h_counters[22]);
+        if (counting) fprintf(stderr, "bzq_gzip finder clocks (x256, summed over waves): total %u, in flushes: waiting for the tables %u, the lanes' look %u, the wave's judgement %u\n", h_counters[12], h_counters[9], h_counters[10], h_counters[11]);
         if (counting) fprintf(stderr, "bzq_gzip finder: %u positions passed the 13-bit filter, %u of them the code length code test, %u of those one lane's look at the code lengths (judged by the whole wave)\n", h_counters[3], h_counters[4], h_counters[5]);
         if (h_counters[0] <= h->pool_pages) break;
         if (attempt == 8) return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: the symbol pool keeps overflowing (" + std::to_string(h->pool_pages) + " pages)");

@@ -4,7 +4,7 @@
 #include <cstdio>
 template <int MODE>
 __global__ void k(uint32_t* out, int n) {
-    __shared__ uint32_t lut[1024];
+    __shared__ uint32_t lut[1024];   // (4 KiB)
     for (int i = threadIdx.x; i < 1024; i += 64) lut[i] = (uint32_t)(i * 2654435761u) >> 22;   // next index
     __syncthreads();
     uint32_t vt = 0, lit = 0;
@@ -30,6 +30,27 @@ __global__ void k(uint32_t* out, int n) {
     if (MODE == 5)   // v_readlane with a scalar lane select feeding SALU
         asm volatile("s_mov_b32 s40, %2\n\ts_mov_b32 s41, 5\n1:\n\ts_and_b32 s42, s41, 63\n\tv_readlane_b32 s41, %1, s42\n\ts_add_i32 s41, s41, s40\n\t"
                      "s_sub_i32 s40, s40, 1\n\ts_cmp_lg_u32 s40, 0\n\ts_cbranch_scc1 1b\n\ts_mov_b32 %0, s41" : "=s"(acc), "+v"(vt) : "s"(n) : "s40", "s41", "s42", "scc");
+    if (MODE == 6) {  // 10 dependent 32-bit VALU shifts
+        uint32_t a = threadIdx.x + 77;
+        asm volatile("s_mov_b32 s40, %1\n1:\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %0, 1, %0\n\t"
+                     "v_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %0, 1, %0\n\tv_lshrrev_b32 %0, 1, %0\n\t"
+                     "s_sub_i32 s40, s40, 1\n\ts_cmp_lg_u32 s40, 0\n\ts_cbranch_scc1 1b" : "+v"(a) : "s"(n) : "s40", "scc");
+        vt = a;
+    }
+    if (MODE == 7) {  // 10 dependent 64-bit VALU shifts
+        unsigned long long a = threadIdx.x + 77;
+        asm volatile("s_mov_b32 s40, %1\n1:\n\tv_lshrrev_b64 %0, 1, %0\n\tv_lshrrev_b64 %0, 1, %0\n\tv_lshrrev_b64 %0, 1, %0\n\tv_lshrrev_b64 %0, 1, %0\n\tv_lshrrev_b64 %0, 1, %0\n\t"
+                     "v_lshrrev_b64 %0, 1, %0\n\tv_lshrrev_b64 %0, 1, %0\n\tv_lshrrev_b64 %0, 1, %0\n\tv_lshrrev_b64 %0, 1, %0\n\tv_lshrrev_b64 %0, 1, %0\n\t"
+                     "s_sub_i32 s40, s40, 1\n\ts_cmp_lg_u32 s40, 0\n\ts_cbranch_scc1 1b" : "+v"(a) : "s"(n) : "s40", "scc");
+        vt = (uint32_t)a;
+    }
+    if (MODE == 8) {  // 10 independent ds_read_u8 at scattered addresses + wait
+        uint32_t a0 = (threadIdx.x * 97u) & 1023u, r0 = 0, r1 = 0;
+        asm volatile("s_mov_b32 s40, %3\n1:\n\tds_read_u8 %1, %0\n\tds_read_u8 %2, %0 offset:1024\n\tds_read_u8 %1, %0 offset:2048\n\tds_read_u8 %2, %0 offset:3000\n\tds_read_u8 %1, %0 offset:77\n\t"
+                     "ds_read_u8 %2, %0 offset:1111\n\tds_read_u8 %1, %0 offset:2222\n\tds_read_u8 %2, %0 offset:333\n\tds_read_u8 %1, %0 offset:444\n\tds_read_u8 %2, %0 offset:555\n\ts_waitcnt lgkmcnt(0)\n\t"
+                     "s_sub_i32 s40, s40, 1\n\ts_cmp_lg_u32 s40, 0\n\ts_cbranch_scc1 1b" : "+v"(a0), "+v"(r0), "+v"(r1) : "s"(n) : "s40", "scc", "memory");
+        vt = r0 + r1;
+    }
     if (threadIdx.x == 0) out[0] = acc + vt + lit;
 }
 template <int MODE> void run(uint32_t* o, const char* what, int extra) {
@@ -52,5 +73,8 @@ int main() {
     run<3>(o, "+ s_and, 2 x (m0, v_writelane), s_lshr_b64", 9);
     run<4>(o, "+ cmp + not-taken branch, cmp + taken forward branch", 7);
     run<5>(o, "+ s_and, v_readlane (scalar select), s_add", 6);
+    run<6>(o, "+ 10 dependent v_lshrrev_b32", 13);
+    run<7>(o, "+ 10 dependent v_lshrrev_b64", 13);
+    run<8>(o, "+ 10 independent ds_read_u8 (scattered) + wait", 14);
     return 0;
 }
