@@ -1067,9 +1067,8 @@ int32_t bzq_gzip_decode(bzq_gzip* h, const uint8_t* comp, uint64_t n, int32_t is
     return bzq::gz::gz_decode(h, comp, n, is_last != 0, d_out, out_capacity, out_bytes, more);
 }
 int32_t bzq_gzip_stage(bzq_gzip* h, const uint8_t* comp, uint64_t n) {
-    if (!h) return BZQ_ERR_ARG;
-    if (n && !comp) { h->err = "bzq_gzip_stage: NULL input"; return BZQ_ERR_ARG; }
-    return bzq::gz::gz_stage(h, comp, n);
+    if (!h || (n && !comp)) return BZQ_ERR_ARG;
+    return bzq::gz::gz_stage(h, comp, n);   // (does not touch the handle's error text: that belongs to the decode thread)
 }
 int32_t bzq_gzip_finished(const bzq_gzip* h) { return h && h->finished ? 1 : 0; }
 int32_t bzq_gzip_get_stats(const bzq_gzip* h, bzq_gzip_stats* out) {

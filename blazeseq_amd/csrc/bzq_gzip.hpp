@@ -1300,6 +1300,7 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_crc(const CrcSeg* segs, int
 // ================================================================================ host side
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <deque>
 #include <mutex>
@@ -1331,7 +1332,7 @@ struct bzq_gzip {
     // the stream
     std::vector<uint8_t> carry;         // compressed bytes not consumed yet
     unsigned long long start_pos = 1;   // where decoding resumes inside `carry`: pos_header(0), or pos_deflate(bit 0..7)
-    bool finished = false;
+    std::atomic<bool> finished{false};   // (read by bzq_gzip_stage, which may run on a second thread)
     uint64_t members_done = 0;
     uint32_t crc_run = 0;               // CRC-32 and length of the open member's output so far
     uint64_t len_run = 0;
@@ -1424,8 +1425,10 @@ inline int gz_open(int device, bzq_gzip** out, std::string& err) {
 // thread does), not concurrently with itself; src must stay untouched until its gz_decode has returned.
 constexpr uint64_t STAGE_RESERVE = 4ull << 20;
 inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
+    // (no h->err in here: that string is the decode thread's.  A piece that could not be staged is copied by its gz_decode, which
+    // then meets whatever was wrong on its own thread; the return value only says that nothing was staged.)
     if (h->finished || !n_new) return 0;
-    GZCHK(h, hipSetDevice(h->device));
+    if (hipSetDevice(h->device) != hipSuccess) return BZQ_ERR_HIP;
     int bi;
     {
         std::lock_guard<std::mutex> lk(h->stage_mu);
@@ -1433,19 +1436,19 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
         if (bi < 0) return 0;
         h->comp_busy[bi] = true;
     }
-    auto give_back = [&]() { std::lock_guard<std::mutex> lk(h->stage_mu); h->comp_busy[bi] = false; };
+    auto give_back = [&](int code) { (void)hipGetLastError(); std::lock_guard<std::mutex> lk(h->stage_mu); h->comp_busy[bi] = false; return code; };
     bzq_gzip::Buf& b = h->comp[bi];
     if (b.cap < STAGE_RESERVE + n_new + 64) {   // (not gz_ensure: that waits for the decode stream, which the other thread may be feeding)
-        if (b.p) { const hipError_t e = hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) { give_back(); return gz_fail(h, BZQ_ERR_HIP, std::string("hipFree: ") + hipGetErrorString(e)); } }
+        if (b.p) { const hipError_t e = hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) return give_back(BZQ_ERR_HIP); }
         const size_t want = (size_t)(STAGE_RESERVE + n_new + n_new / 4 + 256);
-        if (hipMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; (void)hipGetLastError(); give_back(); return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: cannot allocate " + std::to_string(want) + " bytes"); }
+        if (hipMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; return give_back(BZQ_ERR_NOMEM); }
         b.cap = want;
     }
     uint8_t* d = (uint8_t*)b.p + STAGE_RESERVE;
     hipError_t e = hipMemcpyAsync(d, src, n_new, hipMemcpyHostToDevice, h->copy_stream);
     if (e == hipSuccess) e = hipMemsetAsync(d + n_new, 0, 64, h->copy_stream);
     if (e == hipSuccess) e = hipEventRecord(h->staged_ev[bi], h->copy_stream);
-    if (e != hipSuccess) { (void)hipStreamSynchronize(h->copy_stream); give_back(); return gz_fail(h, BZQ_ERR_HIP, std::string("bzq_gzip_stage: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipStreamSynchronize(h->copy_stream); return give_back(BZQ_ERR_HIP); }
     std::lock_guard<std::mutex> lk(h->stage_mu);
     h->staged.push_back(bzq_gzip::StagedPiece{src, n_new, bi});
     return 0;

@@ -522,7 +522,7 @@ class GzipDecoder:
         same array later finds it there.  `comp`: pinned memory (Context.pinned_array), untouched until that feed() returns."""
         a = _as_u8(comp)
         if a.size:
-            self._gcheck(L.lib().bzq_gzip_stage(self._h, a.ctypes.data, a.size), "bzq_gzip_stage")
+            L.lib().bzq_gzip_stage(self._h, a.ctypes.data, a.size)   # (a hint: a piece that was not staged is copied by its feed())
 
     @property
     def finished(self) -> bool:

@@ -421,7 +421,8 @@ int32_t bzq_gzip_decode(bzq_gzip* h, const uint8_t* comp, uint64_t n, int32_t is
 /* Optional read-ahead: a piece that a LATER bzq_gzip_decode will be given starts its way to the device now; the
  * bzq_gzip_decode that gets the same (comp, n) finds it there instead of copying.  comp: pinned host memory, untouched until
  * that call has returned.  Up to two pieces can be outstanding (the one being decoded counts); with both taken the call does
- * nothing.  Pieces are taken in the order staged.  May be called from a second thread while bzq_gzip_decode runs. */
+ * nothing.  Pieces are taken in the order staged.  May be called from a second thread while bzq_gzip_decode runs.  A negative
+ * return only says that nothing was staged (the piece is then copied by its bzq_gzip_decode); bzq_gzip_last_error is not set. */
 int32_t bzq_gzip_stage(bzq_gzip* h, const uint8_t* comp, uint64_t n);
 int32_t bzq_gzip_finished(const bzq_gzip* h);   /* 1 once the stream's end has been seen */
 int32_t bzq_gzip_get_stats(const bzq_gzip* h, bzq_gzip_stats* out);
