@@ -8,11 +8,12 @@
 // here, stage one and two on the device:
 //
 //   0. the compressed piece is cut into chunks of CH bytes.  FIND (k_gz_find, one wave per chunk): the first position in the
-//      chunk at which a DEFLATE block can start -- the lanes test 512 consecutive BIT offsets per round for a non-final dynamic
-//      block header (13 bits that need no arithmetic; the survivors, compacted onto the lanes, for a complete code length code:
-//      up to 57 more bits), what is left is validated by the whole wave (all three Huffman codes must be ones zlib accepts);
-//      byte positions are also tested for a gzip member header followed by a valid block header.  A false positive costs
-//      time, never correctness (below).
+//      chunk at which a DEFLATE block can start -- every lane tests 16 consecutive BIT offsets at once for a non-final dynamic
+//      block header (13 bits that need no arithmetic, by word operations); the survivors, compacted onto the lanes, for a
+//      complete code length code (up to 57 more bits); what passes is queued and looked at 64 at a time, one candidate per lane
+//      (the code lengths and the two codes they describe, by zlib's rules); what is left -- on FASTQ exactly the true starts --
+//      is judged by the whole wave.  Byte positions are also tested for a gzip member header followed by a valid block header.
+//      A false positive costs time, never correctness (below).  ORDER (k_gz_span, k_gz_order): the longest jobs first.
 //   1. DECODE (k_gz_decode, one wave per chunk that has a start): blocks are decoded from the chunk's start until the decoder
 //      arrives EXACTLY at a later chunk's start (a candidate it passes over without meeting it was a false positive and is
 //      dropped), through member trailers and member headers where they come.  What lies more than `pos` bytes back is not
@@ -20,10 +21,12 @@
 //      front of this chunk's output" (rapidgzip's markers); markers are copied by later matches like any symbol.  Output goes
 //      to 128 KiB pages taken from a pool with one atomic (its size is unknown beforehand).
 //   2. the host walks the chain (chunk 0 starts at a known position; every chunk names the chunk it ended on), and the device
-//      finishes: CHAIN (k_gz_chain, one workgroup, sequential over the chain, ~2 us per chunk): the 32 KiB window behind every
-//      chunk from the window in front of it -- the only serial step; RESOLVE (k_gz_resolve, one workgroup per page): every
-//      symbol to its byte, contiguous in the caller's buffer; CRC (k_gz_crc): CRC-32 of every MiB of every member, combined on
-//      the host (crc32_combine) and checked against the member trailers together with ISIZE.
+//      finishes: CHAIN (k_gz_chain / k_gz_chain_groups): the 32 KiB window behind every chunk from the window in front of it
+//      -- window maps compose, so groups of ~sqrt(n) chunks build their composed map in parallel and only the groups are
+//      walked serially; RESOLVE (k_gz_resolve, one workgroup per page): every symbol to its byte, contiguous in the caller's
+//      buffer; CRC (k_gz_crc): CRC-32 of every MiB of every member, combined on the host and checked against the member
+//      trailers together with ISIZE.
+//   The NEXT piece's copy to the device runs under all of this (gz_stage).
 //
 // Correctness does not rest on the speculation: the chain starts at an exact position and only ever follows exact ends, so
 // what is delivered is the sequential decode; a chunk the chain never lands on is ignored.  Streams that defeat the

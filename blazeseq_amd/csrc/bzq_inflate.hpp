@@ -201,8 +201,8 @@ __device__ __forceinline__ void build_lut2(const Code& code, const uint16_t* sym
     __builtin_amdgcn_wave_barrier();
 }
 // lane `lane` of `old` := v (both uniform): v_writelane_b32 with the lane select in M0 (a VALU instruction takes one SGPR; M0 is
-// extra) -- two instructions where "if (lane_id == lane) old = v" costs three.  This compiler has no builtin for it; nothing in
-// these kernels uses M0 otherwise (no LDS-DMA, no movrel).
+// extra) -- two instructions where "if (lane_id == lane) old = v" costs three.  This compiler has no builtin for it.  M0 is
+// written in the same asm statement that reads it (the symbol loop's LDS-direct loads do the same with their base).
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ uint32_t wrlane(uint32_t v, int lane, uint32_t old) {
@@ -234,203 +234,19 @@ __device__ __forceinline__ void build_dlut(const Code& code, const uint16_t* sym
     __builtin_amdgcn_wave_barrier();
 }
 
-// The symbol loop of a BGZF block, by hand.  The decoder is bound by the CU's scalar unit (PMC on the C++ loop: 1.03 scalar
-// instructions per CU cycle, 21.6 per output byte), and what the compiler makes of that loop is ~41 instructions per literal and
-// ~120 per match (SGPR spills reloaded inside it, the reader's counters kept in vector registers, selects and copies around
-// every exit).  Here: refill from the window register (v_readlane), table lookup (one ds_read_b32), one or two literals into
-// the pending register (v_writelane, lane select in M0), shift -- and the whole match path: length from the folded table
-// entry, distance through its own direct table, the checks, the store of the pending literals and the copy of a match of up to
-// 64 bytes that does not overlap itself -- without leaving the asm block (in the benchmark's FASTQ 71 % of the bytes come out of
-// matches of 5.5 bytes on average: what the match path costs decides the rate).  ~21 instructions per literal pair, ~70 per
-// match (the C++ loop: ~41 and ~120).  It leaves with
-//   0  an entry that is neither literal nor a folded length symbol (end of block, long code, no code): e, bits not consumed
-//   2  the window register is used up (refill() and come back; with `len` > 0: come back into the distance half)
-//   3  a distance code the table does not hold: len is decoded, the distance bits are not consumed
-//   4  a match the fast copy does not take (longer than 64 bytes, or overlapping itself): len, dist; pending literals stored
-//   5  invalid: distance beyond the start of the output, or output beyond usize
-// Fixed scalar registers (named in the clobber list) because inline asm cannot name the halves of a 64-bit operand.  (A first
-// version had only the literal run in asm: on a stream of 71 % match bytes, leaving the block at every match ate the gain.)
+// State handed in and out of the hand-written symbol loop.  (pos: bytes stored; ns: literals decoded and not yet stored, the
+// C++ slow paths' business only; len / dist: a match decoded and not yet copied; e: the table entry the loop stopped at.)
 struct SymState { int pos, ns, len, dist; uint32_t e; };
-template <class BitsT>
-__device__ __forceinline__ int sym_run(BitsT& b, const uint32_t* lut2, const uint32_t* dlut, uint8_t* out, int usize, SymState& st, uint32_t& mylit) {
-    uint32_t reason, vt, vt2, ee;
-    u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
-    int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), n = (int)uni((uint32_t)st.ns), pos = (int)uni((uint32_t)st.pos);
-    int len = (int)uni((uint32_t)st.len), dist = 0;
-    const int wb = (int)uni((uint32_t)b.win_base), us = (int)uni((uint32_t)usize);
-    const uint32_t lds = uni((uint32_t)(uintptr_t)lut2), ldd = uni((uint32_t)(uintptr_t)dlut);
-    const u64 ob = ((u64)uni((uint32_t)((uintptr_t)out >> 32)) << 32) | uni((uint32_t)(uintptr_t)out);
-    const uint32_t lane = threadIdx.x & 63;
-    asm volatile(
-        "s_mov_b64 s[40:41], %[buf]\n\t"
-        "s_mov_b32 s42, %[cnt]\n\t"
-        "s_mov_b32 s43, %[next]\n\t"
-        "s_mov_b32 s44, %[pos]\n\t"
-        "s_mov_b32 s45, %[ns]\n\t"
-        "s_mov_b32 s51, %[len]\n\t"
-        "s_mov_b32 s53, %[us]\n\t"
-        "s_mov_b32 s54, %[wb]\n\t"
-        "s_mov_b32 s55, %[lds]\n\t"
-        "s_mov_b32 s56, %[ldd]\n\t"
-        "s_mov_b64 s[60:61], %[ob]\n\t"
-        "s_mov_b32 s52, 0\n\t"
-        "s_cmp_lg_u32 s51, 0\n\t"
-        "s_cbranch_scc1 4f\n"
-        // ---- top: refill, look up
-        "1:\n\t"
-        "s_cmp_gt_i32 s42, 32\n\t"
-        "s_cbranch_scc1 2f\n\t"
-        "s_sub_i32 s47, s43, s54\n\t"
-        "s_cmp_gt_i32 s47, 63\n\t"
-        "s_cbranch_scc1 80f\n\t"
-        "v_readlane_b32 s48, %[win], s47\n\t"
-        "s_mov_b32 s49, 0\n\t"
-        "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
-        "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
-        "s_add_i32 s42, s42, 32\n\t"
-        "s_add_i32 s43, s43, 1\n\t"
-        "s_branch 1b\n"
-        "2:\n\t"
-        "s_and_b32 s47, s40, 0x3ff\n\t"
-        "s_lshl2_add_u32 s47, s47, s55\n\t"
-        "v_mov_b32 %[vt], s47\n\t"
-        "ds_read_b32 %[vt], %[vt]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_readfirstlane_b32 s46, %[vt]\n\t"
-        "s_cmp_lt_i32 s46, 0\n\t"
-        "s_cbranch_scc1 3f\n\t"
-        // ---- one or two literals
-        "s_mov_b32 m0, s45\n\t"
-        "v_writelane_b32 %[lit], s46, m0\n\t"
-        "s_lshr_b32 s47, s46, 8\n\t"
-        "s_add_i32 m0, s45, 1\n\t"
-        "v_writelane_b32 %[lit], s47, m0\n\t"
-        "s_bfe_u32 s47, s46, 0x20018\n\t"
-        "s_add_i32 s45, s45, s47\n\t"
-        "s_bfe_u32 s47, s46, 0x50010\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
-        "s_sub_i32 s42, s42, s47\n\t"
-        "s_cmp_lt_i32 s45, 63\n\t"
-        "s_cbranch_scc1 1b\n\t"
-        // 63 or 64 pending: store them
-        "s_add_i32 s47, s44, s45\n\t"
-        "s_cmp_gt_u32 s47, s53\n\t"
-        "s_cbranch_scc1 85f\n\t"
-        "v_cmp_gt_u32 vcc, s45, %[lane]\n\t"
-        "s_and_saveexec_b64 s[58:59], vcc\n\t"
-        "v_add_u32 %[vt], s44, %[lane]\n\t"
-        "global_store_byte %[vt], %[lit], s[60:61]\n\t"
-        "s_mov_b64 exec, s[58:59]\n\t"
-        "s_mov_b32 s44, s47\n\t"
-        "s_mov_b32 s45, 0\n\t"
-        "s_branch 1b\n"
-        // ---- not a literal
-        "3:\n\t"
-        "s_bitcmp1_b32 s46, 30\n\t"
-        "s_cbranch_scc0 70f\n\t"
-        "s_bfe_u32 s48, s40, s46\n\t"
-        "s_bfe_u32 s51, s46, 0x90005\n\t"
-        "s_add_i32 s51, s51, s48\n\t"
-        "s_bfe_u32 s47, s46, 0x50017\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
-        "s_sub_i32 s42, s42, s47\n"
-        // ---- the distance: refill, look up
-        "4:\n\t"
-        "s_cmp_gt_i32 s42, 32\n\t"
-        "s_cbranch_scc1 5f\n\t"
-        "s_sub_i32 s47, s43, s54\n\t"
-        "s_cmp_gt_i32 s47, 63\n\t"
-        "s_cbranch_scc1 80f\n\t"
-        "v_readlane_b32 s48, %[win], s47\n\t"
-        "s_mov_b32 s49, 0\n\t"
-        "s_lshl_b64 s[48:49], s[48:49], s42\n\t"
-        "s_or_b64 s[40:41], s[40:41], s[48:49]\n\t"
-        "s_add_i32 s42, s42, 32\n\t"
-        "s_add_i32 s43, s43, 1\n\t"
-        "s_branch 4b\n"
-        "5:\n\t"
-        "s_and_b32 s47, s40, 0xff\n\t"
-        "s_lshl2_add_u32 s47, s47, s56\n\t"
-        "v_mov_b32 %[vt], s47\n\t"
-        "ds_read_b32 %[vt], %[vt]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_readfirstlane_b32 s46, %[vt]\n\t"
-        "s_cmp_lt_i32 s46, 0\n\t"
-        "s_cbranch_scc1 83f\n\t"
-        "s_bfe_u32 s47, s46, 0x50014\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
-        "s_sub_i32 s42, s42, s47\n\t"
-        "s_bfe_u32 s47, s46, 0x40010\n\t"
-        "s_bfm_b32 s48, s47, 0\n\t"
-        "s_and_b32 s48, s48, s40\n\t"
-        "s_and_b32 s52, s46, 0x7fff\n\t"
-        "s_add_i32 s52, s52, s48\n\t"
-        "s_lshr_b64 s[40:41], s[40:41], s47\n\t"
-        "s_sub_i32 s42, s42, s47\n\t"
-        // ---- checks, pending literals out, copy
-        "s_add_i32 s47, s44, s45\n\t"
-        "s_cmp_gt_u32 s52, s47\n\t"
-        "s_cbranch_scc1 85f\n\t"
-        "s_add_i32 s48, s47, s51\n\t"
-        "s_cmp_gt_u32 s48, s53\n\t"
-        "s_cbranch_scc1 85f\n\t"
-        "v_cmp_gt_u32 vcc, s45, %[lane]\n\t"
-        "s_and_saveexec_b64 s[58:59], vcc\n\t"
-        "v_add_u32 %[vt], s44, %[lane]\n\t"
-        "global_store_byte %[vt], %[lit], s[60:61]\n\t"
-        "s_mov_b64 exec, s[58:59]\n\t"
-        "s_mov_b32 s44, s47\n\t"
-        "s_mov_b32 s45, 0\n\t"
-        "s_cmp_lt_u32 s52, s51\n\t"
-        "s_cbranch_scc1 84f\n\t"
-        "s_cmp_gt_u32 s51, 64\n\t"
-        "s_cbranch_scc1 84f\n\t"
-        "v_cmp_gt_u32 vcc, s51, %[lane]\n\t"
-        "s_and_saveexec_b64 s[58:59], vcc\n\t"
-        "s_sub_i32 s47, s44, s52\n\t"
-        "v_add_u32 %[vt], s47, %[lane]\n\t"
-        "global_load_ubyte %[vt2], %[vt], s[60:61]\n\t"
-        "v_add_u32 %[vt], s44, %[lane]\n\t"
-        "s_waitcnt vmcnt(0)\n\t"
-        "global_store_byte %[vt], %[vt2], s[60:61]\n\t"
-        "s_mov_b64 exec, s[58:59]\n\t"
-        "s_add_i32 s44, s44, s51\n\t"
-        "s_mov_b32 s51, 0\n\t"
-        "s_branch 1b\n"
-        // ---- ways out
-        "70:\n\t"
-        "s_mov_b32 s50, 0\n\t"
-        "s_branch 9f\n"
-        "80:\n\t"
-        "s_mov_b32 s50, 2\n\t"
-        "s_branch 9f\n"
-        "83:\n\t"
-        "s_mov_b32 s50, 3\n\t"
-        "s_branch 9f\n"
-        "84:\n\t"
-        "s_mov_b32 s50, 4\n\t"
-        "s_branch 9f\n"
-        "85:\n\t"
-        "s_mov_b32 s50, 5\n"
-        "9:\n\t"
-        "s_mov_b64 %[buf], s[40:41]\n\t"
-        "s_mov_b32 %[cnt], s42\n\t"
-        "s_mov_b32 %[next], s43\n\t"
-        "s_mov_b32 %[pos], s44\n\t"
-        "s_mov_b32 %[ns], s45\n\t"
-        "s_mov_b32 %[e], s46\n\t"
-        "s_mov_b32 %[len], s51\n\t"
-        "s_mov_b32 %[dist], s52\n\t"
-        "s_mov_b32 %[reason], s50"
-        : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [ns] "+s"(n), [len] "+s"(len), [dist] "+s"(dist), [lit] "+v"(mylit),
-          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [e] "=s"(ee), [reason] "=s"(reason)
-        : [wb] "s"(wb), [us] "s"(us), [win] "v"(b.win), [lane] "v"(lane), [lds] "s"(lds), [ldd] "s"(ldd), [ob] "s"(ob)
-        : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s58", "s59", "s60", "s61",
-          "m0", "scc", "vcc", "memory");
-    b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.ns = n; st.len = len; st.dist = dist; st.e = ee;
-    return (int)reason;
-}
-// ---- the symbol loop, second generation -------------------------------------------------------------------------------------------
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+// ---- the symbol loop of a block, by hand ------------------------------------------------------------------------------------------
+// PMC on the C++ loop (round 2): 1.03 scalar instructions per CU cycle, 21.6 per output byte -- and in the benchmark's FASTQ 71 %
+// of the bytes come out of matches of 5.5 bytes on average, so what the match path costs decides the rate.  What the compiler
+// makes of the C++ loop is ~41 instructions per literal and ~120 per match (SGPR spills reloaded inside it, the reader's
+// counters kept in vector registers, selects and copies around every exit).  A first hand-written generation (sym_run, round
+// 3, in the history: refill from the window register by v_readlane, one ds_read_b32 per lookup, literals into a pending
+// register by v_writelane, the whole match path inside the block) took that to ~21 scalar-heavy instructions per literal
+// pair and ~70 per match: 26 -> 44 GB/s.  This is the second.
 // What bounds these kernels is the CU's ONE scalar unit (experiments/micro/salu_loop.hip and PMC: the waves of a CU want
 // several scalar instructions per cycle, it issues one), so this loop needs few of them and puts what it can on the vector
 // unit: the table index is computed there (v_bfe, v_lshl_add), literals go from the entry register to the output buffer
@@ -444,8 +260,13 @@ __device__ __forceinline__ int sym_run(BitsT& b, const uint32_t* lut2, const uin
 // is copied inside it (after a wait, if a load into those very slots may be in flight: s57 = the lowest slot written by a
 // load since the last vmcnt(0)); one that straddles buffer and memory is handed back (4).  Every way out writes the buffer
 // out: outside this block `out` holds everything in front of st.pos.  No pending literals in here (st.ns must be 0).
-// It leaves with sym_run's reasons, and
-//   6  fewer than two bytes of the block's size are left (the caller decodes one symbol itself)
+// Fixed scalar registers (named in the clobber list) because inline asm cannot name the halves of a 64-bit operand.  It leaves with
+//   0  an entry that is neither literal nor a folded length symbol (end of block, long code, no code): e, bits not consumed
+//   2  the window register is used up (refill() and come back; with `len` > 0: come back into the distance half)
+//   3  a distance code the table does not hold: len is decoded, the distance bits are not consumed
+//   4  a match the fast copy does not take (longer than 63 bytes, overlapping itself, or straddling buffer and memory): len, dist
+//   5  invalid: distance beyond the start of the output, or output beyond usize
+//   6  fewer than two bytes of the block's size are left (the caller decodes one symbol itself; the bit buffer is refilled)
 constexpr int OB_SLOTS = 192, OB_FLUSH = 128;   // (at most OB_FLUSH + 2 literals, or OB_FLUSH + a match of 63 bytes; the asm has the 128)
 template <class BitsT>
 __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const uint32_t* dlut, uint32_t* obuf, uint8_t* out, int usize, SymState& st) {
