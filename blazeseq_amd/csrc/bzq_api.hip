@@ -1748,16 +1748,19 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
     if (numa) gpu_numa_cpus(device, &g->numa_node, g->numa_cpus);
     g->stats.direct_io = g->fd_direct >= 0 ? 1 : 0;
     g->stats.numa_node = g->numa_node;
+    // compressed input?  gzip magic 1f 8b; BGZF if the first member carries the 'BC' extra subfield
+    uint8_t magic[18] = {0};
+    const bool gzip_magic = g->file_size >= 18 && pread(fd, magic, 18, 0) == 18 && magic[0] == 0x1f && magic[1] == 0x8b;
+    const bool gz_on_device = gzip_magic && !bzq::bgzf_block_size(magic) && gpu_inflate;
+    if (gz_on_device) g->gz_piece = std::max<uint64_t>(g->chunk_bytes / 2, std::min<uint64_t>(g->chunk_bytes, 64ull << 10));   // (a piece is read into a slot's pinned buffer: never more than a chunk)
     bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < bzq::INGEST_SLOTS && ok; ++i) ok = bzq::ingest_alloc_slot(g, i);
+    for (int i = 0; i < bzq::INGEST_SLOTS && ok; ++i) ok = bzq::ingest_alloc_slot(g, i, gz_on_device ? (i < 2 ? g->gz_piece : 0) : g->chunk_bytes);
     if (!ok) {
         err = std::string(who) + ": allocating the pinned / device chunk buffers failed";
         bzq::ingest_free(g);
         return BZQ_ERR_NOMEM;
     }
-    // compressed input?  gzip magic 1f 8b; BGZF if the first member carries the 'BC' extra subfield
-    uint8_t magic[18] = {0};
-    if (g->file_size >= 18 && pread(fd, magic, 18, 0) == 18 && magic[0] == 0x1f && magic[1] == 0x8b) {
+    if (gzip_magic) {
         if (bzq::bgzf_block_size(magic)) {
             g->compression = 2;
             if (gpu_inflate) {   // the compressed bytes travel, the device inflates (bzq_inflate.hpp)
@@ -1774,7 +1777,6 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
             }
         } else if (gpu_inflate) {   // any other gzip file: rapidgzip's two-stage decode on the device (bzq_gzip.hpp)
             g->compression = 1;
-            g->gz_piece = std::max<uint64_t>(g->chunk_bytes / 2, std::min<uint64_t>(g->chunk_bytes, 64ull << 10));   // (a piece is read into a slot's pinned buffer: never more than a chunk)
             g->gz_cap = std::max<uint64_t>(6 * g->chunk_bytes, 64ull << 20);
             int grc = bzq::gz::gz_open(device, &g->gz_dev, err);
             if (!grc && (hipMalloc((void**)&g->gz_fifo[0], g->gz_cap + 64) != hipSuccess || hipMalloc((void**)&g->gz_fifo[1], g->gz_cap + 64) != hipSuccess)) {

@@ -199,9 +199,11 @@ __device__ __forceinline__ int64_t parse_member_header(const uint8_t* comp, int6
 // of the next symbol in it, 0..65536), a match source in front of the job's output becomes a marker -- which is simply the low
 // 16 bits of its (negative) position: 0x8000 | (32768 + q) == q & 0xFFFF for -32768 <= q < 0.  A distance never needs a check
 // here (the format ends at 32768, and 32 KiB in front of the job are addressable as markers).  What the asm block does not take
-// it hands back untouched: a match that would cross the page's end or whose source lies in the page before, is longer than 63
-// symbols or overlaps itself (4), long or missing codes (0, 3), the window register running out (2), a page with fewer than
-// two free slots (6: the caller decodes one symbol itself).  `first` = the page is the job's first (sources may be markers).
+// it hands back untouched: a match that would cross the page's end or whose source lies in the page before, or straddles
+// buffer and page (4), long or missing codes (0, 3), the window register running out (2), a page with fewer than two free
+// slots (6: the caller decodes one symbol itself).  Matches longer than 63 symbols and matches that overlap themselves (runs:
+// common in a sequencer's quality lines) are taken in pieces of up to 63, lane i of a piece reading source symbol i mod dist.
+// `first` = the page is the job's first (sources may be markers).
 //
 // What bounds this kernel is the CU's ONE scalar unit (the microbenchmark experiments/micro/salu_loop.hip and PMC: 24 waves
 // of a CU want ~6 scalar instructions per cycle, it issues 1), so the loop is written to need few of them and to put what it
@@ -223,7 +225,7 @@ using inf::OB_FLUSH;
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const uint32_t* dlut, uint32_t* obuf, uint16_t* page, bool first, inf::SymState& st) {
-    uint32_t reason, vt, vt2, vq, ve, vslot, ee;
+    uint32_t reason, vt, vt2, vq, ve, vslot, vsrc, ee;
     u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
     int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), pos = (int)uni((uint32_t)st.pos);
     int len = (int)uni((uint32_t)st.len), dist = 0;
@@ -231,6 +233,7 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
     const uint32_t lds = uni((uint32_t)(uintptr_t)lut2), ldd = uni((uint32_t)(uintptr_t)dlut), ldo = uni((uint32_t)(uintptr_t)obuf);
     const u64 ob = ((u64)uni((uint32_t)((uintptr_t)page >> 32)) << 32) | uni((uint32_t)(uintptr_t)page);
     const uint32_t lane = threadIdx.x & 63, lane4 = lane << 2, sh8 = lane << 3;
+    const float lh = (float)lane + 0.5f;
     asm volatile(
         "\ts_mov_b64 s[68:69], exec\n"
         "\ts_mov_b64 s[40:41], %[buf]\n"
@@ -314,10 +317,7 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_add_i32 s52, s52, s48\n"
         "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
         "\ts_sub_i32 s42, s42, s47\n"
-        // ---- what the fast copy takes: up to 63 symbols, not overlapping itself, inside this page, source in this page (or markers)
-        "\ts_min_u32 s47, s52, 63\n"
-        "\ts_cmp_gt_u32 s51, s47\n"
-        "\ts_cbranch_scc1 84f\n"
+        // ---- what stays in here: a match inside this page whose source is in this page (or markers)
         "\ts_add_i32 s47, s44, s64\n"
         "\ts_add_i32 s48, s47, s51\n"
         "\ts_cmp_gt_u32 s48, 0x10000\n"
@@ -325,6 +325,10 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_add_i32 s48, s47, s53\n"
         "\ts_cmp_gt_u32 s52, s48\n"
         "\ts_cbranch_scc1 84f\n"
+        // ---- the common kind: up to 63 symbols, not overlapping itself (the others: 70, in pieces)
+        "\ts_min_u32 s48, s52, 63\n"
+        "\ts_cmp_gt_u32 s51, s48\n"
+        "\ts_cbranch_scc1 40f\n"
         // where the source lies: dist - len >= what the buffer holds -> all of it is in memory (or in front of the page: markers)
         "\ts_sub_i32 s48, s52, s51\n"
         "\ts_cmp_ge_u32 s48, s64\n"
@@ -378,6 +382,82 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_waitcnt lgkmcnt(0)\n"
         "\tds_write_b32 %[vt], %[vt2]\n"
         "\ts_branch 63b\n"
+        // ---- a long match, or one that overlaps itself (dist < len: the source repeats with period dist -- runs of one quality value,
+        // poly-G tails, duplicate reads: rare in the benchmark's synthetic FASTQ, common in real files): in pieces of up to 63, lane i
+        // of a piece taking source symbol i mod dist.  Pieces go through the buffer like any match; a later piece may read what an
+        // earlier one wrote (the in-flight test covers that); what straddles buffer and memory is handed back with the rest (4).
+        "40:\n"
+        "\ts_mov_b64 exec, s[68:69]\n"
+        "\ts_min_u32 s70, s51, 63\n"
+        "\ts_min_u32 s71, s70, s52\n"
+        "\tv_mov_b32 %[vsrc], %[lane]\n"
+        "\ts_cmp_le_u32 s70, s52\n"
+        "\ts_cbranch_scc1 41f\n"
+
+        // i mod dist = i - dist * floor((i + 0.5) / dist): exact in fp32 for i < 64 (the quotient stays > 0.007 away from an integer)
+        "\tv_cvt_f32_u32 %[vt], s52\n"
+        "\tv_rcp_f32 %[vt], %[vt]\n"
+        "\ts_nop 1\n"   // (a transcendental's result is not interlocked against the next VALU read: experiments/micro/lane_mod.hip)
+        "\tv_mul_f32 %[vt], %[lh], %[vt]\n"
+        "\tv_cvt_u32_f32 %[vt], %[vt]\n"
+        "\tv_mul_lo_u32 %[vt], %[vt], s52\n"
+        "\tv_sub_u32 %[vsrc], %[lane], %[vt]\n"
+        "41:\n"
+        "\ts_sub_i32 s48, s52, s71\n"
+        "\ts_cmp_ge_u32 s48, s64\n"
+        "\ts_cbranch_scc0 45f\n"
+        "\ts_bfm_b64 exec, s70, 0\n"
+        "\ts_add_i32 s47, s44, s64\n"
+        "\ts_sub_i32 s47, s47, s52\n"
+        "\tv_add_u32 %[vq], s47, %[vsrc]\n"
+        "\ts_lshl2_add_u32 m0, s64, s65\n"
+        "\ts_cmp_ge_i32 s47, 0\n"
+        "\ts_cbranch_scc0 44f\n"
+        "42:\n"
+        "\tv_lshlrev_b32 %[vt], 1, %[vq]\n"
+        "\ts_min_u32 s57, s57, s64\n"
+        "\tglobal_load_lds_ushort %[vt], s[60:61]\n"
+        "43:\n"
+        "\ts_mov_b64 exec, 3\n"
+        "\ts_add_i32 s64, s64, s70\n"
+        "\tv_lshl_add_u32 %[vslot], s70, 2, %[vslot]\n"
+        "\ts_sub_i32 s51, s51, s70\n"
+        "\ts_cmp_eq_u32 s51, 0\n"
+        "\ts_cbranch_scc1 8b\n"
+        "\ts_cmp_le_u32 s64, 128\n"
+        "\ts_cbranch_scc1 40b\n"
+        "\ts_mov_b32 s66, 2\n"
+        "\ts_branch 30f\n"
+        // (first page) lanes with q < 0 write the marker q & 0xFFFF themselves
+        "44:\n"
+        "\tv_cmp_gt_i32 vcc, 0, %[vq]\n"
+        "\ts_and_saveexec_b64 s[62:63], vcc\n"
+        "\tv_and_b32 %[vt2], 0xffff, %[vq]\n"
+        "\ts_lshl2_add_u32 s48, s64, s65\n"
+        "\tv_add_u32 %[vt], s48, %[lane4]\n"
+        "\tds_write_b32 %[vt], %[vt2]\n"
+        "\ts_andn2_b64 exec, s[62:63], vcc\n"
+        "\ts_cbranch_execz 43b\n"
+        "\ts_branch 42b\n"
+        "45:\n"
+        "\ts_cmp_le_u32 s52, s64\n"
+        "\ts_cbranch_scc0 84f\n"
+        "\ts_sub_i32 s47, s64, s52\n"
+        "\ts_add_i32 s48, s47, s71\n"
+        "\ts_cmp_le_u32 s48, s57\n"
+        "\ts_cbranch_scc1 46f\n"
+        "\ts_waitcnt vmcnt(0)\n"
+        "\ts_mov_b32 s57, 0x7fffffff\n"
+        "46:\n"
+        "\ts_bfm_b64 exec, s70, 0\n"
+        "\ts_lshl2_add_u32 s47, s47, s65\n"
+        "\tv_lshl_add_u32 %[vt], %[vsrc], 2, s47\n"
+        "\tds_read_b32 %[vt2], %[vt]\n"
+        "\ts_lshl2_add_u32 s48, s64, s65\n"
+        "\tv_add_u32 %[vt], s48, %[lane4]\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tds_write_b32 %[vt], %[vt2]\n"
+        "\ts_branch 43b\n"
         // ---- the bit buffer's refills (every ~5 symbols: out of the way)
         "10:\n"
         "\ts_sub_i32 s47, s43, s54\n"
@@ -448,9 +528,11 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_sub_i32 s67, 0xfffe, s44\n"
         "\ts_min_i32 s67, s67, 128\n"
         "\tv_add_u32 %[vslot], s65, %[lane4]\n"
-        "\ts_cmp_eq_u32 s66, 0\n"
-        "\ts_cbranch_scc0 91f\n"
+        "\ts_cmp_eq_u32 s66, 1\n"
+        "\ts_cbranch_scc1 91f\n"
         "\ts_mov_b64 exec, 3\n"
+        "\ts_cmp_eq_u32 s66, 2\n"
+        "\ts_cbranch_scc1 40b\n"
         "\ts_branch 8b\n"
         // ---- ways out
         "70:\n"
@@ -480,10 +562,10 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_mov_b32 %[dist], s52\n"
         "\ts_mov_b32 %[reason], s50"
         : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [len] "+s"(len), [dist] "+s"(dist),
-          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [ve] "=&v"(ve), [vslot] "=&v"(vslot), [e] "=s"(ee), [reason] "=s"(reason)
-        : [wb] "s"(wb), [fp] "s"(fp), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
+          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [ve] "=&v"(ve), [vslot] "=&v"(vslot), [vsrc] "=&v"(vsrc), [e] "=s"(ee), [reason] "=s"(reason)
+        : [wb] "s"(wb), [fp] "s"(fp), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lh] "v"(lh), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
         : "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",
-          "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "m0", "scc", "vcc", "memory");
+          "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "m0", "scc", "vcc", "memory");
     b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.len = len; st.dist = dist; st.e = ee;
     return (int)reason;
 }

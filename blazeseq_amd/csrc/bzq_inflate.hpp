@@ -264,13 +264,14 @@ struct SymState { int pos, ns, len, dist; uint32_t e; };
 //   0  an entry that is neither literal nor a folded length symbol (end of block, long code, no code): e, bits not consumed
 //   2  the window register is used up (refill() and come back; with `len` > 0: come back into the distance half)
 //   3  a distance code the table does not hold: len is decoded, the distance bits are not consumed
-//   4  a match the fast copy does not take (longer than 63 bytes, overlapping itself, or straddling buffer and memory): len, dist
+//   4  a match whose source straddles buffer and memory (what is left of it: len, dist).  Long matches and matches that overlap
+//      themselves stay inside: in pieces of up to 63 bytes, lane i of a piece reading source byte i mod dist (label 40)
 //   5  invalid: distance beyond the start of the output, or output beyond usize
 //   6  fewer than two bytes of the block's size are left (the caller decodes one symbol itself; the bit buffer is refilled)
 constexpr int OB_SLOTS = 192, OB_FLUSH = 128;   // (at most OB_FLUSH + 2 literals, or OB_FLUSH + a match of 63 bytes; the asm has the 128)
 template <class BitsT>
 __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const uint32_t* dlut, uint32_t* obuf, uint8_t* out, int usize, SymState& st) {
-    uint32_t reason, vt, vt2, vq, ve, vslot, ee;
+    uint32_t reason, vt, vt2, vq, ve, vslot, vsrc, ee;
     u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
     int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), pos = (int)uni((uint32_t)st.pos);
     int len = (int)uni((uint32_t)st.len), dist = 0;
@@ -278,6 +279,7 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
     const uint32_t lds = uni((uint32_t)(uintptr_t)lut2), ldd = uni((uint32_t)(uintptr_t)dlut), ldo = uni((uint32_t)(uintptr_t)obuf);
     const u64 ob = ((u64)uni((uint32_t)((uintptr_t)out >> 32)) << 32) | uni((uint32_t)(uintptr_t)out);
     const uint32_t lane = threadIdx.x & 63, lane4 = lane << 2, sh8 = lane << 3;
+    const float lh = (float)lane + 0.5f;
     asm volatile(
         "\ts_mov_b64 s[68:69], exec\n"
         "\ts_mov_b64 s[40:41], %[buf]\n"
@@ -369,10 +371,10 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_sub_i32 s48, s48, 2\n"
         "\ts_cmp_gt_i32 s48, s53\n"
         "\ts_cbranch_scc1 85f\n"
-        // ---- what the fast copy takes: up to 63 bytes, not overlapping itself
+        // ---- the common kind: up to 63 bytes, not overlapping itself (the others: 70, in pieces)
         "\ts_min_u32 s48, s52, 63\n"
         "\ts_cmp_gt_u32 s51, s48\n"
-        "\ts_cbranch_scc1 84f\n"
+        "\ts_cbranch_scc1 40f\n"
         // where the source lies: dist - len >= what the buffer holds -> all of it is in memory
         "\ts_sub_i32 s48, s52, s51\n"
         "\ts_cmp_ge_u32 s48, s64\n"
@@ -417,6 +419,68 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_waitcnt lgkmcnt(0)\n"
         "\tds_write_b32 %[vt], %[vt2]\n"
         "\ts_branch 63b\n"
+        // ---- a long match, or one that overlaps itself (dist < len: the source repeats with period dist -- runs of one quality value,
+        // poly-G tails, duplicate reads: rare in the benchmark's synthetic FASTQ, common in real files): in pieces of up to 63, lane i
+        // of a piece taking source symbol i mod dist.  Pieces go through the buffer like any match; a later piece may read what an
+        // earlier one wrote (the in-flight test covers that); what straddles buffer and memory is handed back with the rest (4).
+        "40:\n"
+        "\ts_mov_b64 exec, s[68:69]\n"
+        "\ts_min_u32 s70, s51, 63\n"
+        "\ts_min_u32 s71, s70, s52\n"
+        "\tv_mov_b32 %[vsrc], %[lane]\n"
+        "\ts_cmp_le_u32 s70, s52\n"
+        "\ts_cbranch_scc1 41f\n"
+        // i mod dist = i - dist * floor((i + 0.5) / dist): exact in fp32 for i < 64 (the quotient stays > 0.007 away from an integer)
+        "\tv_cvt_f32_u32 %[vt], s52\n"
+        "\tv_rcp_f32 %[vt], %[vt]\n"
+        "\ts_nop 1\n"   // (a transcendental's result is not interlocked against the next VALU read: experiments/micro/lane_mod.hip)
+        "\tv_mul_f32 %[vt], %[lh], %[vt]\n"
+        "\tv_cvt_u32_f32 %[vt], %[vt]\n"
+        "\tv_mul_lo_u32 %[vt], %[vt], s52\n"
+        "\tv_sub_u32 %[vsrc], %[lane], %[vt]\n"
+        "41:\n"
+        "\ts_sub_i32 s48, s52, s71\n"
+        "\ts_cmp_ge_u32 s48, s64\n"
+        "\ts_cbranch_scc0 45f\n"
+        "\ts_bfm_b64 exec, s70, 0\n"
+        "\ts_add_i32 s47, s44, s64\n"
+        "\ts_sub_i32 s47, s47, s52\n"
+        "\tv_add_u32 %[vq], s47, %[vsrc]\n"
+        "\ts_lshl2_add_u32 m0, s64, s65\n"
+        "42:\n"
+        "\ts_min_u32 s57, s57, s64\n"
+        "\ts_nop 0\n"
+        "\tglobal_load_lds_ubyte %[vq], s[60:61]\n"
+        "43:\n"
+        "\ts_mov_b64 exec, 3\n"
+        "\ts_add_i32 s64, s64, s70\n"
+        "\tv_lshl_add_u32 %[vslot], s70, 2, %[vslot]\n"
+        "\ts_sub_i32 s51, s51, s70\n"
+        "\ts_cmp_eq_u32 s51, 0\n"
+        "\ts_cbranch_scc1 8b\n"
+        "\ts_cmp_le_u32 s64, 128\n"
+        "\ts_cbranch_scc1 40b\n"
+        "\ts_mov_b32 s66, 2\n"
+        "\ts_branch 30f\n"
+        "45:\n"
+        "\ts_cmp_le_u32 s52, s64\n"
+        "\ts_cbranch_scc0 84f\n"
+        "\ts_sub_i32 s47, s64, s52\n"
+        "\ts_add_i32 s48, s47, s71\n"
+        "\ts_cmp_le_u32 s48, s57\n"
+        "\ts_cbranch_scc1 46f\n"
+        "\ts_waitcnt vmcnt(0)\n"
+        "\ts_mov_b32 s57, 0x7fffffff\n"
+        "46:\n"
+        "\ts_bfm_b64 exec, s70, 0\n"
+        "\ts_lshl2_add_u32 s47, s47, s65\n"
+        "\tv_lshl_add_u32 %[vt], %[vsrc], 2, s47\n"
+        "\tds_read_b32 %[vt2], %[vt]\n"
+        "\ts_lshl2_add_u32 s48, s64, s65\n"
+        "\tv_add_u32 %[vt], s48, %[lane4]\n"
+        "\ts_waitcnt lgkmcnt(0)\n"
+        "\tds_write_b32 %[vt], %[vt2]\n"
+        "\ts_branch 43b\n"
         // ---- the bit buffer's refills (every ~5 symbols: out of the way)
         "10:\n"
         "\ts_sub_i32 s47, s43, s54\n"
@@ -486,9 +550,11 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_sub_i32 s67, s53, s44\n"
         "\ts_min_i32 s67, s67, 128\n"
         "\tv_add_u32 %[vslot], s65, %[lane4]\n"
-        "\ts_cmp_eq_u32 s66, 0\n"
-        "\ts_cbranch_scc0 91f\n"
+        "\ts_cmp_eq_u32 s66, 1\n"
+        "\ts_cbranch_scc1 91f\n"
         "\ts_mov_b64 exec, 3\n"
+        "\ts_cmp_eq_u32 s66, 2\n"
+        "\ts_cbranch_scc1 40b\n"
         "\ts_branch 8b\n"
         // ---- ways out
         "70:\n"
@@ -521,10 +587,10 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_mov_b32 %[dist], s52\n"
         "\ts_mov_b32 %[reason], s50"
         : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [len] "+s"(len), [dist] "+s"(dist),
-          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [ve] "=&v"(ve), [vslot] "=&v"(vslot), [e] "=s"(ee), [reason] "=s"(reason)
-        : [wb] "s"(wb), [us2] "s"(us2), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
+          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [ve] "=&v"(ve), [vslot] "=&v"(vslot), [vsrc] "=&v"(vsrc), [e] "=s"(ee), [reason] "=s"(reason)
+        : [wb] "s"(wb), [us2] "s"(us2), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lh] "v"(lh), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
         : "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",
-          "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "m0", "scc", "vcc", "memory");
+          "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "m0", "scc", "vcc", "memory");
     b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.len = len; st.dist = dist; st.e = ee;
     return (int)reason;
 }

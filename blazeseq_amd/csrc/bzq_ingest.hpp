@@ -263,8 +263,11 @@ inline bool ingest_alloc_inflate(bzq_ingest* g, int i) {
            hipMalloc((void**)&g->tab_dev[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16) == hipSuccess &&
            hipHostMalloc((void**)&g->tab_pinned[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16, hipHostMallocDefault) == hipSuccess;
 }
-inline bool ingest_alloc_slot(bzq_ingest* g, int i) {
-    return hipHostMalloc((void**)&g->slot[i].pinned, g->reserve + g->chunk_bytes, hipHostMallocDefault) == hipSuccess &&
+// pinned_bytes: what the slot's host buffer must take behind the reserve (0: the slot has none).  Pinning is the expensive part
+// of an open (~0.1 s per GiB): a plain file stages whole chunks there, a .gz decoded on the device only pieces of compressed
+// bytes, in two of the three slots.
+inline bool ingest_alloc_slot(bzq_ingest* g, int i, uint64_t pinned_bytes) {
+    return (!pinned_bytes || hipHostMalloc((void**)&g->slot[i].pinned, g->reserve + pinned_bytes, hipHostMallocDefault) == hipSuccess) &&
            hipMalloc((void**)&g->slot[i].dev, g->reserve + g->chunk_bytes + 64) == hipSuccess &&
            hipEventCreateWithFlags(&g->slot[i].h2d_done, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&g->dev_free[i], hipEventDisableTiming) == hipSuccess;

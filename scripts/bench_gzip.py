@@ -13,7 +13,7 @@ import numpy as np
 import torch
 import blazeseq_amd as B
 from blazeseq_amd import _lib as L
-from tests.gzip_util import gzip_member
+from tests.gzip_util import gzip_member, sequencer_like
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--gb", type=float, default=1.0)
@@ -26,16 +26,23 @@ ap.add_argument("--chunk-mib", type=int, default=256, help="ingest chunk (decomp
 ap.add_argument("--dir", default="/dev/shm")
 ap.add_argument("--no-stage", action="store_true", help="no bzq_gzip_stage read-ahead of the next piece")
 ap.add_argument("--no-ingest", action="store_true")
+ap.add_argument("--data", default="synthetic", choices=["synthetic", "sequencer"], help="synthetic: the benchmark's generator (random qualities); sequencer: quality runs, duplicates, poly-G tails")
 args = ap.parse_args()
 
 ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
-n_rec = args.slice_mb * (1 << 20) // 318
-size = ctx.generate_synthetic_device(n_rec, 150, 33, 73, "generic", 0, 0)
-buf = torch.empty(size + 64, dtype=torch.uint8, device="cuda")
-ctx.generate_synthetic_device(n_rec, 150, 33, 73, "generic", buf.data_ptr(), buf.numel())
-torch.cuda.synchronize()
-d_plain = buf[:size]
-plain = d_plain.cpu().numpy().tobytes()
+
+
+if args.data == "sequencer":
+    plain, n_rec = sequencer_like(args.slice_mb << 20)
+    d_plain = torch.from_numpy(np.frombuffer(plain, dtype=np.uint8).copy()).cuda()
+else:
+    n_rec = args.slice_mb * (1 << 20) // 318
+    size = ctx.generate_synthetic_device(n_rec, 150, 33, 73, "generic", 0, 0)
+    buf = torch.empty(size + 64, dtype=torch.uint8, device="cuda")
+    ctx.generate_synthetic_device(n_rec, 150, 33, 73, "generic", buf.data_ptr(), buf.numel())
+    torch.cuda.synchronize()
+    d_plain = buf[:size]
+    plain = d_plain.cpu().numpy().tobytes()
 reps = max(1, int(args.gb * 1e9 / len(plain)))
 total_plain, total_rec = len(plain) * reps, n_rec * reps
 HDR = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3])

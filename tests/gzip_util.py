@@ -73,3 +73,32 @@ class DeviceGunzip:
     def close(self):
         self.dec.close()
         L.lib().bzq_device_free(self.ctx.h, self.d_out)
+
+
+def sequencer_like(n_bytes: int, seed: int = 3) -> bytes:
+    """FASTQ with what a sequencer's files have and the synthetic generator's do not: binned qualities in long runs (a match that
+    overlaps itself: distance 1, length up to 258), reads sampled from a small genome (sources tens of KiB back), exact duplicates
+    (matches as long as a read), poly-G tails."""
+    rng = np.random.default_rng(seed)
+    genome = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 2_000_000)
+    qv = np.frombuffer(b"F:,#", dtype=np.uint8)
+    out, n, recent = [], 0, []
+    i = 0
+    while n < n_bytes:
+        if recent and rng.random() < 0.15:
+            seq = recent[int(rng.integers(len(recent)))]
+        else:
+            at = int(rng.integers(0, genome.size - 150))
+            seq = genome[at:at + 150].copy()
+            if rng.random() < 0.1:
+                seq[150 - int(rng.integers(20, 90)):] = ord("G")
+            miss = rng.random(150) < 0.003
+            seq[miss] = rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), int(miss.sum()))
+        recent.append(seq)
+        if len(recent) > 64:
+            recent.pop(0)
+        runs = rng.geometric(0.07, 40)
+        q = np.resize(np.repeat(rng.choice(qv, 40, p=[0.8, 0.12, 0.06, 0.02]), runs), 150)
+        rec = b"@A00123:45:HXXXXXXXX:1:%d:%d:%d 1:N:0:ACGTACGT\n" % (1101 + i // 100000, 1000 + (i * 7) % 30000, 1000 + (i * 13) % 30000) + seq.tobytes() + b"\n+\n" + q.tobytes() + b"\n"
+        out.append(rec); n += len(rec); i += 1
+    return b"".join(out), i

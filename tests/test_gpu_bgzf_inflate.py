@@ -84,6 +84,16 @@ def test_the_last_symbols_of_many_blocks():
         assert inflate_on_device(ctx, comp) == data, level
 
 
+def test_what_a_sequencer_writes():
+    """Quality runs, duplicate reads, poly-G tails (tests/gzip_util.py): overlapping and long matches, taken in pieces by the
+    symbol loop."""
+    from tests.gzip_util import sequencer_like
+    ctx = Context()
+    data, _ = sequencer_like(5 << 20)
+    for level in (1, 6, 9):
+        assert inflate_on_device(ctx, bgzf_compress(data, block=65280, level=level)) == data, level
+
+
 def test_many_blocks_random_mix():
     ctx = Context()
     rng = np.random.default_rng(8)

@@ -9,7 +9,7 @@ import pytest
 
 from blazeseq_amd.parser import Context
 from tests.fastq_fuzz import rand_stream
-from tests.gzip_util import DeviceGunzip, gzip_member
+from tests.gzip_util import DeviceGunzip, gzip_member, sequencer_like
 
 pytestmark = pytest.mark.gpu
 
@@ -130,6 +130,18 @@ def test_staged_pieces_are_the_pieces():
     g.dec.stage(stray[:100])
     assert g.decode(comp, 200000, ahead=1) == data
     g.close()
+
+
+def test_what_a_sequencer_writes():
+    """Quality values in long runs (matches that overlap themselves: distance 1, length up to 258), duplicate reads (matches as
+    long as a read), poly-G tails: the symbol loop takes such matches in pieces, lane i of a piece reading source symbol
+    i mod distance."""
+    data, _ = sequencer_like(6 << 20)
+    ctx = Context()
+    for level in (1, 6, 9):
+        g = DeviceGunzip(ctx, len(data) + 4096)
+        assert g.decode(gzip.compress(data, level)) == data, level
+        g.close()
 
 
 def test_trailing_garbage_is_ignored_like_gzread_does():
