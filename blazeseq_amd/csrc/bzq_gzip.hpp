@@ -1637,7 +1637,6 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 128, hipMemcpyDeviceToHost, s));
         GZCHK(h, hipStreamSynchronize(s));
         lap(2);
-        if (getenv("BZQ_GZ_EARLY")) fprintf(stderr, "early: find %.2f decode %.2f (%d chunks)\n", t_ph[1], t_ph[2], n_chunks);
         if (counting) fprintf(stderr, "bzq_gzip decoder: the symbol loop handed back %u times for a code it does not take / the end of a block, %u for its window, %u for a long distance code, %u for a copy it does not take, %u at a page's end\n",
                               h_counters[16], h_counters[18], h_counters[19], h_counters[20], h_counters[22]);
         if (counting) fprintf(stderr, "bzq_gzip finder clocks (x256, summed over waves): total %u, in flushes: waiting for the tables %u, the lanes' look %u, the wave's judgement %u\n", h_counters[12], h_counters[9], h_counters[10], h_counters[11]);

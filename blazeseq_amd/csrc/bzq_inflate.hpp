@@ -380,9 +380,6 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_cmp_ge_u32 s48, s64\n"
         "\ts_cbranch_scc0 65f\n"
         // far: lane i < len fetches the byte at pos - dist + i STRAIGHT INTO its buffer slot (LDS-direct load: nothing to wait for)
-#ifdef BZQ_OB_NO_FAR
-        "\ts_branch 84f\n"
-#endif
         "\ts_bfm_b64 exec, s51, 0\n"
         "\ts_sub_i32 s47, s47, s52\n"
         "\tv_add_u32 %[vq], s47, %[lane]\n"
@@ -398,9 +395,6 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_branch 8b\n"
         // near: dist <= what the buffer holds -> all of it is in the buffer (slots ob_n - dist ..); anything else straddles: handed back
         "65:\n"
-#ifdef BZQ_OB_NO_NEAR
-        "\ts_branch 84f\n"
-#endif
         "\ts_cmp_le_u32 s52, s64\n"
         "\ts_cbranch_scc0 84f\n"
         "\ts_sub_i32 s47, s64, s52\n"
