@@ -1754,7 +1754,15 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
     const bool gz_on_device = gzip_magic && !bzq::bgzf_block_size(magic) && gpu_inflate;
     if (gz_on_device) g->gz_piece = std::max<uint64_t>(g->chunk_bytes / 2, std::min<uint64_t>(g->chunk_bytes, 64ull << 10));   // (a piece is read into a slot's pinned buffer: never more than a chunk)
     bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < bzq::INGEST_SLOTS && ok; ++i) ok = bzq::ingest_alloc_slot(g, i, gz_on_device ? (i < 2 ? g->gz_piece : 0) : g->chunk_bytes);
+    if (ok) {   // the slots side by side: pinning a chunk-sized buffer takes ~30 ms, and three of them one after the other were most of an open
+        bool slot_ok[bzq::INGEST_SLOTS];
+        std::thread th[bzq::INGEST_SLOTS];
+        for (int i = 0; i < bzq::INGEST_SLOTS; ++i)
+            th[i] = std::thread([g, i, device, gz_on_device, &slot_ok]() {
+                slot_ok[i] = hipSetDevice(device) == hipSuccess && bzq::ingest_alloc_slot(g, i, gz_on_device ? (i < 2 ? g->gz_piece : 0) : g->chunk_bytes);
+            });
+        for (int i = 0; i < bzq::INGEST_SLOTS; ++i) { th[i].join(); ok = ok && slot_ok[i]; }
+    }
     if (!ok) {
         err = std::string(who) + ": allocating the pinned / device chunk buffers failed";
         bzq::ingest_free(g);
