@@ -229,6 +229,7 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
     u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
     int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), pos = (int)uni((uint32_t)st.pos);
     int len = (int)uni((uint32_t)st.len), dist = 0;
+    const int din = (int)uni((uint32_t)st.dist);   // != 0: the match's distance is known (the caller decoded a long distance code): straight to the copy
     const int wb = (int)uni((uint32_t)b.win_base), fp = (int)uni(first ? 0x40000000u : 0u);   // how far in front of the page a source may lie
     const uint32_t lds = uni((uint32_t)(uintptr_t)lut2), ldd = uni((uint32_t)(uintptr_t)dlut), ldo = uni((uint32_t)(uintptr_t)obuf);
     const u64 ob = ((u64)uni((uint32_t)((uintptr_t)page >> 32)) << 32) | uni((uint32_t)(uintptr_t)page);
@@ -247,13 +248,15 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_mov_b32 s56, %[ldd]\n"
         "\ts_mov_b64 s[60:61], %[ob]\n"
         "\ts_mov_b32 s65, %[obuf]\n"
-        "\ts_mov_b32 s52, 0\n"
+        "\ts_mov_b32 s52, %[din]\n"
         "\ts_mov_b32 s64, 0\n"
         "\ts_mov_b32 s57, 0x7fffffff\n"
         "\ts_sub_i32 s67, 0xfffe, s44\n"
         "\ts_min_i32 s67, s67, 128\n"
         "\tv_add_u32 %[vslot], s65, %[lane4]\n"
         "\ts_mov_b64 exec, 3\n"
+        "\ts_cmp_lg_u32 s52, 0\n"
+        "\ts_cbranch_scc1 47f\n"
         "\ts_cmp_lg_u32 s51, 0\n"
         "\ts_cbranch_scc1 4f\n"
         // ---- between symbols: room for two more literals in buffer and page?
@@ -318,6 +321,7 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
         "\ts_sub_i32 s42, s42, s47\n"
         // ---- what stays in here: a match inside this page whose source is in this page (or markers)
+        "47:\n"
         "\ts_add_i32 s47, s44, s64\n"
         "\ts_add_i32 s48, s47, s51\n"
         "\ts_cmp_gt_u32 s48, 0x10000\n"
@@ -563,7 +567,7 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_mov_b32 %[reason], s50"
         : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [len] "+s"(len), [dist] "+s"(dist),
           [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [ve] "=&v"(ve), [vslot] "=&v"(vslot), [vsrc] "=&v"(vsrc), [e] "=s"(ee), [reason] "=s"(reason)
-        : [wb] "s"(wb), [fp] "s"(fp), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lh] "v"(lh), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
+        : [wb] "s"(wb), [fp] "s"(fp), [din] "s"(din), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lh] "v"(lh), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
         : "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",
           "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "m0", "scc", "vcc", "memory");
     b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.len = len; st.dist = dist; st.e = ee;
@@ -703,14 +707,13 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
                 const int why = sym_run_gz(b, lut2, dlut, obuf, cur, cur_idx == 0, st);
                 if (count_them && lane == 0) atomicAdd(&a.counters[16 + why], 1u);
                 opos = (opos & ~(int64_t)(PAGE - 1)) + st.pos;
+                if (why != 4) st.dist = 0;   // (a distance handed in was used; 4 hands the match back: len, dist)
                 if (why == 2) { b.refill(); if (b.ran_out) { ok = false; break; } continue; }   // (with st.len set it resumes in the distance half)
-                if (why == 4) { if (!general_copy(st.len, st.dist)) { ok = false; break; } st.len = 0; continue; }
+                if (why == 4) { if (!general_copy(st.len, st.dist)) { ok = false; break; } st.len = 0; st.dist = 0; continue; }
                 if (why == 3) {   // a distance code the direct table does not hold
                     const int ds = inf::decode_sym(b, dd, sym_d);
                     if (ds < 0 || ds > 29) { ok = false; break; }
-                    const int dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));
-                    if (!general_copy(st.len, dist)) { ok = false; break; }
-                    st.len = 0;
+                    st.dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));   // sym_run_gz goes on with the copy
                     continue;
                 }
                 // why == 0: end of block, a literal / length code longer than the table's index, or no code at all;

@@ -275,6 +275,7 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
     u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
     int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), pos = (int)uni((uint32_t)st.pos);
     int len = (int)uni((uint32_t)st.len), dist = 0;
+    const int din = (int)uni((uint32_t)st.dist);   // != 0: the match's distance is known (the caller decoded a long distance code): straight to the copy
     const int wb = (int)uni((uint32_t)b.win_base), us2 = (int)uni((uint32_t)(usize - 2));
     const uint32_t lds = uni((uint32_t)(uintptr_t)lut2), ldd = uni((uint32_t)(uintptr_t)dlut), ldo = uni((uint32_t)(uintptr_t)obuf);
     const u64 ob = ((u64)uni((uint32_t)((uintptr_t)out >> 32)) << 32) | uni((uint32_t)(uintptr_t)out);
@@ -293,13 +294,15 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_mov_b32 s56, %[ldd]\n"
         "\ts_mov_b64 s[60:61], %[ob]\n"
         "\ts_mov_b32 s65, %[obuf]\n"
-        "\ts_mov_b32 s52, 0\n"
+        "\ts_mov_b32 s52, %[din]\n"
         "\ts_mov_b32 s64, 0\n"
         "\ts_mov_b32 s57, 0x7fffffff\n"
         "\ts_sub_i32 s67, s53, s44\n"
         "\ts_min_i32 s67, s67, 128\n"
         "\tv_add_u32 %[vslot], s65, %[lane4]\n"
         "\ts_mov_b64 exec, 3\n"
+        "\ts_cmp_lg_u32 s52, 0\n"
+        "\ts_cbranch_scc1 47f\n"
         "\ts_cmp_lg_u32 s51, 0\n"
         "\ts_cbranch_scc1 4f\n"
         // ---- between symbols: room for two more literals in buffer and block?
@@ -364,6 +367,7 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
         "\ts_sub_i32 s42, s42, s47\n"
         // ---- invalid: a source in front of the block's output, output beyond the block's size
+        "47:\n"
         "\ts_add_i32 s47, s44, s64\n"
         "\ts_cmp_gt_u32 s52, s47\n"
         "\ts_cbranch_scc1 85f\n"
@@ -582,7 +586,7 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_mov_b32 %[reason], s50"
         : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [len] "+s"(len), [dist] "+s"(dist),
           [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [ve] "=&v"(ve), [vslot] "=&v"(vslot), [vsrc] "=&v"(vsrc), [e] "=s"(ee), [reason] "=s"(reason)
-        : [wb] "s"(wb), [us2] "s"(us2), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lh] "v"(lh), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
+        : [wb] "s"(wb), [us2] "s"(us2), [din] "s"(din), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lh] "v"(lh), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
         : "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",
           "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "m0", "scc", "vcc", "memory");
     b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.len = len; st.dist = dist; st.e = ee;
@@ -761,17 +765,14 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             if (st.pos + st.ns > usize) return false;
             flush();   // (sym_run_ob knows no pending literals)
             const int why = sym_run_ob(b, lut2, dlut, obuf, out, usize, st);
+            if (why != 4) st.dist = 0;   // (a distance handed in was used; 4 hands the match back: len, dist)
             if (why == 2) { b.refill(); continue; }              // (with st.len set it resumes in the distance half)
             if (why == 5) return false;
-            if (why == 4) { copy(st.len, st.dist); st.len = 0; continue; }
+            if (why == 4) { copy(st.len, st.dist); st.len = 0; st.dist = 0; continue; }
             if (why == 3) {   // a distance code the direct table does not hold (longer than 8 bits, or none): the lane method judges it
                 const int ds = decode_sym(b, dd, sym_d);
                 if (ds < 0 || ds > 29) return false;
-                const int dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));
-                if (dist > st.pos + st.ns || st.pos + st.ns + st.len > usize) return false;
-                flush();
-                copy(st.len, dist);
-                st.len = 0;
+                st.dist = (int)(rdlane(dbase, ds) + b.take((int)rdlane(dext, ds)));   // sym_run_ob goes on with the copy (and its checks)
                 continue;
             }
             // why == 0: end of block, a literal / length code longer than the table's index, or no code at all;
