@@ -1143,6 +1143,21 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_order(int n, const uint8_t*
     if (c < n) order[base[key] + s_at[key] + mine] = (uint32_t)c;
 }
 
+static __global__ void k_gz_job0(Job* jobs, u64 start) { jobs[0] = Job{start, 1, 0}; }   // (job 0 = the piece's exact start)
+
+// FIND + ORDER of a piece on `st`: jobs[0] must be set; order_buf = [bins][cursor][order n_chunks][keys n_chunks].  Returns the order array.
+static inline const uint32_t* launch_find(hipStream_t st, const Args& a, void* order_buf, int n_chunks) {
+    hipLaunchKernelGGL(k_gz_find, dim3((unsigned)((n_chunks + WAVES - 1) / WAVES)), dim3(BLOCK), 0, st, a);
+    uint32_t* bins = (uint32_t*)order_buf;
+    uint32_t* order = bins + 2 * ORDER_BINS;
+    uint8_t* keys = (uint8_t*)(order + n_chunks);
+    (void)hipMemsetAsync(bins, 0, 2 * ORDER_BINS * 4, st);
+    const unsigned g1 = (unsigned)((n_chunks + BLOCK - 1) / BLOCK);
+    hipLaunchKernelGGL(k_gz_span, dim3(g1), dim3(BLOCK), 0, st, (const Job*)a.jobs, n_chunks, keys, bins);
+    hipLaunchKernelGGL(k_gz_order, dim3(g1), dim3(BLOCK), 0, st, n_chunks, (const uint8_t*)keys, (const uint32_t*)bins, bins + ORDER_BINS, order);
+    return order;
+}
+
 // ---- CHAIN: the window behind every chain chunk; its tail (the last <= 32 KiB) goes out final ---------------------------------------
 // The window behind chunk i is a function of the window in front of it: new[k] = a byte the chunk wrote, or old[index] where it
 // wrote a marker.  Such functions compose (a table of 32768 symbols whose markers point into the OLDER window), so the chain
@@ -1405,10 +1420,16 @@ struct bzq_gzip {
     int32_t chunk_bytes = 16384;        // CH: one decoder wave per this many compressed bytes (zlib closes a block every ~20 KiB of FASTQ output stream)
     // device
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf comp[2], jobs, outs, order, pool, page_next, counters, events, items, crcs, win[2], chain_maps, chain_wins;
+    Buf comp[2], jobs[2], outs, order[2], counters2, pool, page_next, counters, events, items, crcs, win[2], chain_maps, chain_wins;
     Buf h_outs, h_events, h_pages, h_items, h_crcs;   // pinned host staging
     uint32_t pool_pages = 0;
     int wcur = 0;                       // win[wcur]: the 32 KiB of output in front of the next piece
+    // the NEXT piece's block finder, launched (on find_stream) the moment this piece's chain is known -- its carry is then
+    // known too -- so that it runs under this piece's chain / resolve / CRC kernels and the host work between them
+    struct Pre { bool valid = false; const uint8_t* src = nullptr; uint64_t n_new = 0, nc = 0; unsigned long long start_pos = 0; int jb = 0, cb = 0; } pre;
+    int jlast = 1;                      // which of jobs[] / order[] the last decode used
+    hipStream_t find_stream = nullptr;
+    hipEvent_t pre_ev = nullptr, pre_copy_ev = nullptr;
     // pieces on their way to the device while the one in front of them is decoded (bzq_gzip_stage): comp[b] holds one
     // STAGE_RESERVE bytes in, so that the bytes carried over from the piece in front can be put before it
     struct StagedPiece { const uint8_t* src; uint64_t n; int buf; };
@@ -1475,8 +1496,10 @@ inline void gz_free(bzq_gzip* h) {
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
+    if (h->find_stream) { (void)hipStreamSynchronize(h->find_stream); (void)hipStreamDestroy(h->find_stream); }
+    for (hipEvent_t e : {h->pre_ev, h->pre_copy_ev}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->staged_ev) if (e) (void)hipEventDestroy(e);
-    for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->order, &h->jobs, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
+    for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->order[0], &h->order[1], &h->jobs[0], &h->jobs[1], &h->counters2, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
         if (b->p) (void)hipFree(b->p);
     for (bzq_gzip::Buf* b : {&h->h_outs, &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs})
         if (b->p) (void)hipHostFree(b->p);
@@ -1491,13 +1514,14 @@ inline int gz_open(int device, bzq_gzip** out, std::string& err) {
     h->device = device;
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { err = "bzq_gzip_open: hipStreamCreate failed"; delete h; return BZQ_ERR_HIP; }
     h->stream = h->own_stream;
-    if (hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[0], hipEventDisableTiming) != hipSuccess ||
+    if (hipStreamCreateWithFlags(&h->find_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->pre_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->pre_copy_ev, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->staged_ev[1], hipEventDisableTiming) != hipSuccess) {
         err = "bzq_gzip_open: hipStreamCreate failed"; gz_free(h); return BZQ_ERR_HIP;
     }
     int rc;
-    if ((rc = gz_ensure(h, h->win[0], 32768)) || (rc = gz_ensure(h, h->win[1], 32768)) || (rc = gz_ensure(h, h->counters, 128))) { err = h->err; gz_free(h); return rc; }
-    if (hipMemsetAsync(h->win[0].p, 0, 32768, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { err = "bzq_gzip_open: hipMemset failed"; gz_free(h); return BZQ_ERR_HIP; }
+    if ((rc = gz_ensure(h, h->win[0], 32768)) || (rc = gz_ensure(h, h->win[1], 32768)) || (rc = gz_ensure(h, h->counters, 128)) || (rc = gz_ensure(h, h->counters2, 128))) { err = h->err; gz_free(h); return rc; }
+    if (hipMemsetAsync(h->counters2.p, 0, 128, h->stream) != hipSuccess || hipMemsetAsync(h->win[0].p, 0, 32768, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { err = "bzq_gzip_open: hipMemset failed"; gz_free(h); return BZQ_ERR_HIP; }
     h->start_pos = pos_header(0);
     for (uint64_t len : {1ull, 4097ull, (unsigned long long)CRC_SEG})   // (the combine above against zlib's, once)
         if ((crc_mul(crc_xpow8(len), 0x12345678u) ^ 0x9ABCDEF0u) != (uint32_t)crc32_combine(0x12345678u, 0x9ABCDEF0u, (z_off_t)len)) { err = "bzq_gzip_open: internal: CRC combine self-check failed"; gz_free(h); return BZQ_ERR_HIP; }
@@ -1588,13 +1612,23 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     }
     struct Release { bzq_gzip* h; int b; ~Release() { std::lock_guard<std::mutex> lk(h->stage_mu); h->comp_busy[b] = false; } } release{h, cb};
     if (!use_staged) GZCHK(h, hipEventSynchronize(h->staged_ev[cb]));   // (whatever was last staged into it has arrived)
-    if ((rc = gz_ensure(h, h->order, (size_t)2 * ORDER_BINS * 4 + (size_t)n_chunks * 5 + 64)) || (!use_staged && (rc = gz_ensure(h, h->comp[cb], n + 64))) || (rc = gz_ensure(h, h->jobs, (size_t)n_jobs_cap * sizeof(Job))) ||
+    // was this piece's finder launched under the piece in front (same bytes, same carry, same start)?
+    bool prefound = false;
+    if (h->pre.valid) {
+        prefound = use_staged && h->pre.src == src && h->pre.n_new == n_new && h->pre.nc == nc && h->pre.start_pos == h->start_pos && h->pre.cb == cb;
+        if (!prefound) GZCHK(h, hipStreamSynchronize(h->find_stream));   // (not this piece after all: its buffers are free again once it is done)
+        h->pre.valid = false;
+    }
+    const int jb = prefound ? h->pre.jb : (h->jlast ^ 1);
+    h->jlast = jb;
+    if ((rc = gz_ensure(h, h->order[jb], (size_t)2 * ORDER_BINS * 4 + (size_t)n_chunks * 5 + 64)) || (!use_staged && (rc = gz_ensure(h, h->comp[cb], n + 64))) || (rc = gz_ensure(h, h->jobs[jb], (size_t)n_jobs_cap * sizeof(Job))) ||
         (rc = gz_ensure(h, h->outs, (size_t)n_jobs_cap * sizeof(JobOut))) || (rc = gz_ensure(h, h->events, (size_t)max_events * sizeof(Event))) ||
         (rc = gz_ensure(h, h->h_outs, (size_t)n_jobs_cap * sizeof(JobOut) + 128, true)))
         return rc;
     uint8_t* d_comp = (uint8_t*)h->comp[cb].p + (use_staged ? STAGE_RESERVE - nc : 0);
     // (the carry is pageable memory; the vector is not touched before the stream has been waited for, further down)
-    if (nc) GZCHK(h, hipMemcpyAsync(d_comp, h->carry.data(), nc, hipMemcpyHostToDevice, s));
+    if (prefound) GZCHK(h, hipStreamWaitEvent(s, h->pre_ev, 0));   // (the carry is in place, device to device, and the finder has run)
+    else if (nc) GZCHK(h, hipMemcpyAsync(d_comp, h->carry.data(), nc, hipMemcpyHostToDevice, s));
     if (use_staged) GZCHK(h, hipStreamWaitEvent(s, h->staged_ev[cb], 0));
     else {
         if (n_new) GZCHK(h, hipMemcpyAsync(d_comp + nc, src, n_new, hipMemcpyHostToDevice, s));
@@ -1618,20 +1652,12 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         GZCHK(h, hipMemsetAsync(h->counters.p, 0, 128, s));
         static const uint32_t counting = getenv("BZQ_GZ_COUNT") ? (uint32_t)atoi(getenv("BZQ_GZ_COUNT")) : 0u;   // debug: 1 = survivor / hand-back counts (atomics in the loops: not for timing), 2 = the finder's clocks
         if (counting) GZCHK(h, hipMemcpyAsync((uint32_t*)h->counters.p + 7, &counting, 4, hipMemcpyHostToDevice, s));
-        GZCHK(h, hipMemcpyAsync(h->jobs.p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
-        a = Args{d_comp, (int64_t)n, (Job*)h->jobs.p, (JobOut*)h->outs.p, 0, n_chunks, n_chunks, CH, (uint16_t*)h->pool.p, h->pool_pages,
+        a = Args{d_comp, (int64_t)n, (Job*)h->jobs[jb].p, (JobOut*)h->outs.p, 0, n_chunks, n_chunks, CH, (uint16_t*)h->pool.p, h->pool_pages,
                  (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events, max_job, (int64_t)std::max<uint64_t>(out_cap, 1ull << 20)};
-        const unsigned grid = (unsigned)((n_chunks + WAVES - 1) / WAVES);
-        hipLaunchKernelGGL(k_gz_find, dim3(grid), dim3(BLOCK), 0, s, a);
-        {   // [bins][cursor][order n_chunks][keys n_chunks]
-            uint32_t* bins = (uint32_t*)h->order.p;
-            uint32_t* order = bins + 2 * ORDER_BINS;
-            uint8_t* keys = (uint8_t*)(order + n_chunks);
-            GZCHK(h, hipMemsetAsync(bins, 0, 2 * ORDER_BINS * 4, s));
-            const unsigned g1 = (unsigned)((n_chunks + BLOCK - 1) / BLOCK);
-            hipLaunchKernelGGL(k_gz_span, dim3(g1), dim3(BLOCK), 0, s, (const Job*)h->jobs.p, n_chunks, keys, bins);
-            hipLaunchKernelGGL(k_gz_order, dim3(g1), dim3(BLOCK), 0, s, n_chunks, (const uint8_t*)keys, (const uint32_t*)bins, bins + ORDER_BINS, order);
-            a.order = order;
+        if (prefound && attempt == 0) a.order = (const uint32_t*)h->order[jb].p + 2 * ORDER_BINS;   // (found and ordered under the piece in front)
+        else {
+            GZCHK(h, hipMemcpyAsync(h->jobs[jb].p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
+            a.order = launch_find(s, a, h->order[jb].p, n_chunks);
         }
         if (timing) { GZCHK(h, hipStreamSynchronize(s)); lap(1); }
         hipLaunchKernelGGL(k_gz_decode, dim3((unsigned)n_chunks), dim3(DEC_BLOCK), 0, s, a);
@@ -1670,8 +1696,8 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
             // serially; after MAX_FALLBACK restarts the call hands over what it has (*more).
             if (fallbacks == MAX_FALLBACK) { final_status = ST_SPLIT; final_pos = o.end; break; }
             const int k = n_chunks + fallbacks++;
-            const Job jb{o.end, (int32_t)std::min<uint64_t>((uint64_t)n_chunks, (o.end >> 4) / (uint64_t)CH), 0};
-            GZCHK(h, hipMemcpyAsync((Job*)h->jobs.p + k, &jb, sizeof jb, hipMemcpyHostToDevice, s));
+            const Job jfb{o.end, (int32_t)std::min<uint64_t>((uint64_t)n_chunks, (o.end >> 4) / (uint64_t)CH), 0};
+            GZCHK(h, hipMemcpyAsync((Job*)h->jobs[jb].p + k, &jfb, sizeof jfb, hipMemcpyHostToDevice, s));
             a.job_base = k; a.n_jobs = 1; a.order = nullptr;
             hipLaunchKernelGGL(k_gz_decode, dim3(1), dim3(DEC_BLOCK), 0, s, a);
             GZCHK(h, hipMemcpyAsync(outs + k, (JobOut*)h->outs.p + k, sizeof(JobOut), hipMemcpyDeviceToHost, s));
@@ -1707,6 +1733,33 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
             return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: out_capacity (" + std::to_string(out_cap) + ") is below the output of one run of blocks (" + std::to_string(outs[chain[0]].out_syms) + ")");
         final_pos = outs[chain[accepted]].start; final_status = ST_TARGET;
         *more = 1;
+    }
+
+    // ---- the NEXT piece's finder, now: its carry is what this piece leaves behind final_pos, and that is known.  It runs on its
+    // own stream under this piece's chain / resolve / CRC kernels (3 of a piece's 17 ms of kernels were the finder's).
+    if (!*more && !is_last && (final_status == ST_NEED_MORE || final_status == ST_END_INPUT)) {
+        const uint8_t* src2 = nullptr; uint64_t n2 = 0; int cb2 = -1;
+        { std::lock_guard<std::mutex> lk(h->stage_mu); if (!h->staged.empty()) { src2 = h->staged.front().src; n2 = h->staged.front().n; cb2 = h->staged.front().buf; } }
+        const uint64_t keep2 = (uint64_t)(final_pos >> 4);
+        if (cb2 >= 0 && keep2 <= n && n - keep2 <= STAGE_RESERVE && n - keep2 + n2 <= (1ull << 33)) {
+            const uint64_t nc2 = n - keep2, nn = nc2 + n2;
+            const int nch2 = (int)((nn + (uint64_t)CH - 1) / (uint64_t)CH), jn = jb ^ 1;
+            if ((rc = gz_ensure(h, h->order[jn], (size_t)2 * ORDER_BINS * 4 + (size_t)nch2 * 5 + 64)) || (rc = gz_ensure(h, h->jobs[jn], (size_t)(nch2 + MAX_FALLBACK) * sizeof(Job)))) return rc;
+            uint8_t* d2 = (uint8_t*)h->comp[cb2].p + STAGE_RESERVE - nc2;
+            const hipStream_t fs = h->find_stream;
+            GZCHK(h, hipStreamWaitEvent(fs, h->staged_ev[cb2], 0));
+            if (nc2) GZCHK(h, hipMemcpyAsync(d2, d_comp + keep2, nc2, hipMemcpyDeviceToDevice, fs));
+            GZCHK(h, hipEventRecord(h->pre_copy_ev, fs));
+            const unsigned long long start2 = (final_pos & 1ull) ? pos_header(0) : pos_deflate((final_pos >> 1) & 7ull);
+            hipLaunchKernelGGL(k_gz_job0, dim3(1), dim3(1), 0, fs, (Job*)h->jobs[jn].p, (u64)start2);
+            Args a2{};
+            a2.comp = d2; a2.n = (int64_t)nn; a2.jobs = (Job*)h->jobs[jn].p; a2.n_jobs = nch2; a2.n_cand = nch2; a2.chunk_bytes = CH; a2.counters = (uint32_t*)h->counters2.p;
+            (void)launch_find(fs, a2, h->order[jn].p, nch2);
+            GZCHK(h, hipGetLastError());
+            GZCHK(h, hipEventRecord(h->pre_ev, fs));
+            GZCHK(h, hipEventSynchronize(h->pre_copy_ev));   // (this piece's buffer is given back when the call returns: the carry has left it)
+            h->pre.valid = true; h->pre.src = src2; h->pre.n_new = n2; h->pre.nc = nc2; h->pre.start_pos = start2; h->pre.jb = jn; h->pre.cb = cb2;
+        }
     }
 
     // ---- members that ended inside the accepted part: (position in the output, trailer in the piece)
