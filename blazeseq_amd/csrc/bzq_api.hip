@@ -1752,7 +1752,7 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
     uint8_t magic[18] = {0};
     const bool gzip_magic = g->file_size >= 18 && pread(fd, magic, 18, 0) == 18 && magic[0] == 0x1f && magic[1] == 0x8b;
     const bool gz_on_device = gzip_magic && !bzq::bgzf_block_size(magic) && gpu_inflate;
-    if (gz_on_device) g->gz_piece = g->chunk_bytes;   // (compressed bytes per decoder call: ~13 000 decoder waves per 256 MiB, twice what the device holds at once -- with half of that the per-call costs weighed double)
+    if (gz_on_device) g->gz_piece = std::max<uint64_t>(g->chunk_bytes / 2, std::min<uint64_t>(g->chunk_bytes, 64ull << 10));   // (compressed bytes per decoder call.  A whole chunk per call was tried: +5 % on the benchmark's 2x compressible FASTQ, -25 % on 6x compressible sequencer-like FASTQ, whose output of one call then overflows the FIFO and is cut)
     bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess;
     if (ok) {   // the slots side by side: pinning a chunk-sized buffer takes ~30 ms, and three of them one after the other were most of an open
         bool slot_ok[bzq::INGEST_SLOTS];

@@ -26,7 +26,8 @@
 //      walked serially; RESOLVE (k_gz_resolve, one workgroup per page): every symbol to its byte, contiguous in the caller's
 //      buffer; CRC (k_gz_crc): CRC-32 of every MiB of every member, combined on the host and checked against the member
 //      trailers together with ISIZE.
-//   The NEXT piece's copy to the device runs under all of this (gz_stage).
+//   The NEXT piece's copy to the device runs under all of this (gz_stage), and its FIND under the chain / resolve / CRC of this
+//   one: the finder needs the piece's bytes and its carry, and the carry is known as soon as this piece's chain is.
 //
 // Correctness does not rest on the speculation: the chain starts at an exact position and only ever follows exact ends, so
 // what is delivered is the sequential decode; a chunk the chain never lands on is ignored.  Streams that defeat the

@@ -419,7 +419,8 @@ int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value);
 int32_t bzq_gzip_decode(bzq_gzip* h, const uint8_t* comp, uint64_t n, int32_t is_last, uint8_t* d_out, uint64_t out_capacity,
                         uint64_t* out_bytes, int32_t* more);
 /* Optional read-ahead: a piece that a LATER bzq_gzip_decode will be given starts its way to the device now; the
- * bzq_gzip_decode that gets the same (comp, n) finds it there instead of copying.  comp: pinned host memory, untouched until
+ * bzq_gzip_decode that gets the same (comp, n) finds it there instead of copying -- and, when it is the piece right behind the
+ * one being decoded, with its block finder already run (that starts as soon as the decode in front knows what it leaves over).  comp: pinned host memory, untouched until
  * that call has returned.  Up to two pieces can be outstanding (the one being decoded counts); with both taken the call does
  * nothing.  Pieces are taken in the order staged.  May be called from a second thread while bzq_gzip_decode runs.  A negative
  * return only says that nothing was staged (the piece is then copied by its bzq_gzip_decode); bzq_gzip_last_error is not set. */
