@@ -1752,14 +1752,14 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
     uint8_t magic[18] = {0};
     const bool gzip_magic = g->file_size >= 18 && pread(fd, magic, 18, 0) == 18 && magic[0] == 0x1f && magic[1] == 0x8b;
     const bool gz_on_device = gzip_magic && !bzq::bgzf_block_size(magic) && gpu_inflate;
-    if (gz_on_device) g->gz_piece = std::max<uint64_t>(g->chunk_bytes / 2, std::min<uint64_t>(g->chunk_bytes, 64ull << 10));   // (compressed bytes per decoder call.  A whole chunk per call was tried: +5 % on the benchmark's 2x compressible FASTQ, -25 % on 6x compressible sequencer-like FASTQ, whose output of one call then overflows the FIFO and is cut)
+    if (gz_on_device) g->gz_piece = std::max<uint64_t>(g->chunk_bytes / 2, std::min<uint64_t>(g->chunk_bytes, 64ull << 10));   // (the first pieces; then by the file's compression ratio, up to a chunk: gz_fill_fifo)
     bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess;
     if (ok) {   // the slots side by side: pinning a chunk-sized buffer takes ~30 ms, and three of them one after the other were most of an open
         bool slot_ok[bzq::INGEST_SLOTS];
         std::thread th[bzq::INGEST_SLOTS];
         for (int i = 0; i < bzq::INGEST_SLOTS; ++i)
             th[i] = std::thread([g, i, device, gz_on_device, &slot_ok]() {
-                slot_ok[i] = hipSetDevice(device) == hipSuccess && bzq::ingest_alloc_slot(g, i, gz_on_device ? (i < 2 ? g->gz_piece : 0) : g->chunk_bytes);
+                slot_ok[i] = hipSetDevice(device) == hipSuccess && bzq::ingest_alloc_slot(g, i, gz_on_device && i == 2 ? 0 : g->chunk_bytes);   // (a .gz on the device reads compressed pieces into two of the slots)
             });
         for (int i = 0; i < bzq::INGEST_SLOTS; ++i) { th[i].join(); ok = ok && slot_ok[i]; }
     }

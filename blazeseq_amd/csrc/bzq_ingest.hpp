@@ -73,7 +73,7 @@ struct bzq_ingest {
     uint64_t gz_cap = 0, gz_have = 0, gz_off = 0;   // capacity, bytes waiting, file offset of the next compressed byte
     bool gz_more = false, gz_done = false;
     // read-ahead: while piece k is decoded, helper threads read piece k + 1 into the other slot's pinned buffer
-    uint64_t gz_piece = 0;             // compressed bytes per piece
+    uint64_t gz_piece = 0;             // compressed bytes per piece: starts at half a chunk, then follows the file's compression ratio (gz_fill_fifo)
     std::thread gz_reader;
     bool gz_read_pending = false, gz_read_ok = true;
     int gz_read_buf = 0;               // which pinned buffer the pending / last read went to
@@ -342,6 +342,16 @@ inline bool gz_fill_fifo(bzq_ingest* g, std::string& err) {
         int32_t more = 0;
         if (bzq::gz::gz_decode(g->gz_dev, src, want, file_done, g->gz_fifo[g->gz_cur] + g->gz_have, free_bytes, &got, &more) < 0) { err = g->gz_dev->err; return false; }
         g->gz_have += got;
+        // the pieces to come: as large as half the FIFO takes decoded (the decode kernel works in rounds of ~6 000 decoder
+        // waves: 256 MiB of 2 x compressible FASTQ are 13 000, 128 MiB one round and a bit, which costs a sixth of the rate), at
+        // most a chunk (the pinned buffers' size) -- a file that compresses 6 x keeps its pieces of 128 MiB and does not overflow the FIFO
+        static const bool fixed_piece = getenv("BZQ_GZ_FIXED_PIECE") != nullptr;   // A/B switch: pieces stay half a chunk
+        if (fixed_piece) {}
+        else if (want && got && !more) {
+            const double ratio = (double)got / (double)want;
+            const uint64_t fit = (uint64_t)((double)(g->gz_cap / 2) / (ratio > 1.0 ? ratio : 1.0)) & ~4095ull;
+            g->gz_piece = std::min<uint64_t>(g->chunk_bytes, std::max<uint64_t>(fit, std::min<uint64_t>(g->chunk_bytes, 1ull << 20)));
+        } else if (more && g->gz_piece > (2ull << 20)) g->gz_piece = (g->gz_piece / 2) & ~4095ull;
         g->gz_more = more != 0;
         g->gz_done = (file_done && !more) || g->gz_dev->finished;
         if (!got && !want && !more && !g->gz_done) { err = "gzip: the decoder made no progress"; return false; }
