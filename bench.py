@@ -162,7 +162,7 @@ def inflate_mode(ctx, shard, rec_bytes, dev):
     k = (32 << 20) // rec_bytes * rec_bytes
     d_plain = shard[:k]
     plain = d_plain.cpu().numpy().tobytes()
-    reps = 16
+    reps = 48   # 1.6 GB of FASTQ per decode: the decoders work in rounds of ~6 000 waves, and 0.5 GB was one round and a bit
     out = torch.empty(reps * k + (1 << 20), dtype=torch.uint8, device=dev)
     res = {}
     # (a) gzip: one member per copy of the slice
@@ -174,8 +174,8 @@ def inflate_mode(ctx, shard, rec_bytes, dev):
         dec = B.GzipDecoder(ctx)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        # the file in pieces of 128 MiB, the next piece on its way to the device while this one is decoded (bzq_gzip_stage)
-        host, piece, got, off = pin.numpy(), 128 << 20, 0, 0
+        # the file in pieces of 256 MiB, the next piece on its way to the device while this one is decoded (bzq_gzip_stage)
+        host, piece, got, off = pin.numpy(), 256 << 20, 0, 0
         dec.stage(host[:piece])
         while off < host.size:
             part = host[off:off + piece]
@@ -196,7 +196,7 @@ def inflate_mode(ctx, shard, rec_bytes, dev):
     assert bool((out[:reps * k].view(reps, k) == d_plain.unsqueeze(0)).all()), "gzip: device output differs from the FASTQ"
     res["gzip"] = {"value": round(reps * k / best / 1e9, 3), "unit": "GB/s of FASTQ", "ms": round(best * 1e3, 2), "compressed_mb": round(len(member) * reps / 1e6, 1),
                    "decoder_runs_in_output": int(st.chain_jobs), "restarts": int(st.fallback_jobs),
-                   "note": f"{reps} members of gzip -6 (zlib) in pinned host memory -> bzq_gzip_decode in 128 MiB pieces (the next one staged meanwhile) -> device, verified; the reference's GZFile way (zlib gzread, one host core): ~0.35 GB/s"}
+                   "note": f"{reps} members of gzip -6 (zlib) in pinned host memory -> bzq_gzip_decode in 256 MiB pieces (the next one staged meanwhile) -> device, verified; the reference's GZFile way (zlib gzread, one host core): ~0.35 GB/s"}
     del pin
     # (b) BGZF: 65280-byte blocks
     def block(data):
