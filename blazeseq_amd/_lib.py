@@ -189,6 +189,7 @@ SYMBOLS = {
     "bzq_chunk_result": (C.c_int32, [C.c_void_p, C.POINTER(BzqChunk)]),
     "bzq_batch_view": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(BzqDeviceBatch)]),
     "bzq_batches": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(BzqDeviceBatch), C.c_uint64, C.POINTER(C.c_uint64)]),
+    "bzq_chunk_cumulative_ends": (C.c_int32, [C.c_void_p, C.POINTER(BzqChunk)]),
     "bzq_views": (C.c_int32, [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(BzqDeviceViews)]),
     "bzq_batch_to_host": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.POINTER(BzqHostBatch)]),
     "bzq_copy_to_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

@@ -125,9 +125,23 @@ struct bzq_ctx {
     bool ran_single_pass = false;
     int ingest_gpu_inflate = 1;               // option "ingest_gpu_inflate": BGZF blocks are inflated on the device (bzq_inflate.hpp), 0 = on the reader threads
     int ingest_direct = 0, ingest_numa = 1;   // options "ingest_direct" (O_DIRECT reads), "ingest_numa" (bind readers to the GPU's node)
+    // option "fold_rebase" (default 1): the emit kernel writes the per-batch ends and does the record-length check itself, from the
+    // batch bases k_batch_bases computes between the scan and the emit (FusedArgs::fold) -- no pass over the per-record arrays
+    int fold_opt = 1;
+    bool fold = false;         // ... decided per chunk (decide_fold)
+    bool cum_valid = false;    // the current chunk's chunk-cumulative ends / id_ends hold values (always without fold; with it: after bzq_chunk_cumulative_ends)
+    bool finish_done = false;  // k_tail of this submit already left the chunk totals (enqueue_rebase skips k_finish once)
+    DevBuf tile_last, tileB, btile;
     int pass_a_h = 1;          // option "pass_a_h": pass A from the newline bitmap alone (k_tile_aggregate_h), verified by the emit
     bool exact_pass_a = false; // this chunk is being repeated with the exact pass A
     bool used_h = false;
+    // The hypothesis of k_tile_aggregate_h ("no id loses bytes to _strip_spaces") is a property of the FILE, not of a chunk: a CRLF
+    // file strips a '\r' from every id, and trying the hypothesis on each of its chunks parses every chunk twice.  After a
+    // contradiction the following exact_sticky submits go straight to the exact pass A (16, then doubling up to 1024 each time
+    // the retried hypothesis fails again); option "pass_a_sticky" = 0 restores the per-chunk retry.
+    int sticky_opt = 1;
+    int exact_sticky = 0, exact_sticky_len = 0;
+    int64_t hyp_contradictions = 0;
     int use_stream = 0;        // option "stream" (EXPERIMENTS build): batch mode through the single-read kernel k_stream
     bool ran_stream = false;
     int64_t stream_fallbacks = 0;
@@ -213,7 +227,8 @@ int ensure_tile_arenas(bzq_ctx* c, uint64_t n) {
         if ((rc = ensure(c, c->tile_c, nt * 4)) || (rc = ensure(c, c->tile_a, nt * 8)) ||
             (rc = ensure(c, c->tile_idc, nt * 8)) || (rc = ensure(c, c->tileP, nt * 8)) ||
             (rc = ensure(c, c->tileS, nt * 8)) || (rc = ensure(c, c->tileQ, nt * 8)) ||
-            (rc = ensure(c, c->tileI, nt * 8)) || (rc = ensure(c, c->grp, (nt / SG_TILES + 2) * 80)))
+            (rc = ensure(c, c->tileI, nt * 8)) || (rc = ensure(c, c->grp, (nt / SG_TILES + 2) * 80)) ||
+            (rc = ensure(c, c->tile_last, nt * 8)) || (rc = ensure(c, c->tileB, nt * 4)))
             return rc;
 #if BZQ_EXPERIMENTS
         if ((rc = ensure(c, c->desc, (nt * 6 + (nt / 64 + 2) * 4 + 64) * 8))) return rc;   // single-launch variants only
@@ -326,6 +341,9 @@ EmitArgs make_emit_args(bzq_ctx* c) {
 
 template <bool CA, bool CQ, bool OFFS, bool LB>
 void launch_fused_one(const bzq_ctx* c, dim3 grid, const FusedArgs& a) {
+    if constexpr (!LB) {
+        if (a.fold) { hipLaunchKernelGGL((k_fused<CA, CQ, OFFS, false, true>), grid, dim3(BLOCK), 0, c->stream, a); return; }
+    }
     hipLaunchKernelGGL((k_fused<CA, CQ, OFFS, LB>), grid, dim3(BLOCK), 0, c->stream, a);
 }
 template <bool CA, bool CQ, bool LB>
@@ -357,7 +375,84 @@ FusedArgs make_fused_args(bzq_ctx* c) {
     f.st = c->d_state; f.q_lower = c->cfg.q_lower; f.q_upper = c->cfg.q_upper; f.force_dense = c->force_dense; f.ablate = c->ablate;
     f.walk_limit = walk_limit_of(c);
     f.check_h = c->used_h ? 1 : 0;
+    if (c->fold) {
+        f.fold = 1;
+        f.b_ends = (int64_t*)c->o().b_ends.p; f.b_id_ends = (int64_t*)c->o().b_id_ends.p;
+        f.bb = (const int64_t*)c->o().bb.p; f.bb_cap = c->o().bb_cap;
+        f.tileB = (const int32_t*)c->tileB.p; f.tile_last = (const u64*)c->tile_last.p;
+        f.batch = c->cfg.batch_size; f.first_header = c->cur_first_header;
+        f.len_limit = c->cfg.buffer_growth_enabled ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity;
+    }
     return f;
+}
+
+// The batch-boundary table of the current output set (bzq_batch_view's host cache; with fold also the emit's batch bases): only
+// while it stays small -- batch sizes of a few records on a huge chunk fall back to per-view copies.
+void ensure_bb(bzq_ctx* c) {
+    const int64_t nb_max = c->o().rec_cap / std::max<int64_t>(1, c->cfg.batch_size) + 2;
+    int64_t* bb = nullptr;
+    if (nb_max <= BB_MAX_BATCHES && ensure(c, c->o().bb, (size_t)nb_max * 16) == 0) bb = (int64_t*)c->o().bb.p;
+    c->o().bb_cap = bb ? nb_max : 0;
+}
+
+// Chunk-cumulative ends / id_ends at record r of the current chunk, on the host (cold paths: a stream cut short by an error, a
+// batch view that is not batch aligned).  With fold the emit wrote only the per-batch arrays: value + the batch's base.
+int cum_pair(bzq_ctx* c, int64_t r, int64_t out[2]) {
+    const OutSet& o = c->o();
+    if (!c->fold || c->cum_valid) {
+        HIPCHK(c, hipMemcpy(&out[0], (const int64_t*)o.ends.p + r, 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&out[1], (const int64_t*)o.id_ends.p + r, 8, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    const int64_t k = r / std::max<int64_t>(1, c->cfg.batch_size);
+    int64_t base[2] = {0, 0};
+    HIPCHK(c, hipMemcpy(&out[0], (const int64_t*)o.b_ends.p + r, 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(&out[1], (const int64_t*)o.b_id_ends.p + r, 8, hipMemcpyDeviceToHost));
+    if (k > 0) HIPCHK(c, hipMemcpy(base, (const int64_t*)o.bb.p + 2 * (k - 1), 16, hipMemcpyDeviceToHost));
+    out[0] += base[0]; out[1] += base[1];
+    return 0;
+}
+
+// Can this chunk go without k_rebase?  One pass over the chunk (the bases of a later sub-chunk pass are not known when an
+// earlier one is emitted), at most one batch boundary per fast-path tile, no host-SIMD-width quirk of the quality check
+// (that one reads the quality bytes per record), and the table fits.
+void decide_fold(bzq_ctx* c) {
+    c->fold = false;
+    if (!c->fold_opt || !c->v2 || c->cfg.views_only || c->ran_single_pass || c->ran_stream || c->overlap || c->cur_n == 0) return;
+    if (tiles_for(c->cur_n) > pass_tiles(c)) return;
+    if ((int64_t)c->cfg.batch_size < FOLD_MIN_BATCH) return;
+    if (c->cfg.check_quality && c->cfg.compat_simd_width != 0) return;
+    ensure_bb(c);
+    c->fold = c->o().bb_cap > 0 && ensure(c, c->btile, (size_t)c->o().bb_cap * 8) == 0;
+}
+
+// the per-record outputs of an accepted unterminated last record (parser.mojo:464-475): the columns already hold its bytes
+void launch_fix_last(bzq_ctx* c, int64_t rec, int64_t n, int64_t batch) {
+    if (c->fold && !c->cum_valid)
+        hipLaunchKernelGGL(k_fix_last_b, dim3(1), dim3(64), 0, c->stream, rec, n, batch, (int64_t*)c->o().rec_end.p, (int64_t*)c->o().b_ends.p,
+                           (int64_t*)c->o().b_id_ends.p, (int64_t*)c->o().bb.p, c->o().bb_cap, (const ChunkState*)c->d_state);
+    else
+        hipLaunchKernelGGL(k_fix_last, dim3(1), dim3(64), 0, c->stream, rec, n, batch, (int64_t*)c->o().ends.p, (int64_t*)c->o().id_ends.p,
+                           (int64_t*)c->o().rec_end.p, (int64_t*)c->o().b_ends.p, (int64_t*)c->o().b_id_ends.p, (const ChunkState*)c->d_state);
+}
+
+ChunkFinishArgs finish_args(bzq_ctx* c, bool on) {
+    ChunkFinishArgs f{};
+    if (on && c->fold) {
+        f.on = 1;
+        f.b_ends = (const int64_t*)c->o().b_ends.p; f.b_id_ends = (const int64_t*)c->o().b_id_ends.p; f.rec_end = (const int64_t*)c->o().rec_end.p;
+        f.batch = std::max<int64_t>(1, c->cfg.batch_size); f.first_header = c->cur_first_header; f.rec_cap = c->o().rec_cap;
+        f.bb = c->o().bb_cap ? (int64_t*)c->o().bb.p : nullptr; f.bb_cap = c->o().bb_cap;
+    }
+    return f;
+}
+
+void launch_batch_bases(bzq_ctx* c) {
+    BasesArgs b{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tiles_for(c->cur_n), (const int64_t*)c->tileP.p, (const int64_t*)c->tileQ.p,
+                (const int64_t*)c->tileI.p, (int64_t)c->cfg.batch_size, (int64_t*)c->o().bb.p, c->o().bb_cap, c->d_state, walk_limit_of(c), (const int64_t*)c->btile.p};
+    // boundaries that can exist: the chunk holds at most n / 4 records of four newlines
+    const int64_t nb = std::min<int64_t>(c->o().bb_cap, (int64_t)(c->cur_n / 4) / std::max<int64_t>(1, c->cfg.batch_size));
+    if (nb > 0) hipLaunchKernelGGL(k_batch_bases, dim3((unsigned)nb), dim3(BLOCK), 0, c->stream, b);
 }
 
 #if BZQ_EXPERIMENTS
@@ -477,7 +572,8 @@ int enqueue_single_launch(bzq_ctx* c) {
 void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, int pass) {
     ScanArgs s{tb, te, (const uint32_t*)c->tile_c.p, (const u64*)c->tile_a.p, (const u64*)c->tile_idc.p,
                (int64_t*)c->tileP.p, (int64_t*)c->tileS.p, (int64_t*)c->tileQ.p, (int64_t*)c->tileI.p,
-               (int64_t*)c->grp.p, c->d_state, pass};
+               (int64_t*)c->grp.p, c->d_state, pass, c->fold ? (int32_t*)c->tileB.p : nullptr, std::max<int64_t>(1, c->cfg.batch_size),
+               c->fold ? (int64_t*)c->btile.p : nullptr, c->fold ? c->o().bb_cap : 0};
     const int64_t ng = (te - tb + SG_TILES - 1) / SG_TILES;
     if (ng <= 0) return;
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)ng), dim3(SG_THREADS), 0, c->stream, s);
@@ -529,7 +625,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
         // shard whose aggregates exist already (bzq_shard_scan): only tile 0 (prev byte now known)
         // and the tiles touched by the appended halo change
         AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, 0, 1, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
-                  (u64*)c->tile_idc.p, walk_limit_of(c)};
+                  (u64*)c->tile_idc.p, walk_limit_of(c), (u64*)c->tile_last.p};
         hipLaunchKernelGGL(k_tile_aggregate2, dim3(1), dim3(BLOCK), 0, c->stream, a);
         const int64_t tb = std::max<int64_t>(1, (int64_t)(c->agg_n / TILE));
         if (tb < nt) {
@@ -544,7 +640,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
             if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
             if (!skip_aggregate_mid) {
                 AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p,
-                          (u64*)c->tile_a.p, (u64*)c->tile_idc.p, walk_limit_of(c)};
+                          (u64*)c->tile_a.p, (u64*)c->tile_idc.p, walk_limit_of(c), (u64*)c->tile_last.p};
                 if (views_meta(c)) {
                     LineArgs la{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
                                 (u64*)c->tile_idc.p, (uint32_t*)c->entries.p, (uint32_t*)c->tile_list.p, c->pool_slots, c->d_state,
@@ -555,12 +651,20 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
 #if BZQ_EXPERIMENTS
                 else if (!c->v2) hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
 #endif
-                else if (c->pass_a_h && !c->exact_pass_a) { hipLaunchKernelGGL(k_tile_aggregate_h, grid, dim3(BLOCK), 0, c->stream, a); c->used_h = true; }
+                else if (c->pass_a_h && !c->exact_pass_a && c->exact_sticky == 0) { hipLaunchKernelGGL(k_tile_aggregate_h, grid, dim3(BLOCK), 0, c->stream, a); c->used_h = true; }
                 else hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
             }
             if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
             launch_scan(c, tb, te, (int)passes);
+            if (c->fold) launch_batch_bases(c);
             if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
+        } else if (c->fold) {
+            // re-run after the per-record arrays were re-sized: the batch table grew with them, so the scan notes the boundary
+            // tiles again (same prefixes as before) and the bases are computed again
+            ensure_bb(c);
+            if (c->o().bb_cap == 0 || ensure(c, c->btile, (size_t)c->o().bb_cap * 8) != 0) { c->err = "batch table after a re-size"; return BZQ_ERR_NOMEM; }
+            launch_scan(c, tb, te, (int)passes);
+            launch_batch_bases(c);
         }
         if (c->cfg.views_only) {
             launch_views(c, grid, tb, te);
@@ -608,17 +712,20 @@ void enqueue_rebase(bzq_ctx* c) {
         hipLaunchKernelGGL(k_views_check, dim3((unsigned)(c->num_cu * 8)), dim3(BLOCK), 0, c->stream, va);
         return;
     }
-    // batch boundaries for bzq_batch_view (host cache): only while the table stays small (batch sizes of a few records on a
-    // huge chunk fall back to per-view copies)
+    // batch boundaries for bzq_batch_view (host cache)
+    if (!c->fold) ensure_bb(c);
     const int64_t nb_max = c->o().rec_cap / std::max<int64_t>(1, c->cfg.batch_size) + 2;
-    int64_t* bb = nullptr;
-    if (nb_max <= BB_MAX_BATCHES && ensure(c, c->o().bb, (size_t)nb_max * 16) == 0) bb = (int64_t*)c->o().bb.p;
-    c->o().bb_cap = bb ? nb_max : 0;
+    int64_t* bb = c->o().bb_cap ? (int64_t*)c->o().bb.p : nullptr;
+    if (c->fold) {
+        if (!c->finish_done) hipLaunchKernelGGL(k_finish, dim3(1), dim3(64), 0, c->stream, finish_args(c, true), c->d_state);
+        c->finish_done = false;
+    } else {
     RebaseArgs ra{(const int64_t*)c->o().ends.p, (const int64_t*)c->o().id_ends.p, (const int64_t*)c->o().rec_end.p,
                   (int64_t*)c->o().b_ends.p, (int64_t*)c->o().b_id_ends.p, (int64_t)c->cfg.batch_size, c->cur_first_header,
                   growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->o().rec_cap, c->d_state, c->cur,
                   c->cfg.check_quality ? c->cfg.compat_simd_width : 0, (uint32_t)c->cfg.q_upper, bb, c->o().bb_cap};
     hipLaunchKernelGGL(k_rebase, dim3((unsigned)(c->num_cu * 8)), dim3(BLOCK), 0, c->stream, ra);
+    }
     // mirror the batch-boundary table into pinned memory on the stream: it arrives with the chunk state, no extra synchronisation
     OutSet& o = c->o();
     o.h_bb_batches = 0;
@@ -642,7 +749,7 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     if ((rc = ensure_tile_arenas(c, n)) || (rc = ensure_col_arenas(c, n))) return rc;
     int64_t want = (int64_t)(n / (uint64_t)std::max(4, c->cfg.min_record_bytes)) + 1024;
     if ((rc = ensure_record_arenas(c, want))) return rc;
-    c->views_bytes_once = false; c->tail_pending = false;
+    c->views_bytes_once = false; c->tail_pending = false; c->cum_valid = false;
     if (!reuse_aggregates) c->used_h = false;   // (a shard's aggregates come from bzq_shard_scan, which says how it made them)
     c->cur = d_data; c->cur_n = n; c->cur_stream_pos = stream_pos; c->cur_is_eof = is_eof;
     c->cur_prev_byte = prev_byte; c->cur_first_header = first_header;
@@ -665,11 +772,16 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
         // already ran in bzq_shard_scan and its first lines belong to the previous rank)
         c->ran_stream = !c->ran_single_pass && c->use_stream && !c->cfg.views_only && c->cfg.pass_bytes == 0 && head_lines == 0 &&
                         !reuse_aggregates && !first_nl;
+        decide_fold(c);
         if (c->ran_single_pass) { if ((rc = enqueue_single_launch(c))) return rc; }
         else if (c->ran_stream) { if ((rc = enqueue_stream(c))) return rc; }
-        else if ((rc = enqueue_passes(c, false, reuse_aggregates))) return rc;
-        hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state);
-    }
+        else {
+            if ((rc = enqueue_passes(c, false, reuse_aggregates))) return rc;
+            if (c->exact_sticky > 0 && !c->cfg.views_only) c->exact_sticky -= 1;
+        }
+        hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state, finish_args(c, true));
+        c->finish_done = c->fold;
+    } else c->fold = false;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     enqueue_rebase(c);
@@ -899,7 +1011,7 @@ void bzq_destroy(bzq_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)bzq_comm_destroy(c);
     std::vector<DevBuf*> bufs = {&c->in, &c->tile_c, &c->tile_a, &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc,
-                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf, &c->inflate_tab};
+                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf, &c->inflate_tab, &c->tile_last, &c->tileB, &c->btile};
     for (OutSet& o : c->out) {
         for (DevBuf* b : {&o.seq, &o.qual, &o.id, &o.ends, &o.id_ends, &o.rec_end, &o.b_ends, &o.b_id_ends, &o.off[0], &o.off[1],
                           &o.off[2], &o.off[3], &o.id_start, &o.id_len, &o.bb})
@@ -958,7 +1070,12 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
         c->use_stream = value != 0;
     }
     else if (!strcmp(key, "stream_fallbacks")) return (int32_t)std::min<int64_t>(c->stream_fallbacks, 0x7FFFFFFF);   // query: chunks repeated on the two-pass kernels
+    else if (!strcmp(key, "last_folded")) return c->fold ? 1 : 0;                                                     // query: the last chunk went without k_rebase
+    else if (!strcmp(key, "n_submits")) return (int32_t)std::min<int64_t>(c->n_submits, 0x7FFFFFFF);                  // query: chunks submitted so far
     else if (!strcmp(key, "pass_a_h")) c->pass_a_h = value != 0;
+    else if (!strcmp(key, "fold_rebase")) c->fold_opt = value != 0;
+    else if (!strcmp(key, "cumulative_ends")) c->fold_opt = value == 0;   // 1: bzq_chunk.d_ends / d_id_ends filled with every chunk (the k_rebase path, as before ABI 5)
+    else if (!strcmp(key, "pass_a_sticky")) { c->sticky_opt = value != 0; if (!value) { c->exact_sticky = 0; c->exact_sticky_len = 0; } }
     else if (!strcmp(key, "ingest_direct")) c->ingest_direct = value != 0;
     else if (!strcmp(key, "ingest_numa")) c->ingest_numa = value != 0;
     else if (!strcmp(key, "ingest_gpu_inflate")) c->ingest_gpu_inflate = value != 0;
@@ -1139,6 +1256,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     if (h->lookback_timeout && c->cur_n > 0) {
         // never expected: the single-pass kernel gave up on a predecessor tile.  Same chunk again on
         // the two-pass kernels (no inter-workgroup waiting).
+        const int why = h->lookback_timeout;   // 2: pass A's hypothesis was contradicted
         ChunkState fresh = *h;
         fresh.P = fresh.P0; fresh.S = fresh.S0; fresh.Q = fresh.Q0; fresh.I = fresh.I0;
         fresh.last_nl_tile = -1; fresh.rec_overflow = 0; fresh.lookback_timeout = 0; fresh.dense_tiles = 0;
@@ -1148,11 +1266,17 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         int rc;
         c->ran_single_pass = false; c->ran_stream = false; c->stream_fallbacks += 1;
         if ((rc = ensure_tile_arenas(c, c->cur_n))) return rc;
+        decide_fold(c);
+        if (why == 2 && c->sticky_opt) {   // pass A's hypothesis was contradicted: the next chunks of this file will be too
+            c->hyp_contradictions += 1;
+            c->exact_sticky_len = std::min(1024, std::max(16, 2 * c->exact_sticky_len));
+            c->exact_sticky = c->exact_sticky_len;
+        }
         c->exact_pass_a = true; c->used_h = false;
         rc = enqueue_passes(c, false, false);
         c->exact_pass_a = false;
         if (rc) return rc;
-        hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)c->cur_n, c->d_state);
+        hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)c->cur_n, c->d_state, finish_args(c, false));
         enqueue_rebase(c);
         HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1169,7 +1293,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         int rc;
         c->views_bytes_once = true;
         if ((rc = enqueue_passes(c, false, false))) return rc;
-        hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)c->cur_n, c->d_state);
+        hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)c->cur_n, c->d_state, finish_args(c, false));
         enqueue_rebase(c);
         HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1256,9 +1380,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
                     c->err = "record arrays too small for the unterminated last record";
                     return BZQ_ERR_NOMEM;
                 }
-                hipLaunchKernelGGL(k_fix_last, dim3(1), dim3(64), 0, c->stream, n_complete, n, batch,
-                                   (int64_t*)c->o().ends.p, (int64_t*)c->o().id_ends.p, (int64_t*)c->o().rec_end.p,
-                                   (int64_t*)c->o().b_ends.p, (int64_t*)c->o().b_id_ends.p, (const ChunkState*)c->d_state);
+                launch_fix_last(c, n_complete, n, batch);
                 HIPCHK(c, hipStreamSynchronize(c->stream));
                 if (h->err_valid != ~0ull && key_rec(h->err_valid) == n_complete) {
                     // ... and fails it: the record is not delivered, the stream stops behind the last complete one
@@ -1290,9 +1412,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         else { code = BZQ_UNEXPECTED_EOF; c->term_phase = tail_phase; }
         if (acc) {
             if (n_complete + 1 > c->o().rec_cap) { c->err = "record arrays too small"; return BZQ_ERR_NOMEM; }
-            hipLaunchKernelGGL(k_fix_last, dim3(1), dim3(64), 0, c->stream, n_complete, n, batch,
-                               (int64_t*)c->o().ends.p, (int64_t*)c->o().id_ends.p, (int64_t*)c->o().rec_end.p,
-                               (int64_t*)c->o().b_ends.p, (int64_t*)c->o().b_id_ends.p, (const ChunkState*)c->d_state);
+            launch_fix_last(c, n_complete, n, batch);
             HIPCHK(c, hipStreamSynchronize(c->stream));
             accept_last = true;
             if (h->err_valid != ~0ull && key_rec(h->err_valid) == n_complete) {
@@ -1316,8 +1436,8 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     if (n_records > 0 && !c->cfg.views_only) {
         int64_t e2[2] = {h->last_ends, h->last_id_ends};
         if (n_records != n_complete) { // truncated by an error, or extended by the unterminated last record
-            HIPCHK(c, hipMemcpy(&e2[0], (const int64_t*)c->o().ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(&e2[1], (const int64_t*)c->o().id_ends.p + (n_records - 1), 8, hipMemcpyDeviceToHost));
+            int rc3;
+            if ((rc3 = cum_pair(c, n_records - 1, e2))) return rc3;
         }
         r.qual_bytes = (uint64_t)e2[0];
         r.seq_bytes = accept_last && r.status == BZQ_EOF ? (uint64_t)h->S : (uint64_t)e2[0];
@@ -1325,7 +1445,8 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     }
     if (!c->cfg.views_only) {
         r.d_seq = (const uint8_t*)c->o().seq.p; r.d_qual = (const uint8_t*)c->o().qual.p; r.d_id = (const uint8_t*)c->o().id.p;
-        r.d_ends = (const int64_t*)c->o().ends.p; r.d_id_ends = (const int64_t*)c->o().id_ends.p;
+        // chunk-cumulative arrays: filled with the chunk only on the k_rebase path; otherwise on demand (bzq_chunk_cumulative_ends)
+        if (!c->fold) { r.d_ends = (const int64_t*)c->o().ends.p; r.d_id_ends = (const int64_t*)c->o().id_ends.p; }
         r.d_batch_ends = (const int64_t*)c->o().b_ends.p; r.d_batch_id_ends = (const int64_t*)c->o().b_id_ends.p;
     } else {
         r.d_id_start = (const int64_t*)c->o().id_start.p; r.d_id_len = (const int32_t*)c->o().id_len.p;
@@ -1389,12 +1510,9 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
         if (k > 0) { base[0] = os.h_bb[2 * (k - 1)]; base[1] = os.h_bb[2 * (k - 1) + 1]; }
         last[0] = os.h_bb[2 * k]; last[1] = os.h_bb[2 * k + 1];
     } else {
-        if (first_record > 0) {
-            HIPCHK(c, hipMemcpy(&base[0], c->res.d_ends + (first_record - 1), 8, hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(&base[1], c->res.d_id_ends + (first_record - 1), 8, hipMemcpyDeviceToHost));
-        }
-        HIPCHK(c, hipMemcpy(&last[0], c->res.d_ends + lastrec, 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(&last[1], c->res.d_id_ends + lastrec, 8, hipMemcpyDeviceToHost));
+        int rc4;
+        if (first_record > 0 && (rc4 = cum_pair(c, (int64_t)first_record - 1, base))) return rc4;
+        if ((rc4 = cum_pair(c, (int64_t)lastrec, last))) return rc4;
     }
     out->num_records = (int64_t)nrec;
     out->seq_len = last[0] - base[0];
@@ -1415,8 +1533,12 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
         void* ve = nullptr;
         if ((rc = view_alloc(c, (size_t)nrec * 16, &ve))) return rc;
         int64_t* e = (int64_t*)ve;
-        hipLaunchKernelGGL(k_rebase_range, dim3((unsigned)((nrec + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream,
-                           c->res.d_ends, c->res.d_id_ends, (int64_t)first_record, (int64_t)nrec, e, e + nrec);
+        if (c->fold && !c->cum_valid)
+            hipLaunchKernelGGL(k_rebase_range_b, dim3((unsigned)((nrec + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, c->res.d_batch_ends,
+                               c->res.d_batch_id_ends, (const int64_t*)c->o().bb.p, (int64_t)bs, (int64_t)first_record, (int64_t)nrec, e, e + nrec);
+        else
+            hipLaunchKernelGGL(k_rebase_range, dim3((unsigned)((nrec + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream,
+                               (const int64_t*)c->o().ends.p, (const int64_t*)c->o().id_ends.p, (int64_t)first_record, (int64_t)nrec, e, e + nrec);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         out->ends = e;
         out->id_ends = e + nrec;
@@ -1433,6 +1555,23 @@ int32_t bzq_batches(bzq_ctx* c, uint32_t max_records, bzq_device_batch* out, uin
         const int32_t rc = bzq_batch_view(c, k * (uint64_t)max_records, max_records, &out[k]);
         if (rc < 0) return rc;
     }
+    return 0;
+}
+
+int32_t bzq_chunk_cumulative_ends(bzq_ctx* c, bzq_chunk* inout) {
+    if (!c || !c->have_result) { if (c) c->err = "bzq_chunk_cumulative_ends: no parsed chunk"; return BZQ_ERR_ARG; }
+    if (c->cfg.views_only) { c->err = "bzq_chunk_cumulative_ends: the ctx is in views mode (no columns)"; return BZQ_ERR_ARG; }
+    if (c->fold && !c->cum_valid && c->res.n_records > 0) {
+        HIPCHK(c, hipSetDevice(c->device));
+        const int64_t n = (int64_t)c->res.n_records;
+        const unsigned grid = (unsigned)std::min<int64_t>((n + BLOCK - 1) / BLOCK, (int64_t)c->num_cu * 16);
+        hipLaunchKernelGGL(k_cumulate, dim3(grid), dim3(BLOCK), 0, c->stream, (const int64_t*)c->o().b_ends.p, (const int64_t*)c->o().b_id_ends.p,
+                           (const int64_t*)c->o().bb.p, (int64_t)c->cfg.batch_size, n, (int64_t*)c->o().ends.p, (int64_t*)c->o().id_ends.p);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    c->cum_valid = true;
+    c->res.d_ends = (const int64_t*)c->o().ends.p; c->res.d_id_ends = (const int64_t*)c->o().id_ends.p;
+    if (inout) { inout->d_ends = c->res.d_ends; inout->d_id_ends = c->res.d_id_ends; }
     return 0;
 }
 
@@ -1567,8 +1706,8 @@ static int shard_scan_enqueue(bzq_ctx* c, const uint8_t* d_data, uint64_t n) {
     if (n > 0) {
         HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
         const int64_t nt = tiles_for(n);
-        AggArgs a{d_data, (int64_t)n, 10u, 0, nt, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p, (u64*)c->tile_idc.p, walk_limit_of(c)};
-        c->used_h = c->pass_a_h != 0;
+        AggArgs a{d_data, (int64_t)n, 10u, 0, nt, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p, (u64*)c->tile_idc.p, walk_limit_of(c), (u64*)c->tile_last.p};
+        c->used_h = c->pass_a_h != 0 && c->exact_sticky == 0;
         if (c->used_h) hipLaunchKernelGGL(k_tile_aggregate_h, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
         else hipLaunchKernelGGL(k_tile_aggregate2, dim3((unsigned)nt), dim3(BLOCK), 0, c->stream, a);
         launch_scan(c, 0, nt, 0);

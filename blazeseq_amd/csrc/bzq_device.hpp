@@ -364,7 +364,19 @@ struct AggArgs {
     u64* tile_a;        // 4 x u16: non-newline bytes per line class (local line index & 3)
     u64* tile_idc;      // 4 x u16: id bytes per class if that class were the header role
     int64_t walk_limit; // ByteSrc::walk_limit (0 = none)
+    // 4 x u16: tile offset of the LAST newline of each line class (0xFFFF: the tile has none of that class).  With the line
+    // prefixes of the scan this locates the end of the record before the one that straddles a tile's start without reading
+    // that tile again (the record-length check of the emit kernel, FusedArgs::fold); nullptr = not wanted
+    u64* tile_last;
 };
+
+// tile_last word from the newline table: the last newline of class k is local newline c-1-((c-1-k) & 3)
+__device__ __forceinline__ u64 last_by_class(const uint16_t* s_nl, int c) {
+    u64 w = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w |= (u64)(c > k ? s_nl[c - 1 - ((c - 1 - k) & 3)] : (uint16_t)0xFFFFu) << (16 * k);
+    return w;
+}
 
 #if BZQ_EXPERIMENTS
 static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate(AggArgs a) {
@@ -437,6 +449,13 @@ struct ScanArgs {
     int64_t* grp;        // 10 x int64 per group
     ChunkState* st;
     int32_t pass;        // 0: the carry starts from P0..; k > 0: from pass_carry[k & 1] left by the previous pass
+    // batch index (record / batch) of the record the tile's first line belongs to, 0 for the lines of a shard's head (record < 0);
+    // nullptr = not wanted.  One division per tile here instead of one per record in the emit kernel (FusedArgs::fold)
+    int32_t* tileB;
+    int64_t batch;
+    // btile[k - 1] = the tile that holds the newline ending record k * batch - 1 (line 4 k batch - 1), for k_batch_bases; bb_cap entries
+    int64_t* btile;
+    int64_t bb_cap;
 };
 
 __device__ __forceinline__ int64_t field16(u64 v, int k) { return (int64_t)((v >> (16 * (k & 3))) & 0xFFFFull); }
@@ -582,7 +601,20 @@ static __global__ __launch_bounds__(SG_THREADS) void k_scan_down(ScanArgs a) {
 #pragma unroll
     for (int k = 0; k < SG_ITEMS; ++k) {
         const int64_t i = i0 + k;
-        if (i < a.tile_end) { a.tileP[i] = ps[k]; a.tileS[i] = eS; a.tileQ[i] = eQ; a.tileI[i] = eI; }
+        if (i < a.tile_end) {
+            a.tileP[i] = ps[k]; a.tileS[i] = eS; a.tileQ[i] = eQ; a.tileI[i] = eI;
+            if (a.tileB) {
+                a.tileB[i] = ps[k] >= 4 ? (int32_t)((ps[k] >> 2) / a.batch) : 0;
+                // batch boundaries among this tile's newlines: lines [ps, ps + c) against the lines u k - 1, u = 4 batch
+                const int64_t u = 4 * a.batch, hi_line = ps[k] + c[k];
+                if (c[k] > 0 && hi_line > 0) {
+                    int64_t kb = ps[k] + 1 <= 0 ? 1 : (ps[k] + u) / u;
+                    const int64_t ke = hi_line / u;
+                    for (; kb <= ke; ++kb)
+                        if (kb - 1 < a.bb_cap) a.btile[kb - 1] = i;
+                }
+            }
+        }
         eS += sv[k]; eQ += qv[k]; eI += dv[k];
     }
     if (g == ng - 1 && tid == 0) {   // totals of this pass: the next pass's carry and the host's counts
@@ -597,7 +629,70 @@ static __global__ __launch_bounds__(SG_THREADS) void k_scan_down(ScanArgs a) {
 // Tail after the last newline: where it starts and whether it is more than blanks
 // (_check_end_qual, blazeseq/utils.mojo:292-329).  One workgroup; the last tile with a newline is read as 16-byte
 // pieces like every other tile.
-static __global__ __launch_bounds__(BLOCK) void k_tail(const uint8_t* __restrict__ g, int64_t n, ChunkState* st) {
+// With FusedArgs::fold (no k_rebase behind the emit) the kernel also leaves the chunk totals the host reads with the state and the
+// batch-table entry of the last, partial batch (fin.on).
+struct ChunkFinishArgs {
+    int32_t on;
+    const int64_t* b_ends;      // per-batch ends as the emit wrote them (the chunk-cumulative arrays do not exist in this mode)
+    const int64_t* b_id_ends;
+    const int64_t* rec_end;
+    int64_t batch, first_header, rec_cap;
+    int64_t* bb;
+    int64_t bb_cap;
+};
+__device__ __forceinline__ void chunk_finish(const ChunkFinishArgs& f, ChunkState* st) {
+    const int64_t lines = st->P;
+    int64_t n_rec = lines > 0 ? (lines >> 2) : 0;
+    if (n_rec > f.rec_cap) n_rec = f.rec_cap;   // overflow: the host re-sizes and re-runs
+    st->n_complete = n_rec;
+    st->last_record_end = n_rec ? f.rec_end[n_rec - 1] : f.first_header - 1;
+    int64_t le = 0, li = 0;
+    if (n_rec) {   // chunk-cumulative = per-batch value + the batch's base (the table holds every full batch: FusedArgs::fold requires it)
+        const int64_t k = (n_rec - 1) / f.batch;
+        le = f.b_ends[n_rec - 1] + (k ? f.bb[2 * (k - 1)] : 0);
+        li = f.b_id_ends[n_rec - 1] + (k ? f.bb[2 * (k - 1) + 1] : 0);
+        if (k < f.bb_cap) { f.bb[2 * k] = le; f.bb[2 * k + 1] = li; }
+    }
+    st->last_ends = le; st->last_id_ends = li;
+}
+
+// Chunk-cumulative ends from the per-batch ones (bzq_chunk_cumulative_ends; cold path): ends[r] = b_ends[r] + bb[2 (r / batch - 1)]
+static __global__ __launch_bounds__(BLOCK) void k_cumulate(const int64_t* b_ends, const int64_t* b_id_ends, const int64_t* bb, int64_t batch, int64_t n,
+                                                           int64_t* ends, int64_t* id_ends) {
+    for (int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * BLOCK) {
+        const int64_t k = r / batch;
+        ends[r] = b_ends[r] + (k ? bb[2 * (k - 1)] : 0);
+        id_ends[r] = b_id_ends[r] + (k ? bb[2 * (k - 1) + 1] : 0);
+    }
+}
+
+// k_rebase_range / k_fix_last for a chunk whose per-batch ends were written by the emit (no chunk-cumulative arrays)
+static __global__ __launch_bounds__(BLOCK) void k_rebase_range_b(const int64_t* b_ends, const int64_t* b_id_ends, const int64_t* bb, int64_t batch,
+                                                                 int64_t first, int64_t count, int64_t* out_e, int64_t* out_i) {
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= count) return;
+    auto cum = [&](int64_t x, int64_t& e, int64_t& i) {
+        const int64_t k = x / batch;
+        e = b_ends[x] + (k ? bb[2 * (k - 1)] : 0);
+        i = b_id_ends[x] + (k ? bb[2 * (k - 1) + 1] : 0);
+    };
+    int64_t e0 = 0, i0 = 0, e1, i1;
+    if (first) cum(first - 1, e0, i0);
+    cum(first + r, e1, i1);
+    out_e[r] = e1 - e0;
+    out_i[r] = i1 - i0;
+}
+static __global__ void k_fix_last_b(int64_t rec, int64_t n, int64_t batch, int64_t* rec_end, int64_t* b_ends, int64_t* b_id_ends, int64_t* bb,
+                                    int64_t bb_cap, const ChunkState* st) {
+    if (threadIdx.x || blockIdx.x) return;
+    const int64_t k = rec / batch;
+    rec_end[rec] = n;
+    b_ends[rec] = st->Q - (k ? bb[2 * (k - 1)] : 0);
+    b_id_ends[rec] = st->I - (k ? bb[2 * (k - 1) + 1] : 0);
+    if (k < bb_cap) { bb[2 * k] = st->Q; bb[2 * k + 1] = st->I; }   // the table's last entry now ends at this record
+}
+
+static __global__ __launch_bounds__(BLOCK) void k_tail(const uint8_t* __restrict__ g, int64_t n, ChunkState* st, ChunkFinishArgs fin) {
     __shared__ int s_pos;
     __shared__ int s_nb;
     const int tid = threadIdx.x;
@@ -630,7 +725,10 @@ static __global__ __launch_bounds__(BLOCK) void k_tail(const uint8_t* __restrict
     }
     if (nb) atomicOr(&s_nb, 1);
     __syncthreads();
-    if (tid == 0) { st->tail_start = tail; st->tail_nonblank = s_nb; }
+    if (tid == 0) {
+        st->tail_start = tail; st->tail_nonblank = s_nb;
+        if (fin.on) chunk_finish(fin, st);
+    }
 }
 
 #if BZQ_EXPERIMENTS

@@ -77,7 +77,50 @@ struct FusedArgs {
     // unnecessary is simply given here, so that the kernel's time can be measured and its output compared)
     int64_t xcd_tiles;
     const int64_t* xcd_base;
+    // fold != 0 (two-pass path, one pass, batch_size >= FOLD_MIN_BATCH): the emit writes the per-batch ends DIRECTLY (record_batch.mojo:
+    // 77-87: _ends / _id_ends restart at every batch) from the batch bases k_batch_bases left in bb -- and NOT the chunk-cumulative
+    // `ends` / `id_ends`, which nothing on the batches() path reads (bzq_chunk_cumulative_ends derives them on demand) -- and does the
+    // reference's buffer-capacity refusal (parser.mojo:484-492) from the record's own length, with the end of the record before the
+    // tile's first one located through tileP / tile_last.  The pass over the per-record arrays (k_rebase) is gone, and the emit
+    // writes the same 24 B per record as before (measured: writing both kinds of ends from the emit costs what k_rebase cost)
+    int32_t fold;
+    int64_t* b_ends;
+    int64_t* b_id_ends;
+    const int64_t* bb;         // bb[2k], bb[2k+1]: ends / id_ends at the last record of batch k
+    int64_t bb_cap;            // batches the table holds (a tile beyond it only ends records beyond rec_cap: nothing is written there)
+    const int32_t* tileB;      // batch index of the record the tile's first line belongs to
+    const u64* tile_last;      // AggArgs::tile_last
+    int64_t batch, len_limit, first_header;
 };
+// A pointer that went through LDS as an integer has lost its address space: dereferenced as it is, it becomes a FLAT access, which
+// counts against the LDS counter too and stalls the LDS reads of the scatter behind it (measured: emit + 3 %).  Back to global.
+typedef __attribute__((address_space(1))) int64_t g_i64;
+__device__ __forceinline__ g_i64* as_global(int64_t p) { return (g_i64*)(unsigned long long)p; }
+constexpr int64_t FOLD_MIN_BATCH = 256;   // a fast-path tile ends at most 255 records: at most ONE batch boundary per tile
+
+// End offset (its '\n') of the record whose last line has index lprev, a line that ends before tile t: the tile that holds it is
+// the last one whose line prefix is <= lprev, and there it is the last newline of its class (fewer than four newlines follow it
+// before tile t's first record end).  Gives up (too_long) once the walk has covered more bytes than the longest record the
+// reference's buffer holds: the record that straddles into tile t is refused whatever its exact length.
+__device__ __forceinline__ int64_t prev_record_end(const int64_t* tileP, int64_t tile_last /* address */, int64_t t, int64_t lprev, int64_t len_limit,
+                                                   int64_t p_m1, u64 last_m1, bool& too_long) {
+    // tile t-1 first, from the words the kernel loaded with its own prefixes (no load on this path: nearly every record)
+    int64_t tt = t - 1;
+    int64_t pt = p_m1;
+    u64 lw = last_m1;
+    if (pt > lprev) {
+        const int64_t max_steps = len_limit / TILE + 2;
+        int64_t steps = 0;
+        while (tt > 0 && pt > lprev) {
+            --tt;
+            pt = tileP[tt];
+            if (++steps > max_steps) { too_long = true; return 0; }
+        }
+        lw = (u64)as_global(tile_last)[tt];
+    }
+    const int jl = (int)(lprev - pt);
+    return tt * (int64_t)TILE + (int64_t)((lw >> (16 * (jl & 3))) & 0xFFFFull);
+}
 
 // Exclusive line prefix of tile t (wave 0, all 64 lanes).  Lane i inspects predecessor t-1-i.
 __device__ inline int64_t lookback_lines(const u64* desc_c, int64_t t, int64_t P0, int lane, ChunkState* st) {
@@ -241,7 +284,7 @@ __device__ __forceinline__ void copy16(uint8_t* __restrict__ col, int64_t gaddr,
 // One workgroup per tile, straight-line (no persistent loop: a loop lets the compiler hoist ~35 VGPRs of invariants,
 // and a register-prefetching persistent variant measured 10% SLOWER -- this kernel is bound by HBM traffic, not by
 // reads in flight: capping it at 4 or 5 workgroups per CU instead of 6 does not change its time).
-template <bool CA, bool CQ, bool OFFS, bool LB>
+template <bool CA, bool CQ, bool OFFS, bool LB, bool FOLD = false>
 static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];   // newline bitmap, 16 bits per 16-byte piece
@@ -257,6 +300,10 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     __shared__ uint32_t s_w[4];
     __shared__ int64_t s_bcast[4];   // tile, P / S, Q, I
     __shared__ int s_cnt[3];
+    // FusedArgs::fold, one word per entry: base ends / base id_ends of the tile's first batch [0, 1] and of the next one [2, 3];
+    // tileP[t-1], tile_last[t-1]; first record of the next batch, batch index of the tile's first record; then arguments
+    __shared__ int64_t s_fold[16];
+    enum { F_PM1 = 4, F_LASTM1 = 5, F_NEXTB = 6, F_KB0 = 7, F_BENDS = 8, F_BIDENDS = 9, F_LENLIM = 10, F_FIRSTHDR = 11, F_TILELAST = 12, F_BATCH = 13, F_BB = 14, F_BBCAP = 15 };
 #if BZQ_EXPERIMENTS && defined(BZQ_PAD_LDS)
     __shared__ uint8_t s_pad[BZQ_PAD_LDS];   // experiment: cap workgroups per CU through LDS
     if (a.n < 0) s_pad[a.n & 1023] = 1;
@@ -290,12 +337,32 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     // order, so a load waited for after stores would also wait for those stores' round trip
     uint4 r[4];   // four source pieces per thread (q = tid + 256 s)
     int64_t tP = 0, tS = 0, tQ = 0, tI = 0;
+    int64_t fold_v = 0;   // fold: lanes 0..7 of wave 0 fetch one word each (FOLD_* below) and hand them over through s_fold
     uint32_t prevb = 10u;
     auto fetch = [&](int64_t tt) {
         const int64_t f0 = tt * TILE;
         if (!LB) { tP = a.tileP[tt]; tS = a.tileS[tt]; tQ = a.tileQ[tt]; tI = a.tileI[tt]; }
         prevb = f0 > 0 ? (uint32_t)a.g[f0 - 1] : a.prev_byte;
         tile_fetch(a.g, a.n, f0, (int)((a.n - f0) < TILE ? (a.n - f0) : TILE), r);
+        if (FOLD && tid0 < 16) {
+            // What the fold needs, one word per lane (F_* below), handed over through s_fold: the two batch bases the tile can need
+            // (bb[2 tb - 2 .. 2 tb + 1]), the line prefix and the last-newline word of tile t - 1 -- VECTOR loads behind the tile's
+            // own (they retire in order: nothing waits for them that does not wait for the tile anyway) -- and the kernel
+            // arguments only the per-record outputs use.  Kept as uniform values all of this cost 100 spilled SGPRs in a kernel
+            // that already uses every one of them (measured: emit + 2.5 %).
+            const int64_t tb = a.tileB[tt];
+            const int i = tid0;
+            const int64_t* src = nullptr;
+            if (i < 4) { const int64_t o = 2 * tb - 2 + i; if (o >= 0 && (o >> 1) < a.bb_cap) src = a.bb + o; }
+            else if (i == 4) { if (tt > 0) src = a.tileP + (tt - 1); }
+            else if (i == 5) { if (tt > 0) src = reinterpret_cast<const int64_t*>(a.tile_last) + (tt - 1); }
+            const int64_t args[10] = {(tb + 1) * a.batch, tb, (int64_t)a.b_ends, (int64_t)a.b_id_ends, a.len_limit, a.first_header,
+                                      (int64_t)a.tile_last, a.batch, (int64_t)a.bb, a.bb_cap};
+            int64_t v = 0;
+#pragma unroll
+            for (int k = 0; k < 10; ++k) v = i == 6 + k ? args[k] : v;
+            fold_v = i < 6 ? (src ? *src : 0) : v;
+        }
     };
     fetch(t);
     const int tid = tid0, lane = tid & 63, wave = tid >> 6;
@@ -358,12 +425,30 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     ErrAcc err{~0ull, ~0ull};
     bool overflow = false, h_bad = false;
     const int ph = (int)(P & 3);
+    // fold: the two batches a fast-path tile can touch (uniform loads), and who the tile's first record end is measured from
+    constexpr bool fold = FOLD && !LB;
+    u64 e_buf = ~0ull;
+    // end of the record before the first one that ends in this tile (its quality line is local line (3 - ph) & 3)
+    auto first_prev_end = [&](bool& too_long) -> int64_t {
+        const int64_t lprev = P + (int64_t)((3 - ph) & 3) - 4;
+        if (lprev < 0) return s_fold[F_FIRSTHDR] - 1;   // record 0: measured from its header (a shard's head lines end right before it)
+        return prev_record_end(a.tileP, s_fold[F_TILELAST], t, lprev, s_fold[F_LENLIM], s_fold[F_PM1], (u64)s_fold[F_LASTM1], too_long);
+    };
 
     // walks every line of the tile serially (any input): used by the dense path, count then emit
     auto dense_walk = [&](bool emit, int64_t S, int64_t Q, int64_t I, int64_t& ns, int64_t& nq, int64_t& ni) {
         int64_t rs = S, rq = Q, ri = I;
         int j = 0, line_start = 0;
         bool start_in = first_starts;
+        // fold: batch of the record at hand (records come in order), end of the record before it
+        int64_t dk = fold ? s_fold[F_KB0] : 0, dnext = fold ? s_fold[F_NEXTB] : 0, dbe = fold ? s_fold[0] : 0, dbi = fold ? s_fold[1] : 0, dprev = 0;
+        g_i64* const dbb = as_global(fold ? s_fold[F_BB] : 0);
+        g_i64* const d_be = as_global(fold ? s_fold[F_BENDS] : 0);
+        g_i64* const d_bi = as_global(fold ? s_fold[F_BIDENDS] : 0);
+        bool dlong = false, dfirst = true;
+        auto batch_of = [&](int64_t rec) {
+            while (rec >= dnext) { ++dk; dnext += s_fold[F_BATCH]; if (dk <= s_fold[F_BBCAP]) { dbe = dbb[2 * (dk - 1)]; dbi = dbb[2 * (dk - 1) + 1]; } }
+        };
         auto handle = [&](int start, int end, bool end_in) {
             const int64_t L = P + j;
             const int role = (int)(L & 3);
@@ -385,7 +470,12 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                         if (ri + (p - lo) >= 0) a.col_id[ri + (p - lo)] = ch;
                     }
                 ri += hi - lo;
-                if (emit && end_in && rec >= 0) { if (rec < a.rec_cap) a.id_ends[rec] = ri; else overflow = true; }
+                if (emit && end_in && rec >= 0) {
+                    if (rec < a.rec_cap) {
+                        if (fold) { batch_of(rec); d_bi[rec] = ri - dbi; }
+                        else a.id_ends[rec] = ri;
+                    } else overflow = true;
+                }
             } else if (role == 1) {
                 if (emit && sin && OFFS && rec >= 0 && rec < a.rec_cap) a.o_seq[rec] = ls;
                 if (emit)
@@ -410,8 +500,17 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                         if (rq + (p - start) >= 0) a.col_qual[rq + (p - start)] = ch;
                     }
                 rq += end - start;
+                if (emit && end_in && fold) {   // (head lines of a shard too: the next record is measured from their end)
+                    if (dfirst) { dprev = first_prev_end(dlong); dfirst = false; }
+                    if (rec >= 0 && (dlong || le - dprev > s_fold[F_LENLIM]) && ((u64)rec << 3) < e_buf) e_buf = (u64)rec << 3;
+                    dprev = le; dlong = false;
+                }
                 if (emit && end_in && rec >= 0) {
-                    if (rec < a.rec_cap) { a.ends[rec] = rq; a.rec_end[rec] = le; } else overflow = true;
+                    if (rec < a.rec_cap) {
+                        a.rec_end[rec] = le;
+                        if (fold) { batch_of(rec); d_be[rec] = rq - dbe; }
+                        else a.ends[rec] = rq;
+                    } else overflow = true;
                     if (rs != rq) err.structure(rec, 3);
                 }
             }
@@ -514,6 +613,9 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             if (c > 0) atomicMax((long long*)&a.st->last_nl_tile, (long long)t);
         }
     }
+    // (as late as the barrier in front of the first reader allows: the loads behind fold_v were issued one scalar-load latency
+    // after the tile's, and wave 0 must not wait for them while the other waves wait for wave 0)
+    if (FOLD && tid0 < 16) s_fold[tid0] = fold_v;
     __syncthreads();
     const int64_t S = LB ? s_bcast[1] : cS, Q = LB ? s_bcast[2] : cQ, I = LB ? s_bcast[3] : cI;
     phase_mark(3);   // segment scan
@@ -536,8 +638,11 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             const int j = 4 * tid + jh;           // this thread's header line
             const int64_t rec = (P + j) >> 2;
             if (j < (int)c && rec >= 0) {
-                if (rec < a.rec_cap) a.id_ends[rec] = I + (int64_t)(dh + (int)lh);
-                else overflow = true;
+                if (rec < a.rec_cap) {
+                    const int64_t ie = I + (int64_t)(dh + (int)lh);
+                    if (fold) as_global(s_fold[F_BIDENDS])[rec] = ie - s_fold[rec >= s_fold[F_NEXTB] ? 3 : 1];
+                    else a.id_ends[rec] = ie;
+                } else overflow = true;
             }
         }
         {
@@ -548,9 +653,17 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
                 // sequence bytes up to and including this record's sequence line (line j-2): with this thread's
                 // sequence segment when that line is in the same group of four, else everything before it
                 const int64_t se = S + (int64_t)(jq >= 2 ? ds + (int)lsq : ds);
-                if (rec < a.rec_cap) { a.ends[rec] = qe; a.rec_end[rec] = t0 + (int64_t)s_nl[j]; }
-                else overflow = true;
+                if (rec < a.rec_cap) {
+                    a.rec_end[rec] = t0 + (int64_t)s_nl[j];
+                    if (fold) as_global(s_fold[F_BENDS])[rec] = qe - s_fold[rec >= s_fold[F_NEXTB] ? 2 : 0];
+                    else a.ends[rec] = qe;
+                } else overflow = true;
                 if (se != qe) err.structure(rec, 3); // utils.mojo:458-461 as a cumulative test
+                if (fold) {   // header_start .. '\n' inclusive against the reference's buffer limit (parser.mojo:484-492)
+                    bool too_long = false;
+                    const int64_t prev = j >= 4 ? t0 + (int64_t)s_nl[j - 4] : first_prev_end(too_long);   // (j < 4: thread 0 only)
+                    if (too_long || t0 + (int64_t)s_nl[j] - prev > s_fold[F_LENLIM]) e_buf = (u64)rec << 3;
+                }
             }
         }
         phase_mark(4);   // record outputs
@@ -625,6 +738,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     phase_mark(6);   // junctions
     if (err.e_struct != ~0ull) atomicMin(&a.st->err_struct, err.e_struct);
     if (err.e_valid != ~0ull) atomicMin(&a.st->err_valid, err.e_valid);
+    if (e_buf != ~0ull) atomicMin(&a.st->err_buf, e_buf);
     if (overflow) atomicOr(&a.st->rec_overflow, 1);
     if (h_bad) a.st->lookback_timeout = 2;   // an id lost bytes to the strip: pass A's hypothesis was wrong, the host repeats the chunk with the exact pass A
 }
@@ -671,6 +785,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
             ++idx;
         }
         __syncthreads();
+        if (tid == 0 && a.tile_last) a.tile_last[t] = last_by_class(s_nl, (int)c);
         for (int j = tid; j <= (int)c; j += BLOCK) {
             const int start = j ? (int)s_nl[j - 1] + 1 : 0;
             const bool end_in = j < (int)c;
@@ -688,7 +803,9 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
             int j = 0, line_start = 0;
             bool start_in = first_starts;
             uint32_t la[4] = {0, 0, 0, 0}, li[4] = {0, 0, 0, 0};
+            u64 lastw = ~0ull;
             auto handle = [&](int start, int end, bool end_in) {
+                if (end_in) lastw = (lastw & ~(0xFFFFull << (16 * (j & 3)))) | ((u64)end << (16 * (j & 3)));
                 if (end > start) {
                     int64_t lo, hi;
                     header_kept(bs, t0 + start, t0 + end, start_in, end_in, t0 + valid, lo, hi);
@@ -709,6 +826,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate2(AggArgs a) {
                 }
             }
             handle(line_start, valid, false);
+            if (a.tile_last) a.tile_last[t] = lastw;
             for (int k = 0; k < 4; ++k) { pa |= (u64)la[k] << (16 * k); pi |= (u64)li[k] << (16 * k); }
         }
     }
@@ -768,22 +886,26 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate_h(AggArgs a) {
             ++idx;
         }
         __syncthreads();
+        if (tid == 0 && a.tile_last) a.tile_last[t] = last_by_class(s_nl, (int)c);
         for (int j = tid; j <= (int)c; j += BLOCK) add_line(j, j ? (int)s_nl[j - 1] + 1 : 0, j < (int)c ? (int)s_nl[j] : valid);
     } else {
         __syncthreads();
         if (tid == 0) {   // more newlines than the table holds: one thread walks the bitmap
             int j = 0, line_start = 0;
+            u64 lastw = ~0ull;
             for (int w = 0; w < BLOCK; ++w) {
                 u64 m = s_mask64[w];
                 while (m) {
                     const int bit = __builtin_ctzll(m);
                     m &= m - 1;
                     add_line(j, line_start, w * 64 + bit);
+                    lastw = (lastw & ~(0xFFFFull << (16 * (j & 3)))) | ((u64)(w * 64 + bit) << (16 * (j & 3)));
                     line_start = w * 64 + bit + 1;
                     ++j;
                 }
             }
             add_line(j, line_start, valid);
+            if (a.tile_last) a.tile_last[t] = lastw;
         }
     }
     pa = wave_sum_u64(pa); pi = wave_sum_u64(pi);
@@ -794,6 +916,123 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_aggregate_h(AggArgs a) {
         a.tile_a[t] = s_sum[0];
         a.tile_idc[t] = s_sum[1];
     }
+}
+
+
+// ---- batch bases (FusedArgs::fold) ---------------------------------------------------------------------------------------------
+// FastqBatch._ends / _id_ends restart at every batch (record_batch.mojo:77-87 via parser.mojo:243): batch k's arrays are the
+// chunk's running sums minus their values at the last record of batch k - 1.  Those <= n_records / batch_size values are known
+// BEFORE the emit: record R = k * batch - 1 ends at the newline of line 4 R + 3, the tile prefixes of the scan say which tile
+// holds that newline and what the columns hold before the tile, and one look at that tile gives the rest -- the quality bytes and
+// the kept id bytes of the tile in front of the newline, measured exactly as the emit measures them (header_kept).  One workgroup
+// per boundary (2441 of them for 10 M records in batches of 4096: 40 MB read), so that the emit kernel can write the per-batch
+// arrays itself and the separate pass over the per-record arrays (k_rebase: 0.10 ms of a 1.77 ms step) is gone.
+struct BasesArgs {
+    const uint8_t* g;
+    int64_t n;
+    uint32_t prev_byte;
+    int64_t n_tiles;
+    const int64_t* tileP;
+    const int64_t* tileQ;
+    const int64_t* tileI;
+    int64_t batch;
+    int64_t* bb;
+    int64_t bb_cap;
+    const ChunkState* st;
+    int64_t walk_limit;
+    const int64_t* btile;   // ScanArgs::btile
+};
+
+static __global__ __launch_bounds__(BLOCK) void k_batch_bases(BasesArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile[TILE];
+    __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
+    __shared__ uint16_t s_nl[MAXL_A];
+    __shared__ __attribute__((aligned(8))) uint32_t s_w[4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int64_t k = (int64_t)blockIdx.x + 1;
+    const int64_t lines = a.st->P;
+    const int64_t n_rec = lines > 0 ? (lines >> 2) : 0;
+    const int64_t R = k * a.batch - 1;
+    if (R >= n_rec || k - 1 >= a.bb_cap) return;
+    const int64_t lt = 4 * R + 3;   // line whose newline ends record R
+    const int64_t t = a.btile[k - 1];   // (the scan noted which tile holds that newline: ScanArgs::btile)
+    const int64_t t0 = t * TILE;
+    const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+    const uint32_t prev_b = t0 > 0 ? (uint32_t)a.g[t0 - 1] : a.prev_byte;
+    uint4 r[4];
+    tile_fetch(a.g, a.n, t0, valid, r);
+    tile_stage<true>(r, valid, s_mask, s_tile);
+    ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
+    if (a.walk_limit > 0) bs.walk_limit = a.walk_limit;
+    const bool first_starts = (prev_b == 10u);
+    const int64_t P = a.tileP[t];
+    const int ph = (int)(P & 3);
+    const int jt = (int)(lt - P);   // the tile's local line that ends record R
+    __syncthreads();
+    const u64* s_mask64 = reinterpret_cast<const u64*>(s_mask);
+    const u64 m64 = s_mask64[tid];
+    uint32_t c = 0;
+    const uint32_t excl = block_exclusive_scan<uint32_t, 4>((uint32_t)__popcll(m64), s_w, c);
+    u64* s_sum = reinterpret_cast<u64*>(s_w);
+    if (tid < 2) s_sum[tid] = 0;
+    u64 q = 0, d = 0;   // quality bytes / kept id bytes of the tile in front of that newline
+    if ((int)c <= MAXL_A) {
+        u64 m = m64;
+        int idx = 0;
+        while (m) {
+            const int bit = __builtin_ctzll(m);
+            m &= m - 1;
+            s_nl[excl + idx] = (uint16_t)(tid * 64 + bit);
+            ++idx;
+        }
+        __syncthreads();
+        for (int j = tid; j <= jt && j < (int)c; j += BLOCK) {
+            const int role = (ph + j) & 3;
+            const int start = j ? (int)s_nl[j - 1] + 1 : 0, end = (int)s_nl[j];
+            if (role == 3) q += (u64)(end - start);
+            else if (role == 0 && end > start) {
+                int64_t lo, hi;
+                header_kept(bs, t0 + start, t0 + end, j > 0 ? true : first_starts, true, t0 + valid, lo, hi);
+                d += (u64)(hi - lo);
+            }
+        }
+    } else {
+        __syncthreads();
+        if (tid == 0) {   // more newlines than the table holds: one thread walks the bitmap
+            int j = 0, line_start = 0;
+            bool start_in = first_starts;
+            for (int w = 0; w < BLOCK && j <= jt; ++w) {
+                u64 m = s_mask64[w];
+                while (m && j <= jt) {
+                    const int bit = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const int nl = w * 64 + bit, role = (ph + j) & 3;
+                    if (role == 3) q += (u64)(nl - line_start);
+                    else if (role == 0 && nl > line_start) {
+                        int64_t lo, hi;
+                        header_kept(bs, t0 + line_start, t0 + nl, start_in, true, t0 + valid, lo, hi);
+                        d += (u64)(hi - lo);
+                    }
+                    line_start = nl + 1;
+                    start_in = true;
+                    ++j;
+                }
+            }
+        }
+    }
+    q = wave_sum_u64(q); d = wave_sum_u64(d);
+    if (lane == 0) { atomicAdd(&s_sum[0], q); atomicAdd(&s_sum[1], d); }
+    __syncthreads();
+    if (tid == 0) {
+        a.bb[2 * (k - 1)] = a.tileQ[t] + (int64_t)s_sum[0];
+        a.bb[2 * (k - 1) + 1] = a.tileI[t] + (int64_t)s_sum[1];
+    }
+}
+
+// What is left of k_rebase with FusedArgs::fold, for the re-run paths (the first run does it inside k_tail): one thread.
+static __global__ void k_finish(ChunkFinishArgs f, ChunkState* st) {
+    if (threadIdx.x || blockIdx.x) return;
+    chunk_finish(f, st);
 }
 
 } // namespace bzq

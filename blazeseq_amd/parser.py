@@ -93,6 +93,7 @@ class ChunkResult:
         self.raw = raw
         for name, _ in L.BzqChunk._fields_:
             setattr(self, name, getattr(raw, name))
+        self._serial = L.lib().bzq_set_option(ctx.h, b"n_submits", 0)   # (query) which chunk of the ctx this is
 
     def _i64(self, ptr, count) -> np.ndarray:
         out = np.empty(int(count), dtype=np.int64)
@@ -106,8 +107,21 @@ class ChunkResult:
             self.ctx.copy_to_host(out, ptr, int(count))
         return out
 
-    def ends(self): return self._i64(self.d_ends, self.n_records)
-    def id_ends(self): return self._i64(self.d_id_ends, self.n_records)
+    def _cumulative(self):
+        """bzq_chunk.d_ends / d_id_ends are produced on demand (the emit kernel writes the per-batch arrays directly)."""
+        if not self.d_ends and int(self.n_records):
+            if L.lib().bzq_set_option(self.ctx.h, b"n_submits", 0) != self._serial:
+                raise RuntimeError("ChunkResult.ends(): the ctx has parsed another chunk since; ask for the cumulative ends while the chunk is current")
+            _check(self.ctx.h, L.lib().bzq_chunk_cumulative_ends(self.ctx.h, C.byref(self.raw)), "bzq_chunk_cumulative_ends")
+            self.d_ends, self.d_id_ends = self.raw.d_ends, self.raw.d_id_ends
+
+    def ends(self):
+        self._cumulative()
+        return self._i64(self.d_ends, self.n_records)
+
+    def id_ends(self):
+        self._cumulative()
+        return self._i64(self.d_id_ends, self.n_records)
     def batch_ends(self): return self._i64(self.d_batch_ends, self.n_records)
     def batch_id_ends(self): return self._i64(self.d_batch_id_ends, self.n_records)
     def record_end(self): return self._i64(self.d_record_end, self.n_records)

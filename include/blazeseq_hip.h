@@ -37,7 +37,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define BZQ_ABI_VERSION 1
+#define BZQ_ABI_VERSION 2   /* 2: bzq_chunk.d_ends / d_id_ends are produced on demand (bzq_chunk_cumulative_ends) */
 
 /* FastxErrorCode, blazeseq/errors.mojo:33-68 (values are part of the ABI). */
 enum {
@@ -110,8 +110,12 @@ typedef struct bzq_chunk {
     const uint8_t* d_seq;      /* u8[seq_bytes]  concatenated sequence lines */
     const uint8_t* d_qual;     /* u8[qual_bytes] concatenated quality lines */
     const uint8_t* d_id;       /* u8[id_bytes]   concatenated stripped ids (no '@') */
-    const int64_t* d_ends;     /* i64[n_records] inclusive running sum of quality lengths (Q11) */
-    const int64_t* d_id_ends;  /* i64[n_records] inclusive running sum of id lengths */
+    /* CHUNK-cumulative running sums (i64[n_records]; Q11): an artefact of parsing a chunk at a time -- the reference has only the
+     * per-batch arrays below, and nothing on the batches() path reads these.  NULL until bzq_chunk_cumulative_ends() is called
+     * for the chunk (ABI 2), unless the chunk went through the older per-record pass (batch_size < 256, pass_bytes, the
+     * compat_simd_width quirk, option "cumulative_ends" = 1), which fills them with every chunk. */
+    const int64_t* d_ends;     /* inclusive running sum of quality lengths */
+    const int64_t* d_id_ends;  /* inclusive running sum of id lengths */
     const int64_t* d_batch_ends;    /* same, restarted every batch_size records: exactly the
                                        `_ends` of the FastqBatch that next_batch would build */
     const int64_t* d_batch_id_ends;
@@ -263,6 +267,11 @@ int32_t bzq_batch_view(bzq_ctx* ctx, uint64_t first_record, uint32_t max_records
  * `max_records` records (the last one shorter), exactly what successive bzq_batch_view(k * max_records, max_records) calls
  * return.  cap = entries available in `out`; *n_out = batches the chunk holds (may exceed cap: only cap are written). */
 int32_t bzq_batches(bzq_ctx* ctx, uint32_t max_records, bzq_device_batch* out, uint64_t cap, uint64_t* n_out);
+/* The current chunk's chunk-cumulative `ends` / `id_ends` (bzq_chunk.d_ends / d_id_ends): derived from the per-batch arrays by one
+ * small kernel the first time it is asked for (the emit kernel writes FastqBatch._ends / _id_ends per batch directly,
+ * record_batch.mojo:77-87), free afterwards.  Fills the two pointers of `inout` (may be NULL: then only the ctx's copy of the
+ * chunk is updated).  Valid as long as the chunk's other arrays. */
+int32_t bzq_chunk_cumulative_ends(bzq_ctx* ctx, bzq_chunk* inout);
 /* DeviceFastqBatch.copy_to_host (record_batch.mojo:222-244) */
 int32_t bzq_batch_to_host(bzq_ctx* ctx, const bzq_device_batch* batch, bzq_host_batch* out);
 /* Copy any device range of the current chunk's arrays to the host (tests, error snippets). */

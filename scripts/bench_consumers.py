@@ -37,5 +37,6 @@ t = timed(lambda: d.histogram('sequence'))
 print(f"histogram(seq) {t*1e3:.2f} ms = {S/t/1e9:.0f} GB/s")
 import ctypes as C
 from blazeseq_amd import _lib as L
+res._cumulative()
 t = timed(lambda: L.lib().bzq_column_gc_counts(ctx.h, C.c_void_p(res.d_seq), C.c_void_p(res.d_ends), R, S, C.c_void_p(sums.data_ptr())))
 print(f"gc_counts      {t*1e3:.2f} ms = {S/t/1e9:.0f} GB/s of sequence bytes")

@@ -87,9 +87,10 @@ int main(int argc, char** argv) {
     if ((rc = bzq_shard_stitch(ctx, shard_ptr, n, capacity, &res)) != 0) die(ctx, "bzq_shard_stitch", rc);
 
     /* this rank's records, the reference's FastqBatch.get_record walk over the chunk columns (record_batch.mojo:116-150) */
-    const bzq_chunk* ch = &res.chunk;
+    bzq_chunk* ch = &res.chunk;
     uint8_t *q = malloc(ch->qual_bytes + 1), *s = malloc(ch->seq_bytes + 1), *id = malloc(ch->id_bytes + 1);
     int64_t *ends = malloc(ch->n_records * 8 + 8), *id_ends = malloc(ch->n_records * 8 + 8);
+    if ((rc = bzq_chunk_cumulative_ends(ctx, ch)) < 0) { fprintf(stderr, "bzq_chunk_cumulative_ends: %d\n", rc); return 1; }   /* (ABI 2: produced on demand) */
     if (ch->n_records) {
         if ((rc = bzq_copy_to_host(ctx, q, ch->d_qual, ch->qual_bytes)) || (rc = bzq_copy_to_host(ctx, s, ch->d_seq, ch->seq_bytes)) ||
             (rc = bzq_copy_to_host(ctx, id, ch->d_id, ch->id_bytes)) || (rc = bzq_copy_to_host(ctx, ends, ch->d_ends, ch->n_records * 8)) ||

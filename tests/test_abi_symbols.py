@@ -23,7 +23,7 @@ def test_every_declared_symbol_is_exported_and_bound():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert _lib.lib().bzq_abi_version() == 1
+    assert _lib.lib().bzq_abi_version() == 2
 
 
 def test_struct_sizes_match_header(tmp_path):

@@ -73,6 +73,7 @@ def test_config5_shard_of_the_200gb_file(rank):
     ids = _view(res.d_id, 14 * R, torch.uint8).view(R, 14)
     assert bytes(ids[0].cpu().numpy()) == b"read_%09d" % first_owned and bytes(ids[-1].cpu().numpy()) == b"read_%09d" % (owned_end - 1)
     r = torch.arange(1, R + 1, dtype=torch.int64, device="cuda")
+    res._cumulative()   # (ABI 2: the chunk-cumulative arrays are derived on demand)
     assert torch.equal(_view(res.d_ends, 8 * R, torch.int64), 150 * r)
     assert torch.equal(_view(res.d_id_ends, 8 * R, torch.int64), 14 * r)
     assert torch.equal(_view(res.d_record_end, 8 * R, torch.int64), head + REC * r - 1)

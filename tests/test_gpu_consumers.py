@@ -109,6 +109,7 @@ def test_gc_counts_per_record_on_fastq_and_fasta_columns():
         ctx.submit_device(t.data_ptr(), t.numel(), 0, True)
         res = ctx.result()
         out = torch.empty(n, dtype=torch.int64, device="cuda")
+        res._cumulative()   # the whole chunk as one column: its chunk-cumulative ends (derived on demand since ABI 2)
         assert L.lib().bzq_column_gc_counts(ctx.h, C.c_void_p(res.d_seq), C.c_void_p(res.d_ends), n, int(res.seq_bytes), C.c_void_p(out.data_ptr())) == 0
         assert np.array_equal(out.cpu().numpy(), gc_of(f.seq_bytes, f.ends))
     # a FASTA chunk: mixed case, N and gaps in the sequences, an empty-ish tail record

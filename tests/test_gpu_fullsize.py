@@ -53,6 +53,7 @@ def test_config2_and_3_full_size_columns_are_slices_of_the_input(validate):
     assert torch.equal(_view(res.d_qual, 150 * R2, torch.uint8).view(R2, 150), m[:, 167:317])
     assert torch.equal(_view(res.d_id, 12 * R2, torch.uint8).view(R2, 12), m[:, 1:13])
     r = torch.arange(1, R2 + 1, dtype=torch.int64, device="cuda")
+    res._cumulative()   # (ABI 2: the chunk-cumulative arrays are derived on demand)
     assert torch.equal(_view(res.d_ends, 8 * R2, torch.int64), 150 * r)
     assert torch.equal(_view(res.d_id_ends, 8 * R2, torch.int64), 12 * r)
     assert torch.equal(_view(res.d_record_end, 8 * R2, torch.int64), 318 * r - 1)
@@ -88,6 +89,7 @@ def test_config4_full_size_checksum_of_checksums():
     i = torch.arange(reads, dtype=torch.int64, device="cuda")
     lens = 200 + (i * 31 + 7) % 19_601
     ends = torch.cumsum(lens, 0)
+    res._cumulative()
     assert torch.equal(_view(res.d_ends, 8 * reads, torch.int64), ends)
     assert int(res.seq_bytes) == int(res.qual_bytes) == int(ends[-1].item()) and int(res.id_bytes) == 11 * reads
     rec_end = torch.cumsum(2 * lens + 17, 0) - 1          # "@read_000000\n" 13 + L + "\n+\n" 3 + L + "\n" 1 = 2L + 17

@@ -84,6 +84,7 @@ def test_results_stay_valid_through_the_next_submit_and_consumers_overlap_it():
 
     ctx.submit_device(da.data_ptr(), da.numel(), 0, True)
     ra = ctx.result()
+    ra._cumulative()                                        # chunk-cumulative ends are derived on demand, while the chunk is current (ABI 2)
     view_a = ctx.batch_view(100, 50_000)                    # unaligned: its ends live in chunk A's output set
     sums = torch.zeros(50_000, dtype=torch.int64, device="cuda")
     dba = B.DeviceFastqBatch(ctx, view_a)
