@@ -536,6 +536,11 @@ def main():
                     help="the FASTA path on the reference's FASTA benchmark input (200-3800 bp, line width 60), 1.5 M records/GPU")
     ap.add_argument("--cpu-reads", type=int, default=10_000_000, help="CPU baseline sample: the same 10 M-read workload by default (~15 s of CPU work)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="bzq_set_option on the headline ctx (A/B runs: --opt fold_rebase=0)")
+    ap.add_argument("--from-file", action="store_true",
+                    help="sharded mode (--gpus N, or --force-sharded): the synthetic stream is written to ONE file on /dev/shm and every step starts "
+                         "at the file -- each rank reads its byte range through bzq_shard_read_range (reader threads -> pinned -> device), then "
+                         "bzq_shard_stitch: file-chunk sharding end to end, PCIe inclusive (10 M reads per rank unless --reads says otherwise)")
+    ap.add_argument("--reader-threads", type=int, default=8)
     ap.add_argument("--no-ingest-mode", action="store_true", help="skip the file -> records figures (ingest_mode) of the default line")
     args = ap.parse_args()
 
@@ -588,7 +593,7 @@ def main():
     config5 = world > 1 and not args.long_reads and not args.fasta
     default_reads = args.reads == 0
     if args.reads == 0:
-        args.reads = 78_125_000 if config5 else 10_000_000
+        args.reads = 78_125_000 if (config5 and not args.from_file) else 10_000_000
     if args.fasta:
         return fasta_main(args, world, rank, local_rank, dev, sharded_mode, native_comm, dist_dev)
 
@@ -668,6 +673,32 @@ def main():
 
     import ctypes as C
 
+    file_path = None
+    if args.from_file:
+        if not sharded_mode or args.long_reads or exchange != "native":
+            raise SystemExit("--from-file needs the sharded mode over the library's own communicator (--gpus N or --force-sharded), fixed-length reads")
+        # ONE file for all ranks: rank 0 creates it, every rank writes its own byte range at its offset, then reads it back per step
+        box = [os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"bzq_bench_stream_{os.getpid()}.fastq") if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        file_path = box[0]
+        if rank == 0:
+            with open(file_path, "wb") as f:
+                f.truncate(total_bytes)
+        if world > 1:
+            dist.barrier()
+        host_bytes = shard[:n].cpu().numpy()
+        fd = os.open(file_path, os.O_WRONLY)
+        try:
+            off = 0
+            while off < n:
+                off += os.pwrite(fd, host_bytes[off:off + (256 << 20)], lo + off)
+        finally:
+            os.close(fd)
+        del host_bytes
+        if world > 1:
+            dist.barrier()
+
     def side_mode(d_buf, nbytes, nrec, validate, what, min_rec=None):
         """One more BASELINE configuration beside the headline: its own ctx, batch mode, every batch handed out; host-timed
         steps bracketed by synchronisations, plus the dominant kernel's roofline fraction from the ctx's HIP events."""
@@ -720,6 +751,10 @@ def main():
                 rc = L.lib().bzq_batches(ctx.h, 4096, batch_arr, nb_cap, C.byref(nb_out))
                 assert rc == 0
             return res, None, None
+        if file_path is not None:   # the rank's byte range of the file -> device -> stitch
+            p_, n_, cap_ = ctx.shard_read_range(file_path, lo, hi, slack, args.reader_threads)
+            sr = ctx.shard_stitch(p_, n_, cap_)
+            return sr.chunk, [sr.global_records, sr.global_bases, sr.global_bytes], (sr.first_error_record if sr.first_error_record >= 0 else sharded.NO_ERROR)
         if exchange == "native":
             sr = ctx.shard_stitch(shard.data_ptr(), n, shard.numel())
             return sr.chunk, [sr.global_records, sr.global_bases, sr.global_bytes], (sr.first_error_record if sr.first_error_record >= 0 else sharded.NO_ERROR)
@@ -778,6 +813,11 @@ def main():
     if sharded_mode:
         dist.barrier()
         dist.destroy_process_group()
+    if file_path is not None and rank == 0:
+        try:
+            os.remove(file_path)
+        except OSError:
+            pass
     if rank == 0:
         steps = args.steps
         folded = L.lib().bzq_set_option(ctx.h, b"last_folded", 0) == 1
@@ -819,6 +859,11 @@ def main():
                                        if world > 1 else "single GPU"),
                        "pass_bytes": args.pass_bytes, "exchange": exchange},
             "fraction_of_hbm_peak_input_rate": round(global_bytes / world / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
+            "from_file": ({"path": file_path, "file_gb": round(total_bytes / 1e9, 3), "reader_threads": args.reader_threads,
+                           "pcie_frac_per_gpu": round(global_bytes / world / sec_per_step / 1e9 / PCIE_PEAK_GBS, 3),
+                           "note": "every step starts at the file: bzq_shard_read_range (this rank's byte range: pread -> pinned -> H2D) + bzq_shard_stitch; "
+                                   "PCIe inclusive, so `value` here is NOT the HBM-resident headline and the roofline objects below describe the kernels only"}
+                          if file_path is not None else None),
             "roofline": {
                 "bound": "hbm", "kernel": "k_stream" if args.stream else "k_tile_lines (views mode: line entries)" if args.views else "k_tile_emit" if args.kernels_v1 else ("k_single<look-back>" if args.hier else "k_single<service>" if args.service else ("k_fused<LB=true>" if args.single_pass else "k_fused<LB=false>")),
                 "achieved": round(dom_bytes / emit_s / 1e9, 2) if emit_s > 0 else None,

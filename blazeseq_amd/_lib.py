@@ -205,6 +205,8 @@ SYMBOLS = {
     "bzq_comm_destroy": (C.c_int32, [C.c_void_p]),
     "bzq_plan_shards": (C.c_int32, [C.POINTER(BzqShardSummary), C.c_int32, C.POINTER(BzqShardPlan)]),
     "bzq_shard_stitch": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.POINTER(BzqShardResult)]),
+    "bzq_shard_read_range": (C.c_int32, [C.c_void_p, C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "bzq_global_counts": (C.c_int32, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "bzq_generate_synthetic_device": (C.c_int32, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32,
                                                   C.c_int32, C.c_int32, C.c_char_p, C.c_void_p, C.c_uint64,

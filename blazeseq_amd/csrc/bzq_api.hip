@@ -132,6 +132,11 @@ struct bzq_ctx {
     bool cum_valid = false;    // the current chunk's chunk-cumulative ends / id_ends hold values (always without fold; with it: after bzq_chunk_cumulative_ends)
     bool finish_done = false;  // k_tail of this submit already left the chunk totals (enqueue_rebase skips k_finish once)
     DevBuf tile_last, tileB, btile;
+    // bzq_shard_read_range: the rank's byte range of a file in device memory, and the pinned pieces it travelled through
+    DevBuf shard_buf;
+    std::vector<void*> shard_pin;          // 2 per reader thread, SHARD_PIECE bytes each (pinned once, reused)
+    std::vector<hipStream_t> shard_streams;
+    std::vector<hipEvent_t> shard_events;
     int pass_a_h = 1;          // option "pass_a_h": pass A from the newline bitmap alone (k_tile_aggregate_h), verified by the emit
     bool exact_pass_a = false; // this chunk is being repeated with the exact pass A
     bool used_h = false;
@@ -1011,7 +1016,7 @@ void bzq_destroy(bzq_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)bzq_comm_destroy(c);
     std::vector<DevBuf*> bufs = {&c->in, &c->tile_c, &c->tile_a, &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc,
-                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf, &c->inflate_tab, &c->tile_last, &c->tileB, &c->btile};
+                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf, &c->inflate_tab, &c->tile_last, &c->tileB, &c->btile, &c->shard_buf};
     for (OutSet& o : c->out) {
         for (DevBuf* b : {&o.seq, &o.qual, &o.id, &o.ends, &o.id_ends, &o.rec_end, &o.b_ends, &o.b_id_ends, &o.off[0], &o.off[1],
                           &o.off[2], &o.off[3], &o.id_start, &o.id_len, &o.bb})
@@ -1020,6 +1025,9 @@ void bzq_destroy(bzq_ctx* c) {
         if (o.h_bb) (void)hipHostFree(o.h_bb);
     }
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    for (void* q : c->shard_pin) if (q) (void)hipHostFree(q);
+    for (hipStream_t q : c->shard_streams) if (q) (void)hipStreamDestroy(q);
+    for (hipEvent_t q : c->shard_events) if (q) (void)hipEventDestroy(q);
     if (c->d_state) (void)hipFree(c->d_state);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->stage_pin) (void)hipHostFree(c->stage_pin);
@@ -1968,6 +1976,88 @@ static int ingest_place(bzq_ingest* g, int64_t k, uint64_t carry, hipStream_t qu
     }
     *dst = g->big[b];
     *body_moves = true;
+    return 0;
+}
+
+// ---- file-chunk sharding: a rank's byte range of one file into device memory -------------------------------------------------
+// (north_star "file-chunk sharding across the GPUs"; what FileReader.read_to_buffer does for the reference, io/readers.mojo:86-137,
+// for the range [lo, hi) at once.)  Reader thread w takes pieces w, w + T, w + 2T ... of SHARD_PIECE bytes: pread() into one of its
+// two pinned buffers, H2D on its own stream, the other buffer being read meanwhile -- no thread ever waits for another one, the
+// copies of the T streams share the DMA engines.  The threads run on the CPUs of the GPU's NUMA node (option ingest_numa).
+constexpr uint64_t SHARD_PIECE = 16ull << 20;
+
+int32_t bzq_shard_read_range(bzq_ctx* c, const char* path, uint64_t lo, uint64_t hi, uint64_t halo_room, int32_t n_threads,
+                             uint8_t** d_shard, uint64_t* n_out, uint64_t* capacity_out) {
+    if (!c || !path || !d_shard || !n_out || !capacity_out || hi < lo) { if (c) c->err = "bzq_shard_read_range: bad arguments"; return BZQ_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { c->err = std::string("bzq_shard_read_range: cannot open ") + path; return BZQ_ERR_IO; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || hi > (uint64_t)st.st_size) {
+        close(fd);
+        c->err = std::string("bzq_shard_read_range: not a regular file, or the range ends behind it: ") + path;
+        return BZQ_ERR_IO;
+    }
+    const uint64_t n = hi - lo;
+    const uint64_t cap = ((n + std::max<uint64_t>(halo_room, 4ull << 20) + 64) + 15) & ~15ull;
+    if (c->pending) HIPCHK(c, hipStreamSynchronize(c->stream));   // (a parse of the previous contents of the buffer may still run)
+    int rc;
+    if ((rc = ensure(c, c->shard_buf, cap))) { close(fd); return rc; }
+    uint8_t* dst = (uint8_t*)c->shard_buf.p;
+    const int64_t pieces = (int64_t)((n + SHARD_PIECE - 1) / SHARD_PIECE);
+    const int T = (int)std::max<int64_t>(1, std::min<int64_t>(n_threads > 0 ? n_threads : 8, std::max<int64_t>(pieces, 1)));
+    while ((int)c->shard_streams.size() < T) {
+        hipStream_t q = nullptr;
+        if (hipStreamCreateWithFlags(&q, hipStreamNonBlocking) != hipSuccess) { close(fd); c->err = "bzq_shard_read_range: hipStreamCreate"; return BZQ_ERR_HIP; }
+        c->shard_streams.push_back(q);
+    }
+    while ((int)c->shard_events.size() < 2 * T) {
+        hipEvent_t q = nullptr;
+        if (hipEventCreateWithFlags(&q, hipEventDisableTiming) != hipSuccess) { close(fd); c->err = "bzq_shard_read_range: hipEventCreate"; return BZQ_ERR_HIP; }
+        c->shard_events.push_back(q);
+    }
+    if ((int)c->shard_pin.size() < 2 * T) c->shard_pin.resize(2 * T, nullptr);
+    std::vector<int> cpus;
+    int node = -1;
+    if (c->ingest_numa) gpu_numa_cpus(c->device, &node, cpus);
+    std::atomic<int> fail{0};   // 1 = pinned allocation, 2 = read, 3 = HIP
+    auto work = [&](int w) {
+        if (hipSetDevice(c->device) != hipSuccess) { fail = 3; return; }
+        if (!cpus.empty()) bzq::bind_to_cpus(cpus);
+        hipStream_t q = c->shard_streams[w];
+        bool used[2] = {false, false};
+        int64_t i = 0;
+        for (int64_t k = w; k < pieces && !fail; k += T, ++i) {
+            const int b = (int)(i & 1);
+            void*& pin = c->shard_pin[2 * w + b];
+            if (!pin && hipHostMalloc(&pin, SHARD_PIECE, hipHostMallocDefault) != hipSuccess) { pin = nullptr; fail = 1; return; }   // (pinned here: T threads pin side by side)
+            if (used[b] && hipEventSynchronize(c->shard_events[2 * w + b]) != hipSuccess) { fail = 3; return; }
+            const uint64_t off = (uint64_t)k * SHARD_PIECE, len = std::min<uint64_t>(SHARD_PIECE, n - off);
+            uint64_t got = 0;
+            while (got < len) {
+                const ssize_t r = pread(fd, (uint8_t*)pin + got, (size_t)(len - got), (off_t)(lo + off + got));
+                if (r <= 0) { fail = 2; return; }
+                got += (uint64_t)r;
+            }
+            if (hipMemcpyAsync(dst + off, pin, len, hipMemcpyHostToDevice, q) != hipSuccess || hipEventRecord(c->shard_events[2 * w + b], q) != hipSuccess) { fail = 3; return; }
+            used[b] = true;
+        }
+        if (hipStreamSynchronize(q) != hipSuccess) fail = 3;
+    };
+    {
+        std::vector<std::thread> th;
+        for (int w = 1; w < T && pieces > 0; ++w) th.emplace_back(work, w);
+        if (pieces > 0) work(0);
+        for (auto& t : th) t.join();
+    }
+    close(fd);
+    if (fail) {
+        (void)hipGetLastError();
+        c->err = fail == 1 ? "bzq_shard_read_range: pinning the staging buffers failed" : fail == 2 ? "bzq_shard_read_range: pread failed or the file was truncated"
+                                                                                                    : "bzq_shard_read_range: a copy to the device failed";
+        return fail == 1 ? BZQ_ERR_NOMEM : fail == 2 ? BZQ_ERR_IO : BZQ_ERR_HIP;
+    }
+    *d_shard = dst; *n_out = n; *capacity_out = cap;
     return 0;
 }
 

@@ -289,6 +289,13 @@ class Context:
     def comm_destroy(self):
         _check(self.h, L.lib().bzq_comm_destroy(self.h), "bzq_comm_destroy")
 
+    def shard_read_range(self, path: str, lo: int, hi: int, halo_room: int = 0, n_threads: int = 0):
+        """bzq_shard_read_range: bytes [lo, hi) of a file into device memory of the ctx -> (device pointer, n, capacity) for shard_stitch."""
+        p, n, cap = C.c_void_p(), C.c_uint64(), C.c_uint64()
+        _check(self.h, L.lib().bzq_shard_read_range(self.h, os.fsencode(path), int(lo), int(hi), int(halo_room), int(n_threads),
+                                                    C.byref(p), C.byref(n), C.byref(cap)), "bzq_shard_read_range")
+        return int(p.value or 0), int(n.value), int(cap.value)
+
     def shard_stitch(self, d_ptr: int, n: int, capacity: int) -> "ShardResult":
         raw = L.BzqShardResult()
         _check(self.h, L.lib().bzq_shard_stitch(self.h, C.c_void_p(d_ptr), n, capacity, C.byref(raw)), "bzq_shard_stitch")

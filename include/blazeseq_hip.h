@@ -363,6 +363,14 @@ typedef struct bzq_shard_result {
  * memory, 16-byte aligned, the rank's n bytes at its start.  Collective: every rank calls it once per step.  Without a
  * communicator (or nranks == 1) the same code runs with no exchange. */
 int32_t bzq_shard_stitch(bzq_ctx* ctx, uint8_t* d_shard, uint64_t n, uint64_t capacity, bzq_shard_result* out);
+/* File-chunk sharding: bytes [lo, hi) of the file at `path` -- rank r of N takes [size r / N, size (r + 1) / N), aligned to
+ * nothing -- into device memory of the ctx, ready for bzq_shard_stitch: n_threads reader threads (0 = 8) pread() 16 MiB pieces
+ * into pinned buffers of their own and copy them to the device on streams of their own (what FileReader.read_to_buffer,
+ * io/readers.mojo:86-137, does for the reference, for the whole range and with the copy under the next read).  *d_shard:
+ * 16-byte aligned, *capacity = the range + max(halo_room, 4 MiB) bytes of room for the halo; owned by the ctx, valid until
+ * the next bzq_shard_read_range on it or bzq_destroy.  Not collective: every rank reads for itself. */
+int32_t bzq_shard_read_range(bzq_ctx* ctx, const char* path, uint64_t lo, uint64_t hi, uint64_t halo_room, int32_t n_threads,
+                             uint8_t** d_shard, uint64_t* n, uint64_t* capacity);
 /* records, bases (sequence bytes), bytes over all ranks after the last bzq_shard_stitch */
 int32_t bzq_global_counts(bzq_ctx* ctx, uint64_t out[3]);
 

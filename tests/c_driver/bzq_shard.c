@@ -74,10 +74,19 @@ int main(int argc, char** argv) {
 
     if ((rc = bzq_comm_selftest(ctx)) != 0) die(ctx, "bzq_comm_selftest", rc);
 
-    const uint64_t capacity = n + (4u << 20);   /* room for the halo */
+    uint64_t capacity = n + (4u << 20);   /* room for the halo */
     void* d_shard = NULL;
-    if ((rc = bzq_device_alloc(ctx, capacity, &d_shard)) != 0) die(ctx, "bzq_device_alloc", rc);
-    if ((rc = bzq_copy_to_device(ctx, d_shard, host, n)) != 0) die(ctx, "bzq_copy_to_device", rc);
+    const char* lib_read = getenv("BZQ_SHARD_LIB_READ");   /* N > 0: the LIBRARY reads the rank's byte range of the file (N reader threads) */
+    if (lib_read && atoi(lib_read) > 0) {
+        uint8_t* p = NULL;
+        uint64_t got = 0;
+        if ((rc = bzq_shard_read_range(ctx, argv[5], lo, hi, 4u << 20, atoi(lib_read), &p, &got, &capacity)) != 0) die(ctx, "bzq_shard_read_range", rc);
+        if (got != n) { fprintf(stderr, "bzq_shard_read_range: %llu bytes, expected %llu\n", (unsigned long long)got, (unsigned long long)n); return 2; }
+        d_shard = p;
+    } else {
+        if ((rc = bzq_device_alloc(ctx, capacity, &d_shard)) != 0) die(ctx, "bzq_device_alloc", rc);
+        if ((rc = bzq_copy_to_device(ctx, d_shard, host, n)) != 0) die(ctx, "bzq_copy_to_device", rc);
+    }
 
     bzq_shard_result res;
     /* BZQ_SHARD_INJECT_MISALIGN=R: rank R hands in a pointer the library refuses -- a failure only that rank sees; the call
@@ -118,7 +127,7 @@ int main(int argc, char** argv) {
         if (m >= 0) { printf("# error: "); fwrite(msg, 1, (size_t)(m < 4095 ? m : 4095), stdout); printf("\n"); }
     }
     bzq_comm_destroy(ctx);
-    bzq_device_free(ctx, d_shard);
+    if (!(lib_read && atoi(lib_read) > 0)) bzq_device_free(ctx, d_shard);   /* (the library's own buffer goes with the ctx) */
     bzq_destroy(ctx);
     free(host); free(q); free(s); free(id); free(ends); free(id_ends);
     return 0;

@@ -61,3 +61,17 @@ def test_bench_sharded_harness_torch_cross_check_and_fasta():
     assert out["n_gpus"] == 2 and out["config"]["exchange"] == "torch"
     out = _run(3, ["--fasta"], 20_000)
     assert out["n_gpus"] == 3 and "byte-range shards over 3 rank(s)" in out["config"]["parallelism"]
+
+
+@pytest.mark.gpu
+def test_bench_from_file_mode_shards_one_file_across_the_ranks():
+    """bench.py --from-file: the stream is ONE file on /dev/shm, every rank reads its own byte range of it per
+    step (bzq_shard_read_range) and the ranks stitch; the line counts the whole stream's bytes per step."""
+    reads = 150_000
+    out = _run(3, ["--from-file", "--reader-threads", "3"], reads)
+    assert out["n_gpus"] == 3 and out["config"]["exchange"] == "native"
+    ff = out["from_file"]
+    assert ff and abs(ff["file_gb"] - 3 * reads * out["config"]["record_bytes"] / 1e9) < 1e-3 and ff["reader_threads"] == 3
+    assert not os.path.exists(ff["path"])   # removed again
+    total_bytes = reads * 3 * out["config"]["record_bytes"]
+    assert abs(out["value"] - total_bytes / (out["ms_per_step"] * 1e-3) / 1e9) <= 0.01 * out["value"] + 0.01
