@@ -173,6 +173,7 @@ struct bzq_ctx {
     int tail_code = 0, tail_phase_dec = 0;
     int64_t tail_cap_dec = 0;
     struct bzq_comm* comm = nullptr;   // multi-GPU exchange (bzq_comm.hpp), owned
+    int64_t comm_timeout_ms = 120000;  // option "comm_timeout_ms": host-side deadline of every exchange of the shard protocols
     uint64_t shard_totals[3] = {0, 0, 0};   // records, bases, bytes over all ranks after the last bzq_shard_stitch
     bool have_shard_totals = false;
     float ms_scan_shard = 0.f;         // kernels of the bzq_shard_scan that preceded this submit (pass A + scan)
@@ -1096,6 +1097,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "views_bytes")) c->views_bytes = (int)value;
     else if (!strcmp(key, "overlap")) c->overlap = (int)value;
     else if (!strcmp(key, "records_before")) c->records_before = value;
+    else if (!strcmp(key, "comm_timeout_ms")) { if (value <= 0) { c->err = "comm_timeout_ms must be positive"; return BZQ_ERR_ARG; } c->comm_timeout_ms = value; }
     else if (!strcmp(key, "pass_bytes")) c->cfg.pass_bytes = value > 0 ? std::max<int64_t>(TILE, (value / TILE) * TILE) : 0;
     else { c->err = std::string("unknown option ") + key; return BZQ_ERR_ARG; }
     return 0;
@@ -1839,6 +1841,7 @@ int32_t bzq_generate_synthetic_device(bzq_ctx* c, int64_t num_reads, int64_t fir
 }
 
 #include "bzq_comm.hpp"
+namespace { double comm_timeout_s(const bzq_ctx* c) { return (double)c->comm_timeout_ms / 1e3; } }
 
 // ---- host ingest pipeline (bzq_ingest.hpp) ---------------------------------------------------------------------
 

@@ -36,6 +36,7 @@ struct bzq_comm {
     void* nccl = nullptr;   // ncclComm_t
     int (*p_CommInitRank)(void**, int, bzq_nccl_id, int) = nullptr;
     int (*p_CommDestroy)(void*) = nullptr;
+    int (*p_CommAbort)(void*) = nullptr;
     int (*p_AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*p_Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*p_Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
@@ -52,6 +53,14 @@ struct bzq_comm {
     size_t seg_bytes = 0;
     uint64_t halo_cap = 0;
     std::string shm_name;
+    // ---- deadlines: every exchange has a host-side limit (option "comm_timeout_ms"); when it passes, the call fails with the
+    // ranks that never arrived BY NAME.  Over RCCL nothing tells a rank who is missing, so the ranks of one node also keep a
+    // presence board in shared memory ("/bzq_board_<hash of the ncclUniqueId>": one counter per rank, bumped on entering an
+    // exchange); the shm transport keeps the same counters inside its own segment.
+    int board_fd = -1;
+    std::atomic<uint64_t>* board = nullptr;   // [nranks] exchanges entered so far
+    std::string board_name;
+    uint64_t exchanges = 0;                   // exchanges this rank has entered
 };
 
 namespace {
@@ -69,11 +78,41 @@ struct ShmHeader {
 static_assert(sizeof(ShmHeader) == 64, "ShmHeader is one cache line");
 constexpr uint32_t SHM_MAGIC = 0x425A5131u;   // "BZQ1"
 
-int64_t* shm_rows(bzq_comm* m) { return (int64_t*)(m->seg + sizeof(ShmHeader)); }
-uint8_t* shm_halo(bzq_comm* m, int r) { return m->seg + sizeof(ShmHeader) + (size_t)m->nranks * COMM_ROW * 8 + (size_t)r * m->halo_cap; }
+// segment: header | one arrival counter per rank | the rows of an all-gather | one halo slot per rank
+size_t shm_board_bytes(int nranks) { return ((size_t)nranks * 8 + 63) & ~(size_t)63; }
+std::atomic<uint64_t>* shm_board(bzq_comm* m) { return (std::atomic<uint64_t>*)(m->seg + sizeof(ShmHeader)); }
+int64_t* shm_rows(bzq_comm* m) { return (int64_t*)(m->seg + sizeof(ShmHeader) + shm_board_bytes(m->nranks)); }
+uint8_t* shm_halo(bzq_comm* m, int r) { return m->seg + sizeof(ShmHeader) + shm_board_bytes(m->nranks) + (size_t)m->nranks * COMM_ROW * 8 + (size_t)r * m->halo_cap; }
 
-int shm_barrier(bzq_ctx* c, bzq_comm* m) {
+double comm_timeout_s(const bzq_ctx* c);   // option "comm_timeout_ms" (bzq_api.hip)
+
+extern "C++" {   // (this file is included inside an extern "C" block)
+// "rank 2, rank 5": the ranks whose arrival counter is behind `want` (nobody: an empty string)
+std::string comm_missing(bzq_comm* m, uint64_t want) {
+    std::string who;
+    if (!m->board) return who;
+    for (int r = 0; r < m->nranks; ++r)
+        if (m->board[r].load(std::memory_order_acquire) < want) who += (who.empty() ? "rank " : ", rank ") + std::to_string(r);
+    return who;
+}
+// this rank enters its next exchange
+uint64_t comm_arrive(bzq_comm* m) {
+    m->exchanges += 1;
+    if (m->board) m->board[m->rank].store(m->exchanges, std::memory_order_release);
+    return m->exchanges;
+}
+std::string comm_timeout_text(bzq_ctx* c, bzq_comm* m, uint64_t want, const char* what) {
+    const std::string who = comm_missing(m, want);
+    char t[32];
+    snprintf(t, sizeof t, "%.1f", comm_timeout_s(c));
+    return std::string("bzq_comm: ") + what + " did not complete within " + t + " s on rank " + std::to_string(m->rank) +
+           (who.empty() ? std::string(" (every rank entered it: the transport itself hangs)") : ": " + who + " never entered it");
+}
+}   // extern "C++"
+
+int shm_barrier(bzq_ctx* c, bzq_comm* m, const char* what = "a barrier") {
     ShmHeader* h = (ShmHeader*)m->seg;
+    const uint64_t want = comm_arrive(m);
     const uint32_t g = h->gen.load(std::memory_order_acquire);
     if (h->count.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)m->nranks) {
         h->count.store(0, std::memory_order_relaxed);
@@ -81,11 +120,31 @@ int shm_barrier(bzq_ctx* c, bzq_comm* m) {
         return 0;
     }
     const auto t0 = std::chrono::steady_clock::now();
+    const double limit = comm_timeout_s(c);
     for (uint32_t spins = 0; h->gen.load(std::memory_order_acquire) == g; ++spins) {
         if ((spins & 63) == 63) sched_yield();
-        if ((spins & 0xFFFF) == 0xFFFF && bzq::seconds_since(t0) > 120.0) { c->err = "bzq_comm(shm): a peer did not reach the barrier within 120 s"; return BZQ_ERR_IO; }
+        if ((spins & 0xFFF) == 0xFFF && bzq::seconds_since(t0) > limit) { c->err = comm_timeout_text(c, m, want, what); return BZQ_ERR_IO; }
     }
     return 0;
+}
+
+// RCCL: wait for the ctx stream with a deadline instead of hipStreamSynchronize (a collective a peer never joins does not
+// return, and neither does a synchronisation behind it)
+int comm_stream_wait(bzq_ctx* c, bzq_comm* m, uint64_t want, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const double limit = comm_timeout_s(c);
+    for (uint32_t spins = 0;; ++spins) {
+        const hipError_t q = hipStreamQuery(c->stream);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) { c->err = std::string(what) + ": " + hipGetErrorString(q); return BZQ_ERR_HIP; }
+        if (spins < 2000) sched_yield(); else usleep(50);
+        if ((spins & 0xFF) == 0xFF && bzq::seconds_since(t0) > limit) {
+            c->err = comm_timeout_text(c, m, want, what);
+            // the collective will never finish: take the communicator down so that the stream (and the process) can go on
+            if (m->nccl && m->p_CommAbort) { (void)m->p_CommAbort(m->nccl); m->nccl = nullptr; }
+            return BZQ_ERR_IO;
+        }
+    }
 }
 
 #define NCCLCHK(c, m, call)                                                                                         \
@@ -99,7 +158,7 @@ int shm_barrier(bzq_ctx* c, bzq_comm* m) {
 
 // all-gather of COMM_ROW int64 per rank, host to host.  `row` may be nullptr when d_row already holds the row on the
 // stream (RCCL only: the scan packed it there).
-int comm_gather(bzq_ctx* c, const int64_t* row, int64_t* all) {
+int comm_gather(bzq_ctx* c, const int64_t* row, int64_t* all, const char* what = "an all-gather") {
     bzq_comm* m = c->comm;
     if (!m) { if (row) memcpy(all, row, COMM_ROW * 8); return 0; }
     if (m->kind == 1) {
@@ -107,17 +166,19 @@ int comm_gather(bzq_ctx* c, const int64_t* row, int64_t* all) {
             memcpy(m->h_row, row, COMM_ROW * 8);
             HIPCHK(c, hipMemcpyAsync(m->d_row, m->h_row, COMM_ROW * 8, hipMemcpyHostToDevice, c->stream));
         }
+        const uint64_t want = comm_arrive(m);
         NCCLCHK(c, m, m->p_AllGather(m->d_row, m->d_all, COMM_ROW, NCCL_I64, m->nccl, c->stream));
         HIPCHK(c, hipMemcpyAsync(m->h_all, m->d_all, (size_t)m->nranks * COMM_ROW * 8, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        int wrc;
+        if ((wrc = comm_stream_wait(c, m, want, what))) return wrc;
         memcpy(all, m->h_all, (size_t)m->nranks * COMM_ROW * 8);
         return 0;
     }
     int rc;
     memcpy(shm_rows(m) + (size_t)m->rank * COMM_ROW, row, COMM_ROW * 8);
-    if ((rc = shm_barrier(c, m))) return rc;
+    if ((rc = shm_barrier(c, m, what))) return rc;
     memcpy(all, shm_rows(m), (size_t)m->nranks * COMM_ROW * 8);
-    return shm_barrier(c, m);   // nobody overwrites its row before everybody has read
+    return shm_barrier(c, m, what);   // nobody overwrites its row before everybody has read
 }
 
 // row = {bytes, newlines, first four newlines, first byte | last byte << 8, room behind the shard's bytes}
@@ -137,6 +198,9 @@ void comm_free(bzq_comm* m) {
         if (m->h_row) (void)hipHostFree(m->h_row);
         if (m->h_all) (void)hipHostFree(m->h_all);
         // the library handle stays open: RCCL keeps process-wide state and is shared with other users (torch)
+        if (m->board) munmap((void*)m->board, (size_t)m->nranks * 8);
+        if (m->board_fd >= 0) close(m->board_fd);
+        if (m->rank == 0 && !m->board_name.empty()) shm_unlink(m->board_name.c_str());
     } else if (m->kind == 2) {
         if (m->seg) munmap(m->seg, m->seg_bytes);
         if (m->shm_fd >= 0) close(m->shm_fd);
@@ -212,7 +276,7 @@ int32_t bzq_comm_init(bzq_ctx* c, int32_t rank, int32_t nranks, const void* nccl
         if (!m->dl) m->dl = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!m->dl) { c->err = std::string("bzq_comm_init: cannot load librccl.so.1: ") + dlerror(); delete m; return BZQ_ERR_IO; }
 #define BZQ_SYM(field, name) *(void**)(&m->field) = dlsym(m->dl, name)
-        BZQ_SYM(p_CommInitRank, "ncclCommInitRank"); BZQ_SYM(p_CommDestroy, "ncclCommDestroy"); BZQ_SYM(p_AllGather, "ncclAllGather");
+        BZQ_SYM(p_CommInitRank, "ncclCommInitRank"); BZQ_SYM(p_CommDestroy, "ncclCommDestroy"); BZQ_SYM(p_CommAbort, "ncclCommAbort"); BZQ_SYM(p_AllGather, "ncclAllGather");
         BZQ_SYM(p_Send, "ncclSend"); BZQ_SYM(p_Recv, "ncclRecv"); BZQ_SYM(p_GroupStart, "ncclGroupStart"); BZQ_SYM(p_GroupEnd, "ncclGroupEnd");
         BZQ_SYM(p_GetErrorString, "ncclGetErrorString");
 #undef BZQ_SYM
@@ -232,6 +296,21 @@ int32_t bzq_comm_init(bzq_ctx* c, int32_t rank, int32_t nranks, const void* nccl
             hipHostMalloc((void**)&m->h_all, (size_t)nranks * COMM_ROW * 8, hipHostMallocDefault) != hipSuccess) {
             c->err = "bzq_comm_init: staging buffers"; comm_free(m); return BZQ_ERR_NOMEM;
         }
+        // presence board of the node's ranks (best effort: without it a timeout still fails the call, it just cannot say who).
+        // Every rank opens-or-creates the same name (a fresh object is zero-filled; counters only grow), derived from the id.
+        {
+            uint64_t hsh = 1469598103934665603ull;
+            for (size_t i = 0; i < sizeof(id.internal); ++i) hsh = (hsh ^ (uint8_t)id.internal[i]) * 1099511628211ull;
+            char nm[64];
+            snprintf(nm, sizeof nm, "/bzq_board_%016llx", (unsigned long long)hsh);
+            m->board_name = nm;
+            m->board_fd = shm_open(nm, O_CREAT | O_RDWR, 0600);
+            if (m->board_fd >= 0 && ftruncate(m->board_fd, (off_t)((size_t)nranks * 8)) == 0) {
+                void* p = mmap(nullptr, (size_t)nranks * 8, PROT_READ | PROT_WRITE, MAP_SHARED, m->board_fd, 0);
+                if (p != MAP_FAILED) m->board = (std::atomic<uint64_t>*)p;
+            }
+            if (!m->board) { if (m->board_fd >= 0) close(m->board_fd); m->board_fd = -1; m->board_name.clear(); }
+        }
     }
     c->comm = m;
     return 0;
@@ -249,7 +328,7 @@ int32_t bzq_comm_init_shm(bzq_ctx* c, int32_t rank, int32_t nranks, const char* 
     m->rank = rank; m->nranks = nranks; m->kind = 2;
     m->halo_cap = halo_capacity ? halo_capacity : (4ull << 20);
     m->shm_name = std::string("/bzq_") + name;
-    m->seg_bytes = sizeof(ShmHeader) + (size_t)nranks * COMM_ROW * 8 + (size_t)nranks * m->halo_cap;
+    m->seg_bytes = sizeof(ShmHeader) + shm_board_bytes(nranks) + (size_t)nranks * COMM_ROW * 8 + (size_t)nranks * m->halo_cap;
     const auto t0 = std::chrono::steady_clock::now();
     auto drop = [&]() {
         if (m->seg) { munmap(m->seg, m->seg_bytes); m->seg = nullptr; }
@@ -312,12 +391,57 @@ int32_t bzq_comm_init_shm(bzq_ctx* c, int32_t rank, int32_t nranks, const char* 
         }
     }
     c->comm = m;
-    return shm_barrier(c, m);   // everybody is attached (rank 0 may unlink the name only after all have opened it)
+    m->board = shm_board(m);   // (inside the segment: unmapped with it)
+    return shm_barrier(c, m, "the attach barrier");   // everybody is attached (rank 0 may unlink the name only after all have opened it)
 }
 
-// One ring exchange through the communicator's transport, data checked: rank r sends a 4 KiB pattern to rank r+1 and expects
-// rank r-1's (at one rank: to itself), then an all-gather of the verdicts.  A host calls it once after bzq_comm_init, so that a
-// transport that does not work is reported before the first real step instead of inside it.
+// Heads travel to their owners (step 3 of the protocol; also what bzq_comm_selftest drives with synthetic plans): rank q's first
+// head_bytes bytes go behind the n bytes of rank head_dst, at halo_offset.  One grouped ncclSend / ncclRecv per rank -- a rank with
+// nothing to send and nothing to receive still opens and closes its (empty) group -- or two barriers around the host segment.  A
+// group that was opened is closed whatever happens inside it; a failure only this rank sees is noted (lrc / lerr) and the barriers
+// are still met; the return value is a failure of the transport itself (a deadline that passed included).
+extern "C++" {
+template <typename Plan>
+int comm_exchange_heads(bzq_ctx* c, bzq_comm* m, uint8_t* d_shard, uint64_t n, const std::vector<Plan>& plans, int& lrc, std::string& lerr) {
+    const int P = m ? m->nranks : 1, me = m ? m->rank : 0;
+    if (!m || P <= 1) return 0;
+    const Plan& pl = plans[(size_t)me];
+    auto note_hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && !lrc) { lrc = BZQ_ERR_HIP; lerr = std::string(what) + ": " + hipGetErrorString(e); } };
+    int rc;
+    if (m->kind == 1) {
+        auto nccl_note = [&](int r, const char* what) { if (r != 0 && !lrc) { lrc = BZQ_ERR_HIP; lerr = std::string(what) + ": " + (m->p_GetErrorString ? m->p_GetErrorString(r) : "RCCL error"); } return r; };
+        const uint64_t want = comm_arrive(m);
+        if (nccl_note(m->p_GroupStart(), "ncclGroupStart") == 0) {
+            if (pl.head_bytes > 0) nccl_note(m->p_Send(d_shard, (size_t)pl.head_bytes, NCCL_U8, pl.head_dst, m->nccl, c->stream), "ncclSend");
+            for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
+                if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
+                    nccl_note(m->p_Recv(d_shard + n + plans[(size_t)q].halo_offset, (size_t)plans[(size_t)q].head_bytes, NCCL_U8, q, m->nccl, c->stream), "ncclRecv");
+            nccl_note(m->p_GroupEnd(), "ncclGroupEnd");
+        }
+        // (with a deadline: a peer that never posts its side leaves this rank's stream in the group for ever)
+        if ((rc = comm_stream_wait(c, m, want, "the exchange of the heads (grouped ncclSend / ncclRecv)"))) return rc;
+        return 0;
+    }
+    if (pl.head_bytes > 0) note_hip(hipMemcpy(shm_halo(m, me), d_shard, (size_t)pl.head_bytes, hipMemcpyDeviceToHost), "hipMemcpy(head to segment)");
+    if ((rc = shm_barrier(c, m, "the exchange of the heads"))) return rc;
+    for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
+        if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
+            note_hip(hipMemcpyAsync(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync(halo)");
+    note_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize(halo)");   // the bytes have left the segment before a peer may overwrite it, and are on the device before anything reads them
+    return shm_barrier(c, m, "the exchange of the heads");
+}
+}   // extern "C++"
+
+// Every exchange the protocol makes, with the shapes it makes them in and the data checked on arrival, before the first real
+// step (a host calls it once after bzq_comm_init*): a transport that does not work, or a peer that is not there, is reported
+// here -- by name, within the deadline -- instead of inside a step.  It drives comm_gather and comm_exchange_heads themselves:
+//   round 0  the summary all-gather from a DEVICE-resident row (the path bzq_shard_stitch takes over RCCL) and from a host row;
+//   round 1  every rank but the first sends a head of 40 000 bytes (a long read's remainder) to the rank before it;
+//   round 2  only the odd ranks send (313 bytes): the even ranks' groups hold a receive only, the last even rank's group may be
+//            EMPTY (nothing to send, nothing to receive -- the group is still opened and closed, as in a real step);
+//   round 3  a record longer than a shard: ranks 1 .. min(3, P - 1) all send to rank 0, which receives them at three offsets;
+//   round 4  the ring of the earlier versions (rank r -> r + 1; one rank: to itself) -- over RCCL only (the shm slots are per
+//            sender and the rounds above cover them).
 static __global__ void k_selftest_fill(uint32_t* p, uint32_t seed, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = seed * 2654435761u + (uint32_t)i * 40503u;
@@ -326,53 +450,109 @@ static __global__ void k_selftest_check(const uint32_t* p, uint32_t seed, int n,
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && p[i] != seed * 2654435761u + (uint32_t)i * 40503u) atomicAdd(bad, 1);
 }
+static __global__ void k_selftest_row(int64_t* row, int64_t rank) {
+    if (threadIdx.x < COMM_ROW) row[threadIdx.x] = rank * 1000 + threadIdx.x;
+}
 
 int32_t bzq_comm_selftest(bzq_ctx* c) {
     if (!c) return BZQ_ERR_ARG;
     bzq_comm* m = c->comm;
     if (!m) return 0;
     HIPCHK(c, hipSetDevice(c->device));
-    constexpr int WORDS = 1024;
-    const int P = m->nranks, me = m->rank, to = (me + 1) % P, from = (me + P - 1) % P;
-    uint32_t* d = nullptr;
-    HIPCHK(c, hipMalloc((void**)&d, 2 * WORDS * 4 + 16));
-    int* d_bad = (int*)(d + 2 * WORDS);
-    int bad = 0, rc = 0;
-    hipLaunchKernelGGL(k_selftest_fill, dim3(WORDS / 256), dim3(256), 0, c->stream, d, (uint32_t)(me + 1), WORDS);
-    (void)hipMemsetAsync(d + WORDS, 0, WORDS * 4 + 16, c->stream);
+    const int P = m->nranks, me = m->rank;
+    constexpr uint64_t OWN = 65536, ROOM = 3 * 40000 + 64;   // "shard" bytes in front, room for the halo behind
+    uint8_t* d = nullptr;
+    HIPCHK(c, hipMalloc((void**)&d, OWN + ROOM + 64));
+    int* d_bad = (int*)(d + OWN + ROOM);
+    int rc = 0, lrc = 0;
+    std::string lerr;
+    int64_t bad_total = 0;
+    std::vector<int64_t> all((size_t)P * COMM_ROW);
+    auto done = [&](int r) { (void)hipFree(d); return r; };
+
+    // round 0: both forms of the all-gather
     if (m->kind == 1) {
-        auto ex = [&]() -> int {
-            NCCLCHK(c, m, m->p_GroupStart());
-            NCCLCHK(c, m, m->p_Send(d, WORDS * 4, NCCL_U8, to, m->nccl, c->stream));
-            NCCLCHK(c, m, m->p_Recv(d + WORDS, WORDS * 4, NCCL_U8, from, m->nccl, c->stream));
-            NCCLCHK(c, m, m->p_GroupEnd());
-            return 0;
-        };
-        rc = ex();
-    } else {
-        if (WORDS * 4 > (int)m->halo_cap) { (void)hipFree(d); c->err = "bzq_comm_selftest: halo capacity below 4 KiB"; return BZQ_ERR_ARG; }
-        if (hipMemcpy(shm_halo(m, me), d, WORDS * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = BZQ_ERR_HIP;
-        if (!rc) rc = shm_barrier(c, m);
-        // (on the stream and waited for: a plain hipMemcpy from pageable memory may return with the DMA still in flight on the
-        // null stream, which the ctx stream does not wait for)
-        if (!rc && (hipMemcpyAsync(d + WORDS, shm_halo(m, from), WORDS * 4, hipMemcpyHostToDevice, c->stream) != hipSuccess ||
-                    hipStreamSynchronize(c->stream) != hipSuccess)) rc = BZQ_ERR_HIP;
-        if (!rc) rc = shm_barrier(c, m);
+        hipLaunchKernelGGL(k_selftest_row, dim3(1), dim3(64), 0, c->stream, m->d_row, (int64_t)me);
+        if ((rc = comm_gather(c, nullptr, all.data(), "the selftest's all-gather (device row)"))) return done(rc);
+        for (int r = 0; r < P; ++r)
+            for (int w = 0; w < COMM_ROW; ++w)
+                if (all[(size_t)r * COMM_ROW + w] != (int64_t)r * 1000 + w) bad_total += 1;
     }
-    if (!rc) {
-        hipLaunchKernelGGL(k_selftest_check, dim3(WORDS / 256), dim3(256), 0, c->stream, d + WORDS, (uint32_t)(from + 1), WORDS, d_bad);
-        if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = BZQ_ERR_HIP;
+    {
+        int64_t row[COMM_ROW];
+        for (int w = 0; w < COMM_ROW; ++w) row[w] = (int64_t)me * 77 + w;
+        if ((rc = comm_gather(c, row, all.data(), "the selftest's all-gather (host row)"))) return done(rc);
+        for (int r = 0; r < P; ++r)
+            for (int w = 0; w < COMM_ROW; ++w)
+                if (all[(size_t)r * COMM_ROW + w] != (int64_t)r * 77 + w) bad_total += 1;
+    }
+
+    // rounds 1-3: comm_exchange_heads with synthetic plans (what bzq_plan_shards would produce for such streams)
+    for (int round = 1; round <= 3 && P > 1; ++round) {
+        std::vector<bzq_shard_plan> plans((size_t)P);
+        for (int r = 0; r < P; ++r) { memset(&plans[(size_t)r], 0, sizeof(bzq_shard_plan)); plans[(size_t)r].head_dst = -1; plans[(size_t)r].halo_first_src = -1; }
+        auto send = [&](int from, int to, uint64_t bytes) {
+            bzq_shard_plan &p = plans[(size_t)from], &o = plans[(size_t)to];
+            p.head_bytes = bytes; p.head_dst = to; p.halo_offset = o.halo_bytes;
+            o.halo_bytes += bytes;
+            if (o.halo_first_src < 0) o.halo_first_src = from;
+            o.halo_n_src = from - o.halo_first_src + 1;
+        };
+        if (round == 1) { for (int r = 1; r < P; ++r) send(r, r - 1, 40000); }
+        else if (round == 2) { for (int r = 1; r < P; r += 2) send(r, r - 1, 313); }
+        else { for (int r = 1; r < P && r <= 3; ++r) send(r, 0, 40000 - 1000 * (uint64_t)r); }
+        if (m->kind == 2)
+            for (int r = 0; r < P; ++r)
+                if (plans[(size_t)r].head_bytes > m->halo_cap) { c->err = "bzq_comm_selftest: the communicator's halo capacity is below 40 000 bytes"; return done(BZQ_ERR_ARG); }
+        // own bytes: a pattern that names (rank, round); the halo room: cleared
+        const int words = (int)(OWN / 4);
+        hipLaunchKernelGGL(k_selftest_fill, dim3((words + 255) / 256), dim3(256), 0, c->stream, (uint32_t*)d, (uint32_t)(me * 16 + round), words);
+        (void)hipMemsetAsync(d + OWN, 0, ROOM + 64, c->stream);
+        // (the exchange takes a shard that IS there, like bzq_shard_stitch's: the shm transport copies it out on the null stream)
+        if (hipStreamSynchronize(c->stream) != hipSuccess && !lrc) { lrc = BZQ_ERR_HIP; lerr = "bzq_comm_selftest: filling the pattern"; }
+        if ((rc = comm_exchange_heads(c, m, d, OWN, plans, lrc, lerr))) return done(rc);
+        const bzq_shard_plan& pl = plans[(size_t)me];
+        for (int q = pl.halo_first_src; !lrc && q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q) {
+            const bzq_shard_plan& src = plans[(size_t)q];
+            if (src.head_bytes == 0 || src.head_dst != me) continue;
+            // (heads are whole words in rounds 1 and 3; round 2's 313 bytes: the 78 whole words)
+            const int nw = (int)(src.head_bytes / 4);
+            if (src.halo_offset % 4 == 0)
+                hipLaunchKernelGGL(k_selftest_check, dim3((nw + 255) / 256), dim3(256), 0, c->stream, (const uint32_t*)(d + OWN + src.halo_offset), (uint32_t)(q * 16 + round), nw, d_bad);
+        }
+        int bad = 0;
+        if (!lrc && (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) { lrc = BZQ_ERR_HIP; lerr = "bzq_comm_selftest: reading the verdict back"; }
+        bad_total += bad;
+    }
+
+    // round 4 (RCCL): the ring, P == 1 included (send and receive to itself inside one group)
+    if (m->kind == 1 && !lrc) {
+        constexpr int WORDS = 1024;
+        const int to = (me + 1) % P, from = (me + P - 1) % P;
+        uint32_t* w = (uint32_t*)d;
+        hipLaunchKernelGGL(k_selftest_fill, dim3(WORDS / 256), dim3(256), 0, c->stream, w, (uint32_t)(me + 1), WORDS);
+        (void)hipMemsetAsync(w + WORDS, 0, WORDS * 4, c->stream);
+        (void)hipMemsetAsync(d_bad, 0, 4, c->stream);
+        const uint64_t want = comm_arrive(m);
+        NCCLCHK(c, m, m->p_GroupStart());
+        NCCLCHK(c, m, m->p_Send(w, WORDS * 4, NCCL_U8, to, m->nccl, c->stream));
+        NCCLCHK(c, m, m->p_Recv(w + WORDS, WORDS * 4, NCCL_U8, from, m->nccl, c->stream));
+        NCCLCHK(c, m, m->p_GroupEnd());
+        if ((rc = comm_stream_wait(c, m, want, "the selftest's ring exchange"))) return done(rc);
+        int bad = 0;
+        hipLaunchKernelGGL(k_selftest_check, dim3(WORDS / 256), dim3(256), 0, c->stream, w + WORDS, (uint32_t)(from + 1), WORDS, d_bad);
+        if (hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) { lrc = BZQ_ERR_HIP; lerr = "bzq_comm_selftest: reading the verdict back"; }
+        bad_total += bad;
     }
     (void)hipFree(d);
-    if (rc) return rc;
-    int64_t row[COMM_ROW] = {bad, 0, 0, 0, 0, 0, 0, 0};
-    std::vector<int64_t> all((size_t)P * COMM_ROW);
-    if ((rc = comm_gather(c, row, all.data()))) return rc;
-    for (int r = 0; r < P; ++r)
-        if (all[(size_t)r * COMM_ROW] != 0) {
-            c->err = "bzq_comm_selftest: rank " + std::to_string(r) + " received " + std::to_string(all[(size_t)r * COMM_ROW]) + " wrong words from rank " + std::to_string((r + P - 1) % P);
-            return BZQ_ERR_IO;
-        }
+    // the verdicts: everybody learns of everybody's (collective failure, like the protocol's)
+    int64_t row[COMM_ROW] = {bad_total, lrc, 0, 0, 0, 0, 0, 0};
+    if ((rc = comm_gather(c, row, all.data(), "the selftest's all-gather of the verdicts"))) return rc;
+    for (int r = 0; r < P; ++r) {
+        const int64_t* w = &all[(size_t)r * COMM_ROW];
+        if (w[1] != 0) { c->err = r == me ? lerr : "bzq_comm_selftest: rank " + std::to_string(r) + " failed (" + std::to_string(w[1]) + ")"; return r == me ? lrc : BZQ_ERR_IO; }
+        if (w[0] != 0) { c->err = "bzq_comm_selftest: rank " + std::to_string(r) + " received " + std::to_string(w[0]) + " wrong words"; return BZQ_ERR_IO; }
+    }
     return 0;
 }
 
@@ -417,7 +597,7 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
     if (!lrc) note(shard_scan_enqueue(c, d_shard, n));
     if (!lrc && m && m->kind == 1 && n > 0) {
         hipLaunchKernelGGL(k_pack_summary, dim3(1), dim3(1), 0, c->stream, (const ChunkState*)c->d_state, (int64_t)n, (int64_t)(capacity - n), m->d_row);
-        if ((rc = comm_gather(c, nullptr, all.data()))) return rc;
+        if ((rc = comm_gather(c, nullptr, all.data(), "the all-gather of the shard summaries"))) return rc;
         shard_scan_finish(c, d_shard, n, &sums[(size_t)me]);
     } else {
         int64_t row[COMM_ROW] = {0, 0, -1, -1, -1, -1, 0, 0};
@@ -431,7 +611,7 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
         } else {
             row[6] = (int64_t)(uint32_t)(-lrc) << 32;   // an empty shard that says why
         }
-        if ((rc = comm_gather(c, row, all.data()))) return rc;
+        if ((rc = comm_gather(c, row, all.data(), "the all-gather of the shard summaries"))) return rc;
     }
     if ((rc = everybody_fails(all, 6, 32, "before the shards were exchanged"))) return rc;
     uint64_t stream_pos = 0, total_bytes = 0;
@@ -462,26 +642,8 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
         for (int r = 0; r < P; ++r)   // (the capacity is the same on every rank: all of them fail together)
             if (plans[(size_t)r].head_bytes > m->halo_cap) { c->err = "bzq_shard_stitch(shm): rank " + std::to_string(r) + "'s head of " + std::to_string(plans[(size_t)r].head_bytes) + " bytes exceeds the halo capacity the communicator was created with"; return BZQ_ERR_ARG; }
 
-    // 3. heads travel to their owners.  A group that was opened is closed whatever happens inside it; a copy that fails is
-    // noted and the barriers are still met.
-    if (m && m->kind == 1 && P > 1) {
-        auto nccl_note = [&](int r, const char* what) { if (r != 0 && !lrc) { lrc = BZQ_ERR_HIP; lerr = std::string(what) + ": " + (m->p_GetErrorString ? m->p_GetErrorString(r) : "RCCL error"); } return r; };
-        if (nccl_note(m->p_GroupStart(), "ncclGroupStart") == 0) {
-            if (pl.head_bytes > 0) nccl_note(m->p_Send(d_shard, (size_t)pl.head_bytes, NCCL_U8, pl.head_dst, m->nccl, c->stream), "ncclSend");
-            for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
-                if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
-                    nccl_note(m->p_Recv(d_shard + n + plans[(size_t)q].halo_offset, (size_t)plans[(size_t)q].head_bytes, NCCL_U8, q, m->nccl, c->stream), "ncclRecv");
-            nccl_note(m->p_GroupEnd(), "ncclGroupEnd");
-        }
-    } else if (m && P > 1) {
-        if (pl.head_bytes > 0) note_hip(hipMemcpy(shm_halo(m, me), d_shard, (size_t)pl.head_bytes, hipMemcpyDeviceToHost), "hipMemcpy(head to segment)");
-        if ((rc = shm_barrier(c, m))) return rc;
-        for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
-            if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
-                note_hip(hipMemcpyAsync(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync(halo)");
-        note_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize(halo)");   // the bytes have left the segment before a peer may overwrite it, and are on the device before anything reads them
-        if ((rc = shm_barrier(c, m))) return rc;
-    }
+    // 3. heads travel to their owners
+    if ((rc = comm_exchange_heads(c, m, d_shard, n, plans, lrc, lerr))) return rc;
 
     // 4. parse own bytes + halo (a rank whose whole shard is the middle of somebody else's record delivers nothing)
     const bool owner = n > 0 && pl.head_bytes < n;
@@ -508,7 +670,7 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
         int64_t row[COMM_ROW] = {(int64_t)res.n_records, (int64_t)res.seq_bytes, (int64_t)n, failed ? res.error_record : -1, res.status,
                                  owner && c->tail_pending && !lrc ? 1 : 0, owner ? 1 : 0, lrc};
         rows.assign((size_t)P * COMM_ROW, 0);
-        return comm_gather(c, row, rows.data());
+        return comm_gather(c, row, rows.data(), "the all-gather of the outcomes");
     };
     std::vector<int64_t> oc;
     if ((rc = gather_outcomes(oc))) { c->tail_mode = 0; return rc; }
@@ -543,7 +705,7 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
                     st_row[0] = s.w; st_row[1] = s.end; st_row[2] = s.cap; st_row[3] = s.eof ? 1 : 0; st_row[4] = head; st_row[5] = 1;
                 }
             }
-            if ((rc = comm_gather(c, st_row, st_all.data()))) { c->tail_mode = 0; return rc; }
+            if ((rc = comm_gather(c, st_row, st_all.data(), "the walk of the reader's window through the ranks"))) { c->tail_mode = 0; return rc; }
             const int64_t* w = &st_all[(size_t)round * COMM_ROW];
             if (w[5] && round != me) { s = Window(); s.N = (int64_t)total_bytes; s.w = w[0]; s.end = w[1]; s.cap = w[2]; s.eof = w[3] != 0; head = w[4]; have = true; }
         }

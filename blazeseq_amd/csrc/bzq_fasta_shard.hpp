@@ -130,28 +130,13 @@ int32_t bzq_fasta_shard_stitch(bzq_ctx* c, bzq_fasta* h, uint8_t* d_shard, uint6
             if (plans[(size_t)r].head_bytes > m->halo_cap)
                 return fail("bzq_fasta_shard_stitch(shm): rank " + std::to_string(r) + "'s head of " + std::to_string(plans[(size_t)r].head_bytes) + " bytes exceeds the halo capacity the communicator was created with", BZQ_ERR_ARG);
 
-    // 3. heads travel to their owners (an opened group is always closed; a failed copy is noted and the barriers are still met)
+    // 3. heads travel to their owners (comm_exchange_heads, bzq_comm.hpp: the FASTQ protocol's exchange, deadline included)
     if (m && P > 1) {
         note_hip(hipSetDevice(c->device), "hipSetDevice");
-        if (m->kind == 1) {
-            auto nccl_note = [&](int r, const char* what) { if (r != 0) note_msg(BZQ_ERR_HIP, std::string(what) + ": " + (m->p_GetErrorString ? m->p_GetErrorString(r) : "RCCL error")); return r; };
-            if (nccl_note(m->p_GroupStart(), "ncclGroupStart") == 0) {
-                if (pl.head_bytes > 0) nccl_note(m->p_Send(d_shard, (size_t)pl.head_bytes, NCCL_U8, pl.head_dst, m->nccl, c->stream), "ncclSend");
-                for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
-                    if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
-                        nccl_note(m->p_Recv(d_shard + n + plans[(size_t)q].halo_offset, (size_t)plans[(size_t)q].head_bytes, NCCL_U8, q, m->nccl, c->stream), "ncclRecv");
-                nccl_note(m->p_GroupEnd(), "ncclGroupEnd");
-            }
-            note_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize(halo)");   // the parse runs on the FASTA handle's stream
-        } else {
-            if (pl.head_bytes > 0) note_hip(hipMemcpy(shm_halo(m, me), d_shard, (size_t)pl.head_bytes, hipMemcpyDeviceToHost), "hipMemcpy(head to segment)");
-            if ((rc = shm_barrier(c, m))) return fail(c->err, rc);
-            for (int q = pl.halo_first_src; q >= 0 && q < pl.halo_first_src + pl.halo_n_src; ++q)
-                if (plans[(size_t)q].head_bytes > 0 && plans[(size_t)q].head_dst == me)
-                    note_hip(hipMemcpyAsync(d_shard + n + plans[(size_t)q].halo_offset, shm_halo(m, q), (size_t)plans[(size_t)q].head_bytes, hipMemcpyHostToDevice, c->stream), "hipMemcpyAsync(halo)");
-            note_hip(hipStreamSynchronize(c->stream), "hipStreamSynchronize(halo)");   // (on the device before the FASTA handle's stream parses them, out of the segment before a peer overwrites it)
-            if ((rc = shm_barrier(c, m))) return fail(c->err, rc);
-        }
+        int xl = 0;
+        std::string xe;
+        if ((rc = comm_exchange_heads(c, m, d_shard, n, plans, xl, xe))) return fail(c->err, rc);
+        if (xl) note_msg(xl, xe);
     }
 
     // 4. every owner parses [its first header line, end of range + halo) as one complete stream

@@ -72,7 +72,16 @@ int main(int argc, char** argv) {
         if ((rc = bzq_comm_init_shm(ctx, rank, nranks, argv[4], 0)) != 0) die(ctx, "bzq_comm_init_shm", rc);
     }
 
+    /* BZQ_SHARD_TIMEOUT_MS: the deadline of every exchange; BZQ_SHARD_INJECT_STALL="R:SECONDS[:early]": rank R sleeps before the
+     * stitch (or, with :early, before the selftest) -- its peers must fail within the deadline, naming it */
+    if (getenv("BZQ_SHARD_TIMEOUT_MS") && (rc = bzq_set_option(ctx, "comm_timeout_ms", atoll(getenv("BZQ_SHARD_TIMEOUT_MS")))) != 0) die(ctx, "bzq_set_option", rc);
+    const char* stall = getenv("BZQ_SHARD_INJECT_STALL");
+    int stall_rank = -1, stall_early = 0;
+    double stall_s = 0;
+    if (stall) { stall_rank = atoi(stall); const char* q = strchr(stall, ':'); if (q) { stall_s = atof(q + 1); stall_early = strstr(q + 1, ":early") != NULL; } }
+    if (stall_rank == rank && stall_early) { struct timespec ts = {(time_t)stall_s, (long)((stall_s - (time_t)stall_s) * 1e9)}; nanosleep(&ts, NULL); }
     if ((rc = bzq_comm_selftest(ctx)) != 0) die(ctx, "bzq_comm_selftest", rc);
+    if (stall_rank == rank && !stall_early) { struct timespec ts = {(time_t)stall_s, (long)((stall_s - (time_t)stall_s) * 1e9)}; nanosleep(&ts, NULL); }
 
     uint64_t capacity = n + (4u << 20);   /* room for the halo */
     void* d_shard = NULL;

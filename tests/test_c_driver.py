@@ -299,6 +299,35 @@ def test_a_failure_only_one_rank_sees_fails_the_call_on_every_rank(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("early", [False, True])
+def test_a_rank_that_hangs_fails_every_rank_within_the_deadline_and_is_named(early, tmp_path):
+    """every exchange has a host-side deadline (option comm_timeout_ms).  Rank 1 of 3 stalls for 8 s -- before
+    the stitch, or before it even joins the selftest -- with a deadline of 1.5 s: ranks 0 and 2 must come back with an error that
+    NAMES rank 1, well before it wakes up; rank 1 then finds nobody left and fails by the same deadline."""
+    _build()
+    exe = os.path.join(DRV, "bzq_shard")
+    data = b"".join(b"@r%d\nACGT\n+\nIIII\n" % i for i in range(3000))
+    path = tmp_path / "in.fastq"
+    path.write_bytes(data)
+    name = f"stall{os.getpid()}_{int(early)}"
+    env = dict(os.environ, BZQ_SHARD_TIMEOUT_MS="1500", BZQ_SHARD_INJECT_STALL="1:8" + (":early" if early else ""))
+    t0 = time.time()
+    procs = [subprocess.Popen([exe, "shm", str(r), "3", name, str(path)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env) for r in range(3)]
+    done_at = {}
+    res = [None] * 3
+    for r in (0, 2, 1):
+        res[r] = procs[r].communicate(timeout=60)
+        done_at[r] = time.time() - t0
+    assert [p.returncode for p in procs] == [2, 2, 2], [x[1][-300:] for x in res]
+    for r in (0, 2):
+        assert b"rank 1 never entered it" in res[r][1], res[r][1][-400:]
+        assert b"did not complete within 1.5 s" in res[r][1]
+        assert done_at[r] < 7.0, done_at          # long before rank 1 wakes up
+    assert done_at[1] < 8 + 6.0, done_at          # rank 1: wakes up alone, and gives up by the same deadline
+    assert b"never entered it" in res[1][1] or b"did not complete" in res[1][1]
+
+
+@pytest.mark.gpu
 def test_shm_init_ignores_the_stale_segment_of_a_crashed_run(tmp_path):
     """a fully initialised segment of the same name and shape left behind by a crashed run; rank 1 starts FIRST and
     finds it.  It must end up on the segment rank 0 creates afterwards."""
@@ -310,7 +339,7 @@ def test_shm_init_ignores_the_stale_segment_of_a_crashed_run(tmp_path):
     path.write_bytes(data)
     name = f"stale{os.getpid()}"
     halo = 4 << 20
-    seg = 64 + 2 * 8 * 8 + 2 * halo
+    seg = 64 + 64 + 2 * 8 * 8 + 2 * halo   # header, arrival counters, rows, halo slots
     with open(f"/dev/shm/bzq_{name}", "wb") as f:   # ShmHeader: magic, count, gen, nranks, halo_cap, attached, go
         f.write(struct.pack("<IIIIQII", 0x425A5131, 1, 7, 2, halo, 1, 1))
         f.truncate(seg)
