@@ -13,8 +13,10 @@ ap.add_argument("--gb", type=float, default=2.0)
 ap.add_argument("--slice-mb", type=int, default=48)
 ap.add_argument("--level", type=int, default=6)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--ms", type=int, default=0, help="1: eight blocks per wave (bzq_inflate_ms.hpp, the round-4 experiment); 0: one block per wave (the product)")
 args = ap.parse_args()
 ctx = B.Context()
+ctx.set_option("inflate_ms", args.ms)
 lib = L.lib()
 n_rec = args.slice_mb * (1 << 20) // 318
 size = ctx.generate_synthetic_device(n_rec, 150, 33, 73, "generic", 0, 0)
@@ -45,11 +47,17 @@ for r in range(reps):
 d_comp = torch.from_numpy(comp.copy()).cuda()
 d_out = torch.empty(out_bytes * reps + 64, dtype=torch.uint8, device="cuda")
 torch.cuda.synchronize()
+def run():
+    try:
+        ctx.bgzf_inflate(d_comp.data_ptr(), comp.size, tab, n * reps, d_out.data_ptr(), out_bytes * reps)
+    except RuntimeError:
+        if not os.environ.get("BZQ_IGNORE_FAIL"):   # (timing experiments with builds that decode wrongly on purpose)
+            raise
 for _ in range(2):
-    ctx.bgzf_inflate(d_comp.data_ptr(), comp.size, tab, n * reps, d_out.data_ptr(), out_bytes * reps)
+    run()
 t0 = time.perf_counter()
 for _ in range(args.steps):
-    ctx.bgzf_inflate(d_comp.data_ptr(), comp.size, tab, n * reps, d_out.data_ptr(), out_bytes * reps)
+    run()
 dt = (time.perf_counter() - t0) / args.steps
 ok = bool((d_out[:out_bytes] == buf[:size]).all()) and bool((d_out[out_bytes * (reps - 1):out_bytes * reps] == buf[:size]).all())
 print(f"BGZF level {args.level}: {len(plain)/1e6:.0f} MB of FASTQ -> {comp.size/1e6:.0f} MB ({len(plain)/comp.size:.2f}x), {n} blocks; "

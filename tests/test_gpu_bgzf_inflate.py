@@ -15,6 +15,10 @@ from tests.fastq_fuzz import rand_stream
 pytestmark = pytest.mark.gpu
 
 
+# the product kernel (one wave per block, bzq_inflate.hpp) and the round-4 one that decodes eight blocks per wave (bzq_inflate_ms.hpp;
+# option inflate_ms, off by default: profiles/r4_inflate_ms.md)
+MS_KERNELS, MS_IDS = [0, 1], ["wave_per_block", "eight_blocks_per_wave"]
+
 def inflate_on_device(ctx, comp: bytes) -> bytes:
     a = np.frombuffer(comp, dtype=np.uint8)
     blocks, n, consumed, out_bytes = ctx.bgzf_scan(a)
@@ -48,9 +52,11 @@ def payloads():
     yield "far_matches", (bytes(rng.integers(0, 256, 31000, dtype=np.uint8)) * 6)
 
 
+@pytest.mark.parametrize("ms", MS_KERNELS, ids=MS_IDS)
 @pytest.mark.parametrize("name,data", list(payloads()), ids=[n for n, _ in payloads()])
-def test_levels_and_strategies(name, data):
+def test_levels_and_strategies(name, data, ms):
     ctx = Context()
+    ctx.set_option("inflate_ms", ms)   # 1: the round-4 kernel that decodes eight blocks per wave (bzq_inflate_ms.hpp; an option, off by default)
     for level, strategy in [(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (0, zlib.Z_DEFAULT_STRATEGY),
                             (6, zlib.Z_FIXED), (6, zlib.Z_RLE), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_FILTERED)]:
         block = 65280 if level else 60000
@@ -61,8 +67,10 @@ def test_levels_and_strategies(name, data):
         assert got == data, (name, level, strategy, len(got), len(data))
 
 
-def test_block_sizes_around_the_edges():
+@pytest.mark.parametrize("ms", MS_KERNELS, ids=MS_IDS)
+def test_block_sizes_around_the_edges(ms):
     ctx = Context()
+    ctx.set_option("inflate_ms", ms)
     rng = np.random.default_rng(5)
     base = rand_stream(rng, n_records=700, max_len=150, dirty=0.0, tail=0)
     parts, want = [], []
@@ -84,7 +92,8 @@ def test_the_last_symbols_of_many_blocks():
         assert inflate_on_device(ctx, comp) == data, level
 
 
-def test_what_a_sequencer_writes():
+@pytest.mark.parametrize("ms", MS_KERNELS, ids=MS_IDS)
+def test_what_a_sequencer_writes(ms):
     """Quality runs, duplicate reads, poly-G tails (tests/gzip_util.py): overlapping and long matches, taken in pieces by the
     symbol loop."""
     from tests.gzip_util import sequencer_like
@@ -94,8 +103,10 @@ def test_what_a_sequencer_writes():
         assert inflate_on_device(ctx, bgzf_compress(data, block=65280, level=level)) == data, level
 
 
-def test_many_blocks_random_mix():
+@pytest.mark.parametrize("ms", MS_KERNELS, ids=MS_IDS)
+def test_many_blocks_random_mix(ms):
     ctx = Context()
+    ctx.set_option("inflate_ms", ms)
     rng = np.random.default_rng(8)
     parts, want = [], []
     for i in range(600):
@@ -117,11 +128,13 @@ def test_many_blocks_random_mix():
     assert inflate_on_device(ctx, b"".join(parts)) == b"".join(want)
 
 
-def test_corrupt_blocks_fail():
+@pytest.mark.parametrize("ms", MS_KERNELS, ids=MS_IDS)
+def test_corrupt_blocks_fail(ms):
     """A damaged payload fails -- a bad code, distance, length or size while decoding, or the CRC-32 of the output afterwards
     (RFC 1952 8.) -- unless the damage sits in bits the stream does not use; never a crash, a hang, a write outside the
     block's output or different bytes delivered."""
     ctx = Context()
+    ctx.set_option("inflate_ms", ms)
     rng = np.random.default_rng(2)
     data = rand_stream(rng, n_records=190, max_len=150, dirty=0.0, tail=0)
     good = bgzf_block(data)
@@ -149,9 +162,12 @@ def test_corrupt_blocks_fail():
         inflate_on_device(ctx, bytes(second))
 
 
-def test_crc_of_every_size_class():
+@pytest.mark.parametrize("ms", MS_KERNELS, ids=MS_IDS)
+def test_crc_of_every_size_class(ms):
     """The CRC pieces: 64 lanes x ceil(n / 64) bytes, the last lanes empty or short."""
     ctx = Context()
+    ctx.set_option("inflate_ms", ms)
+    ctx.set_option("inflate_ms", ms)
     rng = np.random.default_rng(4)
     parts, want = [], []
     for n in list(range(0, 200)) + [255, 256, 257, 4095, 4096, 4097, 65535, 65536]:
