@@ -2090,7 +2090,11 @@ int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int3
     if (!c || !path || !out) return BZQ_ERR_ARG;
     const int32_t rc = ingest_open_common(c->device, c->err, "bzq_ingest_open", path, chunk_bytes, n_threads, out, c->ingest_direct, c->ingest_numa,
                                           c->ingest_gpu_inflate ? (c->inflate_ms ? 3 : 1) : 0);
-    if (rc == 0) (*out)->ctx = c;
+    if (rc == 0) {
+        (*out)->ctx = c;
+        // a new stream: the window follower of an earlier one must not judge this one's tail
+        c->follow_on = false; c->stage_valid = false; c->records_before = -1;
+    }
     return rc;
 }
 
@@ -2190,7 +2194,10 @@ int32_t bzq_ingest_get_stats(const bzq_ingest* g, bzq_ingest_stats* out) {
     return 0;
 }
 
-void bzq_ingest_close(bzq_ingest* g) { bzq::ingest_free(g); }
+void bzq_ingest_close(bzq_ingest* g) {
+    if (g && g->ctx) { g->ctx->follow_on = false; g->ctx->stage_valid = false; g->ctx->records_before = -1; }   // (the stream is over: see bzq_ingest_open)
+    bzq::ingest_free(g);
+}
 
 // ---- the same pipeline in front of the FASTA parser (bzq_fasta.hip) -----------------------------------------------------
 

@@ -1914,7 +1914,11 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
 
     if (final_status == ST_EVENTS_FULL || final_status == ST_SPLIT) *more = 1;   // (cannot happen with the event table sized as it is; call again)
     if (*more) return 0;
-    const bool garbage = at_header && (final_status == ST_BAD_HEADER || (is_last && final_status == ST_NEED_MORE));
+    // bytes behind the last member that are no member are ignored like gzread ignores them -- but a member whose magic (1f 8b) is
+    // there and whose header or first block is cut off is a TRUNCATED file, never a clean end (gzread: "unexpected end of file"
+    // once the magic has matched)
+    const bool cut_member = at_header && is_last && final_status == ST_NEED_MORE && h->carry.size() >= 2 && h->carry[0] == 0x1f && h->carry[1] == 0x8b;
+    const bool garbage = at_header && !cut_member && (final_status == ST_BAD_HEADER || (is_last && final_status == ST_NEED_MORE));
     if (final_status == ST_BAD_HEADER && h->members_done == 0) return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: not a gzip stream (no member header at its start)");
     if (garbage && h->members_done > 0) { h->finished = true; h->carry.clear(); return 0; }   // trailing bytes that are no member: ignored, like gzread
     if (is_last) {

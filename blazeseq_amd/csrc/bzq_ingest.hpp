@@ -25,9 +25,10 @@
 namespace bzq {
 
 // chunks in flight between the reader threads and the parser: k is read while k-1 travels / is inflated and is parsed.
-// Two: a third slot was measured (BGZF 15.8 -> 16.0 GB/s end to end: the device inflate is already at 3/4 of its kernel rate
-// with two chunks' blocks in flight) and costs another 288 MiB of pinning in front of a mid-sized file (plain 3 GB file: 50 ->
-// 37 GB/s including the open).
+// Three since round 3: with the asm symbol loop the device inflate of a 256 MiB chunk (4 000 blocks) fills a third of the device,
+// and a third chunk's blocks in flight took BGZF end to end from 17.9 to 27-33 GB/s (16 GB file); a .gz decoded on the device reads
+// its compressed pieces ahead into the third slot.  The price is a third pinned buffer of reserve + chunk bytes at every open
+// (~13 ms when the three are pinned side by side, ingest_open_common; bench.py's ingest_mode reports open_ms / close_ms).
 constexpr int INGEST_SLOTS = 3;
 
 struct IngestSlot {

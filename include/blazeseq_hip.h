@@ -395,7 +395,10 @@ int32_t bzq_bgzf_scan(const uint8_t* comp, uint64_t n, uint64_t max_out, bzq_bgz
                       uint64_t* consumed, uint64_t* out_bytes);
 /* Inflate blocks[0..n_blocks) of the device-resident compressed bytes d_comp[0, comp_bytes) (8 readable bytes of padding
  * behind them are not required) into d_out.  ISIZE, every match distance and length and the CRC-32 of every block's output are checked.
- * Synchronous on the ctx stream.  BZQ_ERR_IO: a block does not decode (bzq_last_error names the first). */
+ * Synchronous on the ctx stream.  BZQ_ERR_IO: a block does not decode (bzq_last_error names the first).
+ * Precondition (BZQ_ERR_ARG otherwise): the blocks are given in the order of their output -- out_offset must not decrease and
+ * the output ranges must not overlap (every block is written by a wave of its own without looking at the others); what
+ * bzq_bgzf_scan produces satisfies it. */
 int32_t bzq_bgzf_inflate(bzq_ctx* ctx, const uint8_t* d_comp, uint64_t comp_bytes, const bzq_bgzf_block* blocks, int64_t n_blocks,
                          uint8_t* d_out, uint64_t out_capacity);
 

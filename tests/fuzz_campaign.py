@@ -87,7 +87,7 @@ for seed in range(lo, hi):
         kw["buffer_capacity"] = int(rng.choice([64, 256, 4096, 65536]))
     if rng.random() < 0.15:
         kw["compat_simd_width"] = int(rng.choice([16, 32, 64]))
-    bs = int(rng.choice([1, 7, 100, 4096]))
+    bs = int(rng.choice([1, 7, 100, 256, 300, 4096]))   # (>= 256: the emit writes the per-batch ends itself, FusedArgs::fold)
     sp = [False, True, "v1"][int(rng.integers(0, 3))] if (EXPERIMENTS and rng.random() < 0.3 and not args.views) else False
     key = (bs, sp, tuple(sorted(kw.items())))
     if key not in pairs:

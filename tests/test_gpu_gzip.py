@@ -148,11 +148,27 @@ def test_trailing_garbage_is_ignored_like_gzread_does():
     data = synthetic_fastq(3000)
     comp = gzip.compress(data, 6)
     ctx = Context()
-    for junk in (b"\0" * 100, b"some text that is no gzip member", b"\x1f\x8b"):
+    for junk in (b"\0" * 100, b"some text that is no gzip member", b"\x1f", b"\x1f\x00\x8b"):
         g = DeviceGunzip(ctx, len(data) + 4096)
         assert g.decode(comp + junk, 50000) == data
         assert g.dec.finished
         g.close()
+
+
+def test_a_later_member_that_is_cut_off_is_a_truncated_file():
+    """once the magic 1f 8b has matched, gzread reports "unexpected end of file" for a member cut inside its header
+    or right behind it -- trailing bytes are only ignored when they are no member at all."""
+    data = synthetic_fastq(3000)
+    comp = gzip.compress(data, 6)
+    second = gzip.compress(b"@r\nACGT\n+\nIIII\n", 6)
+    ctx = Context()
+    for cut in (2, 3, 9, 10, 11, len(second) - 9):   # the magic alone, inside the fixed header, right behind it, inside the block, no trailer
+        g = DeviceGunzip(ctx, len(data) + 4096)
+        with pytest.raises(RuntimeError, match="truncated"):
+            g.decode(comp + second[:cut], 50000)
+        g.close()
+        with pytest.raises((EOFError, Exception)):
+            gzip.decompress(comp + second[:cut])   # (zlib agrees)
 
 
 def test_corrupt_streams_fail_the_call():

@@ -283,6 +283,7 @@ def _run_shards_on_one_gpu(data: np.ndarray, cuts, ocfg, single_pass=False, **kw
         n = bounds[r + 1] - bounds[r]
         t = torch.zeros(n + (1 << 17), dtype=torch.uint8, device="cuda")
         t[:n] = torch.from_numpy(data[bounds[r]:bounds[r + 1]].copy()).cuda()
+        torch.cuda.synchronize()   # torch's stream wrote it, the library's (non-blocking) stream reads it: seed 50820 of the campaign met the race
         ctx = B.Context(B.ParserConfig(**kw), "generic", 4096, 0)
         if single_pass:
             ctx.set_option("single_pass", int(single_pass))
@@ -297,6 +298,7 @@ def _run_shards_on_one_gpu(data: np.ndarray, cuts, ocfg, single_pass=False, **kw
         p = plans[r]
         if p.halo_src >= 0:
             bufs[r][n:n + p.halo_bytes] = bufs[p.halo_src][:p.halo_bytes]
+            torch.cuda.synchronize()
         is_last = all(s[0] == 0 for s in sums[r + 1:])
         ctxs[r].submit_shard(bufs[r].data_ptr(), n, p.halo_bytes, p.lines_before, p.prev_last_byte, bounds[r], is_last)
         res = ctxs[r].result()
