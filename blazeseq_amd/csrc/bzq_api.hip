@@ -115,7 +115,9 @@ struct bzq_ctx {
     ChunkState* d_state = nullptr;
     ChunkState* h_state = nullptr; // pinned
     hipEvent_t ev[8]{};
-    std::vector<hipEvent_t> ev_detail;
+    std::vector<hipEvent_t> ev_detail;        // events recorded by the current submit (option timing_detail) ...
+    std::vector<hipEvent_t> ev_detail_pool;   // ... taken from here: created once (creating and destroying eight events per submit was 2 % of a step)
+    size_t ev_detail_used = 0;
     // options
     int ablate = 0;
     int64_t pool_slots = 0;
@@ -207,6 +209,18 @@ namespace {
             return BZQ_ERR_HIP;                                                                  \
         }                                                                                        \
     } while (0)
+
+// option timing_detail: an event on the ctx stream between two phases of the current submit
+void mark_detail(bzq_ctx* c) {
+    if (c->ev_detail_used == c->ev_detail_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return;
+        c->ev_detail_pool.push_back(e);
+    }
+    hipEvent_t e = c->ev_detail_pool[c->ev_detail_used++];
+    (void)hipEventRecord(e, c->stream);
+    c->ev_detail.push_back(e);
+}
 
 int ensure(bzq_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;
@@ -484,9 +498,9 @@ int enqueue_fused(bzq_ctx* c) {
                            (const int64_t*)c->tileI.p, f.xcd_tiles, nt, xb);
         f.xcd_base = xb;
     }
-    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    if (c->timing_detail) mark_detail(c);
     launch_fused<true>(c, dim3((unsigned)nt), f);
-    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    if (c->timing_detail) mark_detail(c);
     c->n_passes = 1;
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->err = std::string("kernel launch: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
@@ -517,14 +531,14 @@ int enqueue_single(bzq_ctx* c) {
     sa.dc = d + 16; sa.pc = sa.dc + nt; sa.da = sa.pc + nt; sa.ps = sa.da + nt; sa.pq = sa.ps + nt; sa.pi = sa.pq + nt;
     sa.bc = sa.pi + nt; sa.bs = sa.bc + nb; sa.bq = sa.bs + nb; sa.bi = sa.bq + nb;
     const int mode = c->single_pass == 3 ? 1 : 0;
-    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    if (c->timing_detail) mark_detail(c);
     const dim3 grid((unsigned)(nt + (mode == 0 ? 1 : 0)));
     const bool ca = c->cfg.check_ascii != 0, cq = c->cfg.check_quality != 0, off = c->cfg.emit_offsets != 0;
     if (ca && cq) launch_single_off<true, true>(c, off, mode, grid, sa);
     else if (ca) launch_single_off<true, false>(c, off, mode, grid, sa);
     else if (cq) launch_single_off<false, true>(c, off, mode, grid, sa);
     else launch_single_off<false, false>(c, off, mode, grid, sa);
-    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    if (c->timing_detail) mark_detail(c);
     c->n_passes = 1;
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->err = std::string("kernel launch: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
@@ -550,14 +564,14 @@ int enqueue_stream(bzq_ctx* c) {
     StreamArgs sa{};
     sa.f = make_fused_args(c);
     sa.wd = (u64*)c->desc.p; sa.gd = sa.wd + (size_t)n_wg * WD_WORDS; sa.ticket = sa.gd + (size_t)n_grp * GD_WORDS; sa.n_wg = n_wg;
-    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    if (c->timing_detail) mark_detail(c);
     const dim3 grid((unsigned)n_wg);
     const bool ca = c->cfg.check_ascii != 0, cq = c->cfg.check_quality != 0, off = c->cfg.emit_offsets != 0;
     if (ca && cq) launch_stream_off<true, true>(c, off, grid, sa);
     else if (ca) launch_stream_off<true, false>(c, off, grid, sa);
     else if (cq) launch_stream_off<false, true>(c, off, grid, sa);
     else launch_stream_off<false, false>(c, off, grid, sa);
-    if (c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+    if (c->timing_detail) mark_detail(c);
     c->n_passes = 1;
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->err = std::string("kernel launch: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
@@ -645,7 +659,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
         const int64_t te = std::min(nt, tb + pt);
         const dim3 grid((unsigned)(te - tb));
         if (!emit_only) {
-            if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
+            if (c->timing_detail) mark_detail(c);
             if (!skip_aggregate_mid) {
                 AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p,
                           (u64*)c->tile_a.p, (u64*)c->tile_idc.p, walk_limit_of(c), (u64*)c->tile_last.p};
@@ -662,10 +676,10 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
                 else if (c->pass_a_h && !c->exact_pass_a && c->exact_sticky == 0) { hipLaunchKernelGGL(k_tile_aggregate_h, grid, dim3(BLOCK), 0, c->stream, a); c->used_h = true; }
                 else hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
             }
-            if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
+            if (c->timing_detail) mark_detail(c);
             launch_scan(c, tb, te, (int)passes);
             if (c->fold) launch_batch_bases(c);
-            if (c->timing_detail) { hipEvent_t e; (void)hipEventCreate(&e); (void)hipEventRecord(e, c->stream); c->ev_detail.push_back(e); }
+            if (c->timing_detail) mark_detail(c);
         } else if (c->fold) {
             // re-run after the per-record arrays were re-sized: the batch table grew with them, so the scan notes the boundary
             // tiles again (same prefixes as before) and the bases are computed again
@@ -699,7 +713,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
                 launch_fused<false>(c, grid, f);
             }
         }
-        if (!emit_only && c->timing_detail) { hipEvent_t ev; (void)hipEventCreate(&ev); (void)hipEventRecord(ev, c->stream); c->ev_detail.push_back(ev); }
+        if (!emit_only && c->timing_detail) mark_detail(c);
     }
     if (c->overlap && !emit_only && c->v2)
         for (int64_t k = 0; k < passes; ++k) (void)hipStreamWaitEvent(c->stream, c->ev_pipe[2 * k + 1], 0);
@@ -761,8 +775,7 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     if (!reuse_aggregates) c->used_h = false;   // (a shard's aggregates come from bzq_shard_scan, which says how it made them)
     c->cur = d_data; c->cur_n = n; c->cur_stream_pos = stream_pos; c->cur_is_eof = is_eof;
     c->cur_prev_byte = prev_byte; c->cur_first_header = first_header;
-    for (hipEvent_t e : c->ev_detail) (void)hipEventDestroy(e);
-    c->ev_detail.clear();
+    c->ev_detail.clear(); c->ev_detail_used = 0;
     ChunkState* h = c->h_state;
     memset(h, 0, sizeof(*h));
     h->P0 = P0; h->S0 = S0; h->Q0 = Q0; h->I0 = I0;
@@ -1037,7 +1050,7 @@ void bzq_destroy(bzq_ctx* c) {
     if (c->stage_pin) (void)hipHostFree(c->stage_pin);
     if (c->stage_ev) (void)hipEventDestroy(c->stage_ev);
     for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t e : c->ev_detail) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_detail_pool) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     for (hipEvent_t e : c->ev_pipe) (void)hipEventDestroy(e);

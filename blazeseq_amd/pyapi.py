@@ -4,8 +4,8 @@ records expose ``id / sequence / quality`` as ``str`` plus ``phred_scores`` and 
 ``num_records() / get_record(i)`` and iterate over records (pinned by the reference's
 tests/test_python_bindings.py, replayed in tests/test_gpu_pyapi.py).
 
-Everything below is plumbing over ``FastqParser`` (GPU chunks through the C ABI); .gz files are inflated by the ingest
-pipeline's reader threads (zlib; block-parallel for BGZF)."""
+Everything below is plumbing over ``FastqParser`` (GPU chunks through the C ABI); .gz files are inflated on the device by the
+ingest pipeline (BGZF: one wave per block, csrc/bzq_inflate.hpp; any other gzip file: csrc/bzq_gzip.hpp)."""
 from __future__ import annotations
 
 import os
