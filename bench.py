@@ -252,7 +252,9 @@ def ingest_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8):
     tag = f"bzq_bench_{os.getpid()}"
     paths = {m: os.path.join(d, f"{tag}.fastq{ext}") for m, ext in (("plain", ""), ("bgzf", ".bgz"), ("gzip", ".gz"))}
     res = {"file_fastq_gb": round(n_fastq / 1e9, 3), "records": n_rec, "reader_threads": threads, "dir": d,
-           "note": "wall clock of open + every chunk until EOF + close (every run opens cold: ~40 ms of pinning, ~40 ms of unpinning), best of 3; "
+           "note": "wall clock of open + every chunk until EOF + close.  value = best of 3 runs after the process's first one: the pinned and device chunk buffers of a "
+                   "closed file stay in the library's cache for the next open (bzq_bufcache.hpp; a host that parses file after file); first_file_of_the_process = the run "
+                   "with the cache empty (~40 ms of pinning at the open, ~40 ms of unpinning saved at the close); "
                    "the file sits on a RAM-backed filesystem like the reference's runs; pcie_frac = bytes that crossed PCIe / s / 64 GB/s"}
     try:
         co = zlib.compressobj(6, zlib.DEFLATED, -15)
@@ -272,8 +274,11 @@ def ingest_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8):
         ctx = B.Context(B.ParserConfig(), "generic", 4096, local_rank, min_record_bytes=256 if rec_bytes >= 256 else 32)
         for m in ("plain", "bgzf", "gzip"):
             fsize = os.path.getsize(paths[m])
-            best = None
-            for _ in range(3):
+            best = first = None
+            for key, dflt in (("pin_cache_bytes", 2 << 30), ("dev_cache_bytes", 8 << 30)):   # this mode's first run opens like a fresh process
+                ctx.set_option(key, 0)
+                ctx.set_option(key, dflt)
+            for _ in range(4):
                 t0 = time.perf_counter()
                 ing = B.Ingest(ctx, paths[m], chunk_bytes=256 << 20, n_threads=threads)
                 t1 = time.perf_counter()
@@ -288,11 +293,16 @@ def ingest_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8):
                 ing.close()
                 dt = time.perf_counter() - t0
                 assert total == n_rec and int(r.status) == L.EOF, (m, total, n_rec, int(r.status), ctx.format_error())
-                if best is None or dt < best[0]:
-                    best = (dt, t1 - t0, time.perf_counter() - t2)
+                run = (dt, t1 - t0, time.perf_counter() - t2)
+                if first is None:
+                    first = run
+                elif best is None or dt < best[0]:
+                    best = run
             res[m] = {"value": round(n_fastq / best[0] / 1e9, 2), "unit": "GB/s of FASTQ", "mrecords_per_s": round(n_rec / best[0] / 1e6, 1),
                       "ms": round(best[0] * 1e3, 1), "open_ms": round(best[1] * 1e3, 1), "close_ms": round(best[2] * 1e3, 1), "file_gb": round(fsize / 1e9, 3),
-                      "pcie_frac": round(fsize / best[0] / 1e9 / PCIE_PEAK_GBS, 3)}
+                      "pcie_frac": round(fsize / best[0] / 1e9 / PCIE_PEAK_GBS, 3),
+                      "first_file_of_the_process": {"value": round(n_fastq / first[0] / 1e9, 2), "ms": round(first[0] * 1e3, 1), "open_ms": round(first[1] * 1e3, 1),
+                                                    "close_ms": round(first[2] * 1e3, 1)}}
         ctx.close()
         # the reference algorithm on one host core, same files: plain = read + streaming parse; .gz = zlib inflate (GZFile) + parse on a bounded sample
         cfg = O.make_config(buffer_capacity=64 * 1024, batch_size=4096)

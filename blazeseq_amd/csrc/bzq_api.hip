@@ -933,6 +933,7 @@ void sb_put(std::string& s, const char* label, long long v) {
 #include "bzq_consumers.hpp"
 #include "bzq_inflate.hpp"
 #include "bzq_inflate_ms.hpp"
+#include "bzq_bufcache.hpp"
 #include "bzq_gzip.hpp"
 #include "bzq_ingest.hpp"
 
@@ -1042,7 +1043,7 @@ void bzq_destroy(bzq_ctx* c) {
         if (o.h_bb) (void)hipHostFree(o.h_bb);
     }
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
-    for (void* q : c->shard_pin) if (q) (void)hipHostFree(q);
+    for (void* q : c->shard_pin) bzq::cache::pinned_pool().put(q);
     for (hipStream_t q : c->shard_streams) if (q) (void)hipStreamDestroy(q);
     for (hipEvent_t q : c->shard_events) if (q) (void)hipEventDestroy(q);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -1115,6 +1116,15 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "overlap")) c->overlap = (int)value;
     else if (!strcmp(key, "records_before")) c->records_before = value;
     else if (!strcmp(key, "comm_timeout_ms")) { if (value <= 0) { c->err = "comm_timeout_ms must be positive"; return BZQ_ERR_ARG; } c->comm_timeout_ms = value; }
+    else if (!strcmp(key, "pin_cache_bytes") || !strcmp(key, "dev_cache_bytes")) {
+        // process-wide (bzq_bufcache.hpp): how many bytes of pinned / device buffers closed streams leave behind for the next open; 0 drops
+        // everything held now and turns the cache off
+        if (value < 0) { c->err = std::string(key) + " must not be negative"; return BZQ_ERR_ARG; }
+        HIPCHK(c, hipSetDevice(c->device));
+        (key[0] == 'p' ? bzq::cache::pinned_pool() : bzq::cache::device_pool()).trim((uint64_t)value, false);
+    }
+    else if (!strcmp(key, "buf_cache_hits")) { const uint64_t h = bzq::cache::pinned_pool().hits + bzq::cache::device_pool().hits; return (int32_t)std::min<uint64_t>(h, 0x7FFFFFFF); }   // query
+    else if (!strcmp(key, "buf_cache_held_mb")) return (int32_t)((bzq::cache::pinned_pool().held + bzq::cache::device_pool().held) >> 20);   // query
     else if (!strcmp(key, "pass_bytes")) c->cfg.pass_bytes = value > 0 ? std::max<int64_t>(TILE, (value / TILE) * TILE) : 0;
     else { c->err = std::string("unknown option ") + key; return BZQ_ERR_ARG; }
     return 0;
@@ -1972,7 +1982,7 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
             g->compression = 1;
             g->gz_cap = std::max<uint64_t>(6 * g->chunk_bytes, 64ull << 20);
             int grc = bzq::gz::gz_open(device, &g->gz_dev, err);
-            if (!grc && (hipMalloc((void**)&g->gz_fifo[0], g->gz_cap + 64) != hipSuccess || hipMalloc((void**)&g->gz_fifo[1], g->gz_cap + 64) != hipSuccess)) {
+            if (!grc && (!bzq::cache::get_device(device, g->gz_cap + 64, &g->gz_fifo[0]) || !bzq::cache::get_device(device, g->gz_cap + 64, &g->gz_fifo[1]))) {
                 err = std::string(who) + ": allocating the gzip FIFO failed"; grc = BZQ_ERR_NOMEM;
             }
             if (grc) { bzq::ingest_free(g); return grc; }
@@ -2068,7 +2078,7 @@ int32_t bzq_shard_read_range(bzq_ctx* c, const char* path, uint64_t lo, uint64_t
         for (int64_t k = w; k < pieces && !fail; k += T, ++i) {
             const int b = (int)(i & 1);
             void*& pin = c->shard_pin[2 * w + b];
-            if (!pin && hipHostMalloc(&pin, SHARD_PIECE, hipHostMallocDefault) != hipSuccess) { pin = nullptr; fail = 1; return; }   // (pinned here: T threads pin side by side)
+            if (!pin && bzq::cache::pinned_pool().get(c->device, SHARD_PIECE, &pin) != hipSuccess) { pin = nullptr; fail = 1; return; }   // (pinned here: T threads pin side by side)
             if (used[b] && hipEventSynchronize(c->shard_events[2 * w + b]) != hipSuccess) { fail = 3; return; }
             const uint64_t off = (uint64_t)k * SHARD_PIECE, len = std::min<uint64_t>(SHARD_PIECE, n - off);
             uint64_t got = 0;

@@ -1,0 +1,111 @@
+// Process-wide cache of the LARGE buffers a file-backed stream needs (round 4).
+//
+// Opening a file for the ingest pipeline pins three chunk-sized host buffers and allocates their device twins; closing it unpins
+// and frees them.  Measured on MI355X (bench.py ingest_mode, 256 MiB chunks): ~40 ms for the open and ~40 ms for the close, i.e.
+// 80 of the 195 ms a 6.4 GB file takes from open to close -- hipHostMalloc pins pages at ~20 GB/s and hipHostFree unpins them at
+// the same rate.  A host that parses file after file (the reference's runner opens one parser per file,
+// benchmark/throughput/run_throughput_blazeseq.mojo:28-55) pays that per file.  The buffers are therefore handed back to this cache
+// instead of the driver and the next open of the process takes them from here: same capacity class, same device.
+//
+// Rules: a buffer is only put back when no work that touches it is in flight (the callers synchronise first -- the cache skips the
+// implicit device synchronisation of hipFree); a request is served by the smallest cached buffer of the device with
+// want <= capacity <= 1.5 x want; the cache holds at most `limit` bytes per kind (options pin_cache_bytes / dev_cache_bytes, default
+// 2 GiB pinned and 8 GiB device; 0 drops everything held and turns the cache off; environment BZQ_BUF_CACHE=0 does the same for a
+// whole process); what does not fit goes back to the driver.  Buffers still cached when the process ends are the operating system's
+// to reclaim (the HIP runtime may already be gone in a static destructor).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+namespace bzq { namespace cache {
+
+struct Entry { void* p; uint64_t cap; int device; };
+
+struct Pool {
+    const bool pinned;
+    std::mutex mu;
+    std::vector<Entry> idle;
+    std::unordered_map<void*, Entry> out;   // handed out: capacity and device by pointer
+    uint64_t held = 0, limit;
+    uint64_t hits = 0, misses = 0;
+    Pool(bool pin, uint64_t lim) : pinned(pin), limit(lim) {
+        const char* e = getenv("BZQ_BUF_CACHE");
+        if (e && e[0] == '0') limit = 0;
+    }
+    hipError_t raw_alloc(void** p, uint64_t n) { return pinned ? hipHostMalloc(p, n, hipHostMallocDefault) : hipMalloc(p, n); }
+    void raw_free(void* p) { (void)(pinned ? hipHostFree(p) : hipFree(p)); }
+
+    // *out gets a buffer of at least `want` bytes on / for `device` (the caller has set the device)
+    hipError_t get(int device, uint64_t want, void** outp) {
+        *outp = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            int best = -1;
+            for (int i = 0; i < (int)idle.size(); ++i)
+                if (idle[i].device == device && idle[i].cap >= want && idle[i].cap <= want + want / 2 && (best < 0 || idle[i].cap < idle[best].cap)) best = i;
+            if (best >= 0) {
+                const Entry e = idle[best];
+                idle.erase(idle.begin() + best);
+                held -= e.cap;
+                out[e.p] = e;
+                *outp = e.p;
+                ++hits;
+                return hipSuccess;
+            }
+            ++misses;
+        }
+        void* p = nullptr;
+        hipError_t err = raw_alloc(&p, want);
+        if (err != hipSuccess) {   // the cache itself may be what is in the way
+            trim(0, true);
+            err = raw_alloc(&p, want);
+            if (err != hipSuccess) return err;
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        out[p] = Entry{p, want, device};
+        *outp = p;
+        return hipSuccess;
+    }
+    // a pointer from get(); nothing in flight may touch it any more
+    void put(void* p) {
+        if (!p) return;
+        Entry e{p, 0, 0};
+        bool keep = false;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = out.find(p);
+            if (it != out.end()) {
+                e = it->second;
+                out.erase(it);
+                if (e.cap >= (1ull << 20) && held + e.cap <= limit) { idle.push_back(e); held += e.cap; keep = true; }
+            }
+        }
+        if (!keep) raw_free(p);
+    }
+    // give buffers back to the driver until at most `keep_bytes` are held; set_limit: that is also the new limit
+    void trim(uint64_t keep_bytes, bool keep_limit) {
+        std::vector<Entry> drop;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (!keep_limit) limit = keep_bytes;
+            while (held > keep_bytes && !idle.empty()) {
+                drop.push_back(idle.back());
+                held -= idle.back().cap;
+                idle.pop_back();
+            }
+        }
+        for (const Entry& e : drop) raw_free(e.p);
+    }
+};
+
+inline Pool& pinned_pool() { static Pool* p = new Pool(true, 2ull << 30); return *p; }
+inline Pool& device_pool() { static Pool* p = new Pool(false, 8ull << 30); return *p; }
+
+template <class T> inline bool get_pinned(int device, uint64_t want, T** out) { return pinned_pool().get(device, want, (void**)out) == hipSuccess; }
+template <class T> inline bool get_device(int device, uint64_t want, T** out) { return device_pool().get(device, want, (void**)out) == hipSuccess; }
+
+}} // namespace bzq::cache

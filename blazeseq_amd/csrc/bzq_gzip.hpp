@@ -1484,9 +1484,10 @@ inline uint32_t crc_xpow8(uint64_t n) {   // x^(8 n) mod P
 
 inline int gz_ensure(bzq_gzip* h, bzq_gzip::Buf& b, size_t bytes, bool pinned = false) {
     if (bytes <= b.cap) return 0;
-    if (b.p) { GZCHK(h, hipStreamSynchronize(h->stream)); GZCHK(h, pinned ? hipHostFree(b.p) : hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    bzq::cache::Pool& pool = pinned ? bzq::cache::pinned_pool() : bzq::cache::device_pool();   // (bzq_bufcache.hpp: the buffers of a decoder outlive it)
+    if (b.p) { GZCHK(h, hipDeviceSynchronize()); pool.put(b.p); b.p = nullptr; b.cap = 0; }
     const size_t want = bytes + bytes / 4 + 256;
-    const hipError_t e = pinned ? hipHostMalloc(&b.p, want, hipHostMallocDefault) : hipMalloc(&b.p, want);
+    const hipError_t e = pool.get(h->device, want, &b.p);
     if (e != hipSuccess) { b.p = nullptr; (void)hipGetLastError(); return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: cannot allocate " + std::to_string(want) + " bytes"); }
     b.cap = want;
     return 0;
@@ -1500,10 +1501,11 @@ inline void gz_free(bzq_gzip* h) {
     if (h->find_stream) { (void)hipStreamSynchronize(h->find_stream); (void)hipStreamDestroy(h->find_stream); }
     for (hipEvent_t e : {h->pre_ev, h->pre_copy_ev}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->staged_ev) if (e) (void)hipEventDestroy(e);
+    (void)hipDeviceSynchronize();   // (a caller's stream may still run the last decode: what goes back to the cache skips hipFree's wait)
     for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->order[0], &h->order[1], &h->jobs[0], &h->jobs[1], &h->counters2, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
-        if (b->p) (void)hipFree(b->p);
+        bzq::cache::device_pool().put(b->p);
     for (bzq_gzip::Buf* b : {&h->h_outs, &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs})
-        if (b->p) (void)hipHostFree(b->p);
+        bzq::cache::pinned_pool().put(b->p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
@@ -1552,9 +1554,9 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
     auto give_back = [&](int code) { (void)hipGetLastError(); std::lock_guard<std::mutex> lk(h->stage_mu); h->comp_busy[bi] = false; return code; };
     bzq_gzip::Buf& b = h->comp[bi];
     if (b.cap < STAGE_RESERVE + n_new + 64) {   // (not gz_ensure: that waits for the decode stream, which the other thread may be feeding)
-        if (b.p) { const hipError_t e = hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) return give_back(BZQ_ERR_HIP); }
+        if (b.p) { const hipError_t e = hipDeviceSynchronize(); bzq::cache::device_pool().put(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) return give_back(BZQ_ERR_HIP); }
         const size_t want = (size_t)(STAGE_RESERVE + n_new + n_new / 4 + 256);
-        if (hipMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; return give_back(BZQ_ERR_NOMEM); }
+        if (bzq::cache::device_pool().get(h->device, want, &b.p) != hipSuccess) { b.p = nullptr; return give_back(BZQ_ERR_NOMEM); }
         b.cap = want;
     }
     uint8_t* d = (uint8_t*)b.p + STAGE_RESERVE;

@@ -263,7 +263,7 @@ inline bool read_compressed_chunk(bzq_ingest* g, uint8_t* dst, uint64_t cap, uin
 // slot on the path of chunk 1 -- 43 instead of 50 GB/s on a 3 GB file)
 inline bool ingest_alloc_inflate(bzq_ingest* g, int i) {
     return hipStreamCreateWithFlags(&g->inflate_stream[i], hipStreamNonBlocking) == hipSuccess &&
-           hipMalloc((void**)&g->comp_dev[i], g->chunk_bytes + 64) == hipSuccess &&
+           cache::get_device(g->device, g->chunk_bytes + 64, &g->comp_dev[i]) &&
            hipMalloc((void**)&g->tab_dev[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16) == hipSuccess &&
            hipHostMalloc((void**)&g->tab_pinned[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16, hipHostMallocDefault) == hipSuccess;
 }
@@ -271,8 +271,8 @@ inline bool ingest_alloc_inflate(bzq_ingest* g, int i) {
 // of an open (~0.1 s per GiB): a plain file stages whole chunks there, a .gz decoded on the device only pieces of compressed
 // bytes, in two of the three slots.
 inline bool ingest_alloc_slot(bzq_ingest* g, int i, uint64_t pinned_bytes) {
-    return (!pinned_bytes || hipHostMalloc((void**)&g->slot[i].pinned, g->reserve + pinned_bytes, hipHostMallocDefault) == hipSuccess) &&
-           hipMalloc((void**)&g->slot[i].dev, g->reserve + g->chunk_bytes + 64) == hipSuccess &&
+    return (!pinned_bytes || cache::get_pinned(g->device, g->reserve + pinned_bytes, &g->slot[i].pinned)) &&   // (bzq_bufcache.hpp: the next open of the process takes them from there)
+           cache::get_device(g->device, g->reserve + g->chunk_bytes + 64, &g->slot[i].dev) &&
            hipEventCreateWithFlags(&g->slot[i].h2d_done, hipEventDisableTiming) == hipSuccess &&
            hipEventCreateWithFlags(&g->dev_free[i], hipEventDisableTiming) == hipSuccess;
 }
@@ -477,12 +477,14 @@ inline void ingest_free(bzq_ingest* g) {
     if (g->gz_reader.joinable()) g->gz_reader.join();   // (a read-ahead still writing into a slot's pinned buffer)
     (void)hipSetDevice(g->device);
     if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
-    for (int i = 0; i < INGEST_SLOTS; ++i) {
+    for (int i = 0; i < INGEST_SLOTS; ++i)
         if (g->inflate_stream[i]) { (void)hipStreamSynchronize(g->inflate_stream[i]); (void)hipStreamDestroy(g->inflate_stream[i]); }
-        if (g->slot[i].pinned) (void)hipHostFree(g->slot[i].pinned);
-        if (g->slot[i].dev) (void)hipFree(g->slot[i].dev);
+    (void)hipDeviceSynchronize();   // the parser's stream may still read the last chunk: buffers that go back to the cache skip hipFree's implicit wait
+    for (int i = 0; i < INGEST_SLOTS; ++i) {
+        cache::pinned_pool().put(g->slot[i].pinned);
+        cache::device_pool().put(g->slot[i].dev);
         if (g->big[i]) (void)hipFree(g->big[i]);
-        if (g->comp_dev[i]) (void)hipFree(g->comp_dev[i]);
+        cache::device_pool().put(g->comp_dev[i]);
         if (g->ms_scratch[i]) (void)hipFree(g->ms_scratch[i]);
         if (g->tab_dev[i]) (void)hipFree(g->tab_dev[i]);
         if (g->tab_pinned[i]) (void)hipHostFree(g->tab_pinned[i]);
@@ -493,7 +495,7 @@ inline void ingest_free(bzq_ingest* g) {
     if (g->bad_pinned) (void)hipHostFree(g->bad_pinned);
     if (g->gz) gzclose(g->gz);
     if (g->gz_dev) bzq::gz::gz_free(g->gz_dev);
-    for (int i = 0; i < 2; ++i) if (g->gz_fifo[i]) (void)hipFree(g->gz_fifo[i]);
+    for (int i = 0; i < 2; ++i) cache::device_pool().put(g->gz_fifo[i]);
     if (g->fd >= 0) close(g->fd);
     if (g->fd_direct >= 0) close(g->fd_direct);
     delete g;

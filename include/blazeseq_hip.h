@@ -473,7 +473,12 @@ typedef struct bzq_ingest_stats {
 /* chunk_bytes 0 = 256 MiB; n_threads <= 0 = 8.  The ctx must outlive the ingest and is used by it.  Options of the ctx read
  * at open: "ingest_direct" = 1: O_DIRECT reads of whole 4 KiB blocks straight into the pinned buffers (files that are not in
  * the page cache; a filesystem that refuses O_DIRECT is read buffered); "ingest_numa" (default 1): the reader threads run on
- * the CPUs of the GPU's NUMA node. */
+ * the CPUs of the GPU's NUMA node.
+ * The chunk buffers (three pinned host buffers of chunk_bytes + reserve and their device twins; the gzip decoder's pools) are
+ * expensive to pin and unpin (~40 ms each way at 256 MiB chunks), so bzq_ingest_close hands them to a process-wide cache and
+ * the next open of the process on the same device takes them from there.  Options "pin_cache_bytes" (default 2 GiB) and
+ * "dev_cache_bytes" (default 8 GiB) bound what the cache holds, process-wide; 0 gives everything back to the driver now and
+ * turns the cache off (environment BZQ_BUF_CACHE=0: off for the whole process). */
 int32_t bzq_ingest_open(bzq_ctx* ctx, const char* path, uint64_t chunk_bytes, int32_t n_threads, bzq_ingest** out);
 /* Parse the next chunk.  records_taken: how many records of the PREVIOUS chunk the caller consumed (ignored on the
  * first call); the remaining records and the bytes behind them are carried in front of this chunk.  Returns like

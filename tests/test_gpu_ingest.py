@@ -286,3 +286,51 @@ def test_o_direct_reads_give_the_same_stream(chunk, tmp_path):
     assert outs[0][0] == outs[1][0] == f.n_records
     assert outs[0][1] == outs[1][1] == f.seq_bytes.tobytes()
     print("direct_io:", outs[1][2], "numa node:", outs[1][3])
+
+
+@pytest.mark.parametrize("kind", ["plain", "gzip", "bgzf"])
+def test_buffers_of_a_closed_file_serve_the_next_open(kind, tmp_path):
+    """Round 4 (bzq_bufcache.hpp): the pinned / device chunk buffers of a closed stream stay in a process-wide cache; the next open
+    takes them from there -- with whatever bytes the last file left in them -- and must deliver its own file's records; options
+    pin_cache_bytes / dev_cache_bytes = 0 give everything back to the driver."""
+    import gzip
+    import blazeseq_amd as B
+    from blazeseq_amd import _lib as L
+    files = []
+    for i, (n, lo, hi) in enumerate([(30_000, 50, 150), (9_000, 20, 400), (30_000, 50, 150)]):
+        data = bytes(O.generate_synthetic(n, lo, hi, 0, 40, "sanger"))
+        if i == 2:
+            data = data.replace(b"A", b"C")   # the same sizes as file 0, different bytes
+        comp = data if kind == "plain" else gzip.compress(data, 1) if kind == "gzip" else _bgzf(data)
+        path = tmp_path / f"reads{i}.fastq{'' if kind == 'plain' else '.gz'}"
+        path.write_bytes(comp)
+        files.append((str(path), data))
+    probe = B.Context(B.ParserConfig(), "generic", 1000, 0)
+    q = lambda key: L.lib().bzq_set_option(probe.h, key.encode(), 0)
+    for key in ("pin_cache_bytes", "dev_cache_bytes"):
+        probe.set_option(key, 0)
+    assert q("buf_cache_held_mb") == 0
+    probe.set_option("pin_cache_bytes", 2 << 30)
+    probe.set_option("dev_cache_bytes", 8 << 30)
+    hits0 = q("buf_cache_hits")
+    for rnd in range(2):
+        for path, data in files:
+            ref = [b for b in O.StreamParser(np.frombuffer(data, dtype=np.uint8), O.make_config(batch_size=1000)).batches()]
+            p = B.FastqParser(path, batch_size=1000, chunk_bytes=4 << 20, reader_threads=3)
+            got = list(p.batches())
+            assert [len(b) for b in got] == [len(b) for b in ref]
+            for g, r in zip(got, ref):
+                assert g._sequence_bytes.tobytes() == r.seq_bytes and g._quality_bytes.tobytes() == r.qual_bytes
+                assert g._id_bytes.tobytes() == r.id_bytes and g._ends.tolist() == r.ends
+            p.close() if hasattr(p, "close") else None
+            del p
+    import gc
+    gc.collect()
+    assert q("buf_cache_hits") >= hits0 + 6, (hits0, q("buf_cache_hits"))   # at least the three slots' pinned + device buffers, once
+    assert q("buf_cache_held_mb") > 0
+    probe.set_option("pin_cache_bytes", 0)
+    probe.set_option("dev_cache_bytes", 0)
+    assert q("buf_cache_held_mb") == 0
+    probe.set_option("pin_cache_bytes", 2 << 30)
+    probe.set_option("dev_cache_bytes", 8 << 30)
+    probe.close()
