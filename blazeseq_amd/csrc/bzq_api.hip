@@ -702,6 +702,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
             if (c->overlap && !emit_only) {
                 // emit(k) runs on the second stream behind scan(k); pass A of k+1 proceeds on the main stream
                 while ((int64_t)c->ev_pipe.size() <= 2 * passes + 1) { hipEvent_t ev; (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming); c->ev_pipe.push_back(ev); }
+                if (!c->stream2 && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { c->err = "hipStreamCreate (second stream of the sub-chunk passes)"; return BZQ_ERR_HIP; }
                 (void)hipEventRecord(c->ev_pipe[2 * passes], c->stream);
                 (void)hipStreamWaitEvent(c->stream2, c->ev_pipe[2 * passes], 0);
                 hipStream_t keep = c->stream;
@@ -1016,8 +1017,15 @@ int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
         }
         if (prop.multiProcessorCount > 0) c->num_cu = prop.multiProcessorCount;
     }
-    CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    CRT(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    {   // the parser's stream: highest priority.  Its kernels are short and sit on the critical path of a file-backed stream, beside
+        // 10 ms inflate kernels that fill the device; and the runtime keeps a pool of hardware queues per priority
+        // (GPU_MAX_HW_QUEUES = 4, further streams SHARE them): a stream of its own class does not land in a queue behind a helper
+        // stream's long kernel (rocprofv3 timeline of the BGZF ingest, round 4: the parse of chunk k waited for the inflate of k + 1)
+        int lo = 0, hi = 0;
+        const char* e = getenv("BZQ_STREAM_PRIORITY");   // (measurements: 0 = a stream of the default class)
+        if ((!e || e[0] != '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) CRT(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+        else CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    }
     CRT(hipMalloc((void**)&c->d_state, sizeof(ChunkState)));
     CRT(hipHostMalloc((void**)&c->h_state, sizeof(ChunkState), hipHostMallocDefault));
     for (auto& ev : c->ev) CRT(hipEventCreate(&ev));
@@ -1969,6 +1977,7 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
                 g->tab_cap = (int64_t)(g->chunk_bytes / 2048) + 4096;
                 g->gpu_inflate = 1;
                 g->inflate_ms = (gpu_inflate & 2) ? 1 : 0;
+                if (const char* e = getenv("BZQ_INGEST_INFLATE_STREAMS")) g->n_inflate_streams = std::min(bzq::INGEST_SLOTS, std::max(1, atoi(e)));   // (measurements)
                 bool gok = hipHostMalloc((void**)&g->bad_pinned, bzq::INGEST_SLOTS * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess &&
                            hipMalloc((void**)&g->bad_dev, bzq::INGEST_SLOTS * sizeof(unsigned long long)) == hipSuccess;
                 for (int i = 0; i < bzq::INGEST_SLOTS && gok; ++i) { g->bad_pinned[i] = ~0ull; gok = bzq::ingest_alloc_inflate(g, i); }

@@ -15,8 +15,11 @@
 // to reclaim (the HIP runtime may already be gone in a static destructor).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -36,11 +39,37 @@ struct Pool {
         const char* e = getenv("BZQ_BUF_CACHE");
         if (e && e[0] == '0') limit = 0;
     }
-    hipError_t raw_alloc(void** p, uint64_t n) { return pinned ? hipHostMalloc(p, n, hipHostMallocDefault) : hipMalloc(p, n); }
-    void raw_free(void* p) { (void)(pinned ? hipHostFree(p) : hipFree(p)); }
+    static bool tracing() { static const bool t = getenv("BZQ_BUF_CACHE_TRACE") != nullptr; return t; }   // (debug: every driver call that takes > 2 ms, to stderr)
+    hipError_t raw_alloc(void** p, uint64_t n) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const hipError_t e = pinned ? hipHostMalloc(p, n, hipHostMallocDefault) : hipMalloc(p, n);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (tracing() && ms > 2.0) fprintf(stderr, "[bzq cache] %s(%.1f MiB): %.1f ms\n", pinned ? "hipHostMalloc" : "hipMalloc", n / 1048576.0, ms);
+        return e;
+    }
+    void raw_free(void* p) {
+        const auto t0 = std::chrono::steady_clock::now();
+        (void)(pinned ? hipHostFree(p) : hipFree(p));
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (tracing() && ms > 2.0) fprintf(stderr, "[bzq cache] %s: %.1f ms\n", pinned ? "hipHostFree" : "hipFree", ms);
+    }
 
-    // *out gets a buffer of at least `want` bytes on / for `device` (the caller has set the device)
+    // debug: BZQ_BUF_CACHE_POISON=<byte> fills every buffer handed out with that byte (a user of the buffers that relies on what a
+    // fresh allocation happens to contain shows itself)
+    void poison(void* p, uint64_t n) {
+        static const char* e = getenv("BZQ_BUF_CACHE_POISON");
+        if (!e) return;
+        const int v = (int)strtol(e, nullptr, 0) & 0xFF;
+        if (pinned) memset(p, v, n);
+        else { (void)hipMemset(p, v, n); (void)hipDeviceSynchronize(); }
+    }
     hipError_t get(int device, uint64_t want, void** outp) {
+        const hipError_t e = get_(device, want, outp);
+        if (e == hipSuccess) poison(*outp, want);
+        return e;
+    }
+    // *out gets a buffer of at least `want` bytes on / for `device` (the caller has set the device)
+    hipError_t get_(int device, uint64_t want, void** outp) {
         *outp = nullptr;
         {
             std::lock_guard<std::mutex> lk(mu);

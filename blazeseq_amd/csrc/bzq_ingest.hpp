@@ -85,7 +85,12 @@ struct bzq_ingest {
     std::string gz_read_err;
     bzq::IngestSlot slot[bzq::INGEST_SLOTS];
     hipStream_t copy_stream = nullptr;   // H2D of the chunks
-    hipStream_t inflate_stream[bzq::INGEST_SLOTS] = {};   // device inflate: one stream per slot, so that the chunks' kernels overlap
+    // device inflate: consecutive chunks' copies and kernels alternate between TWO streams, so that they overlap -- [0] is copy_stream,
+    // [1] is the ingest's own.  Not one per slot: a process gets 4 hardware queues per device (GPU_MAX_HW_QUEUES) and further streams
+    // SHARE them -- with three inflate streams beside the parser's and the null stream the parser's kernels sat in a queue behind the
+    // NEXT chunk's 10 ms inflate kernel and the pipeline ran in lockstep (rocprofv3 timeline, round 4: 34 -> 4x GB/s)
+    hipStream_t inflate_stream[bzq::INGEST_SLOTS] = {};
+    int n_inflate_streams = 2;
     hipEvent_t dev_free[bzq::INGEST_SLOTS] = {}; // recorded on the ctx stream once slot i's device buffer may be overwritten
     bool dev_free_valid[bzq::INGEST_SLOTS] = {};
     std::thread producer;
@@ -262,8 +267,9 @@ inline bool read_compressed_chunk(bzq_ingest* g, uint8_t* dst, uint64_t cap, uin
 // buffers of slot i (allocated at open: doing it in the reader, when it first gets to the slot, puts the pinning of the second
 // slot on the path of chunk 1 -- 43 instead of 50 GB/s on a 3 GB file)
 inline bool ingest_alloc_inflate(bzq_ingest* g, int i) {
-    return hipStreamCreateWithFlags(&g->inflate_stream[i], hipStreamNonBlocking) == hipSuccess &&
-           cache::get_device(g->device, g->chunk_bytes + 64, &g->comp_dev[i]) &&
+    if (i == 0) g->inflate_stream[0] = g->copy_stream;
+    else if (i < g->n_inflate_streams && hipStreamCreateWithFlags(&g->inflate_stream[i], hipStreamNonBlocking) != hipSuccess) return false;
+    return cache::get_device(g->device, g->chunk_bytes + 64, &g->comp_dev[i]) &&
            hipMalloc((void**)&g->tab_dev[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16) == hipSuccess &&
            hipHostMalloc((void**)&g->tab_pinned[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16, hipHostMallocDefault) == hipSuccess;
 }
@@ -389,7 +395,7 @@ inline void ingest_producer(bzq_ingest* g) {
         int64_t n_blocks = 0;
         // one block is decoded by one wave at its own pace (~20 ms for 64 KiB): a chunk is too few blocks to fill the device,
         // so the inflate kernels of consecutive chunks run side by side on two streams
-        const hipStream_t cs = g->gz_dev ? g->gz_dev->stream : (g->gpu_inflate ? g->inflate_stream[b] : g->copy_stream);
+        const hipStream_t cs = g->gz_dev ? g->gz_dev->stream : (g->gpu_inflate ? g->inflate_stream[k % g->n_inflate_streams] : g->copy_stream);   // (buffers of slot b were last used by chunk k - 3, possibly on the other stream: the wait for h2d_done above covers them)
         bool eof = false, ok;
         const auto t0 = std::chrono::steady_clock::now();
         std::string err;
@@ -476,9 +482,9 @@ inline void ingest_free(bzq_ingest* g) {
     if (g->producer.joinable()) g->producer.join();
     if (g->gz_reader.joinable()) g->gz_reader.join();   // (a read-ahead still writing into a slot's pinned buffer)
     (void)hipSetDevice(g->device);
-    if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
-    for (int i = 0; i < INGEST_SLOTS; ++i)
+    for (int i = 1; i < INGEST_SLOTS; ++i)
         if (g->inflate_stream[i]) { (void)hipStreamSynchronize(g->inflate_stream[i]); (void)hipStreamDestroy(g->inflate_stream[i]); }
+    if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
     (void)hipDeviceSynchronize();   // the parser's stream may still read the last chunk: buffers that go back to the cache skip hipFree's implicit wait
     for (int i = 0; i < INGEST_SLOTS; ++i) {
         cache::pinned_pool().put(g->slot[i].pinned);
