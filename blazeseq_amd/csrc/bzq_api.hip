@@ -1238,6 +1238,18 @@ int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value) {
         h->chunk_bytes = (int32_t)value;
         return 0;
     }
+    if (!strcmp(key, "host_continuation")) { h->host_cont = value != 0; return 0; }   // 0: a stretch without findable block starts stays on the device (one wave)
+    if (!strcmp(key, "far_kib")) {
+        if (value < 16 || value > (1 << 20)) { h->err = "far_kib must lie in [16, 1 GiB]"; return BZQ_ERR_ARG; }
+        h->far_bytes = value << 10;
+        return 0;
+    }
+    if (!strcmp(key, "host_budget_kib")) {   // output per stay on the host before the device is asked again (default 32 MiB, doubling while it keeps handing over)
+        if (value < 64 || value > (1 << 20)) { h->err = "host_budget_kib must lie in [64, 1 GiB]"; return BZQ_ERR_ARG; }
+        h->host_budget = (uint64_t)value << 10; h->host_budget_min = h->host_budget;
+        return 0;
+    }
+    if (!strcmp(key, "host_calls")) return (int32_t)std::min<uint64_t>(h->host_calls, 0x7FFFFFFF);   // query: calls that continued on the host
     h->err = std::string("unknown option ") + key;
     return BZQ_ERR_ARG;
 }

@@ -67,7 +67,9 @@ enum : int32_t {
     ST_LOST = 7,         // passed over more than MAX_PASSED candidates: stopped at the block boundary `end`
     ST_EVENTS_FULL = 8,
     ST_TOO_BIG = 10,     // one block's output went beyond what the caller's buffer can take at all (a decoder fed garbage, or a block larger than out_capacity)
-    ST_SPLIT = 9         // its output reached max_job_syms: stopped at the block boundary `end` (bounds what one job can ask of the caller's buffer)
+    ST_SPLIT = 9,        // its output reached max_job_syms: stopped at the block boundary `end` (bounds what one job can ask of the caller's buffer)
+    ST_FAR = 11          // went far_bytes of compressed input beyond its start without meeting a start the finder found (fixed-Huffman / stored blocks
+                         // only, or a block of that size): stopped at the block boundary `end` -- such a stretch is ONE wave's work here (~10 MB/s), the host takes it
 };
 
 struct Job { u64 start; int32_t cand_from; int32_t pad; };
@@ -92,6 +94,7 @@ struct Args {
     int64_t max_job_syms;                    // a job stops at the first boundary at which it has stored this much
     int64_t hard_cap_syms;                   // ... and gives up in the middle of a block beyond this much (bounds what a wrong guess can take from the pool)
     const uint32_t* order;                   // workgroup k of the decode launch runs job order[k] (nullptr: job_base + k)
+    int64_t far_bytes;                       // 0 = no limit; else a job stops (ST_FAR) at the first boundary this far behind its start
 };
 
 // ---- the bit reader of one wave (cf. inf::Bits), addressed by absolute bit offset in the piece -------------------------------
@@ -639,6 +642,7 @@ __device__ __forceinline__ void run_job(const Args& a, int ji, uint16_t* sym_ll,
             if (hit) { status = ST_TARGET; o.next_job = j; break; }
             if (o.passed > (uint32_t)MAX_PASSED) { status = ST_LOST; break; }
             if (opos >= a.max_job_syms) { status = ST_SPLIT; break; }
+            if (a.far_bytes && (int64_t)(pos >> 4) - (int64_t)(job.start >> 4) > a.far_bytes) { status = ST_FAR; break; }
         }
         if (pos & 1ull) {   // a member header
             const int64_t B = (int64_t)(pos >> 4);
@@ -1446,6 +1450,13 @@ struct bzq_gzip {
     uint64_t members_done = 0;
     uint32_t crc_run = 0;               // CRC-32 and length of the open member's output so far
     uint64_t len_run = 0;
+    // a stretch without block starts the finder can find (ST_FAR) goes to the host (gz_decode_host): zlib, one core, ~30 x one wave
+    bool host_cont = true;              // option "host_continuation"
+    int64_t far_bytes = 256 << 10;      // option "far_kib": how far a decoder may go without meeting a found start
+    bool host_next = false;             // the next call continues on the host
+    uint64_t host_budget = 32ull << 20, host_budget_min = 32ull << 20;   // ... for about this much output; doubles while the device keeps handing over, back to the minimum (option "host_budget_kib") when a piece went through
+    uint64_t host_calls = 0, host_bytes_out = 0;
+    Buf h_host_out;                     // pinned staging of the host's output
     bzq_gzip_stats stats{};
 };
 
@@ -1504,7 +1515,7 @@ inline void gz_free(bzq_gzip* h) {
     (void)hipDeviceSynchronize();   // (a caller's stream may still run the last decode: what goes back to the cache skips hipFree's wait)
     for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->order[0], &h->order[1], &h->jobs[0], &h->jobs[1], &h->counters2, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
         bzq::cache::device_pool().put(b->p);
-    for (bzq_gzip::Buf* b : {&h->h_outs, &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs})
+    for (bzq_gzip::Buf* b : {&h->h_outs, &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs, &h->h_host_out})
         bzq::cache::pinned_pool().put(b->p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -1569,6 +1580,149 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
     return 0;
 }
 
+// ---- gzip member header on the host (the rules of parse_member_header above): > 0 = index of the DEFLATE data, 0 = the input ends inside it, -1 = none
+inline int64_t host_member_header(const uint8_t* in, uint64_t n, uint64_t B) {
+    if (B + 2 <= n && (in[B] != 0x1f || in[B + 1] != 0x8b)) return -1;
+    if (B + 10 > n) return 0;
+    if (in[B + 2] != 8) return -1;
+    const uint32_t flg = in[B + 3];
+    if (flg & 0xE0u) return -1;
+    uint64_t p = B + 10;
+    if (flg & 4u) { if (p + 2 > n) return 0; p += 2 + (uint64_t)(in[p] | (in[p + 1] << 8)); }
+    for (int f = 8; f <= 16; f <<= 1) {
+        if (!(flg & (uint32_t)f)) continue;
+        for (;;) { if (p >= n) return 0; if (in[p++] == 0) break; }
+    }
+    if (flg & 2u) p += 2;
+    return p < n ? (int64_t)p : 0;
+}
+
+// The continuation of the stream ON THE HOST (zlib, raw inflate block by block) from where the device stopped with ST_FAR: a stretch
+// in which the finder finds no block start -- fixed-Huffman or stored blocks only, or one block of hundreds of KiB -- is decoded by
+// ONE wave on the device, at ~10 MB/s; one host core does 300+.  Same contract as gz_decode (whole blocks only, members verified
+// by CRC-32 and ISIZE, the rest stays in the handle); about `budget` bytes of output, then the device is asked again.
+// The reference's GZFile is this loop for the whole file (io/readers.mojo:283-377: gzread).
+inline int gz_decode_host(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_last, uint8_t* d_out, uint64_t out_cap, uint64_t budget, uint64_t* out_bytes, int32_t* more) {
+    const hipStream_t s = h->stream;
+    if (h->pre.valid) { GZCHK(h, hipStreamSynchronize(h->find_stream)); h->pre.valid = false; }   // (a finder launched for the device's next piece: dropped)
+    if (n_new) {   // a piece staged for the device is this call's: its buffer is free again
+        int drop = -1;
+        { std::lock_guard<std::mutex> lk(h->stage_mu); if (!h->staged.empty() && h->staged.front().src == src && h->staged.front().n == n_new) { drop = h->staged.front().buf; h->staged.pop_front(); } }
+        if (drop >= 0) { GZCHK(h, hipEventSynchronize(h->staged_ev[drop])); std::lock_guard<std::mutex> lk(h->stage_mu); h->comp_busy[drop] = false; }
+    }
+    const uint64_t nc = h->carry.size(), n = nc + n_new;
+    std::vector<uint8_t> joined;
+    const uint8_t* in = h->carry.data();
+    if (nc == 0) in = src;
+    else if (n_new) { joined.resize((size_t)n); memcpy(joined.data(), h->carry.data(), (size_t)nc); memcpy(joined.data() + nc, src, (size_t)n_new); in = joined.data(); }
+    // the 32 KiB in front: the dictionary of a stream entered in the middle of a member
+    std::vector<uint8_t> win(32768);
+    GZCHK(h, hipMemcpyAsync(win.data(), h->win[h->wcur].p, 32768, hipMemcpyDeviceToHost, s));
+    GZCHK(h, hipStreamSynchronize(s));
+    const uint64_t lim = std::min<uint64_t>(out_cap, std::max<uint64_t>(budget, 1ull << 20) + (4ull << 20));   // (a block is accepted whole: room beyond the budget for the one that crosses it)
+    int rc;
+    if ((rc = gz_ensure(h, h->h_host_out, (size_t)lim + 64, true))) return rc;
+    uint8_t* hb = (uint8_t*)h->h_host_out.p;
+
+    bool at_header = (h->start_pos & 1ull) != 0;
+    uint64_t ip = 0; int bit = at_header ? 0 : (int)((h->start_pos >> 1) & 7ull);   // next input position
+    uint64_t op = 0;                                                                // output accepted so far
+    uint32_t crc = h->crc_run; uint64_t len = h->len_run;
+    uint64_t members = h->members_done;
+    int32_t status = ST_NEED_MORE;
+    bool stop = false, first_of_call = true;
+    while (!stop) {
+        if (at_header) {
+            if (ip >= n) { status = ST_END_INPUT; break; }
+            const int64_t d = host_member_header(in, n, ip);
+            if (d < 0) { status = ST_BAD_HEADER; break; }
+            if (d == 0) { status = ST_NEED_MORE; break; }
+            ip = (uint64_t)d; bit = 0; at_header = false; crc = 0; len = 0;
+        }
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: inflateInit2 failed");
+        struct End { z_stream* z; ~End() { inflateEnd(z); } } end_guard{&zs};
+        if (first_of_call && len > 0) {   // entered inside a member: what it may refer back to
+            const uint32_t k = (uint32_t)std::min<uint64_t>(len, 32768);
+            if (inflateSetDictionary(&zs, win.data() + 32768 - k, k) != Z_OK) return gz_fail(h, BZQ_ERR_HIP, "bzq_gzip: internal: inflateSetDictionary refused the window");
+        }
+        first_of_call = false;
+        uint64_t fed = ip;   // next input byte not yet given to zlib
+        if (bit) { if (inflatePrime(&zs, 8 - bit, in[ip] >> bit) != Z_OK) return gz_fail(h, BZQ_ERR_HIP, "bzq_gzip: internal: inflatePrime"); fed = ip + 1; }
+        zs.next_in = const_cast<Bytef*>(in + fed); zs.avail_in = 0;
+        zs.next_out = hb + op; zs.avail_out = 0;
+        for (;;) {   // block by block
+            if (zs.avail_in == 0) { const uint64_t m = std::min<uint64_t>(n - fed, 1ull << 30); zs.next_in = const_cast<Bytef*>(in + fed); zs.avail_in = (uInt)m; fed += m; }
+            if (zs.avail_out == 0) { const uint64_t produced = (uint64_t)(zs.next_out - hb); zs.avail_out = (uInt)std::min<uint64_t>(lim - produced, 1ull << 30); }
+            const int zr = inflate(&zs, Z_BLOCK);
+            if (zr != Z_OK && zr != Z_STREAM_END && zr != Z_BUF_ERROR)
+                return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: invalid DEFLATE data near byte " + std::to_string(h->stats.bytes_consumed + (uint64_t)(zs.next_in - in)) + " of the compressed stream");
+            const uint64_t in_pos = (uint64_t)(zs.next_in - in), produced = (uint64_t)(zs.next_out - hb);
+            if (zr == Z_STREAM_END || (zs.data_type & 128)) {   // a block boundary (bit 7: inflate returned right behind an end-of-block code)
+                if (zr == Z_STREAM_END || (zs.data_type & 64)) {   // ... of the member's LAST block: CRC-32 and ISIZE behind the next byte edge (RFC 1952 2.3.1)
+                    const uint64_t T = in_pos;   // (the unused bits of the last byte taken are padding)
+                    if (T + 8 > n) { status = ST_NEED_MORE; stop = true; break; }   // (not accepted: the block is decoded again with the trailer in sight, as on the device)
+                    const uint32_t c2 = (uint32_t)crc32(crc, hb + op, (uInt)(produced - op));
+                    const uint64_t l2 = len + (produced - op);
+                    uint32_t crc_t = 0, isize_t = 0;
+                    for (int q = 0; q < 4; ++q) { crc_t |= (uint32_t)in[T + q] << (8 * q); isize_t |= (uint32_t)in[T + 4 + q] << (8 * q); }
+                    if ((l2 ? c2 : 0u) != crc_t || (uint32_t)l2 != isize_t)
+                        return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: member " + std::to_string(members) + " fails its " + ((uint32_t)l2 != isize_t ? "length" : "CRC-32") + " check (corrupt file)");
+                    members += 1; crc = 0; len = 0; op = produced;
+                    ip = T + 8; bit = 0; at_header = true;
+                    if (op >= budget) { status = ST_SPLIT; stop = true; }
+                    break;   // (the next member, if any, is a new zlib stream)
+                }
+                crc = (uint32_t)crc32(crc, hb + op, (uInt)(produced - op));
+                len += produced - op; op = produced;
+                const uint64_t bits = in_pos * 8 - (uint64_t)(zs.data_type & 7);
+                ip = bits >> 3; bit = (int)(bits & 7);
+                if (op >= budget) { status = ST_SPLIT; stop = true; break; }
+                continue;
+            }
+            if (produced >= lim) {   // the room is used up inside a block
+                if (op == 0 && lim >= out_cap)
+                    return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: out_capacity (" + std::to_string(out_cap) + ") is below the output of one DEFLATE block near byte " +
+                                                         std::to_string(h->stats.bytes_consumed + ip) + " of the compressed stream");
+                status = ST_SPLIT; stop = true; break;
+            }
+            if (zs.avail_in == 0 && fed >= n) { status = ST_NEED_MORE; stop = true; break; }   // the input ends inside the block
+        }
+    }
+    // ---- the output, the window behind it, what stays
+    if (op) {
+        GZCHK(h, hipMemcpyAsync(d_out, hb, (size_t)op, hipMemcpyHostToDevice, s));
+        std::vector<uint8_t> w2(32768);
+        if (op >= 32768) memcpy(w2.data(), hb + op - 32768, 32768);
+        else { memcpy(w2.data(), win.data() + op, (size_t)(32768 - op)); memcpy(w2.data() + (32768 - op), hb, (size_t)op); }
+        GZCHK(h, hipMemcpyAsync(h->win[h->wcur ^ 1].p, w2.data(), 32768, hipMemcpyHostToDevice, s));
+        GZCHK(h, hipStreamSynchronize(s));
+        h->wcur ^= 1;
+    }
+    h->crc_run = crc; h->len_run = len; h->members_done = members;
+    const bool progressed = ip > 0 || op > 0;
+    {
+        std::vector<uint8_t> nk(in + ip, in + n);
+        h->carry.swap(nk);
+        h->start_pos = at_header ? pos_header(0) : pos_deflate((u64)bit);
+    }
+    h->stats.pieces += 1; h->stats.bytes_in += n_new; h->stats.bytes_consumed += ip; h->stats.bytes_out += op; h->stats.members = h->members_done;
+    h->stats.fallback_jobs += 1; h->host_calls += 1; h->host_bytes_out += op;
+    *out_bytes = op;
+    if (status == ST_SPLIT) { *more = 1; return 0; }
+    const bool cut_member = at_header && is_last && status == ST_NEED_MORE && h->carry.size() >= 2 && h->carry[0] == 0x1f && h->carry[1] == 0x8b;
+    const bool garbage = at_header && !cut_member && (status == ST_BAD_HEADER || (is_last && status == ST_NEED_MORE));
+    if (status == ST_BAD_HEADER && h->members_done == 0) return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: not a gzip stream (no member header at its start)");
+    if (garbage && h->members_done > 0) { h->finished = true; h->carry.clear(); return 0; }
+    if (is_last) {
+        if (status == ST_END_INPUT) { h->finished = true; return 0; }
+        return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: unexpected end of the gzip stream (truncated file)");
+    }
+    if (!progressed && h->carry.size() > (1ull << 31)) return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: 2 GiB of compressed bytes hold no whole DEFLATE block");
+    return 0;
+}
+
 // The next piece of the compressed stream (host memory; pinned memory makes the copy a DMA) -> its bytes at d_out (device).
 // As many whole DEFLATE blocks as the piece holds and out_capacity takes are decoded; what is left of the piece is kept
 // inside the handle and decoded in front of the next piece.  *more = 1: the output was cut by out_capacity -- call again (n = 0
@@ -1588,6 +1742,10 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         return 0;
     }
     if (n > (1ull << 33)) return gz_fail(h, BZQ_ERR_ARG, "bzq_gzip: more than 8 GiB of compressed bytes in one piece (a DEFLATE block that never ends?)");
+    if (h->host_next) {   // the device stopped at a stretch it would decode with one wave (ST_FAR): zlib on the host for a while, then the device again
+        h->host_next = false;
+        return gz_decode_host(h, src, n_new, is_last, d_out, out_cap, h->host_budget, out_bytes, more);
+    }
     int rc;
     static const bool timing = getenv("BZQ_GZ_TIMING") != nullptr;   // debug: phase times of every call on stderr
     auto t_prev = std::chrono::steady_clock::now();
@@ -1657,6 +1815,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         if (counting) GZCHK(h, hipMemcpyAsync((uint32_t*)h->counters.p + 7, &counting, 4, hipMemcpyHostToDevice, s));
         a = Args{d_comp, (int64_t)n, (Job*)h->jobs[jb].p, (JobOut*)h->outs.p, 0, n_chunks, n_chunks, CH, (uint16_t*)h->pool.p, h->pool_pages,
                  (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events, max_job, (int64_t)std::max<uint64_t>(out_cap, 1ull << 20)};
+        a.far_bytes = h->host_cont ? std::min<int64_t>(h->far_bytes, std::max<int64_t>(64 << 10, (int64_t)(n / 4))) : 0;   // (a small piece: a quarter of it)
         if (prefound && attempt == 0) a.order = (const uint32_t*)h->order[jb].p + 2 * ORDER_BINS;   // (found and ordered under the piece in front)
         else {
             GZCHK(h, hipMemcpyAsync(h->jobs[jb].p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
@@ -1915,6 +2074,10 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
                 n / 1048576.0, total / 1048576.0, n_chunks, accepted, t_ph[0], t_ph[1], t_ph[2], t_ph[3], t_ph[4], t_ph[5], t_ph[6], t_ph[7]);
 
     if (final_status == ST_EVENTS_FULL || final_status == ST_SPLIT) *more = 1;   // (cannot happen with the event table sized as it is; call again)
+    if (final_status == ST_FAR) {   // the next call continues on the host; the longer the device keeps handing over, the longer the host stays at it
+        *more = 1; h->host_next = true;
+        h->host_budget = total > (8ull << 20) ? h->host_budget_min : std::min<uint64_t>(h->host_budget * 2, 1ull << 30);
+    } else if (total > (8ull << 20)) h->host_budget = h->host_budget_min;
     if (*more) return 0;
     // bytes behind the last member that are no member are ignored like gzread ignores them -- but a member whose magic (1f 8b) is
     // there and whose header or first block is cut off is a TRUNCATED file, never a clean end (gzread: "unexpected end of file"

@@ -364,7 +364,9 @@ inline bool gz_fill_fifo(bzq_ingest* g, std::string& err) {
         } else if (more && g->gz_piece > (2ull << 20)) g->gz_piece = (g->gz_piece / 2) & ~4095ull;
         g->gz_more = more != 0;
         g->gz_done = (file_done && !more) || g->gz_dev->finished;
-        if (!got && !want && !more && !g->gz_done) { err = "gzip: the decoder made no progress"; return false; }
+        // (a call without new input that delivers nothing is fine while the file has more to give -- the host continuation of a
+        // stretch without findable block starts may need the next piece to finish its block -- and a bug behind the file's end)
+        if (!got && !want && !more && !g->gz_done && file_done) { err = "gzip: the decoder made no progress"; return false; }
     }
     return true;
 }

@@ -530,8 +530,16 @@ class GzipDecoder:
         if rc < 0:
             raise RuntimeError(f"{what} failed ({rc}): {(L.lib().bzq_gzip_last_error(self._h) or b'').decode('latin-1')}")
 
+    def set_option(self, key: str, value: int) -> int:
+        """bzq_gzip_set_option: "chunk_bytes", "host_continuation" (default 1: a stretch without block starts the finder can find --
+        fixed-Huffman / stored blocks only -- is continued by zlib on the host), "far_kib"; query "host_calls"."""
+        rc = L.lib().bzq_gzip_set_option(self._h, key.encode(), int(value))
+        self._gcheck(rc, "bzq_gzip_set_option")
+        return rc
+
     def feed(self, comp, is_last: bool, d_out: int, out_capacity: int):
-        """-> (bytes written at d_out, more): `more` = out_capacity cut the output short, call again (an empty piece is fine)."""
+        """-> (bytes written at d_out, more): `more` = out_capacity cut the output short, or the next stretch goes to the host: call
+        again (an empty piece is fine)."""
         a = _as_u8(comp)
         nb, more = C.c_uint64(), C.c_int32()
         self._gcheck(L.lib().bzq_gzip_decode(self._h, a.ctypes.data if a.size else None, a.size, int(is_last), C.c_void_p(d_out), out_capacity,

@@ -428,11 +428,17 @@ typedef struct bzq_gzip_stats {
 
 /* A decoder on ctx's device, with a stream of its own. */
 int32_t bzq_gzip_open(bzq_ctx* ctx, bzq_gzip** out);
-/* "chunk_bytes": compressed bytes per decoder wave (default 16384; 4096 .. 1 MiB). */
+/* "chunk_bytes": compressed bytes per decoder wave (default 16384; 4096 .. 1 MiB).  "host_continuation" (default 1): a stretch of
+ * the stream in which the block finder finds nothing to start from -- fixed-Huffman or stored blocks only, or one block of hundreds
+ * of KiB -- would be ONE wave's work on the device (~10 MB/s); the decoder stops there (*more = 1) and the next bzq_gzip_decode
+ * continues with zlib on the calling thread (200-600 MB/s; same checks, same bytes), for "host_budget_kib" of output (default
+ * 32 MiB, doubling while the device keeps handing over), then the device is asked again.  "far_kib" (default 256): how far a
+ * decoder goes without meeting a found start before it stops.  Query "host_calls": calls that ran on the host. */
 int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value);
 /* The next n compressed bytes (HOST memory; pinned memory makes the copy a DMA) -> their bytes at d_out (DEVICE memory,
  * out_capacity bytes).  Whole DEFLATE blocks only: what is left of the piece stays inside the handle and is decoded in front of
- * the next one.  *more = 1: out_capacity cut the output short -- call again (n = 0 is fine) for the rest.  is_last = 1 with the
+ * the next one.  *more = 1: out_capacity cut the output short, or the next stretch goes to the host (above) -- call again (n = 0
+ * is fine) for the rest.  is_last = 1 with the
  * file's last bytes: a stream that does not end there is an error; bytes behind the last member are ignored (as gzread does).
  * Synchronous: on return the *out_bytes bytes are in d_out.  BZQ_ERR_IO: not a valid gzip stream / CRC-32 or length mismatch
  * (bzq_gzip_last_error says which); never wrong bytes. */

@@ -221,3 +221,131 @@ def test_random_streams_against_zlib():
         got = g.decode(comp, piece)
         g.close()
         assert got == data, (it, kind, len(data), n_members, piece)
+
+
+# ---- round 4: a stretch without block starts the finder can find is continued on the host (gz_decode_host) -----------------------
+def _unfindable(data: bytes, kind: str) -> bytes:
+    """One member whose DEFLATE blocks the finder cannot recognise: fixed-Huffman blocks only (Z_FIXED) / stored blocks only
+    (level 0).  On the device such a stream is ONE wave's work (~10 MB/s): the decoder stops (ST_FAR) and zlib goes on."""
+    return gzip_member(data, 6, zlib.Z_FIXED) if kind == "fixed" else gzip_member(data, 0)
+
+
+@pytest.mark.parametrize("kind", ["fixed", "stored"])
+def test_throughput_floor_of_a_stream_without_findable_block_starts(kind):
+    """'a stream of fixed-Huffman or stored blocks degrades to one wave.  No test pins the throughput floor there.'
+    32 MB of FASTQ: 2.6 s (12 MB/s) on one wave; with the host continuation 0.14 s (230 MB/s, fixed) / 0.06 s (stored) on the
+    GPU box's host.  The floor asserted is far below that (a loaded host) and far above one wave."""
+    import time
+    data = synthetic_fastq(100_000)
+    comp = _unfindable(data, kind)
+    ctx = Context()
+    best = None
+    for _ in range(2):
+        g = DeviceGunzip(ctx, len(data) + (1 << 20))
+        t0 = time.perf_counter()
+        out = g.decode(comp)
+        dt = time.perf_counter() - t0
+        assert out == data
+        assert g.dec.set_option("host_calls", 0) >= 1
+        g.close()
+        best = dt if best is None else min(best, dt)
+    assert len(data) / best / 1e6 >= 60.0, f"{kind}: {len(data) / best / 1e6:.1f} MB/s"
+
+
+@pytest.mark.parametrize("kind", ["fixed", "stored"])
+def test_device_and_host_hand_the_stream_back_and_forth(kind):
+    """A small host budget: device (until ST_FAR) -> host (budget) -> device -> ... inside ONE member -- every hand-over passes the
+    32 KiB window, the bit position inside a byte, the running CRC-32 and length -- through pieces of several sizes and an
+    output buffer smaller than the output."""
+    data = synthetic_fastq(26_000)   # 8 MB
+    comp = _unfindable(data, kind)
+    ctx = Context()
+    for piece, cap, budget_kib, far_kib in [(0, len(data), 256, 64), (300_000, len(data), 64, 16), (1 << 20, 700_000, 512, 32), (77_777, 3 << 20, 100, 16)]:
+        g = DeviceGunzip(ctx, cap, chunk_bytes=4096)
+        g.dec.set_option("host_budget_kib", budget_kib)
+        g.dec.set_option("far_kib", far_kib)
+        assert g.decode(comp, piece) == data, (kind, piece, cap, budget_kib)
+        assert g.dec.set_option("host_calls", 0) >= 3
+        g.close()
+    # and without the continuation the device does it alone (one wave: a small stream)
+    g = DeviceGunzip(ctx, 1 << 20)
+    g.dec.set_option("host_continuation", 0)
+    assert g.decode(_unfindable(data[:600_000], kind)) == data[:600_000]
+    assert g.dec.set_option("host_calls", 0) == 0
+    g.close()
+
+
+def test_host_continuation_across_members_trailers_and_the_end_of_the_stream():
+    """Members of every kind in one file -- findable (dynamic) and not (fixed, stored), small and large, with header fields --
+    so that the host meets member trailers, the next member's header, a member it hands back to the device, the last
+    member's end, and bytes behind it that are no member (ignored, like gzread)."""
+    rng = np.random.default_rng(77)
+    parts, want = [], []
+    for i in range(14):
+        n = int(rng.choice([0, 1, 500, 70_000, 700_000, 2_000_000]))
+        piece = synthetic_fastq(max(1, n // 318 + 1), seed=i)[:n]
+        kind = i % 4
+        m = (gzip_member(piece, 6, zlib.Z_FIXED, name=b"f%d" % i) if kind == 0 else gzip_member(piece, 0, comment=b"stored") if kind == 1
+             else gzip_member(piece, 6) if kind == 2 else gzip_member(piece, 1, zlib.Z_FIXED, extra=b"xx\x02\x00ab", hcrc=True))
+        parts.append(m); want.append(piece)
+    comp, data = b"".join(parts), b"".join(want)
+    ctx = Context()
+    for piece, cap, tail in [(0, len(data) + 1, b""), (200_000, len(data) + 1, b"\0" * 300), (33_333, 900_000, b"not a member")]:
+        g = DeviceGunzip(ctx, cap, chunk_bytes=4096)
+        g.dec.set_option("host_budget_kib", 128)
+        g.dec.set_option("far_kib", 32)
+        assert g.decode(comp + tail, piece) == data, (piece, cap)
+        assert g.dec.stats().members == 14 and g.dec.set_option("host_calls", 0) >= 2
+        g.close()
+
+
+def test_damage_met_by_the_host_fails_the_call():
+    """A truncated file, a wrong CRC-32, a wrong ISIZE and invalid DEFLATE data inside a stretch the host decodes: a runtime
+    error, never bytes."""
+    data = synthetic_fastq(13_000)   # 4 MB
+    good = _unfindable(data, "fixed")
+    ctx = Context()
+
+    def run(comp):
+        g = DeviceGunzip(ctx, len(data) + 1, chunk_bytes=4096)
+        g.dec.set_option("far_kib", 16)
+        try:
+            return g.decode(comp, 500_000)
+        finally:
+            g.close()
+
+    assert run(good) == data
+    for cut in (len(good) - 1, len(good) - 8, len(good) - 9, len(good) // 2):
+        with pytest.raises(RuntimeError, match="truncated|unexpected end"):
+            run(good[:cut])
+    for off, what in ((-8, "CRC-32"), (-4, "length")):
+        bad = bytearray(good); bad[off] ^= 0x40
+        with pytest.raises(RuntimeError, match=what):
+            run(bytes(bad))
+    rng = np.random.default_rng(3)
+    refused = 0
+    for _ in range(12):
+        bad = bytearray(good)
+        for _ in range(3):
+            bad[int(rng.integers(len(good) // 3, len(good) - 8))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            assert run(bytes(bad)) == data   # (cannot happen: the CRC-32 would have to agree)
+        except RuntimeError as e:
+            assert "invalid DEFLATE data" in str(e) or "CRC-32" in str(e) or "length" in str(e) or "truncated" in str(e) or "unexpected end" in str(e), str(e)
+            refused += 1
+    assert refused == 12
+
+
+def test_a_file_without_findable_block_starts_through_the_parser(tmp_path):
+    """The whole way: FastqParser(path) on a fixed-Huffman-only .gz == the streaming oracle on the plain bytes."""
+    import blazeseq_amd as B
+    from oracle import oracle as O
+    data = bytes(O.generate_synthetic(30_000, 50, 150, 0, 40, "sanger"))
+    path = tmp_path / "fixed_only.fastq.gz"
+    path.write_bytes(gzip_member(data, 6, zlib.Z_FIXED))
+    ref = [b for b in O.StreamParser(np.frombuffer(data, dtype=np.uint8), O.make_config(batch_size=1000)).batches()]
+    for chunk in (1 << 18, 1 << 22):
+        got = list(B.FastqParser(str(path), batch_size=1000, chunk_bytes=chunk, reader_threads=2).batches())
+        assert [len(b) for b in got] == [len(b) for b in ref]
+        for g, r in zip(got, ref):
+            assert g._sequence_bytes.tobytes() == r.seq_bytes and g._quality_bytes.tobytes() == r.qual_bytes and g._id_bytes.tobytes() == r.id_bytes
