@@ -1238,6 +1238,8 @@ int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value) {
         h->chunk_bytes = (int32_t)value;
         return 0;
     }
+    if (!strcmp(key, "early_find")) { h->early_find = value != 0; return 0; }   // 0: a staged piece's finder runs once the piece in front has been decoded (round 3)
+    if (!strcmp(key, "predecode")) { h->predecode = value != 0; return 0; }   // 0: a piece's decoders start behind the chain / resolve / CRC kernels of the piece in front (round 3)
     if (!strcmp(key, "host_continuation")) { h->host_cont = value != 0; return 0; }   // 0: a stretch without findable block starts stays on the device (one wave)
     if (!strcmp(key, "far_kib")) {
         if (value < 16 || value > (1 << 20)) { h->err = "far_kib must lie in [16, 1 GiB]"; return BZQ_ERR_ARG; }
@@ -1972,8 +1974,8 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
         bool slot_ok[bzq::INGEST_SLOTS];
         std::thread th[bzq::INGEST_SLOTS];
         for (int i = 0; i < bzq::INGEST_SLOTS; ++i)
-            th[i] = std::thread([g, i, device, gz_on_device, &slot_ok]() {
-                slot_ok[i] = hipSetDevice(device) == hipSuccess && bzq::ingest_alloc_slot(g, i, gz_on_device && i == 2 ? 0 : g->chunk_bytes);   // (a .gz on the device reads compressed pieces into two of the slots)
+            th[i] = std::thread([g, i, device, &slot_ok]() {
+                slot_ok[i] = hipSetDevice(device) == hipSuccess && bzq::ingest_alloc_slot(g, i, g->chunk_bytes);   // (a .gz on the device reads its compressed pieces into the three slots' pinned buffers, two pieces ahead)
             });
         for (int i = 0; i < bzq::INGEST_SLOTS; ++i) { th[i].join(); ok = ok && slot_ok[i]; }
     }

@@ -1150,17 +1150,27 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_order(int n, const uint8_t*
 
 static __global__ void k_gz_job0(Job* jobs, u64 start) { jobs[0] = Job{start, 1, 0}; }   // (job 0 = the piece's exact start)
 
-// FIND + ORDER of a piece on `st`: jobs[0] must be set; order_buf = [bins][cursor][order n_chunks][keys n_chunks].  Returns the order array.
-static inline const uint32_t* launch_find(hipStream_t st, const Args& a, void* order_buf, int n_chunks) {
-    hipLaunchKernelGGL(k_gz_find, dim3((unsigned)((n_chunks + WAVES - 1) / WAVES)), dim3(BLOCK), 0, st, a);
+// starts found on a grid laid over the piece's NEW bytes before its carry was known (gz_stage): jobs[1 ..] += shift, in position units
+static __global__ __launch_bounds__(BLOCK) void k_gz_shift(Job* jobs, int n, long long shift) {
+    const int i = (int)(blockIdx.x * BLOCK + threadIdx.x);
+    if (i < n && jobs[i].start != POS_NONE) jobs[i].start = (u64)((long long)jobs[i].start + shift);
+}
+
+// ORDER of a piece's jobs on `st` (jobs[0] set, the others found); order_buf = [bins][cursor][order n_chunks][keys n_chunks].  Returns the order array.
+static inline const uint32_t* launch_order(hipStream_t st, const Job* jobs, void* order_buf, int n_chunks) {
     uint32_t* bins = (uint32_t*)order_buf;
     uint32_t* order = bins + 2 * ORDER_BINS;
     uint8_t* keys = (uint8_t*)(order + n_chunks);
     (void)hipMemsetAsync(bins, 0, 2 * ORDER_BINS * 4, st);
     const unsigned g1 = (unsigned)((n_chunks + BLOCK - 1) / BLOCK);
-    hipLaunchKernelGGL(k_gz_span, dim3(g1), dim3(BLOCK), 0, st, (const Job*)a.jobs, n_chunks, keys, bins);
+    hipLaunchKernelGGL(k_gz_span, dim3(g1), dim3(BLOCK), 0, st, jobs, n_chunks, keys, bins);
     hipLaunchKernelGGL(k_gz_order, dim3(g1), dim3(BLOCK), 0, st, n_chunks, (const uint8_t*)keys, (const uint32_t*)bins, bins + ORDER_BINS, order);
     return order;
+}
+// FIND + ORDER of a piece on `st`: jobs[0] must be set.
+static inline const uint32_t* launch_find(hipStream_t st, const Args& a, void* order_buf, int n_chunks) {
+    hipLaunchKernelGGL(k_gz_find, dim3((unsigned)((n_chunks + WAVES - 1) / WAVES)), dim3(BLOCK), 0, st, a);
+    return launch_order(st, (const Job*)a.jobs, order_buf, n_chunks);
 }
 
 // ---- CHAIN: the window behind every chain chunk; its tail (the last <= 32 KiB) goes out final ---------------------------------------
@@ -1411,6 +1421,7 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_crc(const CrcSeg* segs, int
 #include <atomic>
 #include <chrono>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1425,24 +1436,36 @@ struct bzq_gzip {
     int32_t chunk_bytes = 16384;        // CH: one decoder wave per this many compressed bytes (zlib closes a block every ~20 KiB of FASTQ output stream)
     // device
     struct Buf { void* p = nullptr; size_t cap = 0; };
-    Buf comp[2], jobs[2], outs, order[2], counters2, pool, page_next, counters, events, items, crcs, win[2], chain_maps, chain_wins;
-    Buf h_outs, h_events, h_pages, h_items, h_crcs;   // pinned host staging
+    // what a piece's decoders write (symbol pool, page links, counters, job results, member events) exists TWICE: piece k + 1 is decoded
+    // (on find_stream, behind its finder) while the chain / resolve / CRC kernels of piece k still read piece k's -- round 4
+    Buf comp[3], jobs[2], jobs_e[3], order_e[3], counters_e[3], outs_[2], order[2], counters2, pool_[2], page_next_[2], counters_[2], events_[2], items, crcs, win[2], chain_maps, chain_wins;
+    Buf h_outs_[2], h_events, h_pages, h_items, h_crcs;   // pinned host staging
+    int pcur = 0;                       // which of the two sets the piece being (last) decoded uses
+    bool predecode = true;              // option "predecode": 0 = a piece's decoders start behind the kernels of the piece in front
     uint32_t pool_pages = 0;
     int wcur = 0;                       // win[wcur]: the 32 KiB of output in front of the next piece
     // the NEXT piece's block finder, launched (on find_stream) the moment this piece's chain is known -- its carry is then
     // known too -- so that it runs under this piece's chain / resolve / CRC kernels and the host work between them
-    struct Pre { bool valid = false; const uint8_t* src = nullptr; uint64_t n_new = 0, nc = 0; unsigned long long start_pos = 0; int jb = 0, cb = 0; } pre;
+    struct Pre { bool valid = false; const uint8_t* src = nullptr; uint64_t n_new = 0, nc = 0; unsigned long long start_pos = 0; int jb = 0, cb = 0;
+                 bool shifted = false; int nch = 0;   // shifted: jobs_e / order_e[cb] hold it, on the grid over the new bytes (job j >= 1 = chunk j - 1 of them)
+                 bool decoded = false; int pb = 0; uint32_t pool_pages = 0; int64_t max_job = 0; } pre;   // decoded: its decoders have run too (set pb), with that pool and job bound
     int jlast = 1;                      // which of jobs[] / order[] the last decode used
     hipStream_t find_stream = nullptr;
-    hipEvent_t pre_ev = nullptr, pre_copy_ev = nullptr;
+    hipEvent_t pre_ev = nullptr, pre_copy_ev = nullptr, pre_dec_ev = nullptr;
     // pieces on their way to the device while the one in front of them is decoded (bzq_gzip_stage): comp[b] holds one
     // STAGE_RESERVE bytes in, so that the bytes carried over from the piece in front can be put before it
-    struct StagedPiece { const uint8_t* src; uint64_t n; int buf; };
+    struct StagedPiece { const uint8_t* src; uint64_t n; int buf; bool found; int nch; };   // found: its finder has been launched too (early_ev[buf]), on a grid of nch - 1 chunks over its own bytes
     std::mutex stage_mu;                // (bzq_gzip_stage may come from a second thread)
     std::deque<StagedPiece> staged;     // oldest first, at most two
-    bool comp_busy[2] = {false, false}; // holds a staged piece, or the piece being decoded
+    bool comp_busy[3] = {false, false, false}; // holds a staged piece, or the piece being decoded (three: the piece whose chain / resolve / CRC run, the one being
+                                        // decoded under them, and the one behind it on its way to the device)
     hipStream_t copy_stream = nullptr;
-    hipEvent_t staged_ev[2] = {nullptr, nullptr};
+    hipEvent_t staged_ev[3] = {nullptr, nullptr, nullptr}, early_ev[3] = {nullptr, nullptr, nullptr};
+    // option "early_find" (default 0): a staged piece's finder runs behind its COPY instead of behind the decoding of the piece in front.
+    // Built and parity-green in round 4, and no faster (27.3 against 28.2 GB/s file -> records): with the finder off the critical path
+    // the chain / resolve / CRC kernels of the piece in front are on it -- beside 16 000 decoder waves they take 12 ms instead of 3
+    // (k_gz_chain_groups, one workgroup: 0.28 -> 8.8 ms), whatever the streams' priorities or CU masks (measured: DESIGN 5c)
+    bool early_find = false;
     // the stream
     std::vector<uint8_t> carry;         // compressed bytes not consumed yet
     unsigned long long start_pos = 1;   // where decoding resumes inside `carry`: pos_header(0), or pos_deflate(bit 0..7)
@@ -1510,12 +1533,13 @@ inline void gz_free(bzq_gzip* h) {
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     if (h->find_stream) { (void)hipStreamSynchronize(h->find_stream); (void)hipStreamDestroy(h->find_stream); }
-    for (hipEvent_t e : {h->pre_ev, h->pre_copy_ev}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {h->pre_ev, h->pre_copy_ev, h->pre_dec_ev}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->staged_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->early_ev) if (e) (void)hipEventDestroy(e);
     (void)hipDeviceSynchronize();   // (a caller's stream may still run the last decode: what goes back to the cache skips hipFree's wait)
-    for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->order[0], &h->order[1], &h->jobs[0], &h->jobs[1], &h->counters2, &h->outs, &h->pool, &h->page_next, &h->counters, &h->events, &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
+    for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->comp[2], &h->jobs_e[0], &h->jobs_e[1], &h->jobs_e[2], &h->order_e[0], &h->order_e[1], &h->order_e[2], &h->counters_e[0], &h->counters_e[1], &h->counters_e[2], &h->order[0], &h->order[1], &h->jobs[0], &h->jobs[1], &h->counters2, &h->outs_[0], &h->outs_[1], &h->pool_[0], &h->pool_[1], &h->page_next_[0], &h->page_next_[1], &h->counters_[0], &h->counters_[1], &h->events_[0], &h->events_[1], &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
         bzq::cache::device_pool().put(b->p);
-    for (bzq_gzip::Buf* b : {&h->h_outs, &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs, &h->h_host_out})
+    for (bzq_gzip::Buf* b : {&h->h_outs_[0], &h->h_outs_[1], &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs, &h->h_host_out})
         bzq::cache::pinned_pool().put(b->p);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
@@ -1526,15 +1550,21 @@ inline int gz_open(int device, bzq_gzip** out, std::string& err) {
     if (hipSetDevice(device) != hipSuccess) { err = "bzq_gzip_open: hipSetDevice failed"; return BZQ_ERR_HIP; }
     bzq_gzip* h = new bzq_gzip();
     h->device = device;
-    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) { err = "bzq_gzip_open: hipStreamCreate failed"; delete h; return BZQ_ERR_HIP; }
+    // the stream of a piece's chain / resolve / CRC kernels: highest priority -- they run beside the NEXT piece's decoders (find_stream),
+    // which fill every CU, and the caller waits for them (BZQ_GZ_PRIORITY=0: default class, for measurements)
+    int plo = 0, phi = 0;
+    const char* pe = getenv("BZQ_GZ_PRIORITY");
+    const bool prio = (!pe || pe[0] != '0') && hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess && phi < plo;
+    if ((prio ? hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, phi) : hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { err = "bzq_gzip_open: hipStreamCreate failed"; delete h; return BZQ_ERR_HIP; }
     h->stream = h->own_stream;
     if (hipStreamCreateWithFlags(&h->find_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->pre_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->pre_copy_ev, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->staged_ev[1], hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&h->pre_copy_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->pre_dec_ev, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->staged_ev[1], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[2], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->early_ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->early_ev[1], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->early_ev[2], hipEventDisableTiming) != hipSuccess) {
         err = "bzq_gzip_open: hipStreamCreate failed"; gz_free(h); return BZQ_ERR_HIP;
     }
     int rc;
-    if ((rc = gz_ensure(h, h->win[0], 32768)) || (rc = gz_ensure(h, h->win[1], 32768)) || (rc = gz_ensure(h, h->counters, 128)) || (rc = gz_ensure(h, h->counters2, 128))) { err = h->err; gz_free(h); return rc; }
+    if ((rc = gz_ensure(h, h->win[0], 32768)) || (rc = gz_ensure(h, h->win[1], 32768)) || (rc = gz_ensure(h, h->counters_e[0], 128)) || (rc = gz_ensure(h, h->counters_e[1], 128)) || (rc = gz_ensure(h, h->counters_e[2], 128)) || (rc = gz_ensure(h, h->counters_[0], 128)) || (rc = gz_ensure(h, h->counters_[1], 128)) || (rc = gz_ensure(h, h->counters2, 128))) { err = h->err; gz_free(h); return rc; }
     if (hipMemsetAsync(h->counters2.p, 0, 128, h->stream) != hipSuccess || hipMemsetAsync(h->win[0].p, 0, 32768, h->stream) != hipSuccess || hipStreamSynchronize(h->stream) != hipSuccess) { err = "bzq_gzip_open: hipMemset failed"; gz_free(h); return BZQ_ERR_HIP; }
     h->start_pos = pos_header(0);
     for (uint64_t len : {1ull, 4097ull, (unsigned long long)CRC_SEG})   // (the combine above against zlib's, once)
@@ -1558,7 +1588,7 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
     int bi;
     {
         std::lock_guard<std::mutex> lk(h->stage_mu);
-        bi = !h->comp_busy[0] ? 0 : !h->comp_busy[1] ? 1 : -1;
+        bi = !h->comp_busy[0] ? 0 : !h->comp_busy[1] ? 1 : !h->comp_busy[2] ? 2 : -1;
         if (bi < 0) return 0;
         h->comp_busy[bi] = true;
     }
@@ -1575,8 +1605,37 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
     if (e == hipSuccess) e = hipMemsetAsync(d + n_new, 0, 64, h->copy_stream);
     if (e == hipSuccess) e = hipEventRecord(h->staged_ev[bi], h->copy_stream);
     if (e != hipSuccess) { (void)hipStreamSynchronize(h->copy_stream); return give_back(BZQ_ERR_HIP); }
+    // The piece's FINDER behind its copy, on the same stream (round 4): it needs the piece's bytes and nothing else -- not where the
+    // piece in front will end -- if its chunk grid is laid over the piece's own bytes: job j >= 1 = chunk j - 1 of them.  Positions
+    // come out relative to CH bytes in front of the piece (the kernel's chunk 0 is job 0's, never looked at); once the carry is
+    // known they are shifted to where the piece then starts (k_gz_shift, gz_decode).  3 of a piece's 15.5 ms off its critical path.
+    bool found = false;
+    int nch = 0;
+    static const bool no_early = getenv("BZQ_GZ_NO_EARLY_FIND") != nullptr;
+    if (h->early_find && !no_early) {
+        const int CH = h->chunk_bytes;
+        nch = (int)((n_new + (uint64_t)CH - 1) / (uint64_t)CH) + 1;
+        auto fit = [&](bzq_gzip::Buf& q, size_t bytes) {   // (the buffers of comp[bi]'s last piece: nothing in flight touches them -- its call has returned)
+            if (bytes <= q.cap) return true;
+            if (q.p) bzq::cache::device_pool().put(q.p);
+            q.p = nullptr; q.cap = 0;
+            const size_t want = bytes + bytes / 4 + 256;
+            if (bzq::cache::device_pool().get(h->device, want, &q.p) != hipSuccess) { q.p = nullptr; return false; }
+            q.cap = want;
+            return true;
+        };
+        if (fit(h->jobs_e[bi], (size_t)(nch + MAX_FALLBACK) * sizeof(Job)) && fit(h->order_e[bi], (size_t)2 * ORDER_BINS * 4 + (size_t)nch * 5 + 64)) {
+            Args a2{};
+            a2.comp = d - CH; a2.n = (int64_t)n_new + CH; a2.jobs = (Job*)h->jobs_e[bi].p; a2.n_jobs = nch; a2.n_cand = nch; a2.chunk_bytes = CH; a2.counters = (uint32_t*)h->counters_e[bi].p;
+            e = hipMemsetAsync(h->counters_e[bi].p, 0, 128, h->copy_stream);
+            if (e == hipSuccess) { hipLaunchKernelGGL(k_gz_find, dim3((unsigned)((nch + WAVES - 1) / WAVES)), dim3(BLOCK), 0, h->copy_stream, a2); e = hipGetLastError(); }
+            if (e == hipSuccess) e = hipEventRecord(h->early_ev[bi], h->copy_stream);
+            found = e == hipSuccess;
+            if (!found) (void)hipGetLastError();
+        }
+    }
     std::lock_guard<std::mutex> lk(h->stage_mu);
-    h->staged.push_back(bzq_gzip::StagedPiece{src, n_new, bi});
+    h->staged.push_back(bzq_gzip::StagedPiece{src, n_new, bi, found, nch});
     return 0;
 }
 
@@ -1604,7 +1663,7 @@ inline int64_t host_member_header(const uint8_t* in, uint64_t n, uint64_t B) {
 // The reference's GZFile is this loop for the whole file (io/readers.mojo:283-377: gzread).
 inline int gz_decode_host(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_last, uint8_t* d_out, uint64_t out_cap, uint64_t budget, uint64_t* out_bytes, int32_t* more) {
     const hipStream_t s = h->stream;
-    if (h->pre.valid) { GZCHK(h, hipStreamSynchronize(h->find_stream)); h->pre.valid = false; }   // (a finder launched for the device's next piece: dropped)
+    if (h->pre.valid) { GZCHK(h, hipStreamSynchronize(h->find_stream)); h->pre.valid = false; h->pre.decoded = false; }   // (finder and decoders launched for the device's next piece: dropped)
     if (n_new) {   // a piece staged for the device is this call's: its buffer is free again
         int drop = -1;
         { std::lock_guard<std::mutex> lk(h->stage_mu); if (!h->staged.empty() && h->staged.front().src == src && h->staged.front().n == n_new) { drop = h->staged.front().buf; h->staged.pop_front(); } }
@@ -1752,9 +1811,6 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     double t_ph[8] = {0};
     auto lap = [&](int k) { if (timing) { const auto t = std::chrono::steady_clock::now(); t_ph[k] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; } };
     const int CH = h->chunk_bytes;
-    const int n_chunks = (int)((n + (uint64_t)CH - 1) / (uint64_t)CH);
-    const int n_jobs_cap = n_chunks + MAX_FALLBACK;
-    const uint32_t max_events = (uint32_t)std::min<uint64_t>(n / 18 + (uint64_t)n_chunks + 64, 1u << 28);
     // the buffer of the compressed bytes: the one this piece was staged into, or a free one (a staged piece that is not
     // this one stays where it is, unless both buffers hold such: then the younger is dropped)
     bool use_staged = false;
@@ -1766,7 +1822,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
             h->staged.pop_front();
             use_staged = nc <= STAGE_RESERVE;   // (else the copy is wasted: the carry does not fit in front of it)
         } else {
-            cb = !h->comp_busy[0] ? 0 : !h->comp_busy[1] ? 1 : -1;
+            cb = !h->comp_busy[0] ? 0 : !h->comp_busy[1] ? 1 : !h->comp_busy[2] ? 2 : -1;
             if (cb < 0) { cb = h->staged.back().buf; h->staged.pop_back(); }
             else h->comp_busy[cb] = true;
         }
@@ -1780,11 +1836,26 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         if (!prefound) GZCHK(h, hipStreamSynchronize(h->find_stream));   // (not this piece after all: its buffers are free again once it is done)
         h->pre.valid = false;
     }
+    // the chunk grid: uniform over the piece (job c = chunk c), or -- found at staging time -- over the piece's new bytes (job j >= 1 = chunk j - 1 of them)
+    const bool shifted = prefound && h->pre.shifted;
+    const int n_chunks = shifted ? h->pre.nch : (int)((n + (uint64_t)CH - 1) / (uint64_t)CH);
+    const int n_jobs_cap = n_chunks + MAX_FALLBACK;
+    const uint32_t max_events = (uint32_t)std::min<uint64_t>(n / 18 + (uint64_t)n_chunks + 64, 1u << 28);
     const int jb = prefound ? h->pre.jb : (h->jlast ^ 1);
-    h->jlast = jb;
-    if ((rc = gz_ensure(h, h->order[jb], (size_t)2 * ORDER_BINS * 4 + (size_t)n_chunks * 5 + 64)) || (!use_staged && (rc = gz_ensure(h, h->comp[cb], n + 64))) || (rc = gz_ensure(h, h->jobs[jb], (size_t)n_jobs_cap * sizeof(Job))) ||
-        (rc = gz_ensure(h, h->outs, (size_t)n_jobs_cap * sizeof(JobOut))) || (rc = gz_ensure(h, h->events, (size_t)max_events * sizeof(Event))) ||
-        (rc = gz_ensure(h, h->h_outs, (size_t)n_jobs_cap * sizeof(JobOut) + 128, true)))
+    if (!shifted) h->jlast = jb;
+    bzq_gzip::Buf &jobsB = shifted ? h->jobs_e[cb] : h->jobs[jb], &orderB = shifted ? h->order_e[cb] : h->order[jb];
+    // one job's output is bounded (it must fit the caller's buffer whole): a quarter of the buffer, 64 KiB .. 16 MiB
+    const int64_t max_job = (int64_t)std::min<uint64_t>(16ull << 20, std::max<uint64_t>(64ull << 10, out_cap / 4));
+    // ... and have its decoders run as well, into the other set of pool / results (with a job bound this call's buffer takes)?
+    bool predecoded = prefound && h->pre.decoded && h->pre.max_job <= max_job;
+    if (h->pre.decoded && !predecoded && prefound) GZCHK(h, hipStreamSynchronize(h->find_stream));   // (the decoders are not used: their set is free once they are done)
+    h->pre.decoded = false;
+    const int pb = predecoded ? h->pre.pb : h->pcur;
+    h->pcur = pb;
+    bzq_gzip::Buf &pool = h->pool_[pb], &d_page_next = h->page_next_[pb], &counters = h->counters_[pb], &d_outs = h->outs_[pb], &events = h->events_[pb], &h_outs = h->h_outs_[pb];
+    if ((rc = gz_ensure(h, orderB, (size_t)2 * ORDER_BINS * 4 + (size_t)n_chunks * 5 + 64)) || (!use_staged && (rc = gz_ensure(h, h->comp[cb], n + 64))) || (rc = gz_ensure(h, jobsB, (size_t)n_jobs_cap * sizeof(Job))) ||
+        (rc = gz_ensure(h, d_outs, (size_t)n_jobs_cap * sizeof(JobOut))) || (rc = gz_ensure(h, events, (size_t)max_events * sizeof(Event))) ||
+        (rc = gz_ensure(h, h_outs, (size_t)n_jobs_cap * sizeof(JobOut) + 128, true)))
         return rc;
     uint8_t* d_comp = (uint8_t*)h->comp[cb].p + (use_staged ? STAGE_RESERVE - nc : 0);
     // (the carry is pageable memory; the vector is not touched before the stream has been waited for, further down)
@@ -1798,43 +1869,47 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     if (timing) GZCHK(h, hipStreamSynchronize(s));
     lap(0);
 
-    JobOut* outs = (JobOut*)h->h_outs.p;
-    uint32_t* h_counters = (uint32_t*)((uint8_t*)h->h_outs.p + (size_t)n_jobs_cap * sizeof(JobOut));
+    JobOut* outs = (JobOut*)h_outs.p;
+    uint32_t* h_counters = (uint32_t*)((uint8_t*)h_outs.p + (size_t)n_jobs_cap * sizeof(JobOut));
     {
         const uint32_t want = (uint32_t)std::min<uint64_t>((n * 5) >> PAGE_SHIFT, 1u << 24) + 2u * (uint32_t)n_chunks + 64u;
         if (h->pool_pages < want) h->pool_pages = want;
     }
-    // one job's output is bounded (it must fit the caller's buffer whole): a quarter of the buffer, 64 KiB .. 16 MiB
-    const int64_t max_job = (int64_t)std::min<uint64_t>(16ull << 20, std::max<uint64_t>(64ull << 10, out_cap / 4));
     Args a{};
     for (int attempt = 0;; ++attempt) {
-        if ((rc = gz_ensure(h, h->pool, ((size_t)h->pool_pages << PAGE_SHIFT) * 2)) || (rc = gz_ensure(h, h->page_next, (size_t)h->pool_pages * 4))) return rc;
+        const uint32_t pages_now = predecoded && attempt == 0 ? h->pre.pool_pages : h->pool_pages;
+        if (!(predecoded && attempt == 0) && ((rc = gz_ensure(h, pool, ((size_t)h->pool_pages << PAGE_SHIFT) * 2)) || (rc = gz_ensure(h, d_page_next, (size_t)h->pool_pages * 4)))) return rc;
         const Job j0{h->start_pos, 1, 0};
-        GZCHK(h, hipMemsetAsync(h->counters.p, 0, 128, s));
+        if (!(predecoded && attempt == 0)) GZCHK(h, hipMemsetAsync(counters.p, 0, 128, s));
         static const uint32_t counting = getenv("BZQ_GZ_COUNT") ? (uint32_t)atoi(getenv("BZQ_GZ_COUNT")) : 0u;   // debug: 1 = survivor / hand-back counts (atomics in the loops: not for timing), 2 = the finder's clocks
-        if (counting) GZCHK(h, hipMemcpyAsync((uint32_t*)h->counters.p + 7, &counting, 4, hipMemcpyHostToDevice, s));
-        a = Args{d_comp, (int64_t)n, (Job*)h->jobs[jb].p, (JobOut*)h->outs.p, 0, n_chunks, n_chunks, CH, (uint16_t*)h->pool.p, h->pool_pages,
-                 (uint32_t*)h->page_next.p, (uint32_t*)h->counters.p, (Event*)h->events.p, max_events, max_job, (int64_t)std::max<uint64_t>(out_cap, 1ull << 20)};
+        if (counting && !(predecoded && attempt == 0)) GZCHK(h, hipMemcpyAsync((uint32_t*)counters.p + 7, &counting, 4, hipMemcpyHostToDevice, s));
+        a = Args{d_comp, (int64_t)n, (Job*)jobsB.p, (JobOut*)d_outs.p, 0, n_chunks, n_chunks, CH, (uint16_t*)pool.p, pages_now,
+                 (uint32_t*)d_page_next.p, (uint32_t*)counters.p, (Event*)events.p, max_events, max_job, (int64_t)std::max<uint64_t>(out_cap, 1ull << 20)};
         a.far_bytes = h->host_cont ? std::min<int64_t>(h->far_bytes, std::max<int64_t>(64 << 10, (int64_t)(n / 4))) : 0;   // (a small piece: a quarter of it)
-        if (prefound && attempt == 0) a.order = (const uint32_t*)h->order[jb].p + 2 * ORDER_BINS;   // (found and ordered under the piece in front)
-        else {
-            GZCHK(h, hipMemcpyAsync(h->jobs[jb].p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
-            a.order = launch_find(s, a, h->order[jb].p, n_chunks);
+        if (predecoded && attempt == 0) {   // found, ordered AND decoded under the piece in front: the results are on their way to h_outs
+            a.order = (const uint32_t*)orderB.p + 2 * ORDER_BINS;
+            GZCHK(h, hipEventSynchronize(h->pre_dec_ev));
+        } else {
+            if (prefound) a.order = (const uint32_t*)orderB.p + 2 * ORDER_BINS;   // (found and ordered under the piece in front; a repeat after a pool overflow keeps that)
+            else {
+                GZCHK(h, hipMemcpyAsync(jobsB.p, &j0, sizeof j0, hipMemcpyHostToDevice, s));
+                a.order = launch_find(s, a, orderB.p, n_chunks);
+            }
+            if (timing) { GZCHK(h, hipStreamSynchronize(s)); lap(1); }
+            hipLaunchKernelGGL(k_gz_decode, dim3((unsigned)n_chunks), dim3(DEC_BLOCK), 0, s, a);
+            GZCHK(h, hipGetLastError());
+            GZCHK(h, hipMemcpyAsync(outs, d_outs.p, (size_t)n_chunks * sizeof(JobOut), hipMemcpyDeviceToHost, s));
+            GZCHK(h, hipMemcpyAsync(h_counters, counters.p, 128, hipMemcpyDeviceToHost, s));
+            GZCHK(h, hipStreamSynchronize(s));
         }
-        if (timing) { GZCHK(h, hipStreamSynchronize(s)); lap(1); }
-        hipLaunchKernelGGL(k_gz_decode, dim3((unsigned)n_chunks), dim3(DEC_BLOCK), 0, s, a);
-        GZCHK(h, hipGetLastError());
-        GZCHK(h, hipMemcpyAsync(outs, h->outs.p, (size_t)n_chunks * sizeof(JobOut), hipMemcpyDeviceToHost, s));
-        GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 128, hipMemcpyDeviceToHost, s));
-        GZCHK(h, hipStreamSynchronize(s));
         lap(2);
         if (counting) fprintf(stderr, "bzq_gzip decoder: the symbol loop handed back %u times for a code it does not take / the end of a block, %u for its window, %u for a long distance code, %u for a copy it does not take, %u at a page's end\n",
                               h_counters[16], h_counters[18], h_counters[19], h_counters[20], h_counters[22]);
         if (counting) fprintf(stderr, "bzq_gzip finder clocks (x256, summed over waves): total %u, in flushes: waiting for the tables %u, the lanes' look %u, the wave's judgement %u\n", h_counters[12], h_counters[9], h_counters[10], h_counters[11]);
         if (counting) fprintf(stderr, "bzq_gzip finder: %u positions passed the 13-bit filter, %u of them the code length code test, %u of those one lane's look at the code lengths (judged by the whole wave)\n", h_counters[3], h_counters[4], h_counters[5]);
-        if (h_counters[0] <= h->pool_pages) break;
+        if (h_counters[0] <= pages_now) break;
         if (attempt == 8) return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: the symbol pool keeps overflowing (" + std::to_string(h->pool_pages) + " pages)");
-        h->pool_pages = std::max<uint32_t>(2u * h->pool_pages, h_counters[0] + (uint32_t)n_chunks);   // (counts the refused requests too)
+        h->pool_pages = std::max<uint32_t>(2u * std::max(h->pool_pages, pages_now), h_counters[0] + (uint32_t)n_chunks);   // (counts the refused requests too)
         h->stats.pool_retries += 1;
     }
 
@@ -1858,12 +1933,13 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
             // serially; after MAX_FALLBACK restarts the call hands over what it has (*more).
             if (fallbacks == MAX_FALLBACK) { final_status = ST_SPLIT; final_pos = o.end; break; }
             const int k = n_chunks + fallbacks++;
-            const Job jfb{o.end, (int32_t)std::min<uint64_t>((uint64_t)n_chunks, (o.end >> 4) / (uint64_t)CH), 0};
-            GZCHK(h, hipMemcpyAsync((Job*)h->jobs[jb].p + k, &jfb, sizeof jfb, hipMemcpyHostToDevice, s));
+            const uint64_t eb = (uint64_t)(o.end >> 4);   // (the first job whose chunk can hold a start at or behind it)
+            const Job jfb{o.end, (int32_t)std::min<uint64_t>((uint64_t)n_chunks, shifted ? (eb < nc ? 1 : (eb - nc) / (uint64_t)CH + 1) : eb / (uint64_t)CH), 0};
+            GZCHK(h, hipMemcpyAsync((Job*)jobsB.p + k, &jfb, sizeof jfb, hipMemcpyHostToDevice, s));
             a.job_base = k; a.n_jobs = 1; a.order = nullptr;
             hipLaunchKernelGGL(k_gz_decode, dim3(1), dim3(DEC_BLOCK), 0, s, a);
-            GZCHK(h, hipMemcpyAsync(outs + k, (JobOut*)h->outs.p + k, sizeof(JobOut), hipMemcpyDeviceToHost, s));
-            GZCHK(h, hipMemcpyAsync(h_counters, h->counters.p, 16, hipMemcpyDeviceToHost, s));
+            GZCHK(h, hipMemcpyAsync(outs + k, (JobOut*)d_outs.p + k, sizeof(JobOut), hipMemcpyDeviceToHost, s));
+            GZCHK(h, hipMemcpyAsync(h_counters, counters.p, 16, hipMemcpyDeviceToHost, s));
             GZCHK(h, hipStreamSynchronize(s));
             if (outs[k].status == ST_POOL_FULL) return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: symbol pool exhausted in a restart");
             h->stats.fallback_jobs += 1;
@@ -1897,30 +1973,67 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         *more = 1;
     }
 
+    std::function<int()> deferred_predecode;   // the next piece's decoders: launched behind this piece's chain / resolve / CRC kernels (below)
     // ---- the NEXT piece's finder, now: its carry is what this piece leaves behind final_pos, and that is known.  It runs on its
     // own stream under this piece's chain / resolve / CRC kernels (3 of a piece's 17 ms of kernels were the finder's).
     if (!*more && !is_last && (final_status == ST_NEED_MORE || final_status == ST_END_INPUT)) {
-        const uint8_t* src2 = nullptr; uint64_t n2 = 0; int cb2 = -1;
-        { std::lock_guard<std::mutex> lk(h->stage_mu); if (!h->staged.empty()) { src2 = h->staged.front().src; n2 = h->staged.front().n; cb2 = h->staged.front().buf; } }
+        const uint8_t* src2 = nullptr; uint64_t n2 = 0; int cb2 = -1; bool early = false; int nch_e = 0;
+        { std::lock_guard<std::mutex> lk(h->stage_mu); if (!h->staged.empty()) { src2 = h->staged.front().src; n2 = h->staged.front().n; cb2 = h->staged.front().buf; early = h->staged.front().found; nch_e = h->staged.front().nch; } }
         const uint64_t keep2 = (uint64_t)(final_pos >> 4);
         if (cb2 >= 0 && keep2 <= n && n - keep2 <= STAGE_RESERVE && n - keep2 + n2 <= (1ull << 33)) {
             const uint64_t nc2 = n - keep2, nn = nc2 + n2;
-            const int nch2 = (int)((nn + (uint64_t)CH - 1) / (uint64_t)CH), jn = jb ^ 1;
-            if ((rc = gz_ensure(h, h->order[jn], (size_t)2 * ORDER_BINS * 4 + (size_t)nch2 * 5 + 64)) || (rc = gz_ensure(h, h->jobs[jn], (size_t)(nch2 + MAX_FALLBACK) * sizeof(Job)))) return rc;
+            const int nch2 = early ? nch_e : (int)((nn + (uint64_t)CH - 1) / (uint64_t)CH), jn = jb ^ 1;
+            bzq_gzip::Buf &jobsN = early ? h->jobs_e[cb2] : h->jobs[jn], &orderN = early ? h->order_e[cb2] : h->order[jn];
+            if (!early && ((rc = gz_ensure(h, orderN, (size_t)2 * ORDER_BINS * 4 + (size_t)nch2 * 5 + 64)) || (rc = gz_ensure(h, jobsN, (size_t)(nch2 + MAX_FALLBACK) * sizeof(Job))))) return rc;
             uint8_t* d2 = (uint8_t*)h->comp[cb2].p + STAGE_RESERVE - nc2;
             const hipStream_t fs = h->find_stream;
-            GZCHK(h, hipStreamWaitEvent(fs, h->staged_ev[cb2], 0));
+            GZCHK(h, hipStreamWaitEvent(fs, early ? h->early_ev[cb2] : h->staged_ev[cb2], 0));
             if (nc2) GZCHK(h, hipMemcpyAsync(d2, d_comp + keep2, nc2, hipMemcpyDeviceToDevice, fs));
             GZCHK(h, hipEventRecord(h->pre_copy_ev, fs));
             const unsigned long long start2 = (final_pos & 1ull) ? pos_header(0) : pos_deflate((final_pos >> 1) & 7ull);
-            hipLaunchKernelGGL(k_gz_job0, dim3(1), dim3(1), 0, fs, (Job*)h->jobs[jn].p, (u64)start2);
-            Args a2{};
-            a2.comp = d2; a2.n = (int64_t)nn; a2.jobs = (Job*)h->jobs[jn].p; a2.n_jobs = nch2; a2.n_cand = nch2; a2.chunk_bytes = CH; a2.counters = (uint32_t*)h->counters2.p;
-            (void)launch_find(fs, a2, h->order[jn].p, nch2);
+            hipLaunchKernelGGL(k_gz_job0, dim3(1), dim3(1), 0, fs, (Job*)jobsN.p, (u64)start2);
+            if (early) {   // found behind its copy (gz_stage), relative to CH bytes in front of its own bytes: to where the piece starts now
+                hipLaunchKernelGGL(k_gz_shift, dim3((unsigned)((nch2 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, fs, (Job*)jobsN.p + 1, nch2 - 1, ((long long)nc2 - (long long)CH) * 16);
+                (void)launch_order(fs, (const Job*)jobsN.p, orderN.p, nch2);
+            } else {
+                Args a2{};
+                a2.comp = d2; a2.n = (int64_t)nn; a2.jobs = (Job*)jobsN.p; a2.n_jobs = nch2; a2.n_cand = nch2; a2.chunk_bytes = CH; a2.counters = (uint32_t*)h->counters2.p;
+                (void)launch_find(fs, a2, orderN.p, nch2);
+            }
             GZCHK(h, hipGetLastError());
             GZCHK(h, hipEventRecord(h->pre_ev, fs));
             GZCHK(h, hipEventSynchronize(h->pre_copy_ev));   // (this piece's buffer is given back when the call returns: the carry has left it)
+            h->pre.shifted = early; h->pre.nch = nch2;
             h->pre.valid = true; h->pre.src = src2; h->pre.n_new = n2; h->pre.nc = nc2; h->pre.start_pos = start2; h->pre.jb = jn; h->pre.cb = cb2;
+            // ... and its DECODERS behind the finder, into the other set: they need nothing of this piece but where it ended, and this
+            // piece's chain / resolve / CRC kernels (5.7 of a 17.6 ms cycle, the scalar-bound decoders idle meanwhile) run beside them
+            h->pre.decoded = false;
+            static const bool no_predecode = getenv("BZQ_GZ_NO_PREDECODE") != nullptr;
+            if (h->predecode && !no_predecode) deferred_predecode = [=, &jobsN, &orderN]() -> int {
+                int rc;
+                const int pn = pb ^ 1;
+                const int ncap2 = nch2 + MAX_FALLBACK;
+                const uint32_t maxev2 = (uint32_t)std::min<uint64_t>(nn / 18 + (uint64_t)nch2 + 64, 1u << 28);
+                const uint32_t want2 = (uint32_t)std::min<uint64_t>((nn * 5) >> PAGE_SHIFT, 1u << 24) + 2u * (uint32_t)nch2 + 64u;
+                if (h->pool_pages < want2) h->pool_pages = want2;
+                if ((rc = gz_ensure(h, h->pool_[pn], ((size_t)h->pool_pages << PAGE_SHIFT) * 2)) || (rc = gz_ensure(h, h->page_next_[pn], (size_t)h->pool_pages * 4)) ||
+                    (rc = gz_ensure(h, h->outs_[pn], (size_t)ncap2 * sizeof(JobOut))) || (rc = gz_ensure(h, h->events_[pn], (size_t)maxev2 * sizeof(Event))) ||
+                    (rc = gz_ensure(h, h->h_outs_[pn], (size_t)ncap2 * sizeof(JobOut) + 128, true)))
+                    return rc;
+                GZCHK(h, hipMemsetAsync(h->counters_[pn].p, 0, 128, fs));
+                Args a3{d2, (int64_t)nn, (Job*)jobsN.p, (JobOut*)h->outs_[pn].p, 0, nch2, nch2, CH, (uint16_t*)h->pool_[pn].p, h->pool_pages,
+                        (uint32_t*)h->page_next_[pn].p, (uint32_t*)h->counters_[pn].p, (Event*)h->events_[pn].p, maxev2, max_job, (int64_t)std::max<uint64_t>(out_cap, 1ull << 20)};
+                a3.order = (const uint32_t*)orderN.p + 2 * ORDER_BINS;
+                a3.far_bytes = h->host_cont ? std::min<int64_t>(h->far_bytes, std::max<int64_t>(64 << 10, (int64_t)(nn / 4))) : 0;
+                hipLaunchKernelGGL(k_gz_decode, dim3((unsigned)nch2), dim3(DEC_BLOCK), 0, fs, a3);
+                GZCHK(h, hipGetLastError());
+                JobOut* ho2 = (JobOut*)h->h_outs_[pn].p;
+                GZCHK(h, hipMemcpyAsync(ho2, h->outs_[pn].p, (size_t)nch2 * sizeof(JobOut), hipMemcpyDeviceToHost, fs));
+                GZCHK(h, hipMemcpyAsync((uint8_t*)ho2 + (size_t)ncap2 * sizeof(JobOut), h->counters_[pn].p, 128, hipMemcpyDeviceToHost, fs));
+                GZCHK(h, hipEventRecord(h->pre_dec_ev, fs));
+                h->pre.decoded = true; h->pre.pb = pn; h->pre.pool_pages = h->pool_pages; h->pre.max_job = max_job;
+                return 0;
+            };
         }
     }
 
@@ -1930,7 +2043,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     const uint32_t n_events = std::min(h_counters[1], max_events);
     if (n_events) {
         if ((rc = gz_ensure(h, h->h_events, (size_t)n_events * sizeof(Event), true))) return rc;
-        GZCHK(h, hipMemcpyAsync(h->h_events.p, h->events.p, (size_t)n_events * sizeof(Event), hipMemcpyDeviceToHost, s));
+        GZCHK(h, hipMemcpyAsync(h->h_events.p, events.p, (size_t)n_events * sizeof(Event), hipMemcpyDeviceToHost, s));
         GZCHK(h, hipStreamSynchronize(s));
         std::vector<int> chain_idx((size_t)n_jobs_total, -1);
         for (size_t i = 0; i < accepted; ++i) chain_idx[(size_t)chain[i]] = (int)i;
@@ -1945,9 +2058,9 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     }
 
     // ---- work lists: chain items, resolve items, CRC segments
-    const uint32_t pages_used = std::min(h_counters[0], h->pool_pages);
+    const uint32_t pages_used = std::min(h_counters[0], a.pool_pages);
     if ((rc = gz_ensure(h, h->h_pages, (size_t)pages_used * 4 + 16, true))) return rc;
-    if (pages_used) GZCHK(h, hipMemcpyAsync(h->h_pages.p, h->page_next.p, (size_t)pages_used * 4, hipMemcpyDeviceToHost, s));
+    if (pages_used) GZCHK(h, hipMemcpyAsync(h->h_pages.p, d_page_next.p, (size_t)pages_used * 4, hipMemcpyDeviceToHost, s));
     GZCHK(h, hipStreamSynchronize(s));
     const uint32_t* page_next = (const uint32_t*)h->h_pages.p;
     std::vector<ChainItem> citems;
@@ -2004,19 +2117,19 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         const int n_groups = n_it ? (n_it + per_group - 1) / per_group : 1;
         const ChainItem* d_items = (const ChainItem*)h->items.p;
         if (n_groups <= 1) {
-            hipLaunchKernelGGL(k_gz_chain<false>, dim3(1), dim3(CHAIN_THREADS), 0, s, d_items, n_it, std::max(1, n_it), (const uint16_t*)h->pool.p, w0, d_out, (uint16_t*)nullptr, w_next);
+            hipLaunchKernelGGL(k_gz_chain<false>, dim3(1), dim3(CHAIN_THREADS), 0, s, d_items, n_it, std::max(1, n_it), (const uint16_t*)pool.p, w0, d_out, (uint16_t*)nullptr, w_next);
         } else {
             if ((rc = gz_ensure(h, h->chain_maps, (size_t)n_groups * 65536)) || (rc = gz_ensure(h, h->chain_wins, (size_t)n_groups * 32768))) return rc;
-            hipLaunchKernelGGL(k_gz_chain<true>, dim3((unsigned)n_groups), dim3(CHAIN_THREADS), 0, s, d_items, n_it, per_group, (const uint16_t*)h->pool.p, (const uint8_t*)nullptr, (uint8_t*)nullptr,
+            hipLaunchKernelGGL(k_gz_chain<true>, dim3((unsigned)n_groups), dim3(CHAIN_THREADS), 0, s, d_items, n_it, per_group, (const uint16_t*)pool.p, (const uint8_t*)nullptr, (uint8_t*)nullptr,
                                (uint16_t*)h->chain_maps.p, (uint8_t*)nullptr);
             hipLaunchKernelGGL(k_gz_chain_groups, dim3(1), dim3(CHAIN_THREADS), 0, s, (const uint16_t*)h->chain_maps.p, n_groups, w0, (uint8_t*)h->chain_wins.p);
-            hipLaunchKernelGGL(k_gz_chain<false>, dim3((unsigned)n_groups), dim3(CHAIN_THREADS), 0, s, d_items, n_it, per_group, (const uint16_t*)h->pool.p, (const uint8_t*)h->chain_wins.p, d_out,
+            hipLaunchKernelGGL(k_gz_chain<false>, dim3((unsigned)n_groups), dim3(CHAIN_THREADS), 0, s, d_items, n_it, per_group, (const uint16_t*)pool.p, (const uint8_t*)h->chain_wins.p, d_out,
                                (uint16_t*)nullptr, w_next);
         }
     }
     if (timing) { GZCHK(h, hipStreamSynchronize(s)); lap(4); }
     if (!ritems.empty())
-        hipLaunchKernelGGL(k_gz_resolve, dim3((unsigned)ritems.size()), dim3(BLOCK), 0, s, (const ResItem*)((uint8_t*)h->items.p + o_res), (const uint16_t*)h->pool.p, w0, d_out);
+        hipLaunchKernelGGL(k_gz_resolve, dim3((unsigned)ritems.size()), dim3(BLOCK), 0, s, (const ResItem*)((uint8_t*)h->items.p + o_res), (const uint16_t*)pool.p, w0, d_out);
     if (timing) { GZCHK(h, hipStreamSynchronize(s)); lap(5); }
     if (!segs.empty()) {
         GZCHK(h, hipMemsetAsync(h->crcs.p, 0, segs.size() * 4, s));
@@ -2025,6 +2138,9 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         GZCHK(h, hipMemcpyAsync(h->h_crcs.p, h->crcs.p, segs.size() * 4, hipMemcpyDeviceToHost, s));
     }
     GZCHK(h, hipGetLastError());
+    // (enqueued BEHIND this piece's last kernels: launched in front of them, the 16 000 decoder waves took every CU and the chain
+    // kernels -- 1024 threads and 64 KiB of LDS a workgroup -- waited for the decoders' end: 8 ms instead of 0.9)
+    if (deferred_predecode && (rc = deferred_predecode())) return rc;
     GZCHK(h, hipStreamSynchronize(s));
     lap(6);
     h->wcur ^= 1;

@@ -77,11 +77,17 @@ struct bzq_ingest {
     uint64_t gz_cap = 0, gz_have = 0, gz_off = 0;   // capacity, bytes waiting, file offset of the next compressed byte
     bool gz_more = false, gz_done = false;
     // read-ahead: while piece k is decoded, helper threads read piece k + 1 into the other slot's pinned buffer
-    uint64_t gz_piece = 0;             // compressed bytes per piece: starts at half a chunk, then follows the file's compression ratio (gz_fill_fifo)
+    std::atomic<uint64_t> gz_piece{0}; // compressed bytes per piece: starts at half a chunk, then follows the file's compression ratio (gz_fill_fifo)
+    // read-ahead: one thread reads piece after piece into the three slots' pinned buffers, up to two pieces in front of the one being
+    // decoded, and sends each on to the device (gz_stage) -- the decoder starts piece k + 1's finder and decoders while piece k's last
+    // kernels run (bzq_gzip.hpp, round 4), so piece k + 2 must be under way by then
     std::thread gz_reader;
-    bool gz_read_pending = false, gz_read_ok = true;
-    int gz_read_buf = 0;               // which pinned buffer the pending / last read went to
-    uint64_t gz_read_len = 0;
+    std::mutex gz_mu;
+    std::condition_variable gz_cv;
+    struct GzPiece { uint64_t len = 0; bool last = false, ok = true; };
+    GzPiece gz_ring[bzq::INGEST_SLOTS];
+    uint64_t gz_rd_ready = 0, gz_rd_taken = 0;   // pieces read and published / pieces whose decode call has returned (their buffer is free)
+    bool gz_stop = false, gz_all_handed = false;
     std::string gz_read_err;
     bzq::IngestSlot slot[bzq::INGEST_SLOTS];
     hipStream_t copy_stream = nullptr;   // H2D of the chunks
@@ -319,38 +325,62 @@ inline bool read_bgzf_window(bzq_ingest* g, uint8_t* pinned, uint64_t cap, bzq::
 // (half a chunk of compressed bytes: enough block starts to fill the device) and are read AHEAD: while piece k is decoded,
 // helper threads read piece k + 1 into the other slot's pinned buffer.  The FIFO is sized so that a piece's output always fits
 // behind a chunk that is still waiting in it (6 chunks; beyond a ratio of 10 the decoder keeps the rest and is asked again).
-inline void gz_start_read(bzq_ingest* g, int buf) {
-    const uint64_t len = std::min<uint64_t>(g->gz_piece, g->file_size - g->gz_off), off = g->gz_off;
-    g->gz_off += len;
-    g->gz_read_buf = buf; g->gz_read_len = len; g->gz_read_pending = true;
-    uint8_t* dst = g->slot[buf].pinned + g->reserve;
-    g->gz_reader = std::thread([g, dst, off, len]() {
-        g->gz_read_ok = parallel_pread(g->fd, dst, off, len, g->n_threads, g->gz_read_err, g->fd_direct, &g->numa_cpus);
-        // on to the device at once: the copy runs behind the decoding of the piece in front (a failure here only means that
-        // the piece is copied by its gz_decode)
-        if (g->gz_read_ok && g->gz_dev) (void)bzq::gz::gz_stage(g->gz_dev, dst, len);
-    });
+inline void gz_read_ahead(bzq_ingest* g) {
+    for (uint64_t seq = 0;; ++seq) {
+        {
+            std::unique_lock<std::mutex> lk(g->gz_mu);
+            g->gz_cv.wait(lk, [&] { return g->gz_stop || seq - g->gz_rd_taken < (uint64_t)INGEST_SLOTS; });
+            if (g->gz_stop) return;
+        }
+        const uint64_t off = g->gz_off;
+        if (off >= g->file_size) return;   // (the piece in front was the last)
+        const uint64_t len = std::min<uint64_t>(g->gz_piece.load(), g->file_size - off);
+        g->gz_off = off + len;
+        const int buf = (int)(seq % INGEST_SLOTS);
+        uint8_t* dst = g->slot[buf].pinned + g->reserve;
+        std::string err;
+        const bool ok = parallel_pread(g->fd, dst, off, len, g->n_threads, err, g->fd_direct, &g->numa_cpus);
+        // on to the device at once: the copy runs behind the decoding of the pieces in front (a failure here only means that the
+        // piece is copied by its gz_decode)
+        if (ok && g->gz_dev) (void)bzq::gz::gz_stage(g->gz_dev, dst, len);
+        const bool last = off + len >= g->file_size;
+        {
+            std::unique_lock<std::mutex> lk(g->gz_mu);
+            g->gz_ring[buf].len = len; g->gz_ring[buf].last = last; g->gz_ring[buf].ok = ok;
+            if (!ok) g->gz_read_err = err;
+            g->gz_rd_ready = seq + 1;
+            g->gz_cv.notify_all();
+        }
+        if (!ok || last) return;
+    }
 }
 inline bool gz_fill_fifo(bzq_ingest* g, std::string& err) {
+    if (!g->gz_reader.joinable() && !g->gz_all_handed && g->gz_rd_ready == 0) g->gz_reader = std::thread(gz_read_ahead, g);
     while (g->gz_have < g->chunk_bytes && !g->gz_done) {
         const uint64_t free_bytes = g->gz_cap - g->gz_have;
         const uint8_t* src = nullptr;
         uint64_t want = 0;
-        bool file_done = g->gz_off >= g->file_size && !g->gz_read_pending;
-        if (!g->gz_more && !file_done) {
-            if (!g->gz_read_pending) gz_start_read(g, 0);
-            g->gz_reader.join();
-            g->gz_read_pending = false;
-            if (!g->gz_read_ok) { err = g->gz_read_err; return false; }
-            src = g->slot[g->gz_read_buf].pinned + g->reserve;
-            want = g->gz_read_len;
-            file_done = g->gz_off >= g->file_size;
-            if (!file_done) gz_start_read(g, g->gz_read_buf ^ 1);   // the next piece travels from the disk while this one is decoded
-            // (gz_read_buf now names the NEXT buffer; `src` keeps this one)
+        bool file_done = g->gz_all_handed, took = false;
+        if (!g->gz_more && !g->gz_all_handed) {
+            std::unique_lock<std::mutex> lk(g->gz_mu);
+            g->gz_cv.wait(lk, [&] { return g->gz_rd_ready > g->gz_rd_taken; });
+            const int buf = (int)(g->gz_rd_taken % INGEST_SLOTS);
+            if (!g->gz_ring[buf].ok) { err = g->gz_read_err; return false; }
+            src = g->slot[buf].pinned + g->reserve;
+            want = g->gz_ring[buf].len;
+            file_done = g->gz_ring[buf].last;
+            if (file_done) g->gz_all_handed = true;
+            took = true;
         }
         uint64_t got = 0;
         int32_t more = 0;
-        if (bzq::gz::gz_decode(g->gz_dev, src, want, file_done, g->gz_fifo[g->gz_cur] + g->gz_have, free_bytes, &got, &more) < 0) { err = g->gz_dev->err; return false; }
+        const int drc = bzq::gz::gz_decode(g->gz_dev, src, want, file_done, g->gz_fifo[g->gz_cur] + g->gz_have, free_bytes, &got, &more);
+        if (took) {   // the piece's pinned buffer is free (what the decoder keeps of it, it keeps in a copy)
+            std::unique_lock<std::mutex> lk(g->gz_mu);
+            g->gz_rd_taken += 1;
+            g->gz_cv.notify_all();
+        }
+        if (drc < 0) { err = g->gz_dev->err; return false; }
         g->gz_have += got;
         // the pieces to come: as large as half the FIFO takes decoded (the decode kernel works in rounds of ~6 000 decoder
         // waves: 256 MiB of 2 x compressible FASTQ are 13 000, 128 MiB one round and a bit, which costs a sixth of the rate), at
@@ -361,7 +391,7 @@ inline bool gz_fill_fifo(bzq_ingest* g, std::string& err) {
             const double ratio = (double)got / (double)want;
             const uint64_t fit = (uint64_t)((double)(g->gz_cap / 2) / (ratio > 1.0 ? ratio : 1.0)) & ~4095ull;
             g->gz_piece = std::min<uint64_t>(g->chunk_bytes, std::max<uint64_t>(fit, std::min<uint64_t>(g->chunk_bytes, 1ull << 20)));
-        } else if (more && g->gz_piece > (2ull << 20)) g->gz_piece = (g->gz_piece / 2) & ~4095ull;
+        } else if (more && g->gz_piece.load() > (2ull << 20)) g->gz_piece = (g->gz_piece.load() / 2) & ~4095ull;
         g->gz_more = more != 0;
         g->gz_done = (file_done && !more) || g->gz_dev->finished;
         // (a call without new input that delivers nothing is fine while the file has more to give -- the host continuation of a
@@ -482,6 +512,7 @@ inline void ingest_free(bzq_ingest* g) {
         g->cv.notify_all();
     }
     if (g->producer.joinable()) g->producer.join();
+    { std::unique_lock<std::mutex> lk(g->gz_mu); g->gz_stop = true; g->gz_cv.notify_all(); }
     if (g->gz_reader.joinable()) g->gz_reader.join();   // (a read-ahead still writing into a slot's pinned buffer)
     (void)hipSetDevice(g->device);
     for (int i = 1; i < INGEST_SLOTS; ++i)

@@ -349,3 +349,26 @@ def test_a_file_without_findable_block_starts_through_the_parser(tmp_path):
         assert [len(b) for b in got] == [len(b) for b in ref]
         for g, r in zip(got, ref):
             assert g._sequence_bytes.tobytes() == r.seq_bytes and g._quality_bytes.tobytes() == r.qual_bytes and g._id_bytes.tobytes() == r.id_bytes
+
+
+@pytest.mark.parametrize("early_find,predecode", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_the_next_piece_under_this_one(early_find, predecode):
+    """Round 4: with pieces staged ahead, piece k + 1's decoders run under piece k's chain / resolve / CRC kernels (option
+    predecode, into the second set of pool / results), and its finder either behind the decoding of piece k (on the piece's
+    uniform chunk grid) or behind its own copy (option early_find: on a grid over its own bytes, shifted once the carry is
+    known).  Every combination == zlib's bytes, through piece sizes that cut blocks, headers and trailers, output buffers that
+    cut pieces, many small members, and a stretch the host continues."""
+    rng = np.random.default_rng(31)
+    fq = synthetic_fastq(60_000)   # 19 MB
+    many = b"".join(gzip_member(fq[i:i + 150_000], int(rng.integers(1, 10))) for i in range(0, 6_000_000, 150_000))
+    mixed = gzip_member(fq[:5_000_000], 6) + gzip_member(fq[5_000_000:7_000_000], 6, zlib.Z_FIXED) + gzip_member(fq[7_000_000:], 9)
+    ctx = Context()
+    for comp, data, piece, cap, ahead in [(gzip.compress(fq, 6), fq, 1 << 20, len(fq), 2), (gzip.compress(fq, 1), fq, 700_001, 5_000_000, 2),
+                                          (many, fq[:6_000_000], 400_000, 6_000_000, 2), (mixed, fq, 1_500_000, len(fq), 2),
+                                          (gzip.compress(fq, 6), fq, 2_000_000, len(fq), 1)]:
+        g = DeviceGunzip(ctx, cap, chunk_bytes=4096)
+        g.dec.set_option("early_find", early_find)
+        g.dec.set_option("predecode", predecode)
+        g.dec.set_option("far_kib", 64)
+        assert g.decode(comp, piece, ahead=ahead) == data, (early_find, predecode, piece, cap, ahead)
+        g.close()
