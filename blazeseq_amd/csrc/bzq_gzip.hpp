@@ -1575,8 +1575,8 @@ inline int gz_open(int device, bzq_gzip** out, std::string& err) {
 
 // A piece that a LATER gz_decode will be given starts its way to the device now (pinned host memory, or the call is
 // pointless): the gz_decode that gets the same (src, n) finds it there instead of copying -- 5 ms of a 256 MiB piece's ~35,
-// hidden behind the decoding of the piece in front.  Two pieces can be outstanding (two buffers: one may be the piece being
-// decoded); with both taken the call does nothing, and that piece is copied by its gz_decode as if never staged.  Pieces are
+// hidden behind the decoding of the piece in front.  Three pieces can be outstanding (three buffers: one may be the piece being
+// decoded); with all taken the call does nothing, and that piece is copied by its gz_decode as if never staged.  Pieces are
 // taken in the order staged.  May be called from another thread than gz_decode's while that runs (the ingest's read-ahead
 // thread does), not concurrently with itself; src must stay untouched until its gz_decode has returned.
 constexpr uint64_t STAGE_RESERVE = 4ull << 20;

@@ -433,7 +433,11 @@ int32_t bzq_gzip_open(bzq_ctx* ctx, bzq_gzip** out);
  * of KiB -- would be ONE wave's work on the device (~10 MB/s); the decoder stops there (*more = 1) and the next bzq_gzip_decode
  * continues with zlib on the calling thread (200-600 MB/s; same checks, same bytes), for "host_budget_kib" of output (default
  * 32 MiB, doubling while the device keeps handing over), then the device is asked again.  "far_kib" (default 256): how far a
- * decoder goes without meeting a found start before it stops.  Query "host_calls": calls that ran on the host. */
+ * decoder goes without meeting a found start before it stops.  Query "host_calls": calls that ran on the host.
+ * "predecode" (default 1): with pieces staged ahead (bzq_gzip_stage; up to three buffers: the piece being decoded and two behind
+ * it), the finder and the decoders of piece k + 1 are launched as soon as piece k's chain is walked and run beside piece k's last
+ * kernels, into a second set of pool / result buffers.  "early_find" (default 0): a staged piece's finder runs behind its copy, on
+ * a chunk grid over its own bytes (measured: no faster). */
 int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value);
 /* The next n compressed bytes (HOST memory; pinned memory makes the copy a DMA) -> their bytes at d_out (DEVICE memory,
  * out_capacity bytes).  Whole DEFLATE blocks only: what is left of the piece stays inside the handle and is decoded in front of
@@ -447,7 +451,7 @@ int32_t bzq_gzip_decode(bzq_gzip* h, const uint8_t* comp, uint64_t n, int32_t is
 /* Optional read-ahead: a piece that a LATER bzq_gzip_decode will be given starts its way to the device now; the
  * bzq_gzip_decode that gets the same (comp, n) finds it there instead of copying -- and, when it is the piece right behind the
  * one being decoded, with its block finder already run (that starts as soon as the decode in front knows what it leaves over).  comp: pinned host memory, untouched until
- * that call has returned.  Up to two pieces can be outstanding (the one being decoded counts); with both taken the call does
+ * that call has returned.  Up to three pieces can be outstanding (the one being decoded counts); with all taken the call does
  * nothing.  Pieces are taken in the order staged.  May be called from a second thread while bzq_gzip_decode runs.  A negative
  * return only says that nothing was staged (the piece is then copied by its bzq_gzip_decode); bzq_gzip_last_error is not set. */
 int32_t bzq_gzip_stage(bzq_gzip* h, const uint8_t* comp, uint64_t n);
