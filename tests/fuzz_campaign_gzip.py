@@ -76,8 +76,16 @@ while time.time() - t0 < args.seconds:
     piece_size = int(rng.choice([0, 1 << 16, 1 << 20, int(rng.integers(1, len(blob) + 2))]))
     cap = len(data) + 4096 if rng.random() < 0.6 else max(300000, len(data) // int(rng.integers(2, 6)))
     g = DeviceGunzip(ctx, cap, chunk_bytes=int(rng.choice([4096, 8192, 16384, 32768, 65536])))
+    # round 4: pieces staged ahead (the next piece's finder / decoders then run under this piece's last kernels), the finder behind
+    # the piece's own copy, the hand-over of a stretch without findable block starts to the host and back -- in every combination
+    ahead = int(rng.choice([0, 0, 1, 2, 3])) if piece_size else 0
+    g.dec.set_option("predecode", int(rng.random() < 0.8))
+    g.dec.set_option("early_find", int(rng.random() < 0.5))
+    g.dec.set_option("host_continuation", int(rng.random() < 0.85))
+    g.dec.set_option("far_kib", int(rng.choice([16, 64, 256])))
+    g.dec.set_option("host_budget_kib", int(rng.choice([64, 512, 32768])))
     try:
-        got = g.decode(blob, piece_size)
+        got = g.decode(blob, piece_size, ahead=ahead)
         if damaged and got != data:
             # a cut that falls exactly behind a member leaves a valid, shorter file (and bytes behind it are ignored)
             prefixes = {b"".join(parts[:k]) for k in range(len(parts) + 1)}
