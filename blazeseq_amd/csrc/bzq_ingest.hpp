@@ -321,10 +321,12 @@ inline bool read_bgzf_window(bzq_ingest* g, uint8_t* pinned, uint64_t cap, bzq::
     return true;
 }
 
-// Device gzip: decode pieces of the file into the FIFO until it holds a chunk (or the stream ends).  Pieces have a fixed size
-// (half a chunk of compressed bytes: enough block starts to fill the device) and are read AHEAD: while piece k is decoded,
-// helper threads read piece k + 1 into the other slot's pinned buffer.  The FIFO is sized so that a piece's output always fits
-// behind a chunk that is still waiting in it (6 chunks; beyond a ratio of 10 the decoder keeps the rest and is asked again).
+// Device gzip: decode pieces of the file into the FIFO until it holds a chunk (or the stream ends).  Pieces are as large as half the
+// FIFO takes decoded, at most a chunk (enough block starts to fill the device), and are read AHEAD by one thread (gz_read_ahead):
+// up to two pieces in front of the one being decoded, into the three slots' pinned buffers in turn, each sent on to the device at
+// once (gz_stage) -- the decoder starts piece k + 1's finder and decoders while piece k's last kernels run, so piece k + 2 must be
+// on its way by then.  The FIFO is sized so that a piece's output always fits behind a chunk that is still waiting in it (6 chunks;
+// beyond a ratio of 10 the decoder keeps the rest and is asked again).
 inline void gz_read_ahead(bzq_ingest* g) {
     for (uint64_t seq = 0;; ++seq) {
         {
