@@ -135,7 +135,7 @@ struct bzq_ctx {
     bool fold = false;         // ... decided per chunk (decide_fold)
     bool cum_valid = false;    // the current chunk's chunk-cumulative ends / id_ends hold values (always without fold; with it: after bzq_chunk_cumulative_ends)
     bool finish_done = false;  // k_tail of this submit already left the chunk totals (enqueue_rebase skips k_finish once)
-    DevBuf tile_last, tileB, btile;
+    DevBuf tile_last, tileB, btile, tile_l4;
     // bzq_shard_read_range: the rank's byte range of a file in device memory, and the pinned pieces it travelled through
     DevBuf shard_buf;
     std::vector<void*> shard_pin;          // 2 per reader thread, SHARD_PIECE bytes each (pinned once, reused)
@@ -260,7 +260,7 @@ int ensure_tile_arenas(bzq_ctx* c, uint64_t n) {
     if (c->cfg.views_only) {   // line entries: a 4 KiB slot per tile + a pool of 64 KiB slots for tiles of tiny records
         c->pool_slots = std::max<int64_t>(16, nt / 8);
         if ((rc = ensure(c, c->entries, (size_t)nt * ENT_STRIDE * 4)) || (rc = ensure(c, c->tile_list, (size_t)c->pool_slots * TILE * 4)) ||
-            (rc = ensure(c, c->tile_vf, (size_t)nt + 64)))
+            (rc = ensure(c, c->tile_vf, (size_t)nt + 64)) || (rc = ensure(c, c->tile_l4, (size_t)nt * 16)))
             return rc;
     }
     return 0;
@@ -620,7 +620,7 @@ void launch_views(bzq_ctx* c, dim3 grid, int64_t tb, int64_t te) {
                    (const uint32_t*)c->tile_list.p, (int64_t*)c->o().off[0].p, (int64_t*)c->o().off[1].p, (int64_t*)c->o().off[2].p,
                    (int64_t*)c->o().off[3].p, (int64_t*)c->o().rec_end.p, (int64_t*)c->o().id_start.p, (int32_t*)c->o().id_len.p, c->o().rec_cap,
                    c->cur_first_header, growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->d_state,
-                   (const uint8_t*)c->tile_vf.p, c->cfg.check_ascii, c->cfg.check_quality};
+                   (const uint8_t*)c->tile_vf.p, c->cfg.check_ascii, c->cfg.check_quality, (const uint32_t*)c->tile_l4.p};
         const dim3 jg((unsigned)((te - tb + JOIN_TILES - 1) / JOIN_TILES));
         if (views_validating(c)) hipLaunchKernelGGL(k_views_join<true>, jg, dim3(BLOCK), 0, c->stream, j);
         else hipLaunchKernelGGL(k_views_join<false>, jg, dim3(BLOCK), 0, c->stream, j);
@@ -666,9 +666,10 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
                 if (views_meta(c)) {
                     LineArgs la{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
                                 (u64*)c->tile_idc.p, (uint32_t*)c->entries.p, (uint32_t*)c->tile_list.p, c->pool_slots, c->d_state,
-                                c->force_dense, (uint8_t*)c->tile_vf.p, (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper};
-                    if (views_validating(c)) hipLaunchKernelGGL(k_tile_lines<true>, grid, dim3(BLOCK), 0, c->stream, la);
-                    else hipLaunchKernelGGL(k_tile_lines<false>, grid, dim3(BLOCK), 0, c->stream, la);
+                                c->force_dense, (uint8_t*)c->tile_vf.p, (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper, (uint32_t*)c->tile_l4.p};
+                    const dim3 lg((unsigned)((te - tb + LINES_TPW - 1) / LINES_TPW));   // a workgroup walks LINES_TPW tiles
+                    if (views_validating(c)) hipLaunchKernelGGL(k_tile_lines<true>, lg, dim3(BLOCK), 0, c->stream, la);
+                    else hipLaunchKernelGGL(k_tile_lines<false>, lg, dim3(BLOCK), 0, c->stream, la);
                 } else if (c->cfg.views_only) hipLaunchKernelGGL(k_tile_count, grid, dim3(BLOCK), 0, c->stream, a);
 #if BZQ_EXPERIMENTS
                 else if (!c->v2) hipLaunchKernelGGL(k_tile_aggregate, grid, dim3(BLOCK), 0, c->stream, a);
@@ -801,7 +802,9 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
             if ((rc = enqueue_passes(c, false, reuse_aggregates))) return rc;
             if (c->exact_sticky > 0 && !c->cfg.views_only) c->exact_sticky -= 1;
         }
-        hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state, finish_args(c, true));
+        // (views mode through line entries: the join's last workgroup looks at the tail itself)
+        if (!(views_meta(c) && !c->ran_single_pass && !c->ran_stream))
+            hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state, finish_args(c, true));
         c->finish_done = c->fold;
     } else c->fold = false;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -1042,7 +1045,7 @@ void bzq_destroy(bzq_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)bzq_comm_destroy(c);
     std::vector<DevBuf*> bufs = {&c->in, &c->tile_c, &c->tile_a, &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc,
-                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf, &c->inflate_tab, &c->tile_last, &c->tileB, &c->btile, &c->shard_buf, &c->inflate_scratch};
+                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf, &c->inflate_tab, &c->tile_last, &c->tileB, &c->btile, &c->tile_l4, &c->shard_buf, &c->inflate_scratch};
     for (OutSet& o : c->out) {
         for (DevBuf* b : {&o.seq, &o.qual, &o.id, &o.ends, &o.id_ends, &o.rec_end, &o.b_ends, &o.b_id_ends, &o.off[0], &o.off[1],
                           &o.off[2], &o.off[3], &o.id_start, &o.id_len, &o.bb})

@@ -65,22 +65,10 @@ struct LineArgs {
     int32_t force_dense;   // test switch: every tile through the pool
     uint8_t* tile_vf;      // validation: per tile, bit 0 / 1 = non-ascii / out-of-range byte after the tile's last newline
     uint32_t q_lower, q_upper;
+    uint32_t* tile_last4;  // [tiles][4]: the tile's last four entries (slot 3 = the last), so that the join finds the lines of the record that
+                           // straddles into the NEXT tile at a fixed address -- no walk back through the prefixes
 };
 
-__device__ __forceinline__ uint32_t line_start_info(const ByteSrc& b, int64_t s) {   // s = first byte of a line
-    if (s >= b.n) return 0u;
-    const uint32_t c0 = b.at(s);
-    uint32_t lead = 0;
-    for (int64_t p = s + 1; p < b.n && lead < ENT_SAT; ++p) {
-        const uint32_t c = b.at(p);
-        if (c == 10u || !is_posix_space(c)) break;
-        ++lead;
-    }
-    return (c0 == 64u ? 1u << 14 : 0u) | (c0 == 43u ? 1u << 15 : 0u) | (lead << 16);
-}
-
-// Pass A of the metadata pipeline: the ONLY kernel that reads the input.  One workgroup per tile; every thread owns the
-// newlines of its 64 bytes.
 // 0x80 in every byte outside [lo, hi] (hi < 128)
 __device__ __forceinline__ uint32_t out_of_range_flags(uint32_t x, uint32_t lo, uint32_t hi) {
     const uint32_t t = x & 0x7F7F7F7Fu;
@@ -88,91 +76,182 @@ __device__ __forceinline__ uint32_t out_of_range_flags(uint32_t x, uint32_t lo, 
     return (~ge_lo | gt_hi | x) & 0x80808080u;
 }
 
+// POSIX space other than '\n' (the byte walks of _strip_spaces stop at the line's own newlines; utils.mojo:221-242, 267-289)
+__device__ __forceinline__ bool is_space_not_nl(uint32_t c) { return c <= 32u && ((0x170003A00ull >> c) & 1ull); }
+
+// Piece (16 bytes) of load round s of this thread, WAVE-contiguous: wave w fetches bytes [4096 w, 4096 (w + 1)) of the tile -- the
+// same bytes its lanes own as 64-byte stretches once the 16-bit masks have gone through LDS.  The transposition is therefore
+// wave-local (a wave's DS operations execute in order: no workgroup barrier between its writes and its reads), and the wave's
+// newline count is known before the tile's one barrier.
+__device__ __forceinline__ int wave_piece(int s) { return (int)(threadIdx.x & ~63u) * 4 + s * 64 + (int)(threadIdx.x & 63u); }
+
+template <bool NT>
+__device__ __forceinline__ void tile_fetch_w(const uint8_t* __restrict__ g, int64_t n, int64_t t0, int valid, uint4 (&r)[4]) {
+    if (valid == TILE) {   // every tile but the last: no guards
+        const uint8_t* __restrict__ p = g + t0 + wave_piece(0) * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) r[s] = load16_any<NT>(p + 1024 * s);
+        return;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int pos = wave_piece(s) * 16;
+        r[s] = make_uint4(0u, 0u, 0u, 0u);
+        if (pos < valid) r[s] = load16(g, t0 + pos, n);
+    }
+}
+
+// Pass A of the metadata pipeline: the ONLY kernel that reads the input.  A workgroup walks LINES_TPW consecutive tiles; every
+// thread owns the newlines of its 64 bytes.  The tile sits in LDS between a 16-byte halo on either side (the bytes before and
+// after it; before the chunk: prev_byte behind newlines, after its end: zeros), so that everything an entry says about the
+// bytes around a newline -- the byte before it, the two after it -- is one unguarded pair of LDS dwords; only a newline that
+// does touch an id space walks on, and a run that leaves the halo is reported saturated (the join then reads it from the
+// input).  The next tile's loads are issued as soon as this tile's registers have gone to LDS: they fly while the entries are
+// written, so a workgroup's slot on the CU never sits without a request in the memory system.
+#ifndef BZQ_LINES_TPW
+#define BZQ_LINES_TPW 1
+#endif
+constexpr int LINES_TPW = BZQ_LINES_TPW;
+
 template <bool VAL>
 static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[16 + TILE + 32];
+    constexpr int HALO = 16;
+    __shared__ __attribute__((aligned(16))) uint8_t s_tile_raw[HALO + TILE + 32];
     __shared__ __attribute__((aligned(16))) uint16_t s_mask[PIECES];
     __shared__ __attribute__((aligned(16))) uint16_t s_hi[VAL ? PIECES : 4], s_out[VAL ? PIECES : 4];
     __shared__ uint32_t s_chain[2][BLOCK / 64];
-    __shared__ uint32_t s_w[BLOCK / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_w[BLOCK / 64];
     __shared__ int64_t s_slot;
-    uint8_t* s_tile = s_tile_raw + 16;
-    const int tid = threadIdx.x;
-    const int64_t t = a.tile_begin + xcd_tile();   // (neighbouring tiles on one XCD: bzq_device.hpp)
+    uint8_t* s_tile = s_tile_raw + HALO;
+    const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(s_tile_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t t = a.tile_begin + xcd_tile() * LINES_TPW;   // (neighbouring runs of tiles on one XCD: bzq_device.hpp)
     if (t >= a.tile_end) return;
-    const int64_t t0 = t * TILE;
-    const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
-    uint4 r[4];
-    tile_fetch<true>(a.g, a.n, t0, valid, r);
-    tile_stage<true>(r, valid, s_mask, s_tile);
-    if (VAL) {
+    const int64_t t_end = t + LINES_TPW < a.tile_end ? t + LINES_TPW : a.tile_end;
+    uint4 r[4], halo = make_uint4(0u, 0u, 0u, 0u);
+    // tile tt into the registers: its 16 KiB, and on two lanes the 16 bytes before / after it
+    auto fetch = [&](int64_t tt) {
+        const int64_t t0 = tt * TILE;
+        const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+        tile_fetch_w<true>(a.g, a.n, t0, valid, r);
+        if (tid == 0) {
+            halo = make_uint4(0x0A0A0A0Au, 0x0A0A0A0Au, 0x0A0A0A0Au, 0x000A0A0Au | (a.prev_byte << 24));
+            if (t0 > 0) halo = load16_any(a.g + t0 - HALO);
+        } else if (tid == 64) {   // (zeros at and beyond the end of the data)
+            halo = make_uint4(0u, 0u, 0u, 0u);
+            if (valid == TILE) halo = load16(a.g, t0 + TILE, a.n);
+        }
+    };
+    // what the bytes around the newline at tile offset pos (-1: the one before the tile) say: flags and id space runs of an entry
+    auto around = [&](int pos) -> uint32_t {
+        const int o = pos + HALO - 1;   // raw offset of the byte before the newline
+        const uint32_t d0 = raw32[o >> 2], d1 = raw32[(o >> 2) + 1];
+        const uint32_t w4 = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)o & 3u);   // bytes pos - 1, pos, pos + 1, pos + 2
+        const uint32_t bp = w4 & 0xFFu, c0 = (w4 >> 16) & 0xFFu, c1 = w4 >> 24;
+        uint32_t e = (c0 == 64u ? 1u << 14 : 0u) | (c0 == 43u ? 1u << 15 : 0u);
+        if (is_space_not_nl(bp) | is_space_not_nl(c1)) {   // an id that _strip_spaces will shorten (or a CRLF file): walk the runs
+            uint32_t trail = 0, lead = 0;
+            int p = pos - 1;
+            while (p >= -HALO && trail < ENT_SAT && is_space_not_nl(s_tile[p])) { ++trail; --p; }
+            if (p < -HALO) trail = ENT_SAT;
+            p = pos + 2;
+            while (p < TILE + HALO && lead < ENT_SAT && is_space_not_nl(s_tile[p])) { ++lead; ++p; }
+            if (p >= TILE + HALO) lead = ENT_SAT;
+            e |= (lead << 16) | (trail << 24);
+        }
+        return e;
+    };
+    fetch(t);
+    for (;;) {
+        const int64_t t0 = t * TILE;
+        const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
+        if (tid == 0) *reinterpret_cast<uint4*>(s_tile_raw) = halo;
+        else if (tid == 64) *reinterpret_cast<uint4*>(s_tile + TILE) = halo;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int q = tid + BLOCK * s;
-            uint32_t h = fa::flag_mask16(r[s].x & 0x80808080u, r[s].y & 0x80808080u, r[s].z & 0x80808080u, r[s].w & 0x80808080u);
-            uint32_t o = fa::flag_mask16(out_of_range_flags(r[s].x, a.q_lower, a.q_upper), out_of_range_flags(r[s].y, a.q_lower, a.q_upper),
-                                         out_of_range_flags(r[s].z, a.q_lower, a.q_upper), out_of_range_flags(r[s].w, a.q_lower, a.q_upper));
-            if (valid != TILE) {
-                const int rem = valid - q * 16;
-                const uint32_t keep = rem >= 16 ? 0xFFFFu : (rem > 0 ? ((1u << rem) - 1u) : 0u);
-                h &= keep; o &= keep;
+            const int q = wave_piece(s), pos = q * 16;
+            uint32_t m = nl_mask16(r[s]);
+            uint32_t keep = 0xFFFFu;
+            if (valid != TILE) {   // last tile: bytes at or beyond the end are not newlines
+                const int rem = valid - pos;
+                keep = rem >= 16 ? 0xFFFFu : (rem > 0 ? ((1u << rem) - 1u) : 0u);
+                m &= keep;
             }
-            s_hi[q] = (uint16_t)h; s_out[q] = (uint16_t)o;
+            s_mask[q] = (uint16_t)m;
+            *reinterpret_cast<uint4*>(s_tile + pos) = r[s];
+            if (VAL) {
+                const uint32_t h = fa::flag_mask16(r[s].x & 0x80808080u, r[s].y & 0x80808080u, r[s].z & 0x80808080u, r[s].w & 0x80808080u);
+                const uint32_t o = fa::flag_mask16(out_of_range_flags(r[s].x, a.q_lower, a.q_upper), out_of_range_flags(r[s].y, a.q_lower, a.q_upper),
+                                                   out_of_range_flags(r[s].z, a.q_lower, a.q_upper), out_of_range_flags(r[s].w, a.q_lower, a.q_upper));
+                s_hi[q] = (uint16_t)(h & keep); s_out[q] = (uint16_t)(o & keep);
+            }
         }
-    }
-    ByteSrc bs{a.g, a.n, a.prev_byte, s_tile, t0, valid};
-    __syncthreads();
-    const u64 m64 = reinterpret_cast<const u64*>(s_mask)[tid];
-    // validation: "such a byte since the last newline of this tile", read just before every newline
-    u64 na_before = 0, or_before = 0;
-    if (VAL) {
-        const u64 hi64 = reinterpret_cast<const u64*>(s_hi)[tid], out64 = reinterpret_cast<const u64*>(s_out)[tid] & ~m64;
-        const fa::WaveChain wh = fa::chain_wave<false>(hi64, m64, s_chain[0]);
-        const fa::WaveChain wo = fa::chain_wave<false>(out64, m64, s_chain[1]);
-        __syncthreads();
-        const fa::Chain ch = fa::chain64(hi64, m64, fa::chain_cin<false>(wh, s_chain[0], 0u));
-        const fa::Chain co = fa::chain64(out64, m64, fa::chain_cin<false>(wo, s_chain[1], 0u));
-        na_before = ch.excl; or_before = co.excl;
-        if (tid == BLOCK - 1) a.tile_vf[t] = (uint8_t)((ch.incl >> 63) | ((co.incl >> 63) << 1));
-    }
-    uint32_t c = 0;
-    const uint32_t excl = block_exclusive_scan<uint32_t, BLOCK / 64>((uint32_t)__popcll(m64), s_w, c);
-    const bool pooled = ((int)c > MAXE) || a.force_dense;
-    if (tid == 0) {
+        const bool more = t + 1 < t_end;
+        if (more) fetch(t + 1);   // (the registers are free again)
+        // wave-local transposition: the four pieces of this lane's 64 bytes were written by lanes of this wave
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const u64 m64 = reinterpret_cast<const u64*>(s_mask)[tid];
+        const uint32_t cnt = (uint32_t)__popcll(m64);
+        const uint32_t incl = dpp_scan_u32(cnt);
+        if (lane == 63) s_w[wave] = incl;
+        // validation: "such a byte since the last newline of this tile", read just before every newline
+        u64 hi64 = 0, out64 = 0;
+        fa::WaveChain wh{}, wo{};
+        if (VAL) {
+            hi64 = reinterpret_cast<const u64*>(s_hi)[tid]; out64 = reinterpret_cast<const u64*>(s_out)[tid] & ~m64;
+            wh = fa::chain_wave<false>(hi64, m64, s_chain[0]);
+            wo = fa::chain_wave<false>(out64, m64, s_chain[1]);
+        }
+        __syncthreads();   // the other waves' bytes, counts and chain codes, the halo
+        const uint4 wc = *reinterpret_cast<const uint4*>(s_w);
+        const uint32_t c = wc.x + wc.y + wc.z + wc.w;
+        const uint32_t excl = (wave > 0 ? wc.x : 0u) + (wave > 1 ? wc.y : 0u) + (wave > 2 ? wc.z : 0u) + incl - cnt;
+        u64 na_before = 0, or_before = 0;
+        if (VAL) {
+            const fa::Chain ch = fa::chain64(hi64, m64, fa::chain_cin<false>(wh, s_chain[0], 0u));
+            const fa::Chain co = fa::chain64(out64, m64, fa::chain_cin<false>(wo, s_chain[1], 0u));
+            na_before = ch.excl; or_before = co.excl;
+            if (tid == BLOCK - 1) a.tile_vf[t] = (uint8_t)((ch.incl >> 63) | ((co.incl >> 63) << 1));
+        }
+        const bool pooled = ((int)c > MAXE) || (a.force_dense & 1);   // (the same for every thread)
         int64_t slot = -1;
         if (pooled) {
-            slot = (int64_t)atomicAdd(&a.st->listed_tiles, 1ull);
-            if (slot >= a.pool_slots) { slot = -2; a.st->views_fallback = 1; }   // the host repeats the chunk on the byte-level kernels
+            if (tid == 0) {
+                int64_t sl = (int64_t)atomicAdd(&a.st->listed_tiles, 1ull);
+                if (sl >= a.pool_slots) { sl = -2; a.st->views_fallback = 1; }   // the host repeats the chunk on the byte-level kernels
+                s_slot = sl;
+            }
+            __syncthreads();
+            slot = s_slot;
         }
-        s_slot = slot;
-        a.tile_c[t] = c; a.tile_a[t] = 0ull; a.tile_idc[t] = slot >= 0 ? (u64)(slot + 1) : 0ull;
-        if (t == 0) a.entries[ENT_STRIDE - 1] = line_start_info(bs, 0);   // the line that starts the chunk
-    }
-    __syncthreads();
-    if (s_slot == -2) return;
-    uint32_t* out = s_slot >= 0 ? a.pool + s_slot * TILE : a.entries + t * ENT_STRIDE;
-    u64 m = m64;
-    uint32_t idx = excl;
-    while (m) {
-        const int bit = __builtin_ctzll(m);
-        m &= m - 1;
-        const int pos = tid * 64 + bit;
-        const int64_t gp = t0 + pos;
-        uint32_t trail = 0;
-        for (int64_t p = gp - 1; trail < ENT_SAT; --p) {
-            const uint32_t ch = bs.at(p);
-            if (ch == 10u || !is_posix_space(ch)) break;
-            ++trail;
+        if (tid == 0) {
+            a.tile_c[t] = c; a.tile_a[t] = 0ull; a.tile_idc[t] = slot >= 0 ? (u64)(slot + 1) : 0ull;
+            if (t == 0) a.entries[ENT_STRIDE - 1] = around(-1) & 0x00FFC000u;   // the line that starts the chunk: its first byte and leading spaces
         }
-        uint32_t e = (uint32_t)pos | line_start_info(bs, gp + 1) | (trail << 24);
-        if (VAL) e |= ((uint32_t)((na_before >> bit) & 1ull) << 23) | ((uint32_t)((or_before >> bit) & 1ull) << 31);
-        out[idx] = e;
-        ++idx;
+        if (slot != -2) {
+            uint32_t* out = slot >= 0 ? a.pool + slot * TILE : a.entries + t * ENT_STRIDE;
+            u64 m = m64;
+            uint32_t idx = excl;
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int pos = tid * 64 + bit;
+                uint32_t e = (uint32_t)pos | around(pos);
+                if (VAL) e |= ((uint32_t)((na_before >> bit) & 1ull) << 23) | ((uint32_t)((or_before >> bit) & 1ull) << 31);
+                out[idx] = e;
+                if (idx + 4 >= c) a.tile_last4[t * 4 + (idx + 4 - c)] = e;
+                ++idx;
+            }
+        }
+        if (!more) break;
+        ++t;
+        __syncthreads();   // everyone is done with this tile's LDS
     }
 }
 
 struct JoinArgs {
-    const uint8_t* g;      // only for id space runs that saturated an entry
+    const uint8_t* g;      // id space runs that saturated an entry; the bytes behind the chunk's last newline
     uint32_t prev_byte;
     int64_t n;
     int64_t tile_begin, tile_end, n_tiles;
@@ -192,51 +271,97 @@ struct JoinArgs {
     ChunkState* st;
     const uint8_t* tile_vf;   // validation (see the entry layout)
     int32_t check_ascii, check_quality;
+    const uint32_t* tile_last4;   // LineArgs::tile_last4
 };
 
-constexpr int JOIN_TILES = 8;   // tiles per workgroup of the join (4 / 8 / 16: 0.216 / 0.206 / 0.204 ms)
+constexpr int JOIN_TILES = BLOCK / 64;                // tiles per workgroup of the join: one wave stages one tile's entries
+constexpr int JOIN_ENT = JOIN_TILES * ENT_STRIDE;     // entries a window holds in LDS (a tile outside the pool has at most MAXE)
 
-// Pass B of the metadata pipeline: one thread per RECORD.  Record r owns the newlines 4r-1 .. 4r+3 (global line index);
-// each is found by its tile (the tile prefixes of the scan) and its rank inside it; the five entries give every offset,
-// both structure bytes, the id span and the length / buffer checks -- 20 bytes read, 52 written, all arrays coalesced.
-// A workgroup takes the records whose LAST newline lies in its JOIN_TILES tiles.
+// Pass B of the metadata pipeline: one thread per RECORD.  Record r owns the newlines 4r-1 .. 4r+3 (global line index); the five
+// entries give every offset, both structure bytes, the id span and the length / buffer checks -- 20 bytes read, 52 written.
+// A workgroup takes the records whose LAST newline lies in its JOIN_TILES tiles.  Everything it needs from memory is asked for
+// at once, before anything has come back: the window's prefixes (scalar loads), the first 256 entries of every tile's slot (one
+// 16-byte load per lane, wave w takes tile w: a tile of ordinary reads has about 200), and the last four entries of the tile
+// before the window (tile_last4: the lines of the record that straddles in).  The entries go to LDS in window order -- consecutive
+// newline indices are consecutive words -- and every record reads its five from there.  One memory latency per workgroup; the
+// walk through the prefixes (`locate`) remains for what this cannot serve: windows with pool tiles, records that began more
+// than one tile before the window (long reads), the chunk's first record.
 template <bool VAL>
 static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
-    __shared__ int64_t s_P[JOIN_TILES + 1];
-    __shared__ u64 s_slot[JOIN_TILES];
-    const int tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) uint32_t s_e[4 + JOIN_ENT];
+    __shared__ int64_t s_tail;
+    __shared__ int s_nb;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t ta = a.tile_begin + xcd_tile() * JOIN_TILES;   // (neighbouring windows on one XCD)
     if (ta >= a.tile_end) return;
     const int64_t tb = ta + JOIN_TILES < a.tile_end ? ta + JOIN_TILES : a.tile_end;
     const int nt = (int)(tb - ta);
-    if (tid < nt) { s_P[tid] = a.tileP[ta + tid]; s_slot[tid] = a.tile_slot[ta + tid]; }
-    if (tid == nt) s_P[nt] = a.tileP[tb - 1] + (int64_t)a.tile_c[tb - 1];
-    __syncthreads();
-    const int64_t Gbeg = s_P[0], Gend = s_P[nt];            // newline indices [Gbeg, Gend) live in this window
+    // ---- requests: all of them before the first wait
+    uint4 spec = make_uint4(0u, 0u, 0u, 0u);
+    if (wave < nt) spec = *reinterpret_cast<const uint4*>(a.entries + (ta + wave) * ENT_STRIDE + 4 * lane);
+    int64_t P[JOIN_TILES + 1];
+    u64 slots = 0;
+#pragma unroll
+    for (int k = 0; k < JOIN_TILES; ++k) {
+        P[k] = k < nt ? a.tileP[ta + k] : 0;
+        slots |= k < nt ? a.tile_slot[ta + k] : 0ull;
+    }
+    const int64_t Pend = a.tileP[tb - 1] + (int64_t)a.tile_c[tb - 1];
+#pragma unroll
+    for (int k = 1; k <= JOIN_TILES; ++k) if (k >= nt) P[k] = Pend;
+    const int64_t Pprev = ta > 0 ? a.tileP[ta - 1] : 0;
+    uint4 l4 = make_uint4(0u, 0u, 0u, 0u);
+    if (ta > 0) l4 = *reinterpret_cast<const uint4*>(a.tile_last4 + (ta - 1) * 4);
     const int64_t P0 = a.st->P0, lines = a.st->P;             // P0 + all newlines of the chunk
+    const int64_t Gbeg = P[0], Gend = Pend;                   // newline indices [Gbeg, Gend) live in this window
+    // the four newlines before the window are the last four of tile ta - 1 when that tile has that many
+    const bool prev_ok = ta > 0 && Gbeg - Pprev >= 4;
+    const bool staged = slots == 0ull && Gend - Gbeg <= JOIN_ENT;
     u64 e_struct = ~0ull, e_buf = ~0ull, e_valid = ~0ull;
     bool overflow = false;
-    int64_t loc_tile = -1;   // tile of the newline the last locate() found (-1: the virtual one before the chunk)
+    int64_t loc_tile = -1;   // tile of the newline the last find() found (-1: the virtual one before the chunk)
 
-    // entry and absolute position of newline G (P0 - 1 = the virtual newline before the chunk's first line)
-    auto locate = [&](int64_t G, int64_t hint, uint32_t& e) -> int64_t {
-        if (G < P0) { e = a.entries[ENT_STRIDE - 1]; loc_tile = -1; return -1; }
-        int64_t tt, j;
-        u64 slot;
-        if (G >= Gbeg) {                                     // inside the window: prefixes and slots are in LDS
-            int w = 0;
-#pragma unroll
-            for (int k = 1; k < JOIN_TILES; ++k) if (k < nt && s_P[k] <= G) w = k;
-            tt = ta + w; j = G - s_P[w]; slot = s_slot[w];
-            (void)hint;
-        } else {                                             // a record that began before the window: a few tiles back
-            tt = ta - 1;
-            while (a.tileP[tt] > G) --tt;
-            j = G - a.tileP[tt]; slot = a.tile_slot[tt];
+    // ---- the window's entries into LDS, in newline order: s_e[4 + (G - Gbeg)]
+    if (staged) {
+        if (tid == 0) *reinterpret_cast<uint4*>(s_e) = l4;
+        if (wave < nt) {
+            const int64_t Pw = wave == 0 ? P[0] : wave == 1 ? P[1] : wave == 2 ? P[2] : P[3];
+            const int64_t Pn = wave == 0 ? P[1] : wave == 1 ? P[2] : wave == 2 ? P[3] : P[4];
+            const int cw = (int)(Pn - Pw);
+            uint32_t* dst = s_e + 4 + (int)(Pw - Gbeg);
+            const int j = 4 * lane;
+            if (j < cw) dst[j] = spec.x;
+            if (j + 1 < cw) dst[j + 1] = spec.y;
+            if (j + 2 < cw) dst[j + 2] = spec.z;
+            if (j + 3 < cw) dst[j + 3] = spec.w;
+            const uint32_t* src = a.entries + (ta + wave) * ENT_STRIDE;
+            for (int jj = 256 + lane; jj < cw; jj += 64) dst[jj] = src[jj];   // (a tile of short records)
         }
+        __syncthreads();
+    }
+    const int B1 = (int)(P[1] - Gbeg), B2 = (int)(P[2] - Gbeg), B3 = (int)(P[3] - Gbeg);
+
+    // entry and absolute position of newline G by the prefixes (P0 - 1 = the virtual newline before the chunk's first line)
+    auto locate = [&](int64_t G, uint32_t& e) -> int64_t {
+        if (G < P0) { e = a.entries[ENT_STRIDE - 1]; loc_tile = -1; return -1; }
+        int64_t tt = tb - 1;
+        while (a.tileP[tt] > G) --tt;
+        const int64_t j = G - a.tileP[tt];
+        const u64 slot = a.tile_slot[tt];
         e = slot ? a.pool[(int64_t)(slot - 1) * TILE + j] : a.entries[tt * ENT_STRIDE + j];
         loc_tile = tt;
         return tt * TILE + (int64_t)(e & 0x3FFFu);
+    };
+    auto find = [&](int64_t G, uint32_t& e) -> int64_t {
+        const int k = (int)(G - Gbeg);
+        if (staged && G >= P0 && (k >= 0 || (prev_ok && k >= -4))) {
+            e = s_e[4 + k];
+            const int w = k < 0 ? -1 : (k >= B1) + (k >= B2) + (k >= B3);
+            loc_tile = ta + w;
+            return loc_tile * TILE + (int64_t)(e & 0x3FFFu);
+        }
+        return locate(G, e);
     };
     // validation flags (bit 0 non-ascii, bit 1 out of range) of the line between two consecutive newlines: the entry of
     // the closing one covers its own tile; the line's earlier tiles are the tail of the opening newline's tile and
@@ -261,13 +386,13 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
     const int64_t r_hi = (Gend - 4) >> 2;                           // floor((Gend - 4) / 4), may be < r_lo
     for (int64_t r = r_lo + tid; r <= r_hi; r += BLOCK) {
         if (r >= a.rec_cap) { overflow = true; continue; }
-        const int64_t G3 = 4 * r + 3, t3 = ta;
+        const int64_t G3 = 4 * r + 3;
         uint32_t e3, e2, e1, e0, ep;
-        const int64_t p3 = locate(G3, t3, e3); const int64_t T3 = loc_tile;
-        const int64_t p2 = locate(G3 - 1, t3, e2); const int64_t T2 = loc_tile;
-        const int64_t p1 = locate(G3 - 2, t3, e1); const int64_t T1 = loc_tile;
-        const int64_t p0 = locate(G3 - 3, t3, e0); const int64_t T0 = loc_tile;
-        const int64_t pp = locate(G3 - 4, t3, ep); const int64_t TP = loc_tile;
+        const int64_t p3 = find(G3, e3); const int64_t T3 = loc_tile;
+        const int64_t p2 = find(G3 - 1, e2); const int64_t T2 = loc_tile;
+        const int64_t p1 = find(G3 - 2, e1); const int64_t T1 = loc_tile;
+        const int64_t p0 = find(G3 - 3, e0); const int64_t T0 = loc_tile;
+        const int64_t pp = find(G3 - 4, ep); const int64_t TP = loc_tile;
         const int64_t hs = pp + 1;
         a.o_hdr[r] = hs; a.o_seq[r] = p0 + 1; a.o_sep[r] = p1 + 1; a.o_qual[r] = p2 + 1; a.rec_end[r] = p3;
         int64_t lo = hs + 1 < p0 ? hs + 1 : p0, hi = lo;
@@ -298,30 +423,30 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
         if (n_rec > a.rec_cap) n_rec = a.rec_cap;
         uint32_t e;
         a.st->n_complete = n_rec;
-        a.st->last_record_end = n_rec ? locate(4 * n_rec - 1, tb - 1, e) : a.first_header - 1;
+        a.st->last_record_end = n_rec ? find(4 * n_rec - 1, e) : a.first_header - 1;
         a.st->last_ends = 0; a.st->last_id_ends = 0;
         const int64_t r = lines > 0 ? (lines >> 2) : 0;
         const int k = lines > 0 ? (int)(lines & 3) : 0;      // newlines of the incomplete record
         if (r < a.rec_cap && lines >= 0) {
             uint32_t ep, e0, e1, e2;
-            const int64_t pp = locate(4 * r - 1, tb - 1, ep);
+            const int64_t pp = find(4 * r - 1, ep);
             if (pp + 1 < a.n) a.o_hdr[r] = pp + 1;
             if (k >= 1) {
-                const int64_t p0 = locate(4 * r, tb - 1, e0);
+                const int64_t p0 = find(4 * r, e0);
                 if (p0 + 1 < a.n) a.o_seq[r] = p0 + 1;
                 int64_t lo, hi;
                 id_of(pp + 1, ep, p0, e0, lo, hi);
                 a.id_start[r] = lo; a.id_len[r] = (int32_t)(hi - lo);
-                if (k >= 2) { const int64_t p1 = locate(4 * r + 1, tb - 1, e1); if (p1 + 1 < a.n) a.o_sep[r] = p1 + 1; }
-                if (k >= 3) { const int64_t p2 = locate(4 * r + 2, tb - 1, e2); if (p2 + 1 < a.n) a.o_qual[r] = p2 + 1; }
+                if (k >= 2) { const int64_t p1 = find(4 * r + 1, e1); if (p1 + 1 < a.n) a.o_sep[r] = p1 + 1; }
+                if (k >= 3) { const int64_t p2 = find(4 * r + 2, e2); if (p2 + 1 < a.n) a.o_qual[r] = p2 + 1; }
                 if (VAL && k == 3) {
                     // an unterminated last record may be delivered (parser.mojo:464-475) and is validated like any other:
                     // its quality line is everything after the chunk's last newline
                     uint32_t x;
-                    (void)locate(4 * r - 1, tb - 1, x); const int64_t tp = loc_tile;
-                    (void)locate(4 * r, tb - 1, x); const int64_t t0l = loc_tile;
-                    (void)locate(4 * r + 1, tb - 1, x); const int64_t t1l = loc_tile;
-                    (void)locate(4 * r + 2, tb - 1, x); const int64_t t2l = loc_tile;
+                    (void)find(4 * r - 1, x); const int64_t tp = loc_tile;
+                    (void)find(4 * r, x); const int64_t t0l = loc_tile;
+                    (void)find(4 * r + 1, x); const int64_t t1l = loc_tile;
+                    (void)find(4 * r + 2, x); const int64_t t2l = loc_tile;
                     const uint32_t fh = line_flags(tp, t0l, e0), fs = line_flags(t0l, t1l, e1);
                     uint32_t fq = 0;
                     for (int64_t t = t2l < 0 ? 0 : t2l; t < a.n_tiles; ++t) fq |= a.tile_vf[t];
@@ -337,6 +462,25 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
     if (e_buf != ~0ull) atomicMin(&a.st->err_buf, e_buf);
     if (VAL && e_valid != ~0ull) atomicMin(&a.st->err_valid, e_valid);
     if (overflow) atomicOr(&a.st->rec_overflow, 1);
+    // The chunk's last workgroup also looks behind the last newline: where the tail starts and whether it is more than blanks
+    // (_check_end_qual, utils.mojo:292-329) -- what k_tail does for the other modes, here without a launch of its own.
+    if (tb == a.n_tiles) {
+        if (tid == 0) {
+            uint32_t e;
+            s_tail = lines > P0 ? find(lines - 1, e) + 1 : 0;
+            s_nb = 0;
+        }
+        __syncthreads();
+        const int64_t tail = s_tail;
+        int nb = 0;
+        for (int64_t p = tail + tid; p < a.n; p += BLOCK) {
+            const uint32_t ch = a.g[p];
+            if (ch != 10u && ch != 13u && ch != 32u && ch != 9u) { nb = 1; break; }
+        }
+        if (nb) atomicOr(&s_nb, 1);
+        __syncthreads();
+        if (tid == 0) { a.st->tail_start = tail; a.st->tail_nonblank = s_nb; }
+    }
 }
 
 static __global__ __launch_bounds__(BLOCK) void k_tile_count(AggArgs a) {
