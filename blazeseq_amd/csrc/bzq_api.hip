@@ -113,6 +113,7 @@ struct bzq_ctx {
     DevBuf tile_c, tile_a, tile_idc, tileP, tileS, tileQ, tileI, grp, desc, consumer_scratch, qpos_scratch, gen_prefix, entries, tile_list, tile_vf, inflate_tab;
     int64_t tile_cap = 0;
     ChunkState* d_state = nullptr;
+    ViewsPool* d_pool = nullptr;   // views mode: the entry pool's ticket (bzq_views.hpp), zero between chunks
     ChunkState* h_state = nullptr; // pinned
     hipEvent_t ev[8]{};
     std::vector<hipEvent_t> ev_detail;        // events recorded by the current submit (option timing_detail) ...
@@ -135,7 +136,13 @@ struct bzq_ctx {
     bool fold = false;         // ... decided per chunk (decide_fold)
     bool cum_valid = false;    // the current chunk's chunk-cumulative ends / id_ends hold values (always without fold; with it: after bzq_chunk_cumulative_ends)
     bool finish_done = false;  // k_tail of this submit already left the chunk totals (enqueue_rebase skips k_finish once)
-    DevBuf tile_last, tileB, btile, tile_l4;
+    bool published = false;    // ... and wrote the chunk state and the batch table into the host's pinned copies itself (no copy packets behind the kernels)
+    // the state's initial values travel on a stream of their own while pass A runs (it does not look at the state); the scan waits for them
+    hipStream_t stream_init = nullptr;
+    hipEvent_t ev_init = nullptr;
+    bool init_in_flight = false;
+    int lean = 1;              // option "lean_submit": 0 = state copies on the ctx stream, before and behind the kernels (as before)
+    DevBuf tile_last, tileB, btile;
     // bzq_shard_read_range: the rank's byte range of a file in device memory, and the pinned pieces it travelled through
     DevBuf shard_buf;
     std::vector<void*> shard_pin;          // 2 per reader thread, SHARD_PIECE bytes each (pinned once, reused)
@@ -211,7 +218,10 @@ namespace {
     } while (0)
 
 // option timing_detail: an event on the ctx stream between two phases of the current submit
-void mark_detail(bzq_ctx* c) {
+// (every event between two kernels costs 3-6 us of an idle queue -- scripts/probes/event_cost_probe.hip, scripts/step_gaps.py -- so
+// a mark that would sit right behind another event takes that event instead: `same_as`)
+void mark_detail(bzq_ctx* c, hipEvent_t same_as = nullptr) {
+    if (same_as) { c->ev_detail.push_back(same_as); return; }
     if (c->ev_detail_used == c->ev_detail_pool.size()) {
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) return;
@@ -260,7 +270,7 @@ int ensure_tile_arenas(bzq_ctx* c, uint64_t n) {
     if (c->cfg.views_only) {   // line entries: a 4 KiB slot per tile + a pool of 64 KiB slots for tiles of tiny records
         c->pool_slots = std::max<int64_t>(16, nt / 8);
         if ((rc = ensure(c, c->entries, (size_t)nt * ENT_STRIDE * 4)) || (rc = ensure(c, c->tile_list, (size_t)c->pool_slots * TILE * 4)) ||
-            (rc = ensure(c, c->tile_vf, (size_t)nt + 64)) || (rc = ensure(c, c->tile_l4, (size_t)nt * 16)))
+            (rc = ensure(c, c->tile_vf, (size_t)nt + 64)))
             return rc;
     }
     return 0;
@@ -465,8 +475,21 @@ ChunkFinishArgs finish_args(bzq_ctx* c, bool on) {
         f.b_ends = (const int64_t*)c->o().b_ends.p; f.b_id_ends = (const int64_t*)c->o().b_id_ends.p; f.rec_end = (const int64_t*)c->o().rec_end.p;
         f.batch = std::max<int64_t>(1, c->cfg.batch_size); f.first_header = c->cur_first_header; f.rec_cap = c->o().rec_cap;
         f.bb = c->o().bb_cap ? (int64_t*)c->o().bb.p : nullptr; f.bb_cap = c->o().bb_cap;
+        if (c->published) { f.h_state = c->h_state; f.h_bb = c->o().h_bb; f.h_bb_cap = c->o().h_bb_cap; }
     }
     return f;
+}
+
+// the pinned mirror of the batch-boundary table (arrives with the chunk state)
+void ensure_h_bb(bzq_ctx* c) {
+    OutSet& o = c->o();
+    const int64_t nb_max = o.rec_cap / std::max<int64_t>(1, c->cfg.batch_size) + 2;
+    if (o.bb_cap && o.h_bb_cap < nb_max) {
+        if (o.h_bb) (void)hipHostFree(o.h_bb);
+        o.h_bb = nullptr; o.h_bb_cap = 0;
+        if (hipHostMalloc((void**)&o.h_bb, (size_t)nb_max * 16, hipHostMallocDefault) == hipSuccess) o.h_bb_cap = nb_max;
+        else (void)hipGetLastError();
+    }
 }
 
 void launch_batch_bases(bzq_ctx* c) {
@@ -591,11 +614,12 @@ int enqueue_single_launch(bzq_ctx* c) {
 #endif
 }
 
+bool views_meta(const bzq_ctx* c);
 void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, int pass) {
     ScanArgs s{tb, te, (const uint32_t*)c->tile_c.p, (const u64*)c->tile_a.p, (const u64*)c->tile_idc.p,
                (int64_t*)c->tileP.p, (int64_t*)c->tileS.p, (int64_t*)c->tileQ.p, (int64_t*)c->tileI.p,
                (int64_t*)c->grp.p, c->d_state, pass, c->fold ? (int32_t*)c->tileB.p : nullptr, std::max<int64_t>(1, c->cfg.batch_size),
-               c->fold ? (int64_t*)c->btile.p : nullptr, c->fold ? c->o().bb_cap : 0};
+               c->fold ? (int64_t*)c->btile.p : nullptr, c->fold ? c->o().bb_cap : 0, views_meta(c) ? c->d_pool : nullptr};
     const int64_t ng = (te - tb + SG_TILES - 1) / SG_TILES;
     if (ng <= 0) return;
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)ng), dim3(SG_THREADS), 0, c->stream, s);
@@ -620,7 +644,7 @@ void launch_views(bzq_ctx* c, dim3 grid, int64_t tb, int64_t te) {
                    (const uint32_t*)c->tile_list.p, (int64_t*)c->o().off[0].p, (int64_t*)c->o().off[1].p, (int64_t*)c->o().off[2].p,
                    (int64_t*)c->o().off[3].p, (int64_t*)c->o().rec_end.p, (int64_t*)c->o().id_start.p, (int32_t*)c->o().id_len.p, c->o().rec_cap,
                    c->cur_first_header, growth ? c->cfg.buffer_max_capacity : c->cfg.buffer_capacity, c->d_state,
-                   (const uint8_t*)c->tile_vf.p, c->cfg.check_ascii, c->cfg.check_quality, (const uint32_t*)c->tile_l4.p};
+                   (const uint8_t*)c->tile_vf.p, c->cfg.check_ascii, c->cfg.check_quality};
         const dim3 jg((unsigned)((te - tb + JOIN_TILES - 1) / JOIN_TILES));
         if (views_validating(c)) hipLaunchKernelGGL(k_views_join<true>, jg, dim3(BLOCK), 0, c->stream, j);
         else hipLaunchKernelGGL(k_views_join<false>, jg, dim3(BLOCK), 0, c->stream, j);
@@ -659,14 +683,14 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
         const int64_t te = std::min(nt, tb + pt);
         const dim3 grid((unsigned)(te - tb));
         if (!emit_only) {
-            if (c->timing_detail) mark_detail(c);
+            if (c->timing_detail) mark_detail(c, passes == 0 ? c->ev[0] : nullptr);   // (the first pass starts where the submit's clock starts)
             if (!skip_aggregate_mid) {
                 AggArgs a{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p,
                           (u64*)c->tile_a.p, (u64*)c->tile_idc.p, walk_limit_of(c), (u64*)c->tile_last.p};
                 if (views_meta(c)) {
                     LineArgs la{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
-                                (u64*)c->tile_idc.p, (uint32_t*)c->entries.p, (uint32_t*)c->tile_list.p, c->pool_slots, c->d_state,
-                                c->force_dense, (uint8_t*)c->tile_vf.p, (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper, (uint32_t*)c->tile_l4.p};
+                                (u64*)c->tile_idc.p, (uint32_t*)c->entries.p, (uint32_t*)c->tile_list.p, c->pool_slots, c->d_pool,
+                                c->force_dense, (uint8_t*)c->tile_vf.p, (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper};
                     const dim3 lg((unsigned)((te - tb + LINES_TPW - 1) / LINES_TPW));   // a workgroup walks LINES_TPW tiles
                     if (views_validating(c)) hipLaunchKernelGGL(k_tile_lines<true>, lg, dim3(BLOCK), 0, c->stream, la);
                     else hipLaunchKernelGGL(k_tile_lines<false>, lg, dim3(BLOCK), 0, c->stream, la);
@@ -678,6 +702,7 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
                 else hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
             }
             if (c->timing_detail) mark_detail(c);
+            if (c->init_in_flight) { (void)hipStreamWaitEvent(c->stream, c->ev_init, 0); c->init_in_flight = false; }
             launch_scan(c, tb, te, (int)passes);
             if (c->fold) launch_batch_bases(c);
             if (c->timing_detail) mark_detail(c);
@@ -754,14 +779,10 @@ void enqueue_rebase(bzq_ctx* c) {
     OutSet& o = c->o();
     o.h_bb_batches = 0;
     if (bb) {
-        if (o.h_bb_cap < nb_max) {
-            if (o.h_bb) (void)hipHostFree(o.h_bb);
-            o.h_bb = nullptr; o.h_bb_cap = 0;
-            if (hipHostMalloc((void**)&o.h_bb, (size_t)nb_max * 16, hipHostMallocDefault) == hipSuccess) o.h_bb_cap = nb_max;
-            else (void)hipGetLastError();
-        }
+        ensure_h_bb(c);
         // (at most what the chunk can hold: n / min_record_bytes records; the count is only known after the kernels)
-        if (o.h_bb && hipMemcpyAsync(o.h_bb, bb, (size_t)nb_max * 16, hipMemcpyDeviceToHost, c->stream) == hipSuccess) o.h_bb_batches = nb_max;
+        if (c->published) { if (o.h_bb) o.h_bb_batches = std::min(nb_max, o.h_bb_cap); }   // k_tail wrote the batches that exist
+        else if (o.h_bb && hipMemcpyAsync(o.h_bb, bb, (size_t)nb_max * 16, hipMemcpyDeviceToHost, c->stream) == hipSuccess) o.h_bb_batches = nb_max;
     }
 }
 
@@ -785,8 +806,19 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     h->last_nl_tile = -1; h->tail_start = 0;
     h->err_struct = ~0ull; h->err_valid = ~0ull; h->err_buf = ~0ull;
     for (int i = 0; i < 4; ++i) h->first_nl[i] = first_nl ? first_nl[i] : -1;
-    HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
+    // Two-pass path from the chunk's first byte: pass A never looks at the state, so its initial values travel beside it and the
+    // scan waits for them (enqueue_passes) -- otherwise the copy sits in front of the kernels.
+    c->init_in_flight = false; c->published = false;
+    const bool plain = c->lean && n > 0 && head_lines == 0 && !first_nl && !reuse_aggregates && c->stream_init && c->ev_init &&
+                       (c->single_pass == 0 || c->cfg.views_only) && !c->use_stream && !c->overlap;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    if (plain) {
+        HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream_init));
+        HIPCHK(c, hipEventRecord(c->ev_init, c->stream_init));
+        c->init_in_flight = true;
+    } else {
+        HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
+    }
     if (head_lines > 0)
         hipLaunchKernelGGL(k_head, dim3(1), dim3(64), 0, c->stream, d_data, (int64_t)n, prev_byte, head_lines, c->d_state);
     if (n > 0) {
@@ -796,6 +828,7 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
         c->ran_stream = !c->ran_single_pass && c->use_stream && !c->cfg.views_only && c->cfg.pass_bytes == 0 && head_lines == 0 &&
                         !reuse_aggregates && !first_nl;
         decide_fold(c);
+        if (c->fold && plain) { ensure_h_bb(c); c->published = c->o().h_bb != nullptr; }
         if (c->ran_single_pass) { if ((rc = enqueue_single_launch(c))) return rc; }
         else if (c->ran_stream) { if ((rc = enqueue_stream(c))) return rc; }
         else {
@@ -807,11 +840,9 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
             hipLaunchKernelGGL(k_tail, dim3(1), dim3(BLOCK), 0, c->stream, c->cur, (int64_t)n, c->d_state, finish_args(c, true));
         c->finish_done = c->fold;
     } else c->fold = false;
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     enqueue_rebase(c);
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));   // ev[0] .. ev[3]: the submit's kernels (two events per submit; option timing_detail adds three)
+    if (!c->published) HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
     c->pending = true; c->have_result = false;
     return follow_consume(c);   // (host work: it overlaps the parse that was just enqueued)
 }
@@ -1030,8 +1061,14 @@ int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
         else CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     }
     CRT(hipMalloc((void**)&c->d_state, sizeof(ChunkState)));
+    CRT(hipMalloc((void**)&c->d_pool, sizeof(ViewsPool)));
+    CRT(hipMemset(c->d_pool, 0, sizeof(ViewsPool)));
     CRT(hipHostMalloc((void**)&c->h_state, sizeof(ChunkState), hipHostMallocDefault));
     for (auto& ev : c->ev) CRT(hipEventCreate(&ev));
+    { const char* e = getenv("BZQ_LEAN_SUBMIT"); if (e && e[0] == '0') c->lean = 0; }   // (bisecting aid: option lean_submit for a whole process)
+    // (a stream and an event for the state's initial values: see submit_common; without them the copy stays on the ctx stream)
+    if (hipStreamCreateWithFlags(&c->stream_init, hipStreamNonBlocking) != hipSuccess) { c->stream_init = nullptr; (void)hipGetLastError(); }
+    if (hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess) { c->ev_init = nullptr; (void)hipGetLastError(); }
 #undef CRT
     *out = c;
     return 0;
@@ -1045,7 +1082,7 @@ void bzq_destroy(bzq_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)bzq_comm_destroy(c);
     std::vector<DevBuf*> bufs = {&c->in, &c->tile_c, &c->tile_a, &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc,
-                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf, &c->inflate_tab, &c->tile_last, &c->tileB, &c->btile, &c->tile_l4, &c->shard_buf, &c->inflate_scratch};
+                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf, &c->inflate_tab, &c->tile_last, &c->tileB, &c->btile, &c->shard_buf, &c->inflate_scratch};
     for (OutSet& o : c->out) {
         for (DevBuf* b : {&o.seq, &o.qual, &o.id, &o.ends, &o.id_ends, &o.rec_end, &o.b_ends, &o.b_id_ends, &o.off[0], &o.off[1],
                           &o.off[2], &o.off[3], &o.id_start, &o.id_len, &o.bb})
@@ -1058,6 +1095,7 @@ void bzq_destroy(bzq_ctx* c) {
     for (hipStream_t q : c->shard_streams) if (q) (void)hipStreamDestroy(q);
     for (hipEvent_t q : c->shard_events) if (q) (void)hipEventDestroy(q);
     if (c->d_state) (void)hipFree(c->d_state);
+    if (c->d_pool) (void)hipFree(c->d_pool);
     if (c->h_state) (void)hipHostFree(c->h_state);
     if (c->stage_pin) (void)hipHostFree(c->stage_pin);
     if (c->stage_ev) (void)hipEventDestroy(c->stage_ev);
@@ -1065,6 +1103,8 @@ void bzq_destroy(bzq_ctx* c) {
     for (hipEvent_t e : c->ev_detail_pool) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream_init) (void)hipStreamDestroy(c->stream_init);
+    if (c->ev_init) (void)hipEventDestroy(c->ev_init);
     for (hipEvent_t e : c->ev_pipe) (void)hipEventDestroy(e);
     delete c;
 }
@@ -1111,6 +1151,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "n_submits")) return (int32_t)std::min<int64_t>(c->n_submits, 0x7FFFFFFF);                  // query: chunks submitted so far
     else if (!strcmp(key, "pass_a_h")) c->pass_a_h = value != 0;
     else if (!strcmp(key, "fold_rebase")) c->fold_opt = value != 0;
+    else if (!strcmp(key, "lean_submit")) c->lean = value != 0;
     else if (!strcmp(key, "cumulative_ends")) c->fold_opt = value == 0;   // 1: bzq_chunk.d_ends / d_id_ends filled with every chunk (the k_rebase path, as before ABI 5)
     else if (!strcmp(key, "pass_a_sticky")) { c->sticky_opt = value != 0; if (!value) { c->exact_sticky = 0; c->exact_sticky_len = 0; } }
     else if (!strcmp(key, "ingest_direct")) c->ingest_direct = value != 0;
@@ -1336,6 +1377,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         // never expected: the single-pass kernel gave up on a predecessor tile.  Same chunk again on
         // the two-pass kernels (no inter-workgroup waiting).
         const int why = h->lookback_timeout;   // 2: pass A's hypothesis was contradicted
+        c->published = false;   // (the repeats below copy the state and the batch table back themselves)
         ChunkState fresh = *h;
         fresh.P = fresh.P0; fresh.S = fresh.S0; fresh.Q = fresh.Q0; fresh.I = fresh.I0;
         fresh.last_nl_tile = -1; fresh.rec_overflow = 0; fresh.lookback_timeout = 0; fresh.dense_tiles = 0;
@@ -1363,6 +1405,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     if (h->views_fallback && c->cur_n > 0) {
         // views mode, a chunk of records of a few bytes: more tiles needed a big entry slot than the pool has.  Same
         // chunk again on the byte-level views kernels (two reads of the input).
+        c->published = false;
         ChunkState fresh = *h;
         fresh.P = fresh.P0; fresh.S = fresh.S0; fresh.Q = fresh.Q0; fresh.I = fresh.I0;
         fresh.last_nl_tile = -1; fresh.rec_overflow = 0; fresh.views_fallback = 0; fresh.listed_tiles = 0; fresh.dense_tiles = 0;
@@ -1379,6 +1422,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     }
     if (h->rec_overflow) {
         // shorter records than the sizing hint assumed: re-size to the exact count, re-run
+        c->published = false;
         const int64_t need = std::max<int64_t>(0, h->P >> 2) + 2;
         int rc;
         if ((rc = ensure_record_arenas(c, need + 1024))) return rc;
@@ -1536,9 +1580,10 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         r.d_sep_start = (const int64_t*)c->o().off[2].p; r.d_qual_start = (const int64_t*)c->o().off[3].p;
     }
     float ms0 = 0.f, ms1 = 0.f;
-    if (hipEventElapsedTime(&ms0, c->ev[0], c->ev[1]) != hipSuccess) ms0 = 0.f;
-    if (hipEventElapsedTime(&ms1, c->ev[2], c->ev[3]) != hipSuccess) ms1 = 0.f;
-    r.ms_total = ms0 + ms1;
+    if (hipEventElapsedTime(&ms0, c->ev[0], c->ev[3]) != hipSuccess) ms0 = 0.f;
+    // what follows the last emit (k_tail, k_rebase / k_finish): known apart only with the marks of option timing_detail
+    if (c->timing_detail && !c->ev_detail.empty() && hipEventElapsedTime(&ms1, c->ev_detail.back(), c->ev[3]) != hipSuccess) ms1 = 0.f;
+    r.ms_total = ms0;
     r.ms_rebase = ms1;
     if (c->shard_mode) { r.ms_total += c->ms_scan_shard; r.ms_aggregate += c->ms_scan_shard; }   // pass A ran in bzq_shard_scan
     if (c->timing_detail && (c->ran_single_pass || c->ran_stream) && c->ev_detail.size() >= 2) {

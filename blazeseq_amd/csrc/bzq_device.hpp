@@ -143,6 +143,13 @@ __device__ __forceinline__ uint4 load16(const uint8_t* __restrict__ g, int64_t p
     return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 
+// views mode (bzq_views.hpp): the ticket of the entry pool.  Pass A draws from it, the scan behind it moves the count into the chunk
+// state and leaves it zero -- so pass A needs nothing initialised by the submit and can start before the state's initial values arrive
+struct ViewsPool {
+    unsigned long long listed;
+    int32_t fallback, _pad;
+};
+
 struct ByteSrc {
     const uint8_t* __restrict__ g;
     int64_t n;
@@ -456,6 +463,7 @@ struct ScanArgs {
     // btile[k - 1] = the tile that holds the newline ending record k * batch - 1 (line 4 k batch - 1), for k_batch_bases; bb_cap entries
     int64_t* btile;
     int64_t bb_cap;
+    ViewsPool* pool;     // views mode: see ViewsPool; nullptr otherwise
 };
 
 __device__ __forceinline__ int64_t field16(u64 v, int k) { return (int64_t)((v >> (16 * (k & 3))) & 0xFFFFull); }
@@ -623,6 +631,11 @@ static __global__ __launch_bounds__(SG_THREADS) void k_scan_down(ScanArgs a) {
         int64_t* pc = a.st->pass_carry[(a.pass + 1) & 1];
         pc[0] = cP + tot; pc[1] = cS + tS; pc[2] = cQ + tQ; pc[3] = cI + tI; pc[4] = last;
         a.st->P = cP + tot; a.st->S = cS + tS; a.st->Q = cQ + tQ; a.st->I = cI + tI; a.st->last_nl_tile = last - 1;
+        if (a.pool) {
+            a.st->listed_tiles += a.pool->listed;
+            if (a.pool->fallback) a.st->views_fallback = 1;
+            a.pool->listed = 0ull; a.pool->fallback = 0;
+        }
     }
 }
 
@@ -639,6 +652,12 @@ struct ChunkFinishArgs {
     int64_t batch, first_header, rec_cap;
     int64_t* bb;
     int64_t bb_cap;
+    // k_tail, the submit's last kernel on this path, also PUBLISHES what the host reads: the chunk state and the batch-boundary table
+    // go straight into the host's pinned copies (zero-copy stores), so that no copy packet -- two idle gaps of the queue -- follows the
+    // kernels.  nullptr = the host copies as before.
+    ChunkState* h_state;
+    int64_t* h_bb;
+    int64_t h_bb_cap;   // batches the pinned table holds
 };
 __device__ __forceinline__ void chunk_finish(const ChunkFinishArgs& f, ChunkState* st) {
     const int64_t lines = st->P;
@@ -728,6 +747,19 @@ static __global__ __launch_bounds__(BLOCK) void k_tail(const uint8_t* __restrict
     if (tid == 0) {
         st->tail_start = tail; st->tail_nonblank = s_nb;
         if (fin.on) chunk_finish(fin, st);
+    }
+    if (fin.on && fin.h_state) {   // (fin is a kernel argument: the same for every thread)
+        __threadfence_block();
+        __syncthreads();
+        const int64_t batch = fin.batch > 0 ? fin.batch : 1;
+        int64_t nb = (st->n_complete + batch - 1) / batch;
+        if (nb > fin.bb_cap) nb = fin.bb_cap;
+        if (nb > fin.h_bb_cap) nb = fin.h_bb_cap;
+        if (fin.h_bb && fin.bb)
+            for (int64_t i = tid; i < 2 * nb; i += BLOCK) fin.h_bb[i] = fin.bb[i];
+        const u64* src = reinterpret_cast<const u64*>(st);
+        u64* dst = reinterpret_cast<u64*>(fin.h_state);
+        for (int i = tid; i < (int)(sizeof(ChunkState) / 8); i += BLOCK) dst[i] = src[i];
     }
 }
 

@@ -61,12 +61,10 @@ struct LineArgs {
     uint32_t* entries;     // [tiles][ENT_STRIDE]
     uint32_t* pool;        // [pool_slots][TILE]
     int64_t pool_slots;
-    ChunkState* st;
+    ViewsPool* pool_state;   // the pool's ticket (never the chunk state: pass A runs before its initial values have arrived)
     int32_t force_dense;   // test switch: every tile through the pool
     uint8_t* tile_vf;      // validation: per tile, bit 0 / 1 = non-ascii / out-of-range byte after the tile's last newline
     uint32_t q_lower, q_upper;
-    uint32_t* tile_last4;  // [tiles][4]: the tile's last four entries (slot 3 = the last), so that the join finds the lines of the record that
-                           // straddles into the NEXT tile at a fixed address -- no walk back through the prefixes
 };
 
 // 0x80 in every byte outside [lo, hi] (hi < 128)
@@ -122,6 +120,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
     __shared__ uint32_t s_chain[2][BLOCK / 64];
     __shared__ __attribute__((aligned(16))) uint32_t s_w[BLOCK / 64];
     __shared__ int64_t s_slot;
+    __shared__ uint32_t s_ent[ENT_STRIDE];
     uint8_t* s_tile = s_tile_raw + HALO;
     const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(s_tile_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,8 +217,8 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
         int64_t slot = -1;
         if (pooled) {
             if (tid == 0) {
-                int64_t sl = (int64_t)atomicAdd(&a.st->listed_tiles, 1ull);
-                if (sl >= a.pool_slots) { sl = -2; a.st->views_fallback = 1; }   // the host repeats the chunk on the byte-level kernels
+                int64_t sl = (int64_t)atomicAdd(&a.pool_state->listed, 1ull);
+                if (sl >= a.pool_slots) { sl = -2; a.pool_state->fallback = 1; }   // the host repeats the chunk on the byte-level kernels
                 s_slot = sl;
             }
             __syncthreads();
@@ -229,8 +228,30 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
             a.tile_c[t] = c; a.tile_a[t] = 0ull; a.tile_idc[t] = slot >= 0 ? (u64)(slot + 1) : 0ull;
             if (t == 0) a.entries[ENT_STRIDE - 1] = around(-1) & 0x00FFC000u;   // the line that starts the chunk: its first byte and leading spaces
         }
-        if (slot != -2) {
-            uint32_t* out = slot >= 0 ? a.pool + slot * TILE : a.entries + t * ENT_STRIDE;
+        if (slot == -1) {
+            // ordinary tile: the entries end at the END of the tile's slot (entry j of c at slot[MAXE - c + j]) -- the join then
+            // finds the tile's LAST entries at fixed addresses without knowing c.  They go out through LDS: every wave gathers
+            // its own (its newlines are a contiguous run of the tile's), then stores them as one contiguous stretch.
+            uint32_t* sl = s_ent + (excl - (incl - cnt));   // this wave's run starts at its exclusive base
+            u64 m = m64;
+            uint32_t k = incl - cnt;                        // index inside the wave's run
+            while (m) {
+                const int bit = __builtin_ctzll(m);
+                m &= m - 1;
+                const int pos = tid * 64 + bit;
+                uint32_t e = (uint32_t)pos | around(pos);
+                if (VAL) e |= ((uint32_t)((na_before >> bit) & 1ull) << 23) | ((uint32_t)((or_before >> bit) & 1ull) << 31);
+                sl[k] = e;
+                ++k;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t wbase = excl - (incl - cnt);
+            const uint32_t wcnt = wave == 0 ? wc.x : wave == 1 ? wc.y : wave == 2 ? wc.z : wc.w;
+            uint32_t* out = a.entries + t * ENT_STRIDE + (MAXE - (int)c) + wbase;
+            for (uint32_t j = lane; j < wcnt; j += 64) out[j] = s_ent[wbase + j];
+        } else if (slot >= 0) {   // a tile of tiny records: straight into its pool slot, from the slot's start
+            uint32_t* out = a.pool + slot * TILE;
             u64 m = m64;
             uint32_t idx = excl;
             while (m) {
@@ -240,7 +261,6 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
                 uint32_t e = (uint32_t)pos | around(pos);
                 if (VAL) e |= ((uint32_t)((na_before >> bit) & 1ull) << 23) | ((uint32_t)((or_before >> bit) & 1ull) << 31);
                 out[idx] = e;
-                if (idx + 4 >= c) a.tile_last4[t * 4 + (idx + 4 - c)] = e;
                 ++idx;
             }
         }
@@ -271,7 +291,6 @@ struct JoinArgs {
     ChunkState* st;
     const uint8_t* tile_vf;   // validation (see the entry layout)
     int32_t check_ascii, check_quality;
-    const uint32_t* tile_last4;   // LineArgs::tile_last4
 };
 
 constexpr int JOIN_TILES = BLOCK / 64;                // tiles per workgroup of the join: one wave stages one tile's entries
@@ -280,9 +299,10 @@ constexpr int JOIN_ENT = JOIN_TILES * ENT_STRIDE;     // entries a window holds 
 // Pass B of the metadata pipeline: one thread per RECORD.  Record r owns the newlines 4r-1 .. 4r+3 (global line index); the five
 // entries give every offset, both structure bytes, the id span and the length / buffer checks -- 20 bytes read, 52 written.
 // A workgroup takes the records whose LAST newline lies in its JOIN_TILES tiles.  Everything it needs from memory is asked for
-// at once, before anything has come back: the window's prefixes (scalar loads), the first 256 entries of every tile's slot (one
-// 16-byte load per lane, wave w takes tile w: a tile of ordinary reads has about 200), and the last four entries of the tile
-// before the window (tile_last4: the lines of the record that straddles in).  The entries go to LDS in window order -- consecutive
+// at once, before anything has come back: the window's prefixes (scalar loads), the LAST 256 entries of every tile's slot (one
+// 16-byte load per lane, wave w takes tile w: a tile of ordinary reads has about 200; pass A aligns a tile's entries with the end
+// of its slot so that these addresses do not depend on the tile's count), and the last four entries of the tile before the
+// window (the lines of the record that straddles in).  The entries go to LDS in window order -- consecutive
 // newline indices are consecutive words -- and every record reads its five from there.  One memory latency per workgroup; the
 // walk through the prefixes (`locate`) remains for what this cannot serve: windows with pool tiles, records that began more
 // than one tile before the window (long reads), the chunk's first record.
@@ -299,7 +319,7 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
     const int nt = (int)(tb - ta);
     // ---- requests: all of them before the first wait
     uint4 spec = make_uint4(0u, 0u, 0u, 0u);
-    if (wave < nt) spec = *reinterpret_cast<const uint4*>(a.entries + (ta + wave) * ENT_STRIDE + 4 * lane);
+    if (wave < nt) spec = *reinterpret_cast<const uint4*>(a.entries + (ta + wave) * ENT_STRIDE + (MAXE - 256) + 4 * lane);
     int64_t P[JOIN_TILES + 1];
     u64 slots = 0;
 #pragma unroll
@@ -312,11 +332,12 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
     for (int k = 1; k <= JOIN_TILES; ++k) if (k >= nt) P[k] = Pend;
     const int64_t Pprev = ta > 0 ? a.tileP[ta - 1] : 0;
     uint4 l4 = make_uint4(0u, 0u, 0u, 0u);
-    if (ta > 0) l4 = *reinterpret_cast<const uint4*>(a.tile_last4 + (ta - 1) * 4);
+    if (ta > 0) l4 = *reinterpret_cast<const uint4*>(a.entries + (ta - 1) * ENT_STRIDE + (MAXE - 4));
+    const u64 slot_prev = ta > 0 ? a.tile_slot[ta - 1] : 1ull;
     const int64_t P0 = a.st->P0, lines = a.st->P;             // P0 + all newlines of the chunk
     const int64_t Gbeg = P[0], Gend = Pend;                   // newline indices [Gbeg, Gend) live in this window
     // the four newlines before the window are the last four of tile ta - 1 when that tile has that many
-    const bool prev_ok = ta > 0 && Gbeg - Pprev >= 4;
+    const bool prev_ok = slot_prev == 0ull && Gbeg - Pprev >= 4;
     const bool staged = slots == 0ull && Gend - Gbeg <= JOIN_ENT;
     u64 e_struct = ~0ull, e_buf = ~0ull, e_valid = ~0ull;
     bool overflow = false;
@@ -330,13 +351,13 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
             const int64_t Pn = wave == 0 ? P[1] : wave == 1 ? P[2] : wave == 2 ? P[3] : P[4];
             const int cw = (int)(Pn - Pw);
             uint32_t* dst = s_e + 4 + (int)(Pw - Gbeg);
-            const int j = 4 * lane;
-            if (j < cw) dst[j] = spec.x;
-            if (j + 1 < cw) dst[j + 1] = spec.y;
-            if (j + 2 < cw) dst[j + 2] = spec.z;
-            if (j + 3 < cw) dst[j + 3] = spec.w;
-            const uint32_t* src = a.entries + (ta + wave) * ENT_STRIDE;
-            for (int jj = 256 + lane; jj < cw; jj += 64) dst[jj] = src[jj];   // (a tile of short records)
+            const int j = cw - 256 + 4 * lane;   // the speculative load took entries cw - 256 .. cw - 1
+            if (j >= 0) dst[j] = spec.x;
+            if (j + 1 >= 0) dst[j + 1] = spec.y;
+            if (j + 2 >= 0) dst[j + 2] = spec.z;
+            if (j + 3 >= 0) dst[j + 3] = spec.w;
+            const uint32_t* src = a.entries + (ta + wave) * ENT_STRIDE + (MAXE - cw);
+            for (int jj = lane; jj < cw - 256; jj += 64) dst[jj] = src[jj];   // (a tile of short records)
         }
         __syncthreads();
     }
@@ -349,7 +370,7 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
         while (a.tileP[tt] > G) --tt;
         const int64_t j = G - a.tileP[tt];
         const u64 slot = a.tile_slot[tt];
-        e = slot ? a.pool[(int64_t)(slot - 1) * TILE + j] : a.entries[tt * ENT_STRIDE + j];
+        e = slot ? a.pool[(int64_t)(slot - 1) * TILE + j] : a.entries[tt * ENT_STRIDE + (MAXE - (int64_t)a.tile_c[tt]) + j];
         loc_tile = tt;
         return tt * TILE + (int64_t)(e & 0x3FFFu);
     };
