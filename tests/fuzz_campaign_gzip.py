@@ -20,6 +20,7 @@ ap.add_argument("--seconds", type=float, default=120)
 args = ap.parse_args()
 ctx = Context()
 t0, seed, streams, nbytes, refused = time.time(), 130_000, 0, 0, 0
+device_alone = 0
 kinds = {}
 
 
@@ -81,7 +82,8 @@ while time.time() - t0 < args.seconds:
     ahead = int(rng.choice([0, 0, 1, 2, 3])) if piece_size else 0
     g.dec.set_option("predecode", int(rng.random() < 0.8))
     g.dec.set_option("early_find", int(rng.random() < 0.5))
-    g.dec.set_option("host_continuation", int(rng.random() < 0.85))
+    hc = int(rng.random() < 0.5)   # half of the streams: the device alone (nothing of the result comes from zlib, the checker)
+    g.dec.set_option("host_continuation", hc)
     g.dec.set_option("far_kib", int(rng.choice([16, 64, 256])))
     g.dec.set_option("host_budget_kib", int(rng.choice([64, 512, 32768])))
     try:
@@ -96,6 +98,10 @@ while time.time() - t0 < args.seconds:
         if got != data:
             print(f"MISMATCH seed={seed} ({len(got)} vs {len(data)} bytes)")
             sys.exit(1)
+        if hc == 0 and g.dec.set_option("host_calls", 0) != 0:
+            print(f"HOST CALLS with host_continuation = 0, seed={seed}")
+            sys.exit(1)
+        device_alone += (hc == 0)
         # (a flipped bit can land in a header field or in bytes zlib ignores too: then the stream still decodes to the same bytes)
     except RuntimeError as e:
         if "out_capacity" in str(e) and cap < len(data) + 4096:
@@ -114,4 +120,4 @@ while time.time() - t0 < args.seconds:
             refused += 1
     g.close()
     streams += 1; nbytes += len(data)
-print(f"gzip campaign: {streams} streams ({nbytes/1e6:.0f} MB; {refused} damaged ones refused) identical to the bytes zlib compressed, by kind {dict(sorted(kinds.items()))} in {time.time()-t0:.0f} s")
+print(f"gzip campaign: {streams} streams ({nbytes/1e6:.0f} MB; {device_alone} by the device alone; {refused} damaged ones refused) identical to the bytes zlib compressed, by kind {dict(sorted(kinds.items()))} in {time.time()-t0:.0f} s")

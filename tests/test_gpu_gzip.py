@@ -33,22 +33,32 @@ def payloads():
     yield "far_matches", (bytes(rng.integers(0, 256, 31000, dtype=np.uint8)) * 20)
 
 
+FINDABLE_PAYLOADS = {"fastq_small", "fastq_4mb", "text", "low_entropy"}   # compressible: zlib writes dynamic-Huffman blocks for them
+
+
+@pytest.mark.parametrize("host_continuation", [0, 1])
 @pytest.mark.parametrize("name,data", list(payloads()), ids=[n for n, _ in payloads()])
-def test_levels_and_strategies(name, data):
+def test_levels_and_strategies(name, data, host_continuation):
+    """Every level / strategy of zlib against zlib's own output, with the device ALONE (host_continuation = 0: no byte of the result
+    comes from the checker's library) and with the default.  With the default, a stream whose blocks the finder can start in
+    (dynamic Huffman) must not have touched the host either: `host_calls` is read for every row."""
     ctx = Context()
-    g = DeviceGunzip(ctx, len(data) + 4096, chunk_bytes=4096)
-    try:
-        for level, strategy in [(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (0, zlib.Z_DEFAULT_STRATEGY),
-                                (6, zlib.Z_FIXED), (6, zlib.Z_RLE), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_FILTERED)]:
-            comp = gzip_member(data, level, strategy)
-            g2 = DeviceGunzip(ctx, len(data) + 4096, chunk_bytes=4096)
+    for level, strategy in [(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (0, zlib.Z_DEFAULT_STRATEGY),
+                            (6, zlib.Z_FIXED), (6, zlib.Z_RLE), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_FILTERED)]:
+        comp = gzip_member(data, level, strategy)
+        g2 = DeviceGunzip(ctx, len(data) + 4096, chunk_bytes=4096)
+        g2.dec.set_option("host_continuation", host_continuation)
+        try:
             got = g2.decode(comp)
             st = g2.dec.stats()
+            host_calls = g2.dec.set_option("host_calls", 0)
+        finally:
             g2.close()
-            assert got == data, (name, level, strategy, len(got), len(data))
-            assert st.members == 1 and st.bytes_out == len(data)
-    finally:
-        g.close()
+        assert got == data, (name, level, strategy, len(got), len(data))
+        assert st.members == 1 and st.bytes_out == len(data)
+        findable = level != 0 and strategy != zlib.Z_FIXED and name in FINDABLE_PAYLOADS
+        if host_continuation == 0 or findable:
+            assert host_calls == 0, (name, level, strategy, host_calls)
 
 
 def test_the_speculation_is_what_runs():
@@ -78,13 +88,17 @@ def test_header_fields_and_members():
     want = b"".join(parts)
     assert gzip.decompress(comp) == want
     ctx = Context()
-    for piece in (0, 1 << 16, 70001, 999):
-        g = DeviceGunzip(ctx, len(want) + 4096, chunk_bytes=4096)
-        got = g.decode(comp, piece)
-        st = g.dec.stats()
-        g.close()
-        assert got == want, piece
-        assert st.members == 5 and g.dec.finished is not None
+    for host_continuation in (0, 1):
+        for piece in (0, 1 << 16, 70001, 999):
+            g = DeviceGunzip(ctx, len(want) + 4096, chunk_bytes=4096)
+            g.dec.set_option("host_continuation", host_continuation)
+            got = g.decode(comp, piece)
+            st = g.dec.stats()
+            host_calls = g.dec.set_option("host_calls", 0)
+            g.close()
+            assert got == want, piece
+            assert st.members == 5 and g.dec.finished is not None
+            assert host_calls == 0, (host_continuation, piece, host_calls)   # (every member here has dynamic blocks or is tiny)
 
 
 def test_many_small_members_decode_in_parallel():
