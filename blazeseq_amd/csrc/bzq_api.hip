@@ -82,6 +82,10 @@ struct OutSet {
     int64_t h_bb_cap = 0;          // entries (batches) the mirror can hold
     int64_t h_bb_batches = 0;      // batches copied for the current chunk (0 = not available)
     int64_t h_bb_records = 0;      // complete records the table covers
+    // what the chunk that lives in this set needs to have its chunk-cumulative ends derived later (bzq_chunk_cumulative_ends serves
+    // the set a bzq_chunk points into: the current one or, under the double-buffer contract, the one before it)
+    bool fold = false, cum_valid = false, parsed = false;
+    int64_t batch = 0, n_records = 0;
     std::vector<DevBuf> view_blocks;
     size_t view_used = 0;          // bytes used in view_blocks.back()
     size_t view_next = 4u << 20;   // size of the next block
@@ -795,6 +799,7 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     int64_t want = (int64_t)(n / (uint64_t)std::max(4, c->cfg.min_record_bytes)) + 1024;
     if ((rc = ensure_record_arenas(c, want))) return rc;
     c->views_bytes_once = false; c->tail_pending = false; c->cum_valid = false;
+    c->o().cum_valid = false; c->o().parsed = false; c->o().fold = false;
     if (!reuse_aggregates) c->used_h = false;   // (a shard's aggregates come from bzq_shard_scan, which says how it made them)
     c->cur = d_data; c->cur_n = n; c->cur_stream_pos = stream_pos; c->cur_is_eof = is_eof;
     c->cur_prev_byte = prev_byte; c->cur_first_header = first_header;
@@ -1152,7 +1157,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "pass_a_h")) c->pass_a_h = value != 0;
     else if (!strcmp(key, "fold_rebase")) c->fold_opt = value != 0;
     else if (!strcmp(key, "lean_submit")) c->lean = value != 0;
-    else if (!strcmp(key, "cumulative_ends")) c->fold_opt = value == 0;   // 1: bzq_chunk.d_ends / d_id_ends filled with every chunk (the k_rebase path, as before ABI 5)
+    else if (!strcmp(key, "cumulative_ends")) c->fold_opt = value == 0;   // 1: bzq_chunk.d_ends / d_id_ends filled with every chunk (the k_rebase path, as before ABI 2)
     else if (!strcmp(key, "pass_a_sticky")) { c->sticky_opt = value != 0; if (!value) { c->exact_sticky = 0; c->exact_sticky_len = 0; } }
     else if (!strcmp(key, "ingest_direct")) c->ingest_direct = value != 0;
     else if (!strcmp(key, "ingest_numa")) c->ingest_numa = value != 0;
@@ -1607,6 +1612,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     r.n_passes = (uint32_t)c->n_passes;
     r._pad = (uint32_t)h->dense_tiles;
     c->res = r;
+    { OutSet& o = c->o(); o.fold = c->fold; o.cum_valid = !c->fold; o.parsed = !c->cfg.views_only; o.batch = std::max<int64_t>(1, c->cfg.batch_size); o.n_records = (int64_t)r.n_records; }
     c->pending = false; c->have_result = true;
     *out = r;
     return (r.status > 0 && r.status != BZQ_EOF) ? r.status : 0;
@@ -1685,17 +1691,29 @@ int32_t bzq_batches(bzq_ctx* c, uint32_t max_records, bzq_device_batch* out, uin
 int32_t bzq_chunk_cumulative_ends(bzq_ctx* c, bzq_chunk* inout) {
     if (!c || !c->have_result) { if (c) c->err = "bzq_chunk_cumulative_ends: no parsed chunk"; return BZQ_ERR_ARG; }
     if (c->cfg.views_only) { c->err = "bzq_chunk_cumulative_ends: the ctx is in views mode (no columns)"; return BZQ_ERR_ARG; }
-    if (c->fold && !c->cum_valid && c->res.n_records > 0) {
+    // which chunk: the one `inout` describes -- its per-batch arrays live in exactly one output set -- else the current one.  The
+    // set keeps what the derivation needs (OutSet::fold, batch, n_records), so the chunk BEFORE the current one is served too, as
+    // long as it is alive (until the second submit after its own).
+    OutSet* os = &c->o();
+    if (inout && inout->d_batch_ends) {
+        os = nullptr;
+        for (OutSet& cand : c->out)
+            if (cand.parsed && (const int64_t*)cand.b_ends.p == inout->d_batch_ends) os = &cand;
+        if (!os) { c->err = "bzq_chunk_cumulative_ends: the chunk's arrays are no longer alive (two chunks have been submitted since)"; return BZQ_ERR_ARG; }
+    }
+    const bool current = os == &c->o();
+    if (os->fold && !os->cum_valid && os->n_records > 0) {
         HIPCHK(c, hipSetDevice(c->device));
-        const int64_t n = (int64_t)c->res.n_records;
+        const int64_t n = os->n_records;
         const unsigned grid = (unsigned)std::min<int64_t>((n + BLOCK - 1) / BLOCK, (int64_t)c->num_cu * 16);
-        hipLaunchKernelGGL(k_cumulate, dim3(grid), dim3(BLOCK), 0, c->stream, (const int64_t*)c->o().b_ends.p, (const int64_t*)c->o().b_id_ends.p,
-                           (const int64_t*)c->o().bb.p, (int64_t)c->cfg.batch_size, n, (int64_t*)c->o().ends.p, (int64_t*)c->o().id_ends.p);
+        // (on the ctx stream: behind the parse that may be running there, which writes the OTHER set)
+        hipLaunchKernelGGL(k_cumulate, dim3(grid), dim3(BLOCK), 0, c->stream, (const int64_t*)os->b_ends.p, (const int64_t*)os->b_id_ends.p,
+                           (const int64_t*)os->bb.p, os->batch, n, (int64_t*)os->ends.p, (int64_t*)os->id_ends.p);
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
-    c->cum_valid = true;
-    c->res.d_ends = (const int64_t*)c->o().ends.p; c->res.d_id_ends = (const int64_t*)c->o().id_ends.p;
-    if (inout) { inout->d_ends = c->res.d_ends; inout->d_id_ends = c->res.d_id_ends; }
+    os->cum_valid = true;
+    if (current) { c->cum_valid = true; c->res.d_ends = (const int64_t*)os->ends.p; c->res.d_id_ends = (const int64_t*)os->id_ends.p; }
+    if (inout) { inout->d_ends = (const int64_t*)os->ends.p; inout->d_id_ends = (const int64_t*)os->id_ends.p; }
     return 0;
 }
 

@@ -84,7 +84,6 @@ def test_results_stay_valid_through_the_next_submit_and_consumers_overlap_it():
 
     ctx.submit_device(da.data_ptr(), da.numel(), 0, True)
     ra = ctx.result()
-    ra._cumulative()                                        # chunk-cumulative ends are derived on demand, while the chunk is current (ABI 2)
     view_a = ctx.batch_view(100, 50_000)                    # unaligned: its ends live in chunk A's output set
     sums = torch.zeros(50_000, dtype=torch.int64, device="cuda")
     dba = B.DeviceFastqBatch(ctx, view_a)
@@ -98,7 +97,9 @@ def test_results_stay_valid_through_the_next_submit_and_consumers_overlap_it():
     np.testing.assert_array_equal(sums.cpu().numpy(), want)
     # chunk A's columns are still what they were, chunk B's are B's
     np.testing.assert_array_equal(ra.seq(), fa.seq_bytes)
-    np.testing.assert_array_equal(ra.ends(), fa.ends)
+    np.testing.assert_array_equal(ra.ends(), fa.ends)      # derived on demand (ABI 2) -- here AFTER chunk B was parsed: the set keeps what it takes
+    np.testing.assert_array_equal(ra.id_ends(), fa.id_ends)
+    np.testing.assert_array_equal(rb.ends(), fb.ends)
     np.testing.assert_array_equal(rb.seq(), fb.seq_bytes)
     np.testing.assert_array_equal(rb.qual(), fb.qual_bytes)
     e = np.empty(50_000, dtype=np.int64)
@@ -108,6 +109,11 @@ def test_results_stay_valid_through_the_next_submit_and_consumers_overlap_it():
     ctx.submit_device(da.data_ptr(), da.numel(), 0, True)
     rc = ctx.result()
     assert rc.d_seq == ra.d_seq and rc.d_seq != rb.d_seq
+    # ... and chunk A (two submits ago) is gone: asking for its cumulative ends now is refused, not answered from chunk C's set
+    import copy
+    stale = copy.copy(ra); stale.d_ends = None; stale.d_id_ends = None
+    with pytest.raises(RuntimeError):
+        stale._cumulative()
     # one set only: results are replaced by the next submit
     ctx.set_option("double_buffer", 0)
     ctx.submit_device(db.data_ptr(), db.numel(), 0, True)
