@@ -131,7 +131,6 @@ struct bzq_ctx {
     int force_dense = 0, timing_detail = 0, single_pass = 0, v2 = 1, num_cu = 256;
     bool ran_single_pass = false;
     int inflate_ms = 0;                       // option "inflate_ms": 1 = BGZF blocks eight to a wave (bzq_inflate_ms.hpp: correct, measured SLOWER -- profiles/r4_inflate_ms.md); 0 = one block per wave (bzq_inflate.hpp)
-    DevBuf inflate_scratch;
     int ingest_gpu_inflate = 1;               // option "ingest_gpu_inflate": BGZF blocks are inflated on the device (bzq_inflate.hpp), 0 = on the reader threads
     int ingest_direct = 0, ingest_numa = 1;   // options "ingest_direct" (O_DIRECT reads), "ingest_numa" (bind readers to the GPU's node)
     // option "fold_rebase" (default 1): the emit kernel writes the per-batch ends and does the record-length check itself, from the
@@ -972,7 +971,9 @@ void sb_put(std::string& s, const char* label, long long v) {
 
 #include "bzq_consumers.hpp"
 #include "bzq_inflate.hpp"
-#include "bzq_inflate_ms.hpp"
+#if BZQ_EXPERIMENTS
+#include "bzq_inflate_ms.hpp"   // experiments/csrc: eight BGZF blocks per wave (correct, 2.7x slower: profiles/r4_inflate_ms.md)
+#endif
 #include "bzq_bufcache.hpp"
 #include "bzq_gzip.hpp"
 #include "bzq_ingest.hpp"
@@ -1087,7 +1088,7 @@ void bzq_destroy(bzq_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     (void)bzq_comm_destroy(c);
     std::vector<DevBuf*> bufs = {&c->in, &c->tile_c, &c->tile_a, &c->tile_idc, &c->tileP, &c->tileS, &c->tileQ, &c->tileI, &c->grp, &c->desc,
-                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf, &c->inflate_tab, &c->tile_last, &c->tileB, &c->btile, &c->shard_buf, &c->inflate_scratch};
+                                 &c->consumer_scratch, &c->qpos_scratch, &c->gen_prefix, &c->entries, &c->tile_list, &c->tile_vf, &c->inflate_tab, &c->tile_last, &c->tileB, &c->btile, &c->shard_buf};
     for (OutSet& o : c->out) {
         for (DevBuf* b : {&o.seq, &o.qual, &o.id, &o.ends, &o.id_ends, &o.rec_end, &o.b_ends, &o.b_id_ends, &o.off[0], &o.off[1],
                           &o.off[2], &o.off[3], &o.id_start, &o.id_len, &o.bb})
@@ -1162,7 +1163,9 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "ingest_direct")) c->ingest_direct = value != 0;
     else if (!strcmp(key, "ingest_numa")) c->ingest_numa = value != 0;
     else if (!strcmp(key, "ingest_gpu_inflate")) c->ingest_gpu_inflate = value != 0;
+#if BZQ_EXPERIMENTS
     else if (!strcmp(key, "inflate_ms")) c->inflate_ms = value != 0;
+#endif
     else if (!strcmp(key, "double_buffer")) {
         if (c->pending) { c->err = "double_buffer cannot change while a chunk is in flight"; return BZQ_ERR_ARG; }
         c->double_buffer = value != 0;
@@ -1245,22 +1248,24 @@ int32_t bzq_bgzf_inflate(bzq_ctx* c, const uint8_t* d_comp, uint64_t comp_bytes,
     const unsigned long long none = ~0ull;
     HIPCHK(c, hipMemcpyAsync(c->inflate_tab.p, hb.data(), tbytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(d_bad, &none, 8, hipMemcpyHostToDevice, c->stream));
-    if (c->inflate_ms) {
-        if ((rc = ensure(c, c->inflate_scratch, bzq::inf::ms_scratch_bytes(n_blocks)))) return rc;
+#if BZQ_EXPERIMENTS
+    if (c->inflate_ms) {   // (all of that kernel's tables live in LDS: no scratch)
         unsigned long long* d_stats = nullptr;
         if (getenv("BZQ_MS_STATS")) {   // debug: iterations of the symbol loop [0] and services by kind [1..4], printed per call
             if ((rc = ensure(c, c->consumer_scratch, 64))) return rc;
             d_stats = (unsigned long long*)c->consumer_scratch.p;
             HIPCHK(c, hipMemsetAsync(d_stats, 0, 64, c->stream));
         }
-        bzq::inf::launch_bgzf_inflate_ms(bzq::inf::ArgsMs{d_comp, comp_bytes, (const bzq::inf::DevBlock*)c->inflate_tab.p, n_blocks, d_out, d_bad, (uint32_t*)c->inflate_scratch.p, d_stats}, c->stream);
+        bzq::inf::launch_bgzf_inflate_ms(bzq::inf::ArgsMs{d_comp, comp_bytes, (const bzq::inf::DevBlock*)c->inflate_tab.p, n_blocks, d_out, d_bad, nullptr, d_stats}, c->stream);
         if (d_stats) {
             unsigned long long hs[8];
             HIPCHK(c, hipStreamSynchronize(c->stream));
             HIPCHK(c, hipMemcpy(hs, d_stats, 64, hipMemcpyDeviceToHost));
             fprintf(stderr, "bzq inflate_ms: %lld blocks, loop iterations %llu, services: header %llu eob %llu; wave-ms total: service %.1f loop %.1f crc %.1f\n", (long long)n_blocks, hs[0], hs[1], hs[2], hs[5] * 1e-5, hs[6] * 1e-5, hs[7] * 1e-5);
         }
-    } else {
+    } else
+#endif
+    {
         bzq::inf::Args a{d_comp, comp_bytes, (const bzq::inf::DevBlock*)c->inflate_tab.p, n_blocks, d_out, d_bad};
         hipLaunchKernelGGL(bzq::inf::k_bgzf_inflate, dim3((unsigned)((n_blocks + bzq::inf::WAVES - 1) / bzq::inf::WAVES)), dim3(BLOCK), 0, c->stream, a);
     }
@@ -1287,7 +1292,7 @@ int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value) {
         h->chunk_bytes = (int32_t)value;
         return 0;
     }
-    if (!strcmp(key, "early_find")) { h->early_find = value != 0; return 0; }   // 0: a staged piece's finder runs once the piece in front has been decoded (round 3)
+    if (!strcmp(key, "early_find")) { h->early_find = BZQ_EXPERIMENTS && value != 0; return 0; }   // 0: a staged piece's finder runs once the piece in front has been decoded (round 3)
     if (!strcmp(key, "predecode")) { h->predecode = value != 0; return 0; }   // 0: a piece's decoders start behind the chain / resolve / CRC kernels of the piece in front (round 3)
     if (!strcmp(key, "host_continuation")) { h->host_cont = value != 0; return 0; }   // 0: a stretch without findable block starts stays on the device (one wave)
     if (!strcmp(key, "far_kib")) {

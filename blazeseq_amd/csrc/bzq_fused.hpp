@@ -18,18 +18,6 @@
 
 namespace bzq {
 
-constexpr u64 DESC_A = 1ull << 62;              // granule holds this tile's own aggregate
-constexpr u64 DESC_P = 2ull << 62;              // granule holds the inclusive prefix through this tile
-constexpr u64 DESC_VMASK = (1ull << 62) - 1ull;
-constexpr int64_t DESC_BIAS = 1ll << 44;        // prefixes may be slightly negative (shard head)
-constexpr int SPIN_LIMIT = 1 << 21;
-
-__device__ __forceinline__ u64 ld_agent(const u64* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent(u64* p, u64 v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
 __device__ __forceinline__ int64_t wave_sum(int64_t v) { return (int64_t)wave_sum_u64((u64)v); }
 
 // Timing experiments (skip / stop-after-phase switches and the phase clock) cost SGPRs and prologue instructions in
@@ -122,75 +110,9 @@ __device__ __forceinline__ int64_t prev_record_end(const int64_t* tileP, int64_t
     return tt * (int64_t)TILE + (int64_t)((lw >> (16 * (jl & 3))) & 0xFFFFull);
 }
 
-// Exclusive line prefix of tile t (wave 0, all 64 lanes).  Lane i inspects predecessor t-1-i.
-__device__ inline int64_t lookback_lines(const u64* desc_c, int64_t t, int64_t P0, int lane, ChunkState* st) {
-    if (t == 0) return P0;
-    int64_t running = 0, base = t - 1;
-    int spins = 0;
-    for (;;) {
-        const int64_t p = base - lane;
-        const u64 g = p >= 0 ? ld_agent(&desc_c[p]) : (DESC_P | (u64)(P0 + DESC_BIAS));
-        const int flag = (int)(g >> 62);
-        const u64 pm = __ballot(flag == 2), xm = __ballot(flag == 0);
-        const int f = pm ? __builtin_ctzll(pm) : 64;
-        const u64 nearer = f >= 64 ? ~0ull : ((1ull << f) - 1ull);
-        if (xm & nearer) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > SPIN_LIMIT) { if (lane == 0) st->lookback_timeout = 1; return running; }
-            continue;
-        }
-        int64_t v = (int64_t)(g & DESC_VMASK);
-        if (flag == 2) v -= DESC_BIAS;
-        running += wave_sum(lane <= f ? v : 0);
-        if (f < 64) return running;
-        base -= 64;
-    }
-}
-
-struct Cols { int64_t s, q, d; };
-
-__device__ inline Cols lookback_cols(const u64* desc_agg, const u64* desc_pre, int64_t t, int64_t S0, int64_t Q0,
-                                     int64_t I0, int lane, ChunkState* st) {
-    if (t == 0) return Cols{S0, Q0, I0};
-    Cols run{0, 0, 0};
-    int64_t base = t - 1;
-    int spins = 0;
-    for (;;) {
-        const int64_t p = base - lane;
-        int flag = 0;
-        int64_t vs = 0, vq = 0, vd = 0;
-        if (p < 0) { flag = 2; vs = S0; vq = Q0; vd = I0; }
-        else {
-            const u64 a = ld_agent(&desc_pre[3 * p]), b = ld_agent(&desc_pre[3 * p + 1]), c = ld_agent(&desc_pre[3 * p + 2]);
-            if ((a >> 62) == 2 && (b >> 62) == 2 && (c >> 62) == 2) {
-                flag = 2;
-                vs = (int64_t)(a & DESC_VMASK) - DESC_BIAS;
-                vq = (int64_t)(b & DESC_VMASK) - DESC_BIAS;
-                vd = (int64_t)(c & DESC_VMASK) - DESC_BIAS;
-            } else {
-                const u64 ag = ld_agent(&desc_agg[p]);
-                if ((ag >> 62) == 1) {
-                    flag = 1;
-                    vs = (int64_t)(ag & 0xFFFFFull); vq = (int64_t)((ag >> 20) & 0xFFFFFull); vd = (int64_t)((ag >> 40) & 0xFFFFFull);
-                }
-            }
-        }
-        const u64 pm = __ballot(flag == 2), xm = __ballot(flag == 0);
-        const int f = pm ? __builtin_ctzll(pm) : 64;
-        const u64 nearer = f >= 64 ? ~0ull : ((1ull << f) - 1ull);
-        if (xm & nearer) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > SPIN_LIMIT) { if (lane == 0) st->lookback_timeout = 1; return run; }
-            continue;
-        }
-        const bool use = lane <= f;
-        run.s += wave_sum(use ? vs : 0);
-        run.q += wave_sum(use ? vq : 0);
-        run.d += wave_sum(use ? vd : 0);
-        if (f < 64) return run;
-        base -= 64;
-    }
-}
+#if BZQ_EXPERIMENTS
+#include "bzq_lookback.hpp"   // experiments/csrc: the decoupled look-backs of the single-read variant (LB = true)
+#endif
 
 template <int ROLE, bool CA, bool CQ>
 __device__ __forceinline__ void validate_window(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, int a, int b,
@@ -366,6 +288,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     };
     fetch(t);
     const int tid = tid0, lane = tid & 63, wave = tid >> 6;
+    (void)lane; (void)wave;   // (the look-back blocks of the EXPERIMENTS build)
     u64 tprev = 0;
     auto phase_mark = [&](int i) {
         if (BZQ_ABLATE(64) && tid == 0 && (t & 63) == 0) {   // 1 workgroup in 64 (all-workgroup atomics would dominate)
@@ -398,6 +321,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         *reinterpret_cast<u64*>(&s_pline[4 * tid]) = (u64)l0 | ((u64)l1 << 16) | ((u64)l2 << 32) | ((u64)l3 << 48);
     }
 
+#if BZQ_EXPERIMENTS
     // ---- look-back 1: line index of the tile's first line --------------------------------------
     if (LB && wave == 0) {
         if (lane == 0 && t > 0) st_agent(&a.desc_c[t], DESC_A | (u64)c);   // (the first tile of a chain publishes its prefix directly below)
@@ -408,6 +332,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             s_bcast[1] = Pex;
         }
     }
+#endif
     if (!dense) { // newline position table (other waves overlap this with wave 0's look-back)
         u64 m = m64;
         int idx = 0;
@@ -532,6 +457,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
     };
 
     int n_id = 0, n_seq = 0, n_qual = 0;
+    (void)n_id; (void)n_seq; (void)n_qual;
     uint32_t lh = 0, lsq = 0, lq = 0;   // this thread's segment (k = tid) of each role: kept length ...
     int dh = 0, ds = 0, dq = 0;         // ... and offset within the tile's part of the column
     if (dense) {
@@ -595,6 +521,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
         n_id = (int)(tot & 0x1FFFFFull); n_seq = (int)((tot >> 21) & 0x1FFFFFull); n_qual = (int)((tot >> 42) & 0x1FFFFFull);
     }
 
+#if BZQ_EXPERIMENTS
     // ---- look-back 2: column offsets --------------------------------------------------------------
     if (LB && wave == 0) {
         if (lane == 0 && t > 0)
@@ -613,6 +540,7 @@ static __global__ __launch_bounds__(BLOCK) void k_fused(FusedArgs a) {
             if (c > 0) atomicMax((long long*)&a.st->last_nl_tile, (long long)t);
         }
     }
+#endif
     // (as late as the barrier in front of the first reader allows: the loads behind fold_v were issued one scalar-load latency
     // after the tile's, and wave 0 must not wait for them while the other waves wait for wave 0)
     if (FOLD && tid0 < 16) s_fold[tid0] = fold_v;

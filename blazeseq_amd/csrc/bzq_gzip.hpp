@@ -1150,11 +1150,13 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_order(int n, const uint8_t*
 
 static __global__ void k_gz_job0(Job* jobs, u64 start) { jobs[0] = Job{start, 1, 0}; }   // (job 0 = the piece's exact start)
 
+#if BZQ_EXPERIMENTS   // option early_find (measured: no gain) -- the EXPERIMENTS library only
 // starts found on a grid laid over the piece's NEW bytes before its carry was known (gz_stage): jobs[1 ..] += shift, in position units
 static __global__ __launch_bounds__(BLOCK) void k_gz_shift(Job* jobs, int n, long long shift) {
     const int i = (int)(blockIdx.x * BLOCK + threadIdx.x);
     if (i < n && jobs[i].start != POS_NONE) jobs[i].start = (u64)((long long)jobs[i].start + shift);
 }
+#endif
 
 // ORDER of a piece's jobs on `st` (jobs[0] set, the others found); order_buf = [bins][cursor][order n_chunks][keys n_chunks].  Returns the order array.
 static inline const uint32_t* launch_order(hipStream_t st, const Job* jobs, void* order_buf, int n_chunks) {
@@ -1461,7 +1463,7 @@ struct bzq_gzip {
                                         // decoded under them, and the one behind it on its way to the device)
     hipStream_t copy_stream = nullptr;
     hipEvent_t staged_ev[3] = {nullptr, nullptr, nullptr}, early_ev[3] = {nullptr, nullptr, nullptr};
-    // option "early_find" (default 0): a staged piece's finder runs behind its COPY instead of behind the decoding of the piece in front.
+    // option "early_find" (default 0; EXPERIMENTS library only -- the product ignores it): a staged piece's finder runs behind its COPY instead of behind the decoding of the piece in front.
     // Built and parity-green in round 4, and no faster (27.3 against 28.2 GB/s file -> records): with the finder off the critical path
     // the chain / resolve / CRC kernels of the piece in front are on it -- beside 16 000 decoder waves they take 12 ms instead of 3
     // (k_gz_chain_groups, one workgroup: 0.28 -> 8.8 ms), whatever the streams' priorities or CU masks (measured: DESIGN 5c)
@@ -1611,6 +1613,7 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
     // known they are shifted to where the piece then starts (k_gz_shift, gz_decode).  3 of a piece's 15.5 ms off its critical path.
     bool found = false;
     int nch = 0;
+#if BZQ_EXPERIMENTS   // (option early_find: compiled into the EXPERIMENTS library only)
     static const bool no_early = getenv("BZQ_GZ_NO_EARLY_FIND") != nullptr;
     if (h->early_find && !no_early) {
         const int CH = h->chunk_bytes;
@@ -1634,6 +1637,7 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
             if (!found) (void)hipGetLastError();
         }
     }
+#endif
     std::lock_guard<std::mutex> lk(h->stage_mu);
     h->staged.push_back(bzq_gzip::StagedPiece{src, n_new, bi, found, nch});
     return 0;
@@ -1992,10 +1996,13 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
             GZCHK(h, hipEventRecord(h->pre_copy_ev, fs));
             const unsigned long long start2 = (final_pos & 1ull) ? pos_header(0) : pos_deflate((final_pos >> 1) & 7ull);
             hipLaunchKernelGGL(k_gz_job0, dim3(1), dim3(1), 0, fs, (Job*)jobsN.p, (u64)start2);
+#if BZQ_EXPERIMENTS
             if (early) {   // found behind its copy (gz_stage), relative to CH bytes in front of its own bytes: to where the piece starts now
                 hipLaunchKernelGGL(k_gz_shift, dim3((unsigned)((nch2 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, fs, (Job*)jobsN.p + 1, nch2 - 1, ((long long)nc2 - (long long)CH) * 16);
                 (void)launch_order(fs, (const Job*)jobsN.p, orderN.p, nch2);
-            } else {
+            } else
+#endif
+            {
                 Args a2{};
                 a2.comp = d2; a2.n = (int64_t)nn; a2.jobs = (Job*)jobsN.p; a2.n_jobs = nch2; a2.n_cand = nch2; a2.chunk_bytes = CH; a2.counters = (uint32_t*)h->counters2.p;
                 (void)launch_find(fs, a2, orderN.p, nch2);

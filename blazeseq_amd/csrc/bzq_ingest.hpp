@@ -59,9 +59,7 @@ struct bzq_ingest {
     // BGZF inflated on the device (bzq_inflate.hpp): the slot's pinned buffer carries the COMPRESSED blocks to comp_dev, the
     // kernel writes the chunk into the slot's device buffer; first_bad travels back behind it
     int gpu_inflate = 0;
-    int inflate_ms = 0;                                    // eight blocks per wave (bzq_inflate_ms.hpp) instead of one
-    uint32_t* ms_scratch[bzq::INGEST_SLOTS] = {};          // its per-block scratch lines, grown to the slot's largest block count
-    size_t ms_scratch_cap[bzq::INGEST_SLOTS] = {};
+    int inflate_ms = 0;                                    // EXPERIMENTS build: eight blocks per wave (experiments/csrc/bzq_inflate_ms.hpp) instead of one
     uint8_t* comp_dev[bzq::INGEST_SLOTS] = {};
     bzq::inf::DevBlock* tab_dev[bzq::INGEST_SLOTS] = {};
     bzq::inf::DevBlock* tab_pinned[bzq::INGEST_SLOTS] = {};
@@ -475,16 +473,12 @@ inline void ingest_producer(bzq_ingest* g) {
                     (he = hipMemcpyAsync(g->tab_dev[b], g->tab_pinned[b], (size_t)n_blocks * sizeof(bzq::inf::DevBlock), hipMemcpyHostToDevice, cs)) != hipSuccess ||
                     (he = hipMemsetAsync(g->bad_dev + b, 0xFF, sizeof(unsigned long long), cs)) != hipSuccess)
                     return fail("reader: host to device copy (compressed blocks)", he);
+#if BZQ_EXPERIMENTS
                 if (g->inflate_ms) {
-                    const size_t need = bzq::inf::ms_scratch_bytes(n_blocks);
-                    if (need > g->ms_scratch_cap[b]) {   // (the slot's previous kernel finished long ago: its chunk has been consumed)
-                        if (g->ms_scratch[b]) (void)hipFree(g->ms_scratch[b]);
-                        g->ms_scratch[b] = nullptr; g->ms_scratch_cap[b] = 0;
-                        if ((he = hipMalloc((void**)&g->ms_scratch[b], need + need / 4)) != hipSuccess) return fail("reader: scratch of the device inflate", he);
-                        g->ms_scratch_cap[b] = need + need / 4;
-                    }
-                    bzq::inf::launch_bgzf_inflate_ms(bzq::inf::ArgsMs{g->comp_dev[b], comp_len, g->tab_dev[b], n_blocks, s.dev + g->reserve, g->bad_dev + b, g->ms_scratch[b], nullptr}, cs);
-                } else {
+                    bzq::inf::launch_bgzf_inflate_ms(bzq::inf::ArgsMs{g->comp_dev[b], comp_len, g->tab_dev[b], n_blocks, s.dev + g->reserve, g->bad_dev + b, nullptr, nullptr}, cs);
+                } else
+#endif
+                {
                     bzq::inf::Args ia{g->comp_dev[b], comp_len, g->tab_dev[b], n_blocks, s.dev + g->reserve, g->bad_dev + b};
                     hipLaunchKernelGGL(bzq::inf::k_bgzf_inflate, dim3((unsigned)((n_blocks + bzq::inf::WAVES - 1) / bzq::inf::WAVES)), dim3(BLOCK), 0, cs, ia);
                 }
@@ -526,7 +520,6 @@ inline void ingest_free(bzq_ingest* g) {
         cache::device_pool().put(g->slot[i].dev);
         if (g->big[i]) (void)hipFree(g->big[i]);
         cache::device_pool().put(g->comp_dev[i]);
-        if (g->ms_scratch[i]) (void)hipFree(g->ms_scratch[i]);
         if (g->tab_dev[i]) (void)hipFree(g->tab_dev[i]);
         if (g->tab_pinned[i]) (void)hipHostFree(g->tab_pinned[i]);
         if (g->slot[i].h2d_done) (void)hipEventDestroy(g->slot[i].h2d_done);

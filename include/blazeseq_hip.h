@@ -437,7 +437,7 @@ int32_t bzq_gzip_open(bzq_ctx* ctx, bzq_gzip** out);
  * "predecode" (default 1): with pieces staged ahead (bzq_gzip_stage; up to three buffers: the piece being decoded and two behind
  * it), the finder and the decoders of piece k + 1 are launched as soon as piece k's chain is walked and run beside piece k's last
  * kernels, into a second set of pool / result buffers.  "early_find" (default 0): a staged piece's finder runs behind its copy, on
- * a chunk grid over its own bytes (measured: no faster). */
+ * a chunk grid over its own bytes (measured: no faster, DESIGN.md 5c -- compiled into the EXPERIMENTS library only, the product ignores the option). */
 int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value);
 /* The next n compressed bytes (HOST memory; pinned memory makes the copy a DMA) -> their bytes at d_out (DEVICE memory,
  * out_capacity bytes).  Whole DEFLATE blocks only: what is left of the piece stays inside the handle and is decoded in front of

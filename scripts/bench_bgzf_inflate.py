@@ -16,7 +16,8 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--ms", type=int, default=0, help="1: eight blocks per wave (bzq_inflate_ms.hpp, the round-4 experiment); 0: one block per wave (the product)")
 args = ap.parse_args()
 ctx = B.Context()
-ctx.set_option("inflate_ms", args.ms)
+if args.ms:
+    ctx.set_option("inflate_ms", 1)   # (EXPERIMENTS library only: BLAZESEQ_HIP_LIB=blazeseq_amd/libblazeseq_hip_exp.so)
 lib = L.lib()
 n_rec = args.slice_mb * (1 << 20) // 318
 size = ctx.generate_synthetic_device(n_rec, 150, 33, 73, "generic", 0, 0)

@@ -15,9 +15,17 @@ from tests.fastq_fuzz import rand_stream
 pytestmark = pytest.mark.gpu
 
 
-# the product kernel (one wave per block, bzq_inflate.hpp) and the round-4 one that decodes eight blocks per wave (bzq_inflate_ms.hpp;
-# option inflate_ms, off by default: profiles/r4_inflate_ms.md)
-MS_KERNELS, MS_IDS = [0, 1], ["wave_per_block", "eight_blocks_per_wave"]
+# the product kernel (one wave per block, bzq_inflate.hpp) and -- in the EXPERIMENTS library only (tests/test_gpu_experiments.py runs
+# this file against it with BZQ_TEST_EXPERIMENTS=1) -- the round-4 one that decodes eight blocks per wave
+# (experiments/csrc/bzq_inflate_ms.hpp, option inflate_ms: correct, 2.7x slower, profiles/r4_inflate_ms.md)
+import os
+EXPERIMENTS = os.environ.get("BZQ_TEST_EXPERIMENTS") == "1"
+MS_KERNELS, MS_IDS = ([0, 1], ["wave_per_block", "eight_blocks_per_wave"]) if EXPERIMENTS else ([0], ["wave_per_block"])
+
+
+def pick_kernel(ctx, ms):
+    if ms:
+        ctx.set_option("inflate_ms", 1)
 
 def inflate_on_device(ctx, comp: bytes) -> bytes:
     a = np.frombuffer(comp, dtype=np.uint8)
@@ -56,7 +64,7 @@ def payloads():
 @pytest.mark.parametrize("name,data", list(payloads()), ids=[n for n, _ in payloads()])
 def test_levels_and_strategies(name, data, ms):
     ctx = Context()
-    ctx.set_option("inflate_ms", ms)   # 1: the round-4 kernel that decodes eight blocks per wave (bzq_inflate_ms.hpp; an option, off by default)
+    pick_kernel(ctx, ms)
     for level, strategy in [(6, zlib.Z_DEFAULT_STRATEGY), (1, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_DEFAULT_STRATEGY), (0, zlib.Z_DEFAULT_STRATEGY),
                             (6, zlib.Z_FIXED), (6, zlib.Z_RLE), (6, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_FILTERED)]:
         block = 65280 if level else 60000
@@ -70,7 +78,7 @@ def test_levels_and_strategies(name, data, ms):
 @pytest.mark.parametrize("ms", MS_KERNELS, ids=MS_IDS)
 def test_block_sizes_around_the_edges(ms):
     ctx = Context()
-    ctx.set_option("inflate_ms", ms)
+    pick_kernel(ctx, ms)
     rng = np.random.default_rng(5)
     base = rand_stream(rng, n_records=700, max_len=150, dirty=0.0, tail=0)
     parts, want = [], []
@@ -106,7 +114,7 @@ def test_what_a_sequencer_writes(ms):
 @pytest.mark.parametrize("ms", MS_KERNELS, ids=MS_IDS)
 def test_many_blocks_random_mix(ms):
     ctx = Context()
-    ctx.set_option("inflate_ms", ms)
+    pick_kernel(ctx, ms)
     rng = np.random.default_rng(8)
     parts, want = [], []
     for i in range(600):
@@ -134,7 +142,7 @@ def test_corrupt_blocks_fail(ms):
     (RFC 1952 8.) -- unless the damage sits in bits the stream does not use; never a crash, a hang, a write outside the
     block's output or different bytes delivered."""
     ctx = Context()
-    ctx.set_option("inflate_ms", ms)
+    pick_kernel(ctx, ms)
     rng = np.random.default_rng(2)
     data = rand_stream(rng, n_records=190, max_len=150, dirty=0.0, tail=0)
     good = bgzf_block(data)
@@ -166,8 +174,7 @@ def test_corrupt_blocks_fail(ms):
 def test_crc_of_every_size_class(ms):
     """The CRC pieces: 64 lanes x ceil(n / 64) bytes, the last lanes empty or short."""
     ctx = Context()
-    ctx.set_option("inflate_ms", ms)
-    ctx.set_option("inflate_ms", ms)
+    pick_kernel(ctx, ms)
     rng = np.random.default_rng(4)
     parts, want = [], []
     for n in list(range(0, 200)) + [255, 256, 257, 4095, 4096, 4097, 65535, 65536]:

@@ -25,7 +25,8 @@ def test_product_library_has_no_experimental_variants():
     assert L.lib().bzq_set_option(ctx.h, b"experiments", 0) == L.ERR_ARG
     syms = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True).stdout
     raw = open(L.LIB_PATH, "rb").read()
-    for name in (b"k_single", b"k_tile_emit", b"lookback_"):
+    assert L.lib().bzq_set_option(ctx.h, b"inflate_ms", 1) == L.ERR_ARG
+    for name in (b"k_single", b"k_tile_emit", b"lookback_", b"k_bgzf_inflate_ms", b"k_gz_shift"):
         assert name not in raw, name
     assert "bzq_submit_chunk_device" in syms
     ctx.close()
@@ -36,6 +37,19 @@ def test_parity_of_every_variant_in_the_experiments_build():
         pytest.skip("libblazeseq_hip_exp.so not built (make -C blazeseq_amd/csrc exp)")
     env = dict(os.environ, BLAZESEQ_HIP_LIB=EXP, BZQ_TEST_EXPERIMENTS="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-4000:], r.stderr[-2000:])
+    print(r.stdout.strip().splitlines()[-1])
+
+
+def test_experimental_inflate_and_gzip_variants_in_the_experiments_build():
+    """Eight BGZF blocks per wave (option inflate_ms) and the gzip finder behind the copy (option early_find): measured losers that
+    live in the EXPERIMENTS library only; their parity tests run against it here."""
+    if not os.path.exists(EXP):
+        pytest.skip("libblazeseq_hip_exp.so not built (make -C blazeseq_amd/csrc exp)")
+    env = dict(os.environ, BLAZESEQ_HIP_LIB=EXP, BZQ_TEST_EXPERIMENTS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_bgzf_inflate.py", "tests/test_gpu_gzip.py::test_the_next_piece_under_this_one",
+                        "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k", "eight_blocks_per_wave or next_piece"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-4000:], r.stderr[-2000:])
     print(r.stdout.strip().splitlines()[-1])
