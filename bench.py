@@ -337,6 +337,91 @@ def ingest_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, chu
     return res
 
 
+def process_mode(ctx, dev, runs=15, warmup=3, modes=("plain", "bgzf", "gzip")):
+    """A WHOLE PROCESS per run, the way the reference times itself (benchmark/throughput/run_throughput_benchmarks.sh:54-62, 141-149:
+    hyperfine --warmup 3 --runs 15 around `run_throughput_blazeseq <file> batches` on a 3 GiB file of 14.7 M x 100 bp reads on a
+    RAM-backed filesystem; published: batches 4.03, views 5.13 GB/s on the authors' host).  The process is the plain-C driver
+    tests/c_driver/bzq_throughput (exec -> bzq_create -> bzq_ingest_open -> every chunk, every batch of 4096 handed out ->
+    `records base_pairs` printed -> exit), the clock is around the subprocess: dynamic loading, HIP initialisation, pinning, the
+    file, teardown -- everything.  plain = the reference generator's own reads; .bgz / .gz = the first 32 MiB of them, compressed
+    once (zlib -6) and repeated to the same size (compressing 3 GiB on one host core would take minutes)."""
+    import statistics
+    import struct
+    import subprocess
+    import zlib
+    import numpy as np
+    import torch
+    exe = os.path.join(ROOT, "tests", "c_driver", "bzq_throughput")
+    if not os.path.exists(exe):
+        return {"error": "tests/c_driver/bzq_throughput is not built (python __graft_entry__.py)"}
+    reads, read_len = 14_700_000, 100
+    n = ctx.generate_synthetic_device(reads, read_len, 33, 73, "generic", 0, 0, first=0, count=reads, max_len=read_len)
+    buf = torch.empty(n + (1 << 20), dtype=torch.uint8, device=dev)
+    ctx.generate_synthetic_device(reads, read_len, 33, 73, "generic", buf.data_ptr(), buf.numel(), first=0, count=reads, max_len=read_len)
+    torch.cuda.synchronize()
+    host = buf[:n].cpu().numpy()
+    del buf
+    rec_bytes = n // reads
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
+    tag = f"bzq_proc_{os.getpid()}"
+    paths = {m: os.path.join(d, f"{tag}.fastq{ext}") for m, ext in (("plain", ""), ("bgzf", ".bgz"), ("gzip", ".gz"))}
+    res = {"file_fastq_gb": round(n / 1e9, 3), "records": reads, "read_len": read_len, "runs": runs, "warmup_runs": warmup, "dir": d,
+           "driver": "tests/c_driver/bzq_throughput <file> batches (plain C over the C ABI; 256 MiB chunks, 8 reader threads)",
+           "reference_published_gb_s": {"batches": 4.03, "views": 5.13, "records": 2.16, "note": "BASELINE.md: the authors' host, their 3 GiB / 100 bp file; context, not a baseline measured here"},
+           "note": "wall clock around a fresh process per run (subprocess: exec, library loading, hipInit, bzq_create, open, every chunk and batch, print, teardown, exit); "
+                   "value = file's FASTQ bytes / mean wall; min / max / stdev over the timed runs beside it"}
+    try:
+        host.tofile(paths["plain"])
+        k = (32 << 20) // rec_bytes * rec_bytes
+        pbytes = host[:k].tobytes()
+        reps = n // k
+        expect = {"plain": (reads, reads * read_len), "bgzf": (reps * (k // rec_bytes), reps * (k // rec_bytes) * read_len)}
+        expect["gzip"] = expect["bgzf"]
+
+        def block(data):
+            c2 = zlib.compressobj(6, zlib.DEFLATED, -15)
+            payload = c2.compress(data) + c2.flush()
+            return (b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(payload) + 8 - 1) + payload +
+                    struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+        if "bgzf" in modes:
+            bg = b"".join(block(pbytes[i:i + 65280]) for i in range(0, k, 65280))
+            with open(paths["bgzf"], "wb") as f:
+                for _ in range(reps):
+                    f.write(bg)
+                f.write(block(b""))
+        if "gzip" in modes:
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            member = bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3]) + co.compress(pbytes) + co.flush() + struct.pack("<II", zlib.crc32(pbytes) & 0xFFFFFFFF, k & 0xFFFFFFFF)
+            with open(paths["gzip"], "wb") as f:
+                for _ in range(reps):
+                    f.write(member)
+        del host
+        for m in modes:
+            fastq_bytes = n if m == "plain" else reps * k
+            walls = []
+            for it in range(warmup + runs):
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, paths[m], "batches"], capture_output=True, text=True, timeout=120)
+                dt = time.perf_counter() - t0
+                if r.returncode != 0:
+                    raise RuntimeError(f"{m}: bzq_throughput exit {r.returncode}: {r.stderr[-300:]}")
+                got = tuple(int(x) for x in r.stdout.split())
+                assert got == expect[m], (m, got, expect[m])
+                if it >= warmup:
+                    walls.append(dt)
+            mean = statistics.fmean(walls)
+            res[m] = {"value": round(fastq_bytes / mean / 1e9, 2), "unit": "GB/s of FASTQ, whole process", "mean_ms": round(mean * 1e3, 1), "stdev_ms": round(statistics.pstdev(walls) * 1e3, 1),
+                      "min_ms": round(min(walls) * 1e3, 1), "max_ms": round(max(walls) * 1e3, 1), "best_gb_s": round(fastq_bytes / min(walls) / 1e9, 2),
+                      "file_gb": round(os.path.getsize(paths[m]) / 1e9, 3), "stdout": " ".join(str(x) for x in got)}
+    finally:
+        for q in paths.values():
+            try:
+                os.remove(q)
+            except OSError:
+                pass
+    return res
+
+
 def crlf_variant(shard, reads, rec_bytes, id_bytes):
     """The same reads with DOS line ends (the reference corpus' example_dos.fastq at scale): '\\r' before each of a record's four
     newlines.  Record layout of the synthetic input: '@' id '\\n' seq '\\n' '+' '\\n' qual '\\n'."""
@@ -562,6 +647,8 @@ def main():
                          "bzq_shard_stitch: file-chunk sharding end to end, PCIe inclusive (10 M reads per rank unless --reads says otherwise)")
     ap.add_argument("--reader-threads", type=int, default=8)
     ap.add_argument("--no-ingest-mode", action="store_true", help="skip the file -> records figures (ingest_mode) of the default line")
+    ap.add_argument("--no-process-mode", action="store_true", help="skip process_mode (a fresh process per run over the reference's own 3 GiB workload, 3 + 15 runs x 3 file kinds: ~40 s)")
+    ap.add_argument("--process-only", action="store_true", help="print only process_mode")
     ap.add_argument("--ingest-chunk-mib", type=int, default=256, help="chunk size of the ingest_mode runs")
     ap.add_argument("--ingest-threads", type=int, default=8, help="reader threads of the ingest_mode runs")
     ap.add_argument("--ingest-only", action="store_true", help="print only ingest_mode (sweeps of the two options above)")
@@ -627,6 +714,9 @@ def main():
     min_record_bytes = 256 if not args.long_reads and args.read_len >= 100 else 32
     ctx = B.Context(cfg, "generic", 4096, local_rank, pass_bytes=args.pass_bytes, min_record_bytes=min_record_bytes)
     ctx.set_option("timing_detail", 1)
+    if args.process_only:   # (sweeps: only the whole-process figures)
+        print(json.dumps({"process_mode": process_mode(ctx, dev)}))
+        return
     if args.hier or args.service or args.single_pass or args.kernels_v1:   # EXPERIMENTS build only (BLAZESEQ_HIP_LIB=.../libblazeseq_hip_exp.so)
         ctx.set_option("single_pass", 3 if args.hier else 2 if args.service else (1 if (args.single_pass and not args.kernels_v1) else 0))
         ctx.set_option("kernels_v2", 0 if args.kernels_v1 else 1)
@@ -1007,6 +1097,11 @@ def main():
                 out["ingest_mode"] = ingest_mode(shard, rec_bytes, dev, local_rank, threads=args.ingest_threads, chunk_mib=args.ingest_chunk_mib)
             except Exception as e:   # noqa: BLE001
                 out["ingest_mode"] = {"error": str(e)[:300]}
+        if extras and not args.views and not args.long_reads and args.read_len == 150 and not args.no_process_mode:
+            try:
+                out["process_mode"] = process_mode(ctx, dev)
+            except Exception as e:   # noqa: BLE001
+                out["process_mode"] = {"error": str(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             k = min(args.cpu_reads, recs)
             host = shard[:k * rec_bytes].cpu().numpy() if not args.long_reads else shard[:n].cpu().numpy()

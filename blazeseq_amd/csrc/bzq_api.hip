@@ -2181,6 +2181,7 @@ int32_t bzq_shard_read_range(bzq_ctx* c, const char* path, uint64_t lo, uint64_t
                 if (r <= 0) { fail = 2; return; }
                 got += (uint64_t)r;
             }
+            bzq::cache::pinned_pool().pin(pin, 0, len);   // (lazy pinning: the pread above has just made the pages)
             if (hipMemcpyAsync(dst + off, pin, len, hipMemcpyHostToDevice, q) != hipSuccess || hipEventRecord(c->shard_events[2 * w + b], q) != hipSuccess) { fail = 3; return; }
             used[b] = true;
         }
@@ -2211,6 +2212,20 @@ int32_t bzq_ingest_open(bzq_ctx* c, const char* path, uint64_t chunk_bytes, int3
         (*out)->ctx = c;
         // a new stream: the window follower of an earlier one must not judge this one's tail
         c->follow_on = false; c->stage_valid = false; c->records_before = -1;
+        // While the reader threads fetch the first chunk: what the first parse would otherwise do before its first kernel -- the
+        // arenas of a whole chunk, and the library's code object onto the device (the runtime loads it at the first launch:
+        // ~20 ms of a fresh process, scripts/process_probe.sh).  Failures are the first submit's to report.
+        if (c->n_submits == 0 && !c->cfg.views_only) {
+            bzq_ingest* g = *out;
+            uint64_t n0 = g->chunk_bytes + g->reserve;
+            if (g->compression == 0) n0 = std::min<uint64_t>(n0, g->file_size);
+            if (n0 && ensure_tile_arenas(c, n0) == 0 && ensure_col_arenas(c, n0) == 0)
+                (void)ensure_record_arenas(c, (int64_t)(n0 / (uint64_t)std::max(4, c->cfg.min_record_bytes)) + 1024);
+            hipLaunchKernelGGL(k_cumulate, dim3(1), dim3(BLOCK), 0, c->stream, (const int64_t*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr,
+                               (int64_t)1, (int64_t)0, (int64_t*)nullptr, (int64_t*)nullptr);
+            (void)hipGetLastError();
+            c->err.clear();
+        }
     }
     return rc;
 }

@@ -19,14 +19,24 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
+#include <sys/mman.h>
 
 namespace bzq { namespace cache {
 
-struct Entry { void* p; uint64_t cap; int device; };
+// Host buffers are PINNED LAZILY (round 5).  What hipHostMalloc costs is not the pinning but the pages: 49 ms for 288 MiB, of which
+// touching (zeroing) the fresh pages is 50 and registering them with the driver 4 (scripts/probes/mmap_register_probe.hip) -- and
+// three such buffers were 175-225 ms of a fresh process's bzq_ingest_open, more than its whole file took to parse.  A host buffer
+// is therefore anonymous memory (transparent huge pages asked for) that nobody touches at the open; the reader threads' own pread
+// is what faults its pages in, eight threads side by side, and `pin` registers it in blocks of 32 MiB just before the first copy
+// that reads from a block (hipHostRegister: ~0.5 ms per block once its pages exist).  A block stays registered while the buffer
+// lives, in the cache too.
+constexpr uint64_t PIN_BLOCK = 32ull << 20;
+struct Entry { void* p; uint64_t cap; int device; uint64_t pinned_blocks = 0; /* bit k: block k is registered (caps up to 2 GiB) */ };
 
 struct Pool {
     const bool pinned;
@@ -42,16 +52,68 @@ struct Pool {
     static bool tracing() { static const bool t = getenv("BZQ_BUF_CACHE_TRACE") != nullptr; return t; }   // (debug: every driver call that takes > 2 ms, to stderr)
     hipError_t raw_alloc(void** p, uint64_t n) {
         const auto t0 = std::chrono::steady_clock::now();
-        const hipError_t e = pinned ? hipHostMalloc(p, n, hipHostMallocDefault) : hipMalloc(p, n);
+        hipError_t e = hipSuccess;
+        if (pinned) {
+            void* m = mmap(nullptr, (size_t)n, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (m == MAP_FAILED) { *p = nullptr; e = hipErrorOutOfMemory; }
+            else { (void)madvise(m, (size_t)n, MADV_HUGEPAGE); *p = m; }
+        } else e = hipMalloc(p, n);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (tracing() && ms > 2.0) fprintf(stderr, "[bzq cache] %s(%.1f MiB): %.1f ms\n", pinned ? "hipHostMalloc" : "hipMalloc", n / 1048576.0, ms);
+        if (tracing() && ms > 2.0) fprintf(stderr, "[bzq cache] %s(%.1f MiB): %.1f ms\n", pinned ? "mmap" : "hipMalloc", n / 1048576.0, ms);
         return e;
     }
-    void raw_free(void* p) {
+    void raw_free(const Entry& en) {
         const auto t0 = std::chrono::steady_clock::now();
-        (void)(pinned ? hipHostFree(p) : hipFree(p));
+        if (pinned) {
+            for (uint64_t k = 0; k * PIN_BLOCK < en.cap; ++k)
+                if (en.pinned_blocks >> k & 1ull) (void)hipHostUnregister((uint8_t*)en.p + k * PIN_BLOCK);
+            (void)munmap(en.p, (size_t)en.cap);
+        } else (void)hipFree(en.p);
         const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (tracing() && ms > 2.0) fprintf(stderr, "[bzq cache] %s: %.1f ms\n", pinned ? "hipHostFree" : "hipFree", ms);
+        if (tracing() && ms > 2.0) fprintf(stderr, "[bzq cache] %s: %.1f ms\n", pinned ? "unregister + munmap" : "hipFree", ms);
+    }
+    // Host buffers: bytes [from, to) of buffer p are about to be read by a copy engine -- register the blocks they touch that are not
+    // registered yet.  Their pages should exist by now (the caller has just written them); a block that cannot be registered is
+    // left as it is (the copy then goes through the runtime's own staging: slower, not wrong).
+    void pin(void* p, uint64_t from, uint64_t to) {
+        if (!pinned || !p || to <= from) return;
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = out.find(p);
+        if (it == out.end()) return;
+        Entry& en = it->second;
+        if (to > en.cap) to = en.cap;
+        for (uint64_t k = from / PIN_BLOCK; k * PIN_BLOCK < to && k < 64; ++k) {
+            if (en.pinned_blocks >> k & 1ull) continue;
+            const uint64_t b0 = k * PIN_BLOCK, b1 = std::min<uint64_t>(en.cap, b0 + PIN_BLOCK);
+            const auto t0 = std::chrono::steady_clock::now();
+            const hipError_t e = hipHostRegister((uint8_t*)en.p + b0, (size_t)(b1 - b0), hipHostRegisterDefault);
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (tracing() && ms > 2.0) fprintf(stderr, "[bzq cache] hipHostRegister(block %llu, %.1f MiB): %.1f ms\n", (unsigned long long)k, (b1 - b0) / 1048576.0, ms);
+            if (e == hipSuccess) en.pinned_blocks |= 1ull << k; else (void)hipGetLastError();
+        }
+    }
+
+    // hipMemcpyAsync(dst, src, n, host to device, st) for a source inside a buffer of this pool: the blocks it touches are registered
+    // first, and the copy is issued block by block -- every block is a registration of its own, and one copy must not span two.
+    // A source that is not in a buffer of this pool is copied as it is.
+    hipError_t h2d(void* dst, const void* src, uint64_t n, hipStream_t st) {
+        if (!n) return hipSuccess;
+        const uint8_t* base = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (const auto& kv : out)
+                if ((const uint8_t*)src >= (const uint8_t*)kv.second.p && (const uint8_t*)src + n <= (const uint8_t*)kv.second.p + kv.second.cap) { base = (const uint8_t*)kv.second.p; break; }
+        }
+        if (!pinned || !base) return hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st);
+        const uint64_t off = (uint64_t)((const uint8_t*)src - base);
+        pin((void*)base, off, off + n);
+        for (uint64_t a = off; a < off + n;) {
+            const uint64_t b = std::min<uint64_t>(off + n, (a / PIN_BLOCK + 1) * PIN_BLOCK);
+            const hipError_t e = hipMemcpyAsync((uint8_t*)dst + (a - off), base + a, (size_t)(b - a), hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return e;
+            a = b;
+        }
+        return hipSuccess;
     }
 
     // debug: BZQ_BUF_CACHE_POISON=<byte> fills every buffer handed out with that byte (a user of the buffers that relies on what a
@@ -60,7 +122,7 @@ struct Pool {
         static const char* e = getenv("BZQ_BUF_CACHE_POISON");
         if (!e) return;
         const int v = (int)strtol(e, nullptr, 0) & 0xFF;
-        if (pinned) memset(p, v, n);
+        if (pinned) memset(p, v, n);   // (touches every page: a debugging aid, not for timing)
         else { (void)hipMemset(p, v, n); (void)hipDeviceSynchronize(); }
     }
     hipError_t get(int device, uint64_t want, void** outp) {
@@ -95,25 +157,26 @@ struct Pool {
             if (err != hipSuccess) return err;
         }
         std::lock_guard<std::mutex> lk(mu);
-        out[p] = Entry{p, want, device};
+        out[p] = Entry{p, want, device, 0};
         *outp = p;
         return hipSuccess;
     }
     // a pointer from get(); nothing in flight may touch it any more
     void put(void* p) {
         if (!p) return;
-        Entry e{p, 0, 0};
-        bool keep = false;
+        Entry e{p, 0, 0, 0};
+        bool keep = false, known = false;
         {
             std::lock_guard<std::mutex> lk(mu);
             auto it = out.find(p);
             if (it != out.end()) {
                 e = it->second;
+                known = true;
                 out.erase(it);
                 if (e.cap >= (1ull << 20) && held + e.cap <= limit) { idle.push_back(e); held += e.cap; keep = true; }
             }
         }
-        if (!keep) raw_free(p);
+        if (!keep && known) raw_free(e);
     }
     // give buffers back to the driver until at most `keep_bytes` are held; set_limit: that is also the new limit
     void trim(uint64_t keep_bytes, bool keep_limit) {
@@ -127,7 +190,7 @@ struct Pool {
                 idle.pop_back();
             }
         }
-        for (const Entry& e : drop) raw_free(e.p);
+        for (const Entry& e : drop) raw_free(e);
     }
 };
 

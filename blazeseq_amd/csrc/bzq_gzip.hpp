@@ -1526,6 +1526,7 @@ inline int gz_ensure(bzq_gzip* h, bzq_gzip::Buf& b, size_t bytes, bool pinned = 
     const hipError_t e = pool.get(h->device, want, &b.p);
     if (e != hipSuccess) { b.p = nullptr; (void)hipGetLastError(); return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: cannot allocate " + std::to_string(want) + " bytes"); }
     b.cap = want;
+    if (pinned) pool.pin(b.p, 0, want);   // (small host buffers the device writes results into: registered whole, at once)
     return 0;
 }
 
@@ -1603,7 +1604,7 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
         b.cap = want;
     }
     uint8_t* d = (uint8_t*)b.p + STAGE_RESERVE;
-    hipError_t e = hipMemcpyAsync(d, src, n_new, hipMemcpyHostToDevice, h->copy_stream);
+    hipError_t e = bzq::cache::pinned_pool().h2d(d, src, n_new, h->copy_stream);   // (the ingest's slots are pinned lazily, block by block: bzq_bufcache.hpp)
     if (e == hipSuccess) e = hipMemsetAsync(d + n_new, 0, 64, h->copy_stream);
     if (e == hipSuccess) e = hipEventRecord(h->staged_ev[bi], h->copy_stream);
     if (e != hipSuccess) { (void)hipStreamSynchronize(h->copy_stream); return give_back(BZQ_ERR_HIP); }
@@ -1867,7 +1868,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     else if (nc) GZCHK(h, hipMemcpyAsync(d_comp, h->carry.data(), nc, hipMemcpyHostToDevice, s));
     if (use_staged) GZCHK(h, hipStreamWaitEvent(s, h->staged_ev[cb], 0));
     else {
-        if (n_new) GZCHK(h, hipMemcpyAsync(d_comp + nc, src, n_new, hipMemcpyHostToDevice, s));
+        if (n_new) GZCHK(h, bzq::cache::pinned_pool().h2d(d_comp + nc, src, n_new, s));
         GZCHK(h, hipMemsetAsync(d_comp + n, 0, 64, s));
     }
     if (timing) GZCHK(h, hipStreamSynchronize(s));

@@ -291,11 +291,11 @@ inline bool ingest_alloc_slot(bzq_ingest* g, int i, uint64_t pinned_bytes) {
 // offsets relative to `pinned`) into tab.  The read is sized from the last chunk's compression ratio; a short read gives a
 // smaller chunk, never a wrong one.
 inline bool read_bgzf_window(bzq_ingest* g, uint8_t* pinned, uint64_t cap, bzq::inf::DevBlock* tab, int64_t* n_blocks, uint64_t* comp_len,
-                             uint64_t* out_len, bool* eof, std::string& err) {
+                             uint64_t* out_len, bool* eof, std::string& err, uint64_t out_cap) {
     *n_blocks = 0; *comp_len = 0; *out_len = 0; *eof = false;
     const uint64_t remaining = g->file_size - g->bgzf_off;
     if (remaining == 0) { *eof = true; return true; }
-    uint64_t want = (uint64_t)((double)g->chunk_bytes * g->ratio_est * 1.05) + (2ull << 20);
+    uint64_t want = (uint64_t)((double)out_cap * g->ratio_est * 1.05) + (2ull << 20);
     want = std::min<uint64_t>({want, cap, remaining});
     if (!parallel_pread(g->fd, pinned, g->bgzf_off, want, g->n_threads, err, g->fd_direct, &g->numa_cpus)) return false;
     uint64_t off = 0, usum = 0;
@@ -307,7 +307,7 @@ inline bool read_bgzf_window(bzq_ingest* g, uint8_t* pinned, uint64_t cap, bzq::
         const uint8_t* t = pinned + off + bs - 4;
         const uint32_t us = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
         if (us > 65536) { if (k == 0) { err = "BGZF: block claims more than 64 KiB"; return false; } break; }
-        if (usum + us > g->chunk_bytes) break;
+        if (usum + us > out_cap) break;
         const uint32_t crc = (uint32_t)t[-4] | ((uint32_t)t[-3] << 8) | ((uint32_t)t[-2] << 16) | ((uint32_t)t[-1] << 24);
         tab[k++] = bzq::inf::DevBlock{off + 18, usum, bs - 26, us, crc, 0u};
         usum += us; off += bs;
@@ -436,7 +436,7 @@ inline void ingest_producer(bzq_ingest* g) {
             len = std::min<uint64_t>(g->gz_have, g->chunk_bytes);
             eof = g->gz_done && g->gz_have <= g->chunk_bytes;
         } else if (g->gpu_inflate) {
-            ok = read_bgzf_window(g, s.pinned + g->reserve, g->chunk_bytes, g->tab_pinned[b], &n_blocks, &comp_len, &len, &eof, err);
+            ok = read_bgzf_window(g, s.pinned + g->reserve, g->chunk_bytes, g->tab_pinned[b], &n_blocks, &comp_len, &len, &eof, err, g->chunk_bytes);
         } else if (g->compression == 0) {
             len = std::min<uint64_t>(g->chunk_bytes, g->file_size - off);
             ok = parallel_pread(g->fd, s.pinned + g->reserve, off, len, g->n_threads, err, g->fd_direct, &g->numa_cpus);
@@ -469,7 +469,7 @@ inline void ingest_producer(bzq_ingest* g) {
         } else if (g->gpu_inflate) {
             g->bad_pinned[b] = ~0ull;   // (the consumer read the previous verdict of this slot two chunks ago)
             if (n_blocks) {
-                if ((he = hipMemcpyAsync(g->comp_dev[b], s.pinned + g->reserve, comp_len, hipMemcpyHostToDevice, cs)) != hipSuccess ||
+                if ((he = cache::pinned_pool().h2d(g->comp_dev[b], s.pinned + g->reserve, comp_len, cs)) != hipSuccess ||   // (lazy pinning, block by block: bzq_bufcache.hpp)
                     (he = hipMemcpyAsync(g->tab_dev[b], g->tab_pinned[b], (size_t)n_blocks * sizeof(bzq::inf::DevBlock), hipMemcpyHostToDevice, cs)) != hipSuccess ||
                     (he = hipMemsetAsync(g->bad_dev + b, 0xFF, sizeof(unsigned long long), cs)) != hipSuccess)
                     return fail("reader: host to device copy (compressed blocks)", he);
@@ -486,7 +486,7 @@ inline void ingest_producer(bzq_ingest* g) {
                     (he = hipMemcpyAsync(g->bad_pinned + b, g->bad_dev + b, sizeof(unsigned long long), hipMemcpyDeviceToHost, cs)) != hipSuccess)
                     return fail("reader: device inflate", he);
             }
-        } else if (len && (he = hipMemcpyAsync(s.dev + g->reserve, s.pinned + g->reserve, len, hipMemcpyHostToDevice, cs)) != hipSuccess)
+        } else if (len && (he = cache::pinned_pool().h2d(s.dev + g->reserve, s.pinned + g->reserve, len, cs)) != hipSuccess)
             return fail("reader: host to device copy", he);
         if ((he = hipEventRecord(s.h2d_done, cs)) != hipSuccess) return fail("reader: hipEventRecord", he);
         s.file_off = off; s.len = len; s.eof = eof;
