@@ -923,7 +923,19 @@ def main():
         assert totals[0] == total_reads and first_err == sharded.NO_ERROR, (totals, first_err)
         global_records, global_bytes = totals[0], total_bytes
 
+    rank_info = None
     if sharded_mode:
+        # what the first 8-GPU run executes for the first time, said out loud: every rank's device, the GPU's NUMA node, how many CPUs its
+        # reader threads are bound to -- and how many ranks' rows the library's own summary all-gather delivered (bzq_shard_stitch
+        # stamps every row with its rank: `ranks_seen` must equal N)
+        q = lambda key: int(L.lib().bzq_set_option(ctx.h, key, 0))
+        mine = {"rank": rank, "device": q(b"device"), "numa_node": (lambda v: None if v == 255 else v)(q(b"numa_node")), "reader_cpus_bound": q(b"numa_cpus"),
+                "reader_threads": args.reader_threads if file_path is not None else None, "ranks_seen": q(b"ranks_seen") if exchange == "native" else None}
+        print(f"[bench rank {rank}] device {mine['device']}, NUMA node {mine['numa_node']}, reader threads bound to {mine['reader_cpus_bound']} CPUs, "
+              f"ranks seen by the summary all-gather: {mine['ranks_seen']}", file=sys.stderr, flush=True)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        rank_info = gathered
         dist.barrier()
         dist.destroy_process_group()
     if file_path is not None and rank == 0:
@@ -972,6 +984,8 @@ def main():
                                        if world > 1 else "single GPU"),
                        "pass_bytes": args.pass_bytes, "exchange": exchange},
             "fraction_of_hbm_peak_input_rate": round(global_bytes / world / sec_per_step / 1e9 / HBM_PEAK_GBS, 4),
+            "ranks_seen": (min(r["ranks_seen"] for r in rank_info) if rank_info and exchange == "native" else None),
+            "ranks": rank_info,
             "from_file": ({"path": file_path, "file_gb": round(total_bytes / 1e9, 3), "reader_threads": args.reader_threads,
                            "pcie_frac_per_gpu": round(global_bytes / world / sec_per_step / 1e9 / PCIE_PEAK_GBS, 3),
                            "note": "every step starts at the file: bzq_shard_read_range (this rank's byte range: pread -> pinned -> H2D) + bzq_shard_stitch; "

@@ -190,6 +190,7 @@ struct bzq_ctx {
     int64_t comm_timeout_ms = 120000;  // option "comm_timeout_ms": host-side deadline of every exchange of the shard protocols
     uint64_t shard_totals[3] = {0, 0, 0};   // records, bases, bytes over all ranks after the last bzq_shard_stitch
     bool have_shard_totals = false;
+    int ranks_seen = 0;                // rows of the last bzq_shard_stitch's summary all-gather that carried their rank's stamp (query "ranks_seen")
     float ms_scan_shard = 0.f;         // kernels of the bzq_shard_scan that preceded this submit (pass A + scan)
     // A stream parsed in several chunks: where the reference's BufferedReader window stands behind every record handed out so
     // far (option "records_before").  Which outcome the reference gives for a stream that ends in bytes that are not a record
@@ -1138,6 +1139,7 @@ int32_t bzq_get_config(const bzq_ctx* c, bzq_config* out) {
     return 0;
 }
 
+static void gpu_numa_cpus(int device, int* node_out, std::vector<int>& cpus);
 int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     if (!c || !key) return BZQ_ERR_ARG;
     if (!strcmp(key, "force_dense")) c->force_dense = (int)value;
@@ -1158,6 +1160,13 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "pass_a_h")) c->pass_a_h = value != 0;
     else if (!strcmp(key, "fold_rebase")) c->fold_opt = value != 0;
     else if (!strcmp(key, "lean_submit")) c->lean = value != 0;
+    else if (!strcmp(key, "ranks_seen")) return c->ranks_seen;   // query
+    else if (!strcmp(key, "device")) return c->device;           // query
+    else if (!strcmp(key, "numa_node") || !strcmp(key, "numa_cpus")) {   // query: the GPU's NUMA node / how many CPUs the reader threads are bound to (0 = not bound)
+        int node = -1; std::vector<int> cpus;
+        if (c->ingest_numa) gpu_numa_cpus(c->device, &node, cpus);
+        return key[5] == 'n' ? (node >= 0 ? node : 255) : (int32_t)cpus.size();   // (255: node unknown)
+    }
     else if (!strcmp(key, "cumulative_ends")) c->fold_opt = value == 0;   // 1: bzq_chunk.d_ends / d_id_ends filled with every chunk (the k_rebase path, as before ABI 2)
     else if (!strcmp(key, "pass_a_sticky")) { c->sticky_opt = value != 0; if (!value) { c->exact_sticky = 0; c->exact_sticky_len = 0; } }
     else if (!strcmp(key, "ingest_direct")) c->ingest_direct = value != 0;

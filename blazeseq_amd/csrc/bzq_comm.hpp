@@ -182,11 +182,11 @@ int comm_gather(bzq_ctx* c, const int64_t* row, int64_t* all, const char* what =
 }
 
 // row = {bytes, newlines, first four newlines, first byte | last byte << 8, room behind the shard's bytes}
-static __global__ void k_pack_summary(const ChunkState* st, int64_t n, int64_t room, int64_t* row) {
+static __global__ void k_pack_summary(const ChunkState* st, int64_t n, int64_t room, int64_t* row, int64_t stamp) {
     if (threadIdx.x || blockIdx.x) return;
     row[0] = n; row[1] = st->P;
     for (int i = 0; i < 4; ++i) row[2 + i] = st->first_nl[i];
-    row[6] = (int64_t)st->edge_first | ((int64_t)st->edge_last << 8); row[7] = room;
+    row[6] = (int64_t)st->edge_first | ((int64_t)st->edge_last << 8) | (stamp << 16); row[7] = room;
 }
 
 void comm_free(bzq_comm* m) {
@@ -596,7 +596,7 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
     std::vector<int64_t> all((size_t)P * COMM_ROW);
     if (!lrc) note(shard_scan_enqueue(c, d_shard, n));
     if (!lrc && m && m->kind == 1 && n > 0) {
-        hipLaunchKernelGGL(k_pack_summary, dim3(1), dim3(1), 0, c->stream, (const ChunkState*)c->d_state, (int64_t)n, (int64_t)(capacity - n), m->d_row);
+        hipLaunchKernelGGL(k_pack_summary, dim3(1), dim3(1), 0, c->stream, (const ChunkState*)c->d_state, (int64_t)n, (int64_t)(capacity - n), m->d_row, (int64_t)(me + 1));
         if ((rc = comm_gather(c, nullptr, all.data(), "the all-gather of the shard summaries"))) return rc;
         shard_scan_finish(c, d_shard, n, &sums[(size_t)me]);
     } else {
@@ -606,17 +606,19 @@ int32_t bzq_shard_stitch(bzq_ctx* c, uint8_t* d_shard, uint64_t n, uint64_t capa
             shard_scan_finish(c, d_shard, n, &sums[(size_t)me]);
             const bzq_shard_summary& s = sums[(size_t)me];
             const int64_t r2[COMM_ROW] = {(int64_t)s.n_bytes, (int64_t)s.n_newlines, s.first_nl[0], s.first_nl[1], s.first_nl[2], s.first_nl[3],
-                                          (int64_t)s.first_byte | ((int64_t)s.last_byte << 8), (int64_t)(capacity - n)};
+                                          (int64_t)s.first_byte | ((int64_t)s.last_byte << 8) | ((int64_t)(me + 1) << 16), (int64_t)(capacity - n)};
             memcpy(row, r2, sizeof(row));
         } else {
-            row[6] = (int64_t)(uint32_t)(-lrc) << 32;   // an empty shard that says why
+            row[6] = ((int64_t)(uint32_t)(-lrc) << 32) | ((int64_t)(me + 1) << 16);   // an empty shard that says why
         }
         if ((rc = comm_gather(c, row, all.data(), "the all-gather of the shard summaries"))) return rc;
     }
     if ((rc = everybody_fails(all, 6, 32, "before the shards were exchanged"))) return rc;
     uint64_t stream_pos = 0, total_bytes = 0;
+    c->ranks_seen = 0;   // rows of the all-gather that carry their rank's stamp (bits 16..31 of word 6): what the transport really delivered
     for (int r = 0; r < P; ++r) {
         const int64_t* w = &all[(size_t)r * COMM_ROW];
+        if (((w[6] >> 16) & 0xFFFF) == r + 1) c->ranks_seen += 1;
         bzq_shard_summary& s = sums[(size_t)r];
         s.n_bytes = (uint64_t)w[0]; s.n_newlines = (uint64_t)w[1];
         for (int i = 0; i < 4; ++i) s.first_nl[i] = w[2 + i];

@@ -50,6 +50,9 @@ def test_bench_sharded_harness_runs_with_real_neighbours(nranks):
     assert abs(out["value"] - total_bytes / (out["ms_per_step"] * 1e-3) / 1e9) <= 0.01 * out["value"] + 0.01
     assert abs(out["mrecords_per_s"] - reads * nranks / (out["ms_per_step"] * 1e-3) / 1e6) <= 0.01 * out["mrecords_per_s"] + 0.01
     assert "cpu_baseline" not in out and "views_mode" not in out   # N = 1 only
+    # the library's own summary all-gather delivered every rank's row, and every rank said where it runs
+    assert out["ranks_seen"] == nranks and len(out["ranks"]) == nranks
+    assert sorted(r["rank"] for r in out["ranks"]) == list(range(nranks)) and all(r["device"] == 0 and r["ranks_seen"] == nranks for r in out["ranks"])
     assert out["roofline"]["frac"] > 0 and out["roofline"]["launches_per_step"] >= 1
 
 
@@ -73,5 +76,6 @@ def test_bench_from_file_mode_shards_one_file_across_the_ranks():
     ff = out["from_file"]
     assert ff and abs(ff["file_gb"] - 3 * reads * out["config"]["record_bytes"] / 1e9) < 1e-3 and ff["reader_threads"] == 3
     assert not os.path.exists(ff["path"])   # removed again
+    assert out["ranks_seen"] == 3 and all(r["reader_threads"] == 3 and r["reader_cpus_bound"] >= 0 for r in out["ranks"])
     total_bytes = reads * 3 * out["config"]["record_bytes"]
     assert abs(out["value"] - total_bytes / (out["ms_per_step"] * 1e-3) / 1e9) <= 0.01 * out["value"] + 0.01
