@@ -2048,7 +2048,8 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
     uint8_t magic[18] = {0};
     const bool gzip_magic = g->file_size >= 18 && pread(fd, magic, 18, 0) == 18 && magic[0] == 0x1f && magic[1] == 0x8b;
     const bool gz_on_device = gzip_magic && !bzq::bgzf_block_size(magic) && gpu_inflate;
-    if (gz_on_device) g->gz_piece = std::max<uint64_t>(g->chunk_bytes / 2, std::min<uint64_t>(g->chunk_bytes, 64ull << 10));   // (the first pieces; then by the file's compression ratio, up to a chunk: gz_fill_fifo)
+    if (gz_on_device) g->gz_piece = std::max<uint64_t>(g->chunk_bytes / 2, std::min<uint64_t>(g->chunk_bytes, 64ull << 10));
+    if (gz_on_device && getenv("BZQ_GZ_PIECE_MIB") && atoll(getenv("BZQ_GZ_PIECE_MIB")) > 0) g->gz_piece = std::min<uint64_t>(g->gz_piece.load(), (uint64_t)atoll(getenv("BZQ_GZ_PIECE_MIB")) << 20);   // (sweeps)   // (the first pieces; then by the file's compression ratio, up to a chunk: gz_fill_fifo)
     bool ok = hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess;
     if (ok) {   // the slots side by side: pinning a chunk-sized buffer takes ~30 ms, and three of them one after the other were most of an open
         bool slot_ok[bzq::INGEST_SLOTS];

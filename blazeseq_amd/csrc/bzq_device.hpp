@@ -755,8 +755,14 @@ static __global__ __launch_bounds__(BLOCK) void k_tail(const uint8_t* __restrict
         int64_t nb = (st->n_complete + batch - 1) / batch;
         if (nb > fin.bb_cap) nb = fin.bb_cap;
         if (nb > fin.h_bb_cap) nb = fin.h_bb_cap;
-        if (fin.h_bb && fin.bb)
-            for (int64_t i = tid; i < 2 * nb; i += BLOCK) fin.h_bb[i] = fin.bb[i];
+        // (16 bytes per lane, a batch's pair: consecutive lanes write consecutive addresses -- the stores cross PCIe, and 8-byte stores
+        // of a strided loop were 8 us of this kernel)
+        if (fin.h_bb && fin.bb) {
+            const uint4* s4 = reinterpret_cast<const uint4*>(fin.bb);
+            uint4* d4 = reinterpret_cast<uint4*>(fin.h_bb);
+            for (int64_t i = tid; i < nb; i += BLOCK) d4[i] = s4[i];
+        }
+        static_assert(sizeof(ChunkState) % 8 == 0, "the state is copied in 8-byte words");
         const u64* src = reinterpret_cast<const u64*>(st);
         u64* dst = reinterpret_cast<u64*>(fin.h_state);
         for (int i = tid; i < (int)(sizeof(ChunkState) / 8); i += BLOCK) dst[i] = src[i];

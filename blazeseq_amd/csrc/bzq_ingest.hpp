@@ -391,6 +391,8 @@ inline bool gz_fill_fifo(bzq_ingest* g, std::string& err) {
             const double ratio = (double)got / (double)want;
             const uint64_t fit = (uint64_t)((double)(g->gz_cap / 2) / (ratio > 1.0 ? ratio : 1.0)) & ~4095ull;
             g->gz_piece = std::min<uint64_t>(g->chunk_bytes, std::max<uint64_t>(fit, std::min<uint64_t>(g->chunk_bytes, 1ull << 20)));
+            static const uint64_t piece_cap = getenv("BZQ_GZ_PIECE_MIB") ? (uint64_t)atoll(getenv("BZQ_GZ_PIECE_MIB")) << 20 : 0;   // sweeps (profiles/r5_gzip_piece_sweep.txt): 0 / unset = no cap
+            if (piece_cap) g->gz_piece = std::min<uint64_t>(g->gz_piece.load(), piece_cap);
         } else if (more && g->gz_piece.load() > (2ull << 20)) g->gz_piece = (g->gz_piece.load() / 2) & ~4095ull;
         g->gz_more = more != 0;
         g->gz_done = (file_done && !more) || g->gz_dev->finished;
