@@ -34,8 +34,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # but READ from the committed rocprofv3 summary of this very command (scripts/gpu_profile.sh -> profiles/<tag>_summary.txt),
 # so the number printed is by construction the one in the cited file (tests/test_bench_contract.py pins the parse).
 # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md (HBM section).
-TRAFFIC_PROFILE = "profiles/r4_fold_summary.txt"
-TRAFFIC_KERNEL = "k_fused<false, false, false, false, true>"
+TRAFFIC_PROFILE = "profiles/r5_final_summary.txt"
+TRAFFIC_KERNEL = "k_fused<false, false, false, false, true>"   # the default emit (per-batch ends folded in); a run without the fold cites the other instantiation
+TRAFFIC_KERNEL_UNFOLDED = "k_fused<false, false, false, false>"
 TRAFFIC_RECORDS = 10_000_000   # the profiled launch: 10 M x 150 bp
 
 
@@ -75,19 +76,19 @@ def profile_kernel_avg_ms(path=TRAFFIC_PROFILE, kernel=TRAFFIC_KERNEL):
 TRAFFIC_MAX_DRIFT = 0.10   # the cited profile must be of THIS kernel: its average launch time within 10 % of this run's
 
 
-def measured_traffic_bytes_per_record(run_avg_launch_ms=None):
+def measured_traffic_bytes_per_record(run_avg_launch_ms=None, kernel=TRAFFIC_KERNEL):
     """Bytes per record from the cited profile, or (None, why) when the profile is missing or stale: a kernel that changed
     since it was profiled runs at a different speed, and its old traffic figure must not be printed beside the new time."""
-    t = profile_traffic()
+    t = profile_traffic(kernel=kernel)
     if t is None:
-        return None, f"{TRAFFIC_PROFILE} is missing or holds no FETCH_SIZE / WRITE_SIZE for {TRAFFIC_KERNEL}"
+        return None, f"{TRAFFIC_PROFILE} is missing or holds no FETCH_SIZE / WRITE_SIZE for {kernel}"
     if run_avg_launch_ms is not None:
-        prof_ms = profile_kernel_avg_ms()
+        prof_ms = profile_kernel_avg_ms(kernel=kernel)
         if prof_ms is None:
-            return None, f"{TRAFFIC_PROFILE} holds no kernel-trace duration for {TRAFFIC_KERNEL}"
+            return None, f"{TRAFFIC_PROFILE} holds no kernel-trace duration for {kernel}"
         drift = abs(prof_ms - run_avg_launch_ms) / run_avg_launch_ms
         if drift > TRAFFIC_MAX_DRIFT:
-            return None, (f"stale profile: {TRAFFIC_KERNEL} averages {prof_ms:.4f} ms in {TRAFFIC_PROFILE} but {run_avg_launch_ms:.4f} ms in this run "
+            return None, (f"stale profile: {kernel} averages {prof_ms:.4f} ms in {TRAFFIC_PROFILE} but {run_avg_launch_ms:.4f} ms in this run "
                           f"({drift * 100:.0f} % apart, limit {TRAFFIC_MAX_DRIFT * 100:.0f} %): re-profile (scripts/gpu_profile.sh)")
     return (2 * t[0] + t[1]) * 1024 / TRAFFIC_RECORDS, None
 
@@ -1001,7 +1002,7 @@ def main():
                 # Only quoted for the profiled configuration (150 bp, validation off, two-pass default).
                 "traffic": None,   # filled in below, for the profiled configuration only
                 "traffic_unit": "GB per launch",
-                "traffic_source": f"{TRAFFIC_PROFILE}: {TRAFFIC_KERNEL} FETCH_SIZE*2 + WRITE_SIZE (KiB), scaled per record; read from the file at run time, not measured in this run; "
+                "traffic_source": f"{TRAFFIC_PROFILE}: {TRAFFIC_KERNEL if folded else TRAFFIC_KERNEL_UNFOLDED} FETCH_SIZE*2 + WRITE_SIZE (KiB), scaled per record; read from the file at run time, not measured in this run; "
                                   f"withheld when the file's kernel-trace duration of that kernel is more than {int(TRAFFIC_MAX_DRIFT * 100)} % from this run's avg_launch_ms",
                 "algorithmic_gb_per_launch": round(dom_bytes / 1e9, 3),
                 "algorithmic_bytes_per_record": round(dom_bytes / max(1, recs), 1),
@@ -1022,7 +1023,7 @@ def main():
         profiled_config = (args.read_len == 150 and not args.long_reads and not args.views and not args.validate and not args.stream
                            and not args.single_pass and not args.service and not args.hier and not args.kernels_v1)
         if profiled_config:
-            bpr, why = measured_traffic_bytes_per_record(out["roofline"]["avg_launch_ms"])
+            bpr, why = measured_traffic_bytes_per_record(out["roofline"]["avg_launch_ms"], TRAFFIC_KERNEL if folded else TRAFFIC_KERNEL_UNFOLDED)
             if bpr is not None:
                 out["roofline"]["traffic"] = round(bpr * per_rank_records / 1e9, 3)
             else:

@@ -15,6 +15,7 @@
 #include "bzq_stream.hpp"   // k_stream: one read of the input with super-tiles staged in registers (correct, 2x slower: profiles/r2_single_read.md)
 #endif
 #include "bzq_views.hpp"
+#include "bzq_bufcache.hpp"
 
 #include <algorithm>
 #include <cstdio>
@@ -241,6 +242,11 @@ int ensure(bzq_ctx* c, DevBuf& b, size_t bytes) {
     if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     size_t want = bytes + 256;
     hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {   // the library's own buffer cache may be what is in the way (bzq_bufcache.hpp): give it back, once
+        (void)hipGetLastError();
+        bzq::cache::device_pool().trim(0, true);
+        e = hipMalloc(&b.p, want);
+    }
     if (e != hipSuccess) {
         c->err = "hipMalloc(" + std::to_string(want) + "): " + hipGetErrorString(e);
         b.p = nullptr;
@@ -975,7 +981,6 @@ void sb_put(std::string& s, const char* label, long long v) {
 #if BZQ_EXPERIMENTS
 #include "bzq_inflate_ms.hpp"   // experiments/csrc: eight BGZF blocks per wave (correct, 2.7x slower: profiles/r4_inflate_ms.md)
 #endif
-#include "bzq_bufcache.hpp"
 #include "bzq_gzip.hpp"
 #include "bzq_ingest.hpp"
 

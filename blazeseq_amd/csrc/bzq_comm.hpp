@@ -161,6 +161,7 @@ int comm_stream_wait(bzq_ctx* c, bzq_comm* m, uint64_t want, const char* what) {
 int comm_gather(bzq_ctx* c, const int64_t* row, int64_t* all, const char* what = "an all-gather") {
     bzq_comm* m = c->comm;
     if (!m) { if (row) memcpy(all, row, COMM_ROW * 8); return 0; }
+    if (m->kind == 1 && !m->nccl) { c->err = std::string(what) + ": the communicator was taken down after an exchange timed out (bzq_comm_destroy + bzq_comm_init to start over)"; return BZQ_ERR_IO; }
     if (m->kind == 1) {
         if (row) {
             memcpy(m->h_row, row, COMM_ROW * 8);
@@ -408,6 +409,7 @@ int comm_exchange_heads(bzq_ctx* c, bzq_comm* m, uint8_t* d_shard, uint64_t n, c
     const Plan& pl = plans[(size_t)me];
     auto note_hip = [&](hipError_t e, const char* what) { if (e != hipSuccess && !lrc) { lrc = BZQ_ERR_HIP; lerr = std::string(what) + ": " + hipGetErrorString(e); } };
     int rc;
+    if (m->kind == 1 && !m->nccl) { c->err = "the exchange of the shard heads: the communicator was taken down after an exchange timed out"; return BZQ_ERR_IO; }
     if (m->kind == 1) {
         auto nccl_note = [&](int r, const char* what) { if (r != 0 && !lrc) { lrc = BZQ_ERR_HIP; lerr = std::string(what) + ": " + (m->p_GetErrorString ? m->p_GetErrorString(r) : "RCCL error"); } return r; };
         const uint64_t want = comm_arrive(m);
