@@ -46,7 +46,7 @@ using inf::uni;
 
 constexpr int WAVES = BLOCK / 64;
 constexpr int PAGE_SHIFT = 16;
-constexpr int PAGE = 1 << PAGE_SHIFT;      // symbols per page (128 KiB of pool)
+constexpr int PAGE = 1 << PAGE_SHIFT;      // symbols per page (128 KiB of pool).  (Every decoder wave leaves its last page partly used: ~2.3 pages of output round up to 3, so the pool is ~24 x the compressed bytes at 16 KiB per wave.  Pages of 32768 symbols -- the window's size, the smallest that keeps a back reference in the current page or the one before it -- were tried in round 5 and are NOT a drop-in: members then fail their CRC)
 constexpr u64 POS_NONE = ~0ull;
 constexpr uint32_t NO_PAGE = 0xFFFFFFFFu;
 constexpr int MAX_PASSED = 4;              // candidates a decoder may pass over before it gives up (a decoder fed garbage passes them all)
@@ -1518,11 +1518,11 @@ inline uint32_t crc_xpow8(uint64_t n) {   // x^(8 n) mod P
         if (e_ != hipSuccess) return bzq::gz::gz_fail((h), BZQ_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-inline int gz_ensure(bzq_gzip* h, bzq_gzip::Buf& b, size_t bytes, bool pinned = false) {
+inline int gz_ensure(bzq_gzip* h, bzq_gzip::Buf& b, size_t bytes, bool pinned = false, int slack_shift = 2) {
     if (bytes <= b.cap) return 0;
     bzq::cache::Pool& pool = pinned ? bzq::cache::pinned_pool() : bzq::cache::device_pool();   // (bzq_bufcache.hpp: the buffers of a decoder outlive it)
     if (b.p) { GZCHK(h, hipDeviceSynchronize()); pool.put(b.p); b.p = nullptr; b.cap = 0; }
-    const size_t want = bytes + bytes / 4 + 256;
+    const size_t want = bytes + (bytes >> slack_shift) + 256;   // (room to grow without a new allocation: a quarter; the symbol pool, gigabytes, a sixteenth)
     const hipError_t e = pool.get(h->device, want, &b.p);
     if (e != hipSuccess) { b.p = nullptr; (void)hipGetLastError(); return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: cannot allocate " + std::to_string(want) + " bytes"); }
     b.cap = want;
@@ -1883,7 +1883,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     Args a{};
     for (int attempt = 0;; ++attempt) {
         const uint32_t pages_now = predecoded && attempt == 0 ? h->pre.pool_pages : h->pool_pages;
-        if (!(predecoded && attempt == 0) && ((rc = gz_ensure(h, pool, ((size_t)h->pool_pages << PAGE_SHIFT) * 2)) || (rc = gz_ensure(h, d_page_next, (size_t)h->pool_pages * 4)))) return rc;
+        if (!(predecoded && attempt == 0) && ((rc = gz_ensure(h, pool, ((size_t)h->pool_pages << PAGE_SHIFT) * 2, false, 4)) || (rc = gz_ensure(h, d_page_next, (size_t)h->pool_pages * 4)))) return rc;
         const Job j0{h->start_pos, 1, 0};
         if (!(predecoded && attempt == 0)) GZCHK(h, hipMemsetAsync(counters.p, 0, 128, s));
         static const uint32_t counting = getenv("BZQ_GZ_COUNT") ? (uint32_t)atoi(getenv("BZQ_GZ_COUNT")) : 0u;   // debug: 1 = survivor / hand-back counts (atomics in the loops: not for timing), 2 = the finder's clocks
@@ -1914,7 +1914,9 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         if (counting) fprintf(stderr, "bzq_gzip finder: %u positions passed the 13-bit filter, %u of them the code length code test, %u of those one lane's look at the code lengths (judged by the whole wave)\n", h_counters[3], h_counters[4], h_counters[5]);
         if (h_counters[0] <= pages_now) break;
         if (attempt == 8) return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: the symbol pool keeps overflowing (" + std::to_string(h->pool_pages) + " pages)");
-        h->pool_pages = std::max<uint32_t>(2u * std::max(h->pool_pages, pages_now), h_counters[0] + (uint32_t)n_chunks);   // (counts the refused requests too)
+        // (h_counters[0] counts the refused requests too, but a job that was refused a page stopped there: what it would still have asked
+        // for is unknown -- a quarter on top, and a page per job; doubling, as rounds 3-4 did, made a 4 GiB pool an 8 GiB one for good)
+        h->pool_pages = std::max<uint32_t>(std::max(h->pool_pages, pages_now) + std::max(h->pool_pages, pages_now) / 4u, h_counters[0] + (uint32_t)n_chunks);
         h->stats.pool_retries += 1;
     }
 
@@ -2024,7 +2026,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
                 const uint32_t maxev2 = (uint32_t)std::min<uint64_t>(nn / 18 + (uint64_t)nch2 + 64, 1u << 28);
                 const uint32_t want2 = (uint32_t)std::min<uint64_t>((nn * 5) >> PAGE_SHIFT, 1u << 24) + 2u * (uint32_t)nch2 + 64u;
                 if (h->pool_pages < want2) h->pool_pages = want2;
-                if ((rc = gz_ensure(h, h->pool_[pn], ((size_t)h->pool_pages << PAGE_SHIFT) * 2)) || (rc = gz_ensure(h, h->page_next_[pn], (size_t)h->pool_pages * 4)) ||
+                if ((rc = gz_ensure(h, h->pool_[pn], ((size_t)h->pool_pages << PAGE_SHIFT) * 2, false, 4)) || (rc = gz_ensure(h, h->page_next_[pn], (size_t)h->pool_pages * 4)) ||
                     (rc = gz_ensure(h, h->outs_[pn], (size_t)ncap2 * sizeof(JobOut))) || (rc = gz_ensure(h, h->events_[pn], (size_t)maxev2 * sizeof(Event))) ||
                     (rc = gz_ensure(h, h->h_outs_[pn], (size_t)ncap2 * sizeof(JobOut) + 128, true)))
                     return rc;
