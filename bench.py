@@ -255,9 +255,10 @@ def ingest_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, chu
     tag = f"bzq_bench_{os.getpid()}"
     paths = {m: os.path.join(d, f"{tag}.fastq{ext}") for m, ext in (("plain", ""), ("bgzf", ".bgz"), ("gzip", ".gz"))}
     res = {"file_fastq_gb": round(n_fastq / 1e9, 3), "records": n_rec, "reader_threads": threads, "chunk_mib": chunk_mib, "dir": d,
-           "note": "wall clock of open + every chunk until EOF + close.  value = best of 3 runs after the process's first one: the pinned and device chunk buffers of a "
-                   "closed file stay in the library's cache for the next open (bzq_bufcache.hpp; a host that parses file after file); first_file_of_the_process = a run "
-                   "with the cache empty (~40 ms of pinning at the open); every figure after one untimed pass over the file, like the reference's warm-up runs; "
+           "note": "wall clock of open + every chunk until EOF + close.  TWO figures per file kind, side by side: value_first_file_of_the_process = a run with the library's "
+                   "buffer cache empty (what a one-file process gets; whole processes: process_mode) and value = best of 3 runs after it with the cache told to keep a "
+                   ".gz stream's buffers too (options pin_cache_bytes = 2 GiB, dev_cache_bytes = 16 GiB: a host that parses file after file; the library's default keeps one "
+                   "set of chunk buffers, 1 GiB each); every figure after one untimed pass over the file, like the reference's warm-up runs; "
                    "the file sits on a RAM-backed filesystem like the reference's runs; pcie_frac = bytes that crossed PCIe / s / 64 GB/s"}
     try:
         co = zlib.compressobj(6, zlib.DEFLATED, -15)
@@ -280,9 +281,11 @@ def ingest_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, chu
             best = first = None
             for it in range(5):
                 if it == 1:   # run 1 opens like the first file of a process (run 0, not reported, is the file's first read: a freshly written tmpfs file reads 3x slower once)
-                    for key, dflt in (("pin_cache_bytes", 2 << 30), ("dev_cache_bytes", 8 << 30)):
+                    # ... and from here on like a host that parses file after file and says so: the library's default cache keeps ONE set of
+                    # chunk buffers (1 GiB pinned, 1 GiB device); a .gz stream's pools and FIFOs (~12 GiB) stay cached only if asked for
+                    for key, val in (("pin_cache_bytes", 2 << 30), ("dev_cache_bytes", 16 << 30)):
                         ctx.set_option(key, 0)
-                        ctx.set_option(key, dflt)
+                        ctx.set_option(key, val)
                 t0 = time.perf_counter()
                 ing = B.Ingest(ctx, paths[m], chunk_bytes=chunk_mib << 20, n_threads=threads)
                 t1 = time.perf_counter()
@@ -307,11 +310,15 @@ def ingest_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, chu
                     first = run
                 elif it > 1 and (best is None or dt < best[0]):
                     best = run
-            res[m] = {"value": round(n_fastq / best[0] / 1e9, 2), "unit": "GB/s of FASTQ", "mrecords_per_s": round(n_rec / best[0] / 1e6, 1),
+            res[m] = {"value": round(n_fastq / best[0] / 1e9, 2), "value_first_file_of_the_process": round(n_fastq / first[0] / 1e9, 2),
+                      "unit": "GB/s of FASTQ", "mrecords_per_s": round(n_rec / best[0] / 1e6, 1),
                       "ms": round(best[0] * 1e3, 1), "open_ms": round(best[1] * 1e3, 1), "close_ms": round(best[2] * 1e3, 1), "file_gb": round(fsize / 1e9, 3),
                       "pcie_frac": round(fsize / best[0] / 1e9 / PCIE_PEAK_GBS, 3),
                       "first_file_of_the_process": {"value": round(n_fastq / first[0] / 1e9, 2), "ms": round(first[0] * 1e3, 1), "open_ms": round(first[1] * 1e3, 1),
                                                     "close_ms": round(first[2] * 1e3, 1)}}
+        for key in ("pin_cache_bytes", "dev_cache_bytes"):   # (give the cached buffers back, and the library's default limits again)
+            ctx.set_option(key, 0)
+            ctx.set_option(key, 1 << 30)
         ctx.close()
         # the reference algorithm on one host core, same files: plain = read + streaming parse; .gz = zlib inflate (GZFile) + parse on a bounded sample
         cfg = O.make_config(buffer_capacity=64 * 1024, batch_size=4096)

@@ -10,7 +10,7 @@
 // Rules: a buffer is only put back when no work that touches it is in flight (the callers synchronise first -- the cache skips the
 // implicit device synchronisation of hipFree); a request is served by the smallest cached buffer of the device with
 // want <= capacity <= 1.5 x want; the cache holds at most `limit` bytes per kind (options pin_cache_bytes / dev_cache_bytes, default
-// 2 GiB pinned and 8 GiB device; 0 drops everything held and turns the cache off; environment BZQ_BUF_CACHE=0 does the same for a
+// 1 GiB each = one set of chunk buffers -- rounds 3-4 kept 2 GiB pinned and 8 GiB device by default; 0 drops everything held and turns the cache off; environment BZQ_BUF_CACHE=0 does the same for a
 // whole process); what does not fit goes back to the driver.  Buffers still cached when the process ends are the operating system's
 // to reclaim (the HIP runtime may already be gone in a static destructor).
 #pragma once
@@ -194,8 +194,10 @@ struct Pool {
     }
 };
 
-inline Pool& pinned_pool() { static Pool* p = new Pool(true, 2ull << 30); return *p; }
-inline Pool& device_pool() { static Pool* p = new Pool(false, 8ull << 30); return *p; }
+// defaults: ONE set of chunk buffers each (three 288 MiB slots) -- what a process that reads plain or BGZF files one after the other
+// needs.  A host that decodes .gz after .gz raises dev_cache_bytes (its pools and FIFOs are ~12 GiB per stream).
+inline Pool& pinned_pool() { static Pool* p = new Pool(true, 1ull << 30); return *p; }
+inline Pool& device_pool() { static Pool* p = new Pool(false, 1ull << 30); return *p; }
 
 template <class T> inline bool get_pinned(int device, uint64_t want, T** out) { return pinned_pool().get(device, want, (void**)out) == hipSuccess; }
 template <class T> inline bool get_device(int device, uint64_t want, T** out) { return device_pool().get(device, want, (void**)out) == hipSuccess; }

@@ -388,3 +388,47 @@ def test_the_next_piece_under_this_one(early_find, predecode):
         g.dec.set_option("far_kib", 64)
         assert g.decode(comp, piece, ahead=ahead) == data, (early_find, predecode, piece, cap, ahead)
         g.close()
+
+
+def test_device_memory_a_gz_stream_holds():
+    """'bound the gzip pool ... with a test that asserts the hipMemGetInfo delta'.  A .gz stream's device memory scales with
+    chunk_bytes (symbol pools ~ 24-27 x the compressed piece, twice; FIFOs 6 x chunk_bytes, twice; three slots; the parser's own
+    arenas): 5.6 GiB at 64 MiB chunks, 13.2 GiB at the default 256 MiB -- the 4 GiB VERDICT asked for is NOT met at the default (it costs a
+    third of the rate, profiles/r5_gzip_piece_sweep.txt); what is pinned here is that the footprint is what INTEGRATION.md says and
+    does not double any more when a piece overflows the pool (round 4: 4 GiB -> 8 GiB for good).  Measured with the library's buffer cache off, after the whole file has been decoded."""
+    import torch
+    import blazeseq_amd as B
+    from blazeseq_amd import _lib as L
+    data = synthetic_fastq(2_600_000)   # 0.83 GB of FASTQ
+    path = "/dev/shm/bzq_footprint_test.fastq.gz" if os.path.isdir("/dev/shm") else "/tmp/bzq_footprint_test.fastq.gz"
+    k = 32 << 20
+    with open(path, "wb") as f:
+        for i in range(0, len(data), k):
+            f.write(gzip_member(data[i:i + k], 6))
+    try:
+        ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
+        for key in ("pin_cache_bytes", "dev_cache_bytes"):
+            ctx.set_option(key, 0)
+        for chunk_mib, limit_gib in ((64, 6.5), (256, 15.0)):   # measured 5.62 / 13.24 GiB (round 5), parser arenas included
+            torch.cuda.synchronize()
+            free0, _ = torch.cuda.mem_get_info()
+            ing = B.Ingest(ctx, path, chunk_bytes=chunk_mib << 20, n_threads=4)
+            taken = total = 0
+            low = free0
+            while True:
+                r = ing.next(taken)
+                taken = int(r.n_records); total += taken
+                low = min(low, torch.cuda.mem_get_info()[0])
+                if int(r.status) != L.OK:
+                    break
+            assert total == 2_600_000 and int(r.status) == L.EOF
+            held = (free0 - low) / 2**30
+            ing.close()
+            torch.cuda.synchronize()
+            assert held <= limit_gib, f"chunk {chunk_mib} MiB: the stream held {held:.2f} GiB of device memory (limit {limit_gib})"
+            print(f"chunk {chunk_mib} MiB: {held:.2f} GiB")
+        for key in ("pin_cache_bytes", "dev_cache_bytes"):
+            ctx.set_option(key, 1 << 30)
+        ctx.close()
+    finally:
+        os.remove(path)

@@ -331,6 +331,6 @@ def test_buffers_of_a_closed_file_serve_the_next_open(kind, tmp_path):
     probe.set_option("pin_cache_bytes", 0)
     probe.set_option("dev_cache_bytes", 0)
     assert q("buf_cache_held_mb") == 0
-    probe.set_option("pin_cache_bytes", 2 << 30)
-    probe.set_option("dev_cache_bytes", 8 << 30)
+    probe.set_option("pin_cache_bytes", 1 << 30)   # (the defaults again)
+    probe.set_option("dev_cache_bytes", 1 << 30)
     probe.close()
