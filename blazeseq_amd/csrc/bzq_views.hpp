@@ -49,6 +49,10 @@ struct ViewArgs {
 constexpr uint32_t ENT_SAT = 127u;
 constexpr int ENT_STRIDE = 1024;   // entries per ordinary tile; slot 1023 of tile 0 describes the line that starts the chunk
 constexpr int MAXE = 1020;         // a tile with more newlines (records of a few bytes) takes a 16384-entry slot of the pool
+// tile_idc of a tile whose entries are NARROW: 16 bits each -- position and the two structure bits, i.e. the low half of an entry -- because
+// none of them has anything in its upper half (no id space at a line's edge, no validation).  Ordinary reads: every tile.  Both
+// forms end at the same byte of the slot (4 MAXE), so the join's speculative loads do not depend on the form.
+constexpr u64 ENT_NARROW = 1ull << 63;
 
 struct LineArgs {
     const uint8_t* g;
@@ -121,6 +125,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_w[BLOCK / 64];
     __shared__ int64_t s_slot;
     __shared__ uint32_t s_ent[ENT_STRIDE];
+    __shared__ int s_wide;
     uint8_t* s_tile = s_tile_raw + HALO;
     const uint32_t* raw32 = reinterpret_cast<const uint32_t*>(s_tile_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -164,7 +169,7 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
     for (;;) {
         const int64_t t0 = t * TILE;
         const int valid = (int)((a.n - t0) < TILE ? (a.n - t0) : TILE);
-        if (tid == 0) *reinterpret_cast<uint4*>(s_tile_raw) = halo;
+        if (tid == 0) { *reinterpret_cast<uint4*>(s_tile_raw) = halo; s_wide = VAL ? 1 : 0; }
         else if (tid == 64) *reinterpret_cast<uint4*>(s_tile + TILE) = halo;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -225,16 +230,19 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
             slot = s_slot;
         }
         if (tid == 0) {
-            a.tile_c[t] = c; a.tile_a[t] = 0ull; a.tile_idc[t] = slot >= 0 ? (u64)(slot + 1) : 0ull;
+            a.tile_c[t] = c; a.tile_a[t] = 0ull;
+            if (slot != -1) a.tile_idc[t] = slot >= 0 ? (u64)(slot + 1) : 0ull;   // (an ordinary tile says below which form its entries have)
             if (t == 0) a.entries[ENT_STRIDE - 1] = around(-1) & 0x00FFC000u;   // the line that starts the chunk: its first byte and leading spaces
         }
         if (slot == -1) {
-            // ordinary tile: the entries end at the END of the tile's slot (entry j of c at slot[MAXE - c + j]) -- the join then
-            // finds the tile's LAST entries at fixed addresses without knowing c.  They go out through LDS: every wave gathers
-            // its own (its newlines are a contiguous run of the tile's), then stores them as one contiguous stretch.
+            // ordinary tile: the entries end at the END of the tile's slot (entry j of c at word MAXE - c + j, or at halfword
+            // 2 MAXE - c + j in the narrow form) -- the join then finds the tile's LAST entries at fixed addresses without knowing c.
+            // They go out through LDS: every wave gathers its own (its newlines are a contiguous run of the tile's), the tile
+            // agrees on the form, and every wave stores its run as one contiguous stretch.
             uint32_t* sl = s_ent + (excl - (incl - cnt));   // this wave's run starts at its exclusive base
             u64 m = m64;
             uint32_t k = incl - cnt;                        // index inside the wave's run
+            uint32_t upper = 0;
             while (m) {
                 const int bit = __builtin_ctzll(m);
                 m &= m - 1;
@@ -242,14 +250,22 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
                 uint32_t e = (uint32_t)pos | around(pos);
                 if (VAL) e |= ((uint32_t)((na_before >> bit) & 1ull) << 23) | ((uint32_t)((or_before >> bit) & 1ull) << 31);
                 sl[k] = e;
+                upper |= e >> 16;
                 ++k;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            if (!VAL && upper) s_wide = 1;
+            __syncthreads();
+            const bool narrow = s_wide == 0;
+            if (tid == 0) a.tile_idc[t] = narrow ? ENT_NARROW : 0ull;
             const uint32_t wbase = excl - (incl - cnt);
             const uint32_t wcnt = wave == 0 ? wc.x : wave == 1 ? wc.y : wave == 2 ? wc.z : wc.w;
-            uint32_t* out = a.entries + t * ENT_STRIDE + (MAXE - (int)c) + wbase;
-            for (uint32_t j = lane; j < wcnt; j += 64) out[j] = s_ent[wbase + j];
+            if (narrow) {
+                uint16_t* out = reinterpret_cast<uint16_t*>(a.entries + t * ENT_STRIDE) + (2 * MAXE - (int)c) + wbase;
+                for (uint32_t j = lane; j < wcnt; j += 64) out[j] = (uint16_t)s_ent[wbase + j];
+            } else {
+                uint32_t* out = a.entries + t * ENT_STRIDE + (MAXE - (int)c) + wbase;
+                for (uint32_t j = lane; j < wcnt; j += 64) out[j] = s_ent[wbase + j];
+            }
         } else if (slot >= 0) {   // a tile of tiny records: straight into its pool slot, from the slot's start
             uint32_t* out = a.pool + slot * TILE;
             u64 m = m64;
@@ -325,7 +341,7 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
 #pragma unroll
     for (int k = 0; k < JOIN_TILES; ++k) {
         P[k] = k < nt ? a.tileP[ta + k] : 0;
-        slots |= k < nt ? a.tile_slot[ta + k] : 0ull;
+        slots |= k < nt ? (a.tile_slot[ta + k] & ~ENT_NARROW) : 0ull;   // (anything but the form bit: a pool tile)
     }
     const int64_t Pend = a.tileP[tb - 1] + (int64_t)a.tile_c[tb - 1];
 #pragma unroll
@@ -337,7 +353,7 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
     const int64_t P0 = a.st->P0, lines = a.st->P;             // P0 + all newlines of the chunk
     const int64_t Gbeg = P[0], Gend = Pend;                   // newline indices [Gbeg, Gend) live in this window
     // the four newlines before the window are the last four of tile ta - 1 when that tile has that many
-    const bool prev_ok = slot_prev == 0ull && Gbeg - Pprev >= 4;
+    const bool prev_ok = (slot_prev & ~ENT_NARROW) == 0ull && Gbeg - Pprev >= 4;
     const bool staged = slots == 0ull && Gend - Gbeg <= JOIN_ENT;
     u64 e_struct = ~0ull, e_buf = ~0ull, e_valid = ~0ull;
     bool overflow = false;
@@ -345,19 +361,35 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
 
     // ---- the window's entries into LDS, in newline order: s_e[4 + (G - Gbeg)]
     if (staged) {
-        if (tid == 0) *reinterpret_cast<uint4*>(s_e) = l4;
+        if (tid == 0) {   // (the last four entries of the tile before the window: its slot's last 16 bytes hold them in either form)
+            if (slot_prev & ENT_NARROW) l4 = make_uint4(l4.z & 0xFFFFu, l4.z >> 16, l4.w & 0xFFFFu, l4.w >> 16);
+            *reinterpret_cast<uint4*>(s_e) = l4;
+        }
         if (wave < nt) {
             const int64_t Pw = wave == 0 ? P[0] : wave == 1 ? P[1] : wave == 2 ? P[2] : P[3];
             const int64_t Pn = wave == 0 ? P[1] : wave == 1 ? P[2] : wave == 2 ? P[3] : P[4];
             const int cw = (int)(Pn - Pw);
             uint32_t* dst = s_e + 4 + (int)(Pw - Gbeg);
-            const int j = cw - 256 + 4 * lane;   // the speculative load took entries cw - 256 .. cw - 1
-            if (j >= 0) dst[j] = spec.x;
-            if (j + 1 >= 0) dst[j + 1] = spec.y;
-            if (j + 2 >= 0) dst[j + 2] = spec.z;
-            if (j + 3 >= 0) dst[j + 3] = spec.w;
-            const uint32_t* src = a.entries + (ta + wave) * ENT_STRIDE + (MAXE - cw);
-            for (int jj = lane; jj < cw - 256; jj += 64) dst[jj] = src[jj];   // (a tile of short records)
+            const u64 form = a.tile_slot[ta + wave];   // (scalar; it came back with the prefixes)
+            if (form & ENT_NARROW) {   // 16 bits per entry: the speculative load took entries cw - 512 .. cw - 1, eight per lane
+                const int j = cw - 512 + 8 * lane;
+                const uint32_t w4[4] = {spec.x, spec.y, spec.z, spec.w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (j + 2 * u >= 0) dst[j + 2 * u] = w4[u] & 0xFFFFu;
+                    if (j + 2 * u + 1 >= 0) dst[j + 2 * u + 1] = w4[u] >> 16;
+                }
+                const uint16_t* src = reinterpret_cast<const uint16_t*>(a.entries + (ta + wave) * ENT_STRIDE) + (2 * MAXE - cw);
+                for (int jj = lane; jj < cw - 512; jj += 64) dst[jj] = src[jj];   // (a tile of short records)
+            } else {
+                const int j = cw - 256 + 4 * lane;   // the speculative load took entries cw - 256 .. cw - 1
+                if (j >= 0) dst[j] = spec.x;
+                if (j + 1 >= 0) dst[j + 1] = spec.y;
+                if (j + 2 >= 0) dst[j + 2] = spec.z;
+                if (j + 3 >= 0) dst[j + 3] = spec.w;
+                const uint32_t* src = a.entries + (ta + wave) * ENT_STRIDE + (MAXE - cw);
+                for (int jj = lane; jj < cw - 256; jj += 64) dst[jj] = src[jj];   // (a tile of short records)
+            }
         }
         __syncthreads();
     }
@@ -370,7 +402,8 @@ static __global__ __launch_bounds__(BLOCK) void k_views_join(JoinArgs a) {
         while (a.tileP[tt] > G) --tt;
         const int64_t j = G - a.tileP[tt];
         const u64 slot = a.tile_slot[tt];
-        e = slot ? a.pool[(int64_t)(slot - 1) * TILE + j] : a.entries[tt * ENT_STRIDE + (MAXE - (int64_t)a.tile_c[tt]) + j];
+        if (slot & ENT_NARROW) e = reinterpret_cast<const uint16_t*>(a.entries + tt * ENT_STRIDE)[2 * MAXE - (int64_t)a.tile_c[tt] + j];
+        else e = slot ? a.pool[(int64_t)(slot - 1) * TILE + j] : a.entries[tt * ENT_STRIDE + (MAXE - (int64_t)a.tile_c[tt]) + j];
         loc_tile = tt;
         return tt * TILE + (int64_t)(e & 0x3FFFu);
     };
