@@ -778,6 +778,9 @@ def main():
         assert shard.data_ptr() % 16 == 0 and shard.numel() >= n + slack
     torch.cuda.synchronize()
 
+    if args.ingest_only:   # (sweeps of --ingest-chunk-mib / --ingest-threads: only the file -> records figures)
+        print(json.dumps({"ingest_mode": ingest_mode(shard, rec_bytes, dev, local_rank, threads=args.ingest_threads, chunk_mib=args.ingest_chunk_mib)}))
+        return
     exchange = None
     if sharded_mode:
         exchange = args.exchange

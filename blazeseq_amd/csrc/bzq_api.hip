@@ -2090,8 +2090,10 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
         } else if (gpu_inflate) {   // any other gzip file: rapidgzip's two-stage decode on the device (bzq_gzip.hpp)
             g->compression = 1;
             g->gz_cap = std::max<uint64_t>(6 * g->chunk_bytes, 64ull << 20);
+            if (const char* e = getenv("BZQ_GZ_FIFO_KIB"))   // tests: a FIFO of a few chunks, so that small files walk through its wrap-around (never below 3 chunks)
+                g->gz_cap = std::max<uint64_t>(3 * g->chunk_bytes, (uint64_t)atoll(e) << 10);
             int grc = bzq::gz::gz_open(device, &g->gz_dev, err);
-            if (!grc && (!bzq::cache::get_device(device, g->gz_cap + 64, &g->gz_fifo[0]) || !bzq::cache::get_device(device, g->gz_cap + 64, &g->gz_fifo[1]))) {
+            if (!grc && !bzq::cache::get_device(device, g->gz_cap + 64, &g->gz_fifo)) {
                 err = std::string(who) + ": allocating the gzip FIFO failed"; grc = BZQ_ERR_NOMEM;
             }
             if (grc) { bzq::ingest_free(g); return grc; }

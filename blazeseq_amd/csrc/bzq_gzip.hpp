@@ -1518,6 +1518,18 @@ inline uint32_t crc_xpow8(uint64_t n) {   // x^(8 n) mod P
         if (e_ != hipSuccess) return bzq::gz::gz_fail((h), BZQ_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+// Pages of the symbol pool a piece of n compressed bytes in n_chunks decoder jobs can need.  Every job rounds its output up to whole
+// pages, so pages <= output symbols / PAGE + jobs (+ restarts); the unknown is the output: n x the stream's ratio so far (and a quarter
+// on top), or 3 x for a stream's first piece (FASTQ under gzip: 2 - 4).  Rounds 3-5 reserved 5 x AND two pages per job: 3.3 GiB per
+// pool for a 128 MiB piece that uses 1.1 -- twice (two pools), 30-80 ms of hipMalloc per GiB in a fresh process.  A piece that needs more
+// says so (counters[0]: the decoders count what they ask for) and is decoded again with that (gz_decode's attempt loop).
+inline uint32_t pool_want(const bzq_gzip* h, uint64_t n, int n_chunks) {
+    double ratio = 3.0;
+    if (h->stats.bytes_consumed >= (4ull << 20)) ratio = std::max(1.5, 1.25 * (double)h->stats.bytes_out / (double)h->stats.bytes_consumed);
+    const double pages = std::min((double)n * ratio / (double)PAGE, (double)(1u << 24));
+    return (uint32_t)pages + (uint32_t)n_chunks + (uint32_t)MAX_FALLBACK + 64u;
+}
+
 inline int gz_ensure(bzq_gzip* h, bzq_gzip::Buf& b, size_t bytes, bool pinned = false, int slack_shift = 2) {
     if (bytes <= b.cap) return 0;
     bzq::cache::Pool& pool = pinned ? bzq::cache::pinned_pool() : bzq::cache::device_pool();   // (bzq_bufcache.hpp: the buffers of a decoder outlive it)
@@ -1877,7 +1889,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     JobOut* outs = (JobOut*)h_outs.p;
     uint32_t* h_counters = (uint32_t*)((uint8_t*)h_outs.p + (size_t)n_jobs_cap * sizeof(JobOut));
     {
-        const uint32_t want = (uint32_t)std::min<uint64_t>((n * 5) >> PAGE_SHIFT, 1u << 24) + 2u * (uint32_t)n_chunks + 64u;
+        const uint32_t want = pool_want(h, n, n_chunks);
         if (h->pool_pages < want) h->pool_pages = want;
     }
     Args a{};
@@ -2024,7 +2036,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
                 const int pn = pb ^ 1;
                 const int ncap2 = nch2 + MAX_FALLBACK;
                 const uint32_t maxev2 = (uint32_t)std::min<uint64_t>(nn / 18 + (uint64_t)nch2 + 64, 1u << 28);
-                const uint32_t want2 = (uint32_t)std::min<uint64_t>((nn * 5) >> PAGE_SHIFT, 1u << 24) + 2u * (uint32_t)nch2 + 64u;
+                const uint32_t want2 = pool_want(h, nn, nch2);
                 if (h->pool_pages < want2) h->pool_pages = want2;
                 if ((rc = gz_ensure(h, h->pool_[pn], ((size_t)h->pool_pages << PAGE_SHIFT) * 2, false, 4)) || (rc = gz_ensure(h, h->page_next_[pn], (size_t)h->pool_pages * 4)) ||
                     (rc = gz_ensure(h, h->outs_[pn], (size_t)ncap2 * sizeof(JobOut))) || (rc = gz_ensure(h, h->events_[pn], (size_t)maxev2 * sizeof(Event))) ||

@@ -70,9 +70,12 @@ struct bzq_ingest {
     // any other gzip file inflated on the device (bzq_gzip.hpp): the compressed pieces travel through the slot's pinned buffer,
     // the decoder's output collects in a device FIFO (its size per piece is not known beforehand) and leaves chunk by chunk
     bzq_gzip* gz_dev = nullptr;
-    uint8_t* gz_fifo[2] = {};      // the FIFO and the buffer its remainder moves to
-    int gz_cur = 0;
-    uint64_t gz_cap = 0, gz_have = 0, gz_off = 0;   // capacity, bytes waiting, file offset of the next compressed byte
+    // ONE buffer (rounds 3-5 kept a second one of the same size that every chunk's remainder moved to: 1.5 GiB more per open .gz
+    // at the default chunk size, and a copy of up to a piece's output per chunk): chunks leave at gz_head, pieces arrive behind the
+    // bytes that wait; when less than half the buffer is free behind them, what waits -- less than a chunk -- moves to the front
+    uint8_t* gz_fifo = nullptr;
+    uint64_t gz_head = 0;
+    uint64_t gz_cap = 0, gz_have = 0, gz_off = 0;   // capacity, bytes waiting (from gz_head on), file offset of the next compressed byte
     bool gz_more = false, gz_done = false;
     // read-ahead: while piece k is decoded, helper threads read piece k + 1 into the other slot's pinned buffer
     std::atomic<uint64_t> gz_piece{0}; // compressed bytes per piece: starts at half a chunk, then follows the file's compression ratio (gz_fill_fifo)
@@ -357,7 +360,20 @@ inline void gz_read_ahead(bzq_ingest* g) {
 inline bool gz_fill_fifo(bzq_ingest* g, std::string& err) {
     if (!g->gz_reader.joinable() && !g->gz_all_handed && g->gz_rd_ready == 0) g->gz_reader = std::thread(gz_read_ahead, g);
     while (g->gz_have < g->chunk_bytes && !g->gz_done) {
-        const uint64_t free_bytes = g->gz_cap - g->gz_have;
+        if (g->gz_have == 0) g->gz_head = 0;
+        if (g->gz_head && g->gz_cap - g->gz_head - g->gz_have < g->gz_cap / 2) {
+            // what waits moves to the front, on the decoder's stream (behind the chunk copies that read the bytes in front of it, in
+            // front of the kernels that write behind it).  It is less than a chunk and gz_head at least one, so source and
+            // destination do not overlap -- pieces of at most gz_head bytes, front to back, hold for any sizes.
+            for (uint64_t done = 0; done < g->gz_have;) {
+                const uint64_t m = std::min<uint64_t>(g->gz_head, g->gz_have - done);
+                const hipError_t he = hipMemcpyAsync(g->gz_fifo + done, g->gz_fifo + g->gz_head + done, m, hipMemcpyDeviceToDevice, g->gz_dev->stream);
+                if (he != hipSuccess) { err = std::string("gzip: moving the FIFO's bytes to its front: ") + hipGetErrorString(he); return false; }
+                done += m;
+            }
+            g->gz_head = 0;
+        }
+        const uint64_t free_bytes = g->gz_cap - g->gz_head - g->gz_have;
         const uint8_t* src = nullptr;
         uint64_t want = 0;
         bool file_done = g->gz_all_handed, took = false;
@@ -374,7 +390,7 @@ inline bool gz_fill_fifo(bzq_ingest* g, std::string& err) {
         }
         uint64_t got = 0;
         int32_t more = 0;
-        const int drc = bzq::gz::gz_decode(g->gz_dev, src, want, file_done, g->gz_fifo[g->gz_cur] + g->gz_have, free_bytes, &got, &more);
+        const int drc = bzq::gz::gz_decode(g->gz_dev, src, want, file_done, g->gz_fifo + g->gz_head + g->gz_have, free_bytes, &got, &more);
         if (took) {   // the piece's pinned buffer is free (what the decoder keeps of it, it keeps in a copy)
             std::unique_lock<std::mutex> lk(g->gz_mu);
             g->gz_rd_taken += 1;
@@ -462,12 +478,9 @@ inline void ingest_producer(bzq_ingest* g) {
             he = g->dev_free_valid[b] ? hipStreamWaitEvent(cs, g->dev_free[b], 0) : hipSuccess;
         }
         if (he != hipSuccess) return fail("reader: hipStreamWaitEvent", he);
-        if (g->gz_dev) {   // the chunk leaves the FIFO, what is left moves to the front of the other buffer
-            uint8_t* from = g->gz_fifo[g->gz_cur];
-            if (len && (he = hipMemcpyAsync(s.dev + g->reserve, from, len, hipMemcpyDeviceToDevice, cs)) != hipSuccess) return fail("reader: FIFO to chunk", he);
-            const uint64_t left = g->gz_have - len;
-            if (left && (he = hipMemcpyAsync(g->gz_fifo[g->gz_cur ^ 1], from + len, left, hipMemcpyDeviceToDevice, cs)) != hipSuccess) return fail("reader: FIFO remainder", he);
-            g->gz_cur ^= 1; g->gz_have = left;
+        if (g->gz_dev) {   // the chunk leaves the FIFO; what is left stays where it is (gz_fill_fifo moves it when room is short)
+            if (len && (he = hipMemcpyAsync(s.dev + g->reserve, g->gz_fifo + g->gz_head, len, hipMemcpyDeviceToDevice, cs)) != hipSuccess) return fail("reader: FIFO to chunk", he);
+            g->gz_head += len; g->gz_have -= len;
         } else if (g->gpu_inflate) {
             g->bad_pinned[b] = ~0ull;   // (the consumer read the previous verdict of this slot two chunks ago)
             if (n_blocks) {
@@ -531,7 +544,7 @@ inline void ingest_free(bzq_ingest* g) {
     if (g->bad_pinned) (void)hipHostFree(g->bad_pinned);
     if (g->gz) gzclose(g->gz);
     if (g->gz_dev) bzq::gz::gz_free(g->gz_dev);
-    for (int i = 0; i < 2; ++i) cache::device_pool().put(g->gz_fifo[i]);
+    cache::device_pool().put(g->gz_fifo);
     if (g->fd >= 0) close(g->fd);
     if (g->fd_direct >= 0) close(g->fd_direct);
     delete g;

@@ -182,6 +182,30 @@ def test_compressed_files_parse_like_the_plain_file(kind, tmp_path):
     assert sum(1 for _ in B.parser(str(path)).records) == 20_000
 
 
+@pytest.mark.parametrize("fifo_kib,chunk", [(192, 1 << 16), (1024, 1 << 16), (3072, 1 << 20)])
+def test_a_gz_stream_through_the_wrap_around_of_its_fifo(fifo_kib, chunk, tmp_path, monkeypatch):
+    """The decoder's output waits in ONE device buffer: chunks leave at its head, pieces arrive behind what waits, and what waits
+    moves to the front when less than half the buffer is free (bzq_ingest.hpp gz_fill_fifo; round 5: the second buffer of the same
+    size is gone).  With the default size (6 chunks, at least 64 MiB) a test file never gets there: BZQ_GZ_FIFO_KIB (read by
+    bzq_ingest_open) makes it 3 chunks to 3 MiB, so that 6.6 MB of FASTQ walk through dozens of moves -- and through pieces whose
+    output does not fit what is free (the decoder keeps the rest and is asked again).  Every batch against the oracle."""
+    import gzip
+    import blazeseq_amd as B
+    data = bytes(O.generate_synthetic(20_000, 50, 150, 0, 40, "sanger"))
+    cut = len(data) // 5 + 7
+    comp = b"".join(gzip.compress(data[i:i + cut], 6 if (i // cut) % 2 else 1) for i in range(0, len(data), cut))
+    path = tmp_path / "reads.fastq.gz"
+    path.write_bytes(comp)
+    ref = [b for b in O.StreamParser(np.frombuffer(data, dtype=np.uint8), O.make_config(batch_size=1000)).batches()]
+    monkeypatch.setenv("BZQ_GZ_FIFO_KIB", str(fifo_kib))
+    p = B.FastqParser(str(path), batch_size=1000, chunk_bytes=chunk, reader_threads=3)
+    got = list(p.batches())
+    assert [len(b) for b in got] == [len(b) for b in ref]
+    for g, r in zip(got, ref):
+        assert g._sequence_bytes.tobytes() == r.seq_bytes and g._quality_bytes.tobytes() == r.qual_bytes
+        assert g._id_bytes.tobytes() == r.id_bytes and g._ends.tolist() == r.ends
+
+
 def test_truncated_gzip_is_a_runtime_error_not_a_parse_result(tmp_path):
     import gzip
     import blazeseq_amd as B
