@@ -1306,7 +1306,10 @@ int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value) {
         h->chunk_bytes = (int32_t)value;
         return 0;
     }
-    if (!strcmp(key, "early_find")) { h->early_find = BZQ_EXPERIMENTS && value != 0; return 0; }   // 0: a staged piece's finder runs once the piece in front has been decoded (round 3)
+    if (!strcmp(key, "early_find")) { h->early_find = value != 0; return 0; }   // 0: a staged piece's finder runs once the piece in front has been decoded (round 3)
+    if (!strcmp(key, "defer_verify")) { h->defer_verify = value != 0; return 0; }   // only for a caller whose consumers are on the handle's stream (bzq_gzip.hpp)
+    if (!strcmp(key, "deferred_calls")) return (int32_t)std::min<uint64_t>(h->deferred_calls, 0x7FFFFFFF);   // query
+    if (!strcmp(key, "chain_l2")) { h->chain_l2 = value != 0; return 0; }   // the chain kernels beside the next piece's decoders (bzq_gzip.hpp: k_gz_chainl_*)
     if (!strcmp(key, "predecode")) { h->predecode = value != 0; return 0; }   // 0: a piece's decoders start behind the chain / resolve / CRC kernels of the piece in front (round 3)
     if (!strcmp(key, "host_continuation")) { h->host_cont = value != 0; return 0; }   // 0: a stretch without findable block starts stays on the device (one wave)
     if (!strcmp(key, "far_kib")) {
@@ -2093,6 +2096,16 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
             if (const char* e = getenv("BZQ_GZ_FIFO_KIB"))   // tests: a FIFO of a few chunks, so that small files walk through its wrap-around (never below 3 chunks)
                 g->gz_cap = std::max<uint64_t>(3 * g->chunk_bytes, (uint64_t)atoll(e) << 10);
             int grc = bzq::gz::gz_open(device, &g->gz_dev, err);
+            if (!grc) {
+                // the pipeline of a FILE (round 5): the FIFO's copies are on the decoder's stream, so a piece's bytes are complete in stream
+                // order and a call need not wait for its last kernels (defer_verify); those kernels then run beside the next piece's
+                // decoders (chain_l2: the form that fits what the decoders leave of a CU) and the piece after next, on the device a
+                // chain's length earlier, is searched behind its copy (early_find).  Steady state 15.8 -> 14.0 ms per 256 MiB piece
+                // (profiles/r5_gzip_pipeline.md); the environment overrides each for A/B runs (gz_open)
+                g->gz_dev->defer_verify = true;
+                if (!getenv("BZQ_GZ_CHAIN_L2")) g->gz_dev->chain_l2 = true;
+                if (!getenv("BZQ_GZ_EARLY_FIND")) g->gz_dev->early_find = true;
+            }
             if (!grc && !bzq::cache::get_device(device, g->gz_cap + 64, &g->gz_fifo)) {
                 err = std::string(who) + ": allocating the gzip FIFO failed"; grc = BZQ_ERR_NOMEM;
             }

@@ -1150,13 +1150,11 @@ static __global__ __launch_bounds__(BLOCK) void k_gz_order(int n, const uint8_t*
 
 static __global__ void k_gz_job0(Job* jobs, u64 start) { jobs[0] = Job{start, 1, 0}; }   // (job 0 = the piece's exact start)
 
-#if BZQ_EXPERIMENTS   // option early_find (measured: no gain) -- the EXPERIMENTS library only
 // starts found on a grid laid over the piece's NEW bytes before its carry was known (gz_stage): jobs[1 ..] += shift, in position units
 static __global__ __launch_bounds__(BLOCK) void k_gz_shift(Job* jobs, int n, long long shift) {
     const int i = (int)(blockIdx.x * BLOCK + threadIdx.x);
     if (i < n && jobs[i].start != POS_NONE) jobs[i].start = (u64)((long long)jobs[i].start + shift);
 }
-#endif
 
 // ORDER of a piece's jobs on `st` (jobs[0] set, the others found); order_buf = [bins][cursor][order n_chunks][keys n_chunks].  Returns the order array.
 static inline const uint32_t* launch_order(hipStream_t st, const Job* jobs, void* order_buf, int n_chunks) {
@@ -1331,6 +1329,152 @@ static __global__ __launch_bounds__(CHAIN_THREADS) void k_gz_chain_groups(const 
     }
 }
 
+// ---- CHAIN, the form that runs BESIDE the decoders (round 5) ------------------------------------------------------------------------
+// The three kernels above keep the window in LDS (64 / 128 KiB, 1024 threads a workgroup): beside the NEXT piece's decoders -- 24
+// one-wave workgroups of 80 VGPRs and 6.5 KiB of LDS a CU, i.e. 480 of a SIMD's 512 VGPRs and 157 of 160 KiB -- such a workgroup
+// gets a CU only when the decoders' queue has drained (k_gz_chain_groups: 0.28 ms alone, 8.9 ms there), so a piece's call returned
+// when the next piece's decoders were through.  What a CU always has left beside them is one wave of <= 32 VGPRs per SIMD and
+// 4 KiB of LDS: these kernels are 256 threads, no LDS, <= 32 VGPRs, and the window lives where the L2 holds it:
+//   pass 1 (k_gz_chainl_tab, a workgroup per group): the composed table of every job goes to one of two 64 KiB tables of the
+//          group in global memory, the lookups of the next job read it from there; the last job's table is the group's;
+//   pass 2 (k_gz_chainl_groups, one workgroup): entry_win[g + 1] = the group's table looked up in entry_win[g] -- the window IS
+//          the array the previous step wrote;
+//   pass 3 (k_gz_chainl_out, a workgroup per group): a job's tail goes out final, markers read the 32 KiB in front of the job
+//          from the OUTPUT itself (this workgroup wrote them one step earlier) or, in front of the group's first job, from
+//          entry_win[g].  No table at all.
+// A step's stores are visible to the step behind it through the barrier (one CU, one vector L1: workgroup scope).
+constexpr int CHL_THREADS = 256;
+constexpr int CHL_VEC = 32768 / 8 / CHL_THREADS;   // 16-byte vectors of a 32768-symbol table per thread: 16
+struct __attribute__((packed, aligned(1))) U64A1 { u64 v; };
+
+__device__ __forceinline__ const uint16_t* chl_sym(const ChainItem& it, const uint16_t* pool, int64_t first, int64_t p) {
+    const uint32_t pg = (p >> PAGE_SHIFT) == (first >> PAGE_SHIFT) ? it.page_a : it.page_b;
+    return pool + ((size_t)pg << PAGE_SHIFT) + (p & (PAGE - 1));
+}
+
+static __global__ __launch_bounds__(CHL_THREADS) void k_gz_chainl_tab(const ChainItem* items, int n_items, int per_group, const uint16_t* pool,
+                                                                      uint16_t* tabs, uint16_t* group_maps) {
+    const int tid = threadIdx.x, g = (int)blockIdx.x;
+    const int i_lo = g * per_group, i_hi = i_lo + per_group < n_items ? i_lo + per_group : n_items;
+    const uint16_t* ow = nullptr;   // the table in front of the job at hand; nullptr = the identity (the group's first job)
+    for (int i = i_lo; i < i_hi; ++i) {
+        const ChainItem it = items[i];
+        const int t = (int)(it.len < 32768 ? it.len : 32768);
+        const int64_t first = it.len - t;
+        const int shift = 32768 - t;      // new[k] = old[k + t] for k < shift, the tail's symbol k - shift behind it
+        uint16_t* nw = i == i_hi - 1 ? group_maps + (size_t)g * 32768 : tabs + ((size_t)g * 2 + (size_t)((i - i_lo) & 1)) * 32768;
+        auto look = [&](uint32_t sym) -> uint32_t { return (sym & 0x8000u) && ow ? (uint32_t)ow[sym & 0x7FFFu] : sym; };
+#pragma unroll 1
+        for (int r = 0; r < CHL_VEC; ++r) {
+            const int k0 = (r * CHL_THREADS + tid) * 8;
+            uint32_t a[8];
+            const int64_t p0 = first + (k0 - shift);
+            if (k0 + 8 <= shift) {   // the old table, shifted (a job that wrote less than 32 KiB)
+                if (ow) {
+                    const V16A2 v = *reinterpret_cast<const V16A2*>(ow + k0 + t);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { a[2 * q] = v.w[q] & 0xFFFFu; a[2 * q + 1] = v.w[q] >> 16; }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = 0x8000u | (uint32_t)(k0 + t + q);
+                }
+            } else if (k0 >= shift && (p0 >> PAGE_SHIFT) == ((p0 + 7) >> PAGE_SHIFT)) {
+                const V16A2 v = *reinterpret_cast<const V16A2*>(chl_sym(it, pool, first, p0));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a[2 * q] = v.w[q] & 0xFFFFu; a[2 * q + 1] = v.w[q] >> 16; }
+                if (ow && ((v.w[0] | v.w[1] | v.w[2] | v.w[3]) & 0x80008000u)) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (a[q] & 0x8000u) a[q] = ow[a[q] & 0x7FFFu];
+                }
+            } else {   // the vector straddles the shift or a page: symbol by symbol, stored at once (rare; kept out of the registers of the paths above)
+#pragma unroll 1
+                for (int q = 0; q < 8; ++q) {
+                    const int k = k0 + q;
+                    uint32_t e;
+                    if (k < shift) e = ow ? (uint32_t)ow[k + t] : (0x8000u | (uint32_t)(k + t));
+                    else e = look(*chl_sym(it, pool, first, first + (k - shift)));
+                    nw[k] = (uint16_t)e;
+                }
+                continue;
+            }
+            *reinterpret_cast<uint4*>(nw + k0) = uint4{a[0] | (a[1] << 16), a[2] | (a[3] << 16), a[4] | (a[5] << 16), a[6] | (a[7] << 16)};
+        }
+        __syncthreads();
+        ow = nw;
+    }
+}
+
+// pass 2: entry_win[0] = w0, entry_win[g + 1][k] = group g's table entry k, markers looked up in entry_win[g]
+static __global__ __launch_bounds__(CHL_THREADS) void k_gz_chainl_groups(const uint16_t* group_maps, int n_groups, const uint8_t* w0, uint8_t* entry_win) {
+    const int tid = threadIdx.x;
+    for (int k = tid * 16; k < 32768; k += CHL_THREADS * 16) *reinterpret_cast<uint4*>(entry_win + k) = *reinterpret_cast<const uint4*>(w0 + k);
+    __syncthreads();
+    for (int g = 0; g + 1 < n_groups; ++g) {
+        const uint8_t* ow = entry_win + (size_t)g * 32768;
+        uint8_t* nw = entry_win + (size_t)(g + 1) * 32768;
+        const uint16_t* map = group_maps + (size_t)g * 32768;
+#pragma unroll 2
+        for (int r = 0; r < CHL_VEC; ++r) {
+            const int k0 = (r * CHL_THREADS + tid) * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(map + k0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t a[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a[2 * q] = w[q] & 0xFFFFu; a[2 * q + 1] = w[q] >> 16; }
+            if ((v.x | v.y | v.z | v.w) & 0x80008000u) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (a[q] & 0x8000u) a[q] = ow[a[q] & 0x7FFFu];
+            }
+            *reinterpret_cast<uint2*>(nw + k0) = uint2{a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24), a[4] | (a[5] << 8) | (a[6] << 16) | (a[7] << 24)};
+        }
+        __syncthreads();
+    }
+}
+
+// pass 3: the tails go out final.  `entry_win` holds the window in front of every group (one group: the piece's entry window itself).
+static __global__ __launch_bounds__(CHL_THREADS) void k_gz_chainl_out(const ChainItem* items, int n_items, int per_group, const uint16_t* pool,
+                                                                      const uint8_t* entry_win, uint8_t* out, uint8_t* w_next) {
+    const int tid = threadIdx.x, g = (int)blockIdx.x;
+    const int i_lo = g * per_group, i_hi = i_lo + per_group < n_items ? i_lo + per_group : n_items;
+    const uint8_t* ew = entry_win + (size_t)g * 32768;
+    const int64_t B0 = i_lo < i_hi ? items[i_lo].out_base : 0;   // the group's output starts here: what lies in front of it is ew
+    // byte at output position gp (inside the 32 KiB in front of a job of this group, or of the piece's end)
+    auto window = [&](int64_t gp) -> uint32_t { return gp >= B0 ? (uint32_t)out[gp] : (uint32_t)ew[gp - (B0 - 32768)]; };
+    int64_t end = B0;
+    for (int i = i_lo; i < i_hi; ++i) {
+        const ChainItem it = items[i];
+        const int t = (int)(it.len < 32768 ? it.len : 32768);
+        const int64_t first = it.len - t, wbase = it.out_base - 32768;
+        const int nv = (t + 7) >> 3;
+        for (int v = tid; v < nv; v += CHL_THREADS) {
+            const int64_t p0 = first + 8 * (int64_t)v;
+            if (p0 + 8 <= it.len && (p0 >> PAGE_SHIFT) == ((p0 + 7) >> PAGE_SHIFT)) {
+                const V16A2 s4 = *reinterpret_cast<const V16A2*>(chl_sym(it, pool, first, p0));
+                uint32_t a[8];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a[2 * q] = s4.w[q] & 0xFFFFu; a[2 * q + 1] = s4.w[q] >> 16; }
+                if ((s4.w[0] | s4.w[1] | s4.w[2] | s4.w[3]) & 0x80008000u) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (a[q] & 0x8000u) a[q] = window(wbase + (int64_t)(a[q] & 0x7FFFu));
+                }
+                reinterpret_cast<U64A1*>(out + it.out_base + p0)->v =
+                    (u64)(a[0] | (a[1] << 8) | (a[2] << 16) | (a[3] << 24)) | ((u64)(a[4] | (a[5] << 8) | (a[6] << 16) | (a[7] << 24)) << 32);
+            } else {
+                for (int64_t p = p0; p < p0 + 8 && p < it.len; ++p) {
+                    uint32_t sym = *chl_sym(it, pool, first, p);
+                    if (sym & 0x8000u) sym = window(wbase + (int64_t)(sym & 0x7FFFu));
+                    out[it.out_base + p] = (uint8_t)sym;
+                }
+            }
+        }
+        __syncthreads();
+        end = it.out_base + it.len;
+    }
+    if (i_hi == n_items && w_next) {   // the last group (or the only one): the window in front of the next piece
+        for (int k = tid; k < 32768; k += CHL_THREADS) w_next[k] = (uint8_t)window(end - 32768 + k);
+    }
+}
+
 // ---- RESOLVE: one page of symbols -> bytes at their final place -------------------------------------------------------------------
 struct ResItem { uint32_t page, n; int64_t dst, chunk_base; };   // symbols [0, n) of the page -> out[dst ..); the chunk's output starts at chunk_base
 struct __attribute__((packed, aligned(1))) U64U { u64 v; };
@@ -1440,7 +1584,7 @@ struct bzq_gzip {
     struct Buf { void* p = nullptr; size_t cap = 0; };
     // what a piece's decoders write (symbol pool, page links, counters, job results, member events) exists TWICE: piece k + 1 is decoded
     // (on find_stream, behind its finder) while the chain / resolve / CRC kernels of piece k still read piece k's -- round 4
-    Buf comp[3], jobs[2], jobs_e[3], order_e[3], counters_e[3], outs_[2], order[2], counters2, pool_[2], page_next_[2], counters_[2], events_[2], items, crcs, win[2], chain_maps, chain_wins;
+    Buf comp[3], jobs[2], jobs_e[3], order_e[3], counters_e[3], outs_[2], order[2], counters2, pool_[2], page_next_[2], counters_[2], events_[2], items, crcs, win[2], chain_maps, chain_wins, chain_tabs;
     Buf h_outs_[2], h_events, h_pages, h_items, h_crcs;   // pinned host staging
     int pcur = 0;                       // which of the two sets the piece being (last) decoded uses
     bool predecode = true;              // option "predecode": 0 = a piece's decoders start behind the kernels of the piece in front
@@ -1453,6 +1597,7 @@ struct bzq_gzip {
                  bool decoded = false; int pb = 0; uint32_t pool_pages = 0; int64_t max_job = 0; } pre;   // decoded: its decoders have run too (set pb), with that pool and job bound
     int jlast = 1;                      // which of jobs[] / order[] the last decode used
     hipStream_t find_stream = nullptr;
+    hipStream_t early_stream = nullptr;   // option early_find: a staged piece's finder, behind its copy (not ON the copy stream: beside the decoders it takes 9 ms, and the next piece's copy would wait behind it)
     hipEvent_t pre_ev = nullptr, pre_copy_ev = nullptr, pre_dec_ev = nullptr;
     // pieces on their way to the device while the one in front of them is decoded (bzq_gzip_stage): comp[b] holds one
     // STAGE_RESERVE bytes in, so that the bytes carried over from the piece in front can be put before it
@@ -1463,11 +1608,22 @@ struct bzq_gzip {
                                         // decoded under them, and the one behind it on its way to the device)
     hipStream_t copy_stream = nullptr;
     hipEvent_t staged_ev[3] = {nullptr, nullptr, nullptr}, early_ev[3] = {nullptr, nullptr, nullptr};
-    // option "early_find" (default 0; EXPERIMENTS library only -- the product ignores it): a staged piece's finder runs behind its COPY instead of behind the decoding of the piece in front.
-    // Built and parity-green in round 4, and no faster (27.3 against 28.2 GB/s file -> records): with the finder off the critical path
-    // the chain / resolve / CRC kernels of the piece in front are on it -- beside 16 000 decoder waves they take 12 ms instead of 3
-    // (k_gz_chain_groups, one workgroup: 0.28 -> 8.8 ms), whatever the streams' priorities or CU masks (measured: DESIGN 5c)
+    // option "early_find" (default 0; the ingest sets it): a staged piece's finder runs behind its COPY (on a stream of its own) instead of
+    // behind the decoding of the piece in front.  Alone it was no gain in round 4 (27.3 against 28.2 GB/s file -> records: with the finder
+    // off the critical path the chain / resolve / CRC kernels of the piece in front were on it -- beside 16 000 decoder waves they took
+    // 12 ms instead of 3); with chain_l2 and defer_verify (round 5) the three are the file pipeline's steady state, 15.8 -> 14.0 ms a piece
     bool early_find = false;
+    // option "chain_l2": the chain kernels in the form that runs BESIDE the next piece's decoders (k_gz_chainl_*: 256 threads, no LDS, <= 32 VGPRs, windows through the L2)
+    bool chain_l2 = false;
+    // option "defer_verify" (the ingest sets it; default 0): a call that launched the NEXT piece's decoders returns without waiting for
+    // its own chain / resolve / CRC kernels -- its output is complete in STREAM ORDER (on `stream`), not at return -- and the member
+    // checks of the piece (CRC-32, ISIZE) are made at the start of the next call, which fails if they fail.  Only for a caller whose
+    // consumers are on `stream` (the ingest's FIFO copies are): the piece's pinned buffer then goes back to the reader a chain's
+    // length earlier, and the piece after next is on the device -- and its finder through -- when the next chain has been walked.
+    bool defer_verify = false;
+    struct PendingVerify { bool on = false; std::vector<int32_t> seg_n; std::vector<uint8_t> closes; std::vector<uint32_t> crc_t, isize_t; } pend;
+    hipEvent_t ver_ev = nullptr;
+    uint64_t deferred_calls = 0;        // query "deferred_calls"
     // the stream
     std::vector<uint8_t> carry;         // compressed bytes not consumed yet
     unsigned long long start_pos = 1;   // where decoding resumes inside `carry`: pos_header(0), or pos_deflate(bit 0..7)
@@ -1548,11 +1704,12 @@ inline void gz_free(bzq_gzip* h) {
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
     if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
     if (h->find_stream) { (void)hipStreamSynchronize(h->find_stream); (void)hipStreamDestroy(h->find_stream); }
-    for (hipEvent_t e : {h->pre_ev, h->pre_copy_ev, h->pre_dec_ev}) if (e) (void)hipEventDestroy(e);
+    if (h->early_stream) { (void)hipStreamSynchronize(h->early_stream); (void)hipStreamDestroy(h->early_stream); }
+    for (hipEvent_t e : {h->pre_ev, h->pre_copy_ev, h->pre_dec_ev, h->ver_ev}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->staged_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->early_ev) if (e) (void)hipEventDestroy(e);
     (void)hipDeviceSynchronize();   // (a caller's stream may still run the last decode: what goes back to the cache skips hipFree's wait)
-    for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->comp[2], &h->jobs_e[0], &h->jobs_e[1], &h->jobs_e[2], &h->order_e[0], &h->order_e[1], &h->order_e[2], &h->counters_e[0], &h->counters_e[1], &h->counters_e[2], &h->order[0], &h->order[1], &h->jobs[0], &h->jobs[1], &h->counters2, &h->outs_[0], &h->outs_[1], &h->pool_[0], &h->pool_[1], &h->page_next_[0], &h->page_next_[1], &h->counters_[0], &h->counters_[1], &h->events_[0], &h->events_[1], &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins})
+    for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->comp[2], &h->jobs_e[0], &h->jobs_e[1], &h->jobs_e[2], &h->order_e[0], &h->order_e[1], &h->order_e[2], &h->counters_e[0], &h->counters_e[1], &h->counters_e[2], &h->order[0], &h->order[1], &h->jobs[0], &h->jobs[1], &h->counters2, &h->outs_[0], &h->outs_[1], &h->pool_[0], &h->pool_[1], &h->page_next_[0], &h->page_next_[1], &h->counters_[0], &h->counters_[1], &h->events_[0], &h->events_[1], &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins, &h->chain_tabs})
         bzq::cache::device_pool().put(b->p);
     for (bzq_gzip::Buf* b : {&h->h_outs_[0], &h->h_outs_[1], &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs, &h->h_host_out})
         bzq::cache::pinned_pool().put(b->p);
@@ -1564,6 +1721,8 @@ inline int gz_open(int device, bzq_gzip** out, std::string& err) {
     *out = nullptr;
     if (hipSetDevice(device) != hipSuccess) { err = "bzq_gzip_open: hipSetDevice failed"; return BZQ_ERR_HIP; }
     bzq_gzip* h = new bzq_gzip();
+    if (const char* e = getenv("BZQ_GZ_CHAIN_L2")) h->chain_l2 = atoi(e) != 0;   // (A/B runs through the ingest, which has no handle to set options on)
+    if (const char* e = getenv("BZQ_GZ_EARLY_FIND")) h->early_find = atoi(e) != 0;
     h->device = device;
     // the stream of a piece's chain / resolve / CRC kernels: highest priority -- they run beside the NEXT piece's decoders (find_stream),
     // which fill every CU, and the caller waits for them (BZQ_GZ_PRIORITY=0: default class, for measurements)
@@ -1573,7 +1732,7 @@ inline int gz_open(int device, bzq_gzip** out, std::string& err) {
     if ((prio ? hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, phi) : hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { err = "bzq_gzip_open: hipStreamCreate failed"; delete h; return BZQ_ERR_HIP; }
     h->stream = h->own_stream;
     if (hipStreamCreateWithFlags(&h->find_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->pre_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->pre_copy_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->pre_dec_ev, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->pre_copy_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ver_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->pre_dec_ev, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->staged_ev[1], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->early_ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->early_ev[1], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->early_ev[2], hipEventDisableTiming) != hipSuccess) {
         err = "bzq_gzip_open: hipStreamCreate failed"; gz_free(h); return BZQ_ERR_HIP;
@@ -1594,6 +1753,32 @@ inline int gz_open(int device, bzq_gzip** out, std::string& err) {
 // decoded); with all taken the call does nothing, and that piece is copied by its gz_decode as if never staged.  Pieces are
 // taken in the order staged.  May be called from another thread than gz_decode's while that runs (the ingest's read-ahead
 // thread does), not concurrently with itself; src must stay untouched until its gz_decode has returned.
+// ---- CRC-32 and ISIZE of every member that ended in the last piece (RFC 1952 2.3.1): the device's per-segment remainders (h_crcs, behind
+// ver_ev when the call that launched them did not wait) combined in stream order and compared with the trailers noted in h->pend
+inline int gz_verify_pending(bzq_gzip* h) {
+    bzq_gzip::PendingVerify& p = h->pend;
+    if (p.seg_n.empty() && !p.on) return 0;
+    if (p.on) { p.on = false; GZCHK(h, hipEventSynchronize(h->ver_ev)); }
+    const uint32_t* crcs = (const uint32_t*)h->h_crcs.p;
+    const uint32_t xp_full = crc_xpow8((uint64_t)CRC_SEG);
+    int rc = 0;
+    for (size_t k = 0; k < p.seg_n.size() && !rc; ++k) {
+        if (p.seg_n[k]) {
+            h->crc_run = h->len_run ? crc_mul(p.seg_n[k] == CRC_SEG ? xp_full : crc_xpow8((uint64_t)p.seg_n[k]), h->crc_run) ^ crcs[k] : crcs[k];
+            h->len_run += (uint64_t)p.seg_n[k];
+        }
+        if (p.closes[k]) {
+            if ((h->len_run ? h->crc_run : 0u) != p.crc_t[k] || (uint32_t)h->len_run != p.isize_t[k])
+                rc = gz_fail(h, BZQ_ERR_IO, "bzq_gzip: member " + std::to_string(h->members_done) + " fails its " + ((uint32_t)h->len_run != p.isize_t[k] ? "length" : "CRC-32") +
+                                                " check (corrupt file)");
+            else { h->members_done += 1; h->crc_run = 0; h->len_run = 0; }
+        }
+    }
+    p.seg_n.clear(); p.closes.clear(); p.crc_t.clear(); p.isize_t.clear();
+    h->stats.members = h->members_done;
+    return rc;
+}
+
 constexpr uint64_t STAGE_RESERVE = 4ull << 20;
 inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
     // (no h->err in here: that string is the decode thread's.  A piece that could not be staged is copied by its gz_decode, which
@@ -1616,7 +1801,8 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
         b.cap = want;
     }
     uint8_t* d = (uint8_t*)b.p + STAGE_RESERVE;
-    hipError_t e = bzq::cache::pinned_pool().h2d(d, src, n_new, h->copy_stream);   // (the ingest's slots are pinned lazily, block by block: bzq_bufcache.hpp)
+    hipError_t e = h->early_stream ? hipStreamWaitEvent(h->copy_stream, h->early_ev[bi], 0) : hipSuccess;   // (a finder of this buffer's last piece that nobody waited for: a piece that was dropped)
+    if (e == hipSuccess) e = bzq::cache::pinned_pool().h2d(d, src, n_new, h->copy_stream);   // (the ingest's slots are pinned lazily, block by block: bzq_bufcache.hpp)
     if (e == hipSuccess) e = hipMemsetAsync(d + n_new, 0, 64, h->copy_stream);
     if (e == hipSuccess) e = hipEventRecord(h->staged_ev[bi], h->copy_stream);
     if (e != hipSuccess) { (void)hipStreamSynchronize(h->copy_stream); return give_back(BZQ_ERR_HIP); }
@@ -1626,7 +1812,6 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
     // known they are shifted to where the piece then starts (k_gz_shift, gz_decode).  3 of a piece's 15.5 ms off its critical path.
     bool found = false;
     int nch = 0;
-#if BZQ_EXPERIMENTS   // (option early_find: compiled into the EXPERIMENTS library only)
     static const bool no_early = getenv("BZQ_GZ_NO_EARLY_FIND") != nullptr;
     if (h->early_find && !no_early) {
         const int CH = h->chunk_bytes;
@@ -1643,14 +1828,15 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
         if (fit(h->jobs_e[bi], (size_t)(nch + MAX_FALLBACK) * sizeof(Job)) && fit(h->order_e[bi], (size_t)2 * ORDER_BINS * 4 + (size_t)nch * 5 + 64)) {
             Args a2{};
             a2.comp = d - CH; a2.n = (int64_t)n_new + CH; a2.jobs = (Job*)h->jobs_e[bi].p; a2.n_jobs = nch; a2.n_cand = nch; a2.chunk_bytes = CH; a2.counters = (uint32_t*)h->counters_e[bi].p;
-            e = hipMemsetAsync(h->counters_e[bi].p, 0, 128, h->copy_stream);
-            if (e == hipSuccess) { hipLaunchKernelGGL(k_gz_find, dim3((unsigned)((nch + WAVES - 1) / WAVES)), dim3(BLOCK), 0, h->copy_stream, a2); e = hipGetLastError(); }
-            if (e == hipSuccess) e = hipEventRecord(h->early_ev[bi], h->copy_stream);
+            if (!h->early_stream) e = hipStreamCreateWithFlags(&h->early_stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipStreamWaitEvent(h->early_stream, h->staged_ev[bi], 0);
+            if (e == hipSuccess) e = hipMemsetAsync(h->counters_e[bi].p, 0, 128, h->early_stream);
+            if (e == hipSuccess) { hipLaunchKernelGGL(k_gz_find, dim3((unsigned)((nch + WAVES - 1) / WAVES)), dim3(BLOCK), 0, h->early_stream, a2); e = hipGetLastError(); }
+            if (e == hipSuccess) e = hipEventRecord(h->early_ev[bi], h->early_stream);
             found = e == hipSuccess;
             if (!found) (void)hipGetLastError();
         }
     }
-#endif
     std::lock_guard<std::mutex> lk(h->stage_mu);
     h->staged.push_back(bzq_gzip::StagedPiece{src, n_new, bi, found, nch});
     return 0;
@@ -1807,6 +1993,7 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     *out_bytes = 0; *more = 0;
     if (h->finished) return 0;   // (whatever follows the last member is ignored, like gzread does)
     GZCHK(h, hipSetDevice(h->device));
+    { const int vrc = gz_verify_pending(h); if (vrc) return vrc; }   // (option defer_verify: the piece in front is judged now)
     const hipStream_t s = h->stream;
     const uint64_t nc = h->carry.size(), n = nc + n_new;
     auto byte_at = [&](uint64_t i) -> uint32_t { return i < nc ? h->carry[(size_t)i] : src[i - nc]; };
@@ -2011,12 +2198,10 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
             GZCHK(h, hipEventRecord(h->pre_copy_ev, fs));
             const unsigned long long start2 = (final_pos & 1ull) ? pos_header(0) : pos_deflate((final_pos >> 1) & 7ull);
             hipLaunchKernelGGL(k_gz_job0, dim3(1), dim3(1), 0, fs, (Job*)jobsN.p, (u64)start2);
-#if BZQ_EXPERIMENTS
             if (early) {   // found behind its copy (gz_stage), relative to CH bytes in front of its own bytes: to where the piece starts now
                 hipLaunchKernelGGL(k_gz_shift, dim3((unsigned)((nch2 + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, fs, (Job*)jobsN.p + 1, nch2 - 1, ((long long)nc2 - (long long)CH) * 16);
                 (void)launch_order(fs, (const Job*)jobsN.p, orderN.p, nch2);
             } else
-#endif
             {
                 Args a2{};
                 a2.comp = d2; a2.n = (int64_t)nn; a2.jobs = (Job*)jobsN.p; a2.n_jobs = nch2; a2.n_cand = nch2; a2.chunk_bytes = CH; a2.counters = (uint32_t*)h->counters2.p;
@@ -2138,7 +2323,20 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
         while (per_group * per_group < n_it) per_group += 8;
         const int n_groups = n_it ? (n_it + per_group - 1) / per_group : 1;
         const ChainItem* d_items = (const ChainItem*)h->items.p;
-        if (n_groups <= 1) {
+        if (h->chain_l2 && deferred_predecode) {   // the form that runs beside the next piece's decoders (windows through the L2, no LDS, <= 32 VGPRs); alone, the LDS form is 6 x faster
+            if (n_groups <= 1) {
+                hipLaunchKernelGGL(k_gz_chainl_out, dim3(1), dim3(CHL_THREADS), 0, s, d_items, n_it, std::max(1, n_it), (const uint16_t*)pool.p, w0, d_out, w_next);
+            } else {
+                if ((rc = gz_ensure(h, h->chain_maps, (size_t)n_groups * 65536)) || (rc = gz_ensure(h, h->chain_wins, (size_t)n_groups * 32768)) ||
+                    (rc = gz_ensure(h, h->chain_tabs, (size_t)n_groups * 131072)))
+                    return rc;
+                hipLaunchKernelGGL(k_gz_chainl_tab, dim3((unsigned)n_groups), dim3(CHL_THREADS), 0, s, d_items, n_it, per_group, (const uint16_t*)pool.p, (uint16_t*)h->chain_tabs.p,
+                                   (uint16_t*)h->chain_maps.p);
+                hipLaunchKernelGGL(k_gz_chainl_groups, dim3(1), dim3(CHL_THREADS), 0, s, (const uint16_t*)h->chain_maps.p, n_groups, w0, (uint8_t*)h->chain_wins.p);
+                hipLaunchKernelGGL(k_gz_chainl_out, dim3((unsigned)n_groups), dim3(CHL_THREADS), 0, s, d_items, n_it, per_group, (const uint16_t*)pool.p, (const uint8_t*)h->chain_wins.p, d_out,
+                                   w_next);
+            }
+        } else if (n_groups <= 1) {
             hipLaunchKernelGGL(k_gz_chain<false>, dim3(1), dim3(CHAIN_THREADS), 0, s, d_items, n_it, std::max(1, n_it), (const uint16_t*)pool.p, w0, d_out, (uint16_t*)nullptr, w_next);
         } else {
             if ((rc = gz_ensure(h, h->chain_maps, (size_t)n_groups * 65536)) || (rc = gz_ensure(h, h->chain_wins, (size_t)n_groups * 32768))) return rc;
@@ -2162,29 +2360,36 @@ inline int gz_decode(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool is_la
     GZCHK(h, hipGetLastError());
     // (enqueued BEHIND this piece's last kernels: launched in front of them, the 16 000 decoder waves took every CU and the chain
     // kernels -- 1024 threads and 64 KiB of LDS a workgroup -- waited for the decoders' end: 8 ms instead of 0.9)
+    const bool next_launched = (bool)deferred_predecode;
     if (deferred_predecode && (rc = deferred_predecode())) return rc;
-    GZCHK(h, hipStreamSynchronize(s));
-    lap(6);
-    h->wcur ^= 1;
-
-    // ---- CRC-32 and ISIZE of every member that ended (RFC 1952 2.3.1)
-    const uint32_t* crcs = (const uint32_t*)h->h_crcs.p;
-    const uint32_t xp_full = crc_xpow8((uint64_t)CRC_SEG);
-    for (size_t k = 0; k < segs.size(); ++k) {
-        if (segs[k].n) {
-            h->crc_run = h->len_run ? crc_mul(segs[k].n == CRC_SEG ? xp_full : crc_xpow8((uint64_t)segs[k].n), h->crc_run) ^ crcs[k] : crcs[k];
-            h->len_run += (uint64_t)segs[k].n;
+    // ---- CRC-32 and ISIZE of every member that ended (RFC 1952 2.3.1): what the check needs from the piece's bytes is noted now (the
+    // piece's buffer goes back to the reader when the call returns); the check itself waits for the CRC kernel -- here, or, with
+    // option defer_verify and the next piece's decoders launched, at the start of the next call (gz_verify_pending)
+    {
+        bzq_gzip::PendingVerify& p = h->pend;
+        p.seg_n.resize(segs.size()); p.closes.assign(segs.size(), 0); p.crc_t.assign(segs.size(), 0u); p.isize_t.assign(segs.size(), 0u);
+        for (size_t k = 0; k < segs.size(); ++k) {
+            p.seg_n[k] = segs[k].n;
+            if (seg_closes[k] >= 0) {
+                const uint64_t T = ends[(size_t)seg_closes[k]].trailer;
+                uint32_t crc_t = 0, isize_t = 0;
+                for (int q = 0; q < 4; ++q) { crc_t |= byte_at(T + q) << (8 * q); isize_t |= byte_at(T + 4 + q) << (8 * q); }
+                p.closes[k] = 1; p.crc_t[k] = crc_t; p.isize_t[k] = isize_t;
+            }
         }
-        if (seg_closes[k] >= 0) {
-            const uint64_t T = ends[(size_t)seg_closes[k]].trailer;
-            uint32_t crc_t = 0, isize_t = 0;
-            for (int q = 0; q < 4; ++q) { crc_t |= byte_at(T + q) << (8 * q); isize_t |= byte_at(T + 4 + q) << (8 * q); }
-            if ((h->len_run ? h->crc_run : 0u) != crc_t || (uint32_t)h->len_run != isize_t)
-                return gz_fail(h, BZQ_ERR_IO, "bzq_gzip: member " + std::to_string(h->members_done) + " fails its " + ((uint32_t)h->len_run != isize_t ? "length" : "CRC-32") +
-                                                  " check (corrupt file)");
-            h->members_done += 1; h->crc_run = 0; h->len_run = 0;
+        static const int defer_env = getenv("BZQ_GZ_DEFER") ? atoi(getenv("BZQ_GZ_DEFER")) : -1;   // A/B switch
+        const bool defer = (defer_env >= 0 ? defer_env != 0 : h->defer_verify) && next_launched && !timing && !is_last && !*more;
+        if (defer) {
+            GZCHK(h, hipEventRecord(h->ver_ev, s));
+            p.on = true;
+            h->deferred_calls += 1;
+        } else {
+            GZCHK(h, hipStreamSynchronize(s));
+            if ((rc = gz_verify_pending(h))) return rc;
         }
     }
+    lap(6);
+    h->wcur ^= 1;
 
     // ---- what stays for the next call
     const bool at_header = (final_pos & 1ull) != 0;

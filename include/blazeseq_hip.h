@@ -436,8 +436,15 @@ int32_t bzq_gzip_open(bzq_ctx* ctx, bzq_gzip** out);
  * decoder goes without meeting a found start before it stops.  Query "host_calls": calls that ran on the host.
  * "predecode" (default 1): with pieces staged ahead (bzq_gzip_stage; up to three buffers: the piece being decoded and two behind
  * it), the finder and the decoders of piece k + 1 are launched as soon as piece k's chain is walked and run beside piece k's last
- * kernels, into a second set of pool / result buffers.  "early_find" (default 0): a staged piece's finder runs behind its copy, on
- * a chunk grid over its own bytes (measured: no faster, DESIGN.md 5c -- compiled into the EXPERIMENTS library only, the product ignores the option). */
+ * kernels, into a second set of pool / result buffers.  The file pipeline's three (each default 0 on a handle of its own; bzq_ingest_open sets
+ * all three on the decoder it owns): "early_find": a staged piece's finder runs behind its copy, on a chunk grid over its own bytes,
+ * shifted once the bytes carried over from the piece in front are known.  "chain_l2": beside a predecode, piece k's chain kernels
+ * run in the form that fits what the next piece's decoders leave of a CU (256 threads, no LDS, <= 32 VGPRs, windows through the
+ * L2) instead of waiting for the decoders to drain.  "defer_verify": a call that launched the next piece's decoders returns
+ * WITHOUT waiting for its own last kernels -- d_out is complete in stream order on the handle's stream, not at return -- and the
+ * piece's member checks (CRC-32, ISIZE) are made at the start of the next call, which fails if they fail: only for a caller whose
+ * consumers of d_out are enqueued on that stream (like gzread, bytes of a damaged member may then have been handed on before the
+ * error is).  Query "deferred_calls". */
 int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value);
 /* The next n compressed bytes (HOST memory; pinned memory makes the copy a DMA) -> their bytes at d_out (DEVICE memory,
  * out_capacity bytes).  Whole DEFLATE blocks only: what is left of the piece stays inside the handle and is decoded in front of

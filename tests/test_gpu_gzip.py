@@ -366,14 +366,14 @@ def test_a_file_without_findable_block_starts_through_the_parser(tmp_path):
             assert g._sequence_bytes.tobytes() == r.seq_bytes and g._quality_bytes.tobytes() == r.qual_bytes and g._id_bytes.tobytes() == r.id_bytes
 
 
-# (early_find = 1 exists in the EXPERIMENTS library only -- measured: no gain; tests/test_gpu_experiments.py runs this test against it)
-@pytest.mark.parametrize("early_find,predecode", [(0, 0), (0, 1), (1, 0), (1, 1)] if os.environ.get("BZQ_TEST_EXPERIMENTS") == "1" else [(0, 0), (0, 1)])
-def test_the_next_piece_under_this_one(early_find, predecode):
+@pytest.mark.parametrize("early_find,predecode,chain_l2", [(0, 0, 0), (0, 1, 0), (1, 0, 0), (1, 1, 0), (0, 1, 1), (1, 1, 1)])
+def test_the_next_piece_under_this_one(early_find, predecode, chain_l2):
     """Round 4: with pieces staged ahead, piece k + 1's decoders run under piece k's chain / resolve / CRC kernels (option
     predecode, into the second set of pool / results), and its finder either behind the decoding of piece k (on the piece's
     uniform chunk grid) or behind its own copy (option early_find: on a grid over its own bytes, shifted once the carry is
-    known).  Every combination == zlib's bytes, through piece sizes that cut blocks, headers and trailers, output buffers that
-    cut pieces, many small members, and a stretch the host continues."""
+    known).  Round 5: option chain_l2 -- beside a predecode the chain kernels run in the form that fits what the decoders leave of
+    a CU (k_gz_chainl_*: windows through the L2).  Every combination == zlib's bytes, through piece sizes that cut blocks, headers
+    and trailers, output buffers that cut pieces, many small members, and a stretch the host continues."""
     rng = np.random.default_rng(31)
     fq = synthetic_fastq(60_000)   # 19 MB
     many = b"".join(gzip_member(fq[i:i + 150_000], int(rng.integers(1, 10))) for i in range(0, 6_000_000, 150_000))
@@ -385,8 +385,9 @@ def test_the_next_piece_under_this_one(early_find, predecode):
         g = DeviceGunzip(ctx, cap, chunk_bytes=4096)
         g.dec.set_option("early_find", early_find)
         g.dec.set_option("predecode", predecode)
+        g.dec.set_option("chain_l2", chain_l2)
         g.dec.set_option("far_kib", 64)
-        assert g.decode(comp, piece, ahead=ahead) == data, (early_find, predecode, piece, cap, ahead)
+        assert g.decode(comp, piece, ahead=ahead) == data, (early_find, predecode, chain_l2, piece, cap, ahead)
         g.close()
 
 

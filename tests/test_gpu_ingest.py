@@ -227,6 +227,30 @@ def test_truncated_gzip_is_a_runtime_error_not_a_parse_result(tmp_path):
             list(B.FastqParser(str(path), batch_size=1000, gpu_inflate=gpu_inflate).batches())
 
 
+@pytest.mark.parametrize("defer", ["0", "1"])
+def test_a_damaged_member_in_an_early_piece_fails_the_file(defer, tmp_path, monkeypatch):
+    """Round 5: through the ingest a piece's member checks (CRC-32, ISIZE) are made at the start of the NEXT bzq_gzip_decode call (option
+    defer_verify: the call that launched the next piece's decoders returns without waiting for its own last kernels).  A member whose
+    trailer is wrong in the middle of a file of many pieces still fails the file -- like gzread, bytes of the damaged member may have been
+    delivered before the error is -- and an undamaged file gives the same records either way (BZQ_GZ_DEFER overrides the option)."""
+    import gzip
+    import blazeseq_amd as B
+    data = bytes(O.generate_synthetic(30_000, 100, 100, 0, 40, "sanger"))
+    cut = len(data) // 12 + 5
+    members = [gzip.compress(data[i:i + cut], 6) for i in range(0, len(data), cut)]
+    monkeypatch.setenv("BZQ_GZ_DEFER", defer)
+    path = tmp_path / "good.fastq.gz"
+    path.write_bytes(b"".join(members))
+    assert sum(len(b) for b in B.FastqParser(str(path), batch_size=1000, chunk_bytes=1 << 18, reader_threads=2).batches()) == 30_000
+    for which, field in ((2, -8), (5, -4)):   # a wrong CRC-32 in member 2, a wrong ISIZE in member 5
+        bad = [bytearray(m) for m in members]
+        bad[which][field] ^= 0x01
+        path = tmp_path / "bad.fastq.gz"
+        path.write_bytes(b"".join(bytes(m) for m in bad))
+        with pytest.raises(RuntimeError, match="CRC-32|length"):
+            list(B.FastqParser(str(path), batch_size=1000, chunk_bytes=1 << 18, reader_threads=2).batches())
+
+
 # ---- the reference's window at the end of a stream that came in several chunks ----------------------------------------
 
 @pytest.mark.parametrize("source", ["memory", "file"])
