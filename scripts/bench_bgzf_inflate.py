@@ -4,6 +4,7 @@ blocks = bgzip), the compressed blocks are repeated on the device to --gb of OUT
 import argparse, ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch   # (before the library: INTEGRATION.md)
 import blazeseq_amd as B
 from blazeseq_amd import _lib as L
 from tests.bgzf_util import bgzf_compress
@@ -21,7 +22,6 @@ if args.ms:
 lib = L.lib()
 n_rec = args.slice_mb * (1 << 20) // 318
 size = ctx.generate_synthetic_device(n_rec, 150, 33, 73, "generic", 0, 0)
-import torch
 buf = torch.empty(size + 64, dtype=torch.uint8, device="cuda")
 ctx.generate_synthetic_device(n_rec, 150, 33, 73, "generic", buf.data_ptr(), buf.numel())
 torch.cuda.synchronize()
