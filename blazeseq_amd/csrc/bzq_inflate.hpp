@@ -234,6 +234,30 @@ __device__ __forceinline__ void build_dlut(const Code& code, const uint16_t* sym
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same table with 64-bit entries, for sym_run_ob: the low word IS the operand of the s_bfe_u32 that pulls the extra bits out of the
+// bit buffer BEFORE the code is shifted out (bits 0..4 = offset = code bits, 16..22 = width = number of extra bits), bits 23..27 = code
+// bits + extra bits (one shift consumes both), bit 31 as above; the high word = the base distance.  Five scalar instructions per match
+// where the 32-bit entry takes ten (two shifts of the buffer, a mask built and applied, the base masked out).  2 KiB; its last 512 bytes
+// serve as the 16-bit table while it is built.
+__device__ __forceinline__ void build_dlut64(const Code& code, const uint16_t* symtab, const uint8_t* lens, uint32_t* dlut) {
+    const int lane = threadIdx.x & 63;
+    uint16_t* t16 = reinterpret_cast<uint16_t*>(dlut) + 3 * (1 << DLUT_BITS);
+    build_lut<DLUT_BITS>(code, symtab, lens, t16);
+    uint32_t lo[(1 << DLUT_BITS) / 64], hi[(1 << DLUT_BITS) / 64];
+#pragma unroll
+    for (int k = 0; k < (1 << DLUT_BITS) / 64; ++k) {
+        const uint32_t e1 = t16[k * 64 + lane], sym = e1 & 0xFFFu;
+        if (e1 == LUT_LONG || sym > 29u) { lo[k] = 0x80000000u; hi[k] = 0u; continue; }
+        const uint32_t ext = sym < 4u ? 0u : (sym - 2u) >> 1, bits = e1 >> 12;
+        lo[k] = bits | (ext << 16) | ((bits + ext) << 23);
+        hi[k] = sym < 4u ? 1u + sym : 1u + ((2u + (sym & 1u)) << ext);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < (1 << DLUT_BITS) / 64; ++k) { dlut[2 * (k * 64 + lane)] = lo[k]; dlut[2 * (k * 64 + lane) + 1] = hi[k]; }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // State handed in and out of the hand-written symbol loop.  (pos: bytes stored; ns: literals decoded and not yet stored, the
 // C++ slow paths' business only; len / dist: a match decoded and not yet copied; e: the table entry the loop stopped at.)
 struct SymState { int pos, ns, len, dist; uint32_t e; };
@@ -271,7 +295,7 @@ struct SymState { int pos, ns, len, dist; uint32_t e; };
 constexpr int OB_SLOTS = 192, OB_FLUSH = 128;   // (at most OB_FLUSH + 2 literals, or OB_FLUSH + a match of 63 bytes; the asm has the 128)
 template <class BitsT>
 __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const uint32_t* dlut, uint32_t* obuf, uint8_t* out, int usize, SymState& st) {
-    uint32_t reason, vt, vt2, vq, ve, vslot, vsrc, ee;
+    uint32_t reason, vt, vt2, vq, ve, vh, vslot, vsrc, ee;
     u64 buf = ((u64)uni((uint32_t)(b.buf >> 32)) << 32) | uni((uint32_t)b.buf);
     int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), pos = (int)uni((uint32_t)st.pos);
     int len = (int)uni((uint32_t)st.len), dist = 0;
@@ -356,20 +380,18 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_cmp_ge_i32 s42, 0\n"
         "\ts_cbranch_scc0 11f\n"
         "\tv_bfe_u32 %[vt], s40, 0, 8\n"
-        "\tv_lshl_add_u32 %[vt], %[vt], 2, s56\n"
+        "\tv_lshl_add_u32 %[vt], %[vt], 3, s56\n"
         "\tds_read_b32 %[ve], %[vt]\n"
+        "\tds_read_b32 %[vh], %[vt] offset:4\n"
         "\ts_waitcnt lgkmcnt(0)\n"
         "\tv_readfirstlane_b32 s46, %[ve]\n"
         "\ts_cmp_lt_i32 s46, 0\n"
         "\ts_cbranch_scc1 83f\n"
-        "\ts_bfe_u32 s47, s46, 0x50014\n"
-        "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
-        "\ts_sub_i32 s42, s42, s47\n"
-        "\ts_bfe_u32 s47, s46, 0x40010\n"
-        "\ts_bfm_b32 s48, s47, 0\n"
-        "\ts_and_b32 s48, s48, s40\n"
-        "\ts_and_b32 s52, s46, 0x7fff\n"
+        // (build_dlut64: the entry's low word is the operand that takes the extra bits from behind the code, its high word the base)
+        "\tv_readfirstlane_b32 s52, %[vh]\n"
+        "\ts_bfe_u32 s48, s40, s46\n"
         "\ts_add_i32 s52, s52, s48\n"
+        "\ts_bfe_u32 s47, s46, 0x50017\n"
         "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
         "\ts_sub_i32 s42, s42, s47\n"
         // ---- invalid: a source in front of the block's output, output beyond the block's size
@@ -608,7 +630,7 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_mov_b32 %[dist], s52\n"
         "\ts_mov_b32 %[reason], s50"
         : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [len] "+s"(len), [dist] "+s"(dist),
-          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [ve] "=&v"(ve), [vslot] "=&v"(vslot), [vsrc] "=&v"(vsrc), [e] "=s"(ee), [reason] "=s"(reason)
+          [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [ve] "=&v"(ve), [vh] "=&v"(vh), [vslot] "=&v"(vslot), [vsrc] "=&v"(vsrc), [e] "=s"(ee), [reason] "=s"(reason)
         : [wb] "s"(wb), [us2] "s"(us2), [din] "s"(din), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lh] "v"(lh), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
         : "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",
           "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "m0", "scc", "vcc", "memory");
@@ -747,7 +769,7 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             __builtin_amdgcn_wave_barrier();
             if (!build_code(lens, 288, sym_ll, ll) || !build_code(lens + 288, 30, sym_d, dd)) return false;
             build_lut2(ll, sym_ll, lens, lut2);
-            build_dlut(dd, sym_d, lens + 288, dlut);
+            build_dlut64(dd, sym_d, lens + 288, dlut);
         } else {           // dynamic code (3.2.7)
             const int hlit = (int)b.take(5) + 257, hdist = (int)b.take(5) + 1, hclen = (int)b.take(4) + 4;
             if (hlit > 286 || hdist > 30) return false;
@@ -781,7 +803,7 @@ __device__ __forceinline__ bool inflate_block(const uint8_t* comp, int64_t comp_
             if (lens[32 + 256] == 0) return false;   // no end-of-block code
             if (!build_code(lens + 32, hlit, sym_ll, ll) || !build_code(lens + 32 + hlit, hdist, sym_d, dd)) return false;
             build_lut2(ll, sym_ll, lens + 32, lut2);
-            build_dlut(dd, sym_d, lens + 32 + hlit, dlut);
+            build_dlut64(dd, sym_d, lens + 32 + hlit, dlut);
         }
         // the symbols: sym_run does the common cases without leaving its asm block; what it hands back is rare
         for (;;) {
@@ -827,7 +849,7 @@ static __global__ __launch_bounds__(BLOCK) void k_bgzf_inflate(Args a) {
     __shared__ uint32_t s_ob[WAVES][OB_SLOTS];   // sym_run_ob's output buffer; between its calls (it leaves it empty) the code lengths of a block header
     static_assert(OB_FLUSH == 128 && OB_SLOTS >= OB_FLUSH + 64 && OB_SLOTS * 4 >= 320 + 64, "the code lengths share the output buffer");
     __shared__ uint32_t s_lut[WAVES][1 << LUT_BITS];
-    __shared__ uint32_t s_dlut[WAVES][1 << DLUT_BITS];
+    __shared__ uint32_t s_dlut[WAVES][2 << DLUT_BITS];   // (64-bit entries: build_dlut64)
     __shared__ uint32_t s_crc_tab[256], s_x2n[32];
     crc_tables(s_crc_tab, s_x2n);
     __syncthreads();
