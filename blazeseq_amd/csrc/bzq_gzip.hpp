@@ -242,7 +242,7 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
     asm volatile(
         "\ts_mov_b64 s[68:69], exec\n"
         "\ts_mov_b64 s[40:41], %[buf]\n"
-        "\ts_mov_b32 s42, %[cnt]\n"
+        "\ts_sub_i32 s42, %[cnt], 33\n"
         "\ts_mov_b32 s43, %[next]\n"
         "\ts_mov_b32 s44, %[pos]\n"
         "\ts_mov_b32 s51, %[len]\n"
@@ -273,8 +273,9 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_branch 30f\n"
         // ---- a symbol: look up (lanes 0 and 1 are the active ones here)
         "1:\n"
-        "\ts_cmp_gt_i32 s42, 32\n"
+        "\ts_cmp_ge_i32 s42, 0\n"
         "\ts_cbranch_scc0 10f\n"
+        "2:\n"
         "\tv_bfe_u32 %[vt], s40, 0, 10\n"
         "\tv_lshl_add_u32 %[vt], %[vt], 2, s55\n"
         "\tds_read_b32 %[ve], %[vt]\n"
@@ -291,7 +292,12 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\tv_lshl_add_u32 %[vslot], s47, 2, %[vslot]\n"
         "\ts_bfe_u32 s47, s46, 0x50010\n"
         "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
-        "\ts_sub_i32 s42, s42, s47\n"
+        // (s42 = bits in the buffer - 33, >= 0 here: the subtraction's borrow IS "fewer than 33 left"; then the room test of label 8 in
+        // place -- two scalar instructions fewer per lookup than the branch to 8 and its two tests; inf::sym_run_ob has the same)
+        "\ts_sub_u32 s42, s42, s47\n"
+        "\ts_cbranch_scc1 13f\n"
+        "\ts_cmp_le_i32 s64, s67\n"
+        "\ts_cbranch_scc1 2b\n"
         "\ts_branch 8b\n"
         // ---- not a literal: a length symbol with its base and extra bits folded into the entry (the entry is the s_bfe operand)
         "3:\n"
@@ -305,7 +311,7 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_sub_i32 s42, s42, s47\n"
         // ---- the distance
         "4:\n"
-        "\ts_cmp_gt_i32 s42, 32\n"
+        "\ts_cmp_ge_i32 s42, 0\n"
         "\ts_cbranch_scc0 11f\n"
         "\tv_bfe_u32 %[vt], s40, 0, 8\n"
         "\tv_lshl_add_u32 %[vt], %[vt], 2, s56\n"
@@ -358,6 +364,8 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_add_i32 s64, s64, s51\n"
         "\tv_lshl_add_u32 %[vslot], s51, 2, %[vslot]\n"
         "\ts_mov_b32 s51, 0\n"
+        "\ts_cmp_le_i32 s64, s67\n"
+        "\ts_cbranch_scc1 1b\n"
         "\ts_branch 8b\n"
         // (first page) lanes with q < 0 write the marker q & 0xFFFF themselves
         "64:\n"
@@ -473,32 +481,47 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_cbranch_scc1 80f\n"
         "\tv_readlane_b32 s48, %[win], s47\n"
         "\ts_mov_b32 s49, 0\n"
-        "\ts_lshl_b64 s[48:49], s[48:49], s42\n"
+        "\ts_add_i32 s47, s42, 33\n"
+        "\ts_lshl_b64 s[48:49], s[48:49], s47\n"
         "\ts_or_b64 s[40:41], s[40:41], s[48:49]\n"
         "\ts_add_i32 s42, s42, 32\n"
         "\ts_add_i32 s43, s43, 1\n"
         "\ts_branch 1b\n"
+        "13:\n"
+        "\ts_sub_i32 s47, s43, s54\n"
+        "\ts_cmp_gt_i32 s47, 63\n"
+        "\ts_cbranch_scc1 80f\n"
+        "\tv_readlane_b32 s48, %[win], s47\n"
+        "\ts_mov_b32 s49, 0\n"
+        "\ts_add_i32 s47, s42, 33\n"
+        "\ts_lshl_b64 s[48:49], s[48:49], s47\n"
+        "\ts_or_b64 s[40:41], s[40:41], s[48:49]\n"
+        "\ts_add_i32 s42, s42, 32\n"
+        "\ts_add_i32 s43, s43, 1\n"
+        "\ts_branch 8b\n"
         "11:\n"
         "\ts_sub_i32 s47, s43, s54\n"
         "\ts_cmp_gt_i32 s47, 63\n"
         "\ts_cbranch_scc1 80f\n"
         "\tv_readlane_b32 s48, %[win], s47\n"
         "\ts_mov_b32 s49, 0\n"
-        "\ts_lshl_b64 s[48:49], s[48:49], s42\n"
+        "\ts_add_i32 s47, s42, 33\n"
+        "\ts_lshl_b64 s[48:49], s[48:49], s47\n"
         "\ts_or_b64 s[40:41], s[40:41], s[48:49]\n"
         "\ts_add_i32 s42, s42, 32\n"
         "\ts_add_i32 s43, s43, 1\n"
         "\ts_branch 4b\n"
         // (on the way out through 6 the bit buffer is as full as on every other way out: the caller decodes a symbol from it)
         "12:\n"
-        "\ts_cmp_gt_i32 s42, 32\n"
+        "\ts_cmp_ge_i32 s42, 0\n"
         "\ts_cbranch_scc1 86f\n"
         "\ts_sub_i32 s47, s43, s54\n"
         "\ts_cmp_gt_i32 s47, 63\n"
         "\ts_cbranch_scc1 80f\n"
         "\tv_readlane_b32 s48, %[win], s47\n"
         "\ts_mov_b32 s49, 0\n"
-        "\ts_lshl_b64 s[48:49], s[48:49], s42\n"
+        "\ts_add_i32 s47, s42, 33\n"
+        "\ts_lshl_b64 s[48:49], s[48:49], s47\n"
         "\ts_or_b64 s[40:41], s[40:41], s[48:49]\n"
         "\ts_add_i32 s42, s42, 32\n"
         "\ts_add_i32 s43, s43, 1\n"
@@ -562,7 +585,7 @@ __device__ __forceinline__ int sym_run_gz(GBits& b, const uint32_t* lut2, const 
         "\ts_branch 30b\n"
         "91:\n"
         "\ts_mov_b64 %[buf], s[40:41]\n"
-        "\ts_mov_b32 %[cnt], s42\n"
+        "\ts_add_i32 %[cnt], s42, 33\n"
         "\ts_mov_b32 %[next], s43\n"
         "\ts_mov_b32 %[pos], s44\n"
         "\ts_mov_b32 %[e], s46\n"
