@@ -300,7 +300,7 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
     int cnt = (int)uni((uint32_t)b.cnt), next = (int)uni((uint32_t)b.next), pos = (int)uni((uint32_t)st.pos);
     int len = (int)uni((uint32_t)st.len), dist = 0;
     const int din = (int)uni((uint32_t)st.dist);   // != 0: the match's distance is known (the caller decoded a long distance code): straight to the copy
-    const int wb = (int)uni((uint32_t)b.win_base), us2 = (int)uni((uint32_t)(usize - 2));
+    const int wb = (int)uni((uint32_t)b.win_base), us2 = (int)uni((uint32_t)(usize - 2)), us = (int)uni((uint32_t)usize);
     const uint32_t lds = uni((uint32_t)(uintptr_t)lut2), ldd = uni((uint32_t)(uintptr_t)dlut), ldo = uni((uint32_t)(uintptr_t)obuf);
     const u64 ob = ((u64)uni((uint32_t)((uintptr_t)out >> 32)) << 32) | uni((uint32_t)(uintptr_t)out);
     const uint32_t lane = threadIdx.x & 63, lane4 = lane << 2, sh8 = lane << 3;
@@ -313,6 +313,7 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_mov_b32 s44, %[pos]\n"
         "\ts_mov_b32 s51, %[len]\n"
         "\ts_mov_b32 s53, %[us2]\n"
+        "\ts_mov_b32 s63, %[us]\n"
         "\ts_mov_b32 s54, %[wb]\n"
         "\ts_mov_b32 s55, %[lds]\n"
         "\ts_mov_b32 s56, %[ldd]\n"
@@ -374,11 +375,10 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_add_i32 s51, s51, s48\n"
         "\ts_bfe_u32 s47, s46, 0x50017\n"
         "\ts_lshr_b64 s[40:41], s[40:41], s47\n"
-        "\ts_sub_i32 s42, s42, s47\n"
-        // ---- the distance
-        "4:\n"
-        "\ts_cmp_ge_i32 s42, 0\n"
-        "\ts_cbranch_scc0 11f\n"
+        "\ts_sub_u32 s42, s42, s47\n"       // (s42 >= 0 here: the borrow is the refill test; 11 comes back through label 4)
+        "\ts_cbranch_scc1 11f\n"
+        // ---- the distance (label 4, out of line: the ways in with a length pending -- the call's start, a refill)
+        "5:\n"
         "\tv_bfe_u32 %[vt], s40, 0, 8\n"
         "\tv_lshl_add_u32 %[vt], %[vt], 3, s56\n"
         "\tds_read_b32 %[ve], %[vt]\n"
@@ -400,8 +400,7 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_cmp_gt_u32 s52, s47\n"
         "\ts_cbranch_scc1 85f\n"
         "\ts_add_i32 s48, s47, s51\n"
-        "\ts_sub_i32 s48, s48, 2\n"
-        "\ts_cmp_gt_i32 s48, s53\n"
+        "\ts_cmp_gt_i32 s48, s63\n"
         "\ts_cbranch_scc1 85f\n"
         // ---- the common kind: up to 63 bytes, not overlapping itself (the others: 70, in pieces)
         "\ts_min_u32 s48, s52, 63\n"
@@ -509,6 +508,10 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_waitcnt lgkmcnt(0)\n"
         "\tds_write_b32 %[vt], %[vt2]\n"
         "\ts_branch 43b\n"
+        "4:\n"
+        "\ts_cmp_ge_i32 s42, 0\n"
+        "\ts_cbranch_scc1 5b\n"
+        "\ts_branch 11f\n"
         // ---- the bit buffer's refills (every ~5 symbols: out of the way)
         "10:\n"
         "\ts_sub_i32 s47, s43, s54\n"
@@ -631,7 +634,7 @@ __device__ __forceinline__ int sym_run_ob(BitsT& b, const uint32_t* lut2, const 
         "\ts_mov_b32 %[reason], s50"
         : [buf] "+s"(buf), [cnt] "+s"(cnt), [next] "+s"(next), [pos] "+s"(pos), [len] "+s"(len), [dist] "+s"(dist),
           [vt] "=&v"(vt), [vt2] "=&v"(vt2), [vq] "=&v"(vq), [ve] "=&v"(ve), [vh] "=&v"(vh), [vslot] "=&v"(vslot), [vsrc] "=&v"(vsrc), [e] "=s"(ee), [reason] "=s"(reason)
-        : [wb] "s"(wb), [us2] "s"(us2), [din] "s"(din), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lh] "v"(lh), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
+        : [wb] "s"(wb), [us2] "s"(us2), [us] "s"(us), [din] "s"(din), [win] "v"(b.win), [lane] "v"(lane), [lane4] "v"(lane4), [sh8] "v"(sh8), [lh] "v"(lh), [lds] "s"(lds), [ldd] "s"(ldd), [obuf] "s"(ldo), [ob] "s"(ob)
         : "s40", "s41", "s42", "s43", "s44", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61",
           "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "m0", "scc", "vcc", "memory");
     b.buf = buf; b.cnt = cnt; b.next = next; st.pos = pos; st.len = len; st.dist = dist; st.e = ee;
