@@ -1197,8 +1197,8 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
         HIPCHK(c, hipSetDevice(c->device));
         (key[0] == 'p' ? bzq::cache::pinned_pool() : bzq::cache::device_pool()).trim((uint64_t)value, false);
     }
-    else if (!strcmp(key, "buf_cache_hits")) { const uint64_t h = bzq::cache::pinned_pool().hits + bzq::cache::device_pool().hits; return (int32_t)std::min<uint64_t>(h, 0x7FFFFFFF); }   // query
-    else if (!strcmp(key, "buf_cache_held_mb")) return (int32_t)((bzq::cache::pinned_pool().held + bzq::cache::device_pool().held) >> 20);   // query
+    else if (!strcmp(key, "buf_cache_hits")) { const uint64_t h = bzq::cache::pinned_pool().hits_now() + bzq::cache::device_pool().hits_now(); return (int32_t)std::min<uint64_t>(h, 0x7FFFFFFF); }   // query
+    else if (!strcmp(key, "buf_cache_held_mb")) return (int32_t)((bzq::cache::pinned_pool().held_now() + bzq::cache::device_pool().held_now()) >> 20);   // query
     else if (!strcmp(key, "pass_bytes")) c->cfg.pass_bytes = value > 0 ? std::max<int64_t>(TILE, (value / TILE) * TILE) : 0;
     else { c->err = std::string("unknown option ") + key; return BZQ_ERR_ARG; }
     return 0;

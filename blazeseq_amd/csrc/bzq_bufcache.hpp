@@ -178,6 +178,9 @@ struct Pool {
         }
         if (!keep && known) raw_free(e);
     }
+    // the counters, read under the lock (the option queries of bzq_set_option: another thread may be inside get / put)
+    uint64_t hits_now() { std::lock_guard<std::mutex> lk(mu); return hits; }
+    uint64_t held_now() { std::lock_guard<std::mutex> lk(mu); return held; }
     // give buffers back to the driver until at most `keep_bytes` are held; set_limit: that is also the new limit
     void trim(uint64_t keep_bytes, bool keep_limit) {
         std::vector<Entry> drop;
@@ -195,7 +198,7 @@ struct Pool {
 };
 
 // defaults: ONE set of chunk buffers each (three 288 MiB slots) -- what a process that reads plain or BGZF files one after the other
-// needs.  A host that decodes .gz after .gz raises dev_cache_bytes (its pools and FIFOs are ~12 GiB per stream).
+// needs.  A host that decodes .gz after .gz raises dev_cache_bytes (its pools and FIFO are ~8 GiB per stream).
 inline Pool& pinned_pool() { static Pool* p = new Pool(true, 1ull << 30); return *p; }
 inline Pool& device_pool() { static Pool* p = new Pool(false, 1ull << 30); return *p; }
 
