@@ -81,7 +81,8 @@ while time.time() - t0 < args.seconds:
     # the piece's own copy, the hand-over of a stretch without findable block starts to the host and back -- in every combination
     ahead = int(rng.choice([0, 0, 1, 2, 3])) if piece_size else 0
     g.dec.set_option("predecode", int(rng.random() < 0.8))
-    g.dec.set_option("early_find", int(rng.random() < 0.5))   # (the product ignores it; the EXPERIMENTS library has the variant)
+    g.dec.set_option("early_find", int(rng.random() < 0.5))
+    g.dec.set_option("chain_l2", int(rng.random() < 0.5))     # round 5: beside a predecode, the chain kernels that read their window through the L2
     hc = int(rng.random() < 0.5)   # half of the streams: the device alone (nothing of the result comes from zlib, the checker)
     g.dec.set_option("host_continuation", hc)
     g.dec.set_option("far_kib", int(rng.choice([16, 64, 256])))
