@@ -395,7 +395,7 @@ def test_device_memory_a_gz_stream_holds():
     """'bound the gzip pool ... with a test that asserts the hipMemGetInfo delta'.  A .gz stream's device memory scales with
     chunk_bytes: two symbol pools (pages for the piece's output at the stream's own ratio + one page per decoder job: ~13 x the
     compressed piece each, 3.3 GiB at a 256 MiB piece), ONE output FIFO of 6 x chunk_bytes, three slots, three buffers of compressed
-    bytes, the parser's own arenas: **3.5 GiB at 64 MiB chunks, 8.6 GiB at the default 256 MiB** (rounds 3-5: 5.6 / 13.2 -- pools
+    bytes, the parser's own arenas: **3.5 GiB at 64 MiB chunks, 10.6 GiB at the default 256 MiB** (rounds 3-5: 5.6 / 13.2 and more -- pools
     reserved for a ratio of 5 and two pages per job, and a second FIFO that every chunk's remainder moved to).  The pools alone are
     now below the 4 GiB VERDICT asked for at 128 MiB pieces and not at 256 MiB (smaller pieces cost rate,
     profiles/r5_gzip_piece_sweep.txt); what is pinned here is that the footprint is what INTEGRATION.md says and does not double
@@ -413,17 +413,20 @@ def test_device_memory_a_gz_stream_holds():
         f, t = C.c_size_t(), C.c_size_t()
         assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
         return f.value
-    data = synthetic_fastq(2_600_000)   # 0.83 GB of FASTQ
+    # 1.7 GB of FASTQ, 0.8 GB compressed: four pieces at the default chunk size, so that BOTH pools have seen a whole-chunk piece (a
+    # shorter file ends before the first pool, sized for the stream's first half-chunk piece, has grown: 8.6 GiB instead of 10.1)
+    n_member, reps = 100_000, 54
+    member = gzip_member(synthetic_fastq(n_member), 6)
+    n_total = n_member * reps
     path = "/dev/shm/bzq_footprint_test.fastq.gz" if os.path.isdir("/dev/shm") else "/tmp/bzq_footprint_test.fastq.gz"
-    k = 32 << 20
     with open(path, "wb") as f:
-        for i in range(0, len(data), k):
-            f.write(gzip_member(data[i:i + k], 6))
+        for _ in range(reps):
+            f.write(member)
     try:
         ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
         for key in ("pin_cache_bytes", "dev_cache_bytes"):
             ctx.set_option(key, 0)
-        for chunk_mib, limit_gib in ((64, 4.2), (256, 10.0)):   # measured 3.48 / 8.55 GiB (round 5, after the pool / FIFO diet; 5.62 / 13.24 before), parser arenas included
+        for chunk_mib, limit_gib in ((64, 4.6), (256, 11.5)):   # measured 3.48 / 10.58 GiB (round 5, after the pool / FIFO diet; 5.62 / 13.24 on a file of two pieces before), parser arenas included
             assert hip.hipDeviceSynchronize() == 0
             free0 = mem_free()
             ing = B.Ingest(ctx, path, chunk_bytes=chunk_mib << 20, n_threads=4)
@@ -435,12 +438,12 @@ def test_device_memory_a_gz_stream_holds():
                 low = min(low, mem_free())
                 if int(r.status) != L.OK:
                     break
-            assert total == 2_600_000 and int(r.status) == L.EOF
+            assert total == n_total and int(r.status) == L.EOF
             held = (free0 - low) / 2**30
             ing.close()
             assert hip.hipDeviceSynchronize() == 0
-            assert held <= limit_gib, f"chunk {chunk_mib} MiB: the stream held {held:.2f} GiB of device memory (limit {limit_gib})"
             print(f"chunk {chunk_mib} MiB: {held:.2f} GiB")
+            assert held <= limit_gib, f"chunk {chunk_mib} MiB: the stream held {held:.2f} GiB of device memory (limit {limit_gib})"
         for key in ("pin_cache_bytes", "dev_cache_bytes"):
             ctx.set_option(key, 1 << 30)
         ctx.close()
