@@ -140,6 +140,7 @@ struct bzq_ctx {
     bool fold = false;         // ... decided per chunk (decide_fold)
     bool cum_valid = false;    // the current chunk's chunk-cumulative ends / id_ends hold values (always without fold; with it: after bzq_chunk_cumulative_ends)
     bool finish_done = false;  // k_tail of this submit already left the chunk totals (enqueue_rebase skips k_finish once)
+    int stream_prio = 0; bool stream_has_prio = false;   // the priority `stream` was created with (stream_init gets the same)
     bool published = false;    // ... and wrote the chunk state and the batch table into the host's pinned copies itself (no copy packets behind the kernels)
     // the state's initial values travel on a stream of their own while pass A runs (it does not look at the state); the scan waits for them
     hipStream_t stream_init = nullptr;
@@ -1069,7 +1070,7 @@ int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
         // stream's long kernel (rocprofv3 timeline of the BGZF ingest, round 4: the parse of chunk k waited for the inflate of k + 1)
         int lo = 0, hi = 0;
         const char* e = getenv("BZQ_STREAM_PRIORITY");   // (measurements: 0 = a stream of the default class)
-        if ((!e || e[0] != '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) CRT(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+        if ((!e || e[0] != '0') && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo) { CRT(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi)); c->stream_prio = hi; c->stream_has_prio = true; }
         else CRT(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     }
     CRT(hipMalloc((void**)&c->d_state, sizeof(ChunkState)));
@@ -1079,7 +1080,10 @@ int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
     for (auto& ev : c->ev) CRT(hipEventCreate(&ev));
     { const char* e = getenv("BZQ_LEAN_SUBMIT"); if (e && e[0] == '0') c->lean = 0; }   // (bisecting aid: option lean_submit for a whole process)
     // (a stream and an event for the state's initial values: see submit_common; without them the copy stays on the ctx stream)
-    if (hipStreamCreateWithFlags(&c->stream_init, hipStreamNonBlocking) != hipSuccess) { c->stream_init = nullptr; (void)hipGetLastError(); }
+    // IN THE PARSER'S PRIORITY CLASS: a stream of the default class shares the four hardware queues of that class with the ingest's
+    // copy / inflate streams, and the scan, which waits for this copy, then sits behind a 5 ms inflate kernel -- in a process that had
+    // created few streams before, the BGZF ingest ran at 30 GB/s instead of 44 (bench.py --ingest-only against the default line)
+    if ((c->stream_has_prio ? hipStreamCreateWithPriority(&c->stream_init, hipStreamNonBlocking, c->stream_prio) : hipStreamCreateWithFlags(&c->stream_init, hipStreamNonBlocking)) != hipSuccess) { c->stream_init = nullptr; (void)hipGetLastError(); }
     if (hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess) { c->ev_init = nullptr; (void)hipGetLastError(); }
 #undef CRT
     *out = c;
