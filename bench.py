@@ -40,6 +40,59 @@ TRAFFIC_KERNEL_UNFOLDED = "k_fused<false, false, false, false>"
 TRAFFIC_RECORDS = 10_000_000   # the profiled launch: 10 M x 150 bp
 
 
+def launch_ranks(nranks, argv, script=None, deadline_s=3600.0, poll_s=0.05):
+    """`python3 bench.py --gpus N` typed as ONE command (the reference's harness is one command per run,
+    benchmark/throughput/run_throughput_benchmarks.sh:56-62): this process becomes the launcher of N ranks of the same
+    script, one per GPU -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR (127.0.0.1) / MASTER_PORT (a free one) in each
+    child's environment, exactly what torch.distributed.run would set.  Rank 0 owns this process's stdout (its ONE JSON
+    line is the launcher's); the other ranks' stdout goes to stderr.  The first rank that exits non-zero is NAMED, the
+    others are stopped (by their own PIDs) and the launcher exits with that rank's code; the same when the deadline
+    passes.  Returns the exit code (0 = every rank exited 0)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    script = script or os.path.abspath(__file__)
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                   GROUP_RANK="0", ROLE_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BZQ_BENCH_LAUNCHER_PID=str(os.getpid()))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this host driver
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+    t_end = time.monotonic() + deadline_s
+    failed = None
+    live = set(range(nranks))
+    while live and failed is None:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                failed = (r, rc, f"rank {r} of {nranks} (pid {procs[r].pid}) exited with code {rc}")
+                break
+        if failed is None and live and time.monotonic() > t_end:
+            failed = (min(live), 124, f"deadline of {deadline_s:.0f} s passed with rank(s) {sorted(live)} of {nranks} still running")
+        if live and failed is None:
+            time.sleep(poll_s)
+    if failed is None:
+        return 0
+    for r in sorted(live):   # stop what is left: exactly the PIDs started here
+        if procs[r].poll() is None:
+            procs[r].terminate()
+    t_kill = time.monotonic() + 10.0
+    for r in sorted(live):
+        try:
+            procs[r].wait(timeout=max(0.1, t_kill - time.monotonic()))
+        except Exception:   # noqa: BLE001
+            procs[r].kill()
+            procs[r].wait()
+    print(f"[bench launcher] FAILED: {failed[2]}; the other ranks were stopped; no JSON line is valid for this run", file=sys.stderr, flush=True)
+    return failed[1] if 0 < failed[1] < 256 else 1
+
+
 def profile_traffic(path=TRAFFIC_PROFILE, kernel=TRAFFIC_KERNEL):
     """(FETCH_SIZE, WRITE_SIZE) per dispatch of `kernel`, in the counter's unit (KiB), from a scripts/summarize_prof.py text."""
     vals, section, cur = {}, None, None
@@ -660,7 +713,13 @@ def main():
     ap.add_argument("--ingest-chunk-mib", type=int, default=256, help="chunk size of the ingest_mode runs")
     ap.add_argument("--ingest-threads", type=int, default=8, help="reader threads of the ingest_mode runs")
     ap.add_argument("--ingest-only", action="store_true", help="print only ingest_mode (sweeps of the two options above)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help="harness check: this rank exits with code 3 before it joins anything (the launcher must name it)")
+    ap.add_argument("--launch-deadline", type=float, default=3600.0, help="self-launched ranks (--gpus N without a launcher): stop everything after this many seconds")
     args = ap.parse_args()
+
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1 and "BZQ_BENCH_LAUNCHER_PID" not in os.environ:
+        # the plain command `python3 bench.py --gpus N ...`: start the N ranks here (torch.distributed.run remains welcome: it sets WORLD_SIZE)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], deadline_s=args.launch_deadline))
 
     import torch
     import torch.distributed as dist
@@ -670,10 +729,12 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if args.fail_rank == rank and world > 1:
+        print(f"[bench rank {rank}] --fail-rank: exiting with code 3", file=sys.stderr, flush=True)
+        sys.exit(3)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: the launcher (python -m torch.distributed.run, or this file's own) must start exactly --gpus ranks")
     one_gpu = args.ranks_on_one_gpu > 0
     if one_gpu:
         if args.ranks_on_one_gpu != world:

@@ -79,3 +79,23 @@ def test_bench_from_file_mode_shards_one_file_across_the_ranks():
     assert out["ranks_seen"] == 3 and all(r["reader_threads"] == 3 and r["reader_cpus_bound"] >= 0 for r in out["ranks"])
     total_bytes = reads * 3 * out["config"]["record_bytes"]
     assert abs(out["value"] - total_bytes / (out["ms_per_step"] * 1e-3) / 1e9) <= 0.01 * out["value"] + 0.01
+
+
+@pytest.mark.gpu
+def test_plain_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT torch.distributed.run in front -- bench.py starts the ranks itself
+    (bench.launch_ranks), rank 0 prints the ONE line, every rank's row reached the library's summary all-gather."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--ranks-on-one-gpu", "2", "--reads", "200000",
+           "--steps", "3", "--warmup", "1", "--min-seconds", "0.05"]
+    r = subprocess.run(cmd, capture_output=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and sorted(x["rank"] for x in out["ranks"]) == [0, 1]
+    assert out["config"]["exchange"] == "native" and out["steps"] == 3
+    # a rank that dies takes the run down with its name (no JSON line): rank 1 is told to use a device that does not exist
+    bad = subprocess.run(cmd + ["--fail-rank", "1"], capture_output=True, timeout=600, cwd=ROOT, env=env)
+    assert bad.returncode != 0 and "rank 1 of 2" in bad.stderr.decode()
+    assert not [ln for ln in bad.stdout.decode().splitlines() if ln.startswith("{")]
