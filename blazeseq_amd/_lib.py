@@ -50,7 +50,7 @@ class BzqChunk(C.Structure):
         ("d_qual_start", C.c_void_p),
         ("ms_total", C.c_float), ("ms_aggregate", C.c_float), ("ms_scan", C.c_float),
         ("ms_emit", C.c_float), ("ms_rebase", C.c_float),
-        ("n_passes", C.c_uint32), ("_pad", C.c_uint32),
+        ("n_passes", C.c_uint32), ("chunk_serial", C.c_uint32),
         ("d_id_start", C.c_void_p), ("d_id_len", C.c_void_p),
     ]
 

@@ -87,6 +87,7 @@ struct OutSet {
     // the set a bzq_chunk points into: the current one or, under the double-buffer contract, the one before it)
     bool fold = false, cum_valid = false, parsed = false;
     int64_t batch = 0, n_records = 0;
+    uint32_t serial = 0;   // ... and which submit it was (bzq_chunk::chunk_serial): bzq_chunk_cumulative_ends refuses a stale bzq_chunk
     std::vector<DevBuf> view_blocks;
     size_t view_used = 0;          // bytes used in view_blocks.back()
     size_t view_next = 4u << 20;   // size of the next block
@@ -146,6 +147,10 @@ struct bzq_ctx {
     hipStream_t stream_init = nullptr;
     hipEvent_t ev_init = nullptr;
     bool init_in_flight = false;
+    bool init_deferred = false;   // ... and are handed to the side stream only BEHIND pass A's launch (the host's copy call is not in front of the first kernel)
+    int init_in_kernel = 0;    // diagnostic option "state_init_in_kernel" (1 / 2: ScanArgs::init_mode); DESIGN 10
+    bool init_by_kernel_now = false;
+    int64_t h_init[4] = {0, 0, 0, 0};
     int lean = 1;              // option "lean_submit": 0 = state copies on the ctx stream, before and behind the kernels (as before)
     DevBuf tile_last, tileB, btile;
     // bzq_shard_read_range: the rank's byte range of a file in device memory, and the pinned pieces it travelled through
@@ -172,9 +177,16 @@ struct bzq_ctx {
     int cur_is_eof = 0;
     uint32_t cur_prev_byte = 10;
     int64_t cur_first_header = 0;
+    int64_t last_dense_tiles = 0;   // query "dense_tiles": tiles of the last parsed chunk that took the serial path (diagnostic)
     bool pending = false, have_result = false;
     int64_t n_passes = 0;
     bzq_chunk res{};
+    // The chunk `res` describes lives in out[res_set] and stays there until the SECOND submit after its own (the double-buffer
+    // contract): bzq_batch_view / bzq_batches / bzq_views keep serving it while the NEXT chunk is already being parsed, so a host can
+    // take a result, submit the next chunk at once and walk the batches of the one it holds under the parse of the next.
+    int res_set = 0;
+    bool res_alive = false;
+    const uint8_t* res_cur = nullptr;   // the device chunk `res` belongs to (bzq_device_views::chunk)
     // terminal-status details for bzq_format_error
     int term_phase = 0;
     int64_t term_cap = 0;
@@ -302,6 +314,7 @@ int begin_submit(bzq_ctx* c) {
     if (c->pending) HIPCHK(c, hipStreamSynchronize(c->stream)); // h_state is reused
     if (c->double_buffer) c->cur_set = (int)(c->n_submits & 1);
     c->n_submits += 1;
+    if (!c->double_buffer || c->cur_set == c->res_set) c->res_alive = false;   // the set the last result lives in is written again
     OutSet& o = c->o();
     if (o.view_blocks.size() > 1) {   // settle on one block as large as everything the last chunk needed
         size_t total = 0;
@@ -314,8 +327,7 @@ int begin_submit(bzq_ctx* c) {
 }
 
 // storage for the rebased ends of one unaligned batch view: stays where it is until the set is recycled
-int view_alloc(bzq_ctx* c, size_t bytes, void** out) {
-    OutSet& o = c->o();
+int view_alloc(bzq_ctx* c, OutSet& o, size_t bytes, void** out) {
     bytes = (bytes + 255) & ~(size_t)255;
     if (o.view_blocks.empty() || o.view_used + bytes > o.view_blocks.back().cap) {
         DevBuf b;
@@ -440,9 +452,8 @@ void ensure_bb(bzq_ctx* c) {
 
 // Chunk-cumulative ends / id_ends at record r of the current chunk, on the host (cold paths: a stream cut short by an error, a
 // batch view that is not batch aligned).  With fold the emit wrote only the per-batch arrays: value + the batch's base.
-int cum_pair(bzq_ctx* c, int64_t r, int64_t out[2]) {
-    const OutSet& o = c->o();
-    if (!c->fold || c->cum_valid) {
+int cum_pair(bzq_ctx* c, const OutSet& o, bool fold, bool cum_valid, int64_t r, int64_t out[2]) {
+    if (!fold || cum_valid) {
         HIPCHK(c, hipMemcpy(&out[0], (const int64_t*)o.ends.p + r, 8, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(&out[1], (const int64_t*)o.id_ends.p + r, 8, hipMemcpyDeviceToHost));
         return 0;
@@ -455,6 +466,7 @@ int cum_pair(bzq_ctx* c, int64_t r, int64_t out[2]) {
     out[0] += base[0]; out[1] += base[1];
     return 0;
 }
+int cum_pair(bzq_ctx* c, int64_t r, int64_t out[2]) { return cum_pair(c, c->o(), c->fold, c->cum_valid, r, out); }
 
 // Can this chunk go without k_rebase?  One pass over the chunk (the bases of a later sub-chunk pass are not known when an
 // earlier one is emitted), at most one batch boundary per fast-path tile, no host-SIMD-width quirk of the quality check
@@ -630,7 +642,9 @@ void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, int pass) {
     ScanArgs s{tb, te, (const uint32_t*)c->tile_c.p, (const u64*)c->tile_a.p, (const u64*)c->tile_idc.p,
                (int64_t*)c->tileP.p, (int64_t*)c->tileS.p, (int64_t*)c->tileQ.p, (int64_t*)c->tileI.p,
                (int64_t*)c->grp.p, c->d_state, pass, c->fold ? (int32_t*)c->tileB.p : nullptr, std::max<int64_t>(1, c->cfg.batch_size),
-               c->fold ? (int64_t*)c->btile.p : nullptr, c->fold ? c->o().bb_cap : 0, views_meta(c) ? c->d_pool : nullptr};
+               c->fold ? (int64_t*)c->btile.p : nullptr, c->fold ? c->o().bb_cap : 0, views_meta(c) ? c->d_pool : nullptr,
+               c->init_by_kernel_now ? c->init_in_kernel : 0, {c->h_init[0], c->h_init[1], c->h_init[2], c->h_init[3]}};
+    c->init_by_kernel_now = false;   // (only the first scan of a submit: a repeat keeps what the host copied in)
     const int64_t ng = (te - tb + SG_TILES - 1) / SG_TILES;
     if (ng <= 0) return;
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)ng), dim3(SG_THREADS), 0, c->stream, s);
@@ -713,6 +727,12 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
                 else hipLaunchKernelGGL(k_tile_aggregate2, grid, dim3(BLOCK), 0, c->stream, a);
             }
             if (c->timing_detail) mark_detail(c);
+            if (c->init_deferred) {   // pass A is on its way: now the state's initial values, on the side stream
+                c->init_deferred = false;
+                HIPCHK(c, hipMemcpyAsync(c->d_state, c->h_state, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream_init));
+                HIPCHK(c, hipEventRecord(c->ev_init, c->stream_init));
+                c->init_in_flight = true;
+            }
             if (c->init_in_flight) { (void)hipStreamWaitEvent(c->stream, c->ev_init, 0); c->init_in_flight = false; }
             launch_scan(c, tb, te, (int)passes);
             if (c->fold) launch_batch_bases(c);
@@ -820,14 +840,16 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     for (int i = 0; i < 4; ++i) h->first_nl[i] = first_nl ? first_nl[i] : -1;
     // Two-pass path from the chunk's first byte: pass A never looks at the state, so its initial values travel beside it and the
     // scan waits for them (enqueue_passes) -- otherwise the copy sits in front of the kernels.
-    c->init_in_flight = false; c->published = false;
+    c->init_in_flight = false; c->init_deferred = false; c->published = false;
     const bool plain = c->lean && n > 0 && head_lines == 0 && !first_nl && !reuse_aggregates && c->stream_init && c->ev_init &&
                        (c->single_pass == 0 || c->cfg.views_only) && !c->use_stream && !c->overlap;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    if (plain) {
-        HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream_init));
-        HIPCHK(c, hipEventRecord(c->ev_init, c->stream_init));
-        c->init_in_flight = true;
+    c->init_by_kernel_now = false;
+    if (plain && c->init_in_kernel && pass_tiles(c) >= tiles_for(n)) {   // diagnostic: no copy at all, the scan's first workgroup writes the values
+        c->h_init[0] = P0; c->h_init[1] = S0; c->h_init[2] = Q0; c->h_init[3] = I0;
+        c->init_by_kernel_now = true;
+    } else if (plain) {
+        c->init_deferred = true;   // (enqueue_passes, behind pass A's launch)
     } else {
         HIPCHK(c, hipMemcpyAsync(c->d_state, h, sizeof(ChunkState), hipMemcpyHostToDevice, c->stream));
     }
@@ -1165,10 +1187,12 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     }
     else if (!strcmp(key, "stream_fallbacks")) return (int32_t)std::min<int64_t>(c->stream_fallbacks, 0x7FFFFFFF);   // query: chunks repeated on the two-pass kernels
     else if (!strcmp(key, "last_folded")) return c->fold ? 1 : 0;                                                     // query: the last chunk went without k_rebase
+    else if (!strcmp(key, "dense_tiles")) return (int32_t)std::min<int64_t>(c->last_dense_tiles, 0x7FFFFFFF);          // query
     else if (!strcmp(key, "n_submits")) return (int32_t)std::min<int64_t>(c->n_submits, 0x7FFFFFFF);                  // query: chunks submitted so far
     else if (!strcmp(key, "pass_a_h")) c->pass_a_h = value != 0;
     else if (!strcmp(key, "fold_rebase")) c->fold_opt = value != 0;
     else if (!strcmp(key, "lean_submit")) c->lean = value != 0;
+    else if (!strcmp(key, "state_init_in_kernel")) c->init_in_kernel = (int)value;
     else if (!strcmp(key, "ranks_seen")) return c->ranks_seen;   // query
     else if (!strcmp(key, "device")) return c->device;           // query
     else if (!strcmp(key, "numa_node") || !strcmp(key, "numa_cpus")) {   // query: the GPU's NUMA node / how many CPUs the reader threads are bound to (0 = not bound)
@@ -1636,16 +1660,19 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         o.h_bb_records = (!c->cfg.views_only && o.h_bb && nb > 0 && nb <= o.h_bb_batches) ? n_complete : 0;
     }
     r.n_passes = (uint32_t)c->n_passes;
-    r._pad = (uint32_t)h->dense_tiles;
+    r.chunk_serial = (uint32_t)c->n_submits;
+    c->last_dense_tiles = (int64_t)h->dense_tiles;
     c->res = r;
-    { OutSet& o = c->o(); o.fold = c->fold; o.cum_valid = !c->fold; o.parsed = !c->cfg.views_only; o.batch = std::max<int64_t>(1, c->cfg.batch_size); o.n_records = (int64_t)r.n_records; }
+    { OutSet& o = c->o(); o.fold = c->fold; o.cum_valid = !c->fold; o.parsed = !c->cfg.views_only; o.batch = std::max<int64_t>(1, c->cfg.batch_size); o.n_records = (int64_t)r.n_records;
+      o.serial = r.chunk_serial; }
     c->pending = false; c->have_result = true;
+    c->res_set = c->cur_set; c->res_alive = true; c->res_cur = c->cur;
     *out = r;
     return (r.status > 0 && r.status != BZQ_EOF) ? r.status : 0;
 }
 
 int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, bzq_device_batch* out) {
-    if (!c || !out || !c->have_result) { if (c) c->err = "bzq_batch_view: no parsed chunk"; return BZQ_ERR_ARG; }
+    if (!c || !out || !(c->have_result || c->res_alive)) { if (c) c->err = "bzq_batch_view: no parsed chunk (or two chunks have been submitted since its result was taken)"; return BZQ_ERR_ARG; }
     if (max_records == 0) { c->err = "bzq_batch_view: max_records must be > 0"; return BZQ_ERR_ARG; }
     if (c->cfg.views_only) { c->err = "bzq_batch_view: the ctx is in views mode (no columns); use bzq_views"; return BZQ_ERR_ARG; }
     const uint64_t bs = (uint64_t)c->cfg.batch_size;
@@ -1655,7 +1682,7 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
     if (first_record >= c->res.n_records) return 0; // empty batch: the iterator stops (parser.mojo:727-729)
     const uint64_t nrec = std::min<uint64_t>(max_records, c->res.n_records - first_record);
     int64_t base[2] = {0, 0}, last[2] = {0, 0};
-    const OutSet& os = c->o();
+    OutSet& os = c->out[c->res_set];   // (the set of the chunk `res` describes: the current one, or the one before while the next is in flight)
     const uint64_t lastrec = first_record + nrec - 1;
     // batch aligned inside the complete records: both ends come from the host copy of the batch-boundary table
     const bool cached = os.h_bb_records > 0 && first_record % bs == 0 && lastrec < (uint64_t)os.h_bb_records &&
@@ -1667,8 +1694,8 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
         last[0] = os.h_bb[2 * k]; last[1] = os.h_bb[2 * k + 1];
     } else {
         int rc4;
-        if (first_record > 0 && (rc4 = cum_pair(c, (int64_t)first_record - 1, base))) return rc4;
-        if ((rc4 = cum_pair(c, (int64_t)lastrec, last))) return rc4;
+        if (first_record > 0 && (rc4 = cum_pair(c, os, os.fold, os.cum_valid, (int64_t)first_record - 1, base))) return rc4;
+        if ((rc4 = cum_pair(c, os, os.fold, os.cum_valid, (int64_t)lastrec, last))) return rc4;
     }
     out->num_records = (int64_t)nrec;
     out->seq_len = last[0] - base[0];
@@ -1687,14 +1714,15 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
         // its own storage: a view handed out earlier keeps its ends (they stay valid as long as the chunk's columns)
         int rc;
         void* ve = nullptr;
-        if ((rc = view_alloc(c, (size_t)nrec * 16, &ve))) return rc;
+        if ((rc = view_alloc(c, os, (size_t)nrec * 16, &ve))) return rc;
         int64_t* e = (int64_t*)ve;
-        if (c->fold && !c->cum_valid)
+        // (on the ctx stream: behind the parse of the next chunk if one is in flight -- it writes the OTHER set)
+        if (os.fold && !os.cum_valid)
             hipLaunchKernelGGL(k_rebase_range_b, dim3((unsigned)((nrec + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream, c->res.d_batch_ends,
-                               c->res.d_batch_id_ends, (const int64_t*)c->o().bb.p, (int64_t)bs, (int64_t)first_record, (int64_t)nrec, e, e + nrec);
+                               c->res.d_batch_id_ends, (const int64_t*)os.bb.p, (int64_t)bs, (int64_t)first_record, (int64_t)nrec, e, e + nrec);
         else
             hipLaunchKernelGGL(k_rebase_range, dim3((unsigned)((nrec + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, c->stream,
-                               (const int64_t*)c->o().ends.p, (const int64_t*)c->o().id_ends.p, (int64_t)first_record, (int64_t)nrec, e, e + nrec);
+                               (const int64_t*)os.ends.p, (const int64_t*)os.id_ends.p, (int64_t)first_record, (int64_t)nrec, e, e + nrec);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         out->ends = e;
         out->id_ends = e + nrec;
@@ -1703,7 +1731,7 @@ int32_t bzq_batch_view(bzq_ctx* c, uint64_t first_record, uint32_t max_records, 
 }
 
 int32_t bzq_batches(bzq_ctx* c, uint32_t max_records, bzq_device_batch* out, uint64_t cap, uint64_t* n_out) {
-    if (!c || !n_out || (cap && !out) || !c->have_result) { if (c) c->err = "bzq_batches: no parsed chunk"; return BZQ_ERR_ARG; }
+    if (!c || !n_out || (cap && !out) || !(c->have_result || c->res_alive)) { if (c) c->err = "bzq_batches: no parsed chunk (or two chunks have been submitted since its result was taken)"; return BZQ_ERR_ARG; }
     if (max_records == 0) { c->err = "bzq_batches: max_records must be > 0"; return BZQ_ERR_ARG; }
     const uint64_t n = c->res.n_records, nb = (n + max_records - 1) / max_records;
     *n_out = nb;
@@ -1715,19 +1743,24 @@ int32_t bzq_batches(bzq_ctx* c, uint32_t max_records, bzq_device_batch* out, uin
 }
 
 int32_t bzq_chunk_cumulative_ends(bzq_ctx* c, bzq_chunk* inout) {
-    if (!c || !c->have_result) { if (c) c->err = "bzq_chunk_cumulative_ends: no parsed chunk"; return BZQ_ERR_ARG; }
+    if (!c) return BZQ_ERR_ARG;
     if (c->cfg.views_only) { c->err = "bzq_chunk_cumulative_ends: the ctx is in views mode (no columns)"; return BZQ_ERR_ARG; }
     // which chunk: the one `inout` describes -- its per-batch arrays live in exactly one output set -- else the current one.  The
     // set keeps what the derivation needs (OutSet::fold, batch, n_records), so the chunk BEFORE the current one is served too, as
     // long as it is alive (until the second submit after its own).
-    OutSet* os = &c->o();
+    // A set's pointers outlive the chunk (the arrays are reused): the chunk is recognised by its pointers AND its serial, so a
+    // bzq_chunk from two submits ago is refused instead of being served the newer chunk's ends in its name.  The set of a
+    // chunk whose successor is still in flight (no result taken yet) is served too: OutSet::parsed, not "the ctx has a result".
+    OutSet* os = nullptr;
     if (inout && inout->d_batch_ends) {
-        os = nullptr;
         for (OutSet& cand : c->out)
-            if (cand.parsed && (const int64_t*)cand.b_ends.p == inout->d_batch_ends) os = &cand;
+            if (cand.parsed && (const int64_t*)cand.b_ends.p == inout->d_batch_ends && cand.serial == inout->chunk_serial) os = &cand;
         if (!os) { c->err = "bzq_chunk_cumulative_ends: the chunk's arrays are no longer alive (two chunks have been submitted since)"; return BZQ_ERR_ARG; }
+    } else {
+        if (!c->have_result) { c->err = "bzq_chunk_cumulative_ends: no parsed chunk"; return BZQ_ERR_ARG; }
+        os = &c->o();
     }
-    const bool current = os == &c->o();
+    const bool current = os == &c->o() && c->have_result;
     if (os->fold && !os->cum_valid && os->n_records > 0) {
         HIPCHK(c, hipSetDevice(c->device));
         const int64_t n = os->n_records;
@@ -1744,11 +1777,11 @@ int32_t bzq_chunk_cumulative_ends(bzq_ctx* c, bzq_chunk* inout) {
 }
 
 int32_t bzq_views(bzq_ctx* c, uint64_t first_record, uint32_t max_records, bzq_device_views* out) {
-    if (!c || !out || !c->have_result) { if (c) c->err = "bzq_views: no parsed chunk"; return BZQ_ERR_ARG; }
+    if (!c || !out || !(c->have_result || c->res_alive)) { if (c) c->err = "bzq_views: no parsed chunk (or two chunks have been submitted since its result was taken)"; return BZQ_ERR_ARG; }
     if (!c->cfg.views_only) { c->err = "bzq_views: the ctx is not in views mode (config.views_only)"; return BZQ_ERR_ARG; }
     memset(out, 0, sizeof(*out));
     out->first_record = first_record;
-    out->chunk = c->cur;
+    out->chunk = c->res_cur;
     if (first_record >= c->res.n_records) return 0;
     out->num_records = (int64_t)std::min<uint64_t>(max_records, c->res.n_records - first_record);
     out->header_start = c->res.d_header_start + first_record; out->seq_start = c->res.d_seq_start + first_record;

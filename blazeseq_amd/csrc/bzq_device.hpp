@@ -464,6 +464,10 @@ struct ScanArgs {
     int64_t* btile;
     int64_t bb_cap;
     ViewsPool* pool;     // views mode: see ViewsPool; nullptr otherwise
+    // diagnostic (option state_init_in_kernel): the chunk state's initial values are written by workgroup 0 of
+    // k_scan_reduce instead of being copied in.  0 = off (the product's way: a copy on the side stream)
+    int32_t init_mode;
+    int64_t init0[4];    // P0, S0, Q0, I0
 };
 
 __device__ __forceinline__ int64_t field16(u64 v, int k) { return (int64_t)((v >> (16 * (k & 3))) & 0xFFFFull); }
@@ -487,6 +491,30 @@ static __global__ __launch_bounds__(SG_THREADS) void k_scan_reduce(ScanArgs a) {
     __shared__ int64_t s_acc[NW][9];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t i0 = a.tile_begin + (int64_t)blockIdx.x * SG_TILES + (int64_t)tid * SG_ITEMS;
+    if (a.init_mode && blockIdx.x == 0) {   // diagnostic only (see ScanArgs::init_mode)
+        u64* w = reinterpret_cast<u64*>(a.st);
+        constexpr int NWORDS = (int)(sizeof(ChunkState) / 8);
+        static_assert(sizeof(ChunkState) % 8 == 0, "ChunkState is a whole number of 8-byte words");
+        if (a.init_mode == 1) {   // every word by one thread, in order: no two threads store to the same word
+            if (tid == 0) {
+                ChunkState z{};
+                z.P0 = a.init0[0]; z.S0 = a.init0[1]; z.Q0 = a.init0[2]; z.I0 = a.init0[3];
+                z.P = z.P0; z.S = z.S0; z.Q = z.Q0; z.I = z.I0;
+                z.last_nl_tile = -1; z.err_struct = ~0ull; z.err_valid = ~0ull; z.err_buf = ~0ull;
+                for (int i = 0; i < 4; ++i) z.first_nl[i] = -1;
+                *a.st = z;
+            }
+        } else {                  // init_mode 2: the words zeroed by all threads, the non-zero fields by thread 0 BEHIND a barrier
+            for (int i = tid; i < NWORDS; i += SG_THREADS) w[i] = 0ull;
+            __syncthreads();
+            if (tid == 0) {
+                a.st->P0 = a.init0[0]; a.st->S0 = a.init0[1]; a.st->Q0 = a.init0[2]; a.st->I0 = a.init0[3];
+                a.st->P = a.init0[0]; a.st->S = a.init0[1]; a.st->Q = a.init0[2]; a.st->I = a.init0[3];
+                a.st->last_nl_tile = -1; a.st->err_struct = ~0ull; a.st->err_valid = ~0ull; a.st->err_buf = ~0ull;
+                for (int i = 0; i < 4; ++i) a.st->first_nl[i] = -1;
+            }
+        }
+    }
     int64_t c[SG_ITEMS];
     u64 av[SG_ITEMS], iv[SG_ITEMS];
     int64_t sum = 0, my_last = 0;   // last tile with a newline, + 1 (0 = none)

@@ -110,9 +110,8 @@ class ChunkResult:
     def _cumulative(self):
         """bzq_chunk.d_ends / d_id_ends are produced on demand (the emit kernel writes the per-batch arrays directly)."""
         if not self.d_ends and int(self.n_records):
-            # the library finds the chunk's output set by its arrays: the current chunk or the one before it (double buffering)
-            if L.lib().bzq_set_option(self.ctx.h, b"n_submits", 0) - self._serial > 1:
-                raise RuntimeError("ChunkResult.ends(): two chunks have been submitted since; the chunk's arrays are gone")
+            # the library finds the chunk's output set by its arrays and its serial (bzq_chunk.chunk_serial): the current chunk or the
+            # one before it (double buffering); a chunk from two submits ago is refused there (BZQ_ERR_ARG -> RuntimeError)
             _check(self.ctx.h, L.lib().bzq_chunk_cumulative_ends(self.ctx.h, C.byref(self.raw)), "bzq_chunk_cumulative_ends")
             self.d_ends, self.d_id_ends = self.raw.d_ends, self.raw.d_id_ends
 

@@ -130,7 +130,9 @@ typedef struct bzq_chunk {
     float ms_total;            /* first kernel start -> last kernel end */
     float ms_aggregate, ms_scan, ms_emit, ms_rebase;
     uint32_t n_passes;
-    uint32_t _pad;
+    uint32_t chunk_serial;     /* which submit of the ctx this chunk was (1, 2, ...; the low 32 bits): bzq_chunk_cumulative_ends refuses a
+                                  bzq_chunk whose output set has been written again since (same pointers, another chunk).  Occupies what
+                                  was padding in ABI 2 (same layout); the dense-tile diagnostic that sat here is the query "dense_tiles" */
     /* views mode only (config.views_only): the stripped id of record r is chunk[d_id_start[r] .. + d_id_len[r])
      * (FastqView.id(), record.mojo:431-472); the three column pointers and d_*ends are NULL in that mode */
     const int64_t* d_id_start;

@@ -195,3 +195,57 @@ def test_all_batches_in_one_call_equal_successive_views():
             ctx.copy_to_host(e[:m], a.ends, 8 * m)
             np.testing.assert_array_equal(e[:m], f.ends[lo:lo + m] - base)
     ctx.close()
+
+
+def test_batches_of_a_chunk_are_served_while_the_next_chunk_is_parsed():
+    """The host's pipeline under the double-buffer contract: result(k) -> submit(k + 1) at once -> walk the batches of chunk k under the
+    parse of chunk k + 1 (bench.py's step does exactly this).  bzq_batches / bzq_batch_view / bzq_chunk_cumulative_ends serve the
+    chunk the last RESULT described until its output set is written again -- the second submit after its own -- and refuse after."""
+    import torch
+    import blazeseq_amd as B
+    a = O.generate_synthetic(30_000, 20, 180, 0, 40, "sanger")
+    b = O.generate_synthetic(21_000, 100, 100, 5, 35, "sanger")
+    fa, fb = O.flat_parse(a, O.make_config(batch_size=512)), O.flat_parse(b, O.make_config(batch_size=512))
+    ctx = B.Context(B.ParserConfig(), "generic", 512, 0)
+    da, db = torch.from_numpy(a.copy()).cuda(), torch.from_numpy(b.copy()).cuda()
+
+    def check_batches(f, bs):
+        arr, nb = ctx.batches(bs)
+        assert nb == (f.n_records + bs - 1) // bs
+        e = np.empty(bs, dtype=np.int64)
+        for k in range(nb):
+            lo, m = k * bs, int(arr[k].num_records)
+            base = int(f.ends[lo - 1]) if lo else 0
+            assert m == min(bs, f.n_records - lo) and int(arr[k].seq_len) == int(f.ends[lo + m - 1]) - base
+            if k in (0, 1, nb // 2, nb - 1):
+                ctx.copy_to_host(e[:m], arr[k].ends, 8 * m)
+                np.testing.assert_array_equal(e[:m], f.ends[lo:lo + m] - base)
+                q = np.empty(int(arr[k].seq_len), dtype=np.uint8)
+                ctx.copy_to_host(q, arr[k].qual_buffer, q.size)
+                np.testing.assert_array_equal(q, f.qual_bytes[base:base + q.size])
+
+    ctx.submit_device(da.data_ptr(), da.numel(), 0, True)
+    ra = ctx.result()
+    ctx.submit_device(db.data_ptr(), db.numel(), 0, True)      # chunk B in flight, no result taken
+    check_batches(fa, 512)                                     # aligned: zero copy, host-cached boundaries of chunk A's set
+    check_batches(fa, 300)                                     # unaligned: own storage in chunk A's set, kernels queue behind B's parse
+    np.testing.assert_array_equal(ra.ends(), fa.ends)          # cumulative ends of A derived while B is pending (OutSet::parsed)
+    rb = ctx.result()
+    check_batches(fb, 512)
+    np.testing.assert_array_equal(rb.id_ends(), fb.id_ends)
+    # two submits without a result in between: the set the last result (B) lives in is written again -> nothing to serve
+    ctx.submit_device(da.data_ptr(), da.numel(), 0, True)
+    check_batches(fb, 512)                                     # (one submit later: still B)
+    ctx.submit_device(db.data_ptr(), db.numel(), 0, True)
+    with pytest.raises(RuntimeError):
+        ctx.batches(512)
+    rd = ctx.result()
+    check_batches(fb, 300)
+    # a bzq_chunk from two submits ago names arrays that hold ANOTHER chunk now (same pointers): refused by its serial
+    assert rd.raw.chunk_serial == 4 and rb.raw.chunk_serial == 2 and rd.raw.d_batch_ends == rb.raw.d_batch_ends
+    import copy
+    stale = copy.copy(rb.raw); stale.d_ends = None; stale.d_id_ends = None
+    import ctypes as C
+    from blazeseq_amd import _lib as L
+    assert L.lib().bzq_chunk_cumulative_ends(ctx.h, C.byref(stale)) < 0 and b"no longer alive" in L.lib().bzq_last_error(ctx.h)
+    ctx.close()

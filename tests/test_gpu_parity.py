@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import oracle as O
 from fastq_fuzz import rand_stream
+from blazeseq_amd import _lib as L_
 from gpu_util import make_pair, check_against_oracle, EXPERIMENTS, VARIANTS, VARIANTS_LB, SHARD_VARIANTS
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -141,7 +142,7 @@ def test_tiny_records_take_serial_path_and_resize():
     for sp in VARIANTS:
         ctx, oc = make_pair(emit_offsets=True, check_ascii=True, check_quality=True, single_pass=sp)
         res, f = check_against_oracle(ctx, oc, data, offsets=True, what=f"tiny single_pass={sp}")
-        assert res._pad > 0  # dense tiles were used
+        assert L_.lib().bzq_set_option(ctx.h, b"dense_tiles", 0) > 0  # dense tiles were used
         ctx.close()
 
 
