@@ -177,6 +177,7 @@ struct bzq_ctx {
     int cur_is_eof = 0;
     uint32_t cur_prev_byte = 10;
     int64_t cur_first_header = 0;
+    int64_t dbg[3][12] = {};        // diagnostic: see bzq_chunk_result (query "dump_state")
     int64_t last_dense_tiles = 0;   // query "dense_tiles": tiles of the last parsed chunk that took the serial path (diagnostic)
     bool pending = false, have_result = false;
     int64_t n_passes = 0;
@@ -847,7 +848,8 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     c->init_by_kernel_now = false;
     if (plain && c->init_in_kernel && pass_tiles(c) >= tiles_for(n)) {   // diagnostic: no copy at all, the scan's first workgroup writes the values
         c->h_init[0] = P0; c->h_init[1] = S0; c->h_init[2] = Q0; c->h_init[3] = I0;
-        c->init_by_kernel_now = true;
+        if (c->init_in_kernel == 4) hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, c->stream, c->d_state, P0, S0, Q0, I0);
+        else c->init_by_kernel_now = true;
     } else if (plain) {
         c->init_deferred = true;   // (enqueue_passes, behind pass A's launch)
     } else {
@@ -1187,6 +1189,13 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     }
     else if (!strcmp(key, "stream_fallbacks")) return (int32_t)std::min<int64_t>(c->stream_fallbacks, 0x7FFFFFFF);   // query: chunks repeated on the two-pass kernels
     else if (!strcmp(key, "last_folded")) return c->fold ? 1 : 0;                                                     // query: the last chunk went without k_rebase
+    else if (!strcmp(key, "dump_state")) {   // query (diagnostic): the last result's state snapshots to stderr
+        for (int i = 0; i < 3; ++i) if (c->dbg[i][11])
+            fprintf(stderr, "bzq state[%s]: err_struct %lld overflow %lld P %lld n_complete %lld err_valid %lld err_buf %lld P0 %lld last_nl_tile %lld fallback %lld tail_start %lld last_record_end %lld\n",
+                    i == 0 ? "first" : i == 1 ? "after views fallback" : "after re-size", (long long)c->dbg[i][0], (long long)c->dbg[i][1], (long long)c->dbg[i][2], (long long)c->dbg[i][3],
+                    (long long)c->dbg[i][4], (long long)c->dbg[i][5], (long long)c->dbg[i][6], (long long)c->dbg[i][7], (long long)c->dbg[i][8], (long long)c->dbg[i][9], (long long)c->dbg[i][10]);
+        return 0;
+    }
     else if (!strcmp(key, "dense_tiles")) return (int32_t)std::min<int64_t>(c->last_dense_tiles, 0x7FFFFFFF);          // query
     else if (!strcmp(key, "n_submits")) return (int32_t)std::min<int64_t>(c->n_submits, 0x7FFFFFFF);                  // query: chunks submitted so far
     else if (!strcmp(key, "pass_a_h")) c->pass_a_h = value != 0;
@@ -1350,6 +1359,7 @@ int32_t bzq_gzip_set_option(bzq_gzip* h, const char* key, int64_t value) {
         h->host_budget = (uint64_t)value << 10; h->host_budget_min = h->host_budget;
         return 0;
     }
+    if (!strcmp(key, "host_out_mib")) return (int32_t)std::min<uint64_t>(h->host_bytes_out >> 20, 0x7FFFFFFF);   // query: MiB those calls produced
     if (!strcmp(key, "host_calls")) return (int32_t)std::min<uint64_t>(h->host_calls, 0x7FFFFFFF);   // query: calls that continued on the host
     h->err = std::string("unknown option ") + key;
     return BZQ_ERR_ARG;
@@ -1423,6 +1433,11 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     ChunkState* h = c->h_state; // filled by the async D2H enqueued behind k_rebase
+    // diagnostic snapshots of the state as the host first sees it, and again behind a re-make (query "dump_state" prints them)
+    auto snap = [&](int i) { int64_t* d = c->dbg[i]; d[0] = (int64_t)h->err_struct; d[1] = h->rec_overflow; d[2] = h->P; d[3] = h->n_complete; d[4] = (int64_t)h->err_valid;
+                             d[5] = (int64_t)h->err_buf; d[6] = h->P0; d[7] = h->last_nl_tile; d[8] = h->views_fallback; d[9] = h->tail_start; d[10] = h->last_record_end; d[11] = 1; };
+    c->dbg[1][11] = 0; c->dbg[2][11] = 0;
+    snap(0);
     if (c->ablate & 64) {   // debug: emit-kernel phase cycles (thread 0 of every workgroup)
         fprintf(stderr, "bzq phase_cycles:");
         for (int i = 0; i < 8; ++i) fprintf(stderr, " %llu", h->phase_cycles[i]);
@@ -1474,6 +1489,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         enqueue_rebase(c);
         HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        snap(1);
     }
     if (h->rec_overflow) {
         // shorter records than the sizing hint assumed: re-size to the exact count, re-run
@@ -1493,6 +1509,7 @@ int32_t bzq_chunk_result(bzq_ctx* c, bzq_chunk* out) {
         enqueue_rebase(c);
         HIPCHK(c, hipMemcpyAsync(h, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        snap(2);
         if (h->rec_overflow) { c->err = "record arrays still too small after re-size"; return BZQ_ERR_NOMEM; }
     }
     const int64_t n = (int64_t)c->cur_n;
@@ -2120,8 +2137,8 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
                 g->gpu_inflate = 1;
                 g->inflate_ms = (gpu_inflate & 2) ? 1 : 0;
                 if (const char* e = getenv("BZQ_INGEST_INFLATE_STREAMS")) g->n_inflate_streams = std::min(bzq::INGEST_SLOTS, std::max(1, atoi(e)));   // (measurements)
-                bool gok = hipHostMalloc((void**)&g->bad_pinned, bzq::INGEST_SLOTS * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess &&
-                           hipMalloc((void**)&g->bad_dev, bzq::INGEST_SLOTS * sizeof(unsigned long long)) == hipSuccess;
+                bool gok = (g->bad_pinned = (unsigned long long*)bzq::cache::host_small().get(bzq::INGEST_SLOTS * sizeof(unsigned long long))) != nullptr &&
+                           bzq::cache::get_device(g->device, bzq::INGEST_SLOTS * sizeof(unsigned long long), &g->bad_dev);
                 for (int i = 0; i < bzq::INGEST_SLOTS && gok; ++i) { g->bad_pinned[i] = ~0ull; gok = bzq::ingest_alloc_inflate(g, i); }
                 if (!gok) {
                     err = std::string(who) + ": allocating the buffers of the device inflate failed";
@@ -2396,7 +2413,13 @@ int32_t bzq_ingest_get_stats(const bzq_ingest* g, bzq_ingest_stats* out) {
 }
 
 void bzq_ingest_close(bzq_ingest* g) {
-    if (g && g->ctx) { g->ctx->follow_on = false; g->ctx->stage_valid = false; g->ctx->records_before = -1; }   // (the stream is over: see bzq_ingest_open)
+    if (g && g->ctx) {
+        g->ctx->follow_on = false; g->ctx->stage_valid = false; g->ctx->records_before = -1;   // (the stream is over: see bzq_ingest_open)
+        // who may still touch the chunk buffers: the parser's stream, and in views mode the consumer stream (views point into the chunk)
+        g->quiesce_device = false;
+        g->quiesce_stream = g->ctx->stream;
+        g->quiesce_stream2 = g->ctx->cfg.views_only ? g->ctx->consumer_stream : nullptr;
+    }
     bzq::ingest_free(g);
 }
 
@@ -2635,6 +2658,32 @@ int32_t bzq_batch_quality_by_position(bzq_ctx* c, const bzq_device_batch* b, int
     }
     HIPCHK(c, hipMemcpyAsync(counts, c->qpos_scratch.p, bytes, hipMemcpyDeviceToHost, cs));
     HIPCHK(c, hipStreamSynchronize(cs));
+    return 0;
+}
+
+int32_t bzq_batch_nw_scores_dev(bzq_ctx* c, const bzq_device_batch* b, const uint8_t* d_ref, int32_t ref_len, int32_t* d_scores) {
+    if (!c || !b || ref_len < 0 || (ref_len && !d_ref) || (b->num_records && !d_scores)) return BZQ_ERR_ARG;
+    if (ref_len > NW_MAX_LEN) { c->err = "bzq_batch_nw_scores_dev: ref_len > 256 (the synchronous call scores such a reference 0 like the example; here it is refused)"; return BZQ_ERR_ARG; }
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t cs = c->consumer_stream ? c->consumer_stream : c->stream;
+    const int64_t n = b->num_records;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_nw_scores, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, cs, d_ref, (int)ref_len,
+                       b->sequence_buffer, b->ends, n, d_scores);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { c->err = std::string("k_nw_scores: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
+    return 0;
+}
+
+int32_t bzq_batch_quality_by_position_acc(bzq_ctx* c, const bzq_device_batch* b, int32_t max_positions, uint64_t* d_counts) {
+    if (!c || !b || max_positions <= 0 || !d_counts) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t cs = c->consumer_stream ? c->consumer_stream : c->stream;
+    if (b->num_records <= 0) return 0;
+    const dim3 grid((unsigned)((max_positions + QP_POS - 1) / QP_POS), (unsigned)((b->num_records + QP_RECS - 1) / QP_RECS));
+    hipLaunchKernelGGL(k_quality_by_position, grid, dim3(BLOCK), 0, cs, b->qual_buffer, b->ends, b->num_records, (int)max_positions, (u64*)d_counts);
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) { c->err = std::string("k_quality_by_position: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
     return 0;
 }
 

@@ -45,6 +45,10 @@ struct Pool {
     std::unordered_map<void*, Entry> out;   // handed out: capacity and device by pointer
     uint64_t held = 0, limit;
     uint64_t hits = 0, misses = 0;
+    // Buffers below 1 MiB (block tables, verdict words) are kept as well, up to SMALL_MAX of them whatever `limit` says (unless the cache
+    // is off): handing them to hipFree would make every close a device-wide wait -- hipFree waits for ALL streams of the device.
+    static constexpr int SMALL_MAX = 64;
+    int n_small = 0;
     Pool(bool pin, uint64_t lim) : pinned(pin), limit(lim) {
         const char* e = getenv("BZQ_BUF_CACHE");
         if (e && e[0] == '0') limit = 0;
@@ -142,6 +146,7 @@ struct Pool {
                 const Entry e = idle[best];
                 idle.erase(idle.begin() + best);
                 held -= e.cap;
+                if (e.cap < (1ull << 20)) --n_small;
                 out[e.p] = e;
                 *outp = e.p;
                 ++hits;
@@ -173,7 +178,8 @@ struct Pool {
                 e = it->second;
                 known = true;
                 out.erase(it);
-                if (e.cap >= (1ull << 20) && held + e.cap <= limit) { idle.push_back(e); held += e.cap; keep = true; }
+                const bool small = e.cap < (1ull << 20);
+                if (limit && ((small && n_small < SMALL_MAX) || (!small && held + e.cap <= limit))) { idle.push_back(e); held += e.cap; n_small += small ? 1 : 0; keep = true; }
             }
         }
         if (!keep && known) raw_free(e);
@@ -190,6 +196,7 @@ struct Pool {
             while (held > keep_bytes && !idle.empty()) {
                 drop.push_back(idle.back());
                 held -= idle.back().cap;
+                if (idle.back().cap < (1ull << 20)) --n_small;
                 idle.pop_back();
             }
         }
@@ -201,6 +208,34 @@ struct Pool {
 // needs.  A host that decodes .gz after .gz raises dev_cache_bytes (its pools and FIFO are ~8 GiB per stream).
 inline Pool& pinned_pool() { static Pool* p = new Pool(true, 1ull << 30); return *p; }
 inline Pool& device_pool() { static Pool* p = new Pool(false, 1ull << 30); return *p; }
+
+// Small host buffers the DEVICE writes into (verdict words, block tables): really pinned (hipHostMalloc), and never given back to the
+// driver while the process lives -- hipHostFree, like hipFree, waits for every stream of the device.  A free list by size; at most
+// HOST_SMALL_MAX buffers are kept, the rest is freed (with that wait).
+struct HostSmall {
+    std::mutex mu;
+    std::vector<std::pair<void*, uint64_t>> idle;
+    static constexpr size_t HOST_SMALL_MAX = 32;
+    void* get(uint64_t n) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].second == n) { void* p = idle[i].first; idle.erase(idle.begin() + (long)i); return p; }
+        }
+        void* p = nullptr;
+        if (hipHostMalloc(&p, (size_t)n, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        return p;
+    }
+    void put(void* p, uint64_t n) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (idle.size() < HOST_SMALL_MAX) { idle.emplace_back(p, n); return; }
+        }
+        (void)hipHostFree(p);
+    }
+};
+inline HostSmall& host_small() { static HostSmall* h = new HostSmall(); return *h; }
 
 template <class T> inline bool get_pinned(int device, uint64_t want, T** out) { return pinned_pool().get(device, want, (void**)out) == hipSuccess; }
 template <class T> inline bool get_device(int device, uint64_t want, T** out) { return device_pool().get(device, want, (void**)out) == hipSuccess; }

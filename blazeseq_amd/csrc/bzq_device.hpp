@@ -485,6 +485,17 @@ __device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t* s_r) {
     return t;
 }
 
+// diagnostic (state_init_in_kernel = 4): the state's initial values by a kernel of its own, in FRONT of pass A on the ctx stream
+static __global__ __launch_bounds__(64) void k_state_init(ChunkState* st, int64_t P0, int64_t S0, int64_t Q0, int64_t I0) {
+    if (threadIdx.x == 0) {
+        ChunkState z{};
+        z.P0 = P0; z.S0 = S0; z.Q0 = Q0; z.I0 = I0; z.P = P0; z.S = S0; z.Q = Q0; z.I = I0;
+        z.last_nl_tile = -1; z.err_struct = ~0ull; z.err_valid = ~0ull; z.err_buf = ~0ull;
+        for (int i = 0; i < 4; ++i) z.first_nl[i] = -1;
+        *st = z;
+    }
+}
+
 static __global__ __launch_bounds__(SG_THREADS) void k_scan_reduce(ScanArgs a) {
     constexpr int NW = SG_THREADS / 64;
     __shared__ int64_t s_w[NW];
@@ -495,7 +506,7 @@ static __global__ __launch_bounds__(SG_THREADS) void k_scan_reduce(ScanArgs a) {
         u64* w = reinterpret_cast<u64*>(a.st);
         constexpr int NWORDS = (int)(sizeof(ChunkState) / 8);
         static_assert(sizeof(ChunkState) % 8 == 0, "ChunkState is a whole number of 8-byte words");
-        if (a.init_mode == 1) {   // every word by one thread, in order: no two threads store to the same word
+        if (a.init_mode == 1 || a.init_mode == 3) {   // every word by one thread, in order: no two threads store to the same word
             if (tid == 0) {
                 ChunkState z{};
                 z.P0 = a.init0[0]; z.S0 = a.init0[1]; z.Q0 = a.init0[2]; z.I0 = a.init0[3];
@@ -503,6 +514,7 @@ static __global__ __launch_bounds__(SG_THREADS) void k_scan_reduce(ScanArgs a) {
                 z.last_nl_tile = -1; z.err_struct = ~0ull; z.err_valid = ~0ull; z.err_buf = ~0ull;
                 for (int i = 0; i < 4; ++i) z.first_nl[i] = -1;
                 *a.st = z;
+                if (a.init_mode == 3) __threadfence();   // (3: an agent-scope release by the writer itself, before the kernel's own end-of-kernel release)
             }
         } else {                  // init_mode 2: the words zeroed by all threads, the non-zero fields by thread 0 BEHIND a barrier
             for (int i = tid; i < NWORDS; i += SG_THREADS) w[i] = 0ull;

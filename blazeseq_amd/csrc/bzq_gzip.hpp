@@ -1709,10 +1709,20 @@ inline uint32_t pool_want(const bzq_gzip* h, uint64_t n, int n_chunks) {
     return (uint32_t)pages + (uint32_t)n_chunks + (uint32_t)MAX_FALLBACK + 64u;
 }
 
+// every stream this decoder enqueues work on: the call's stream (the caller's, or its own) and its side streams
+inline hipError_t gz_quiesce(bzq_gzip* h) {
+    hipError_t e = hipSuccess, r;
+    for (hipStream_t s : {h->stream, h->own_stream, h->copy_stream, h->find_stream, h->early_stream})
+        if (s && (r = hipStreamSynchronize(s)) != hipSuccess) e = r;
+    return e;
+}
+
 inline int gz_ensure(bzq_gzip* h, bzq_gzip::Buf& b, size_t bytes, bool pinned = false, int slack_shift = 2) {
     if (bytes <= b.cap) return 0;
     bzq::cache::Pool& pool = pinned ? bzq::cache::pinned_pool() : bzq::cache::device_pool();   // (bzq_bufcache.hpp: the buffers of a decoder outlive it)
-    if (b.p) { GZCHK(h, hipDeviceSynchronize()); pool.put(b.p); b.p = nullptr; b.cap = 0; }
+    // (what goes back to the cache skips hipFree's wait: whoever may still touch the old buffer is waited for here -- the decoder's own
+    // streams, not the device: a caller's kernels on other streams are not this decoder's business)
+    if (b.p) { GZCHK(h, gz_quiesce(h)); pool.put(b.p); b.p = nullptr; b.cap = 0; }
     const size_t want = bytes + (bytes >> slack_shift) + 256;   // (room to grow without a new allocation: a quarter; the symbol pool, gigabytes, a sixteenth)
     const hipError_t e = pool.get(h->device, want, &b.p);
     if (e != hipSuccess) { b.p = nullptr; (void)hipGetLastError(); return gz_fail(h, BZQ_ERR_NOMEM, "bzq_gzip: cannot allocate " + std::to_string(want) + " bytes"); }
@@ -1731,7 +1741,7 @@ inline void gz_free(bzq_gzip* h) {
     for (hipEvent_t e : {h->pre_ev, h->pre_copy_ev, h->pre_dec_ev, h->ver_ev}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->staged_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->early_ev) if (e) (void)hipEventDestroy(e);
-    (void)hipDeviceSynchronize();   // (a caller's stream may still run the last decode: what goes back to the cache skips hipFree's wait)
+    if (h->stream) (void)hipStreamSynchronize(h->stream);   // (a caller's stream may still run the last decode: what goes back to the cache skips hipFree's wait)
     for (bzq_gzip::Buf* b : {&h->comp[0], &h->comp[1], &h->comp[2], &h->jobs_e[0], &h->jobs_e[1], &h->jobs_e[2], &h->order_e[0], &h->order_e[1], &h->order_e[2], &h->counters_e[0], &h->counters_e[1], &h->counters_e[2], &h->order[0], &h->order[1], &h->jobs[0], &h->jobs[1], &h->counters2, &h->outs_[0], &h->outs_[1], &h->pool_[0], &h->pool_[1], &h->page_next_[0], &h->page_next_[1], &h->counters_[0], &h->counters_[1], &h->events_[0], &h->events_[1], &h->items, &h->crcs, &h->win[0], &h->win[1], &h->chain_maps, &h->chain_wins, &h->chain_tabs})
         bzq::cache::device_pool().put(b->p);
     for (bzq_gzip::Buf* b : {&h->h_outs_[0], &h->h_outs_[1], &h->h_events, &h->h_pages, &h->h_items, &h->h_crcs, &h->h_host_out})
@@ -1977,7 +1987,9 @@ inline int gz_decode_host(bzq_gzip* h, const uint8_t* src, uint64_t n_new, bool 
     }
     // ---- the output, the window behind it, what stays
     if (op) {
-        GZCHK(h, hipMemcpyAsync(d_out, hb, (size_t)op, hipMemcpyHostToDevice, s));
+        // hb is a buffer of the pinned pool: anonymous memory registered in 32 MiB blocks, and one copy must not span two registrations
+        // (bzq_bufcache.hpp) -- the host continuation can emit more than a block in one call (its budget is 32 MiB + 4, and doubles)
+        GZCHK(h, bzq::cache::pinned_pool().h2d(d_out, hb, op, s));
         std::vector<uint8_t> w2(32768);
         if (op >= 32768) memcpy(w2.data(), hb + op - 32768, 32768);
         else { memcpy(w2.data(), win.data() + op, (size_t)(32768 - op)); memcpy(w2.data() + (32768 - op), hb, (size_t)op); }

@@ -116,6 +116,8 @@ struct bzq_ingest {
     // a carry larger than the reserve in front of a slot's body (a record or a batch longer than chunk/8): the chunk is
     // assembled in a buffer of its own, grown on demand -- the reference has no record-size limit either
     uint8_t* big[bzq::INGEST_SLOTS] = {};
+    bool quiesce_device = true;   // bzq_ingest_close names the streams instead
+    hipStream_t quiesce_stream = nullptr, quiesce_stream2 = nullptr;   // whose work may still touch the buffers at the close (ingest_free)
     uint64_t big_cap[bzq::INGEST_SLOTS] = {};
     uint64_t prev_stream_pos = 0;
     bzq_chunk prev_res{};
@@ -277,8 +279,8 @@ inline bool ingest_alloc_inflate(bzq_ingest* g, int i) {
     if (i == 0) g->inflate_stream[0] = g->copy_stream;
     else if (i < g->n_inflate_streams && hipStreamCreateWithFlags(&g->inflate_stream[i], hipStreamNonBlocking) != hipSuccess) return false;
     return cache::get_device(g->device, g->chunk_bytes + 64, &g->comp_dev[i]) &&
-           hipMalloc((void**)&g->tab_dev[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16) == hipSuccess &&
-           hipHostMalloc((void**)&g->tab_pinned[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16, hipHostMallocDefault) == hipSuccess;
+           cache::get_device(g->device, (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16, &g->tab_dev[i]) &&
+           (g->tab_pinned[i] = (bzq::inf::DevBlock*)cache::host_small().get((size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16)) != nullptr;
 }
 // pinned_bytes: what the slot's host buffer must take behind the reserve (0: the slot has none).  Pinning is the expensive part
 // of an open (~0.1 s per GiB): a plain file stages whole chunks there, a .gz decoded on the device only pieces of compressed
@@ -529,19 +531,25 @@ inline void ingest_free(bzq_ingest* g) {
     for (int i = 1; i < INGEST_SLOTS; ++i)
         if (g->inflate_stream[i]) { (void)hipStreamSynchronize(g->inflate_stream[i]); (void)hipStreamDestroy(g->inflate_stream[i]); }
     if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
-    (void)hipDeviceSynchronize();   // the parser's stream may still read the last chunk: buffers that go back to the cache skip hipFree's implicit wait
+    // Buffers that go back to the cache skip hipFree's implicit wait, so whoever may still touch them is waited for HERE -- and only
+    // they: the parser's stream (it may still read the last chunk) and, in views mode, the ctx's consumer stream (bzq_device_views point
+    // INTO the chunk).  Not the whole device (rounds 4-5 did that): a caller's kernels on other streams -- a consumer of the batches'
+    // columns, which live in the ctx, not here -- are none of this close's business.
+    if (g->quiesce_device) (void)hipDeviceSynchronize();   // (the FASTA ingest, and an open that failed half way: as before)
+    if (g->quiesce_stream) (void)hipStreamSynchronize(g->quiesce_stream);
+    if (g->quiesce_stream2) (void)hipStreamSynchronize(g->quiesce_stream2);
     for (int i = 0; i < INGEST_SLOTS; ++i) {
         cache::pinned_pool().put(g->slot[i].pinned);
         cache::device_pool().put(g->slot[i].dev);
-        if (g->big[i]) (void)hipFree(g->big[i]);
+        if (g->big[i]) (void)hipFree(g->big[i]);   // (only a stream whose batch outgrew the reserve has one: this free does wait for the device)
         cache::device_pool().put(g->comp_dev[i]);
-        if (g->tab_dev[i]) (void)hipFree(g->tab_dev[i]);
-        if (g->tab_pinned[i]) (void)hipHostFree(g->tab_pinned[i]);
+        cache::device_pool().put(g->tab_dev[i]);
+        cache::host_small().put(g->tab_pinned[i], (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16);
         if (g->slot[i].h2d_done) (void)hipEventDestroy(g->slot[i].h2d_done);
         if (g->dev_free[i]) (void)hipEventDestroy(g->dev_free[i]);
     }
-    if (g->bad_dev) (void)hipFree(g->bad_dev);
-    if (g->bad_pinned) (void)hipHostFree(g->bad_pinned);
+    cache::device_pool().put(g->bad_dev);
+    cache::host_small().put(g->bad_pinned, INGEST_SLOTS * sizeof(unsigned long long));
     if (g->gz) gzclose(g->gz);
     if (g->gz_dev) bzq::gz::gz_free(g->gz_dev);
     cache::device_pool().put(g->gz_fifo);

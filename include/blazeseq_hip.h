@@ -535,6 +535,16 @@ int32_t bzq_batch_quality_sums(bzq_ctx* ctx, const bzq_device_batch* b, int64_t*
  * follow the per-position mean / quantiles of Phred (v - quality_offset) and the read-length distribution
  * (records reaching position p = sum over v).  Synchronous. */
 int32_t bzq_batch_quality_by_position(bzq_ctx* ctx, const bzq_device_batch* b, int32_t max_positions, uint64_t* counts);
+/* The two consumers above for a PIPELINE -- file -> records -> consumer with no host round trip, the reference's only GPU use
+ * (examples/nw_gpu/execution.mojo:100-130: next_batch -> batch.to_device(ctx) -> nw_kernel): everything stays on the device and
+ * nothing is synchronised, the kernels are enqueued on the consumer stream (bzq_set_consumer_stream; default: the ctx stream).
+ * The caller orders them against the parser by the two-chunk lifetime rule: a batch's columns are valid until the SECOND submit
+ * after its chunk's, so a consumer of chunk k has to be through before chunk k + 2 is submitted (an event on the consumer stream).
+ *   _dev:  the reference bytes are already on the device (d_ref, ref_len <= 256), d_scores: device int32[num_records];
+ *   _acc:  d_counts: device uint64[max_positions * 128], ACCUMULATED into (the caller zeroes it once): the per-cycle quality
+ *          distribution of a whole file in one table. */
+int32_t bzq_batch_nw_scores_dev(bzq_ctx* ctx, const bzq_device_batch* b, const uint8_t* d_ref, int32_t ref_len, int32_t* d_scores);
+int32_t bzq_batch_quality_by_position_acc(bzq_ctx* ctx, const bzq_device_batch* b, int32_t max_positions, uint64_t* d_counts);
 /* 256-bin byte histogram of a device column (base composition of sequence_buffer, quality distribution of
  * qual_buffer; the v0.1 quality_distribution example, CHANGELOG.md:73).  hist: host uint64[256]. */
 int32_t bzq_column_histogram(bzq_ctx* ctx, const uint8_t* d_col, uint64_t n, uint64_t* hist);

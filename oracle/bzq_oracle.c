@@ -603,6 +603,64 @@ int64_t orc_bench_run(const uint8_t* data, int64_t n, const orc_config* cfg, int
     return records;
 }
 
+/* ==================================================================== consumers of a FastqBatch (CPU twins)
+ * Test infrastructure like the rest of this file: the reference's example consumers restated on the CPU, so that the device-side
+ * consumers (blazeseq_amd/csrc/bzq_consumers.hpp) have a checker and bench.py's pipeline_mode has a host figure beside it. */
+
+/* examples/nw_gpu/kernels.mojo:21-89 (nw_kernel): two DP rows, match +1, mismatch -1, gap -1; a query or reference longer than
+ * 256 scores 0 (48-50); an empty query leaves the first row: the score is -ref_len. */
+int32_t orc_nw_score(const uint8_t* ref, int64_t ref_len, const uint8_t* q, int64_t q_len) {
+    if (q_len > 256 || ref_len > 256) return 0;
+    int32_t row0[257], row1[257];
+    int32_t* prev = row0; int32_t* curr = row1;
+    for (int64_t i = 0; i <= ref_len; ++i) prev[i] = -(int32_t)i;          /* 60-62 */
+    for (int64_t j = 1; j <= q_len; ++j) {                                 /* 65-86 */
+        curr[0] = -(int32_t)j;
+        const uint8_t qb = q[j - 1];
+        for (int64_t i = 1; i <= ref_len; ++i) {
+            int32_t best = prev[i - 1] + (ref[i - 1] == qb ? 1 : -1);
+            const int32_t del = prev[i] - 1, ins = curr[i - 1] - 1;
+            if (del > best) best = del;
+            if (ins > best) best = ins;
+            curr[i] = best;
+        }
+        int32_t* t = prev; prev = curr; curr = t;
+    }
+    return prev[ref_len];                                                  /* 88 */
+}
+
+/* The reference's GPU use case on the host (examples/nw_gpu/execution.mojo:100-130: next_batch -> consumer): the streaming parser in
+ * batches(cfg->batch_size) mode and, per batch, (a) the NW score of every record against `ref` (scores summed into *score_sum so
+ * that the work cannot be optimised away and two runs can be compared) and (b) the per-position quality distribution
+ * counts[p * 128 + v] += 1 for every record's quality byte v at position p < max_pos (bytes >= 128 count in bin 127; the v0.1
+ * quality_distribution example, CHANGELOG.md:73).  Returns the records parsed. */
+int64_t orc_pipeline_run(const uint8_t* data, int64_t n, const orc_config* cfg, const uint8_t* ref, int64_t ref_len,
+                         int64_t max_pos, uint64_t* counts, int64_t* score_sum, int64_t* base_pairs) {
+    orc_parser* p = orc_parser_new(data, n, cfg);
+    int64_t records = 0, bp = 0, ss = 0;
+    orc_batch b; orc_batch_init(&b);
+    for (;;) {
+        int rc = orc_parser_next_batch(p, cfg->batch_size, &b);
+        if (rc != ORC_OK || b.n == 0) break;
+        for (int64_t r = 0; r < b.n; ++r) {
+            const int64_t q0 = r ? b.ends[r - 1] : 0, q1 = b.ends[r];
+            ss += orc_nw_score(ref, ref_len, b.seq_bytes + q0, q1 - q0);
+            const int64_t m = (q1 - q0) < max_pos ? (q1 - q0) : max_pos;
+            for (int64_t k = 0; k < m; ++k) {
+                const uint8_t v = b.qual_bytes[q0 + k];
+                counts[k * 128 + (v < 128 ? v : 127)] += 1;
+            }
+        }
+        records += b.n;
+        bp += b.seq_bytes_len;
+    }
+    orc_batch_free(&b);
+    if (score_sum) *score_sum = ss;
+    if (base_pairs) *base_pairs = bp;
+    orc_parser_free(p);
+    return records;
+}
+
 /* ==================================================================== flat path */
 
 typedef struct {

@@ -175,6 +175,10 @@ int64_t orc_compute_num_reads_for_size(int64_t target, int64_t min_len, int64_t 
  * parsed; *base_pairs gets the sequence bytes. */
 int64_t orc_bench_run(const uint8_t* data, int64_t n, const orc_config* cfg, int mode,
                       int64_t* base_pairs);
+/* consumers of a FastqBatch on the CPU (examples/nw_gpu/kernels.mojo:21-89; CHANGELOG.md:73): see bzq_oracle.c */
+int32_t orc_nw_score(const uint8_t* ref, int64_t ref_len, const uint8_t* q, int64_t q_len);
+int64_t orc_pipeline_run(const uint8_t* data, int64_t n, const orc_config* cfg, const uint8_t* ref, int64_t ref_len,
+                         int64_t max_pos, uint64_t* counts, int64_t* score_sum, int64_t* base_pairs);
 
 #ifdef __cplusplus
 }

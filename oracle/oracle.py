@@ -128,6 +128,11 @@ def lib():
         L.orc_compute_num_reads_for_size.restype = C.c_int64
         L.orc_bench_run.argtypes = [C.c_void_p, C.c_int64, C.POINTER(OrcConfig), C.c_int, C.POINTER(C.c_int64)]
         L.orc_bench_run.restype = C.c_int64
+        L.orc_nw_score.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64]
+        L.orc_nw_score.restype = C.c_int32
+        L.orc_pipeline_run.argtypes = [C.c_void_p, C.c_int64, C.POINTER(OrcConfig), C.c_char_p, C.c_int64, C.c_int64, C.c_void_p,
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.orc_pipeline_run.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -358,3 +363,18 @@ def bench_run(data: np.ndarray, config: OrcConfig, mode: str = "batches"):
     d = _as_u8(data)
     n = lib().orc_bench_run(d.ctypes.data, d.size, C.byref(config), 0 if mode == "views" else 1, C.byref(bp))
     return n, bp.value
+
+
+def nw_score(ref: bytes, query: bytes) -> int:
+    """examples/nw_gpu/kernels.mojo:21-89 on the CPU (orc_nw_score)."""
+    return int(lib().orc_nw_score(ref, len(ref), query, len(query)))
+
+
+def pipeline_run(data: np.ndarray, config: OrcConfig, ref: bytes, max_pos: int):
+    """parse in batches(config.batch_size) + NW score of every record + per-position quality distribution, one thread
+    (orc_pipeline_run).  Returns (records, counts[max_pos, 128], sum of the scores)."""
+    d = _as_u8(data)
+    counts = np.zeros((max_pos, 128), dtype=np.uint64)
+    ss, bp = C.c_int64(), C.c_int64()
+    n = lib().orc_pipeline_run(d.ctypes.data, d.size, C.byref(config), ref, len(ref), max_pos, counts.ctypes.data, C.byref(ss), C.byref(bp))
+    return int(n), counts, int(ss.value)

@@ -148,3 +148,56 @@ def test_quality_distribution_per_read_position():
             np.add.at(want, (np.arange(a.size), a), 1)
         np.testing.assert_array_equal(got, want)
     assert int(d.quality_by_position(240).sum()) == sum(len(q) for q in quals)
+
+
+def test_pipeline_consumers_stay_on_the_device_and_equal_the_cpu_twin(tmp_path):
+    """The reference's GPU use case as a pipeline (examples/nw_gpu/execution.mojo:100-130): file -> bzq_ingest_next -> batches ->
+    bzq_batch_nw_scores_dev + bzq_batch_quality_by_position_acc on the consumer stream, nothing synchronised per batch, chunk k's
+    consumers running under the parse of chunk k + 1 (an event per chunk keeps the two-chunk lifetime rule).  Scores and the
+    accumulated per-position table must equal the oracle's CPU twin (orc_pipeline_run) over the same file."""
+    import ctypes as C
+    import torch
+    import blazeseq_amd as B
+    from blazeseq_amd import _lib as L
+    REF = b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT"
+    data = O.generate_synthetic(60_000, 20, 200, 0, 40, "sanger")
+    path = tmp_path / "p.fastq"
+    path.write_bytes(data.tobytes())
+    n_want, counts_want, ss_want = O.pipeline_run(data, O.make_config(buffer_capacity=64 * 1024, batch_size=4096), REF, 150)
+    f = O.flat_parse(data, O.make_config())
+
+    ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
+    side = torch.cuda.Stream()
+    ctx.set_consumer_stream(side.cuda_stream)
+    d_ref = torch.frombuffer(bytearray(REF), dtype=torch.uint8).cuda()
+    d_counts = torch.zeros(150 * 128, dtype=torch.int64, device="cuda")
+    d_scores = torch.full((n_want,), -99999, dtype=torch.int32, device="cuda")
+    ing = B.Ingest(ctx, str(path), chunk_bytes=1 << 20, n_threads=2)      # ~12 chunks
+    taken = total = 0
+    events = []
+    while True:
+        r = ing.next(taken)
+        taken = int(r.n_records)
+        if len(events) >= 1:
+            events[-1].synchronize()    # the consumers of the chunk before this one are through before the NEXT next() submits again
+        arr, nb = ctx.batches(4096)
+        for k in range(nb):
+            assert L.lib().bzq_batch_nw_scores_dev(ctx.h, C.byref(arr[k]), C.c_void_p(d_ref.data_ptr()), len(REF),
+                                                   C.c_void_p(d_scores.data_ptr() + 4 * (total + k * 4096))) == 0
+            assert L.lib().bzq_batch_quality_by_position_acc(ctx.h, C.byref(arr[k]), 150, C.c_void_p(d_counts.data_ptr())) == 0
+        ev = torch.cuda.Event(); ev.record(side); events.append(ev)
+        total += taken
+        if int(r.status) != L.OK:
+            break
+    ing.close()
+    side.synchronize()
+    assert total == n_want == 60_000 and len(events) > 5
+    np.testing.assert_array_equal(d_counts.cpu().numpy().reshape(150, 128).astype(np.uint64), counts_want)
+    scores = d_scores.cpu().numpy()
+    assert int(scores.astype(np.int64).sum()) == ss_want
+    e = np.concatenate([[0], f.ends])
+    for r_ in (0, 1, 4095, 4096, 31_234, 59_999):
+        assert int(scores[r_]) == O.nw_score(REF, f.seq_bytes[e[r_]:e[r_ + 1]].tobytes())
+    # refused, not clamped: a reference longer than the kernel's limit
+    assert L.lib().bzq_batch_nw_scores_dev(ctx.h, C.byref(arr[0]), C.c_void_p(d_ref.data_ptr()), 300, C.c_void_p(d_scores.data_ptr())) < 0
+    ctx.close()

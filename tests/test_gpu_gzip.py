@@ -267,6 +267,21 @@ def test_throughput_floor_of_a_stream_without_findable_block_starts(kind):
     assert len(data) / best / 1e6 >= 60.0, f"{kind}: {len(data) / best / 1e6:.1f} MB/s"
 
 
+def test_host_continuation_emits_more_than_one_pinned_block_per_call():
+    """the host continuation's output buffer is lazily pinned memory registered in 32 MiB blocks, and one copy must not
+    span two registrations.  Under the DEFAULT options (budget 32 MiB + 4 MiB of room, doubling while the device keeps handing over)
+    a long stretch without findable block starts makes one call emit more than a block: 120 MB of stored blocks in one member."""
+    data = synthetic_fastq(380_000)   # ~120 MB
+    comp = _unfindable(data, "stored")
+    ctx = Context()
+    g = DeviceGunzip(ctx, len(data) + (1 << 20))
+    out = g.decode(comp)
+    assert len(out) == len(data) and out == data
+    calls, mib = g.dec.set_option("host_calls", 0), g.dec.set_option("host_out_mib", 0)
+    assert calls >= 1 and mib >= 100 and calls * 32 <= mib, (calls, mib)   # nearly all of it by the host, >= 32 MiB (+ the block that crosses the budget) per call: every call's copy spans two or more 32 MiB registrations
+    g.close()
+
+
 @pytest.mark.parametrize("kind", ["fixed", "stored"])
 def test_device_and_host_hand_the_stream_back_and_forth(kind):
     """A small host budget: device (until ST_FAR) -> host (budget) -> device -> ... inside ONE member -- every hand-over passes the
