@@ -1099,7 +1099,14 @@ int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
     }
     CRT(hipMalloc((void**)&c->d_state, sizeof(ChunkState)));
     CRT(hipMalloc((void**)&c->d_pool, sizeof(ViewsPool)));
-    CRT(hipMemset(c->d_pool, 0, sizeof(ViewsPool)));
+    // diagnostics of the create-time race hunt: BZQ_POOL_POISON = fill the ticket with garbage first (so that a zeroing
+    // that comes late is SEEN); BZQ_POOL_ZERO = 0: hipMemset on the NULL stream as rounds 4-5 did, 1 (default): on the ctx stream
+    {
+        const char* pz = getenv("BZQ_POOL_ZERO");
+        if (getenv("BZQ_POOL_POISON")) CRT(hipMemset(c->d_pool, 0x7F, sizeof(ViewsPool)));
+        if (pz && pz[0] == '0') CRT(hipMemset(c->d_pool, 0, sizeof(ViewsPool)));
+        else CRT(hipMemsetAsync(c->d_pool, 0, sizeof(ViewsPool), c->stream));
+    }
     CRT(hipHostMalloc((void**)&c->h_state, sizeof(ChunkState), hipHostMallocDefault));
     for (auto& ev : c->ev) CRT(hipEventCreate(&ev));
     { const char* e = getenv("BZQ_LEAN_SUBMIT"); if (e && e[0] == '0') c->lean = 0; }   // (bisecting aid: option lean_submit for a whole process)

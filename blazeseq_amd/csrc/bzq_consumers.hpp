@@ -38,7 +38,7 @@ static __global__ __launch_bounds__(BLOCK) void k_nw_scores(const uint8_t* __res
                                                       const uint8_t* __restrict__ seq, const int64_t* __restrict__ ends,
                                                       int64_t num_records, int32_t* __restrict__ scores) {
     const int lane = threadIdx.x & 63;
-    const int64_t rec = (int64_t)blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+    const int64_t rec = (int64_t)blockIdx.x * (BLOCK / 64) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform: scalar loads, scalar loop control)
     if (rec >= num_records) return;
     const int64_t q0 = rec ? ends[rec - 1] : 0;
     const int64_t qlen64 = ends[rec] - q0;
@@ -46,7 +46,7 @@ static __global__ __launch_bounds__(BLOCK) void k_nw_scores(const uint8_t* __res
         if (lane == 0) scores[rec] = 0;
         return;
     }
-    const int qlen = (int)qlen64;
+    const int qlen = __builtin_amdgcn_readfirstlane((int)qlen64);
     const int nseg = (ref_len + 63) >> 6;   // reference position i = 64*s + lane + 1
     uint32_t rb[4];
     int prev[4];
@@ -56,9 +56,17 @@ static __global__ __launch_bounds__(BLOCK) void k_nw_scores(const uint8_t* __res
         rb[s] = i <= ref_len ? ref[i - 1] : 0x100u;   // never equal to a query byte
         prev[s] = -i;                                   // first row: gap * i (kernels.mojo:61-62)
     }
+    // The query sits in registers, base 64 s + lane in qv[s] (four coalesced loads up front), and row j takes its base by v_readlane:
+    // a load of seq[q0 + j - 1] at the top of every row put one memory latency on each of the 150 serial rows of a record (round 6:
+    // the kernel was latency bound, ~75 us per record and wave; profiles/r6_pipeline.md).
+    uint32_t qv[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { const int k = 64 * s + lane; qv[s] = k < qlen ? (uint32_t)seq[q0 + k] : 0u; }
     int prev0 = 0;   // dp[j-1][0]
     for (int j = 1; j <= qlen; ++j) {
-        const uint32_t qb = seq[q0 + j - 1];   // uniform across the wave
+        const int jb = j - 1;                  // (uniform: the row counter)
+        const uint32_t qsel = jb < 64 ? qv[0] : jb < 128 ? qv[1] : jb < 192 ? qv[2] : qv[3];
+        const uint32_t qb = (uint32_t)__builtin_amdgcn_readlane((int)qsel, jb & 63);
         const int curr0 = -j;                  // dp[j][0] = gap * j
         int carry = curr0;                     // max over positions k < this segment of (curr-candidate[k] + k)
         int left_edge = prev0;                 // dp[j-1][i-1] for lane 0 of the segment

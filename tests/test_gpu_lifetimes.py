@@ -243,10 +243,9 @@ def test_batches_of_a_chunk_are_served_while_the_next_chunk_is_parsed():
     check_batches(fb, 300)
     # a bzq_chunk from two submits ago names arrays that hold ANOTHER chunk now (same pointers): refused by its serial
     assert rd.raw.chunk_serial == 4 and rb.raw.chunk_serial == 2 and rd.raw.d_batch_ends == rb.raw.d_batch_ends
-    import copy
-    stale = copy.copy(rb.raw); stale.d_ends = None; stale.d_id_ends = None
     import ctypes as C
     from blazeseq_amd import _lib as L
+    stale = L.BzqChunk.from_buffer_copy(bytes(rb.raw)); stale.d_ends = None; stale.d_id_ends = None
     assert L.lib().bzq_chunk_cumulative_ends(ctx.h, C.byref(stale)) < 0 and b"no longer alive" in L.lib().bzq_last_error(ctx.h)
     ctx.close()
 
@@ -292,7 +291,8 @@ def test_ingest_close_does_not_wait_for_a_callers_other_streams(tmp_path, kind):
 
     run_file().close()                       # warm: first-use costs, and the cache holds the buffers
     side = torch.cuda.Stream()
-    rate = torch.cuda.get_device_properties(0).clock_rate * 1e3      # shader clock, Hz (an upper bound of the sleep counter's rate)
+    torch.cuda.synchronize(); t0 = time.perf_counter(); torch.cuda._sleep(100_000_000); torch.cuda.synchronize()
+    rate = 100_000_000 / (time.perf_counter() - t0)                  # the spin kernel's counter, ticks per second
     ing = run_file()
     with torch.cuda.stream(side):
         torch.cuda._sleep(int(1.5 * rate))   # a caller's kernel that is nowhere near done: >= ~1 s on its own stream
