@@ -146,6 +146,7 @@ struct bzq_ctx {
     // the state's initial values travel on a stream of their own while pass A runs (it does not look at the state); the scan waits for them
     hipStream_t stream_init = nullptr;
     hipEvent_t ev_init = nullptr;
+    bool pool_dirty = false;      // views mode: pass A may have taken pool tickets that no scan has folded and zeroed yet (a submit that failed in between)
     bool init_in_flight = false;
     bool init_deferred = false;   // ... and are handed to the side stream only BEHIND pass A's launch (the host's copy call is not in front of the first kernel)
     int init_in_kernel = 0;    // diagnostic option "state_init_in_kernel" (1 / 2: ScanArgs::init_mode); DESIGN 10
@@ -650,6 +651,7 @@ void launch_scan(bzq_ctx* c, int64_t tb, int64_t te, int pass) {
     if (ng <= 0) return;
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)ng), dim3(SG_THREADS), 0, c->stream, s);
     hipLaunchKernelGGL(k_scan_down, dim3((unsigned)ng), dim3(SG_THREADS), 0, c->stream, s);
+    if (s.pool && hipPeekAtLastError() == hipSuccess) c->pool_dirty = false;   // (its last workgroup folds the ticket into the state and zeroes it)
 }
 
 // views mode through line entries: pass A leaves a 4-byte entry per line and pass B never reads the input again.  With
@@ -717,6 +719,10 @@ int enqueue_passes(bzq_ctx* c, bool emit_only, bool skip_aggregate_mid) {
                     LineArgs la{c->cur, (int64_t)c->cur_n, c->cur_prev_byte, tb, te, (uint32_t*)c->tile_c.p, (u64*)c->tile_a.p,
                                 (u64*)c->tile_idc.p, (uint32_t*)c->entries.p, (uint32_t*)c->tile_list.p, c->pool_slots, c->d_pool,
                                 c->force_dense, (uint8_t*)c->tile_vf.p, (uint32_t)c->cfg.q_lower, (uint32_t)c->cfg.q_upper};
+                    // the ticket is zero between chunks: the scan's last workgroup folds and zeroes it -- unless a submit died between
+                    // pass A and its scan; then it is zeroed here, on the ctx stream, in front of the next pass A
+                    if (c->pool_dirty) HIPCHK(c, hipMemsetAsync(c->d_pool, 0, sizeof(ViewsPool), c->stream));
+                    c->pool_dirty = true;
                     const dim3 lg((unsigned)((te - tb + LINES_TPW - 1) / LINES_TPW));   // a workgroup walks LINES_TPW tiles
                     if (views_validating(c)) hipLaunchKernelGGL(k_tile_lines<true>, lg, dim3(BLOCK), 0, c->stream, la);
                     else hipLaunchKernelGGL(k_tile_lines<false>, lg, dim3(BLOCK), 0, c->stream, la);
@@ -2599,6 +2605,20 @@ int32_t bzq_release_batch(bzq_ctx* c, bzq_device_batch* b) {
 
 // ---- device-side consumers of a DeviceFastqBatch (bzq_consumers.hpp) --------------------------------------------
 
+// the nw_gpu example's scores of a batch: one thread per record for references of at most 64 bases, one wave per record beyond
+static void launch_nw(hipStream_t cs, const uint8_t* d_ref, int ref_len, const bzq_device_batch* b, int32_t* d_scores) {
+    const int64_t n = b->num_records;
+    const dim3 tg((unsigned)((n + BLOCK - 1) / BLOCK));
+#define BZQ_NW_T(RL) hipLaunchKernelGGL(k_nw_scores_t<RL>, tg, dim3(BLOCK), 0, cs, d_ref, ref_len, b->sequence_buffer, b->ends, n, b->sequence_bytes, d_scores)
+    if (ref_len <= 16) BZQ_NW_T(16);
+    else if (ref_len <= 32) BZQ_NW_T(32);
+    else if (ref_len <= 40) BZQ_NW_T(40);
+    else if (ref_len <= 48) BZQ_NW_T(48);
+    else if (ref_len <= 64) BZQ_NW_T(64);
+    else hipLaunchKernelGGL(k_nw_scores, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, cs, d_ref, ref_len, b->sequence_buffer, b->ends, n, d_scores);
+#undef BZQ_NW_T
+}
+
 int32_t bzq_batch_nw_scores(bzq_ctx* c, const bzq_device_batch* b, const uint8_t* ref, int32_t ref_len, int32_t* d_scores) {
     if (!c || !b || ref_len < 0 || (ref_len && !ref) || (b->num_records && !d_scores)) return BZQ_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));
@@ -2608,9 +2628,7 @@ int32_t bzq_batch_nw_scores(bzq_ctx* c, const bzq_device_batch* b, const uint8_t
     if ((rc = ensure(c, c->consumer_scratch, 4096))) return rc;
     const int copy = ref_len > NW_MAX_LEN ? NW_MAX_LEN : ref_len;   // longer references score 0 like the example
     if (copy) HIPCHK(c, hipMemcpyAsync(c->consumer_scratch.p, ref, (size_t)copy, hipMemcpyHostToDevice, cs));
-    const int64_t n = b->num_records;
-    hipLaunchKernelGGL(k_nw_scores, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, cs,
-                       (const uint8_t*)c->consumer_scratch.p, (int)ref_len, b->sequence_buffer, b->ends, n, d_scores);
+    launch_nw(cs, (const uint8_t*)c->consumer_scratch.p, (int)ref_len, b, d_scores);
     HIPCHK(c, hipStreamSynchronize(cs));   // the host reference bytes may go away after the call
     return 0;
 }
@@ -2675,8 +2693,7 @@ int32_t bzq_batch_nw_scores_dev(bzq_ctx* c, const bzq_device_batch* b, const uin
     hipStream_t cs = c->consumer_stream ? c->consumer_stream : c->stream;
     const int64_t n = b->num_records;
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_nw_scores, dim3((unsigned)((n + BLOCK / 64 - 1) / (BLOCK / 64))), dim3(BLOCK), 0, cs, d_ref, (int)ref_len,
-                       b->sequence_buffer, b->ends, n, d_scores);
+    launch_nw(cs, d_ref, (int)ref_len, b, d_scores);
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) { c->err = std::string("k_nw_scores: ") + hipGetErrorString(le); return BZQ_ERR_HIP; }
     return 0;

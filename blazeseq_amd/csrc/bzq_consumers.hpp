@@ -97,6 +97,73 @@ static __global__ __launch_bounds__(BLOCK) void k_nw_scores(const uint8_t* __res
     if (lane == 0) scores[rec] = out;
 }
 
+// The same scores with ONE THREAD per record, for references of at most 64 bases (the example's has 40).  The wave-per-record kernel
+// above spends ~25 vector instructions on a ROW of the table (a prefix maximum over the lanes for the insertion chain) whatever the
+// reference's length: 150 rows x 25 = 3 750 wave instructions per record, and the file -> records -> scores pipeline was bound by it
+// (profiles/r6_pipeline.md).  Here a lane owns a record and keeps the table's current row in registers, and the recurrence is
+// normalised so that a cell costs four instructions: with R[j][i] = H[j][i] + i + j (H = the example's table, gap = -1) the two gap
+// moves cost NOTHING and the diagonal adds 3 for a match and 1 for a mismatch,
+//     R[j][i] = max3(R[j-1][i-1] + (ref[i] == q[j] ? 3 : 1), R[j-1][i], R[j][i-1]),     R[0][i] = R[j][0] = 0,
+// so a row is RL x (compare, select, add, max3) and the score is R[qlen][ref_len] - ref_len - qlen.  RL cells per row (a template
+// parameter >= ref_len: the row lives in registers, indexed statically; cells beyond the reference compare against a byte that is
+// never a base).  Lanes whose record is shorter than the wave's longest one sit out the remaining rows (EXEC mask, no per-cell cost).
+// 64 records per wave: 40 x 150 x 4 = 24 000 wave instructions per 64 records = 375 per record, a tenth of the kernel above.
+template <int RL>
+static __global__ __launch_bounds__(BLOCK) void k_nw_scores_t(const uint8_t* __restrict__ ref, int ref_len, const uint8_t* __restrict__ seq,
+                                                              const int64_t* __restrict__ ends, int64_t num_records, int64_t col_len,
+                                                              int32_t* __restrict__ scores) {
+    const int64_t rec = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = rec < num_records;
+    int64_t q0 = 0;
+    int qlen = 0;
+    bool zero = false;   // kernels.mojo:48-50: a query longer than 256 scores 0
+    if (live) {
+        q0 = rec ? ends[rec - 1] : 0;
+        const int64_t l = ends[rec] - q0;
+        zero = l > NW_MAX_LEN;
+        qlen = zero ? 0 : (int)l;
+    }
+    uint32_t rb[RL];
+#pragma unroll
+    for (int i = 0; i < RL; ++i) rb[i] = i < ref_len ? (uint32_t)ref[i] : 0x100u;   // (uniform: scalar loads)
+    int row[RL + 1];
+#pragma unroll
+    for (int i = 0; i <= RL; ++i) row[i] = 0;
+    int longest = qlen;   // rows the wave walks: its longest record
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(longest, off, 64); longest = o > longest ? o : longest; }
+    longest = __builtin_amdgcn_readfirstlane(longest);
+    for (int j0 = 0; j0 < longest; j0 += 4) {
+        uint32_t q4 = 0;   // this lane's next four bases
+        if (j0 < qlen) {
+            const int64_t p = q0 + j0;
+            if (p + 4 <= col_len) { struct __attribute__((packed, aligned(1))) U4 { uint32_t v; }; q4 = reinterpret_cast<const U4*>(seq + p)->v; }
+            else for (int k = 0; k < 4 && p + k < col_len; ++k) q4 |= (uint32_t)seq[p + k] << (8 * k);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            if (j0 + jj < qlen) {
+                const uint32_t qb = (q4 >> (8 * jj)) & 0xFFu;
+                int diag = 0;   // R[j-1][0]
+#pragma unroll
+                for (int i = 1; i <= RL; ++i) {
+                    const int up = row[i];
+                    const int d = diag + (rb[i - 1] == qb ? 3 : 1);
+                    const int m = up > row[i - 1] ? up : row[i - 1];
+                    row[i] = d > m ? d : m;
+                    diag = up;
+                }
+            }
+        }
+    }
+    if (live) {
+        int out = row[0];
+#pragma unroll
+        for (int i = 1; i <= RL; ++i) out = i == ref_len ? row[i] : out;
+        scores[rec] = zero ? 0 : out - ref_len - qlen;
+    }
+}
+
 // Sum of the bytes of four dwords (v_sad_u8 against zero: four bytes per instruction).
 __device__ __forceinline__ uint32_t sum_bytes16(uint4 v, uint32_t acc) {
     acc = __builtin_amdgcn_sad_u8(v.x, 0u, acc);

@@ -193,7 +193,9 @@ static __global__ __launch_bounds__(BLOCK) void k_tile_lines(LineArgs a) {
         const bool more = t + 1 < t_end;
         if (more) fetch(t + 1);   // (the registers are free again)
         // wave-local transposition: the four pieces of this lane's 64 bytes were written by lanes of this wave
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        // (acquire AND release: the reads below must not move above it either -- a wave's DS operations execute in order, so this is a
+        // statement to the compiler, not a wait)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const u64 m64 = reinterpret_cast<const u64*>(s_mask)[tid];
         const uint32_t cnt = (uint32_t)__popcll(m64);

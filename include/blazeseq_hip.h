@@ -126,7 +126,10 @@ typedef struct bzq_chunk {
     const int64_t* d_seq_start;
     const int64_t* d_sep_start;
     const int64_t* d_qual_start;
-    /* timing of the kernels of this chunk, hipEvent on the ctx stream (milliseconds) */
+    /* timing of the kernels of this chunk, hipEvent on the ctx stream (milliseconds).  Since round 5 (lean submit): ms_total is ONE
+     * interval, the submit's first event to its last (rounds 1-4: the sum of two intervals around a copy); the four parts are filled
+     * only with option "timing_detail" = 1 (three more events per submit), else 0; ms_rebase = what follows the last emit (k_tail /
+     * k_finish, or k_rebase where the per-record pass still runs). */
     float ms_total;            /* first kernel start -> last kernel end */
     float ms_aggregate, ms_scan, ms_emit, ms_rebase;
     uint32_t n_passes;
