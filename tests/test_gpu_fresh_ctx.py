@@ -7,7 +7,7 @@ chunk's pass A; a fill that landed while pass A was handing out pool slots reset
 one overwrote the other's line entries.  It needs a fresh ctx, a first chunk with pool tiles (records of a few bytes) and the fill
 to be late -- which is why a campaign that keeps 40 ctxs alive met it once in 25 000 streams and a single-ctx stress never did.
 The fill is on the ctx stream now.  Here: (1) the deterministic reproducer -- a spin kernel holds the NULL stream while the ctx is
-created and its first chunk, 0.4 GB with pool tiles all along, is parsed: rounds 4-5's create (kept behind BZQ_POOL_ZERO=0 as this
+created and its first chunk, 0.8 GB with pool tiles all along, is parsed -- rounds 4-5's create (kept behind BZQ_POOL_ZERO=0 as this
 test's hook) gives wrong results whenever the spin ends inside pass A, the shipped create never; (2) bounded stress of fresh ctxs on
 the two campaign streams that failed (views mode: pool tiles, record arrays that overflow and are re-made) and a batch-mode twin."""
 import os
@@ -46,7 +46,7 @@ def _pool_chunk(total_mb):
 def test_a_late_fill_of_the_pool_ticket_is_the_round_5_mismatch_and_the_shipped_create_is_immune(monkeypatch):
     import torch
     import blazeseq_amd as B
-    data, want = _pool_chunk(400)
+    data, want = _pool_chunk(800)
     d_chunk = torch.from_numpy(data.copy()).cuda()
     torch.cuda.synchronize(); t0 = time.perf_counter(); torch.cuda._sleep(100_000_000); torch.cuda.synchronize()
     rate = 100_000_000 / (time.perf_counter() - t0)          # the spin kernel's counter, ticks per second
@@ -62,7 +62,7 @@ def test_a_late_fill_of_the_pool_ticket_is_the_round_5_mismatch_and_the_shipped_
         ctx.close()
         return got
 
-    spins = [0] + list(range(150, 1500, 50))                  # pass A of 0.4 GB takes ~0.1 ms; create + submit ~0.3 ms of host time
+    spins = [0] + list(range(150, 1500, 50))                  # pass A of 0.8 GB takes ~0.15 ms and starts 0.5-0.7 ms after the spin was launched (create + submit on the host)
     monkeypatch.setenv("BZQ_POOL_ZERO", "1")
     assert run(0) == (want, 6)                                # (first-use costs out of the way)
     wrong_new = [s for s in spins for _ in range(2) if run(s) != (want, 6)]
