@@ -420,7 +420,7 @@ REF_40BP = b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT"   # examples/nw_gpu/execu
 PIPE_BATCH = 65536                                        # examples/nw_gpu/execution.mojo:34 (BATCH_SIZE)
 
 
-def pipeline_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, chunk_mib=256):
+def pipeline_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, chunk_mib=256, kinds=("plain", "bgzf", "gzip")):
     """File -> records -> consumer with no host round trip: the reference's ONLY GPU use case (examples/nw_gpu/execution.mojo:100-130:
     `next_batch(65536)` -> `batch.to_device(ctx)` -> `nw_kernel`; the v0.1 quality_distribution kernel, CHANGELOG.md:73) and the regime
     this path exists for -- the records never leave the device.  A ~6.4 GB FASTQ file on /dev/shm -> bzq_ingest_next (reader threads ->
@@ -428,7 +428,9 @@ def pipeline_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, c
     alignment score of every read against the example's 40 bp reference) + bzq_batch_quality_by_position_acc (per-cycle quality
     distribution of the whole file in one device table) on the consumer stream, chunk k's consumers under the ingest of chunk k + 1.
     Wall clock open -> last consumer kernel done; GB/s of FASTQ.  Parity: the accumulated table and the sum of all scores must equal
-    the oracle's CPU twin (orc_pipeline_run) -- asserted.  Beside it: that twin (parse + the same two reductions) on every host core."""
+    the oracle's CPU twin (orc_pipeline_run) -- asserted.  Beside it: that twin (parse + the same two reductions) on every host core.
+    `value` is the plain file; the same pipeline over the file as BGZF and as an ordinary multi-member gzip file (what reads are
+    stored as; both inflated on the device) stands beside it (`bgzf`, `gzip`)."""
     import ctypes as C
     import threading
     import numpy as np
@@ -441,15 +443,32 @@ def pipeline_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, c
     reps = max(2, int(target_gb * 1e9 / k))
     n_fastq, n_rec = reps * k, reps * (k // rec_bytes)
     d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else "/tmp"
-    path = os.path.join(d, f"bzq_bench_pipe_{os.getpid()}.fastq")
+    paths = {m: os.path.join(d, f"bzq_bench_pipe_{os.getpid()}.fastq{ext}") for m, ext in (("plain", ""), ("bgzf", ".bgz"), ("gzip", ".gz"))}
     read_len = (rec_bytes - 18) // 2
     res = {"file_fastq_gb": round(n_fastq / 1e9, 3), "records": n_rec, "batch_records": PIPE_BATCH, "reference_bp": len(REF_40BP), "reader_threads": threads,
            "chunk_mib": chunk_mib}
     try:
+        import struct
+        import zlib
         pb = piece.tobytes()
-        with open(path, "wb") as f:
-            for _ in range(reps):
-                f.write(pb)
+
+        def block(data):
+            c2 = zlib.compressobj(6, zlib.DEFLATED, -15)
+            payload = c2.compress(data) + c2.flush()
+            return (b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 18 + len(payload) + 8 - 1) + payload +
+                    struct.pack("<II", zlib.crc32(data) & 0xFFFFFFFF, len(data)))
+        pieces = {"plain": (pb, b"")}
+        if "bgzf" in kinds:
+            pieces["bgzf"] = (b"".join(block(pb[i:i + 65280]) for i in range(0, k, 65280)), block(b""))
+        if "gzip" in kinds:
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            pieces["gzip"] = (bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 0, 3]) + co.compress(pb) + co.flush() + struct.pack("<II", zlib.crc32(pb) & 0xFFFFFFFF, k & 0xFFFFFFFF), b"")
+        for m, (body, trailer) in pieces.items():
+            with open(paths[m], "wb") as f:
+                for _ in range(reps):
+                    f.write(body)
+                f.write(trailer)
+        del pieces
         # ---- the CPU twin on one piece: the expected table / score sum (the file is the piece repeated, record aligned) and the host figure
         cfg = O.make_config(buffer_capacity=64 * 1024, batch_size=PIPE_BATCH)
         cores = max(1, os.cpu_count() or 1)
@@ -483,40 +502,59 @@ def pipeline_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, c
         nb_cap = (chunk_mib << 20) // rec_bytes // PIPE_BATCH + 8
         arr = (L.BzqDeviceBatch * nb_cap)()
         nb_out = C.c_uint64()
-        best = None
-        for it in range(4):          # run 0: the file's first read + first-use costs, not reported
-            d_counts.zero_()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            ing = B.Ingest(ctx, path, chunk_bytes=chunk_mib << 20, n_threads=threads)
-            taken = total = chunks = 0
-            prev_ev = None
-            t_cons = 0.0
-            while True:
-                r = ing.next(taken)
-                taken = int(r.n_records)
-                if prev_ev is not None:
-                    prev_ev.synchronize()    # two-chunk lifetime rule: chunk k - 1's consumers are through before chunk k + 1 is submitted
-                assert L.lib().bzq_batches(ctx.h, PIPE_BATCH, arr, nb_cap, C.byref(nb_out)) == 0 and nb_out.value <= nb_cap
-                for b in range(nb_out.value):
-                    assert L.lib().bzq_batch_nw_scores_dev(ctx.h, C.byref(arr[b]), C.c_void_p(d_ref.data_ptr()), len(REF_40BP),
-                                                           C.c_void_p(d_scores.data_ptr() + 4 * (total + b * PIPE_BATCH))) == 0
-                    assert L.lib().bzq_batch_quality_by_position_acc(ctx.h, C.byref(arr[b]), read_len, C.c_void_p(d_counts.data_ptr())) == 0
-                prev_ev = torch.cuda.Event(); prev_ev.record(side)
-                total += taken
-                chunks += 1
-                if int(r.status) != L.OK:
-                    break
-            ing.close()
-            side.synchronize()
-            dt = time.perf_counter() - t0
-            assert total == n_rec and int(r.status) == L.EOF, (total, n_rec, int(r.status))
-            if it and (best is None or dt < best):
-                best = dt
-        # parity on the consumer outputs, every run's last: the whole file's table and score sum
-        got = d_counts.cpu().numpy().reshape(read_len, 128).astype(np.uint64)
-        assert np.array_equal(got, counts1 * np.uint64(reps)), "pipeline_mode: per-position quality table differs from the CPU twin"
-        assert int(d_scores.to(torch.int64).sum().item()) == ss1 * reps, "pipeline_mode: NW scores differ from the CPU twin"
+        def run_kind(path):
+            best = None
+            for it in range(4):          # run 0: the file's first read + first-use costs, not reported
+                d_counts.zero_()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ing = B.Ingest(ctx, path, chunk_bytes=chunk_mib << 20, n_threads=threads)
+                taken = total = chunks = 0
+                prev_ev = None
+                t_cons = 0.0
+                while True:
+                    r = ing.next(taken)
+                    taken = int(r.n_records)
+                    if prev_ev is not None:
+                        prev_ev.synchronize()    # two-chunk lifetime rule: chunk k - 1's consumers are through before chunk k + 1 is submitted
+                    assert L.lib().bzq_batches(ctx.h, PIPE_BATCH, arr, nb_cap, C.byref(nb_out)) == 0 and nb_out.value <= nb_cap
+                    for b in range(nb_out.value):
+                        assert L.lib().bzq_batch_nw_scores_dev(ctx.h, C.byref(arr[b]), C.c_void_p(d_ref.data_ptr()), len(REF_40BP),
+                                                               C.c_void_p(d_scores.data_ptr() + 4 * (total + b * PIPE_BATCH))) == 0
+                        assert L.lib().bzq_batch_quality_by_position_acc(ctx.h, C.byref(arr[b]), read_len, C.c_void_p(d_counts.data_ptr())) == 0
+                    prev_ev = torch.cuda.Event(); prev_ev.record(side)
+                    total += taken
+                    chunks += 1
+                    if int(r.status) != L.OK:
+                        break
+                ing.close()
+                side.synchronize()
+                dt = time.perf_counter() - t0
+                assert total == n_rec and int(r.status) == L.EOF, (total, n_rec, int(r.status))
+                if it and (best is None or dt < best):
+                    best = dt
+            return best, chunks
+
+        def check_outputs(kind):
+            # parity on the consumer outputs of the kind's last run: the whole file's table and score sum
+            got = d_counts.cpu().numpy().reshape(read_len, 128).astype(np.uint64)
+            assert np.array_equal(got, counts1 * np.uint64(reps)), f"pipeline_mode ({kind}): per-position quality table differs from the CPU twin"
+            assert int(d_scores.to(torch.int64).sum().item()) == ss1 * reps, f"pipeline_mode ({kind}): NW scores differ from the CPU twin"
+
+        best, chunks = run_kind(paths["plain"])
+        check_outputs("plain")
+        for m in kinds:
+            if m == "plain":
+                continue
+            if m == "gzip":   # (a .gz stream's pools and FIFO are ~10 GiB: let the library's cache keep them between the runs, as ingest_mode does)
+                ctx.set_option("dev_cache_bytes", 16 << 30)
+            bm, cm = run_kind(paths[m])
+            check_outputs(m)
+            res[m] = {"value": round(n_fastq / bm / 1e9, 2), "unit": "GB/s of FASTQ", "ms": round(bm * 1e3, 1), "chunks": cm,
+                      "file_gb": round(os.path.getsize(paths[m]) / 1e9, 3), "consumer_outputs_equal_cpu_twin": True}
+        for key in ("pin_cache_bytes", "dev_cache_bytes"):   # (give the cached buffers back, and the library's default limits again)
+            ctx.set_option(key, 0)
+            ctx.set_option(key, 1 << 30)
         ctx.close()
         cpu_bytes = cores * per * rec_bytes
         res.update({"value": round(n_fastq / best / 1e9, 2), "unit": "GB/s of FASTQ", "mrecords_per_s": round(n_rec / best / 1e6, 1), "ms": round(best * 1e3, 1),
@@ -531,10 +569,11 @@ def pipeline_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, c
                             "(no host round trip; chunk k's consumers under chunk k+1's ingest); wall clock open -> last consumer done, best of 3 after one untimed pass; "
                             "PCIe inclusive; the CPU twin works from memory (no file read)"})
     finally:
-        try:
-            os.remove(path)
-        except OSError:
-            pass
+        for q in paths.values():
+            try:
+                os.remove(q)
+            except OSError:
+                pass
     return res
 
 
@@ -546,6 +585,7 @@ def process_mode(ctx, dev, runs=15, warmup=3, modes=("plain", "bgzf", "gzip")):
     `records base_pairs` printed -> exit), the clock is around the subprocess: dynamic loading, HIP initialisation, pinning, the
     file, teardown -- everything.  plain = the reference generator's own reads; .bgz / .gz = the first 32 MiB of them, compressed
     once (zlib -6) and repeated to the same size (compressing 3 GiB on one host core would take minutes)."""
+    import re
     import statistics
     import struct
     import subprocess
@@ -599,10 +639,11 @@ def process_mode(ctx, dev, runs=15, warmup=3, modes=("plain", "bgzf", "gzip")):
         del host
         for m in modes:
             fastq_bytes = n if m == "plain" else reps * k
-            walls = []
+            walls, parts = [], []
+            env_t = dict(os.environ, BZQ_THROUGHPUT_TIMES="1")   # (one line on stderr at the very end of main: where the process's time went)
             for it in range(warmup + runs):
                 t0 = time.perf_counter()
-                r = subprocess.run([exe, paths[m], "batches"], capture_output=True, text=True, timeout=120)
+                r = subprocess.run([exe, paths[m], "batches"], capture_output=True, text=True, timeout=120, env=env_t)
                 dt = time.perf_counter() - t0
                 if r.returncode != 0:
                     raise RuntimeError(f"{m}: bzq_throughput exit {r.returncode}: {r.stderr[-300:]}")
@@ -610,10 +651,17 @@ def process_mode(ctx, dev, runs=15, warmup=3, modes=("plain", "bgzf", "gzip")):
                 assert got == expect[m], (m, got, expect[m])
                 if it >= warmup:
                     walls.append(dt)
+                    mt = re.search(r"create ([\d.]+) ms, open ([\d.]+) ms, first chunk ([\d.]+) ms, remaining \d+ chunks ([\d.]+) ms, close\+destroy ([\d.]+) ms, main total ([\d.]+) ms", r.stderr)
+                    if mt:
+                        v = [float(x) for x in mt.groups()]
+                        parts.append(v[:5] + [dt * 1e3 - v[5]])
             mean = statistics.fmean(walls)
             res[m] = {"value": round(fastq_bytes / mean / 1e9, 2), "unit": "GB/s of FASTQ, whole process", "mean_ms": round(mean * 1e3, 1), "stdev_ms": round(statistics.pstdev(walls) * 1e3, 1),
                       "min_ms": round(min(walls) * 1e3, 1), "max_ms": round(max(walls) * 1e3, 1), "best_gb_s": round(fastq_bytes / min(walls) / 1e9, 2),
                       "file_gb": round(os.path.getsize(paths[m]) / 1e9, 3), "stdout": " ".join(str(x) for x in got)}
+            if parts:   # mean milliseconds of the timed runs: bzq_create is HIP's start-up; outside_main = exec, dynamic loading, the runtime's teardown
+                res[m]["where_ms"] = {kname: round(statistics.fmean(pv[i] for pv in parts), 1)
+                                      for i, kname in enumerate(("bzq_create_hip_start_up", "ingest_open", "first_chunk", "remaining_chunks", "close_and_destroy", "outside_main"))}
     finally:
         for q in paths.values():
             try:

@@ -441,7 +441,11 @@ def test_device_memory_a_gz_stream_holds():
         ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
         for key in ("pin_cache_bytes", "dev_cache_bytes"):
             ctx.set_option(key, 0)
-        for chunk_mib, limit_gib in ((64, 4.6), (256, 11.5)):   # measured 3.48 / 10.58 GiB (round 5, after the pool / FIFO diet; 5.62 / 13.24 on a file of two pieces before), parser arenas included
+        # measured 3.48 / 10.58 GiB (round 5, after the pool / FIFO diet; 5.62 / 13.24 on a file of two pieces before), parser arenas included --
+        # and 12.25 GiB at 256 MiB when piece 1 is planned before piece 0's ratio is known (its finder and decoders run under piece 0's
+        # chain: which one happens first is timing), so that BOTH pools are sized by the first-piece rule (3 x instead of the stream's
+        # own 2.1 x 1.25): the bound below is that case, the deterministic upper end (round 6: seen once in four runs)
+        for chunk_mib, limit_gib in ((64, 4.6), (256, 12.6)):
             assert hip.hipDeviceSynchronize() == 0
             free0 = mem_free()
             ing = B.Ingest(ctx, path, chunk_bytes=chunk_mib << 20, n_threads=4)
