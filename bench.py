@@ -48,8 +48,16 @@ def launch_ranks(nranks, argv, script=None, deadline_s=3600.0, poll_s=0.05):
     line is the launcher's); the other ranks' stdout goes to stderr.  The first rank that exits non-zero is NAMED, the
     others are stopped (by their own PIDs) and the launcher exits with that rank's code; the same when the deadline
     passes.  Returns the exit code (0 = every rank exited 0)."""
+    import signal
     import socket
     import subprocess
+
+    def die_with_parent():   # (Linux: a rank must not outlive a launcher that was killed -- it would keep its GPU busy)
+        try:
+            import ctypes
+            ctypes.CDLL(None).prctl(1, signal.SIGTERM)   # PR_SET_PDEATHSIG
+        except Exception:   # noqa: BLE001
+            pass
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -60,7 +68,19 @@ def launch_ranks(nranks, argv, script=None, deadline_s=3600.0, poll_s=0.05):
                    GROUP_RANK="0", ROLE_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BZQ_BENCH_LAUNCHER_PID=str(os.getpid()))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this host driver
         env.setdefault("OMP_NUM_THREADS", "1")
-        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=None if r == 0 else sys.stderr))
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=None if r == 0 else sys.stderr, preexec_fn=die_with_parent))
+
+    def stop_all(signum, frame):   # the launcher is being stopped (a driver's timeout, ^C): take the ranks along, exactly the PIDs started here
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        print(f"[bench launcher] stopped by signal {signum}: the ranks were told to stop", file=sys.stderr, flush=True)
+        os._exit(128 + signum)
+    for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        try:
+            signal.signal(sg, stop_all)
+        except (ValueError, OSError):   # (not the main thread: a test harness)
+            pass
     t_end = time.monotonic() + deadline_s
     failed = None
     live = set(range(nranks))

@@ -67,3 +67,27 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode != 0 and b"WORLD_SIZE is 2" in r.stderr
+
+
+def test_a_stopped_launcher_takes_its_ranks_along(tmp_path):
+    """A driver that times out kills the launcher: the ranks must not stay behind on their GPUs."""
+    import signal
+    child = tmp_path / "child.py"
+    child.write_text("import os, sys, time\nopen(sys.argv[1] + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(600)\n")
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); import bench; "
+            f"sys.exit(bench.launch_ranks(2, [{str(tmp_path / 'pid')!r}], script={str(child)!r}))")
+    p = subprocess.Popen([sys.executable, "-c", code], cwd=ROOT, stderr=subprocess.PIPE,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    t0 = time.monotonic()
+    while not all((tmp_path / f"pid{r}").exists() and (tmp_path / f"pid{r}").read_text() for r in (0, 1)):
+        assert time.monotonic() - t0 < 60 and p.poll() is None
+        time.sleep(0.05)
+    pids = [int((tmp_path / f"pid{r}").read_text()) for r in (0, 1)]
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(timeout=30) == 128 + signal.SIGTERM
+    t0 = time.monotonic()
+    alive = pids
+    while alive and time.monotonic() - t0 < 20:
+        alive = [q for q in alive if os.path.exists(f"/proc/{q}") and "Z" not in open(f"/proc/{q}/stat").read().split()[2]]
+        time.sleep(0.1)
+    assert not alive, alive
