@@ -679,6 +679,19 @@ def process_mode(ctx, dev, runs=15, warmup=3, modes=("plain", "bgzf", "gzip")):
             res[m] = {"value": round(fastq_bytes / mean / 1e9, 2), "unit": "GB/s of FASTQ, whole process", "mean_ms": round(mean * 1e3, 1), "stdev_ms": round(statistics.pstdev(walls) * 1e3, 1),
                       "min_ms": round(min(walls) * 1e3, 1), "max_ms": round(max(walls) * 1e3, 1), "best_gb_s": round(fastq_bytes / min(walls) / 1e9, 2),
                       "file_gb": round(os.path.getsize(paths[m]) / 1e9, 3), "stdout": " ".join(str(x) for x in got)}
+            if m == "plain":   # the same process leaving at once behind its result line (no close / destroy / runtime teardown): beside `value`, never in its place
+                fw = []
+                env_f = dict(os.environ, BZQ_THROUGHPUT_FAST_EXIT="1")
+                for it in range(warmup + runs):
+                    t0 = time.perf_counter()
+                    r = subprocess.run([exe, paths[m], "batches"], capture_output=True, text=True, timeout=120, env=env_f)
+                    dt = time.perf_counter() - t0
+                    assert r.returncode == 0 and tuple(int(x) for x in r.stdout.split()) == expect[m]
+                    if it >= warmup:
+                        fw.append(dt)
+                fm = statistics.fmean(fw)
+                res[m]["fast_exit"] = {"value": round(fastq_bytes / fm / 1e9, 2), "mean_ms": round(fm * 1e3, 1), "stdev_ms": round(statistics.pstdev(fw) * 1e3, 1),
+                                       "min_ms": round(min(fw) * 1e3, 1), "note": "BZQ_THROUGHPUT_FAST_EXIT=1: _exit(0) behind the result line"}
             if parts:   # mean milliseconds of the timed runs: bzq_create is HIP's start-up; outside_main = exec, dynamic loading, the runtime's teardown
                 res[m]["where_ms"] = {kname: round(statistics.fmean(pv[i] for pv in parts), 1)
                                       for i, kname in enumerate(("bzq_create_hip_start_up", "ingest_open", "first_chunk", "remaining_chunks", "close_and_destroy", "outside_main"))}

@@ -458,7 +458,13 @@ inline void ingest_producer(bzq_ingest* g) {
         } else if (g->gpu_inflate) {
             ok = read_bgzf_window(g, s.pinned + g->reserve, g->chunk_bytes, g->tab_pinned[b], &n_blocks, &comp_len, &len, &eof, err, g->chunk_bytes);
         } else if (g->compression == 0) {
-            len = std::min<uint64_t>(g->chunk_bytes, g->file_size - off);
+            // A file of several chunks starts with SHORT ones (an eighth, a quarter, half a chunk): read -> copy -> parse of chunk 0
+            // are in series, nothing overlaps them, and with a whole first chunk that was 20-35 ms of a fresh process's ~100 ms for
+            // the file (bench.py process_mode).  From chunk 3 on the chunk size is the caller's.  BZQ_INGEST_RAMP=0: off (A/B).
+            static const bool ramp = !(getenv("BZQ_INGEST_RAMP") && getenv("BZQ_INGEST_RAMP")[0] == '0');
+            uint64_t want_len = g->chunk_bytes;
+            if (ramp && k < 3 && g->file_size > 2 * g->chunk_bytes && g->chunk_bytes >= (8ull << 20)) want_len = (g->chunk_bytes >> (3 - k)) & ~4095ull;
+            len = std::min<uint64_t>(want_len, g->file_size - off);
             ok = parallel_pread(g->fd, s.pinned + g->reserve, off, len, g->n_threads, err, g->fd_direct, &g->numa_cpus);
             eof = off + len >= g->file_size;
         } else {
