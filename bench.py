@@ -34,7 +34,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 # but READ from the committed rocprofv3 summary of this very command (scripts/gpu_profile.sh -> profiles/<tag>_summary.txt),
 # so the number printed is by construction the one in the cited file (tests/test_bench_contract.py pins the parse).
 # FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled per the gfx950 correction of MI355X_MICROARCH.md (HBM section).
-TRAFFIC_PROFILE = "profiles/r5_final_summary.txt"
+TRAFFIC_PROFILE = "profiles/r6_final_summary.txt"
 TRAFFIC_KERNEL = "k_fused<false, false, false, false, true>"   # the default emit (per-batch ends folded in); a run without the fold cites the other instantiation
 TRAFFIC_KERNEL_UNFOLDED = "k_fused<false, false, false, false>"
 TRAFFIC_RECORDS = 10_000_000   # the profiled launch: 10 M x 150 bp
