@@ -1809,6 +1809,12 @@ int32_t bzq_chunk_cumulative_ends(bzq_ctx* c, bzq_chunk* inout) {
 int32_t bzq_views(bzq_ctx* c, uint64_t first_record, uint32_t max_records, bzq_device_views* out) {
     if (!c || !out || !(c->have_result || c->res_alive)) { if (c) c->err = "bzq_views: no parsed chunk (or two chunks have been submitted since its result was taken)"; return BZQ_ERR_ARG; }
     if (!c->cfg.views_only) { c->err = "bzq_views: the ctx is not in views mode (config.views_only)"; return BZQ_ERR_ARG; }
+    // views point INTO the chunk: served behind the next submit only where the chunk's bytes are the caller's (bzq_submit_chunk_device);
+    // a host submit's bytes sit in the ctx's staging buffer, which the next host submit overwrites
+    if (!c->have_result && c->res_cur && c->res_cur == (const uint8_t*)c->in.p) {
+        c->err = "bzq_views: the chunk was submitted from host memory and the next chunk has been submitted since (its bytes on the device are being overwritten)";
+        return BZQ_ERR_ARG;
+    }
     memset(out, 0, sizeof(*out));
     out->first_record = first_record;
     out->chunk = c->res_cur;

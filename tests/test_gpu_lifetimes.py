@@ -305,3 +305,37 @@ def test_ingest_close_does_not_wait_for_a_callers_other_streams(tmp_path, kind):
     total_sleep = time.perf_counter() - t0
     assert still_running and dt < 0.25 * total_sleep, (dt, total_sleep, still_running)   # the close came back while the other stream was still busy
     ctx.close()
+
+
+def test_views_of_a_chunk_behind_the_next_submit():
+    """Views mode hands out offsets INTO the chunk.  Behind the next submit they are served where the chunk's bytes are the caller's
+    (bzq_submit_chunk_device: the double-buffer contract covers the offset arrays, the caller keeps its buffer) and refused where they
+    sat in the ctx's staging buffer that the next host submit overwrites."""
+    import ctypes as C
+    import torch
+    import blazeseq_amd as B
+    from blazeseq_amd import _lib as L
+    a = O.generate_synthetic(20_000, 30, 160, 0, 40, "sanger")
+    b = O.generate_synthetic(15_000, 100, 100, 5, 35, "sanger")
+    fa = O.flat_parse(a, O.make_config())
+    ctx = B.Context(B.ParserConfig(views_only=True), "generic", 4096, 0)
+    da, db = torch.from_numpy(a.copy()).cuda(), torch.from_numpy(b.copy()).cuda()
+    ctx.submit_device(da.data_ptr(), da.numel(), 0, True)
+    ra = ctx.result()
+    ctx.submit_device(db.data_ptr(), db.numel(), 0, True)          # chunk B in flight
+    v = L.BzqDeviceViews()
+    assert L.lib().bzq_views(ctx.h, 100, 5000, C.byref(v)) == 0 and v.num_records == 5000 and v.chunk == da.data_ptr()
+    e = np.empty(5000, dtype=np.int64)
+    ctx.copy_to_host(e, v.record_end, e.nbytes)
+    np.testing.assert_array_equal(e, fa.record_end[100:5100])
+    ctx.copy_to_host(e, v.seq_start, e.nbytes)
+    np.testing.assert_array_equal(e, fa.seq_start[100:5100])
+    rb = ctx.result()
+    assert int(rb.n_records) == 15_000
+    # host submits: the chunk's bytes live in the ctx's staging buffer
+    ra2 = ctx.parse(a, 0, True)
+    assert L.lib().bzq_views(ctx.h, 0, 10, C.byref(v)) == 0 and v.num_records == 10
+    ctx.submit_host(b, 0, True)
+    assert L.lib().bzq_views(ctx.h, 0, 10, C.byref(v)) < 0 and b"overwritten" in L.lib().bzq_last_error(ctx.h)
+    assert int(ctx.result().n_records) == 15_000
+    ctx.close()
