@@ -229,7 +229,15 @@ int32_t bzq_get_config(const bzq_ctx* ctx, bzq_config* out);
  * chunk is parsed -- so that trailing bytes that are not a record are judged with that window where it
  * really sits, io/buffered.mojo:239-290; -1 (default) = each chunk is judged as a stream of its own;
  * bzq_ingest_next sets it itself);
- * "double_buffer" (1 default / 0: number of output sets, see the lifetime rule at the top). */
+ * "double_buffer" (1 default / 0: number of output sets, see the lifetime rule at the top).
+ * Queries (the value is ignored, the answer is the return value): "n_submits", "stream_fallbacks" (chunks parsed twice because pass A's
+ * hypothesis failed), "dense_tiles" (tiles of the last parsed chunk that took the serial in-kernel path), "last_folded", "ranks_seen",
+ * "device", "numa_node", "numa_cpus", "buf_cache_hits", "buf_cache_held_mb".
+ * Diagnostics of round 6's race hunt, off by default and of no use to a host: "state_init_in_kernel" (1-4: the chunk
+ * state's initial values written by a kernel instead of copied in), "dump_state" (query: the last result's state snapshots to stderr);
+ * environment BZQ_POOL_ZERO=0 restores rounds 4-5's create (the views pool's ticket zeroed on the NULL stream: the defect, kept as the
+ * hook of tests/test_gpu_fresh_ctx.py), BZQ_POOL_POISON=1 fills the ticket with garbage first, BZQ_INGEST_RAMP=0 reads a plain file in
+ * whole chunks from the first one on (A/B of the short first chunks). */
 int32_t bzq_set_option(bzq_ctx* ctx, const char* key, int64_t value);
 
 /* DeviceContext.enqueue_create_host_buffer (record_batch.mojo:316-323): pinned staging the host
