@@ -225,6 +225,7 @@ SYMBOLS = {
     "bzq_batch_quality_by_position": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.c_int32, C.POINTER(C.c_uint64)]),
     "bzq_batch_nw_scores_dev": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.c_void_p, C.c_int32, C.c_void_p]),
     "bzq_batch_quality_by_position_acc": (C.c_int32, [C.c_void_p, C.POINTER(BzqDeviceBatch), C.c_int32, C.c_void_p]),
+    "bzq_consumer_synchronize": (C.c_int32, [C.c_void_p]),
     "bzq_column_histogram": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "bzq_column_gc_counts": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "bzq_fasta_create": (C.c_int32, [C.c_int32, C.POINTER(BzqFastaConfig), C.POINTER(C.c_void_p)]),

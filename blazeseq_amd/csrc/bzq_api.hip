@@ -2717,6 +2717,13 @@ int32_t bzq_batch_quality_by_position_acc(bzq_ctx* c, const bzq_device_batch* b,
     return 0;
 }
 
+int32_t bzq_consumer_synchronize(bzq_ctx* c) {
+    if (!c) return BZQ_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->consumer_stream ? c->consumer_stream : c->stream));
+    return 0;
+}
+
 int32_t bzq_column_histogram(bzq_ctx* c, const uint8_t* d_col, uint64_t n, uint64_t* hist) {
     if (!c || !hist || (n && !d_col)) return BZQ_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->device));

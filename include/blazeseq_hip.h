@@ -556,6 +556,11 @@ int32_t bzq_batch_quality_by_position(bzq_ctx* ctx, const bzq_device_batch* b, i
  *          distribution of a whole file in one table. */
 int32_t bzq_batch_nw_scores_dev(bzq_ctx* ctx, const bzq_device_batch* b, const uint8_t* d_ref, int32_t ref_len, int32_t* d_scores);
 int32_t bzq_batch_quality_by_position_acc(bzq_ctx* ctx, const bzq_device_batch* b, int32_t max_positions, uint64_t* d_counts);
+/* Waits for everything enqueued so far on the consumer stream (bzq_set_consumer_stream; default: the ctx stream): what a host without a
+ * HIP binding of its own calls before it reads the asynchronous consumers' outputs (bzq_copy_to_host does not wait for that stream) and
+ * before the second submit after a chunk whose consumers may still be running.  DeviceContext.synchronize() of the example,
+ * examples/nw_gpu/execution.mojo:126-130. */
+int32_t bzq_consumer_synchronize(bzq_ctx* ctx);
 /* 256-bin byte histogram of a device column (base composition of sequence_buffer, quality distribution of
  * qual_buffer; the v0.1 quality_distribution example, CHANGELOG.md:73).  hist: host uint64[256]. */
 int32_t bzq_column_histogram(bzq_ctx* ctx, const uint8_t* d_col, uint64_t n, uint64_t* hist);

@@ -378,3 +378,25 @@ def test_gunzip_from_plain_c(tmp_path):
     path.write_bytes(bytes(bad))
     r = subprocess.run([exe, str(path)], capture_output=True, timeout=300)
     assert r.returncode == 3 and b"bzq_gzip" in r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["plain", "gz"])
+def test_the_references_gpu_example_as_a_plain_c_pipeline(tmp_path, kind):
+    """tests/c_driver/bzq_pipeline.c = examples/nw_gpu/execution.mojo:100-130 over the C ABI from a host with no HIP binding: file ->
+    bzq_ingest_next -> batches(65536) -> bzq_batch_nw_scores_dev + bzq_batch_quality_by_position_acc -> bzq_consumer_synchronize ->
+    results.  Records, the sum of all scores and the per-cycle quality table (sum and FNV-1a) must equal the oracle's CPU twin."""
+    import gzip
+    from oracle import oracle as O
+    _build()
+    exe = os.path.join(DRV, "bzq_pipeline")
+    data = O.generate_synthetic(150_000, 30, 220, 0, 40, "sanger")           # ~24 MB: three 8 MiB chunks, variable-length reads
+    path = tmp_path / ("p.fastq" if kind == "plain" else "p.fastq.gz")
+    path.write_bytes(data.tobytes() if kind == "plain" else gzip.compress(data.tobytes(), 1))
+    n, counts, score_sum = O.pipeline_run(data, O.make_config(buffer_capacity=64 * 1024, batch_size=65536), b"ACGTACGTACGTACGTACGTACGTACGTACGTACGTACGT", 150)
+    fnv = 1469598103934665603
+    for byte in counts.astype("<u8").tobytes():
+        fnv = ((fnv ^ byte) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    r = subprocess.run([exe, str(path), "150"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [int(x) for x in r.stdout.split()] == [n, score_sum, int(counts.sum()), fnv], (r.stdout, n, score_sum)
