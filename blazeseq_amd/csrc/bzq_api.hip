@@ -2133,7 +2133,7 @@ static int32_t ingest_open_common(int device, std::string& err, const char* who,
     if (gz_on_device && getenv("BZQ_GZ_PIECE_MIB") && atoll(getenv("BZQ_GZ_PIECE_MIB")) > 0) g->gz_piece = std::min<uint64_t>(g->gz_piece.load(), (uint64_t)atoll(getenv("BZQ_GZ_PIECE_MIB")) << 20);   // (sweeps)   // (the first pieces; then by the file's compression ratio, up to a chunk: gz_fill_fifo)
     // (a .gz decoded on the device copies on the decoder's own streams: one stream less in the default class, whose four hardware queues
     // the decoder's find / copy / finder streams then have to themselves)
-    bool ok = gz_on_device || hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    bool ok = gz_on_device || bzq::cache::stream_pool().get(g->device, &g->copy_stream) == hipSuccess;
     if (ok) {   // the slots side by side: pinning a chunk-sized buffer takes ~30 ms, and three of them one after the other were most of an open
         bool slot_ok[bzq::INGEST_SLOTS];
         std::thread th[bzq::INGEST_SLOTS];

@@ -237,6 +237,35 @@ struct HostSmall {
 };
 inline HostSmall& host_small() { static HostSmall* h = new HostSmall(); return *h; }
 
+// Helper streams (non-blocking, default priority class: copy / inflate / finder streams of the ingest and the gzip decoder) are kept
+// for the process instead of being destroyed at a close: hipStreamDestroy finishes the stream's hardware queue with a marker
+// (0.3-0.6 ms even when idle) -- and the runtime maps streams onto FOUR hardware queues per priority class, so that marker can land
+// behind a long kernel of a caller's stream that happens to share the queue (seen once in round 6: a close waited 1.5 s for another
+// stream's spin kernel).  A stream from here continues in order behind whatever its previous user left; callers synchronise it
+// before they put it back if work of theirs may still be in flight.
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;   // (device, stream)
+    static constexpr size_t MAX_IDLE = 24;
+    hipError_t get(int device, hipStream_t* out) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].first == device) { *out = idle[i].second; idle.erase(idle.begin() + (long)i); return hipSuccess; }
+        }
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    }
+    void put(int device, hipStream_t s) {
+        if (!s) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (idle.size() < MAX_IDLE) { idle.emplace_back(device, s); return; }
+        }
+        (void)hipStreamDestroy(s);
+    }
+};
+inline StreamPool& stream_pool() { static StreamPool* p = new StreamPool(); return *p; }
+
 template <class T> inline bool get_pinned(int device, uint64_t want, T** out) { return pinned_pool().get(device, want, (void**)out) == hipSuccess; }
 template <class T> inline bool get_device(int device, uint64_t want, T** out) { return device_pool().get(device, want, (void**)out) == hipSuccess; }
 

@@ -1735,9 +1735,10 @@ inline void gz_free(bzq_gzip* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
-    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
-    if (h->find_stream) { (void)hipStreamSynchronize(h->find_stream); (void)hipStreamDestroy(h->find_stream); }
-    if (h->early_stream) { (void)hipStreamSynchronize(h->early_stream); (void)hipStreamDestroy(h->early_stream); }
+    // (helper streams go back to the process-wide pool instead of hipStreamDestroy: bzq_bufcache.hpp)
+    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); bzq::cache::stream_pool().put(h->device, h->copy_stream); }
+    if (h->find_stream) { (void)hipStreamSynchronize(h->find_stream); bzq::cache::stream_pool().put(h->device, h->find_stream); }
+    if (h->early_stream) { (void)hipStreamSynchronize(h->early_stream); bzq::cache::stream_pool().put(h->device, h->early_stream); }
     for (hipEvent_t e : {h->pre_ev, h->pre_copy_ev, h->pre_dec_ev, h->ver_ev}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->staged_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->early_ev) if (e) (void)hipEventDestroy(e);
@@ -1764,8 +1765,8 @@ inline int gz_open(int device, bzq_gzip** out, std::string& err) {
     const bool prio = (!pe || pe[0] != '0') && hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess && phi < plo;
     if ((prio ? hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, phi) : hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking)) != hipSuccess) { err = "bzq_gzip_open: hipStreamCreate failed"; delete h; return BZQ_ERR_HIP; }
     h->stream = h->own_stream;
-    if (hipStreamCreateWithFlags(&h->find_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->pre_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->pre_copy_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ver_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->pre_dec_ev, hipEventDisableTiming) != hipSuccess || hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[0], hipEventDisableTiming) != hipSuccess ||
+    if (bzq::cache::stream_pool().get(device, &h->find_stream) != hipSuccess || hipEventCreateWithFlags(&h->pre_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->pre_copy_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->ver_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->pre_dec_ev, hipEventDisableTiming) != hipSuccess || bzq::cache::stream_pool().get(device, &h->copy_stream) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->staged_ev[1], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->staged_ev[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&h->early_ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->early_ev[1], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&h->early_ev[2], hipEventDisableTiming) != hipSuccess) {
         err = "bzq_gzip_open: hipStreamCreate failed"; gz_free(h); return BZQ_ERR_HIP;
@@ -1861,7 +1862,7 @@ inline int gz_stage(bzq_gzip* h, const uint8_t* src, uint64_t n_new) {
         if (fit(h->jobs_e[bi], (size_t)(nch + MAX_FALLBACK) * sizeof(Job)) && fit(h->order_e[bi], (size_t)2 * ORDER_BINS * 4 + (size_t)nch * 5 + 64)) {
             Args a2{};
             a2.comp = d - CH; a2.n = (int64_t)n_new + CH; a2.jobs = (Job*)h->jobs_e[bi].p; a2.n_jobs = nch; a2.n_cand = nch; a2.chunk_bytes = CH; a2.counters = (uint32_t*)h->counters_e[bi].p;
-            if (!h->early_stream) e = hipStreamCreateWithFlags(&h->early_stream, hipStreamNonBlocking);
+            if (!h->early_stream) e = bzq::cache::stream_pool().get(h->device, &h->early_stream);
             if (e == hipSuccess) e = hipStreamWaitEvent(h->early_stream, h->staged_ev[bi], 0);
             if (e == hipSuccess) e = hipMemsetAsync(h->counters_e[bi].p, 0, 128, h->early_stream);
             if (e == hipSuccess) { hipLaunchKernelGGL(k_gz_find, dim3((unsigned)((nch + WAVES - 1) / WAVES)), dim3(BLOCK), 0, h->early_stream, a2); e = hipGetLastError(); }

@@ -277,7 +277,7 @@ inline bool read_compressed_chunk(bzq_ingest* g, uint8_t* dst, uint64_t cap, uin
 // slot on the path of chunk 1 -- 43 instead of 50 GB/s on a 3 GB file)
 inline bool ingest_alloc_inflate(bzq_ingest* g, int i) {
     if (i == 0) g->inflate_stream[0] = g->copy_stream;
-    else if (i < g->n_inflate_streams && hipStreamCreateWithFlags(&g->inflate_stream[i], hipStreamNonBlocking) != hipSuccess) return false;
+    else if (i < g->n_inflate_streams && cache::stream_pool().get(g->device, &g->inflate_stream[i]) != hipSuccess) return false;
     return cache::get_device(g->device, g->chunk_bytes + 64, &g->comp_dev[i]) &&
            cache::get_device(g->device, (size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16, &g->tab_dev[i]) &&
            (g->tab_pinned[i] = (bzq::inf::DevBlock*)cache::host_small().get((size_t)g->tab_cap * sizeof(bzq::inf::DevBlock) + 16)) != nullptr;
@@ -525,6 +525,15 @@ inline void ingest_producer(bzq_ingest* g) {
 
 inline void ingest_free(bzq_ingest* g) {
     if (!g) return;
+    // BZQ_CLOSE_TRACE=1: where a close spends its time, to stderr (a close that waits for somebody else's kernel shows itself here)
+    static const bool trace = getenv("BZQ_CLOSE_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bzq close] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     {
         std::unique_lock<std::mutex> lk(g->mu);
         g->stop = true;
@@ -533,10 +542,11 @@ inline void ingest_free(bzq_ingest* g) {
     if (g->producer.joinable()) g->producer.join();
     { std::unique_lock<std::mutex> lk(g->gz_mu); g->gz_stop = true; g->gz_cv.notify_all(); }
     if (g->gz_reader.joinable()) g->gz_reader.join();   // (a read-ahead still writing into a slot's pinned buffer)
+    lap("threads joined");
     (void)hipSetDevice(g->device);
     for (int i = 1; i < INGEST_SLOTS; ++i)
-        if (g->inflate_stream[i]) { (void)hipStreamSynchronize(g->inflate_stream[i]); (void)hipStreamDestroy(g->inflate_stream[i]); }
-    if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); (void)hipStreamDestroy(g->copy_stream); }
+        if (g->inflate_stream[i]) { (void)hipStreamSynchronize(g->inflate_stream[i]); lap("inflate stream synchronised"); cache::stream_pool().put(g->device, g->inflate_stream[i]); }
+    if (g->copy_stream) { (void)hipStreamSynchronize(g->copy_stream); lap("copy stream synchronised"); cache::stream_pool().put(g->device, g->copy_stream); }   // (kept for the process, not destroyed: bzq_bufcache.hpp)
     // Buffers that go back to the cache skip hipFree's implicit wait, so whoever may still touch them is waited for HERE -- and only
     // they: the parser's stream (it may still read the last chunk) and, in views mode, the ctx's consumer stream (bzq_device_views point
     // INTO the chunk).  Not the whole device (rounds 4-5 did that): a caller's kernels on other streams -- a consumer of the batches'
@@ -544,6 +554,7 @@ inline void ingest_free(bzq_ingest* g) {
     if (g->quiesce_device) (void)hipDeviceSynchronize();   // (the FASTA ingest, and an open that failed half way: as before)
     if (g->quiesce_stream) (void)hipStreamSynchronize(g->quiesce_stream);
     if (g->quiesce_stream2) (void)hipStreamSynchronize(g->quiesce_stream2);
+    lap("parser stream(s) synchronised");
     for (int i = 0; i < INGEST_SLOTS; ++i) {
         cache::pinned_pool().put(g->slot[i].pinned);
         cache::device_pool().put(g->slot[i].dev);
@@ -556,6 +567,7 @@ inline void ingest_free(bzq_ingest* g) {
     }
     cache::device_pool().put(g->bad_dev);
     cache::host_small().put(g->bad_pinned, INGEST_SLOTS * sizeof(unsigned long long));
+    lap("buffers and events returned");
     if (g->gz) gzclose(g->gz);
     if (g->gz_dev) bzq::gz::gz_free(g->gz_dev);
     cache::device_pool().put(g->gz_fifo);

@@ -289,6 +289,11 @@ def test_ingest_close_does_not_wait_for_a_callers_other_streams(tmp_path, kind):
         assert total == 40_000 and int(r.status) == L.EOF
         return ing
 
+    # (what a close cannot keep in the library's buffer cache goes back to the driver through hipFree, which does wait for the device:
+    # empty the cache of whatever earlier tests of this process left in it, and give it room for this file's buffers)
+    for key in ("pin_cache_bytes", "dev_cache_bytes"):
+        ctx.set_option(key, 0)
+        ctx.set_option(key, 2 << 30)
     run_file().close()                       # warm: first-use costs, and the cache holds the buffers
     side = torch.cuda.Stream()
     torch.cuda.synchronize(); t0 = time.perf_counter(); torch.cuda._sleep(100_000_000); torch.cuda.synchronize()
@@ -304,6 +309,9 @@ def test_ingest_close_does_not_wait_for_a_callers_other_streams(tmp_path, kind):
     side.synchronize()
     total_sleep = time.perf_counter() - t0
     assert still_running and dt < 0.25 * total_sleep, (dt, total_sleep, still_running)   # the close came back while the other stream was still busy
+    for key in ("pin_cache_bytes", "dev_cache_bytes"):
+        ctx.set_option(key, 0)
+        ctx.set_option(key, 1 << 30)
     ctx.close()
 
 
