@@ -2615,7 +2615,9 @@ int32_t bzq_release_batch(bzq_ctx* c, bzq_device_batch* b) {
 static void launch_nw(hipStream_t cs, const uint8_t* d_ref, int ref_len, const bzq_device_batch* b, int32_t* d_scores) {
     const int64_t n = b->num_records;
     const dim3 tg((unsigned)((n + BLOCK - 1) / BLOCK));
-#define BZQ_NW_T(RL) hipLaunchKernelGGL(k_nw_scores_t<RL>, tg, dim3(BLOCK), 0, cs, d_ref, ref_len, b->sequence_buffer, b->ends, n, b->sequence_bytes, d_scores)
+    // (valid bytes of the sequence column: a batch struct filled by hand may lack sequence_bytes; the records then end at seq_len)
+    const int64_t col_len = b->sequence_bytes > 0 ? b->sequence_bytes : b->seq_len;
+#define BZQ_NW_T(RL) hipLaunchKernelGGL(k_nw_scores_t<RL>, tg, dim3(BLOCK), 0, cs, d_ref, ref_len, b->sequence_buffer, b->ends, n, col_len, d_scores)
     if (ref_len <= 16) BZQ_NW_T(16);
     else if (ref_len <= 32) BZQ_NW_T(32);
     else if (ref_len <= 40) BZQ_NW_T(40);
