@@ -253,6 +253,14 @@ struct StreamPool {
             for (size_t i = 0; i < idle.size(); ++i)
                 if (idle[i].first == device) { *out = idle[i].second; idle.erase(idle.begin() + (long)i); return hipSuccess; }
         }
+        // Helper streams live in the LOWEST priority class: a class has hardware queues of its own, so a helper stream never shares
+        // one with a caller's default-class stream (a consumer's) nor with the parser's (highest class).  Measured in the default
+        // bench line (round 6): with pooled helper streams of the default class the BGZF pipeline figure fell from 35 to 22 GB/s of
+        // FASTQ -- the consumer stream had landed in a hardware queue with an inflate stream, and 5 ms inflate kernels sat in front of
+        // its kernels -- in the lowest class it is 33-35 again and nothing else moved.  BZQ_HELPER_PRIO=default: the default class (A/B).
+        static const bool low = [] { const char* e = getenv("BZQ_HELPER_PRIO"); return !(e && e[0] == 'd'); }();
+        int lo = 0, hi = 0;
+        if (low && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo > hi) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, lo);
         return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
     }
     void put(int device, hipStream_t s) {
