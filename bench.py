@@ -1293,8 +1293,10 @@ def main():
             "mrecords_per_s": round(global_records / sec_per_step / 1e6, 3),
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "warmup_steps_run": warm_done,
             "ms_per_step": round(sec_per_step * 1e3, 4),
-            "step": ("result(k) -> submit(k+1) -> batches(k): chunk k's 2442 batch views are handed out under the parse of chunk k+1 (double-buffer contract); "
-                     "K submits + K results + K x all batches inside the timed region" if pipelined else "submit -> result -> batches, synchronous"),
+            "step": (("result(k) -> submit(k+1): chunk k+1 is submitted as soon as chunk k's result is taken (double-buffer contract; views mode hands out no batches); "
+                      "K submits + K results inside the timed region" if args.views else
+                      "result(k) -> submit(k+1) -> batches(k): every batch view of chunk k is handed out under the parse of chunk k+1 (double-buffer contract); "
+                      "K submits + K results + K x all batches inside the timed region") if pipelined else "submit -> result -> batches, synchronous"),
             "synchronous": ({"value": round(global_bytes / (sync_elapsed / steps) / 1e9, 3), "unit": "GB/s", "ms_per_step": round(sync_elapsed / steps * 1e3, 4),
                              "note": "the same K steps, each submit -> result -> batches with nothing in flight in between (rounds 1-5's timed loop)"}
                             if sync_elapsed is not None else None),
