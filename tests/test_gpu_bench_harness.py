@@ -99,3 +99,26 @@ def test_plain_command_launches_its_own_ranks():
     bad = subprocess.run(cmd + ["--fail-rank", "1"], capture_output=True, timeout=600, cwd=ROOT, env=env)
     assert bad.returncode != 0 and "rank 1 of 2" in bad.stderr.decode()
     assert not [ln for ln in bad.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--views"], ["--synchronous"]])
+def test_single_gpu_line_at_a_reduced_size(extra):
+    """The default (N = 1) path of bench.py -- the pipelined timed loop (result k -> submit k+1 -> batches k), the synchronous loop
+    beside it, the roofline object -- at a size that runs in seconds: the driver's bench run must not meet this code for the first time."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--reads", "300000", "--steps", "4", "--warmup", "1", "--min-seconds", "0.05",
+           "--no-extra-modes", "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, capture_output=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["unit"] == "GB/s" and out["dtype"] == "u8" and out["value"] > 0
+    assert abs(out["value"] - 300000 * out["config"]["record_bytes"] / (out["ms_per_step"] * 1e-3) / 1e9) <= 0.01 * out["value"] + 0.01
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1 and rf["avg_launch_ms"] > 0
+    if "--synchronous" in extra:
+        assert out["synchronous"] is None and out["step"].startswith("submit -> result")
+    else:
+        assert out["synchronous"]["ms_per_step"] > 0 and out["step"].startswith("result(k) -> submit(k+1)")
