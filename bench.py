@@ -516,6 +516,10 @@ def pipeline_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, c
         ctx = B.Context(B.ParserConfig(), "generic", PIPE_BATCH, local_rank, min_record_bytes=256 if rec_bytes >= 256 else 32)
         side = torch.cuda.Stream(device=dev)
         ctx.set_consumer_stream(side.cuda_stream)
+        # the two-chunk lifetime rule (chunk k - 1's consumers through before chunk k + 1 is submitted) is kept by the library on the
+        # device (option consumer_guard: the host never blocks for it); BZQ_PIPE_HOST_EVENTS=1: by a host-side event wait instead (A/B)
+        host_events = os.environ.get("BZQ_PIPE_HOST_EVENTS", "0") == "1"
+        ctx.set_option("consumer_guard", 0 if host_events else 1)
         d_ref = torch.frombuffer(bytearray(REF_40BP), dtype=torch.uint8).to(dev)
         d_counts = torch.zeros(read_len * 128, dtype=torch.int64, device=dev)
         d_scores = torch.empty(n_rec, dtype=torch.int32, device=dev)
@@ -535,14 +539,15 @@ def pipeline_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, c
                 while True:
                     r = ing.next(taken)
                     taken = int(r.n_records)
-                    if prev_ev is not None:
-                        prev_ev.synchronize()    # two-chunk lifetime rule: chunk k - 1's consumers are through before chunk k + 1 is submitted
+                    if host_events and prev_ev is not None:
+                        prev_ev.synchronize()    # two-chunk lifetime rule by hand: chunk k - 1's consumers are through before chunk k + 1 is submitted
                     assert L.lib().bzq_batches(ctx.h, PIPE_BATCH, arr, nb_cap, C.byref(nb_out)) == 0 and nb_out.value <= nb_cap
                     for b in range(nb_out.value):
                         assert L.lib().bzq_batch_nw_scores_dev(ctx.h, C.byref(arr[b]), C.c_void_p(d_ref.data_ptr()), len(REF_40BP),
                                                                C.c_void_p(d_scores.data_ptr() + 4 * (total + b * PIPE_BATCH))) == 0
                         assert L.lib().bzq_batch_quality_by_position_acc(ctx.h, C.byref(arr[b]), read_len, C.c_void_p(d_counts.data_ptr())) == 0
-                    prev_ev = torch.cuda.Event(); prev_ev.record(side)
+                    if host_events:
+                        prev_ev = torch.cuda.Event(); prev_ev.record(side)
                     total += taken
                     chunks += 1
                     if int(r.status) != L.OK:
@@ -586,7 +591,7 @@ def pipeline_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, c
                     "cpu_1core": {"value": round(k / one_core_s / 1e9, 4), "unit": "GB/s of FASTQ", "sample": f"orc_pipeline_run over one {k} B piece of the file"},
                     "speedup_vs_cpu_all_cores": round((n_fastq / best) / (cpu_bytes / best_cpu), 2),
                     "note": "file on /dev/shm -> bzq_ingest_next -> batches(65536) -> bzq_batch_nw_scores_dev + bzq_batch_quality_by_position_acc on the consumer stream "
-                            "(no host round trip; chunk k's consumers under chunk k+1's ingest); wall clock open -> last consumer done, best of 3 after one untimed pass; "
+                            "(no host round trip; chunk k's consumers under chunk k+1's ingest; the lifetime rule kept on the device by option consumer_guard); wall clock open -> last consumer done, best of 3 after one untimed pass; "
                             "PCIe inclusive; the CPU twin works from memory (no file read)"})
     finally:
         for q in paths.values():

@@ -178,6 +178,14 @@ struct bzq_ctx {
     int cur_is_eof = 0;
     uint32_t cur_prev_byte = 10;
     int64_t cur_first_header = 0;
+    // option "consumer_guard" (0 default): 1 = the library itself keeps the two-chunk lifetime rule for work on the consumer stream.
+    // Every submit records an event on the consumer stream and waits -- on the device, the host does not block -- for the event the
+    // PREVIOUS submit recorded: what the consumer stream held when chunk k was submitted (the consumers of chunk k - 1 and before,
+    // for a host that enqueues a chunk's consumers before it submits the next chunk) is through before chunk k + 1's kernels start
+    // writing chunk k - 1's output set, and chunk k + 1's parse still overlaps chunk k's consumers (bench.py pipeline_mode)
+    int consumer_guard = 0;
+    hipEvent_t ev_guard[2] = {nullptr, nullptr};
+    int64_t guard_serial = 0;   // submits that recorded an event
     int64_t dbg[3][12] = {};        // diagnostic: see bzq_chunk_result (query "dump_state")
     int64_t last_dense_tiles = 0;   // query "dense_tiles": tiles of the last parsed chunk that took the serial path (diagnostic)
     bool pending = false, have_result = false;
@@ -829,6 +837,14 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
                   const int64_t* first_nl = nullptr, int head_lines = 0, bool reuse_aggregates = false) {
     int rc;
     if ((rc = begin_submit(c))) return rc;
+    if (c->consumer_guard && c->consumer_stream && c->consumer_stream != c->stream) {
+        // the set this submit writes held the chunk before the previous one: its consumers were on the consumer stream when the
+        // previous submit recorded its event
+        for (hipEvent_t& e : c->ev_guard) if (!e) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (c->guard_serial > 0) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_guard[(c->guard_serial - 1) & 1], 0));
+        HIPCHK(c, hipEventRecord(c->ev_guard[c->guard_serial & 1], c->consumer_stream));
+        c->guard_serial += 1;
+    }
     if ((rc = ensure_tile_arenas(c, n)) || (rc = ensure_col_arenas(c, n))) return rc;
     int64_t want = (int64_t)(n / (uint64_t)std::max(4, c->cfg.min_record_bytes)) + 1024;
     if ((rc = ensure_record_arenas(c, want))) return rc;
@@ -1158,6 +1174,7 @@ void bzq_destroy(bzq_ctx* c) {
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream_init) (void)hipStreamDestroy(c->stream_init);
     if (c->ev_init) (void)hipEventDestroy(c->ev_init);
+    for (hipEvent_t e : c->ev_guard) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_pipe) (void)hipEventDestroy(e);
     delete c;
 }
@@ -1214,6 +1231,7 @@ int32_t bzq_set_option(bzq_ctx* c, const char* key, int64_t value) {
     else if (!strcmp(key, "pass_a_h")) c->pass_a_h = value != 0;
     else if (!strcmp(key, "fold_rebase")) c->fold_opt = value != 0;
     else if (!strcmp(key, "lean_submit")) c->lean = value != 0;
+    else if (!strcmp(key, "consumer_guard")) c->consumer_guard = value != 0;
     else if (!strcmp(key, "state_init_in_kernel")) c->init_in_kernel = (int)value;
     else if (!strcmp(key, "ranks_seen")) return c->ranks_seen;   // query
     else if (!strcmp(key, "device")) return c->device;           // query

@@ -232,7 +232,11 @@ int32_t bzq_get_config(const bzq_ctx* ctx, bzq_config* out);
  * chunk is parsed -- so that trailing bytes that are not a record are judged with that window where it
  * really sits, io/buffered.mojo:239-290; -1 (default) = each chunk is judged as a stream of its own;
  * bzq_ingest_next sets it itself);
- * "double_buffer" (1 default / 0: number of output sets, see the lifetime rule at the top).
+ * "double_buffer" (1 default / 0: number of output sets, see the lifetime rule at the top);
+ * "consumer_guard" (0 default / 1: the library keeps the lifetime rule for work on the consumer stream itself -- every submit records an
+ * event on that stream and the ctx stream waits, ON THE DEVICE, for the event of the submit before: a host that enqueues a chunk's
+ * consumers on bzq_set_consumer_stream's stream BEFORE it submits the next chunk needs no events of its own and never blocks, and the
+ * parse of chunk k+1 still overlaps the consumers of chunk k).
  * Queries (the value is ignored, the answer is the return value): "n_submits", "stream_fallbacks" (chunks parsed twice because pass A's
  * hypothesis failed), "dense_tiles" (tiles of the last parsed chunk that took the serial in-kernel path), "last_folded", "ranks_seen",
  * "device", "numa_node", "numa_cpus", "buf_cache_hits", "buf_cache_held_mb".

@@ -150,11 +150,13 @@ def test_quality_distribution_per_read_position():
     assert int(d.quality_by_position(240).sum()) == sum(len(q) for q in quals)
 
 
-def test_pipeline_consumers_stay_on_the_device_and_equal_the_cpu_twin(tmp_path):
+@pytest.mark.parametrize("guard", [0, 1])
+def test_pipeline_consumers_stay_on_the_device_and_equal_the_cpu_twin(tmp_path, guard):
     """The reference's GPU use case as a pipeline (examples/nw_gpu/execution.mojo:100-130): file -> bzq_ingest_next -> batches ->
     bzq_batch_nw_scores_dev + bzq_batch_quality_by_position_acc on the consumer stream, nothing synchronised per batch, chunk k's
-    consumers running under the parse of chunk k + 1 (an event per chunk keeps the two-chunk lifetime rule).  Scores and the
-    accumulated per-position table must equal the oracle's CPU twin (orc_pipeline_run) over the same file."""
+    consumers running under the parse of chunk k + 1.  The two-chunk lifetime rule is kept by a host-side event per chunk (guard 0) or
+    by the library on the device (option consumer_guard = 1: no event, no host wait).  Scores and the accumulated per-position table
+    must equal the oracle's CPU twin (orc_pipeline_run) over the same file."""
     import ctypes as C
     import torch
     import blazeseq_amd as B
@@ -169,6 +171,7 @@ def test_pipeline_consumers_stay_on_the_device_and_equal_the_cpu_twin(tmp_path):
     ctx = B.Context(B.ParserConfig(), "generic", 4096, 0)
     side = torch.cuda.Stream()
     ctx.set_consumer_stream(side.cuda_stream)
+    ctx.set_option("consumer_guard", guard)
     d_ref = torch.frombuffer(bytearray(REF), dtype=torch.uint8).cuda()
     d_counts = torch.zeros(150 * 128, dtype=torch.int64, device="cuda")
     d_scores = torch.full((n_want,), -99999, dtype=torch.int32, device="cuda")
@@ -178,7 +181,7 @@ def test_pipeline_consumers_stay_on_the_device_and_equal_the_cpu_twin(tmp_path):
     while True:
         r = ing.next(taken)
         taken = int(r.n_records)
-        if len(events) >= 1:
+        if not guard and len(events) >= 1:
             events[-1].synchronize()    # the consumers of the chunk before this one are through before the NEXT next() submits again
         arr, nb = ctx.batches(4096)
         for k in range(nb):
