@@ -149,7 +149,8 @@ struct bzq_ctx {
     bool pool_dirty = false;      // views mode: pass A may have taken pool tickets that no scan has folded and zeroed yet (a submit that failed in between)
     bool init_in_flight = false;
     bool init_deferred = false;   // ... and are handed to the side stream only BEHIND pass A's launch (the host's copy call is not in front of the first kernel)
-    int init_in_kernel = 0;    // diagnostic option "state_init_in_kernel" (1 / 2: ScanArgs::init_mode); DESIGN 10
+    int init_in_kernel = 1;    // option "state_init_in_kernel": 1 (default; 2-4: variants of the race hunt) = ScanArgs::init_mode, 0 = copied in on a side stream
+    bool init_stream_failed = false;
     bool init_by_kernel_now = false;
     int64_t h_init[4] = {0, 0, 0, 0};
     int lean = 1;              // option "lean_submit": 0 = state copies on the ctx stream, before and behind the kernels (as before)
@@ -832,6 +833,19 @@ void enqueue_rebase(bzq_ctx* c) {
     }
 }
 
+// the side stream of the state's initial values (option state_init_in_kernel = 0, and chunks parsed in several passes): created on
+// first use, IN THE PARSER'S PRIORITY CLASS -- a stream of the default class shares the hardware queues of that class with a caller's
+// streams and the scan, which waits for this copy, can end up behind somebody's long kernel (round 5: BGZF ingest 30 instead of 44 GB/s)
+static bool ensure_init_stream(bzq_ctx* c) {
+    if (c->stream_init && c->ev_init) return true;
+    if (c->init_stream_failed) return false;
+    if (!c->stream_init && (c->stream_has_prio ? hipStreamCreateWithPriority(&c->stream_init, hipStreamNonBlocking, c->stream_prio)
+                                               : hipStreamCreateWithFlags(&c->stream_init, hipStreamNonBlocking)) != hipSuccess) { c->stream_init = nullptr; (void)hipGetLastError(); }
+    if (!c->ev_init && hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess) { c->ev_init = nullptr; (void)hipGetLastError(); }
+    c->init_stream_failed = !(c->stream_init && c->ev_init);
+    return !c->init_stream_failed;
+}
+
 int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream_pos, int is_eof,
                   int64_t P0, int64_t S0, int64_t Q0, int64_t I0, uint32_t prev_byte, int64_t first_header,
                   const int64_t* first_nl = nullptr, int head_lines = 0, bool reuse_aggregates = false) {
@@ -864,11 +878,18 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     // Two-pass path from the chunk's first byte: pass A never looks at the state, so its initial values travel beside it and the
     // scan waits for them (enqueue_passes) -- otherwise the copy sits in front of the kernels.
     c->init_in_flight = false; c->init_deferred = false; c->published = false;
-    const bool plain = c->lean && n > 0 && head_lines == 0 && !first_nl && !reuse_aggregates && c->stream_init && c->ev_init &&
-                       (c->single_pass == 0 || c->cfg.views_only) && !c->use_stream && !c->overlap;
+    // Two-pass path from the chunk's first byte, one pass over the chunk: NO copy at all -- the first workgroup of k_scan_reduce
+    // writes the state's initial values (pass A does not look at the state; everything that does comes behind the scan).  Round 5 tried
+    // this and dropped it over a wrong answer that turned out to be bzq_create's; round 6 made it the default: one stream
+    // and one event less per ctx (a stream costs 9-20 ms to create: scripts/probes/create_probe.hip), one copy packet less per submit.
+    // Option state_init_in_kernel = 0: the copy on a side stream (created on first use), as rounds 5-6 shipped it.
+    bool plain = c->lean && n > 0 && head_lines == 0 && !first_nl && !reuse_aggregates &&
+                 (c->single_pass == 0 || c->cfg.views_only) && !c->use_stream && !c->overlap;
+    const bool by_kernel = plain && c->init_in_kernel && pass_tiles(c) >= tiles_for(n);
+    if (plain && !by_kernel && !ensure_init_stream(c)) plain = false;   // (no side stream: the copy stays on the ctx stream)
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     c->init_by_kernel_now = false;
-    if (plain && c->init_in_kernel && pass_tiles(c) >= tiles_for(n)) {   // diagnostic: no copy at all, the scan's first workgroup writes the values
+    if (by_kernel) {
         c->h_init[0] = P0; c->h_init[1] = S0; c->h_init[2] = Q0; c->h_init[3] = I0;
         if (c->init_in_kernel == 4) hipLaunchKernelGGL(k_state_init, dim3(1), dim3(64), 0, c->stream, c->d_state, P0, S0, Q0, I0);
         else c->init_by_kernel_now = true;
@@ -1132,12 +1153,7 @@ int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
     CRT(hipHostMalloc((void**)&c->h_state, sizeof(ChunkState), hipHostMallocDefault));
     for (auto& ev : c->ev) CRT(hipEventCreate(&ev));
     { const char* e = getenv("BZQ_LEAN_SUBMIT"); if (e && e[0] == '0') c->lean = 0; }   // (bisecting aid: option lean_submit for a whole process)
-    // (a stream and an event for the state's initial values: see submit_common; without them the copy stays on the ctx stream)
-    // IN THE PARSER'S PRIORITY CLASS: a stream of the default class shares the four hardware queues of that class with the ingest's
-    // copy / inflate streams, and the scan, which waits for this copy, then sits behind a 5 ms inflate kernel -- in a process that had
-    // created few streams before, the BGZF ingest ran at 30 GB/s instead of 44 (bench.py --ingest-only against the default line)
-    if ((c->stream_has_prio ? hipStreamCreateWithPriority(&c->stream_init, hipStreamNonBlocking, c->stream_prio) : hipStreamCreateWithFlags(&c->stream_init, hipStreamNonBlocking)) != hipSuccess) { c->stream_init = nullptr; (void)hipGetLastError(); }
-    if (hipEventCreateWithFlags(&c->ev_init, hipEventDisableTiming) != hipSuccess) { c->ev_init = nullptr; (void)hipGetLastError(); }
+    // (the side stream of the state's initial values is created on first use: ensure_init_stream)
 #undef CRT
     *out = c;
     return 0;
