@@ -240,8 +240,9 @@ int32_t bzq_get_config(const bzq_ctx* ctx, bzq_config* out);
  * Queries (the value is ignored, the answer is the return value): "n_submits", "stream_fallbacks" (chunks parsed twice because pass A's
  * hypothesis failed), "dense_tiles" (tiles of the last parsed chunk that took the serial in-kernel path), "last_folded", "ranks_seen",
  * "device", "numa_node", "numa_cpus", "buf_cache_hits", "buf_cache_held_mb".
- * Diagnostics of round 6's race hunt, off by default and of no use to a host: "state_init_in_kernel" (1-4: the chunk
- * state's initial values written by a kernel instead of copied in), "dump_state" (query: the last result's state snapshots to stderr);
+ * "state_init_in_kernel" (1 default: the chunk state's initial values are written by the scan's first workgroup; 0: copied in on a side
+ * stream, created on first use, as rounds 5-6 shipped it; 2-4: variants of round 6's race hunt), "dump_state" (query,
+ * diagnostic: the last result's state snapshots to stderr);
  * environment BZQ_POOL_ZERO=0 restores rounds 4-5's create (the views pool's ticket zeroed on the NULL stream: the defect, kept as the
  * hook of tests/test_gpu_fresh_ctx.py), BZQ_POOL_POISON=1 fills the ticket with garbage first, BZQ_INGEST_RAMP=0 reads a plain file in
  * whole chunks from the first one on (A/B of the short first chunks). */
