@@ -921,7 +921,11 @@ int submit_common(bzq_ctx* c, const uint8_t* d_data, uint64_t n, uint64_t stream
     } else c->fold = false;
     enqueue_rebase(c);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));   // ev[0] .. ev[3]: the submit's kernels (two events per submit; option timing_detail adds three)
-    if (!c->published) HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
+    if (!c->published) {
+        // views mode on the plain path: a one-workgroup kernel writes the state into the pinned copy (no copy packet); everything else copies
+        if (plain && n > 0 && c->cfg.views_only && c->lean) hipLaunchKernelGGL(k_publish_state, dim3(1), dim3(128), 0, c->stream, (const ChunkState*)c->d_state, c->h_state);
+        else HIPCHK(c, hipMemcpyAsync(c->h_state, c->d_state, sizeof(ChunkState), hipMemcpyDeviceToHost, c->stream));
+    }
     c->pending = true; c->have_result = false;
     return follow_consume(c);   // (host work: it overlaps the parse that was just enqueued)
 }

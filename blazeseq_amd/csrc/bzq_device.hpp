@@ -715,6 +715,16 @@ __device__ __forceinline__ void chunk_finish(const ChunkFinishArgs& f, ChunkStat
     st->last_ends = le; st->last_id_ends = li;
 }
 
+// The chunk state into the host's pinned copy by zero-copy stores (views mode, whose last kernel -- the join -- has many workgroups and
+// cannot publish itself): one small kernel instead of a copy packet behind the kernels (a 664-byte device-to-host copy is a blit
+// kernel of its own, ~10-14 us in the queue).
+static __global__ __launch_bounds__(128) void k_publish_state(const ChunkState* st, ChunkState* h_state) {
+    static_assert(sizeof(ChunkState) % 8 == 0, "the state is copied in 8-byte words");
+    const u64* src = reinterpret_cast<const u64*>(st);
+    u64* dst = reinterpret_cast<u64*>(h_state);
+    for (int i = threadIdx.x; i < (int)(sizeof(ChunkState) / 8); i += 128) dst[i] = src[i];
+}
+
 // Chunk-cumulative ends from the per-batch ones (bzq_chunk_cumulative_ends; cold path): ends[r] = b_ends[r] + bb[2 (r / batch - 1)]
 static __global__ __launch_bounds__(BLOCK) void k_cumulate(const int64_t* b_ends, const int64_t* b_id_ends, const int64_t* bb, int64_t batch, int64_t n,
                                                            int64_t* ends, int64_t* id_ends) {
