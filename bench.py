@@ -514,7 +514,11 @@ def pipeline_mode(shard, rec_bytes, dev, local_rank, target_gb=6.4, threads=8, c
         assert n1 == recs_piece
         # ---- the device pipeline
         ctx = B.Context(B.ParserConfig(), "generic", PIPE_BATCH, local_rank, min_record_bytes=256 if rec_bytes >= 256 else 32)
-        side = torch.cuda.Stream(device=dev)
+        # The consumer stream is created in the HIGHEST priority class (the parser's).  The runtime maps streams onto a few hardware
+        # queues per class and WHICH queue a stream gets depends on how many streams the process created before it: in the full default
+        # line a default-class consumer stream gave 37-38 GB/s where the same code alone (--pipeline-only) gave 43 -- same box, A/B
+        # (profiles/RESULTS.md, round 6); in the highest class it is 43 in both.  BZQ_PIPE_SIDE_PRIO=0: the default class.
+        side = torch.cuda.Stream(device=dev, priority=int(os.environ.get("BZQ_PIPE_SIDE_PRIO", "-1")))
         ctx.set_consumer_stream(side.cuda_stream)
         # the two-chunk lifetime rule (chunk k - 1's consumers through before chunk k + 1 is submitted) is kept by the library on the
         # device (option consumer_guard: the host never blocks for it); BZQ_PIPE_HOST_EVENTS=1: by a host-side event wait instead (A/B)

@@ -1157,6 +1157,7 @@ int32_t bzq_create(int32_t device, const bzq_config* cfg, bzq_ctx** out) {
     CRT(hipHostMalloc((void**)&c->h_state, sizeof(ChunkState), hipHostMallocDefault));
     for (auto& ev : c->ev) CRT(hipEventCreate(&ev));
     { const char* e = getenv("BZQ_LEAN_SUBMIT"); if (e && e[0] == '0') c->lean = 0; }   // (bisecting aid: option lean_submit for a whole process)
+    { const char* e = getenv("BZQ_STATE_INIT"); if (e && e[0] >= '0' && e[0] <= '4') c->init_in_kernel = e[0] - '0'; }   // (the same for option state_init_in_kernel)
     // (the side stream of the state's initial values is created on first use: ensure_init_stream)
 #undef CRT
     *out = c;

@@ -219,8 +219,10 @@ int32_t bzq_set_stream(bzq_ctx* ctx, void* hip_stream);
 /* The stream the bzq_batch_* / bzq_column_* consumer kernels are launched on (NULL = the ctx stream).  With a stream
  * of its own a consumer of chunk k overlaps the parse of chunk k+1 (the results of chunk k stay valid, see above).
  * Priority classes: the parser's own stream is of the HIGHEST class, the library's helper streams (copies, inflate, block finder) of the
- * LOWEST; a consumer stream of the default class therefore shares a hardware queue with neither (the runtime maps streams onto four
- * hardware queues per class, and a stream behind a 5 ms inflate kernel in a shared queue waits for it). */
+ * LOWEST (the runtime maps streams onto a few hardware queues per class, and a stream behind a 5 ms inflate kernel in a shared queue
+ * waits for it).  Which queue a caller's stream gets depends on how many streams the process created before it; measured (bench.py
+ * pipeline_mode, round 6): a consumer stream of the HIGHEST class kept its rate in every context, one of the default class lost 13 %
+ * in a process that had created many streams. */
 int32_t bzq_set_consumer_stream(bzq_ctx* ctx, void* hip_stream);
 int32_t bzq_get_config(const bzq_ctx* ctx, bzq_config* out);
 /* Run-time knobs that are not part of ParserConfig: "pass_bytes" (bytes per kernel round),
